@@ -1,0 +1,111 @@
+"""ctypes binding of libffvd_hip.so (include/ffvd_abi.h).  Fails loudly when the library is missing:
+there is no CPU fallback anywhere in this package."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libffvd_hip.so")
+
+FFVD_OK, FFVD_EINVAL, FFVD_ENOMEM, FFVD_EDEVICE, FFVD_ENOTPD = 0, -1, -2, -3, 1
+KERNEL_KIND = {"SquaredExponential": 0, "LinearK": 1}
+BRANCH_A, BRANCH_B = 0, 1
+PRIOR_TYPE = {"uniform": 0, "normal": 1}
+PARAMS_ON_DEVICE = 1
+TERM_NAMES = ("nll_part_prior", "nll_log_likelihood", "x_t_prior_Q", "nll_reg_trace_inverse_Q_B",
+              "later_term1", "later_term2", "nll")
+
+
+class FfvdConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "T", "D", "C", "M", "S_local", "Ydim", "d_begin", "d_count", "shared_terms", "dtype",
+        "kernel_kind", "branch", "prior_type", "device_id", "chains_per_pass", "reserved")] + [("jitter", C.c_double)]
+
+
+class FfvdParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "X", "Z", "U", "logvariance", "loglengthscales", "log_Q", "CC", "DD", "log_Rchols")]
+
+
+_dp = C.POINTER(C.c_double)
+_SIGNATURES = {
+    "ffvd_create": (C.c_int, [C.POINTER(FfvdConfig), C.POINTER(C.c_void_p)]),
+    "ffvd_destroy": (C.c_int, [C.c_void_p]),
+    "ffvd_last_error": (C.c_char_p, [C.c_void_p]),
+    "ffvd_sync": (C.c_int, [C.c_void_p]),
+    "ffvd_workspace_bytes": (C.c_int64, [C.c_void_p]),
+    "ffvd_set_data": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "ffvd_set_params": (C.c_int, [C.c_void_p, C.POINTER(FfvdParams), C.c_int]),
+    "ffvd_elbo": (C.c_int, [C.c_void_p, C.POINTER(FfvdParams), C.c_uint32, _dp, _dp]),
+    "ffvd_elbo_async": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ffvd_chain_nll": (C.c_int, [C.c_void_p, _dp]),
+    "ffvd_time_elbo": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
+    "ffvd_profile_stages": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "ffvd_stage_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "ffvd_stage_times": (C.c_int, [C.c_void_p, _dp, C.POINTER(C.c_int32)]),
+    "ffvd_op_kernel_matrix": (C.c_int, [C.c_int, _dp, C.c_int, _dp, C.c_int, C.c_int, C.c_double, _dp, C.c_double, _dp]),
+    "ffvd_op_kernel_diag": (C.c_int, [C.c_int, _dp, C.c_int, C.c_int, C.c_double, _dp]),
+    "ffvd_op_cholesky": (C.c_int, [_dp, C.c_int, C.c_int, _dp, C.POINTER(C.c_int32)]),
+    "ffvd_op_kernel_pre_cal": (C.c_int, [C.c_int, _dp, C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_double, _dp]),
+    "ffvd_op_collapse": (C.c_int, [C.c_int, _dp, _dp, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp,
+                                   C.c_double, C.c_double, _dp]),
+    "ffvd_op_conditional": (C.c_int, [C.c_int, _dp, C.c_int, _dp, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp,
+                                      C.c_double, _dp, _dp]),
+}
+
+_lib = None
+
+
+class FfvdError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libffvd_hip.so (once).  Raises if it has not been built: `python -m ffvd_amd.build`."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FfvdError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built (run `python -m ffvd_amd.build` "
+            "or `__graft_entry__.build()`); ffvd_amd has no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = ABI/header mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return tuple(_SIGNATURES)
+
+
+def as_f64(a, shape=None, name="array"):
+    """Contiguous fp64 view/copy; validates the shape when given."""
+    arr = np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+    if shape is not None and tuple(arr.shape) != tuple(shape):
+        raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(arr.shape)}")
+    return arr
+
+
+def dptr(arr):
+    return arr.ctypes.data_as(_dp)
+
+
+def check(rc, handle=None, what="ffvd"):
+    if rc == FFVD_OK:
+        return
+    msg = load().ffvd_last_error(handle)
+    msg = msg.decode() if msg else ""
+    if rc == FFVD_ENOTPD:
+        raise np.linalg.LinAlgError(f"{what}: {msg}")
+    if rc == FFVD_EINVAL:
+        raise ValueError(f"{what}: {msg}")
+    if rc == FFVD_ENOMEM:
+        raise MemoryError(f"{what}: {msg}")
+    raise FfvdError(f"{what}: {msg} (status {rc})")

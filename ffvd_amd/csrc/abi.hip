@@ -1,0 +1,758 @@
+// C ABI of libffvd_hip.so (see include/ffvd_abi.h): handle lifetime, resident buffers, the per-iteration
+// launch sequence of the ELBO, and operator-level entry points used by the Python mirror of the reference API.
+#include "../../include/ffvd_abi.h"
+#include "kernels.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace ffvd;
+
+static thread_local std::string g_last_error;
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            char buf_[512];                                                                   \
+            snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                     __FILE__, __LINE__);                                                     \
+            return set_error(h, (e_ == hipErrorOutOfMemory) ? FFVD_ENOMEM : FFVD_EDEVICE, buf_); \
+        }                                                                                     \
+    } while (0)
+
+struct ffvd_handle {
+    ffvd_config cfg;
+    int P = 0, Mp = 0, Tp = 0, Dl = 0, nbatch = 0, ng = 0, cpp = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::vector<void *> allocs;
+    int64_t ws_bytes = 0;
+    // resident parameters / data (handle-owned copies)
+    double *X = nullptr, *Z = nullptr, *U = nullptr, *logvar = nullptr, *loglen = nullptr, *logQ = nullptr;
+    double *CC = nullptr, *DD = nullptr, *logR = nullptr, *Y = nullptr, *ctrl = nullptr;
+    ffvd_params cur{};          // pointers the kernels read (resident copies or caller's device pointers)
+    bool have_params = false, have_data = false;
+    // workspace
+    double *variance = nullptr, *len = nullptr, *Zs = nullptr, *zz = nullptr;
+    double *Kuu = nullptr, *F = nullptr, *H = nullptr, *rowsq = nullptr, *fmean = nullptr;
+    double *hterms = nullptr, *chain_terms = nullptr, *chain_nll = nullptr, *out_terms = nullptr;
+    int32_t *info = nullptr;
+    // pinned host staging
+    double *h_out = nullptr, *h_chain = nullptr;
+    int32_t *h_info = nullptr;
+    // optional live stage timing (HIP events on the handle's stream)
+    bool timing_on = false;
+    std::vector<hipEvent_t> ev_pool;
+    std::vector<int> ev_stage;
+    size_t ev_used = 0;
+};
+
+static int set_error(ffvd_handle *h, int code, const std::string &msg) {
+    if (h) h->err = msg;
+    g_last_error = msg;
+    return code;
+}
+static int set_error(std::nullptr_t, int code, const std::string &msg) {
+    g_last_error = msg;
+    return code;
+}
+
+template <class T>
+static hipError_t dev_alloc(ffvd_handle *h, T **p, size_t count) {
+    size_t bytes = (count ? count : 1) * sizeof(T);
+    hipError_t e = hipMalloc((void **)p, bytes);
+    if (e == hipSuccess) {
+        h->allocs.push_back((void *)*p);
+        h->ws_bytes += (int64_t)bytes;
+    }
+    return e;
+}
+
+extern "C" const char *ffvd_last_error(const ffvd_handle *h) {
+    return h ? h->err.c_str() : g_last_error.c_str();
+}
+
+extern "C" int64_t ffvd_workspace_bytes(const ffvd_handle *h) { return h ? h->ws_bytes : 0; }
+
+extern "C" int ffvd_destroy(ffvd_handle *h) {
+    if (!h) return FFVD_OK;
+    hipSetDevice(h->cfg.device_id);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    for (void *p : h->allocs) hipFree(p);
+    for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
+    if (h->h_out) hipHostFree(h->h_out);
+    if (h->h_chain) hipHostFree(h->h_chain);
+    if (h->h_info) hipHostFree(h->h_info);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+    return FFVD_OK;
+}
+
+static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
+    const ffvd_config &c = h->cfg;
+    h->P = c.D + c.C;
+    h->Dl = c.d_count > 0 ? c.d_count : c.D;
+    h->Mp = round_up(c.M, NB);
+    h->Tp = round_up(c.T, STRIP);
+    h->ng = (h->Mp + 511) / 512;
+    h->nbatch = c.S_local * h->Dl;
+    const size_t Mp = h->Mp, Tp = h->Tp, Dl = h->Dl, P = h->P;
+    // chains per pass: keep the F slabs of one pass near the 256 MiB Infinity Cache unless told otherwise
+    if (c.chains_per_pass > 0) h->cpp = c.chains_per_pass;
+    else {
+        const size_t per_chain = Dl * Tp * Mp * sizeof(double);
+        size_t n = (size_t)192 * 1024 * 1024 / (per_chain ? per_chain : 1);
+        if (n < 1) n = 1;
+        h->cpp = (int)n;
+    }
+    if (h->cpp > c.S_local) h->cpp = c.S_local;
+    HIP_TRY(hipSetDevice(c.device_id));
+    HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIP_TRY(dev_alloc(h, &h->X, (size_t)c.S_local * (c.T + 1) * c.D));
+    HIP_TRY(dev_alloc(h, &h->Z, (size_t)c.M * P));
+    HIP_TRY(dev_alloc(h, &h->U, (size_t)c.M * c.D));
+    HIP_TRY(dev_alloc(h, &h->logvar, (size_t)c.D));
+    HIP_TRY(dev_alloc(h, &h->loglen, (size_t)c.D * P));
+    HIP_TRY(dev_alloc(h, &h->logQ, (size_t)c.D));
+    HIP_TRY(dev_alloc(h, &h->CC, (size_t)c.D * c.Ydim));
+    HIP_TRY(dev_alloc(h, &h->DD, (size_t)c.Ydim));
+    HIP_TRY(dev_alloc(h, &h->logR, (size_t)c.Ydim * c.Ydim));
+    HIP_TRY(dev_alloc(h, &h->Y, (size_t)c.T * c.Ydim));
+    HIP_TRY(dev_alloc(h, &h->ctrl, (size_t)c.T * c.C));
+    HIP_TRY(dev_alloc(h, &h->variance, Dl));
+    HIP_TRY(dev_alloc(h, &h->len, Dl * P));
+    HIP_TRY(dev_alloc(h, &h->Zs, Dl * Mp * P));
+    HIP_TRY(dev_alloc(h, &h->zz, Dl * Mp));
+    HIP_TRY(dev_alloc(h, &h->Kuu, Dl * 2 * Mp * Mp));
+    HIP_TRY(dev_alloc(h, &h->rowsq, (size_t)h->nbatch * h->ng * Tp));
+    HIP_TRY(dev_alloc(h, &h->fmean, (size_t)h->nbatch * h->ng * Tp));
+    if (c.branch == FFVD_BRANCH_B) {
+        const size_t pass_b = (size_t)h->cpp * Dl;
+        HIP_TRY(dev_alloc(h, &h->F, pass_b * Tp * Mp));
+        HIP_TRY(dev_alloc(h, &h->H, pass_b * (Mp + NB) * Mp));
+        HIP_TRY(hipMemsetAsync(h->H, 0, pass_b * (Mp + NB) * Mp * sizeof(double), h->stream));
+    }
+    HIP_TRY(dev_alloc(h, &h->hterms, (size_t)h->nbatch * 2));
+    HIP_TRY(dev_alloc(h, &h->chain_terms, (size_t)c.S_local * 8));
+    HIP_TRY(dev_alloc(h, &h->chain_nll, (size_t)c.S_local));
+    HIP_TRY(dev_alloc(h, &h->out_terms, (size_t)8));
+    HIP_TRY(dev_alloc(h, &h->info, (size_t)(Dl + h->nbatch)));
+    HIP_TRY(hipHostMalloc((void **)&h->h_out, 8 * sizeof(double)));
+    HIP_TRY(hipHostMalloc((void **)&h->h_chain, (size_t)(c.S_local ? c.S_local : 1) * sizeof(double)));
+    HIP_TRY(hipHostMalloc((void **)&h->h_info, (size_t)(Dl + h->nbatch) * sizeof(int32_t)));
+    HIP_TRY(hipMemsetAsync(h->U, 0, (size_t)(c.M * c.D ? c.M * c.D : 1) * sizeof(double), h->stream));
+    HIP_TRY(hipMemsetAsync(h->loglen, 0, (size_t)c.D * P * sizeof(double), h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    (void)cfg;
+    return FFVD_OK;
+}
+
+extern "C" int ffvd_create(const ffvd_config *cfg, ffvd_handle **out) {
+    if (!cfg || !out) return set_error(nullptr, FFVD_EINVAL, "ffvd_create: null argument");
+    *out = nullptr;
+    char msg[256];
+    if (cfg->T < 1 || cfg->D < 1 || cfg->C < 0 || cfg->M < 1 || cfg->S_local < 1 || cfg->Ydim < 1) {
+        snprintf(msg, sizeof msg, "ffvd_create: bad shape T=%d D=%d C=%d M=%d S_local=%d Ydim=%d", cfg->T, cfg->D,
+                 cfg->C, cfg->M, cfg->S_local, cfg->Ydim);
+        return set_error(nullptr, FFVD_EINVAL, msg);
+    }
+    if (cfg->D + cfg->C > MAXP) {
+        snprintf(msg, sizeof msg, "ffvd_create: GP input dim P = D + C = %d exceeds %d", cfg->D + cfg->C, MAXP);
+        return set_error(nullptr, FFVD_EINVAL, msg);
+    }
+    if (cfg->dtype != FFVD_F64) return set_error(nullptr, FFVD_EINVAL, "ffvd_create: only FFVD_F64 is implemented");
+    if (cfg->kernel_kind != FFVD_KERNEL_SE && cfg->kernel_kind != FFVD_KERNEL_LINEAR)
+        return set_error(nullptr, FFVD_EINVAL, "ffvd_create: unknown kernel_kind");
+    if (cfg->branch != FFVD_BRANCH_A && cfg->branch != FFVD_BRANCH_B)
+        return set_error(nullptr, FFVD_EINVAL, "ffvd_create: unknown branch");
+    if (cfg->prior_type != FFVD_PRIOR_UNIFORM && cfg->prior_type != FFVD_PRIOR_NORMAL)
+        return set_error(nullptr, FFVD_EINVAL, "ffvd_create: unsupported prior_type (uniform / normal only)");
+    const int dcount = cfg->d_count > 0 ? cfg->d_count : cfg->D;
+    if (cfg->d_begin < 0 || cfg->d_begin + dcount > cfg->D)
+        return set_error(nullptr, FFVD_EINVAL, "ffvd_create: latent-dim shard [d_begin, d_begin + d_count) out of range");
+    if (!(cfg->jitter >= 0.0)) return set_error(nullptr, FFVD_EINVAL, "ffvd_create: jitter must be >= 0");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || cfg->device_id < 0 || cfg->device_id >= ndev) {
+        snprintf(msg, sizeof msg, "ffvd_create: device %d not available (%d HIP devices visible)", cfg->device_id, ndev);
+        return set_error(nullptr, FFVD_EDEVICE, msg);
+    }
+    ffvd_handle *h = new (std::nothrow) ffvd_handle();
+    if (!h) return set_error(nullptr, FFVD_ENOMEM, "ffvd_create: host allocation failed");
+    h->cfg = *cfg;
+    int rc = create_impl(cfg, h);
+    if (rc != FFVD_OK) {
+        std::string m = h->err;
+        ffvd_destroy(h);
+        return set_error(nullptr, rc, m);
+    }
+    *out = h;
+    return FFVD_OK;
+}
+
+extern "C" int ffvd_sync(ffvd_handle *h) {
+    if (!h) return set_error(nullptr, FFVD_EINVAL, "ffvd_sync: null handle");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return FFVD_OK;
+}
+
+static int copy_in(ffvd_handle *h, double *dst, const double *src, size_t count, int on_device) {
+    if (count == 0) return FFVD_OK;
+    HIP_TRY(hipMemcpyAsync(dst, src, count * sizeof(double), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                           h->stream));
+    return FFVD_OK;
+}
+
+extern "C" int ffvd_set_data(ffvd_handle *h, const double *Y, const double *control_inputs, int on_device) {
+    if (!h) return set_error(nullptr, FFVD_EINVAL, "ffvd_set_data: null handle");
+    const ffvd_config &c = h->cfg;
+    if (!Y) return set_error(h, FFVD_EINVAL, "ffvd_set_data: Y is null");
+    if (c.C > 0 && !control_inputs) return set_error(h, FFVD_EINVAL, "ffvd_set_data: control_inputs is null but C > 0");
+    HIP_TRY(hipSetDevice(c.device_id));
+    int rc;
+    if ((rc = copy_in(h, h->Y, Y, (size_t)c.T * c.Ydim, on_device))) return rc;
+    if ((rc = copy_in(h, h->ctrl, control_inputs, (size_t)c.T * c.C, on_device))) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->have_data = true;
+    return FFVD_OK;
+}
+
+static int check_params(ffvd_handle *h, const ffvd_params *p, const char *who) {
+    const ffvd_config &c = h->cfg;
+    std::string w(who);
+    if (!p) return set_error(h, FFVD_EINVAL, w + ": params is null");
+    if (!p->X || !p->Z || !p->logvariance || !p->log_Q || !p->CC || !p->DD || !p->log_Rchols)
+        return set_error(h, FFVD_EINVAL, w + ": a required parameter pointer is null (X, Z, logvariance, log_Q, CC, DD, log_Rchols)");
+    if (c.kernel_kind == FFVD_KERNEL_SE && !p->loglengthscales)
+        return set_error(h, FFVD_EINVAL, w + ": loglengthscales is null for the SquaredExponential kernel");
+    if (c.branch == FFVD_BRANCH_A && !p->U)
+        return set_error(h, FFVD_EINVAL, w + ": U is null in the explicit-U branch");
+    return FFVD_OK;
+}
+
+extern "C" int ffvd_set_params(ffvd_handle *h, const ffvd_params *p, int on_device) {
+    if (!h) return set_error(nullptr, FFVD_EINVAL, "ffvd_set_params: null handle");
+    int rc = check_params(h, p, "ffvd_set_params");
+    if (rc) return rc;
+    const ffvd_config &c = h->cfg;
+    const size_t P = h->P;
+    HIP_TRY(hipSetDevice(c.device_id));
+    if ((rc = copy_in(h, h->X, p->X, (size_t)c.S_local * (c.T + 1) * c.D, on_device))) return rc;
+    if ((rc = copy_in(h, h->Z, p->Z, (size_t)c.M * P, on_device))) return rc;
+    if (p->U && (rc = copy_in(h, h->U, p->U, (size_t)c.M * c.D, on_device))) return rc;
+    if ((rc = copy_in(h, h->logvar, p->logvariance, (size_t)c.D, on_device))) return rc;
+    if (p->loglengthscales && (rc = copy_in(h, h->loglen, p->loglengthscales, (size_t)c.D * P, on_device))) return rc;
+    if ((rc = copy_in(h, h->logQ, p->log_Q, (size_t)c.D, on_device))) return rc;
+    if ((rc = copy_in(h, h->CC, p->CC, (size_t)c.D * c.Ydim, on_device))) return rc;
+    if ((rc = copy_in(h, h->DD, p->DD, (size_t)c.Ydim, on_device))) return rc;
+    if ((rc = copy_in(h, h->logR, p->log_Rchols, (size_t)c.Ydim * c.Ydim, on_device))) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->cur.X = h->X; h->cur.Z = h->Z; h->cur.U = h->U; h->cur.logvariance = h->logvar;
+    h->cur.loglengthscales = h->loglen; h->cur.log_Q = h->logQ; h->cur.CC = h->CC; h->cur.DD = h->DD;
+    h->cur.log_Rchols = h->logR;
+    h->have_params = true;
+    return FFVD_OK;
+}
+
+// ---- the per-iteration launch sequence -------------------------------------------------------
+// Stage timing: an event is recorded after each stage's launches; the interval ending at an event is
+// attributed to that stage (stage -1 = origin of an iteration).  Events come from a pool owned by the handle.
+struct StageTimer {
+    ffvd_handle *h;
+    void mark(int stage_id) {
+        if (h->ev_used == h->ev_pool.size()) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return;
+            h->ev_pool.push_back(e);
+            h->ev_stage.push_back(0);
+        }
+        hipEventRecord(h->ev_pool[h->ev_used], h->stream);
+        h->ev_stage[h->ev_used] = stage_id;
+        ++h->ev_used;
+    }
+};
+
+static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
+    StageTimer live{h};
+    if (!st && h->timing_on) st = &live;
+    const ffvd_config &c = h->cfg;
+    const int Mp = h->Mp, Tp = h->Tp, Dl = h->Dl, P = h->P;
+    hipStream_t s = h->stream;
+    const ffvd_params &p = h->cur;
+    if (st) st->mark(-1);
+    HIP_TRY(hipMemsetAsync(h->info, 0, (size_t)(Dl + h->nbatch) * sizeof(int32_t), s));
+    launch_prep_hypers(s, c.kernel_kind, p.Z, c.M, Mp, P, Dl, c.d_begin, p.logvariance, p.loglengthscales,
+                       h->variance, h->len, h->Zs, h->zz);
+    HyperView hv{h->variance, h->len, h->Zs, h->zz};
+    launch_kuu_build(s, c.kernel_kind, hv, c.M, Mp, P, Dl, c.jitter, h->Kuu);
+    const size_t kstride = (size_t)2 * Mp * Mp;
+    launch_potrf_ext(s, h->Kuu, Mp, Mp, 1, Dl, kstride, h->info);
+    if (st) st->mark(0);
+    for (int s0 = 0; s0 < c.S_local; s0 += h->cpp) {
+        const int ns = (s0 + h->cpp <= c.S_local) ? h->cpp : c.S_local - s0;
+        ProjectArgs pa{};
+        pa.kind = c.kernel_kind;
+        pa.x = p.X; pa.x_chain_stride = (size_t)(c.T + 1) * c.D; pa.x_ld = c.D; pa.x_cols = c.D;
+        pa.ctrl = h->ctrl; pa.T = c.T; pa.Tp = Tp; pa.C = c.C; pa.P = P; pa.M = c.M; pa.Mp = Mp; pa.Dl = Dl;
+        pa.d_begin = c.d_begin; pa.hv = hv; pa.W = h->Kuu + (size_t)Mp * Mp; pa.w_stride = kstride;
+        pa.U = p.U; pa.u_ld = c.D; pa.b0 = s0 * Dl; pa.nb = ns * Dl;
+        pa.F = (c.branch == FFVD_BRANCH_B) ? h->F : nullptr;
+        pa.rowsq = h->rowsq;
+        pa.fmean = (c.branch == FFVD_BRANCH_A) ? h->fmean : nullptr;
+        pa.ng = h->ng;
+        launch_project(s, pa);
+        if (st) st->mark(1);
+        if (c.branch == FFVD_BRANCH_B) {
+            GramArgs ga{};
+            ga.F = h->F; ga.X = p.X; ga.log_Q = p.log_Q; ga.T = c.T; ga.Tp = Tp; ga.D = c.D; ga.Mp = Mp; ga.Dl = Dl;
+            ga.d_begin = c.d_begin; ga.b0 = s0 * Dl; ga.nb = ns * Dl; ga.yn_over_batch = 1.0;
+            ga.H = h->H; ga.h_stride = (size_t)(Mp + NB) * Mp;
+            launch_gram(s, ga);
+            if (st) st->mark(2);
+            launch_potrf_ext(s, h->H, Mp, NB, 0, ns * Dl, ga.h_stride, h->info + Dl + s0 * Dl);
+            launch_h_finish(s, h->H, Mp, ga.h_stride, ns * Dl, h->hterms + (size_t)2 * s0 * Dl);
+            if (st) st->mark(3);
+        }
+    }
+    ReduceArgs ra{};
+    ra.kind = c.kernel_kind; ra.branch = c.branch; ra.X = p.X; ra.ctrl = h->ctrl; ra.Y = h->Y;
+    ra.log_Q = p.log_Q; ra.CC = p.CC; ra.DD = p.DD; ra.log_Rchols = p.log_Rchols; ra.variance = h->variance;
+    ra.T = c.T; ra.Tp = Tp; ra.D = c.D; ra.C = c.C; ra.Ydim = c.Ydim; ra.Dl = Dl; ra.d_begin = c.d_begin;
+    ra.S = c.S_local; ra.ng = h->ng; ra.shared_terms = c.shared_terms;
+    ra.xk = p.X; ra.xk_chain_stride = (size_t)(c.T + 1) * c.D; ra.xk_ld = c.D; ra.xk_cols = c.D;
+    ra.rowsq = h->rowsq; ra.fmean = h->fmean; ra.chain_terms = h->chain_terms;
+    launch_chain_reduce(s, ra);
+    FinalizeArgs fa{};
+    fa.kind = c.kernel_kind; fa.branch = c.branch; fa.prior_type = c.prior_type; fa.shared_terms = c.shared_terms;
+    fa.T = c.T; fa.D = c.D; fa.P = P; fa.M = c.M; fa.Ydim = c.Ydim; fa.Dl = Dl; fa.d_begin = c.d_begin;
+    fa.S = c.S_local; fa.Z = p.Z; fa.U = p.U; fa.logvar = p.logvariance; fa.loglen = p.loglengthscales;
+    fa.log_Q = p.log_Q; fa.CC = p.CC; fa.DD = p.DD; fa.log_Rchols = p.log_Rchols;
+    fa.chain_terms = h->chain_terms; fa.hterms = h->hterms; fa.chain_nll = h->chain_nll;
+    fa.out_terms = out_dev ? out_dev : h->out_terms;
+    launch_finalize(s, fa);
+    if (st) st->mark(4);
+    HIP_TRY(hipGetLastError());
+    return FFVD_OK;
+}
+
+static int ready(ffvd_handle *h, const char *who) {
+    if (!h->have_data) return set_error(h, FFVD_EINVAL, std::string(who) + ": call ffvd_set_data first");
+    if (!h->have_params) return set_error(h, FFVD_EINVAL, std::string(who) + ": no parameters bound (ffvd_set_params or pass params)");
+    return FFVD_OK;
+}
+
+static int check_info(ffvd_handle *h) {
+    const int Dl = h->Dl;
+    for (int i = 0; i < Dl + h->nbatch; ++i) {
+        if (h->h_info[i] != 0) {
+            char msg[256];
+            if (i < Dl)
+                snprintf(msg, sizeof msg, "Cholesky of K_uu + jitter*I failed: latent dim %d, pivot %d is not positive",
+                         h->cfg.d_begin + i, h->h_info[i] - 1);
+            else
+                snprintf(msg, sizeof msg, "Cholesky of H failed: chain %d, latent dim %d, pivot %d is not positive",
+                         (i - Dl) / Dl, h->cfg.d_begin + (i - Dl) % Dl, h->h_info[i] - 1);
+            return set_error(h, FFVD_ENOTPD, msg);
+        }
+    }
+    return FFVD_OK;
+}
+
+extern "C" int ffvd_elbo(ffvd_handle *h, const ffvd_params *p, uint32_t flags, double out_terms[8], double *out_nll) {
+    if (!h) return set_error(nullptr, FFVD_EINVAL, "ffvd_elbo: null handle");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    int rc;
+    if (p) {
+        if (flags & FFVD_PARAMS_ON_DEVICE) {
+            if ((rc = check_params(h, p, "ffvd_elbo"))) return rc;
+            h->cur = *p;
+            if (!h->cur.U) h->cur.U = h->U;
+            if (!h->cur.loglengthscales) h->cur.loglengthscales = h->loglen;
+            h->have_params = true;
+        } else if ((rc = ffvd_set_params(h, p, 0))) return rc;
+    }
+    if ((rc = ready(h, "ffvd_elbo"))) return rc;
+    if ((rc = enqueue_elbo(h, nullptr, nullptr))) return rc;
+    HIP_TRY(hipMemcpyAsync(h->h_out, h->out_terms, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->h_chain, h->chain_nll, (size_t)h->cfg.S_local * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->h_info, h->info, (size_t)(h->Dl + h->nbatch) * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if ((rc = check_info(h))) return rc;
+    if (out_terms) memcpy(out_terms, h->h_out, 8 * sizeof(double));
+    if (out_nll) *out_nll = h->h_out[FFVD_TERM_NLL] / (double)h->cfg.S_local;
+    return FFVD_OK;
+}
+
+extern "C" int ffvd_elbo_async(ffvd_handle *h, double *out_terms_dev) {
+    if (!h) return set_error(nullptr, FFVD_EINVAL, "ffvd_elbo_async: null handle");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    int rc;
+    if ((rc = ready(h, "ffvd_elbo_async"))) return rc;
+    return enqueue_elbo(h, out_terms_dev, nullptr);
+}
+
+extern "C" int ffvd_chain_nll(ffvd_handle *h, double *out) {
+    if (!h || !out) return set_error(h, FFVD_EINVAL, "ffvd_chain_nll: null argument");
+    memcpy(out, h->h_chain, (size_t)h->cfg.S_local * sizeof(double));
+    return FFVD_OK;
+}
+
+extern "C" int ffvd_time_elbo(ffvd_handle *h, int iters, float *out_ms) {
+    if (!h || !out_ms || iters < 1) return set_error(h, FFVD_EINVAL, "ffvd_time_elbo: bad argument");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    int rc;
+    if ((rc = ready(h, "ffvd_time_elbo"))) return rc;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, h->stream));
+    for (int i = 0; i < iters; ++i)
+        if ((rc = enqueue_elbo(h, nullptr, nullptr))) return rc;
+    HIP_TRY(hipEventRecord(e1, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->h_info, h->info, (size_t)(h->Dl + h->nbatch) * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipEventElapsedTime(out_ms, e0, e1));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return check_info(h);
+}
+
+static void drain_stage_times(ffvd_handle *h, double ms[8], int32_t n[8]) {
+    for (int i = 0; i < 8; ++i) { ms[i] = 0.0; n[i] = 0; }
+    for (size_t i = 1; i < h->ev_used; ++i) {
+        const int st = h->ev_stage[i];
+        if (st < 0 || st >= 8) continue;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, h->ev_pool[i - 1], h->ev_pool[i]) == hipSuccess) { ms[st] += t; ++n[st]; }
+    }
+    h->ev_used = 0;
+}
+
+extern "C" int ffvd_profile_stages(ffvd_handle *h, float out_ms[8]) {
+    if (!h || !out_ms) return set_error(h, FFVD_EINVAL, "ffvd_profile_stages: bad argument");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    int rc;
+    if ((rc = ready(h, "ffvd_profile_stages"))) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->ev_used = 0;
+    StageTimer st{h};
+    if ((rc = enqueue_elbo(h, nullptr, &st))) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    double ms[8];
+    int32_t n[8];
+    drain_stage_times(h, ms, n);
+    for (int i = 0; i < 8; ++i) out_ms[i] = (float)ms[i];
+    return FFVD_OK;
+}
+
+extern "C" int ffvd_stage_timing(ffvd_handle *h, int enable) {
+    if (!h) return set_error(nullptr, FFVD_EINVAL, "ffvd_stage_timing: null handle");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->timing_on = enable != 0;
+    h->ev_used = 0;
+    return FFVD_OK;
+}
+
+extern "C" int ffvd_stage_times(ffvd_handle *h, double out_ms[8], int32_t out_launches[8]) {
+    if (!h || !out_ms || !out_launches) return set_error(h, FFVD_EINVAL, "ffvd_stage_times: bad argument");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    drain_stage_times(h, out_ms, out_launches);
+    return FFVD_OK;
+}
+
+// ---- operator-level entry points (temporaries allocated per call; not the hot path) --------------
+namespace {
+struct Scratch {
+    std::vector<void *> ptrs;
+    hipStream_t stream = nullptr;
+    ~Scratch() {
+        if (stream) { hipStreamSynchronize(stream); hipStreamDestroy(stream); }
+        for (void *p : ptrs) hipFree(p);
+    }
+    template <class T>
+    T *alloc(size_t n) {
+        void *p = nullptr;
+        if (hipMalloc(&p, (n ? n : 1) * sizeof(T)) != hipSuccess) return nullptr;
+        ptrs.push_back(p);
+        return (T *)p;
+    }
+    double *upload(const double *src, size_t n) {
+        double *d = alloc<double>(n);
+        if (d && n && hipMemcpyAsync(d, src, n * sizeof(double), hipMemcpyHostToDevice, stream) != hipSuccess) return nullptr;
+        return d;
+    }
+};
+}  // namespace
+
+#define OP_BEGIN(name)                                                                       \
+    ffvd_handle *h = nullptr;                                                                \
+    (void)h;                                                                                 \
+    Scratch sc;                                                                              \
+    if (hipStreamCreate(&sc.stream) != hipSuccess)                                           \
+        return set_error(nullptr, FFVD_EDEVICE, name ": no usable HIP device / stream creation failed");
+#define OP_CHECK(ptr, name) \
+    if (!(ptr)) return set_error(nullptr, FFVD_ENOMEM, name ": device allocation or upload failed");
+
+extern "C" int ffvd_op_kernel_matrix(int kind, const double *X, int N, const double *X2, int N2, int P,
+                                     double logvariance, const double *loglengthscales, double jitter, double *out) {
+    if (!X || !out || N < 0 || P < 1 || (X2 && N2 < 0) || (kind == FFVD_KERNEL_SE && !loglengthscales) ||
+        (kind != FFVD_KERNEL_SE && kind != FFVD_KERNEL_LINEAR))
+        return set_error(nullptr, FFVD_EINVAL, "ffvd_op_kernel_matrix: bad argument");
+    OP_BEGIN("ffvd_op_kernel_matrix");
+    const int same = (X2 == nullptr);
+    if (same) N2 = N;
+    if ((size_t)N * N2 == 0) return FFVD_OK;
+    double *dX = sc.upload(X, (size_t)N * P);
+    OP_CHECK(dX, "ffvd_op_kernel_matrix");
+    double *dX2 = same ? dX : sc.upload(X2, (size_t)N2 * P);
+    OP_CHECK(dX2, "ffvd_op_kernel_matrix");
+    double *dl = sc.alloc<double>(P);
+    OP_CHECK(dl, "ffvd_op_kernel_matrix");
+    if (loglengthscales) HIP_TRY(hipMemcpyAsync(dl, loglengthscales, P * sizeof(double), hipMemcpyHostToDevice, sc.stream));
+    double *dO = sc.alloc<double>((size_t)N * N2);
+    OP_CHECK(dO, "ffvd_op_kernel_matrix");
+    launch_kernel_matrix(sc.stream, kind, dX, N, dX2, N2, P, logvariance, dl, jitter, same, dO);
+    HIP_TRY(hipMemcpyAsync(out, dO, (size_t)N * N2 * sizeof(double), hipMemcpyDeviceToHost, sc.stream));
+    HIP_TRY(hipStreamSynchronize(sc.stream));
+    return FFVD_OK;
+}
+
+extern "C" int ffvd_op_kernel_diag(int kind, const double *X, int N, int P, double logvariance, double *out) {
+    if (!X || !out || N < 0 || P < 1) return set_error(nullptr, FFVD_EINVAL, "ffvd_op_kernel_diag: bad argument");
+    OP_BEGIN("ffvd_op_kernel_diag");
+    if (N == 0) return FFVD_OK;
+    double *dX = sc.upload(X, (size_t)N * P);
+    OP_CHECK(dX, "ffvd_op_kernel_diag");
+    double *dO = sc.alloc<double>(N);
+    OP_CHECK(dO, "ffvd_op_kernel_diag");
+    launch_kernel_diag(sc.stream, kind, dX, N, P, logvariance, dO);
+    HIP_TRY(hipMemcpyAsync(out, dO, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, sc.stream));
+    HIP_TRY(hipStreamSynchronize(sc.stream));
+    return FFVD_OK;
+}
+
+extern "C" int ffvd_op_cholesky(const double *A, int n, int batch, double *L, int32_t *info) {
+    if (!A || !L || n < 1 || batch < 0) return set_error(nullptr, FFVD_EINVAL, "ffvd_op_cholesky: bad argument");
+    OP_BEGIN("ffvd_op_cholesky");
+    if (batch == 0) return FFVD_OK;
+    const int np = round_up(n, NB);
+    const size_t slab = (size_t)np * np;
+    std::vector<double> pad(slab * batch, 0.0);
+    for (int b = 0; b < batch; ++b) {
+        double *S = pad.data() + slab * b;
+        for (int i = 0; i < np; ++i) {
+            if (i < n) memcpy(S + (size_t)i * np, A + ((size_t)b * n + i) * n, (size_t)n * sizeof(double));
+            else S[(size_t)i * np + i] = 1.0;
+        }
+    }
+    double *dA = sc.upload(pad.data(), pad.size());
+    OP_CHECK(dA, "ffvd_op_cholesky");
+    int32_t *dinfo = sc.alloc<int32_t>(batch);
+    OP_CHECK(dinfo, "ffvd_op_cholesky");
+    HIP_TRY(hipMemsetAsync(dinfo, 0, batch * sizeof(int32_t), sc.stream));
+    launch_potrf_ext(sc.stream, dA, np, 0, 0, batch, slab, dinfo);
+    std::vector<int32_t> hinfo(batch, 0);
+    HIP_TRY(hipMemcpyAsync(pad.data(), dA, pad.size() * sizeof(double), hipMemcpyDeviceToHost, sc.stream));
+    HIP_TRY(hipMemcpyAsync(hinfo.data(), dinfo, batch * sizeof(int32_t), hipMemcpyDeviceToHost, sc.stream));
+    HIP_TRY(hipStreamSynchronize(sc.stream));
+    int bad = -1;
+    for (int b = 0; b < batch; ++b) {
+        const double *S = pad.data() + slab * b;
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) L[((size_t)b * n + i) * n + j] = (j <= i) ? S[(size_t)i * np + j] : 0.0;
+        if (info) info[b] = hinfo[b];
+        if (hinfo[b] != 0 && bad < 0) bad = b;
+    }
+    if (bad >= 0) {
+        char msg[160];
+        snprintf(msg, sizeof msg, "ffvd_op_cholesky: matrix %d is not positive definite (pivot %d)", bad, hinfo[bad] - 1);
+        return set_error(nullptr, FFVD_ENOTPD, msg);
+    }
+    return FFVD_OK;
+}
+
+// shared by kernel_pre_cal / conditional: device-side hypers + K_uu + extended Cholesky
+struct KuuWork {
+    double *variance, *len, *Zs, *zz, *Kuu, *logvar, *loglen;
+    int32_t *info;
+    int Mp;
+};
+static int build_kuu(Scratch &sc, int kind, const double *Z, int M, int P, int D, const double *logvariance,
+                     const double *loglengthscales, double jitter, KuuWork &w, double **dZ_out) {
+    const int Mp = round_up(M, NB);
+    w.Mp = Mp;
+    double *dZ = sc.upload(Z, (size_t)M * P);
+    w.logvar = sc.upload(logvariance, D);
+    w.loglen = sc.alloc<double>((size_t)D * P);
+    w.variance = sc.alloc<double>(D);
+    w.len = sc.alloc<double>((size_t)D * P);
+    w.Zs = sc.alloc<double>((size_t)D * Mp * P);
+    w.zz = sc.alloc<double>((size_t)D * Mp);
+    w.Kuu = sc.alloc<double>((size_t)D * 2 * Mp * Mp);
+    w.info = sc.alloc<int32_t>(D);
+    if (!dZ || !w.logvar || !w.loglen || !w.variance || !w.len || !w.Zs || !w.zz || !w.Kuu || !w.info) return FFVD_ENOMEM;
+    if (loglengthscales &&
+        hipMemcpyAsync(w.loglen, loglengthscales, (size_t)D * P * sizeof(double), hipMemcpyHostToDevice, sc.stream) != hipSuccess)
+        return FFVD_EDEVICE;
+    if (hipMemsetAsync(w.info, 0, D * sizeof(int32_t), sc.stream) != hipSuccess) return FFVD_EDEVICE;
+    launch_prep_hypers(sc.stream, kind, dZ, M, Mp, P, D, 0, w.logvar, w.loglen, w.variance, w.len, w.Zs, w.zz);
+    HyperView hv{w.variance, w.len, w.Zs, w.zz};
+    launch_kuu_build(sc.stream, kind, hv, M, Mp, P, D, jitter, w.Kuu);
+    launch_potrf_ext(sc.stream, w.Kuu, Mp, Mp, 1, D, (size_t)2 * Mp * Mp, w.info);
+    if (dZ_out) *dZ_out = dZ;
+    return FFVD_OK;
+}
+static int check_kuu_info(Scratch &sc, const KuuWork &w, int D, const char *who) {
+    std::vector<int32_t> hinfo(D, 0);
+    if (hipMemcpyAsync(hinfo.data(), w.info, D * sizeof(int32_t), hipMemcpyDeviceToHost, sc.stream) != hipSuccess ||
+        hipStreamSynchronize(sc.stream) != hipSuccess)
+        return set_error(nullptr, FFVD_EDEVICE, std::string(who) + ": device error while reading Cholesky status");
+    for (int d = 0; d < D; ++d)
+        if (hinfo[d]) {
+            char msg[200];
+            snprintf(msg, sizeof msg, "%s: Cholesky of K_uu + jitter*I failed: latent dim %d, pivot %d is not positive", who, d,
+                     hinfo[d] - 1);
+            return set_error(nullptr, FFVD_ENOTPD, msg);
+        }
+    return FFVD_OK;
+}
+
+extern "C" int ffvd_op_kernel_pre_cal(int kind, const double *Z, int M, int P, int D, const double *logvariance,
+                                      const double *loglengthscales, double jitter, double *Lm_inverse_seq) {
+    if (!Z || !logvariance || !Lm_inverse_seq || M < 1 || P < 1 || P > MAXP || D < 1 ||
+        (kind == FFVD_KERNEL_SE && !loglengthscales))
+        return set_error(nullptr, FFVD_EINVAL, "ffvd_op_kernel_pre_cal: bad argument");
+    OP_BEGIN("ffvd_op_kernel_pre_cal");
+    KuuWork w{};
+    int rc = build_kuu(sc, kind, Z, M, P, D, logvariance, loglengthscales, jitter, w, nullptr);
+    if (rc) return set_error(nullptr, rc, "ffvd_op_kernel_pre_cal: device allocation or upload failed");
+    const size_t Mp = w.Mp;
+    std::vector<double> host((size_t)D * 2 * Mp * Mp);
+    HIP_TRY(hipMemcpyAsync(host.data(), w.Kuu, host.size() * sizeof(double), hipMemcpyDeviceToHost, sc.stream));
+    if ((rc = check_kuu_info(sc, w, D, "ffvd_op_kernel_pre_cal"))) return rc;
+    for (int d = 0; d < D; ++d) {
+        const double *Wd = host.data() + (size_t)d * 2 * Mp * Mp + Mp * Mp;
+        for (int i = 0; i < M; ++i)
+            memcpy(Lm_inverse_seq + ((size_t)d * M + i) * M, Wd + (size_t)i * Mp, (size_t)M * sizeof(double));
+    }
+    return FFVD_OK;
+}
+
+extern "C" int ffvd_op_collapse(int kind, const double *Lm_inverse_seq, const double *X_combine, const double *X,
+                                const double *Z, int T, int M, int P, int D, const double *logvariance,
+                                const double *loglengthscales, const double *Q, double batch_size, double Y_N,
+                                double out3[3]) {
+    if (!Lm_inverse_seq || !X_combine || !X || !Z || !logvariance || !Q || !out3 || T < 1 || M < 1 || P < 1 ||
+        P > MAXP || D < 1 || (kind == FFVD_KERNEL_SE && !loglengthscales) || !(batch_size > 0.0))
+        return set_error(nullptr, FFVD_EINVAL, "ffvd_op_collapse: bad argument");
+    OP_BEGIN("ffvd_op_collapse");
+    const int Mp = round_up(M, NB), Tp = round_up(T, STRIP), ng = (Mp + 511) / 512;
+    // pad the caller's L^{-T} stack to Mp with an identity block
+    std::vector<double> Wp((size_t)D * Mp * Mp, 0.0);
+    for (int d = 0; d < D; ++d)
+        for (int i = 0; i < Mp; ++i) {
+            double *row = Wp.data() + ((size_t)d * Mp + i) * Mp;
+            if (i < M) memcpy(row, Lm_inverse_seq + ((size_t)d * M + i) * M, (size_t)M * sizeof(double));
+            else row[i] = 1.0;
+        }
+    std::vector<double> logQ(D);
+    for (int d = 0; d < D; ++d) logQ[d] = log(Q[d]);
+    double *dW = sc.upload(Wp.data(), Wp.size());
+    double *dXc = sc.upload(X_combine, (size_t)T * P);
+    double *dX = sc.upload(X, (size_t)(T + 1) * D);
+    double *dZ = sc.upload(Z, (size_t)M * P);
+    double *dlv = sc.upload(logvariance, D);
+    double *dll = sc.alloc<double>((size_t)D * P);
+    double *dlq = sc.upload(logQ.data(), D);
+    double *variance = sc.alloc<double>(D), *len = sc.alloc<double>((size_t)D * P);
+    double *Zs = sc.alloc<double>((size_t)D * Mp * P), *zz = sc.alloc<double>((size_t)D * Mp);
+    double *F = sc.alloc<double>((size_t)D * Tp * Mp);
+    const size_t hstride = (size_t)(Mp + NB) * Mp;
+    double *H = sc.alloc<double>((size_t)D * hstride);
+    double *rowsq = sc.alloc<double>((size_t)D * ng * Tp);
+    double *hterms = sc.alloc<double>((size_t)D * 2), *cterms = sc.alloc<double>(8);
+    int32_t *info = sc.alloc<int32_t>(D);
+    if (!dW || !dXc || !dX || !dZ || !dlv || !dll || !dlq || !variance || !len || !Zs || !zz || !F || !H || !rowsq ||
+        !hterms || !cterms || !info)
+        return set_error(nullptr, FFVD_ENOMEM, "ffvd_op_collapse: device allocation or upload failed");
+    if (loglengthscales)
+        HIP_TRY(hipMemcpyAsync(dll, loglengthscales, (size_t)D * P * sizeof(double), hipMemcpyHostToDevice, sc.stream));
+    HIP_TRY(hipMemsetAsync(H, 0, (size_t)D * hstride * sizeof(double), sc.stream));
+    HIP_TRY(hipMemsetAsync(info, 0, D * sizeof(int32_t), sc.stream));
+    launch_prep_hypers(sc.stream, kind, dZ, M, Mp, P, D, 0, dlv, dll, variance, len, Zs, zz);
+    HyperView hv{variance, len, Zs, zz};
+    ProjectArgs pa{};
+    pa.kind = kind; pa.x = dXc; pa.x_chain_stride = 0; pa.x_ld = P; pa.x_cols = P; pa.ctrl = nullptr;
+    pa.T = T; pa.Tp = Tp; pa.C = 0; pa.P = P; pa.M = M; pa.Mp = Mp; pa.Dl = D; pa.d_begin = 0; pa.hv = hv;
+    pa.W = dW; pa.w_stride = (size_t)Mp * Mp; pa.U = nullptr; pa.u_ld = 0; pa.b0 = 0; pa.nb = D; pa.F = F;
+    pa.rowsq = rowsq; pa.fmean = nullptr; pa.ng = ng;
+    launch_project(sc.stream, pa);
+    GramArgs ga{};
+    ga.F = F; ga.X = dX; ga.log_Q = dlq; ga.T = T; ga.Tp = Tp; ga.D = D; ga.Mp = Mp; ga.Dl = D; ga.d_begin = 0;
+    ga.b0 = 0; ga.nb = D; ga.yn_over_batch = Y_N / batch_size; ga.H = H; ga.h_stride = hstride;
+    launch_gram(sc.stream, ga);
+    launch_potrf_ext(sc.stream, H, Mp, NB, 0, D, hstride, info);
+    launch_h_finish(sc.stream, H, Mp, hstride, D, hterms);
+    ReduceArgs ra{};
+    ra.kind = kind; ra.branch = FFVD_BRANCH_B; ra.X = dX; ra.ctrl = nullptr; ra.Y = nullptr; ra.log_Q = dlq;
+    ra.CC = nullptr; ra.DD = nullptr; ra.log_Rchols = nullptr; ra.variance = variance; ra.T = T; ra.Tp = Tp; ra.D = D;
+    ra.C = 0; ra.Ydim = 0; ra.Dl = D; ra.d_begin = 0; ra.S = 1; ra.ng = ng; ra.shared_terms = 0;
+    ra.xk = dXc; ra.xk_chain_stride = 0; ra.xk_ld = P; ra.xk_cols = P; ra.rowsq = rowsq; ra.fmean = nullptr;
+    ra.chain_terms = cterms;
+    launch_chain_reduce(sc.stream, ra);
+    std::vector<double> ht((size_t)D * 2), ct(8);
+    std::vector<int32_t> hinfo(D);
+    HIP_TRY(hipMemcpyAsync(ht.data(), hterms, ht.size() * sizeof(double), hipMemcpyDeviceToHost, sc.stream));
+    HIP_TRY(hipMemcpyAsync(ct.data(), cterms, 8 * sizeof(double), hipMemcpyDeviceToHost, sc.stream));
+    HIP_TRY(hipMemcpyAsync(hinfo.data(), info, D * sizeof(int32_t), hipMemcpyDeviceToHost, sc.stream));
+    HIP_TRY(hipStreamSynchronize(sc.stream));
+    for (int d = 0; d < D; ++d)
+        if (hinfo[d]) {
+            char msg[160];
+            snprintf(msg, sizeof msg, "ffvd_op_collapse: Cholesky of H failed: latent dim %d, pivot %d is not positive", d, hinfo[d] - 1);
+            return set_error(nullptr, FFVD_ENOTPD, msg);
+        }
+    double term1 = 0.0, term2 = 0.0;
+    for (int d = 0; d < D; ++d) { term1 += -0.5 * ht[2 * d]; term2 += 0.5 * ht[2 * d + 1]; }
+    out3[0] = -term1 / Y_N;
+    out3[1] = -term2 / Y_N;
+    out3[2] = -ct[2] / Y_N;      // chain_reduce's trace sum: sum_d sum_t -0.5 (Kdiag - |F_t|^2) / Q_d
+    return FFVD_OK;
+}
+
+extern "C" int ffvd_op_conditional(int kind, const double *Xnew, int N, const double *Z, int M, int P, int D,
+                                   const double *logvariance, const double *loglengthscales, const double *f,
+                                   double jitter, double *mean, double *var) {
+    if (!Xnew || !Z || !logvariance || !f || !mean || !var || N < 0 || M < 1 || P < 1 || P > MAXP || D < 1 ||
+        (kind == FFVD_KERNEL_SE && !loglengthscales))
+        return set_error(nullptr, FFVD_EINVAL, "ffvd_op_conditional: bad argument");
+    OP_BEGIN("ffvd_op_conditional");
+    if (N == 0) return FFVD_OK;
+    KuuWork w{};
+    int rc = build_kuu(sc, kind, Z, M, P, D, logvariance, loglengthscales, jitter, w, nullptr);
+    if (rc) return set_error(nullptr, rc, "ffvd_op_conditional: device allocation or upload failed");
+    const int Mp = w.Mp, Tp = round_up(N, STRIP), ng = (Mp + 511) / 512;
+    double *dX = sc.upload(Xnew, (size_t)N * P);
+    double *dU = sc.upload(f, (size_t)M * D);
+    double *rowsq = sc.alloc<double>((size_t)D * ng * Tp), *fmean = sc.alloc<double>((size_t)D * ng * Tp);
+    double *dmean = sc.alloc<double>((size_t)N * D), *dvar = sc.alloc<double>((size_t)N * D);
+    if (!dX || !dU || !rowsq || !fmean || !dmean || !dvar)
+        return set_error(nullptr, FFVD_ENOMEM, "ffvd_op_conditional: device allocation or upload failed");
+    HyperView hv{w.variance, w.len, w.Zs, w.zz};
+    ProjectArgs pa{};
+    pa.kind = kind; pa.x = dX; pa.x_chain_stride = 0; pa.x_ld = P; pa.x_cols = P; pa.ctrl = nullptr;
+    pa.T = N; pa.Tp = Tp; pa.C = 0; pa.P = P; pa.M = M; pa.Mp = Mp; pa.Dl = D; pa.d_begin = 0; pa.hv = hv;
+    pa.W = w.Kuu + (size_t)Mp * Mp; pa.w_stride = (size_t)2 * Mp * Mp; pa.U = dU; pa.u_ld = D; pa.b0 = 0; pa.nb = D;
+    pa.F = nullptr; pa.rowsq = rowsq; pa.fmean = fmean; pa.ng = ng;
+    launch_project(sc.stream, pa);
+    launch_conditional_finish(sc.stream, kind, dX, N, P, w.variance, rowsq, fmean, ng, Tp, D, dmean, dvar);
+    HIP_TRY(hipMemcpyAsync(mean, dmean, (size_t)N * D * sizeof(double), hipMemcpyDeviceToHost, sc.stream));
+    HIP_TRY(hipMemcpyAsync(var, dvar, (size_t)N * D * sizeof(double), hipMemcpyDeviceToHost, sc.stream));
+    return check_kuu_info(sc, w, D, "ffvd_op_conditional");
+}

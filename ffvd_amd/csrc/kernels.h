@@ -1,0 +1,115 @@
+// Device-side launchers of the FFVD ELBO engine (gfx950 / CDNA4, fp64).
+// Every function only ENQUEUES work on `stream`; none allocates or synchronises.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ffvd {
+
+constexpr int NB = 64;        // universal block size: M is padded to a multiple of NB (identity padding)
+constexpr int STRIP = 64;     // rows of K_fu handled by one workgroup of the projection kernel
+constexpr int MAXP = 32;      // largest GP input dimension P = D + C supported by the LDS layout
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// Per-latent-dim kernel hyper-parameters prepared on device (prep_hypers).
+struct HyperView {
+    const double *variance;   // [Dl]     exp(logvariance)
+    const double *len;        // [Dl][P]  exp(loglengthscales) (SE) or 1 (LINEAR)
+    const double *Zs;         // [Dl][Mp][P] inducing inputs divided by lengthscales (rows >= M are 0)
+    const double *zz;         // [Dl][Mp]    |Zs_m|^2
+};
+
+// hyp <- exp of the log-parameters; Zs, zz as above.  logvar/loglen are indexed by GLOBAL dim (d_begin + dl).
+void launch_prep_hypers(hipStream_t stream, int kind, const double *Z, int M, int Mp, int P, int Dl, int d_begin,
+                        const double *logvar, const double *loglen, double *variance, double *len,
+                        double *Zs, double *zz);
+
+// A[dl] (ld = Mp, rows 0..Mp-1) = K_dl(Z, Z) + jitter*I with identity padding; rows Mp..2Mp-1 = I (the
+// "extra rows" that the extended Cholesky turns into L^{-T}).  A has Dl slabs of 2*Mp*Mp doubles.
+void launch_kuu_build(hipStream_t stream, int kind, HyperView hv, int M, int Mp, int P, int Dl, double jitter, double *A);
+
+// General kernel matrix for the operator API: out[N x N2] = K(X, X2) for ONE kernel (dl = 0 of hv is not used;
+// lengthscale scaling is applied on the fly).  diag_jitter added where row == col if `same`.
+void launch_kernel_matrix(hipStream_t stream, int kind, const double *X, int N, const double *X2, int N2, int P,
+                          double logvar, const double *loglen_dev, double jitter, int same, double *out);
+void launch_kernel_diag(hipStream_t stream, int kind, const double *X, int N, int P, double logvar, double *out);
+
+// Extended blocked Cholesky, in place, batched:  each slab holds an n x n SPD matrix (n multiple of NB, lower
+// triangle referenced) followed by `extra_rows` further rows R (same ld = n).  On exit the lower triangle holds
+// L and the extra rows hold R * L^{-T}.  identity_extra != 0 declares that R is the n x n identity on entry
+// (so R L^{-T} = L^{-T} is upper triangular and zero blocks are skipped).  info[b] = 0 or 1 + first bad pivot.
+void launch_potrf_ext(hipStream_t stream, double *A, int n, int extra_rows, int identity_extra, int batch,
+                      size_t slab_stride, int32_t *info);
+
+struct ProjectArgs {
+    int kind;
+    // GP inputs x_t = [ x[chain][t][0:x_cols] | ctrl[t][0:C] ], P = x_cols + C  (dgp_model.py:269)
+    const double *x;        // rows of the first x_cols input columns
+    size_t x_chain_stride;  // doubles between chains ((T+1)*D for Layer.X)
+    int x_ld, x_cols;
+    const double *ctrl;     // [T][C] control inputs (may be null when C == 0)
+    int T, Tp, C, P, M, Mp, Dl, d_begin;
+    HyperView hv;
+    const double *W;        // [Dl] slabs: W[dl] = L^{-T} (Mp x Mp, upper), slab stride w_stride doubles
+    size_t w_stride;
+    const double *U;        // [M][u_ld] whitened inducing outputs (branch A), column d_begin + dl; or null
+    int u_ld;
+    int b0, nb;             // batches [b0, b0+nb): b = s*Dl + dl
+    double *F;              // [nb][Tp][Mp] or null
+    double *rowsq;          // [nbatch_total][ng][Tp] or null   (sum_j F[t][j]^2 per column group)
+    double *fmean;          // [nbatch_total][ng][Tp] or null   (sum_j F[t][j] * U[j][d])
+    int ng;                 // column groups = ceil(Mp / 512)
+};
+// F = K_fu * L^{-T} with K_fu generated on the fly (never stored).
+void launch_project(hipStream_t stream, const ProjectArgs &a);
+
+struct GramArgs {
+    const double *F;        // [nb][Tp][Mp]
+    const double *X;        // [S][T+1][D]
+    const double *log_Q;    // [D] (global dim index)
+    int T, Tp, D, Mp, Dl, d_begin;
+    int b0, nb;
+    double yn_over_batch;   // Y_N / batch_size (== 1 for the full batch)
+    double *H;              // [nb] slabs of (Mp + NB) x Mp: H = F^T F * scale + I (lower), row Mp = scale * delta^T F
+    size_t h_stride;
+};
+void launch_gram(hipStream_t stream, const GramArgs &a);
+
+// hterms[b] = { logdet(H) = 2 sum log diag(L_H),  b^T H^{-1} b = |row Mp|^2 } after launch_potrf_ext on H.
+void launch_h_finish(hipStream_t stream, const double *H, int Mp, size_t h_stride, int nb, double *hterms /*[nb][2]*/);
+
+struct ReduceArgs {
+    int kind, branch;
+    const double *X, *ctrl, *Y;    // X [S][T+1][D]; ctrl [T][C]; Y [T][Ydim]
+    const double *log_Q, *CC, *DD, *log_Rchols, *variance /*[Dl]*/;
+    int T, Tp, D, C, Ydim, Dl, d_begin, S, ng, shared_terms;
+    // rows whose LinearK.Kdiag enters the trace term: [ xk[chain][t][0:xk_cols] | ctrl[t][0:C] ]
+    const double *xk;
+    size_t xk_chain_stride;
+    int xk_ld, xk_cols;
+    const double *rowsq, *fmean;   // [S*Dl][ng][Tp]
+    double *chain_terms;           // [S][8] partial sums per chain
+};
+void launch_chain_reduce(hipStream_t stream, const ReduceArgs &a);
+
+struct FinalizeArgs {
+    int kind, branch, prior_type, shared_terms;
+    int T, D, P, M, Ydim, Dl, d_begin, S;
+    const double *Z, *U, *logvar, *loglen, *log_Q, *CC, *DD, *log_Rchols;
+    const double *chain_terms;     // [S][8]
+    const double *hterms;          // [S*Dl][2] (branch B) or null
+    double *chain_nll;             // [S]
+    double *out_terms;             // [8]
+};
+void launch_finalize(hipStream_t stream, const FinalizeArgs &a);
+
+// conditional() epilogue: mean[n][d] = sum_g fmean, var[n][d] = Kdiag(x_n) - sum_g rowsq  (N x D outputs)
+void launch_conditional_finish(hipStream_t stream, int kind, const double *x, int N, int P, const double *variance,
+                               const double *rowsq, const double *fmean, int ng, int Tp, int D, double *mean,
+                               double *var);
+
+// small utilities
+void launch_fill(hipStream_t stream, double *p, size_t n, double v);
+
+}  // namespace ffvd

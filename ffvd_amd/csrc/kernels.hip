@@ -1,0 +1,824 @@
+// Hand-written HIP kernels of the FFVD ELBO hot path for gfx950 (MI355X, CDNA4), fp64.
+//
+// Reference arithmetic (TensorFlow op call sites):
+//   K1/K2  kernels_multi_output.py:163-182,246-247 (SE), kernels.py:270-281 (LinearK)
+//   K3/K4  conditionals_multi_output.py:159-166  chol(K_uu + jitter I), L^{-T}
+//   K5b    conditionals_multi_output.py:242      F = K_fu L^{-T}
+//   K6/K7  conditionals_multi_output.py:246-248  H = F^T F / Q + I,  b = delta^T F / Q
+//   K9/K10 conditionals_multi_output.py:253-254  logdet H, b H^{-1} b^T
+//   K8     conditionals_multi_output.py:255, :41 per-point explained variance
+//   K11    conditionals_multi_output.py:48       GP mean A^T u
+//   K12/13 likelihoods.py:76-111, dgp_model.py:105-143,248-297,326-359
+//
+// Design notes (DESIGN.md has the full story):
+//   * every M x M matrix is padded to Mp = multiple of 64 with an identity block, T to a multiple of 64 with
+//     zero rows of K_fu, so no kernel has edge handling along M or T;
+//   * dense contractions run on v_mfma_f64_16x16x4_f64 (one f64 A and B element per lane, 4 accumulators per lane);
+//   * K_fu is produced tile-wise in LDS and consumed by the MFMA in the same workgroup; it never reaches HBM;
+//   * Cholesky is a blocked right-looking factorisation whose "extra rows" carry a right-hand side through the
+//     same panel/trailing kernels: identity rows become L^{-T}, the row delta^T F / Q becomes L_H^{-1} b.
+#include "kernels.h"
+
+namespace ffvd {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// D(16x16) += A(16x4) * B(4x16).  Lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15];
+// it owns D[(l >> 4) + 4 r][l & 15] in element r of the accumulator.
+__device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ double block_sum_256(double v, double *scratch /*[256]*/) {
+    const int tid = threadIdx.x;
+    scratch[tid] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) scratch[tid] += scratch[tid + s];
+        __syncthreads();
+    }
+    double r = scratch[0];
+    __syncthreads();
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// small utilities
+// ---------------------------------------------------------------------------------------------
+__global__ void fill_kernel(double *p, size_t n, double v) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = v;
+}
+void launch_fill(hipStream_t stream, double *p, size_t n, double v) {
+    if (n == 0) return;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, stream, p, n, v);
+}
+
+// ---------------------------------------------------------------------------------------------
+// hyper-parameter preparation: variance = exp(logvariance) (kernels_multi_output.py:157),
+// lengthscales = exp(loglengthscales) (:161), Zs = Z / lengthscales (:170), zz = reduce_sum(square(Zs)) (:171)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void prep_hypers_kernel(int kind, const double *Z, int M, int Mp, int P, int d_begin,
+                                                          const double *logvar, const double *loglen,
+                                                          double *variance, double *len, double *Zs, double *zz) {
+    __shared__ double ls[MAXP];
+    const int dl = blockIdx.x, dg = d_begin + dl, tid = threadIdx.x;
+    if (tid == 0) variance[dl] = exp(logvar[dg]);
+    if (tid < P) {
+        double l = (kind == 0) ? exp(loglen[(size_t)dg * P + tid]) : 1.0;
+        ls[tid] = l;
+        len[(size_t)dl * P + tid] = l;
+    }
+    __syncthreads();
+    for (int m = tid; m < Mp; m += 256) {
+        double s = 0.0;
+        for (int p = 0; p < P; ++p) {
+            double v = (m < M) ? Z[(size_t)m * P + p] / ls[p] : 0.0;
+            Zs[((size_t)dl * Mp + m) * P + p] = v;
+            s += v * v;
+        }
+        zz[(size_t)dl * Mp + m] = s;
+    }
+}
+void launch_prep_hypers(hipStream_t stream, int kind, const double *Z, int M, int Mp, int P, int Dl, int d_begin,
+                        const double *logvar, const double *loglen, double *variance, double *len,
+                        double *Zs, double *zz) {
+    hipLaunchKernelGGL(prep_hypers_kernel, dim3(Dl), dim3(256), 0, stream, kind, Z, M, Mp, P, d_begin, logvar,
+                       loglen, variance, len, Zs, zz);
+}
+
+// K(i,j) of one kernel from pre-scaled rows.  SE: variance * exp(-(-2 x.z + (|x|^2 + |z|^2)) / 2)
+// (kernels_multi_output.py:180-181,247); LINEAR: sum_p (x_p * variance) * z_p (kernels.py:276).
+template <int KIND>
+__device__ __forceinline__ double kernel_value(double dot, double xx, double zz, double variance) {
+    if (KIND == 0) {
+        double r2 = -2.0 * dot + (xx + zz);
+        return variance * exp(-r2 / 2.0);
+    }
+    return dot;   // LINEAR: variance already folded into the x operand
+}
+
+__global__ __launch_bounds__(256) void kuu_build_kernel(int kind, HyperView hv, int M, int Mp, int P, double jitter,
+                                                        double *A) {
+    const int dl = blockIdx.z;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)Mp * Mp) return;
+    const int i = (int)(idx / Mp), j = (int)(idx % Mp);
+    double *slab = A + (size_t)dl * 2 * Mp * Mp;
+    if (blockIdx.y == 1) {   // extra rows: identity, becomes L^{-T}
+        slab[(size_t)Mp * Mp + idx] = (i == j) ? 1.0 : 0.0;
+        return;
+    }
+    double v;
+    if (i >= M || j >= M) {
+        v = (i == j) ? 1.0 : 0.0;
+    } else {
+        const double *zi = hv.Zs + ((size_t)dl * Mp + i) * P;
+        const double *zj = hv.Zs + ((size_t)dl * Mp + j) * P;
+        const double var = hv.variance[dl];
+        double dot = 0.0;
+        if (kind == 0) {
+            for (int p = 0; p < P; ++p) dot += zi[p] * zj[p];
+            v = kernel_value<0>(dot, hv.zz[(size_t)dl * Mp + i], hv.zz[(size_t)dl * Mp + j], var);
+        } else {
+            for (int p = 0; p < P; ++p) dot += (zi[p] * var) * zj[p];
+            v = dot;
+        }
+        if (i == j) v += jitter;   // conditionals_multi_output.py:108,159
+    }
+    slab[idx] = v;
+}
+void launch_kuu_build(hipStream_t stream, int kind, HyperView hv, int M, int Mp, int P, int Dl, double jitter, double *A) {
+    dim3 grid((unsigned)(((size_t)Mp * Mp + 255) / 256), 2, Dl);
+    hipLaunchKernelGGL(kuu_build_kernel, grid, dim3(256), 0, stream, kind, hv, M, Mp, P, jitter, A);
+}
+
+// Operator-API kernel matrix (one kernel, arbitrary N, N2; no padding).
+__global__ __launch_bounds__(256) void kernel_matrix_kernel(int kind, const double *X, int N, const double *X2, int N2,
+                                                            int P, double logvar, const double *loglen, double jitter,
+                                                            int same, double *out) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)N * N2) return;
+    const int i = (int)(idx / N2), j = (int)(idx % N2);
+    const double var = exp(logvar);
+    const double *xi = X + (size_t)i * P, *zj = X2 + (size_t)j * P;
+    double v;
+    if (kind == 0) {
+        double dot = 0.0, xx = 0.0, zz = 0.0;
+        for (int p = 0; p < P; ++p) {
+            double l = exp(loglen[p]);
+            double a = xi[p] / l, b = zj[p] / l;
+            dot += a * b; xx += a * a; zz += b * b;
+        }
+        v = kernel_value<0>(dot, xx, zz, var);
+    } else {
+        double dot = 0.0;
+        for (int p = 0; p < P; ++p) dot += (xi[p] * var) * zj[p];
+        v = dot;
+    }
+    if (same && i == j) v += jitter;
+    out[idx] = v;
+}
+void launch_kernel_matrix(hipStream_t stream, int kind, const double *X, int N, const double *X2, int N2, int P,
+                          double logvar, const double *loglen_dev, double jitter, int same, double *out) {
+    size_t n = (size_t)N * N2;
+    if (n == 0) return;
+    hipLaunchKernelGGL(kernel_matrix_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, kind, X, N, X2,
+                       N2, P, logvar, loglen_dev, jitter, same, out);
+}
+__global__ void kernel_diag_kernel(int kind, const double *X, int N, int P, double logvar, double *out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const double var = exp(logvar);
+    if (kind == 0) { out[i] = var; return; }                     // kernels_multi_output.py:199-200
+    double s = 0.0;
+    for (int p = 0; p < P; ++p) { double x = X[(size_t)i * P + p]; s += (x * x) * var; }   // kernels.py:278-281
+    out[i] = s;
+}
+void launch_kernel_diag(hipStream_t stream, int kind, const double *X, int N, int P, double logvar, double *out) {
+    if (N == 0) return;
+    hipLaunchKernelGGL(kernel_diag_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, kind, X, N, P, logvar, out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Extended blocked Cholesky (right-looking, NB = 64)
+// ---------------------------------------------------------------------------------------------
+// Step k, panel kernel: every workgroup factorises the 64x64 diagonal block in LDS (redundantly; workgroup 0 of a
+// matrix writes it back) and solves its 64-row chunk of the rows below:  R <- R * D^{-T}.
+__global__ __launch_bounds__(256) void potrf_panel_kernel(double *A, int n, int k, int nmain, int nchunks,
+                                                          size_t slab_stride, int32_t *info) {
+    __shared__ double Ds[NB][NB + 1];
+    __shared__ double Rs[NB][NB + 1];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    double *S = A + (size_t)b * slab_stride;
+    const int k0 = k * NB;
+
+    for (int idx = tid; idx < NB * NB; idx += 256) {
+        int i = idx >> 6, j = idx & 63;
+        Ds[i][j] = S[(size_t)(k0 + i) * n + k0 + j];
+    }
+    __syncthreads();
+    // unblocked lower Cholesky of Ds (tf.linalg.cholesky, conditionals_multi_output.py:28,162)
+    for (int j = 0; j < NB; ++j) {
+        const double ajj = Ds[j][j];
+        if (!(ajj > 0.0) && tid == 0 && chunk == 0 && info[b] == 0) info[b] = k0 + j + 1;
+        const double piv = sqrt(ajj);
+        if (tid < NB && tid > j) Ds[tid][j] = Ds[tid][j] / piv;
+        __syncthreads();
+        {
+            const int i = tid & 63, q = tid >> 6;
+            if (i > j) {
+                const double lij = Ds[i][j];
+                for (int c = j + 1 + q; c <= i; c += 4) Ds[i][c] -= lij * Ds[c][j];
+            }
+            if (tid == j) Ds[j][j] = piv;
+        }
+        __syncthreads();
+    }
+    if (chunk == 0) {
+        for (int idx = tid; idx < NB * NB; idx += 256) {
+            int i = idx >> 6, j = idx & 63;
+            if (j <= i) S[(size_t)(k0 + i) * n + k0 + j] = Ds[i][j];
+        }
+    }
+    if (chunk >= nchunks) return;
+    const int row0 = (chunk < nmain) ? (k + 1 + chunk) * NB : n + (chunk - nmain) * NB;
+    for (int idx = tid; idx < NB * NB; idx += 256) {
+        int i = idx >> 6, j = idx & 63;
+        Rs[i][j] = S[(size_t)(row0 + i) * n + k0 + j];
+    }
+    __syncthreads();
+    // forward substitution per row r: y_c = (R_rc - sum_{j<c} y_j D_cj) / D_cc ; 4 threads share a row
+    {
+        const int r = tid >> 2, q = tid & 3;
+        for (int c = 0; c < NB; ++c) {
+            double s = 0.0;
+            for (int j = q; j < c; j += 4) s += Rs[r][j] * Ds[c][j];
+            s += __shfl_xor(s, 1);
+            s += __shfl_xor(s, 2);
+            if (q == 0) Rs[r][c] = (Rs[r][c] - s) / Ds[c][c];
+            __syncthreads();
+        }
+    }
+    for (int idx = tid; idx < NB * NB; idx += 256) {
+        int i = idx >> 6, j = idx & 63;
+        S[(size_t)(row0 + i) * n + k0 + j] = Rs[i][j];
+    }
+}
+
+// Step k, trailing update: one wavefront per 64x64 tile,  C(i,j) -= P_i * P_j^T  with P = solved panel (columns of block k).
+// Tiles: main lower triangle (k < j <= i < nb) then extra-row tiles (e, j) for j in (k, nb).
+__global__ __launch_bounds__(64) void potrf_trail_kernel(double *A, int n, int k, int nmain_tiles, int n1,
+                                                         size_t slab_stride) {
+    const int b = blockIdx.y;
+    int tile = blockIdx.x;
+    double *S = A + (size_t)b * slab_stride;
+    const int k0 = k * NB;
+    int rowblk0, colblk;   // first row / first col of the tile
+    if (tile < nmain_tiles) {
+        int i = 0;          // unrank lower triangle: tile = i(i+1)/2 + j
+        while ((i + 1) * (i + 2) / 2 <= tile) ++i;
+        int j = tile - i * (i + 1) / 2;
+        rowblk0 = (k + 1 + i) * NB;
+        colblk = (k + 1 + j) * NB;
+    } else {
+        int t = tile - nmain_tiles;
+        int e = t / n1, j = t % n1;
+        rowblk0 = n + e * NB;
+        colblk = (k + 1 + j) * NB;
+    }
+    const int lane = threadIdx.x, lr = lane & 15, lk = lane >> 4;
+    d4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[a][c] = (d4){0.0, 0.0, 0.0, 0.0};
+    const double *Pi = S + (size_t)rowblk0 * n + k0;
+    const double *Pj = S + (size_t)colblk * n + k0;
+#pragma unroll 2
+    for (int ks = 0; ks < NB / 4; ++ks) {
+        double af[4], bf[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            af[t] = Pi[(size_t)(16 * t + lr) * n + 4 * ks + lk];   // A[row][k]
+            bf[t] = Pj[(size_t)(16 * t + lr) * n + 4 * ks + lk];   // B[k][col] = P_j[col][k]
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[a][c] = mfma_f64(af[a], bf[c], acc[a][c]);
+    }
+    double *Ct = S + (size_t)rowblk0 * n + colblk;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                size_t off = (size_t)(16 * a + lk + 4 * q) * n + 16 * c + lr;
+                Ct[off] -= acc[a][c][q];
+            }
+}
+
+void launch_potrf_ext(hipStream_t stream, double *A, int n, int extra_rows, int identity_extra, int batch,
+                      size_t slab_stride, int32_t *info) {
+    const int nb = n / NB;
+    const int nextra_all = extra_rows / NB;
+    for (int k = 0; k < nb; ++k) {
+        const int nmain = nb - k - 1;
+        // identity extras: block-row e of L^{-T} is zero in block-columns < e, so only e <= k is live at step k
+        const int nextra = identity_extra ? ((k + 1 < nextra_all) ? k + 1 : nextra_all) : nextra_all;
+        const int nchunks = nmain + nextra;
+        dim3 pgrid(nchunks > 0 ? nchunks : 1, batch);
+        hipLaunchKernelGGL(potrf_panel_kernel, pgrid, dim3(256), 0, stream, A, n, k, nmain, nchunks, slab_stride, info);
+        const int n1 = nmain;
+        if (n1 > 0) {
+            const int nmain_tiles = n1 * (n1 + 1) / 2;
+            const int ntiles = nmain_tiles + nextra * n1;
+            hipLaunchKernelGGL(potrf_trail_kernel, dim3(ntiles, batch), dim3(64), 0, stream, A, n, k, nmain_tiles, n1,
+                               slab_stride);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Projection:  F = K_fu * L^{-T}  (conditionals_multi_output.py:240-242), K_fu generated on the fly.
+// One workgroup (8 wavefronts) = 64 rows of one (chain, latent dim) x one column group of <= 512 columns.
+// ---------------------------------------------------------------------------------------------
+constexpr int KC = 16;          // k-chunk (columns of K_fu produced per barrier)
+constexpr int KS_LD = STRIP + 16;   // LDS row stride of the K chunk: 80 doubles => lanes l and l+16 hit different bank halves
+
+template <int KIND>
+__global__ __launch_bounds__(512) void project_kernel(ProjectArgs a) {
+    __shared__ double Ks[2][KC][KS_LD];
+    __shared__ double xs[MAXP][STRIP];
+    __shared__ double xx[STRIP];
+    __shared__ double zs[2][KC][MAXP];
+    __shared__ double zzs[2][KC];
+    __shared__ double part[2][8][STRIP];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lk = lane >> 4;
+    const int t0 = blockIdx.x * STRIP;
+    const int g = blockIdx.y;
+    const int bz = blockIdx.z;                 // index inside this pass
+    const int b = a.b0 + bz;                   // global batch index
+    const int s = b / a.Dl, dl = b % a.Dl, dg = a.d_begin + dl;
+    const int P = a.P, Mp = a.Mp;
+    const double var = a.hv.variance[dl];
+    const double *Zsd = a.hv.Zs + (size_t)dl * Mp * P;
+    const double *zzd = a.hv.zz + (size_t)dl * Mp;
+    const double *Wd = a.W + (size_t)dl * a.w_stride;
+
+    // ---- x rows of this strip, divided by the lengthscales (kernels_multi_output.py:170) ----
+    for (int p = tid >> 6; p < P; p += 8) {
+        const int t = t0 + lane;
+        double v = 0.0;
+        if (t < a.T) {
+            v = (p < a.x_cols) ? a.x[(size_t)s * a.x_chain_stride + (size_t)t * a.x_ld + p]
+                               : a.ctrl[(size_t)t * a.C + (p - a.x_cols)];
+            if (KIND == 0) v = v / a.hv.len[(size_t)dl * P + p];
+            else v = v * var;                                    // kernels.py:276  (X * variance) @ X2^T
+        }
+        xs[p][lane] = v;
+    }
+    const int kend = (g + 1) * 512 < Mp ? (g + 1) * 512 : Mp;
+    const int nchunk = kend / KC;
+    auto load_z = [&](int c, int buf) {
+        if (tid < KC * P) {
+            const int kk = tid / P, p = tid % P;
+            zs[buf][kk][p] = Zsd[(size_t)(c * KC + kk) * P + p];
+        }
+        if (tid < KC) zzs[buf][tid] = zzd[c * KC + tid];
+    };
+    load_z(0, 0);
+    __syncthreads();
+    if (tid < STRIP) {
+        double acc = 0.0;
+        if (KIND == 0) for (int p = 0; p < P; ++p) acc += xs[p][tid] * xs[p][tid];
+        xx[tid] = acc;
+    }
+    __syncthreads();
+    auto gen = [&](int c, int buf) {
+        const int row = lane;
+#pragma unroll
+        for (int i = 0; i < KC / 8; ++i) {
+            const int kk = (tid >> 6) + 8 * i;
+            const int kcol = c * KC + kk;
+            double dot = 0.0;
+            for (int p = 0; p < P; ++p) dot += xs[p][row] * zs[buf][kk][p];
+            double v = kernel_value<KIND>(dot, xx[row], zzs[buf][kk], var);
+            if (t0 + row >= a.T || kcol >= a.M) v = 0.0;
+            Ks[buf][kk][row] = v;
+        }
+    };
+    gen(0, 0);
+    if (nchunk > 1) load_z(1, 1);
+    __syncthreads();
+
+    // ---- column tiles owned by this wavefront (snake order balances the triangular work) ----
+    int c0[4];
+    bool tv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int lt = r * 8 + ((r & 1) ? 7 - wave : wave);
+        c0[r] = (g * 32 + lt) * 16;
+        tv[r] = c0[r] < kend;
+    }
+    d4 acc[4][4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[rt][r] = (d4){0.0, 0.0, 0.0, 0.0};
+
+    for (int c = 0; c < nchunk; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunk) gen(c + 1, buf ^ 1);       // zs[buf^1] was loaded one iteration ago
+        if (c + 2 < nchunk) load_z(c + 2, buf);        // zs[buf] was consumed by gen(c) before the last barrier
+#pragma unroll
+        for (int ks = 0; ks < KC / 4; ++ks) {
+            const int kglob = c * KC + 4 * ks;
+            double af[4];
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) af[rt] = Ks[buf][4 * ks + lk][16 * rt + lr];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (tv[r] && kglob < c0[r] + 16) {   // L^{-T} is upper triangular: rows k > column are zero
+                    const double bf = Wd[(size_t)(kglob + lk) * Mp + c0[r] + lr];
+#pragma unroll
+                    for (int rt = 0; rt < 4; ++rt) acc[rt][r] = mfma_f64(af[rt], bf, acc[rt][r]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue ----
+    if (a.F) {
+        double *Fb = a.F + ((size_t)bz * a.Tp + t0) * Mp;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (!tv[r]) continue;
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    Fb[(size_t)(16 * rt + lk + 4 * q) * Mp + c0[r] + lr] = acc[rt][r][q];
+        }
+    }
+    if (a.rowsq || a.fmean) {
+        double uc[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int col = c0[r] + lr;
+            uc[r] = (a.fmean && tv[r] && col < a.M) ? a.U[(size_t)col * a.u_ld + dg] : 0.0;
+        }
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                double sq = 0.0, fm = 0.0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double v = tv[r] ? acc[rt][r][q] : 0.0;
+                    sq += v * v;
+                    fm += v * uc[r];
+                }
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) {
+                    sq += __shfl_xor(sq, m);
+                    fm += __shfl_xor(fm, m);
+                }
+                if (lr == 0) {
+                    part[0][wave][16 * rt + lk + 4 * q] = sq;
+                    part[1][wave][16 * rt + lk + 4 * q] = fm;
+                }
+            }
+        __syncthreads();
+        if (tid < STRIP) {
+            double sq = 0.0, fm = 0.0;
+            for (int w = 0; w < 8; ++w) { sq += part[0][w][tid]; fm += part[1][w][tid]; }
+            const size_t o = ((size_t)b * a.ng + g) * a.Tp + t0 + tid;
+            if (a.rowsq) a.rowsq[o] = sq;
+            if (a.fmean) a.fmean[o] = fm;
+        }
+    }
+}
+
+void launch_project(hipStream_t stream, const ProjectArgs &a) {
+    dim3 grid(a.Tp / STRIP, a.ng, a.nb);
+    if (a.kind == 0) hipLaunchKernelGGL(project_kernel<0>, grid, dim3(512), 0, stream, a);
+    else hipLaunchKernelGGL(project_kernel<1>, grid, dim3(512), 0, stream, a);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Gram:  H = F^T F * (Y_N / (batch Q_d)) + I,  extra row Mp = delta^T F * (Y_N / (batch Q_d))
+// (conditionals_multi_output.py:246-248).  Workgroup = 128x128 tile of the lower triangle, 4 wavefronts of 64x64.
+// ---------------------------------------------------------------------------------------------
+constexpr int GT = 16;              // rows of F per LDS chunk
+constexpr int G_LD = 128 + 16;      // LDS row stride (doubles)
+
+__global__ __launch_bounds__(256) void gram_kernel(GramArgs a, int n128, int ntiles) {
+    __shared__ double As[2][GT][G_LD];
+    __shared__ double Bs[2][GT][G_LD];
+    __shared__ double dls[2][GT];
+
+    // XCD-aware mapping: all tiles of one (chain, dim) share blockIdx % 8, i.e. one XCD's L2 (speed only)
+    const int id = blockIdx.x;
+    const int xcd = id & 7, loc = id >> 3;
+    const int bz = (loc / ntiles) * 8 + xcd;
+    if (bz >= a.nb) return;
+    int tile = loc % ntiles;
+    int ti = 0;
+    while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
+    const int tj = tile - ti * (ti + 1) / 2;
+    const bool diag = (ti == tj);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int lr = lane & 15, lk = lane >> 4;
+    const int Mp = a.Mp, Tp = a.Tp;
+    const int b = a.b0 + bz, s = b / a.Dl, dl = b % a.Dl, dg = a.d_begin + dl;
+    const int I0 = ti * 128 + wr * 64, J0 = tj * 128 + wc * 64;
+    const bool active = (I0 < Mp) && (J0 < Mp) && (J0 <= I0);
+
+    const double *Fb = a.F + (size_t)bz * Tp * Mp;
+    const double *Xs = a.X + (size_t)s * (a.T + 1) * a.D;
+    const int colA = ti * 128 + 2 * lane, colB = tj * 128 + 2 * lane;
+    const int rowl = tid >> 6;   // 0..3
+
+    double2 ra[4], rb[4];
+    double dreg = 0.0;
+    auto gload = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const size_t t = (size_t)c * GT + rowl + 4 * i;
+            ra[i] = (colA < Mp) ? *reinterpret_cast<const double2 *>(Fb + t * Mp + colA) : make_double2(0.0, 0.0);
+            if (!diag) rb[i] = (colB < Mp) ? *reinterpret_cast<const double2 *>(Fb + t * Mp + colB) : make_double2(0.0, 0.0);
+        }
+        if (diag && tid < GT) {
+            const int t = c * GT + tid;
+            dreg = (t < a.T) ? Xs[(size_t)(t + 1) * a.D + dg] - Xs[(size_t)t * a.D + dg] : 0.0;   // :247
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = rowl + 4 * i;
+            *reinterpret_cast<double2 *>(&As[buf][r][2 * lane]) = ra[i];
+            if (!diag) *reinterpret_cast<double2 *>(&Bs[buf][r][2 * lane]) = rb[i];
+        }
+        if (diag && tid < GT) dls[buf][tid] = dreg;
+    };
+
+    d4 acc[4][4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
+    double bsum = 0.0;
+
+    const int nchunk = Tp / GT;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunk) gload(c + 1);
+        if (active) {
+            const double(*Bp)[G_LD] = diag ? As[buf] : Bs[buf];
+#pragma unroll
+            for (int ks = 0; ks < GT / 4; ++ks) {
+                double af[4], bf[4];
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    af[x] = As[buf][4 * ks + lk][wr * 64 + 16 * x + lr];
+                    bf[x] = Bp[4 * ks + lk][wc * 64 + 16 * x + lr];
+                }
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+#pragma unroll
+                    for (int y = 0; y < 4; ++y) acc[x][y] = mfma_f64(af[x], bf[y], acc[x][y]);
+            }
+        }
+        if (diag && tid < 128) {
+#pragma unroll
+            for (int r = 0; r < GT; ++r) bsum += As[buf][r][tid] * dls[buf][r];
+        }
+        if (c + 1 < nchunk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    const double scale = a.yn_over_batch / exp(a.log_Q[dg]);
+    double *Hb = a.H + (size_t)bz * a.h_stride;
+    if (active) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int y = 0; y < 4; ++y)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = I0 + 16 * x + lk + 4 * q, j = J0 + 16 * y + lr;
+                    Hb[(size_t)i * Mp + j] = acc[x][y][q] * scale + ((i == j) ? 1.0 : 0.0);
+                }
+    }
+    if (diag && tid < 128) {
+        const int col = ti * 128 + tid;
+        if (col < Mp) Hb[(size_t)Mp * Mp + col] = bsum * scale;
+    }
+}
+
+void launch_gram(hipStream_t stream, const GramArgs &a) {
+    const int nwt = a.Mp / NB;
+    const int n128 = (nwt + 1) / 2;
+    const int ntiles = n128 * (n128 + 1) / 2;
+    const int groups = (a.nb + 7) / 8;
+    hipLaunchKernelGGL(gram_kernel, dim3(groups * 8 * ntiles), dim3(256), 0, stream, a, n128, ntiles);
+}
+
+// ---------------------------------------------------------------------------------------------
+// logdet(H) = 2 sum log diag(L_H)  (tf.linalg.logdet, :253);  b H^{-1} b^T = |L_H^{-1} b|^2 (:254)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void h_finish_kernel(const double *H, int Mp, size_t h_stride, double *hterms) {
+    __shared__ double scratch[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const double *Hb = H + (size_t)b * h_stride;
+    double ld = 0.0, qd = 0.0;
+    for (int i = tid; i < Mp; i += 256) {
+        ld += log(Hb[(size_t)i * Mp + i]);
+        const double y = Hb[(size_t)Mp * Mp + i];
+        qd += y * y;
+    }
+    ld = block_sum_256(ld, scratch);
+    qd = block_sum_256(qd, scratch);
+    if (tid == 0) { hterms[2 * b] = 2.0 * ld; hterms[2 * b + 1] = qd; }
+}
+void launch_h_finish(hipStream_t stream, const double *H, int Mp, size_t h_stride, int nb, double *hterms) {
+    hipLaunchKernelGGL(h_finish_kernel, dim3(nb), dim3(256), 0, stream, H, Mp, h_stride, hterms);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-chain streaming reductions (likelihoods.py:76-111; dgp_model.py:250-252,283-284,346-351)
+// chain_terms[s] = { lik quadratic sum, transition quadratic sum, trace sum, prior_x_0 }
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void chain_reduce_kernel(ReduceArgs a) {
+    __shared__ double scratch[256];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const int T = a.T, D = a.D;
+    const double *Xs = a.X + (size_t)s * (T + 1) * D;
+    double lik = 0.0, xq = 0.0, tr = 0.0;
+    for (int t = tid; t < T; t += 256) {
+        if (a.shared_terms) {
+            for (int j = 0; j < a.Ydim; ++j) {
+                double ym = 0.0;
+                for (int d = 0; d < D; ++d) ym += Xs[(size_t)(t + 1) * D + d] * a.CC[(size_t)d * a.Ydim + j];   // :76-79
+                ym += a.DD[j];
+                const double R = exp(a.log_Rchols[j]);          // Rchols[0] = first row (dgp_model.py:250)
+                const double r = (a.Y[(size_t)t * a.Ydim + j] - ym) / R;
+                lik += -0.5 * (r * r);
+            }
+        }
+        double xsq = 0.0;
+        if (a.kind == 1) {                                       // LinearK.Kdiag (kernels.py:278-281), per unit variance
+            const double *xr = a.xk + (size_t)s * a.xk_chain_stride + (size_t)t * a.xk_ld;
+            for (int p = 0; p < a.xk_cols; ++p) xsq += xr[p] * xr[p];
+            for (int p = 0; p < a.C; ++p) { double x = a.ctrl[(size_t)t * a.C + p]; xsq += x * x; }
+        }
+        for (int dl = 0; dl < a.Dl; ++dl) {
+            const int dg = a.d_begin + dl;
+            const double Q = exp(a.log_Q[dg]);
+            const double sq = sqrt(Q);                           // Q ** 0.5 (dgp_model.py:284,351)
+            const size_t bb = ((size_t)s * a.Dl + dl) * a.ng;
+            double rs = 0.0, fm = 0.0;
+            for (int g = 0; g < a.ng; ++g) {
+                rs += a.rowsq[(bb + g) * a.Tp + t];
+                if (a.branch == 0) fm += a.fmean[(bb + g) * a.Tp + t];
+            }
+            const double kdiag = (a.kind == 0) ? a.variance[dl] : xsq * a.variance[dl];
+            tr += -0.5 * ((kdiag - rs) / Q);                     // conditionals_multi_output.py:255 / dgp_model.py:348
+            const double x1 = Xs[(size_t)(t + 1) * D + dg], x0 = Xs[(size_t)t * D + dg];
+            double r;
+            if (a.branch == 1) r = (x1 - x0) / sq;               // dgp_model.py:283-284
+            else r = (x1 - (fm + x0)) / sq;                      // dgp_model.py:346,351
+            xq += -0.5 * (r * r);
+        }
+    }
+    lik = block_sum_256(lik, scratch);
+    xq = block_sum_256(xq, scratch);
+    tr = block_sum_256(tr, scratch);
+    if (tid == 0) {
+        double px0 = 0.0;
+        for (int d = 0; d < D; ++d) px0 += Xs[d] * Xs[d];
+        double *o = a.chain_terms + (size_t)s * 8;
+        o[0] = lik; o[1] = xq; o[2] = tr; o[3] = -px0 / 2.0;     // prior_x_0 dgp_model.py:252
+    }
+}
+void launch_chain_reduce(hipStream_t stream, const ReduceArgs &a) {
+    hipLaunchKernelGGL(chain_reduce_kernel, dim3(a.S), dim3(256), 0, stream, a);
+}
+
+// conditional() outputs (conditionals_multi_output.py:41,48,120): mean N x D, var N x D
+__global__ void conditional_finish_kernel(int kind, const double *x, int N, int P, const double *variance,
+                                          const double *rowsq, const double *fmean, int ng, int Tp, int D,
+                                          double *mean, double *var) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * D) return;
+    const int n = idx / D, d = idx % D;
+    double rs = 0.0, fm = 0.0;
+    for (int g = 0; g < ng; ++g) {
+        rs += rowsq[((size_t)d * ng + g) * Tp + n];
+        fm += fmean[((size_t)d * ng + g) * Tp + n];
+    }
+    double kd = variance[d];
+    if (kind == 1) {
+        double s = 0.0;
+        for (int p = 0; p < P; ++p) { double v = x[(size_t)n * P + p]; s += (v * v) * variance[d]; }
+        kd = s;
+    }
+    mean[idx] = fm;
+    var[idx] = kd - rs;
+}
+void launch_conditional_finish(hipStream_t stream, int kind, const double *x, int N, int P, const double *variance,
+                               const double *rowsq, const double *fmean, int ng, int Tp, int D, double *mean,
+                               double *var) {
+    if (N * D == 0) return;
+    hipLaunchKernelGGL(conditional_finish_kernel, dim3((N * D + 255) / 256), dim3(256), 0, stream, kind, x, N, P,
+                       variance, rowsq, fmean, ng, Tp, D, mean, var);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Priors + nll assembly (dgp_model.py:105-143, 259-297, 326-334)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
+    __shared__ double scratch[256];
+    __shared__ double sh[8];
+    const int tid = threadIdx.x;
+    const double Tn = (double)a.T;      // batch_size == Y_N == T for the full batch (dgp_model.py:261-262)
+    // shared priors
+    double zsum = 0.0, usum = 0.0;
+    if (a.shared_terms && a.prior_type == 1)
+        for (int i = tid; i < a.M * a.P; i += 256) zsum += a.Z[i] * a.Z[i];
+    if (a.branch == 0)
+        for (int i = tid; i < a.M * a.Dl; i += 256) {
+            const int m = i / a.Dl, dl = i % a.Dl;
+            const double u = a.U[(size_t)m * a.D + a.d_begin + dl];
+            usum += u * u;
+        }
+    zsum = block_sum_256(zsum, scratch);
+    usum = block_sum_256(usum, scratch);
+    if (tid == 0) {
+        double prior_hyper = 0.0;       // Layer.prior_hyper dgp_model.py:123-130 over the local dims
+        for (int dl = 0; dl < a.Dl; ++dl) {
+            const int dg = a.d_begin + dl;
+            if (a.kind == 0) {
+                double l2 = 0.0;
+                for (int p = 0; p < a.P; ++p) { double l = a.loglen[(size_t)dg * a.P + p]; l2 += l * l; }
+                prior_hyper += -l2 / 2.0;
+            }
+            const double dv = a.logvar[dg] - log(0.05);
+            prior_hyper += -(dv * dv) / 2.0;
+        }
+        double hyp = 0.0;               // hypaparameter_prior dgp_model.py:326-334
+        if (a.shared_terms) {
+            double q2 = 0.0, c2 = 0.0, d2 = 0.0, r2 = 0.0;
+            for (int d = 0; d < a.D; ++d) q2 += a.log_Q[d] * a.log_Q[d];
+            for (int i = 0; i < a.D * a.Ydim; ++i) c2 += a.CC[i] * a.CC[i];
+            for (int j = 0; j < a.Ydim; ++j) d2 += a.DD[j] * a.DD[j];
+            for (int i = 0; i < a.Ydim * a.Ydim; ++i) r2 += a.log_Rchols[i] * a.log_Rchols[i];
+            hyp = -q2 / 2.0 - c2 / 2.0 - d2 / 2.0 - r2 / 2.0;
+        }
+        double logR = 0.0;              // -reduce_sum(log(Rchols)) likelihoods.py:101
+        for (int j = 0; j < a.Ydim; ++j) logR += log(exp(a.log_Rchols[j]));
+        double logsqQ = 0.0;            // -sum_d log(Q_d ** 0.5) likelihoods.py:91 / :101
+        for (int dl = 0; dl < a.Dl; ++dl) logsqQ += log(sqrt(exp(a.log_Q[a.d_begin + dl])));
+        sh[0] = prior_hyper;
+        sh[1] = hyp;
+        sh[2] = (a.shared_terms && a.prior_type == 1) ? -zsum / 2.0 : 0.0;   // prior_Z dgp_model.py:108-109
+        sh[3] = (a.branch == 0) ? -0.5 * usum : 0.0;                          // prior_U dgp_model.py:134-135
+        sh[4] = logR;
+        sh[5] = logsqQ;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double sums[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int s = 0; s < a.S; ++s) {
+            const double *ct = a.chain_terms + (size_t)s * 8;
+            double terms[7] = {0, 0, 0, 0, 0, 0, 0};
+            double prior = sh[0] + sh[3];
+            if (a.shared_terms) {
+                prior += sh[2] + ct[3] + sh[1];
+                terms[1] = -(ct[0] + Tn * (-sh[4])) / Tn;                  // nll_log_likelihood :264
+            }
+            terms[0] = -prior / Tn;                                          // nll_part_prior :286 / :296
+            terms[2] = -(ct[1] + Tn * (-sh[5])) / Tn;                      // x_t_prior_Q :283-284 / :294
+            terms[3] = -ct[2] / Tn;                                          // trace term :257 / :292
+            if (a.branch == 1) {
+                double term1 = 0.0, term2 = 0.0;
+                for (int dl = 0; dl < a.Dl; ++dl) {
+                    const double *ht = a.hterms + ((size_t)s * a.Dl + dl) * 2;
+                    term1 += -0.5 * ht[0];                                   // :253
+                    term2 += 0.5 * ht[1];                                    // :254
+                }
+                terms[4] = -term1 / Tn;                                      // :257
+                terms[5] = -term2 / Tn;
+            }
+            terms[6] = terms[0] + terms[1] + terms[2] + terms[3] + terms[4] + terms[5];   // :288 / :297
+            a.chain_nll[s] = terms[6];
+            for (int i = 0; i < 7; ++i) sums[i] += terms[i];
+        }
+        sums[7] = a.shared_terms ? (double)a.S : 0.0;
+        for (int i = 0; i < 8; ++i) a.out_terms[i] = sums[i];
+    }
+}
+void launch_finalize(hipStream_t stream, const FinalizeArgs &a) {
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, stream, a);
+}
+
+}  // namespace ffvd

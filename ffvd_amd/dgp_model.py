@@ -1,0 +1,114 @@
+"""DGPSSM: the model object whose `nll` is the hot path -- counterpart of vfegpssm/dgp_model.py:160-324.
+
+The reference builds a TensorFlow graph whose root tensor is `self.nll` and evaluates it with
+`session.run` (base_model.py:952-989).  Here the same quantities are methods backed by one ElboEngine
+(hand-written HIP kernels behind the C ABI); parameters live in NumPy arrays on the object with the
+reference's attribute names (layers[-1].X / .U / .Z, kernels, log_Q, likelihood.CC / .DD / .log_Rchols).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .engine import ElboEngine
+from .kernels import stack_hypers
+
+
+class Layer:
+    """Layer.__init__ (dgp_model.py:46-94): variables X (T+1, D), U (M, D), Z (M, P) and the kernel list."""
+
+    def __init__(self, ZZ, U_ini, X_0_ini, X_train_ini, kern, outputs, n_inducing, x_dims_l, Y_len,
+                 prior_type="uniform", kernel_type="SquaredExponential"):
+        self.inputs, self.outputs, self.kernel, self.kernel_type = kern[0].input_dim, outputs, kern, kernel_type
+        self.M = n_inducing
+        self.prior_type = prior_type
+        X_ini_val = np.zeros((Y_len + 1, x_dims_l))            # dgp_model.py:56
+        X_ini_val[0] = X_0_ini                                 # :57
+        X_ini_val[1:] = X_train_ini                            # :58
+        self.X = X_ini_val
+        self.U = np.array(U_ini, dtype=np.float64)             # :66
+        self.Z = np.array(ZZ, dtype=np.float64)                # :67
+
+
+class DGPSSM:
+    """One-layer GP state-space model; `nll()` / `nll_terms()` evaluate dgp_model.py:248-297 on the GPU.
+
+    Constructor arguments keep the reference's names (dgp_model.py:160-166).  `num_chains` > 1 evaluates
+    S latent trajectories X_s in one call (`set_X`), which is what BASELINE.json's metric measures."""
+
+    def __init__(self, Y, x_dims, n_inducing, kernels, likelihood, minibatch_size=None, window_size=64,
+                 output_dim=None, prior_type="uniform", full_cov=False, epsilon=0.01, mdecay=0.05, QQ_chol=None,
+                 ZZ=None, variance=None, lengthscales=None, control_inputs=None, kernel_type="SquaredExponential",
+                 kernel_train_flag=True, U_ini=None, X_0_ini=None, X_train_ini=None, X_PG=False, PG_particles=100,
+                 hyperparameter_sampling=False, kernel_optimization=False, U_optimization=False, U_collapse=False,
+                 Z_optimization=False, case_val=1, num_chains=1, device=0, **engine_kw):
+        if full_cov:
+            raise NotImplementedError("full_cov=True is not used by the GP-SSM path (FFVD_Main.py:266)")
+        if len(kernels) != 1:
+            raise NotImplementedError("n_layers != 1 (FFVD_Main.py:360 default 1; the nll uses layers[-1] only)")
+        Y = np.asarray(Y, dtype=np.float64)
+        if Y.ndim == 1:
+            Y = Y[:, None]                                      # models.py:44-45
+        self.Y = Y
+        self.x_dims, self.n_inducing, self.kernels, self.likelihood = x_dims, n_inducing, kernels, likelihood
+        self.minibatch_size, self.window_size = minibatch_size, window_size
+        self.output_dim = output_dim or x_dims[-1]
+        self.kernel_type, self.U_collapse, self.case_val = kernel_type, bool(U_collapse), case_val
+        self.prior_type = prior_type
+        self.log_Q = np.array(2.0 * np.log(np.asarray(QQ_chol, dtype=np.float64)))     # dgp_model.py:182
+        kern = kernels[-1]
+        D = self.output_dim
+        if len(kern) != D:
+            raise ValueError(f"expected one kernel per latent dim ({D}), got {len(kern)}")
+        self.layers = [Layer(ZZ, U_ini, X_0_ini, X_train_ini, kern, D, n_inducing, x_dims[-1], Y.shape[0],
+                             prior_type=prior_type, kernel_type=kernel_type)]
+        self.X_N = self.layers[-1].X.shape[0]
+        T = self.X_N - 1
+        if control_inputs is None or np.asarray(control_inputs).shape[0] == 0:
+            self.control_inputs = np.zeros((T, 0))
+        else:
+            self.control_inputs = np.asarray(control_inputs, dtype=np.float64)
+        C = self.control_inputs.shape[1]
+        self.num_chains = int(num_chains)
+        self._X_chains = np.repeat(self.layers[-1].X[None], self.num_chains, axis=0)
+        self.engine = ElboEngine(T, D, C, n_inducing, self.num_chains, Ydim=Y.shape[1], kernel_type=kernel_type,
+                                 U_collapse=self.U_collapse, prior_type=prior_type, device=device, **engine_kw)
+        self.engine.set_data(Y, self.control_inputs)
+        self._last = None
+
+    @property
+    def Q(self):
+        return np.exp(self.log_Q)                               # dgp_model.py:186
+
+    def set_X(self, X_chains):
+        """Latent trajectories to evaluate: (S, T+1, D) (or (T+1, D) for one chain)."""
+        X = np.asarray(X_chains, dtype=np.float64)
+        if X.ndim == 2:
+            X = X[None]
+        if X.shape != self._X_chains.shape:
+            raise ValueError(f"X: expected {self._X_chains.shape}, got {X.shape}")
+        self._X_chains = X
+        self.layers[-1].X = X[0]
+
+    def parameters(self):
+        """The parameter dictionary the engine consumes, gathered from the reference-named attributes."""
+        lay = self.layers[-1]
+        _, _, logvar, loglen = stack_hypers(lay.kernel)
+        return dict(X=self._X_chains, Z=lay.Z, U=lay.U, logvariance=logvar, loglengthscales=loglen,
+                    log_Q=self.log_Q, CC=self.likelihood.CC, DD=self.likelihood.DD,
+                    log_Rchols=self.likelihood.log_Rchols)
+
+    def nll_terms(self):
+        """nll and the named component tensors of dgp_model.py:264-297 (mean over chains)."""
+        self._last = self.engine.nll_terms(self.parameters())
+        return self._last
+
+    def nll(self):
+        return self.nll_terms()["nll"]
+
+    def print_sample_performance(self):
+        """Counterpart of BaseModel.print_sample_performance (base_model.py:952-989): the component breakdown."""
+        t = self.nll_terms()
+        for k, v in t.items():
+            if k != "nll_per_chain":
+                print(f"{k}: {v}")
+        return t

@@ -1,0 +1,172 @@
+"""ElboEngine: thin Python owner of one `ffvd_handle` (one GPU, one HIP stream, resident buffers).
+
+This is plumbing over include/ffvd_abi.h: every number it returns is computed by the HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes as ct
+
+import numpy as np
+
+from . import _lib
+
+PARAM_KEYS = ("X", "Z", "U", "logvariance", "loglengthscales", "log_Q", "CC", "DD", "log_Rchols")
+
+
+class ElboEngine:
+    """Evaluates `DGPSSM.nll` (dgp_model.py:248-297) for S latent trajectories on one MI355X.
+
+    Shapes follow SURVEY.md: X (S, T+1, D); Z (M, D+C); U (M, D); logvariance (D,);
+    loglengthscales (D, D+C); log_Q (D,); CC (D, Ydim); DD (Ydim,); log_Rchols (Ydim, Ydim).
+    """
+
+    def __init__(self, T, D, C, M, S, Ydim=1, kernel_type="SquaredExponential", U_collapse=True,
+                 prior_type="normal", device=0, d_begin=0, d_count=0, shared_terms=True,
+                 chains_per_pass=0, jitter=1e-5):
+        if kernel_type not in _lib.KERNEL_KIND:
+            raise ValueError("Invalid kernel type")
+        if prior_type not in _lib.PRIOR_TYPE:
+            raise ValueError("Invalid prior type")           # models.py:41
+        self.lib = _lib.load()
+        self.T, self.D, self.C, self.M, self.S, self.Ydim = int(T), int(D), int(C), int(M), int(S), int(Ydim)
+        self.P = self.D + self.C
+        self.kernel_type, self.U_collapse = kernel_type, bool(U_collapse)
+        self.d_begin, self.d_count = int(d_begin), int(d_count) or int(D)
+        self.shared_terms = bool(shared_terms)
+        cfg = _lib.FfvdConfig(
+            T=self.T, D=self.D, C=self.C, M=self.M, S_local=self.S, Ydim=self.Ydim, d_begin=self.d_begin,
+            d_count=self.d_count, shared_terms=int(self.shared_terms), dtype=0,
+            kernel_kind=_lib.KERNEL_KIND[kernel_type], branch=_lib.BRANCH_B if U_collapse else _lib.BRANCH_A,
+            prior_type=_lib.PRIOR_TYPE[prior_type], device_id=int(device), chains_per_pass=int(chains_per_pass),
+            reserved=0, jitter=float(jitter))
+        self._h = ct.c_void_p()
+        _lib.check(self.lib.ffvd_create(ct.byref(cfg), ct.byref(self._h)), None, "ffvd_create")
+        self._keep = {}
+
+    # -- lifetime ---------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.ffvd_destroy(self._h)
+            self._h = ct.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def workspace_bytes(self):
+        return int(self.lib.ffvd_workspace_bytes(self._h))
+
+    # -- inputs -----------------------------------------------------------------------------
+    def set_data(self, Y, control_inputs):
+        """Y: (T, Ydim); control_inputs: (>=T, C), the first T rows are used (dgp_model.py:255)."""
+        Y = _lib.as_f64(Y, (self.T, self.Ydim), "Y")
+        if self.C > 0:
+            c = np.asarray(control_inputs, dtype=np.float64)
+            if c.ndim != 2 or c.shape[1] != self.C or c.shape[0] < self.T:
+                raise ValueError(f"control_inputs: expected (>= {self.T}, {self.C}), got {c.shape}")
+            c = np.ascontiguousarray(c[: self.T])
+            cp = c.ctypes.data
+        else:
+            c, cp = None, None
+        _lib.check(self.lib.ffvd_set_data(self._h, Y.ctypes.data, cp, 0), self._h, "ffvd_set_data")
+
+    def _pack(self, params):
+        X = np.asarray(params["X"], dtype=np.float64)
+        if X.ndim == 2:
+            X = X[None]
+        arrs = {
+            "X": _lib.as_f64(X, (self.S, self.T + 1, self.D), "X"),
+            "Z": _lib.as_f64(params["Z"], (self.M, self.P), "Z"),
+            "logvariance": _lib.as_f64(params["logvariance"], (self.D,), "logvariance"),
+            "log_Q": _lib.as_f64(params["log_Q"], (self.D,), "log_Q"),
+            "CC": _lib.as_f64(params["CC"], (self.D, self.Ydim), "CC"),
+            "DD": _lib.as_f64(params["DD"], (self.Ydim,), "DD"),
+            "log_Rchols": _lib.as_f64(params["log_Rchols"], (self.Ydim, self.Ydim), "log_Rchols"),
+        }
+        if params.get("U") is not None:
+            arrs["U"] = _lib.as_f64(params["U"], (self.M, self.D), "U")
+        elif not self.U_collapse:
+            raise ValueError("U is required in the explicit-U branch")
+        if self.kernel_type == "SquaredExponential":
+            arrs["loglengthscales"] = _lib.as_f64(params["loglengthscales"], (self.D, self.P), "loglengthscales")
+        p = _lib.FfvdParams()
+        for k in PARAM_KEYS:
+            setattr(p, k, arrs[k].ctypes.data if k in arrs else None)
+        return p, arrs
+
+    def set_params(self, params):
+        """Upload the parameters into the handle's resident device buffers."""
+        p, arrs = self._pack(params)
+        _lib.check(self.lib.ffvd_set_params(self._h, ct.byref(p), 0), self._h, "ffvd_set_params")
+
+    # -- the hot path -------------------------------------------------------------------------
+    def elbo_sums(self, params=None):
+        """One ELBO iteration.  Returns the 8-vector of ffvd_abi.h: sums over local chains + chain count."""
+        out = np.zeros(8)
+        nll = ct.c_double()
+        if params is not None:
+            p, arrs = self._pack(params)
+            rc = self.lib.ffvd_elbo(self._h, ct.byref(p), 0, _lib.dptr(out), ct.byref(nll))
+        else:
+            rc = self.lib.ffvd_elbo(self._h, None, 0, _lib.dptr(out), ct.byref(nll))
+        _lib.check(rc, self._h, "ffvd_elbo")
+        return out
+
+    def nll_terms(self, params=None):
+        """Mean over the local chains of nll and its named component terms (reference names)."""
+        sums = self.elbo_sums(params)
+        names = _lib.TERM_NAMES if self.U_collapse else _lib.TERM_NAMES[:4] + ("nll",)
+        idx = {n: i for i, n in enumerate(_lib.TERM_NAMES)}
+        out = {n: float(sums[idx[n]] / self.S) for n in names}
+        out["nll_per_chain"] = self.chain_nll()
+        return out
+
+    def nll(self, params=None):
+        return self.nll_terms(params)["nll"]
+
+    def chain_nll(self):
+        out = np.zeros(self.S)
+        _lib.check(self.lib.ffvd_chain_nll(self._h, _lib.dptr(out)), self._h, "ffvd_chain_nll")
+        return out
+
+    def elbo_async(self, out_dev_ptr=None):
+        """Enqueue one iteration; the 8 partial sums land in device memory `out_dev_ptr` (int address)."""
+        _lib.check(self.lib.ffvd_elbo_async(self._h, out_dev_ptr), self._h, "ffvd_elbo_async")
+
+    def sync(self):
+        _lib.check(self.lib.ffvd_sync(self._h), self._h, "ffvd_sync")
+
+    def time_elbo(self, iters):
+        """Total milliseconds (HIP events on the handle's stream) of `iters` back-to-back iterations."""
+        ms = ct.c_float()
+        _lib.check(self.lib.ffvd_time_elbo(self._h, int(iters), ct.byref(ms)), self._h, "ffvd_time_elbo")
+        return float(ms.value)
+
+    STAGES = ("kuu_chol_inverse", "project_F", "gram_H", "chol_H_solve", "reduce_finalize")
+
+    def stage_timing(self, enable=True):
+        """Record HIP events around every stage of subsequent iterations (live, on the handle's stream)."""
+        _lib.check(self.lib.ffvd_stage_timing(self._h, int(bool(enable))), self._h, "ffvd_stage_timing")
+
+    def stage_times(self):
+        """{stage: (total ms, timed launch groups)} accumulated since the last read."""
+        ms = np.zeros(8)
+        n = np.zeros(8, dtype=np.int32)
+        _lib.check(self.lib.ffvd_stage_times(self._h, _lib.dptr(ms), n.ctypes.data_as(ct.POINTER(ct.c_int32))),
+                   self._h, "ffvd_stage_times")
+        return {name: (float(ms[i]), int(n[i])) for i, name in enumerate(self.STAGES)}
+
+    def profile_stages(self):
+        ms = (ct.c_float * 8)()
+        _lib.check(self.lib.ffvd_profile_stages(self._h, ms), self._h, "ffvd_profile_stages")
+        names = ("kuu_chol_inverse", "project_F", "gram_H", "chol_H_solve", "reduce_finalize")
+        return {n: float(ms[i]) for i, n in enumerate(names)}

@@ -1,0 +1,82 @@
+"""Model / RegressionModel facade -- counterpart of vfegpssm/models.py (driver-facing surface).
+
+`RegressionModel(prior_type)` exposes the class-attribute bag `ARGS` that FFVD_Main.py:236-340 fills and a
+`fit(Y_train, ...)` that builds the kernels (models.py:57-62), the Gaussian likelihood (models.py:320) and the
+DGPSSM (models.py:66-74).  The optimiser / sampler loop of models.py:142-182 is the next scope row
+(SURVEY 8f-1/2); `fit` therefore constructs the model and records the initial nll, which is what every
+iteration of that loop evaluates.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .dgp_model import DGPSSM
+from .kernels import LinearK, SquaredExponential
+from .likelihoods import Gaussian
+
+
+class Model:
+    def __init__(self, prior_type, output_dim=None):
+        class ARGS:                                  # models.py:21-32
+            num_inducing = 100
+            iterations = 10000
+            minibatch_size = 10000
+            window_size = 64
+            num_posterior_samples = 100
+            posterior_sample_spacing = 50
+            full_cov = False
+            n_layers = 1
+            prior_type = None
+        ARGS.prior_type = prior_type
+        self.ARGS = ARGS
+        self.model = None
+        self.output_dim = output_dim
+        if prior_type not in ("determinantal", "normal", "strauss", "uniform"):
+            raise Exception("Invalid prior type")    # models.py:35-41
+
+    def _fit(self, Y_train, lik, kernel_type, kernel_train_flag, **kwargs):
+        Y_train = np.asarray(Y_train, dtype=np.float64)
+        if Y_train.ndim == 1:
+            Y_train = Y_train[:, None]
+        A = self.ARGS
+        if not self.model:
+            control = np.asarray(A.control_inputs, dtype=np.float64)
+            D = A.x_dims[-1]
+            Z_dim = control.shape[1] + D                                        # models.py:51
+            if kernel_type == "SquaredExponential":
+                kern = [SquaredExponential(Z_dim, ARD=True, variance=A.variance[kk], lengthscales=A.lengthscales[kk],
+                                           kernel_optimization=A.kernel_optimization) for kk in range(D)]   # :57-59
+            elif kernel_type == "LinearK":
+                # the reference appends ONE LinearK object, which cannot run;
+                # here: D LinearK kernels with variance[kk] each through the list path.
+                var = np.broadcast_to(np.asarray(1.0 if A.variance is None else A.variance, dtype=np.float64), (D,))
+                kern = [LinearK(Z_dim, ARD=False, variance=float(var[kk])) for kk in range(D)]
+            else:
+                raise ValueError("Invalid kernel type")
+            self.model = DGPSSM(Y_train, A.x_dims, A.num_inducing, [kern], lik, minibatch_size=A.minibatch_size,
+                                window_size=A.window_size, full_cov=A.full_cov, prior_type=A.prior_type,
+                                output_dim=self.output_dim, QQ_chol=A.QQ_chol, ZZ=A.ZZ, variance=A.variance,
+                                lengthscales=A.lengthscales, control_inputs=control, kernel_type=kernel_type,
+                                kernel_train_flag=kernel_train_flag, U_ini=A.UU_ini, X_0_ini=A.XX_0_ini,
+                                X_train_ini=A.x_initialization, X_PG=getattr(A, "X_PG", False),
+                                U_collapse=A.U_collapse, case_val=getattr(A, "case_val", 4), **kwargs)
+        self.nll_seq, self.rmse_seq, self.ll_seq, self.running_time_seq = [], [], [], []   # models.py:89-92
+        self.nll_seq.append(self.model.nll())
+        return self
+
+
+class RegressionModel(Model):
+    def __init__(self, prior_type, output_dim=None):
+        super().__init__(prior_type, output_dim)
+
+    def fit(self, Y_train, Y_test=None, tensorboard_savepath="", dataname="", fileid="",
+            kernel_type="SquaredExponential", kernel_train_flag=True, likelihood_traning=True, X_train=None,
+            X_test=None, Ystd=None, data_uu=None, epsilon=0.01, **kwargs):
+        Y_train = np.asarray(Y_train, dtype=np.float64)
+        if Y_train.ndim == 1:
+            Y_train = Y_train[:, None]
+        A = self.ARGS
+        lik = Gaussian(Y_train.shape[1], A.x_dims[-1], CC=A.CC, DD=A.DD, RR_chol=A.RR_chol,
+                       hyperparameter_sampling=getattr(A, "hyperparameter_sampling", False),
+                       likelihood_traning=likelihood_traning)                     # models.py:320
+        return self._fit(Y_train, lik, kernel_type, kernel_train_flag, **kwargs)

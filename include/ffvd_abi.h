@@ -1,0 +1,165 @@
+/*
+ * ffvd_abi.h -- C ABI of the MI355X-native FFVD ELBO engine (libffvd_hip.so).
+ *
+ * The reference (xuhuifan/FFVD) has no FFI: its "model/ELBO callable" is the
+ * TensorFlow tensor `DGPSSM.nll` (vfegpssm/dgp_model.py:248-297) evaluated by
+ * `session.run` (vfegpssm/base_model.py:952-989).  This header is the boundary
+ * a maintainer binds instead (ctypes stub in INTEGRATION.md): plain pointers
+ * and sizes, row-major contiguous fp64 arrays, no torch / numpy types.
+ *
+ * Conventions
+ *   - status: 0 = OK, <0 usage/runtime error, >0 numerical error (FFVD_ENOTPD);
+ *     the message is retrievable with ffvd_last_error(); nothing aborts or throws.
+ *   - a handle = one device + one HIP stream + all device workspace (allocated in
+ *     ffvd_create, nothing is allocated on the hot path).  Not thread-safe;
+ *     distinct handles are independent.
+ *   - pointer arguments are HOST pointers unless the call has an `on_device`
+ *     flag / FFVD_PARAMS_ON_DEVICE, in which case they are device pointers used
+ *     in place (zero copy).  Caller owns every buffer it passes in.
+ *   - calls that write host outputs synchronise the handle's stream; the
+ *     `_async` forms only enqueue.
+ */
+#ifndef FFVD_ABI_H
+#define FFVD_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FFVD_OK        0
+#define FFVD_EINVAL   (-1)   /* bad shape / null pointer / unsupported option */
+#define FFVD_ENOMEM   (-2)   /* device or host allocation failed */
+#define FFVD_EDEVICE  (-3)   /* HIP runtime error (message in ffvd_last_error) */
+#define FFVD_ENOTPD     1    /* Cholesky met a non-positive pivot (which matrix/pivot: ffvd_last_error) */
+
+#define FFVD_F64 0
+
+#define FFVD_KERNEL_SE      0   /* kernels_multi_output.py:140-247 SquaredExponential (ARD) */
+#define FFVD_KERNEL_LINEAR  1   /* kernels.py:250-281 LinearK, one scalar variance per latent dim */
+
+#define FFVD_BRANCH_A 0   /* explicit U:  dgp_model.py:289-297 (regularizer :337-359, conditional) */
+#define FFVD_BRANCH_B 1   /* collapsed U: dgp_model.py:267-288 (kernel_pre_cal + collapse_after_kernel_precalculation) */
+
+#define FFVD_PRIOR_UNIFORM 0    /* Layer.prior_Z dgp_model.py:106-107 */
+#define FFVD_PRIOR_NORMAL  1    /* dgp_model.py:108-109 */
+
+#define FFVD_PARAMS_ON_DEVICE 1u
+
+/* indices into the 8-double term vector written by ffvd_elbo*()               */
+#define FFVD_TERM_PART_PRIOR   0   /* nll_part_prior            dgp_model.py:286/296 */
+#define FFVD_TERM_LOG_LIK      1   /* nll_log_likelihood        dgp_model.py:264     */
+#define FFVD_TERM_X_PRIOR_Q    2   /* x_t_prior_Q               dgp_model.py:283/294 */
+#define FFVD_TERM_TRACE        3   /* nll_reg_trace_inverse_Q_B dgp_model.py:275/292 */
+#define FFVD_TERM_LATER1       4   /* later_term1 (branch B)    dgp_model.py:275     */
+#define FFVD_TERM_LATER2       5   /* later_term2 (branch B)    dgp_model.py:275     */
+#define FFVD_TERM_NLL          6   /* nll                       dgp_model.py:288/297 */
+#define FFVD_TERM_COUNT        7   /* number of chains the sums cover (for the mean after an all-reduce) */
+
+typedef struct ffvd_handle ffvd_handle;
+
+typedef struct ffvd_config {
+    int32_t T;            /* transitions = len(Y_train); X has T+1 rows            */
+    int32_t D;            /* latent dim x_dims[-1] (columns of X)                  */
+    int32_t C;            /* control-input dim; GP input dim P = D + C (models.py:51) */
+    int32_t M;            /* inducing points                                        */
+    int32_t S_local;      /* latent trajectories (posterior samples/chains) this handle evaluates */
+    int32_t Ydim;         /* observation dim                                        */
+    int32_t d_begin;      /* first latent dim this handle evaluates (shard D: BASELINE config 5) */
+    int32_t d_count;      /* number of latent dims evaluated; 0 = all D             */
+    int32_t shared_terms; /* 1: also add the terms not tied to a latent dim (likelihood, prior_Z, prior_x_0, hyper prior) */
+    int32_t dtype;        /* FFVD_F64                                               */
+    int32_t kernel_kind;  /* FFVD_KERNEL_*                                          */
+    int32_t branch;       /* FFVD_BRANCH_*                                          */
+    int32_t prior_type;   /* FFVD_PRIOR_*                                           */
+    int32_t device_id;    /* HIP device ordinal                                     */
+    int32_t chains_per_pass; /* chains whose T x M projections are resident at once; 0 = auto */
+    int32_t reserved;
+    double  jitter;       /* 1e-5: conditionals_multi_output.py:108,159             */
+} ffvd_config;
+
+/* All arrays fp64, row-major, contiguous. */
+typedef struct ffvd_params {
+    const double *X;               /* S_local x (T+1) x D   Layer.X        dgp_model.py:56-64 */
+    const double *Z;               /* M x P                 Layer.Z        dgp_model.py:67    */
+    const double *U;               /* M x D (branch A; NULL allowed in B)  dgp_model.py:66    */
+    const double *logvariance;     /* D                     kernels_multi_output.py:156       */
+    const double *loglengthscales; /* D x P (SE; NULL for LINEAR)  kernels_multi_output.py:160 */
+    const double *log_Q;           /* D                     dgp_model.py:182                  */
+    const double *CC;              /* D x Ydim              likelihoods.py:19                 */
+    const double *DD;              /* Ydim                  likelihoods.py:23                 */
+    const double *log_Rchols;      /* Ydim x Ydim           likelihoods.py:54                 */
+} ffvd_params;
+
+/* ---- lifetime ----------------------------------------------------------- */
+int  ffvd_create(const ffvd_config *cfg, ffvd_handle **out);
+int  ffvd_destroy(ffvd_handle *h);
+/* message of the most recent failure on `h` (or of the last failed ffvd_create / handle-less op when h == NULL) */
+const char *ffvd_last_error(const ffvd_handle *h);
+int  ffvd_sync(ffvd_handle *h);
+/* bytes of device workspace owned by the handle */
+int64_t ffvd_workspace_bytes(const ffvd_handle *h);
+
+/* ---- data and parameters (resident copies owned by the handle) ------------ */
+/* Y: T x Ydim observations (base_model.py:14); control_inputs: at least T x C rows, the first T are used (dgp_model.py:255). */
+int  ffvd_set_data(ffvd_handle *h, const double *Y, const double *control_inputs, int on_device);
+int  ffvd_set_params(ffvd_handle *h, const ffvd_params *p, int on_device);
+
+/* ---- the hot path ---------------------------------------------------------- */
+/*
+ * One ELBO iteration = DGPSSM.nll and its component tensors (dgp_model.py:248-297) for the
+ * S_local trajectories of this handle.  p == NULL: use the resident parameters.  Otherwise p is
+ * uploaded first (host pointers) or used in place (flags & FFVD_PARAMS_ON_DEVICE).
+ * out_terms[0..6] = SUMS over the local chains of the per-chain terms, out_terms[7] = chain count
+ * (so that an all-reduce(sum) over ranks followed by a division yields the mean);
+ * out_nll = out_terms[6] / out_terms[7] (mean nll over the local chains).
+ */
+int  ffvd_elbo(ffvd_handle *h, const ffvd_params *p, uint32_t flags, double out_terms[8], double *out_nll);
+/* enqueue only; the 8 doubles are written to device memory `out_terms_dev` (e.g. the buffer a
+ * collective library all-reduces).  ffvd_sync() or a later synchronous call reports numerical errors. */
+int  ffvd_elbo_async(ffvd_handle *h, double *out_terms_dev);
+/* after a synchronous ffvd_elbo: per-chain nll values (S_local doubles, host) */
+int  ffvd_chain_nll(ffvd_handle *h, double *out_nll_per_chain);
+/* timing helper for benchmarks: run `iters` back-to-back ffvd_elbo_async on the resident inputs,
+ * bracketed by HIP events on the handle's stream; returns total milliseconds. */
+int  ffvd_time_elbo(ffvd_handle *h, int iters, float *out_ms);
+/* HIP-event timing of each stage of one iteration (ms): [0] K_uu build+Cholesky+inverse,
+ * [1] K_fu projection (F = K_fu L^-T), [2] Gram H = F^T F, [3] Cholesky(H)+solve, [4] reductions. */
+int  ffvd_profile_stages(ffvd_handle *h, float out_ms[8]);
+/* live stage timing: while enabled, every ffvd_elbo* records HIP events on the handle's stream around the
+ * stages above; ffvd_stage_times() synchronises, returns the accumulated milliseconds and the number of timed
+ * intervals (= kernel-launch groups) per stage since the last read, and resets the accumulators. */
+int  ffvd_stage_timing(ffvd_handle *h, int enable);
+int  ffvd_stage_times(ffvd_handle *h, double out_ms[8], int32_t out_launches[8]);
+
+/* ---- operator-level entry points (host pointers in/out; they allocate temporaries) ----------
+ * These mirror the reference's pure functions so that parity tests read like calls of the reference. */
+
+/* kernel.K(X, X2) / kernel.K(X) (X2 == NULL) for ONE kernel: kernels_multi_output.py:202-214, kernels.py:270-276.
+ * jitter is added to the diagonal when X2 == NULL. out: N x N2. */
+int  ffvd_op_kernel_matrix(int kind, const double *X, int N, const double *X2, int N2, int P,
+                           double logvariance, const double *loglengthscales, double jitter, double *out);
+/* kernel.Kdiag(X): kernels_multi_output.py:199-200, kernels.py:278-281. out: N. */
+int  ffvd_op_kernel_diag(int kind, const double *X, int N, int P, double logvariance, double *out);
+/* batched lower Cholesky of `batch` n x n SPD matrices (tf.linalg.cholesky, conditionals_multi_output.py:28,162).
+ * A and L may alias. info[b] = 0 or 1 + index of the first non-positive pivot. Returns FFVD_ENOTPD if any info != 0. */
+int  ffvd_op_cholesky(const double *A, int n, int batch, double *L, int32_t *info);
+/* kernel_pre_cal (conditionals_multi_output.py:124-169): for D kernels returns the stack of L_d^{-T} (D x M x M, upper). */
+int  ffvd_op_kernel_pre_cal(int kind, const double *Z, int M, int P, int D, const double *logvariance,
+                            const double *loglengthscales, double jitter, double *Lm_inverse_seq);
+/* collapse_after_kernel_precalculation (conditionals_multi_output.py:230-257).
+ * X_combine: T x P, X: (T+1) x D, Q: D.  out3 = (-term1/Y_N, -term2/Y_N, -trace/Y_N). */
+int  ffvd_op_collapse(int kind, const double *Lm_inverse_seq, const double *X_combine, const double *X,
+                      const double *Z, int T, int M, int P, int D, const double *logvariance,
+                      const double *loglengthscales, const double *Q, double batch_size, double Y_N, double out3[3]);
+/* conditional(Xnew, Z, kern, f, white=True, full_cov=False) (conditionals_multi_output.py:73-120 -> base_conditional :6-70).
+ * Xnew: N x P, f: M x D.  mean, var: N x D. */
+int  ffvd_op_conditional(int kind, const double *Xnew, int N, const double *Z, int M, int P, int D,
+                         const double *logvariance, const double *loglengthscales, const double *f,
+                         double jitter, double *mean, double *var);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FFVD_ABI_H */

@@ -1,0 +1,178 @@
+"""GPU parity, model level: the full ELBO (`nll` + component terms) through the C ABI against the committed
+golden vectors, the oracle on the same seeded inputs, and size-independent properties at BASELINE's full size."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from ffvd_amd import synthetic
+from ffvd_amd.engine import ElboEngine
+from ffvd_amd.dgp_model import DGPSSM
+from ffvd_amd.kernels import SquaredExponential
+from ffvd_amd.likelihoods import Gaussian
+from ffvd_amd.models import RegressionModel
+from oracle import ffvd_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-9      # fp64 GPU vs fp64 CPU oracle; north-star acceptance is 1e-4
+TERMS_B = ("nll_part_prior", "nll_log_likelihood", "x_t_prior_Q", "nll_reg_trace_inverse_Q_B", "later_term1",
+           "later_term2", "nll")
+TERMS_A = ("nll_part_prior", "nll_log_likelihood", "x_t_prior_Q", "nll_reg_trace_inverse_Q_B", "nll")
+
+
+def run_engine(params, Y, c, meta, collapse, **kw):
+    with ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], params["X"].shape[0], Ydim=Y.shape[1],
+                    kernel_type=meta["kernel_type"], U_collapse=collapse, **kw) as eng:
+        eng.set_data(Y, c)
+        return eng.nll_terms(params)
+
+
+def assert_terms(got, ref, names, rtol=RTOL, prefix=""):
+    for n in names:
+        r = float(ref[prefix + n])
+        # the trace term is a cancellation (T*sigma^2 - |F|^2): its absolute floor is set by |F|^2 * eps
+        atol = 1e-11 if n != "nll_reg_trace_inverse_Q_B" else 1e-10
+        assert got[n] == pytest.approx(r, rel=rtol, abs=atol), (n, got[n], r)
+
+
+@pytest.mark.parametrize("name", ["tiny", "small", "ragged", "small_lin"])
+@pytest.mark.parametrize("branch", ["B", "A"])
+def test_synthetic_golden(name, branch):
+    params, Y, c, meta = synthetic.make_named(name)
+    g = load_golden(name)
+    got = run_engine(params, Y, c, meta, collapse=(branch == "B"))
+    assert_terms(got, g, TERMS_B if branch == "B" else TERMS_A, prefix=branch + "_")
+    np.testing.assert_allclose(got["nll_per_chain"], g[branch + "_nll_per_chain"], rtol=RTOL)
+
+
+@pytest.mark.parametrize("branch", ["B", "A"])
+def test_actuator_config1(actuator, branch):
+    """BASELINE config 1: actuator, M=100, D=4, T=512 -- golden values reproduce SURVEY's anchors."""
+    params, Y, c = actuator
+    meta = dict(T=512, D=4, C=1, M=100, kernel_type="SquaredExponential")
+    p = dict(params)
+    p["X"] = params["X"][None]
+    got = run_engine(p, Y, c, meta, collapse=(branch == "B"))
+    assert_terms(got, load_golden("actuator"), TERMS_B if branch == "B" else TERMS_A, prefix=branch + "_")
+
+
+def test_model_facade_matches_engine(actuator):
+    """RegressionModel/DGPSSM (reference-named surface) give the same nll as the raw engine."""
+    params, Y, c = actuator
+    m = RegressionModel("normal")
+    A = m.ARGS
+    A.CC, A.DD = params["CC"], params["DD"]
+    A.QQ_chol = np.exp(0.5 * params["log_Q"])
+    A.RR_chol = np.exp(params["log_Rchols"])
+    A.lengthscales, A.variance = np.exp(params["loglengthscales"]), np.exp(params["logvariance"])
+    A.UU_ini, A.XX_0_ini, A.x_initialization = params["U"], params["X"][0], params["X"][1:]
+    A.control_inputs, A.num_inducing, A.x_dims, A.ZZ = c, 100, [4], params["Z"]
+    A.U_collapse, A.kernel_optimization, A.case_val = True, True, 4
+    m.fit(Y, kernel_type="SquaredExponential")
+    g = load_golden("actuator")
+    assert m.nll_seq[0] == pytest.approx(float(g["B_nll"]), rel=RTOL)
+    t = m.model.nll_terms()
+    assert t["later_term1"] == pytest.approx(float(g["B_later_term1"]), rel=RTOL)
+
+
+def test_chain_and_dim_sharding_sum_to_the_whole():
+    """partial sums of chain shards / latent-dim shards add up to the unsharded sums."""
+    params, Y, c, meta = synthetic.make_named("small")
+    S, D = meta["S"], meta["D"]
+
+    def sums(collapse, s0, s1, d0, dc, shared):
+        p = dict(params)
+        p["X"] = params["X"][s0:s1]
+        with ElboEngine(meta["T"], D, meta["C"], meta["M"], s1 - s0, U_collapse=collapse, d_begin=d0, d_count=dc,
+                        shared_terms=shared) as e:
+            e.set_data(Y, c)
+            return e.elbo_sums(p)
+
+    for collapse in (True, False):
+        whole = sums(collapse, 0, S, 0, D, True)
+        chains = sums(collapse, 0, 1, 0, D, True) + sums(collapse, 1, S, 0, D, True)
+        np.testing.assert_allclose(chains, whole, rtol=1e-12, atol=1e-13)
+        dims = sums(collapse, 0, S, 0, 1, True) + sums(collapse, 0, S, 1, D - 1, False)
+        np.testing.assert_allclose(dims, whole, rtol=1e-12, atol=1e-13)
+        assert whole[7] == S
+
+
+def test_chains_per_pass_is_invisible():
+    params, Y, c, meta = synthetic.make_named("small")
+    a = run_engine(params, Y, c, meta, True, chains_per_pass=1)
+    b = run_engine(params, Y, c, meta, True, chains_per_pass=3)
+    d = run_engine(params, Y, c, meta, True)
+    for n in TERMS_B:
+        assert a[n] == b[n] == d[n]
+
+
+def test_resident_parameters_and_repeatability():
+    params, Y, c, meta = synthetic.make_named("small")
+    with ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], meta["S"]) as e:
+        e.set_data(Y, c)
+        e.set_params(params)
+        a, b = e.elbo_sums(), e.elbo_sums()
+        np.testing.assert_array_equal(a, b)           # bitwise reproducible: no atomics anywhere
+        ms = e.time_elbo(3)
+        assert ms > 0
+        np.testing.assert_array_equal(e.elbo_sums(), a)
+        st = e.profile_stages()
+        assert st["project_F"] > 0 and st["gram_H"] > 0
+
+
+def test_wide_inputs_and_multi_output():
+    """P up to 17 (config-5 shape) and Ydim > 1."""
+    params, Y, c, meta = synthetic.make_workload(T=200, D=16, C=1, M=70, S=2, kernel_type="LinearK", U_collapse=False)
+    got = run_engine(params, Y, c, meta, collapse=False)
+    ref = orc.nll_terms_chains(params, Y, c, U_collapse=False, kernel_type="LinearK")
+    assert_terms(got, ref, TERMS_A)
+    params, Y, c, meta = synthetic.make_workload(T=130, D=3, C=2, M=40, S=2, Ydim=2)
+    params["log_Rchols"] = np.log(np.array([[0.4, 0.7], [9.0, 9.0]]))     # only row 0 is used (dgp_model.py:250)
+    got = run_engine(params, Y, c, meta, collapse=True)
+    ref = orc.nll_terms_chains(params, Y, c, U_collapse=True)
+    assert_terms(got, ref, TERMS_B)
+
+
+def test_not_positive_definite_is_reported():
+    params, Y, c, meta = synthetic.make_named("tiny")
+    p = dict(params)
+    p["Z"] = params["Z"].copy()
+    p["Z"][5] = p["Z"][4]                                # duplicate inducing point, no jitter => singular K_uu
+    with ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], meta["S"], jitter=0.0) as e:
+        e.set_data(Y, c)
+        with pytest.raises(np.linalg.LinAlgError, match="K_uu"):
+            e.nll_terms(p)
+        good = e.nll_terms(params)                       # the handle stays usable after a numerical error
+        assert np.isfinite(good["nll"])
+
+
+def test_usage_errors():
+    params, Y, c, meta = synthetic.make_named("tiny")
+    with ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], meta["S"]) as e:
+        with pytest.raises(ValueError, match="ffvd_set_data"):
+            e.elbo_sums()
+        e.set_data(Y, c)
+        with pytest.raises(ValueError):
+            e.set_params(dict(params, Z=params["Z"][:-1]))
+        with pytest.raises(ValueError):
+            e.set_data(Y[:-1], c)
+
+
+def test_full_size_config2_properties():
+    """BASELINE config 2 shape (T=4096, M=512, D=4) with S=4: two chains checked against the oracle
+    (seconds on CPU), all chains through permutation equivariance and linearity of the partial sums."""
+    params, Y, c, meta = synthetic.make_named("c2", S=4)
+    with ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], 4) as e:
+        e.set_data(Y, c)
+        t = e.nll_terms(params)
+        per = t["nll_per_chain"].copy()
+        perm = [2, 0, 3, 1]
+        t2 = e.nll_terms(dict(params, X=params["X"][perm]))
+        np.testing.assert_allclose(t2["nll_per_chain"], per[perm], rtol=1e-13)
+        assert t2["nll"] == pytest.approx(t["nll"], rel=1e-13)
+    assert t["nll"] == pytest.approx(per.mean(), rel=1e-13)
+    for s in (0, 3):
+        p = dict(params)
+        p["X"] = params["X"][s]
+        ref = orc.nll_terms(p, Y, c, U_collapse=True)
+        assert per[s] == pytest.approx(ref["nll"], rel=1e-8)

@@ -1,0 +1,121 @@
+"""GPU parity, operator level: each HIP entry point against the NumPy oracle on the same inputs, through the
+C ABI.  Tolerances are stated per test (fp64; the north-star acceptance is rtol 1e-4 on the ELBO)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from ffvd_amd import _lib, synthetic
+from ffvd_amd import conditionals, conditionals_multi_output as cmo
+from ffvd_amd.kernels import LinearK, SquaredExponential
+from oracle import ffvd_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def tiny():
+    params, Y, c, meta = synthetic.make_named("tiny")
+    X0 = params["X"][0]
+    xc = np.concatenate((X0[:-1], c[: meta["T"]]), axis=1)
+    kern = [SquaredExponential(meta["P"], variance=np.exp(params["logvariance"][d]),
+                               lengthscales=np.exp(params["loglengthscales"][d])) for d in range(meta["D"])]
+    return params, Y, c, meta, X0, xc, kern
+
+
+def test_se_kernel_matrix_matches_golden():
+    params, Y, c, meta, X0, xc, kern = tiny()
+    g = np.load(os.path.join(GOLDEN, "ops_tiny.npz"))
+    for d, k in enumerate(kern):
+        np.testing.assert_allclose(k.K(params["Z"]), g["Kuu"][d], rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(k.K(xc, params["Z"]), g["Kfu"][d], rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(k.Kdiag(xc), g["Kdiag"][d], rtol=1e-15)
+    lin = LinearK(meta["P"], variance=0.07)
+    np.testing.assert_allclose(lin.K(xc, params["Z"]), g["Klin"], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(lin.Kdiag(xc), g["Klin_diag"], rtol=1e-13)
+
+
+@pytest.mark.parametrize("N,N2,P", [(1, 1, 1), (3, 130, 17), (257, 5, 9), (64, 64, 5)])
+def test_kernel_matrix_shapes(N, N2, P):
+    rng = np.random.default_rng(N * 1000 + N2)
+    X, X2 = rng.standard_normal((N, P)), rng.standard_normal((N2, P))
+    ls = 0.5 + rng.random(P)
+    k = SquaredExponential(P, variance=0.7, lengthscales=ls)
+    ok = orc.SquaredExponential(np.log(0.7), np.log(ls))
+    np.testing.assert_allclose(k.K(X, X2), ok.K(X, X2), rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(k.K(X), ok.K(X), rtol=1e-12, atol=1e-15)
+    assert k.K(X[:0], X2).shape == (0, N2)          # empty input
+
+
+@pytest.mark.parametrize("n,batch", [(1, 1), (5, 3), (64, 2), (65, 2), (200, 3), (512, 2)])
+def test_cholesky_matches_numpy(n, batch):
+    lib = _lib.load()
+    rng = np.random.default_rng(n + batch)
+    B = rng.standard_normal((batch, n, n + 3))
+    A = B @ np.swapaxes(B, 1, 2) + 0.1 * np.eye(n)
+    L = np.empty_like(A)
+    info = np.zeros(batch, dtype=np.int32)
+    rc = lib.ffvd_op_cholesky(_lib.dptr(A), n, batch, _lib.dptr(L), info.ctypes.data_as(_lib.C.POINTER(_lib.C.c_int32)))
+    assert rc == 0 and not info.any()
+    ref = np.linalg.cholesky(A)
+    np.testing.assert_allclose(L, ref, rtol=1e-10, atol=1e-11)
+    np.testing.assert_allclose(L @ np.swapaxes(L, 1, 2), A, rtol=1e-12, atol=1e-11)   # factorisation property
+
+
+def test_cholesky_reports_non_pd():
+    lib = _lib.load()
+    A = np.eye(70)[None].repeat(2, 0).copy()
+    A[1, 66, 66] = -1.0
+    L = np.empty_like(A)
+    info = np.zeros(2, dtype=np.int32)
+    rc = lib.ffvd_op_cholesky(_lib.dptr(A), 70, 2, _lib.dptr(L), info.ctypes.data_as(_lib.C.POINTER(_lib.C.c_int32)))
+    assert rc == _lib.FFVD_ENOTPD
+    assert info[0] == 0 and info[1] == 67
+    assert b"matrix 1" in lib.ffvd_last_error(None)
+
+
+def test_kernel_pre_cal_matches_oracle():
+    params, Y, c, meta, X0, xc, kern = tiny()
+    g = np.load(os.path.join(GOLDEN, "ops_tiny.npz"))
+    W = cmo.kernel_pre_cal(params["Z"], kern)
+    # L^-T of a kappa ~ 1e6 matrix: compare through the defining property too
+    np.testing.assert_allclose(np.stack(W), g["Lm_inverse_seq"], rtol=1e-6, atol=1e-7)
+    for d, k in enumerate(kern):
+        Kuu = g["Kuu"][d] + 1e-5 * np.eye(meta["M"])
+        np.testing.assert_allclose(W[d].T @ Kuu @ W[d], np.eye(meta["M"]), atol=1e-8)
+        assert np.allclose(np.tril(W[d], -1), 0.0)
+
+
+def test_conditional_matches_oracle():
+    params, Y, c, meta, X0, xc, kern = tiny()
+    g = np.load(os.path.join(GOLDEN, "ops_tiny.npz"))
+    mean, var = cmo.conditional(xc, params["Z"], kern, params["U"], white=True)
+    np.testing.assert_allclose(mean, g["cond_mean"], rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(var, g["cond_var"], rtol=1e-7, atol=1e-10)
+    with pytest.raises(NotImplementedError):
+        cmo.conditional(xc, params["Z"], kern, params["U"], white=False)
+    # single-kernel variant (conditionals.py, jitter 1e-7): R GPs sharing one kernel
+    ok = orc.SquaredExponential(params["logvariance"][0], params["loglengthscales"][0])
+    m1, v1 = conditionals.conditional(xc[:10], params["Z"], kern[0], params["U"], white=True)
+    m2, v2 = orc.conditional(xc[:10], params["Z"], [ok] * meta["D"], params["U"], white=True, jitter=1e-7)
+    np.testing.assert_allclose(m1, m2, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(v1, v2, rtol=1e-5, atol=1e-9)
+
+
+def test_collapse_matches_oracle():
+    params, Y, c, meta, X0, xc, kern = tiny()
+    g = np.load(os.path.join(GOLDEN, "ops_tiny.npz"))
+    Q = np.exp(params["log_Q"])
+    T = float(meta["T"])
+    # reference call pattern dgp_model.py:273-280: pre-cal then collapse
+    W = cmo.kernel_pre_cal(params["Z"], kern)
+    out = cmo.collapse_after_kernel_precalculation(W, xc, X0, params["Z"], kern, Q, T, T)
+    np.testing.assert_allclose(out, g["collapse"], rtol=1e-8)
+    # and with the ORACLE's L^-T handed in: isolates projection + Gram + Cholesky(H)
+    out2 = cmo.collapse_after_kernel_precalculation(list(g["Lm_inverse_seq"]), xc, X0, params["Z"], kern, Q, T, T)
+    np.testing.assert_allclose(out2, g["collapse"], rtol=1e-9)
+    # mini-batch rescaling factors stay parameterised (:246-248): batch_size != Y_N
+    okern = orc.make_kernels(params)
+    ref = orc.collapse_after_kernel_precalculation(list(g["Lm_inverse_seq"]), xc, X0, params["Z"], okern, Q, T, 2 * T)
+    out3 = cmo.collapse_after_kernel_precalculation(list(g["Lm_inverse_seq"]), xc, X0, params["Z"], kern, Q, T, 2 * T)
+    np.testing.assert_allclose(out3, ref, rtol=1e-9)

@@ -1,0 +1,116 @@
+"""CPU: host-side logic that needs no device -- sharding plans, partial-sum finishing, kernel objects,
+and the world_size-2 gloo rehearsal of the multi-GPU reduction."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from ffvd_amd import distributed as dist_mod
+from ffvd_amd import synthetic
+from ffvd_amd.kernels import LinearK, SquaredExponential, stack_hypers
+from ffvd_amd.likelihoods import Gaussian
+
+
+def test_shard_range_covers_everything():
+    for n in (1, 7, 32, 33):
+        for world in (1, 2, 3, 8):
+            spans = [dist_mod.shard_range(n, world, r) for r in range(world)]
+            assert sum(c for _, c in spans) == n
+            pos = 0
+            for b, c in spans:
+                assert b == pos
+                pos += c
+    with pytest.raises(ValueError):
+        dist_mod.shard_range(4, 2, 2)
+
+
+def test_plans():
+    meta = dict(S=32, D=4)
+    p = dist_mod.plan(meta, 8, 3, "chains")
+    assert (p["s_begin"], p["s_count"], p["d_count"], p["shared_terms"]) == (12, 4, 4, True)
+    meta = dict(S=1, D=16)
+    p0, p5 = dist_mod.plan(meta, 8, 0, "dims"), dist_mod.plan(meta, 8, 5, "dims")
+    assert p0["shared_terms"] and not p5["shared_terms"]
+    assert (p5["d_begin"], p5["d_count"]) == (10, 2)
+    with pytest.raises(ValueError):
+        dist_mod.plan(dict(S=1, D=16), 8, 0, "chains")
+
+
+def test_finish():
+    sums = np.array([1.0, 2, 3, 4, 5, 6, 21, 2])
+    t = dist_mod.finish(sums)
+    assert t["nll"] == 10.5 and t["nll_part_prior"] == 0.5
+    with pytest.raises(ValueError):
+        dist_mod.finish(np.zeros(8))
+
+
+def test_kernel_objects_follow_reference_parameterisation():
+    k = SquaredExponential(5, variance=0.3, lengthscales=np.arange(1.0, 6.0), ARD=True)
+    assert k.logvariance == pytest.approx(np.log(0.3))
+    np.testing.assert_allclose(k.lengthscales, np.arange(1.0, 6.0))
+    kind, name, lv, ll = stack_hypers([k, k])
+    assert kind == 0 and name == "SquaredExponential" and lv.shape == (2,) and ll.shape == (2, 5)
+    lin = LinearK(5, variance=0.07)
+    assert stack_hypers([lin])[3] is None
+    with pytest.raises(ValueError):
+        stack_hypers([k, lin])
+    with pytest.raises(ValueError):
+        LinearK(5, variance=np.ones(5))
+
+
+def test_gaussian_likelihood_parameters():
+    lik = Gaussian(1, 4, CC=np.ones((4, 1)) * 0.5, DD=np.array([0.1]), RR_chol=np.array([[0.4]]))
+    assert lik.log_Rchols[0, 0] == pytest.approx(np.log(0.4))
+    assert lik.Rchols[0, 0] == pytest.approx(0.4)
+    assert Gaussian(1, 4).log_Rchols[0, 0] == pytest.approx(np.log(0.1))      # likelihoods.py:52
+
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["FFVD_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+from ffvd_amd import synthetic, distributed as dm
+from oracle import ffvd_oracle as orc
+from ffvd_amd._lib import TERM_NAMES
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+mode, name = sys.argv[1], sys.argv[2]
+dist.init_process_group("gloo", rank=rank, world_size=world)
+params, Y, c, meta = synthetic.make_named(name)
+pl = dm.plan(meta, world, rank, mode)
+# rank-local partial sums; the ORACLE stands in for the GPU engine (test-only fake backend)
+sums = np.zeros(8)
+kw = dict(U_collapse=meta["U_collapse"], kernel_type=meta["kernel_type"])
+for s in range(pl["s_begin"], pl["s_begin"] + pl["s_count"]):
+    p = dict(params); p["X"] = params["X"][s]
+    t = orc.nll_terms(p, Y, c, **kw)
+    for i, n in enumerate(TERM_NAMES):
+        sums[i] += t.get(n, 0.0)
+    sums[7] += 1.0 if pl["shared_terms"] else 0.0
+t = torch.from_numpy(sums)
+dm.all_reduce_sums(t)
+if rank == 0:
+    ref = orc.nll_terms_chains(params, Y, c, **kw)
+    got = dm.finish(t.numpy())
+    for n in TERM_NAMES:
+        if n in ref:
+            assert abs(got[n] - ref[n]) <= 1e-12 * max(1.0, abs(ref[n])), (n, got[n], ref[n])
+    print("OK", got["nll"])
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("world", [2])
+def test_gloo_world2_chain_sharding(tmp_path, world):
+    """world_size-2 rehearsal of mode='chains': shard -> local partial sums -> all-reduce -> mean."""
+    import subprocess
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, FFVD_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", WORLD_SIZE=str(world),
+               OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script), "chains", "tiny"], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "OK" in outs[0]
