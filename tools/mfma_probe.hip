@@ -27,6 +27,23 @@ __global__ __launch_bounds__(256) void mfma_rate_kernel(double *out, int iters) 
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// in-kernel clock: shader cycles (s_memtime) per 100 MHz reference tick (s_memrealtime) around an MFMA loop
+__global__ __launch_bounds__(256) void mfma_clock_kernel(double *out, unsigned long long *stamps, int iters) {
+    d4 acc[8];
+    for (int i = 0; i < 8; ++i) acc[i] = (d4){0, 0, 0, 0};
+    double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+    unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    double s = 0;
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0) { stamps[2 * blockIdx.x] = c1 - c0; stamps[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
 __global__ __launch_bounds__(256) void fma_rate_kernel(double *out, int iters) {
     double x[16];
     for (int i = 0; i < 16; ++i) x[i] = threadIdx.x * 1e-9 + i;
@@ -98,6 +115,20 @@ int main() {
         ms = time_ms([&] { hipLaunchKernelGGL(mfma_rate_kernel<2>, dim3(CU * wpc), dim3(256), 0, 0, dout, iters); }, 5);
         fl = (double)CU * wpc * 4 * iters * 2 * 2048.0;
         printf("fp64 MFMA 16x16x4, 2 accumulators, %d wave/SIMD: %.1f TFLOP/s\n", wpc, fl / ms / 1e9);
+    }
+    {   // sustained run (~1 s) + in-kernel clock
+        unsigned long long *dst_; CK(hipMalloc(&dst_, (size_t)CU * 4 * 16));
+        for (int wpc : {1, 2, 4}) {
+            const int it2 = 40000;
+            float ms = time_ms([&] { hipLaunchKernelGGL(mfma_clock_kernel, dim3(CU * wpc), dim3(256), 0, 0, dout, dst_, it2); }, 10);
+            std::vector<unsigned long long> st((size_t)CU * wpc * 2);
+            CK(hipMemcpy(st.data(), dst_, st.size() * 8, hipMemcpyDeviceToHost));
+            double cyc = 0, ref = 0;
+            for (int i = 0; i < CU * wpc; ++i) { cyc += st[2 * i]; ref += st[2 * i + 1]; }
+            double fl = (double)CU * wpc * 4 * (double)it2 * 8 * 2048.0;
+            printf("sustained fp64 MFMA, %d wave/SIMD, %.0f ms/launch: %.1f TFLOP/s, in-kernel clock %.2f GHz, %.1f cycles per MFMA per wave\n",
+                   wpc, ms, fl / ms / 1e9, cyc / ref * 0.1, cyc / (CU * wpc) / ((double)it2 * 8));
+        }
     }
     for (int wpc : {1, 2, 4}) {
         float ms = time_ms([&] { hipLaunchKernelGGL(fma_rate_kernel, dim3(CU * wpc), dim3(256), 0, 0, dout, iters); }, 5);
