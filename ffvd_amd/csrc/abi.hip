@@ -101,12 +101,14 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
     h->ng = (h->Mp + 511) / 512;
     h->nbatch = c.S_local * h->Dl;
     const size_t Mp = h->Mp, Tp = h->Tp, Dl = h->Dl, P = h->P;
-    // chains per pass: keep the F slabs of one pass near the 256 MiB Infinity Cache unless told otherwise
+    // chains per pass: every launch should cover as many (chain, dim) units as possible (the batched Cholesky and
+    // the Gram grid need >= 1 workgroup per CU); F costs Dl*Tp*Mp*8 bytes per chain, budget 48 GiB of the 288 GB.
     if (c.chains_per_pass > 0) h->cpp = c.chains_per_pass;
     else {
         const size_t per_chain = Dl * Tp * Mp * sizeof(double);
-        size_t n = (size_t)192 * 1024 * 1024 / (per_chain ? per_chain : 1);
+        size_t n = ((size_t)48 << 30) / (per_chain ? per_chain : 1);
         if (n < 1) n = 1;
+        if (n > (size_t)c.S_local) n = c.S_local;
         h->cpp = (int)n;
     }
     if (h->cpp > c.S_local) h->cpp = c.S_local;

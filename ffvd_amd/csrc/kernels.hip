@@ -18,6 +18,7 @@
 //   * Cholesky is a blocked right-looking factorisation whose "extra rows" carry a right-hand side through the
 //     same panel/trailing kernels: identity rows become L^{-T}, the row delta^T F / Q becomes L_H^{-1} b.
 #include "kernels.h"
+#include <cstdlib>
 
 namespace ffvd {
 
@@ -184,78 +185,127 @@ void launch_kernel_diag(hipStream_t stream, int kind, const double *X, int N, in
 }
 
 // ---------------------------------------------------------------------------------------------
-// Extended blocked Cholesky (right-looking, NB = 64)
+// Extended blocked Cholesky (right-looking, NB = 64), three launches per block step:
+//   panel(k):  rows below the diagonal block  R <- R * L_kk^{-T}   (forward substitution, lane = row,
+//              L_kk broadcast from LDS; one wavefront per 64 rows)
+//   trail(k):  C(i,j) -= P_i P_j^T for the remaining tiles (one wavefront per 64x64 tile, MFMA)
+//   diag(k+1): factorise the next 64x64 diagonal block
+// The 64x64 diagonal factorisation runs in ONE wavefront (lane = row, row in registers, pivot column broadcast
+// through LDS): no workgroup barrier, and no other workgroup reads a diagonal block before a finished launch
+// has published its factor.
 // ---------------------------------------------------------------------------------------------
-// Step k, panel kernel: every workgroup factorises the 64x64 diagonal block in LDS (redundantly; workgroup 0 of a
-// matrix writes it back) and solves its 64-row chunk of the rows below:  R <- R * D^{-T}.
-__global__ __launch_bounds__(256) void potrf_panel_kernel(double *A, int n, int k, int nmain, int nchunks,
-                                                          size_t slab_stride, int32_t *info) {
-    __shared__ double Ds[NB][NB + 1];
-    __shared__ double Rs[NB][NB + 1];
-    const int tid = threadIdx.x;
-    const int b = blockIdx.y, chunk = blockIdx.x;
-    double *S = A + (size_t)b * slab_stride;
-    const int k0 = k * NB;
-
-    for (int idx = tid; idx < NB * NB; idx += 256) {
-        int i = idx >> 6, j = idx & 63;
-        Ds[i][j] = S[(size_t)(k0 + i) * n + k0 + j];
-    }
-    __syncthreads();
-    // unblocked lower Cholesky of Ds (tf.linalg.cholesky, conditionals_multi_output.py:28,162)
-    for (int j = 0; j < NB; ++j) {
-        const double ajj = Ds[j][j];
-        if (!(ajj > 0.0) && tid == 0 && chunk == 0 && info[b] == 0) info[b] = k0 + j + 1;
-        const double piv = sqrt(ajj);
-        if (tid < NB && tid > j) Ds[tid][j] = Ds[tid][j] / piv;
-        __syncthreads();
-        {
-            const int i = tid & 63, q = tid >> 6;
-            if (i > j) {
-                const double lij = Ds[i][j];
-                for (int c = j + 1 + q; c <= i; c += 4) Ds[i][c] -= lij * Ds[c][j];
-            }
-            if (tid == j) Ds[j][j] = piv;
-        }
-        __syncthreads();
-    }
-    if (chunk == 0) {
-        for (int idx = tid; idx < NB * NB; idx += 256) {
-            int i = idx >> 6, j = idx & 63;
-            if (j <= i) S[(size_t)(k0 + i) * n + k0 + j] = Ds[i][j];
-        }
-    }
-    if (chunk >= nchunks) return;
-    const int row0 = (chunk < nmain) ? (k + 1 + chunk) * NB : n + (chunk - nmain) * NB;
-    for (int idx = tid; idx < NB * NB; idx += 256) {
-        int i = idx >> 6, j = idx & 63;
-        Rs[i][j] = S[(size_t)(row0 + i) * n + k0 + j];
-    }
-    __syncthreads();
-    // forward substitution per row r: y_c = (R_rc - sum_{j<c} y_j D_cj) / D_cc ; 4 threads share a row
-    {
-        const int r = tid >> 2, q = tid & 3;
-        for (int c = 0; c < NB; ++c) {
-            double s = 0.0;
-            for (int j = q; j < c; j += 4) s += Rs[r][j] * Ds[c][j];
-            s += __shfl_xor(s, 1);
-            s += __shfl_xor(s, 2);
-            if (q == 0) Rs[r][c] = (Rs[r][c] - s) / Ds[c][c];
-            __syncthreads();
-        }
-    }
-    for (int idx = tid; idx < NB * NB; idx += 256) {
-        int i = idx >> 6, j = idx & 63;
-        S[(size_t)(row0 + i) * n + k0 + j] = Rs[i][j];
-    }
+__device__ __forceinline__ double readlane_f64(double v, int srclane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
+    return __hiloint2double(hi, lo);
 }
 
-// Step k, trailing update: one wavefront per 64x64 tile,  C(i,j) -= P_i * P_j^T  with P = solved panel (columns of block k).
+// LDS hand-off between the lanes of ONE wavefront: order the LDS traffic for the compiler and the hardware.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// In: a[k] = A[lane][k] (lower triangle of an SPD 64x64 block referenced).  Out: a[k] = L[lane][k] for k <= lane.
+// col: LDS scratch [2][NB].  Returns 0 or 1 + index of the first non-positive pivot.
+__device__ __forceinline__ int chol64_rows(double (&a)[NB], double (*col)[NB], const int lane) {
+    int bad = 0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const double ajj = readlane_f64(a[j], j);
+        if (!(ajj > 0.0) && bad == 0) bad = j + 1;
+        const double piv = sqrt(ajj);                       // tf.linalg.cholesky (conditionals_multi_output.py:28,162)
+        const double l = (lane > j) ? a[j] / piv : 0.0;
+        a[j] = (lane == j) ? piv : ((lane > j) ? l : a[j]);
+        col[j & 1][lane] = l;                               // pivot column, zero at and above the diagonal
+        wave_lds_sync();
+        // only k <= lane is meaningful; a scheduling fence every 8 columns keeps few LDS reads in flight
+#pragma unroll
+        for (int k = j + 1; k < NB; ++k) {
+            a[k] -= l * col[j & 1][k];
+            if (((k - j) & 7) == 0) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    return bad;
+}
+
+// Factorise the diagonal block held in LDS tile `Ts` (row-major, stride NB+1) and publish L in place (lower).
+__device__ __forceinline__ void diag_block_finish(double (*Ts)[NB + 1], double (*col)[NB], double *S, int n, int k0,
+                                                   int32_t *info_b, const int lane) {
+    double a[NB];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) a[c] = Ts[lane][c];
+    const int bad = chol64_rows(a, col, lane);
+    if (bad && lane == 0 && *info_b == 0) *info_b = k0 + bad;
+    wave_lds_sync();
+#pragma unroll
+    for (int c = 0; c < NB; ++c) Ts[lane][c] = a[c];
+    wave_lds_sync();
+    for (int r = 0; r < NB; ++r)
+        if (lane <= r) S[(size_t)(k0 + r) * n + k0 + lane] = Ts[r][lane];         // coalesced rows of L
+}
+
+__global__ __launch_bounds__(64) void potrf_diag_kernel(double *A, int n, int k, size_t slab_stride, int32_t *info) {
+    __shared__ double Ts[NB][NB + 1];
+    __shared__ double col[2][NB];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    double *S = A + (size_t)b * slab_stride;
+    const int k0 = k * NB;
+    for (int r = 0; r < NB; ++r) Ts[r][lane] = S[(size_t)(k0 + r) * n + k0 + lane];
+    wave_lds_sync();
+    diag_block_finish(Ts, col, S, n, k0, info + b, lane);
+}
+
+// tile bookkeeping shared by the panel and trailing kernels
+__device__ __forceinline__ int chunk_row0(int chunk, int k, int nmain, int n) {
+    return (chunk < nmain) ? (k + 1 + chunk) * NB : n + (chunk - nmain) * NB;
+}
+
+// R <- R * L_kk^{-T} for one 64-row chunk: per row, y_c = (R_c - sum_{j<c} y_j L[c][j]) / L[c][c]
+__global__ __launch_bounds__(64) void potrf_panel_kernel(double *A, int n, int k, int nmain, size_t slab_stride) {
+    __shared__ double Ls[NB][NB];          // read with wave-uniform addresses only (broadcast)
+    __shared__ double Rs[NB][NB + 1];
+    __shared__ double invd[NB];
+    const int b = blockIdx.y, lane = threadIdx.x;
+    double *S = A + (size_t)b * slab_stride;
+    const int k0 = k * NB;
+    const int row0 = chunk_row0(blockIdx.x, k, nmain, n);
+    double *R = S + (size_t)row0 * n + k0;
+    for (int r = 0; r < NB; ++r) {
+        Ls[r][lane] = S[(size_t)(k0 + r) * n + k0 + lane];
+        Rs[r][lane] = R[(size_t)r * n + lane];
+    }
+    wave_lds_sync();
+    invd[lane] = 1.0 / Ls[lane][lane];
+    double y[NB];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) y[c] = Rs[lane][c];
+    wave_lds_sync();
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+        double s0 = y[c], s1 = 0.0;
+#pragma unroll
+        for (int j = 0; j + 1 < c; j += 2) {
+            s0 -= y[j] * Ls[c][j];
+            s1 -= y[j + 1] * Ls[c][j + 1];
+        }
+        if (c & 1) s0 -= y[c - 1] * Ls[c][c - 1];
+        y[c] = (s0 + s1) * invd[c];
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int c = 0; c < NB; ++c) Rs[lane][c] = y[c];
+    wave_lds_sync();
+    for (int r = 0; r < NB; ++r) R[(size_t)r * n + lane] = Rs[r][lane];
+}
+
+// Trailing update of step k: one wavefront per 64x64 tile,  C(i,j) -= P_i * P_j^T  with P = solved panel.
 // Tiles: main lower triangle (k < j <= i < nb) then extra-row tiles (e, j) for j in (k, nb).
 __global__ __launch_bounds__(64) void potrf_trail_kernel(double *A, int n, int k, int nmain_tiles, int n1,
                                                          size_t slab_stride) {
     const int b = blockIdx.y;
-    int tile = blockIdx.x;
+    const int tile = blockIdx.x;
     double *S = A + (size_t)b * slab_stride;
     const int k0 = k * NB;
     int rowblk0, colblk;   // first row / first col of the tile
@@ -309,12 +359,14 @@ void launch_potrf_ext(hipStream_t stream, double *A, int n, int extra_rows, int 
     const int nb = n / NB;
     const int nextra_all = extra_rows / NB;
     for (int k = 0; k < nb; ++k) {
+        hipLaunchKernelGGL(potrf_diag_kernel, dim3(batch), dim3(64), 0, stream, A, n, k, slab_stride, info);
         const int nmain = nb - k - 1;
         // identity extras: block-row e of L^{-T} is zero in block-columns < e, so only e <= k is live at step k
         const int nextra = identity_extra ? ((k + 1 < nextra_all) ? k + 1 : nextra_all) : nextra_all;
         const int nchunks = nmain + nextra;
-        dim3 pgrid(nchunks > 0 ? nchunks : 1, batch);
-        hipLaunchKernelGGL(potrf_panel_kernel, pgrid, dim3(256), 0, stream, A, n, k, nmain, nchunks, slab_stride, info);
+        if (nchunks > 0)
+            hipLaunchKernelGGL(potrf_panel_kernel, dim3(nchunks, batch), dim3(64), 0, stream, A, n, k, nmain,
+                               slab_stride);
         const int n1 = nmain;
         if (n1 > 0) {
             const int nmain_tiles = n1 * (n1 + 1) / 2;
@@ -332,19 +384,22 @@ void launch_potrf_ext(hipStream_t stream, double *A, int n, int extra_rows, int 
 constexpr int KC = 16;          // k-chunk (columns of K_fu produced per barrier)
 constexpr int KS_LD = STRIP + 16;   // LDS row stride of the K chunk: 80 doubles => lanes l and l+16 hit different bank halves
 
-template <int KIND>
-__global__ __launch_bounds__(512) void project_kernel(ProjectArgs a) {
+template <int KIND, int NW>
+__global__ __launch_bounds__(NW * 64) void project_kernel(ProjectArgs a) {
+    constexpr int NT = NW * 64;          // threads
+    constexpr int TPW = 32 / NW;         // 16-column tiles per wavefront
     __shared__ double Ks[2][KC][KS_LD];
     __shared__ double xs[MAXP][STRIP];
     __shared__ double xx[STRIP];
     __shared__ double zs[2][KC][MAXP];
     __shared__ double zzs[2][KC];
-    __shared__ double part[2][8][STRIP];
+    __shared__ double part[2][NW][STRIP];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lk = lane >> 4;
+    const int dbg = a.dbg;
     const int t0 = blockIdx.x * STRIP;
     const int g = blockIdx.y;
     const int bz = blockIdx.z;                 // index inside this pass
@@ -357,7 +412,7 @@ __global__ __launch_bounds__(512) void project_kernel(ProjectArgs a) {
     const double *Wd = a.W + (size_t)dl * a.w_stride;
 
     // ---- x rows of this strip, divided by the lengthscales (kernels_multi_output.py:170) ----
-    for (int p = tid >> 6; p < P; p += 8) {
+    for (int p = tid >> 6; p < P; p += NW) {
         const int t = t0 + lane;
         double v = 0.0;
         if (t < a.T) {
@@ -388,8 +443,8 @@ __global__ __launch_bounds__(512) void project_kernel(ProjectArgs a) {
     auto gen = [&](int c, int buf) {
         const int row = lane;
 #pragma unroll
-        for (int i = 0; i < KC / 8; ++i) {
-            const int kk = (tid >> 6) + 8 * i;
+        for (int i = 0; i < (KC * STRIP) / NT; ++i) {
+            const int kk = (tid >> 6) + NW * i;
             const int kcol = c * KC + kk;
             double dot = 0.0;
             for (int p = 0; p < P; ++p) dot += xs[p][row] * zs[buf][kk][p];
@@ -403,47 +458,68 @@ __global__ __launch_bounds__(512) void project_kernel(ProjectArgs a) {
     __syncthreads();
 
     // ---- column tiles owned by this wavefront (snake order balances the triangular work) ----
-    int c0[4];
-    bool tv[4];
+    int c0[TPW];
+    bool tv[TPW];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int lt = r * 8 + ((r & 1) ? 7 - wave : wave);
+    for (int r = 0; r < TPW; ++r) {
+        const int lt = r * NW + ((r & 1) ? NW - 1 - wave : wave);
         c0[r] = (g * 32 + lt) * 16;
         tv[r] = c0[r] < kend;
     }
-    d4 acc[4][4];
+    d4 acc[4][TPW];
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[rt][r] = (d4){0.0, 0.0, 0.0, 0.0};
+        for (int r = 0; r < TPW; ++r) acc[rt][r] = (d4){0.0, 0.0, 0.0, 0.0};
 
+    // B fragments (rows of L^{-T}) are prefetched one k-step ahead straight from L2 into registers.
+    // L^{-T} is upper triangular: a 16-column tile starting at c0 only needs rows k < c0 + 16.
+    auto loadB = [&](int kglob, double(&bv)[TPW]) {
+#pragma unroll
+        for (int r = 0; r < TPW; ++r)
+            bv[r] = (dbg & 2) ? 1.0 : ((tv[r] && kglob < c0[r] + 16) ? Wd[(size_t)(kglob + lk) * Mp + c0[r] + lr] : 0.0);
+    };
+    // SIMD partners (waves w and w+4) alternate roles inside a chunk: one generates the next K_fu chunk on the
+    // VALU while the other feeds the matrix pipe, instead of all eight waves doing the same phase in lockstep.
+    const bool gen_first = ((wave >> 2) & 1) == 0;
+    double bcur[TPW], bnxt[TPW];
+    loadB(0, bcur);
     for (int c = 0; c < nchunk; ++c) {
         const int buf = c & 1;
-        if (c + 1 < nchunk) gen(c + 1, buf ^ 1);       // zs[buf^1] was loaded one iteration ago
         if (c + 2 < nchunk) load_z(c + 2, buf);        // zs[buf] was consumed by gen(c) before the last barrier
+        if (!(dbg & 1) && gen_first && c + 1 < nchunk) gen(c + 1, buf ^ 1);   // zs[buf^1] was loaded one iteration ago
+        double af[4], afn[4];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) af[rt] = Ks[buf][lk][16 * rt + lr];
 #pragma unroll
         for (int ks = 0; ks < KC / 4; ++ks) {
             const int kglob = c * KC + 4 * ks;
-            double af[4];
+            if (kglob + 4 < kend) loadB(kglob + 4, bnxt);
+            if (ks + 1 < KC / 4) {
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt) af[rt] = Ks[buf][4 * ks + lk][16 * rt + lr];
+                for (int rt = 0; rt < 4; ++rt) afn[rt] = Ks[buf][4 * (ks + 1) + lk][16 * rt + lr];
+            }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (tv[r] && kglob < c0[r] + 16) {   // L^{-T} is upper triangular: rows k > column are zero
-                    const double bf = Wd[(size_t)(kglob + lk) * Mp + c0[r] + lr];
+            for (int r = 0; r < TPW; ++r) {
+                if (tv[r] && kglob < c0[r] + 16) {
 #pragma unroll
-                    for (int rt = 0; rt < 4; ++rt) acc[rt][r] = mfma_f64(af[rt], bf, acc[rt][r]);
+                    for (int rt = 0; rt < 4; ++rt) acc[rt][r] = mfma_f64(af[rt], bcur[r], acc[rt][r]);
                 }
             }
+#pragma unroll
+            for (int r = 0; r < TPW; ++r) bcur[r] = bnxt[r];
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) af[rt] = afn[rt];
         }
-        __syncthreads();
+        if (!(dbg & 1) && !gen_first && c + 1 < nchunk) gen(c + 1, buf ^ 1);
+        if (!(dbg & 8)) __syncthreads();
     }
 
     // ---- epilogue ----
-    if (a.F) {
+    if (a.F && !(dbg & 4)) {
         double *Fb = a.F + ((size_t)bz * a.Tp + t0) * Mp;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < TPW; ++r) {
             if (!tv[r]) continue;
 #pragma unroll
             for (int rt = 0; rt < 4; ++rt)
@@ -453,9 +529,9 @@ __global__ __launch_bounds__(512) void project_kernel(ProjectArgs a) {
         }
     }
     if (a.rowsq || a.fmean) {
-        double uc[4];
+        double uc[TPW];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < TPW; ++r) {
             const int col = c0[r] + lr;
             uc[r] = (a.fmean && tv[r] && col < a.M) ? a.U[(size_t)col * a.u_ld + dg] : 0.0;
         }
@@ -465,7 +541,7 @@ __global__ __launch_bounds__(512) void project_kernel(ProjectArgs a) {
             for (int q = 0; q < 4; ++q) {
                 double sq = 0.0, fm = 0.0;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
+                for (int r = 0; r < TPW; ++r) {
                     const double v = tv[r] ? acc[rt][r][q] : 0.0;
                     sq += v * v;
                     fm += v * uc[r];
@@ -483,7 +559,7 @@ __global__ __launch_bounds__(512) void project_kernel(ProjectArgs a) {
         __syncthreads();
         if (tid < STRIP) {
             double sq = 0.0, fm = 0.0;
-            for (int w = 0; w < 8; ++w) { sq += part[0][w][tid]; fm += part[1][w][tid]; }
+            for (int w = 0; w < NW; ++w) { sq += part[0][w][tid]; fm += part[1][w][tid]; }
             const size_t o = ((size_t)b * a.ng + g) * a.Tp + t0 + tid;
             if (a.rowsq) a.rowsq[o] = sq;
             if (a.fmean) a.fmean[o] = fm;
@@ -493,8 +569,16 @@ __global__ __launch_bounds__(512) void project_kernel(ProjectArgs a) {
 
 void launch_project(hipStream_t stream, const ProjectArgs &a) {
     dim3 grid(a.Tp / STRIP, a.ng, a.nb);
-    if (a.kind == 0) hipLaunchKernelGGL(project_kernel<0>, grid, dim3(512), 0, stream, a);
-    else hipLaunchKernelGGL(project_kernel<1>, grid, dim3(512), 0, stream, a);
+    static const int dbgv = [] { const char *e = getenv("FFVD_DBG"); return e ? atoi(e) : 0; }();
+    ProjectArgs a2 = a; a2.dbg = dbgv;
+    static const int nw = [] { const char *e = getenv("FFVD_PROJECT_WAVES"); return e ? atoi(e) : 8; }();
+    if (nw == 16) {
+        if (a.kind == 0) hipLaunchKernelGGL((project_kernel<0, 16>), grid, dim3(1024), 0, stream, a2);
+        else hipLaunchKernelGGL((project_kernel<1, 16>), grid, dim3(1024), 0, stream, a2);
+    } else {
+        if (a.kind == 0) hipLaunchKernelGGL((project_kernel<0, 8>), grid, dim3(512), 0, stream, a2);
+        else hipLaunchKernelGGL((project_kernel<1, 8>), grid, dim3(512), 0, stream, a2);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -504,7 +588,7 @@ void launch_project(hipStream_t stream, const ProjectArgs &a) {
 constexpr int GT = 16;              // rows of F per LDS chunk
 constexpr int G_LD = 128 + 16;      // LDS row stride (doubles)
 
-__global__ __launch_bounds__(256) void gram_kernel(GramArgs a, int n128, int ntiles) {
+__global__ __launch_bounds__(256, 2) void gram_kernel(GramArgs a, int n128, int ntiles) {
     __shared__ double As[2][GT][G_LD];
     __shared__ double Bs[2][GT][G_LD];
     __shared__ double dls[2][GT];

@@ -44,6 +44,33 @@ __global__ __launch_bounds__(256) void mfma_clock_kernel(double *out, unsigned l
     if (threadIdx.x == 0) { stamps[2 * blockIdx.x] = c1 - c0; stamps[2 * blockIdx.x + 1] = r1 - r0; }
 }
 
+// co-execution: per workgroup of 512 threads, waves 0-3 run fp64 MFMA, waves 4-7 run fp64 VALU FMA (one of each per SIMD)
+__global__ __launch_bounds__(512) void coexec_kernel(double *out, int iters_mfma, int iters_fma, int mode) {
+    const int wave = threadIdx.x >> 6;
+    double s = 0;
+    const bool do_mfma = (mode == 0) ? (wave < 4) : (mode == 1);
+    if (do_mfma) {
+        d4 acc[8];
+        for (int i = 0; i < 8; ++i) acc[i] = (d4){0, 0, 0, 0};
+        double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+        for (int it = 0; it < iters_mfma; ++it) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+        }
+        for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    } else {
+        double x[16];
+        for (int i = 0; i < 16; ++i) x[i] = threadIdx.x * 1e-9 + i;
+        const double a = 1.0000001, b = 1e-9;
+        for (int it = 0; it < iters_fma; ++it) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) x[i] = __builtin_fma(x[i], a, b);
+        }
+        for (int i = 0; i < 16; ++i) s += x[i];
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 __global__ __launch_bounds__(256) void fma_rate_kernel(double *out, int iters) {
     double x[16];
     for (int i = 0; i < 16; ++i) x[i] = threadIdx.x * 1e-9 + i;
@@ -129,6 +156,15 @@ int main() {
             printf("sustained fp64 MFMA, %d wave/SIMD, %.0f ms/launch: %.1f TFLOP/s, in-kernel clock %.2f GHz, %.1f cycles per MFMA per wave\n",
                    wpc, ms, fl / ms / 1e9, cyc / ref * 0.1, cyc / (CU * wpc) / ((double)it2 * 8));
         }
+    }
+    {   // MFMA and VALU fp64 side by side on every SIMD
+        const int im = 20000, iff = 20000 * 8 * 140 / (16 * 8);   // roughly equal run times when alone
+        float t_m = time_ms([&] { hipLaunchKernelGGL(coexec_kernel, dim3(CU), dim3(512), 0, 0, dout, im, iff, 1); }, 5);
+        float t_f = time_ms([&] { hipLaunchKernelGGL(coexec_kernel, dim3(CU), dim3(512), 0, 0, dout, im, iff, 2); }, 5);
+        float t_c = time_ms([&] { hipLaunchKernelGGL(coexec_kernel, dim3(CU), dim3(512), 0, 0, dout, im, iff, 0); }, 5);
+        double fl_m8 = (double)CU * 8 * (double)im * 8 * 2048.0, fl_f8 = (double)CU * 512 * (double)iff * 16 * 2.0;
+        printf("co-exec: 8 MFMA waves/CU alone %.1f TF (%.2f ms); 8 FMA waves/CU alone %.1f TF (%.2f ms); 4 MFMA + 4 FMA waves/CU: %.2f ms => MFMA %.1f TF + VALU %.1f TF = %.1f TF\n",
+               fl_m8 / t_m / 1e9, t_m, fl_f8 / t_f / 1e9, t_f, t_c, fl_m8 / 2 / t_c / 1e9, fl_f8 / 2 / t_c / 1e9, (fl_m8 + fl_f8) / 2 / t_c / 1e9);
     }
     for (int wpc : {1, 2, 4}) {
         float ms = time_ms([&] { hipLaunchKernelGGL(fma_rate_kernel, dim3(CU * wpc), dim3(256), 0, 0, dout, iters); }, 5);
