@@ -14,6 +14,7 @@ FFVD_OK, FFVD_EINVAL, FFVD_ENOMEM, FFVD_EDEVICE, FFVD_ENOTPD = 0, -1, -2, -3, 1
 KERNEL_KIND = {"SquaredExponential": 0, "LinearK": 1}
 BRANCH_A, BRANCH_B = 0, 1
 PRIOR_TYPE = {"uniform": 0, "normal": 1}
+ROUTE = {"reference": 0, "gram": 1}
 PARAMS_ON_DEVICE = 1
 TERM_NAMES = ("nll_part_prior", "nll_log_likelihood", "x_t_prior_Q", "nll_reg_trace_inverse_Q_B",
               "later_term1", "later_term2", "nll")
@@ -22,7 +23,7 @@ TERM_NAMES = ("nll_part_prior", "nll_log_likelihood", "x_t_prior_Q", "nll_reg_tr
 class FfvdConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "T", "D", "C", "M", "S_local", "Ydim", "d_begin", "d_count", "shared_terms", "dtype",
-        "kernel_kind", "branch", "prior_type", "device_id", "chains_per_pass", "reserved")] + [("jitter", C.c_double)]
+        "kernel_kind", "branch", "prior_type", "device_id", "chains_per_pass", "route")] + [("jitter", C.c_double)]
 
 
 class FfvdParams(C.Structure):

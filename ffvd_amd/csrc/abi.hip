@@ -39,6 +39,8 @@ struct ffvd_handle {
     // workspace
     double *variance = nullptr, *len = nullptr, *Zs = nullptr, *zz = nullptr;
     double *Kuu = nullptr, *F = nullptr, *H = nullptr, *rowsq = nullptr, *fmean = nullptr;
+    double *Kcopy = nullptr, *Linv = nullptr, *Kinv = nullptr, *trpart = nullptr, *kterms = nullptr;   // GRAM route
+    int ntiles = 0;
     double *hterms = nullptr, *chain_terms = nullptr, *chain_nll = nullptr, *out_terms = nullptr;
     int32_t *info = nullptr;
     // pinned host staging
@@ -138,6 +140,14 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
         HIP_TRY(dev_alloc(h, &h->H, pass_b * (Mp + NB) * Mp));
         HIP_TRY(hipMemsetAsync(h->H, 0, pass_b * (Mp + NB) * Mp * sizeof(double), h->stream));
     }
+    h->ntiles = gram_ntiles(h->Mp);
+    if (c.branch == FFVD_BRANCH_B && c.route == FFVD_ROUTE_GRAM) {
+        HIP_TRY(dev_alloc(h, &h->Kcopy, Dl * Mp * Mp));
+        HIP_TRY(dev_alloc(h, &h->Linv, Dl * Mp * Mp));
+        HIP_TRY(dev_alloc(h, &h->Kinv, Dl * Mp * Mp));
+        HIP_TRY(dev_alloc(h, &h->trpart, (size_t)h->nbatch * h->ntiles));
+        HIP_TRY(dev_alloc(h, &h->kterms, Dl * 2));
+    }
     HIP_TRY(dev_alloc(h, &h->hterms, (size_t)h->nbatch * 2));
     HIP_TRY(dev_alloc(h, &h->chain_terms, (size_t)c.S_local * 8));
     HIP_TRY(dev_alloc(h, &h->chain_nll, (size_t)c.S_local));
@@ -177,6 +187,10 @@ extern "C" int ffvd_create(const ffvd_config *cfg, ffvd_handle **out) {
     if (cfg->d_begin < 0 || cfg->d_begin + dcount > cfg->D)
         return set_error(nullptr, FFVD_EINVAL, "ffvd_create: latent-dim shard [d_begin, d_begin + d_count) out of range");
     if (!(cfg->jitter >= 0.0)) return set_error(nullptr, FFVD_EINVAL, "ffvd_create: jitter must be >= 0");
+    if (cfg->route != FFVD_ROUTE_REFERENCE && cfg->route != FFVD_ROUTE_GRAM)
+        return set_error(nullptr, FFVD_EINVAL, "ffvd_create: unknown route");
+    if (cfg->route == FFVD_ROUTE_GRAM && cfg->branch != FFVD_BRANCH_B)
+        return set_error(nullptr, FFVD_EINVAL, "ffvd_create: FFVD_ROUTE_GRAM only applies to the collapsed-U branch");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || cfg->device_id < 0 || cfg->device_id >= ndev) {
         snprintf(msg, sizeof msg, "ffvd_create: device %d not available (%d HIP devices visible)", cfg->device_id, ndev);
@@ -290,9 +304,20 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
     launch_prep_hypers(s, c.kernel_kind, p.Z, c.M, Mp, P, Dl, c.d_begin, p.logvariance, p.loglengthscales,
                        h->variance, h->len, h->Zs, h->zz);
     HyperView hv{h->variance, h->len, h->Zs, h->zz};
-    launch_kuu_build(s, c.kernel_kind, hv, c.M, Mp, P, Dl, c.jitter, h->Kuu);
+    const bool gram_route = (c.branch == FFVD_BRANCH_B && c.route == FFVD_ROUTE_GRAM);
+    launch_kuu_build(s, c.kernel_kind, hv, c.M, Mp, P, Dl, c.jitter, h->Kuu, gram_route ? h->Kcopy : nullptr);
     const size_t kstride = (size_t)2 * Mp * Mp;
+    const size_t msq = (size_t)Mp * Mp;
     launch_potrf_ext(s, h->Kuu, Mp, Mp, 1, Dl, kstride, h->info);
+    if (gram_route) {
+        // K^-1 = L^-T L^-1 (shared by all chains) and log|K|
+        launch_transpose(s, h->Kuu + msq, kstride, h->Linv, msq, Mp, Dl);
+        GramArgs gk{};
+        gk.mode = GRAM_PLAIN; gk.A = h->Linv; gk.a_stride = msq; gk.rows = Mp; gk.with_row = 0; gk.Mp = Mp; gk.Dl = Dl;
+        gk.d_begin = c.d_begin; gk.b0 = 0; gk.nb = Dl; gk.yn_over_batch = 1.0; gk.H = h->Kinv; gk.h_stride = msq;
+        launch_gram(s, gk);
+        launch_h_finish(s, h->Kuu, Mp, kstride, Dl, h->kterms);
+    }
     if (st) st->mark(0);
     for (int s0 = 0; s0 < c.S_local; s0 += h->cpp) {
         const int ns = (s0 + h->cpp <= c.S_local) ? h->cpp : c.S_local - s0;
@@ -300,19 +325,23 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
         pa.kind = c.kernel_kind;
         pa.x = p.X; pa.x_chain_stride = (size_t)(c.T + 1) * c.D; pa.x_ld = c.D; pa.x_cols = c.D;
         pa.ctrl = h->ctrl; pa.T = c.T; pa.Tp = Tp; pa.C = c.C; pa.P = P; pa.M = c.M; pa.Mp = Mp; pa.Dl = Dl;
-        pa.d_begin = c.d_begin; pa.hv = hv; pa.W = h->Kuu + (size_t)Mp * Mp; pa.w_stride = kstride;
+        pa.d_begin = c.d_begin; pa.hv = hv; pa.W = h->Kuu + msq; pa.w_stride = kstride;
         pa.U = p.U; pa.u_ld = c.D; pa.b0 = s0 * Dl; pa.nb = ns * Dl;
         pa.F = (c.branch == FFVD_BRANCH_B) ? h->F : nullptr;
         pa.rowsq = h->rowsq;
         pa.fmean = (c.branch == FFVD_BRANCH_A) ? h->fmean : nullptr;
         pa.ng = h->ng;
-        launch_project(s, pa);
+        if (gram_route) launch_kfu_build(s, pa);
+        else launch_project(s, pa);
         if (st) st->mark(1);
         if (c.branch == FFVD_BRANCH_B) {
             GramArgs ga{};
-            ga.F = h->F; ga.X = p.X; ga.log_Q = p.log_Q; ga.T = c.T; ga.Tp = Tp; ga.D = c.D; ga.Mp = Mp; ga.Dl = Dl;
+            ga.mode = gram_route ? GRAM_KFU : GRAM_F;
+            ga.A = h->F; ga.a_stride = (size_t)Tp * Mp; ga.rows = Tp; ga.with_row = 1;
+            ga.X = p.X; ga.log_Q = p.log_Q; ga.T = c.T; ga.D = c.D; ga.Mp = Mp; ga.Dl = Dl;
             ga.d_begin = c.d_begin; ga.b0 = s0 * Dl; ga.nb = ns * Dl; ga.yn_over_batch = 1.0;
             ga.H = h->H; ga.h_stride = (size_t)(Mp + NB) * Mp;
+            ga.Kadd = h->Kcopy; ga.kadd_stride = msq; ga.Kinv = h->Kinv; ga.kinv_stride = msq; ga.trpart = h->trpart;
             launch_gram(s, ga);
             if (st) st->mark(2);
             launch_potrf_ext(s, h->H, Mp, NB, 0, ns * Dl, ga.h_stride, h->info + Dl + s0 * Dl);
@@ -326,7 +355,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
     ra.T = c.T; ra.Tp = Tp; ra.D = c.D; ra.C = c.C; ra.Ydim = c.Ydim; ra.Dl = Dl; ra.d_begin = c.d_begin;
     ra.S = c.S_local; ra.ng = h->ng; ra.shared_terms = c.shared_terms;
     ra.xk = p.X; ra.xk_chain_stride = (size_t)(c.T + 1) * c.D; ra.xk_ld = c.D; ra.xk_cols = c.D;
-    ra.rowsq = h->rowsq; ra.fmean = h->fmean; ra.chain_terms = h->chain_terms;
+    ra.rowsq = gram_route ? nullptr : h->rowsq; ra.fmean = h->fmean; ra.chain_terms = h->chain_terms;
     launch_chain_reduce(s, ra);
     FinalizeArgs fa{};
     fa.kind = c.kernel_kind; fa.branch = c.branch; fa.prior_type = c.prior_type; fa.shared_terms = c.shared_terms;
@@ -334,6 +363,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
     fa.S = c.S_local; fa.Z = p.Z; fa.U = p.U; fa.logvar = p.logvariance; fa.loglen = p.loglengthscales;
     fa.log_Q = p.log_Q; fa.CC = p.CC; fa.DD = p.DD; fa.log_Rchols = p.log_Rchols;
     fa.chain_terms = h->chain_terms; fa.hterms = h->hterms; fa.chain_nll = h->chain_nll;
+    fa.route = gram_route ? 1 : 0; fa.kterms = h->kterms; fa.trpart = h->trpart; fa.ntiles = h->ntiles;
     fa.out_terms = out_dev ? out_dev : h->out_terms;
     launch_finalize(s, fa);
     if (st) st->mark(4);
@@ -605,7 +635,7 @@ static int build_kuu(Scratch &sc, int kind, const double *Z, int M, int P, int D
     if (hipMemsetAsync(w.info, 0, D * sizeof(int32_t), sc.stream) != hipSuccess) return FFVD_EDEVICE;
     launch_prep_hypers(sc.stream, kind, dZ, M, Mp, P, D, 0, w.logvar, w.loglen, w.variance, w.len, w.Zs, w.zz);
     HyperView hv{w.variance, w.len, w.Zs, w.zz};
-    launch_kuu_build(sc.stream, kind, hv, M, Mp, P, D, jitter, w.Kuu);
+    launch_kuu_build(sc.stream, kind, hv, M, Mp, P, D, jitter, w.Kuu, nullptr);
     launch_potrf_ext(sc.stream, w.Kuu, Mp, Mp, 1, D, (size_t)2 * Mp * Mp, w.info);
     if (dZ_out) *dZ_out = dZ;
     return FFVD_OK;
@@ -696,7 +726,8 @@ extern "C" int ffvd_op_collapse(int kind, const double *Lm_inverse_seq, const do
     pa.rowsq = rowsq; pa.fmean = nullptr; pa.ng = ng;
     launch_project(sc.stream, pa);
     GramArgs ga{};
-    ga.F = F; ga.X = dX; ga.log_Q = dlq; ga.T = T; ga.Tp = Tp; ga.D = D; ga.Mp = Mp; ga.Dl = D; ga.d_begin = 0;
+    ga.mode = GRAM_F; ga.A = F; ga.a_stride = (size_t)Tp * Mp; ga.rows = Tp; ga.with_row = 1;
+    ga.X = dX; ga.log_Q = dlq; ga.T = T; ga.D = D; ga.Mp = Mp; ga.Dl = D; ga.d_begin = 0;
     ga.b0 = 0; ga.nb = D; ga.yn_over_batch = Y_N / batch_size; ga.H = H; ga.h_stride = hstride;
     launch_gram(sc.stream, ga);
     launch_potrf_ext(sc.stream, H, Mp, NB, 0, D, hstride, info);

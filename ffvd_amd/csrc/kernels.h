@@ -27,7 +27,10 @@ void launch_prep_hypers(hipStream_t stream, int kind, const double *Z, int M, in
 
 // A[dl] (ld = Mp, rows 0..Mp-1) = K_dl(Z, Z) + jitter*I with identity padding; rows Mp..2Mp-1 = I (the
 // "extra rows" that the extended Cholesky turns into L^{-T}).  A has Dl slabs of 2*Mp*Mp doubles.
-void launch_kuu_build(hipStream_t stream, int kind, HyperView hv, int M, int Mp, int P, int Dl, double jitter, double *A);
+void launch_kuu_build(hipStream_t stream, int kind, HyperView hv, int M, int Mp, int P, int Dl, double jitter, double *A,
+                      double *Kcopy /* optional [Dl][Mp*Mp] copy that survives the factorisation */);
+void launch_transpose(hipStream_t stream, const double *in, size_t in_stride, double *out, size_t out_stride, int Mp,
+                      int Dl);
 
 // General kernel matrix for the operator API: out[N x N2] = K(X, X2) for ONE kernel (dl = 0 of hv is not used;
 // lengthscale scaling is applied on the fly).  diag_jitter added where row == col if `same`.
@@ -64,18 +67,32 @@ struct ProjectArgs {
 };
 // F = K_fu * L^{-T} with K_fu generated on the fly (never stored).
 void launch_project(hipStream_t stream, const ProjectArgs &a);
+// a.F[bz][t][m] = K_fu itself (route K_uu + K_uf K_fu / Q); uses x, ctrl, hv, T, Tp, M, Mp, b0, nb of `a`.
+void launch_kfu_build(hipStream_t stream, const ProjectArgs &a);
 
+enum { GRAM_F = 0, GRAM_KFU = 1, GRAM_PLAIN = 2 };
 struct GramArgs {
-    const double *F;        // [nb][Tp][Mp]
+    int mode;               // GRAM_*
+    const double *A;        // [nb] slabs of rows x Mp (F, K_fu or L^-1), slab stride a_stride doubles
+    size_t a_stride;
+    int rows;               // rows of A summed over (multiple of 16; Tp for F / K_fu)
+    int with_row;           // 1: also write the extra row Mp = scale * delta^T A (needs X, T, D)
     const double *X;        // [S][T+1][D]
     const double *log_Q;    // [D] (global dim index)
-    int T, Tp, D, Mp, Dl, d_begin;
-    int b0, nb;
+    int T, D, Mp, Dl, d_begin;
+    int b0, nb;             // batches [b0, b0 + nb): b = s*Dl + dl
     double yn_over_batch;   // Y_N / batch_size (== 1 for the full batch)
-    double *H;              // [nb] slabs of (Mp + NB) x Mp: H = F^T F * scale + I (lower), row Mp = scale * delta^T F
+    double *H;              // [nb] output slabs (ld Mp), lower-triangular tiles; slab stride h_stride
     size_t h_stride;
+    const double *Kadd;     // GRAM_KFU: [Dl] K_uu + jitter I (ld Mp), slab stride kadd_stride
+    size_t kadd_stride;
+    const double *Kinv;     // GRAM_KFU: [Dl] (K_uu + jitter I)^-1 (ld Mp), slab stride kinv_stride
+    size_t kinv_stride;
+    double *trpart;         // GRAM_KFU: [nbatch_total][ntiles] partial sums of tr(K^-1 K_uf K_fu)
+    int ntiles;             // filled by launch_gram
 };
-void launch_gram(hipStream_t stream, const GramArgs &a);
+int gram_ntiles(int Mp);
+void launch_gram(hipStream_t stream, GramArgs a);
 
 // hterms[b] = { logdet(H) = 2 sum log diag(L_H),  b^T H^{-1} b = |row Mp|^2 } after launch_potrf_ext on H.
 void launch_h_finish(hipStream_t stream, const double *H, int Mp, size_t h_stride, int nb, double *hterms /*[nb][2]*/);
@@ -100,6 +117,10 @@ struct FinalizeArgs {
     const double *Z, *U, *logvar, *loglen, *log_Q, *CC, *DD, *log_Rchols;
     const double *chain_terms;     // [S][8]
     const double *hterms;          // [S*Dl][2] (branch B) or null
+    int route;                     // 0: F = K_fu L^-T route, 1: K_uu + K_uf K_fu / Q route
+    const double *kterms;          // route 1: [Dl][2], kterms[2 dl] = log det (K_uu + jitter I)
+    const double *trpart;          // route 1: [S*Dl][ntiles] partial sums of tr(K^-1 K_uf K_fu)
+    int ntiles;
     double *chain_nll;             // [S]
     double *out_terms;             // [8]
 };

@@ -103,7 +103,7 @@ __device__ __forceinline__ double kernel_value(double dot, double xx, double zz,
 }
 
 __global__ __launch_bounds__(256) void kuu_build_kernel(int kind, HyperView hv, int M, int Mp, int P, double jitter,
-                                                        double *A) {
+                                                        double *A, double *Kcopy) {
     const int dl = blockIdx.z;
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (size_t)Mp * Mp) return;
@@ -131,10 +131,79 @@ __global__ __launch_bounds__(256) void kuu_build_kernel(int kind, HyperView hv, 
         if (i == j) v += jitter;   // conditionals_multi_output.py:108,159
     }
     slab[idx] = v;
+    if (Kcopy) Kcopy[(size_t)dl * Mp * Mp + idx] = v;     // the factorisation overwrites `slab` in place
 }
-void launch_kuu_build(hipStream_t stream, int kind, HyperView hv, int M, int Mp, int P, int Dl, double jitter, double *A) {
+void launch_kuu_build(hipStream_t stream, int kind, HyperView hv, int M, int Mp, int P, int Dl, double jitter, double *A,
+                      double *Kcopy) {
     dim3 grid((unsigned)(((size_t)Mp * Mp + 255) / 256), 2, Dl);
-    hipLaunchKernelGGL(kuu_build_kernel, grid, dim3(256), 0, stream, kind, hv, M, Mp, P, jitter, A);
+    hipLaunchKernelGGL(kuu_build_kernel, grid, dim3(256), 0, stream, kind, hv, M, Mp, P, jitter, A, Kcopy);
+}
+
+// out[dl][i][j] = in[dl][j][i] for Dl square Mp x Mp matrices (L^-T -> L^-1)
+__global__ __launch_bounds__(256) void transpose_kernel(const double *in, size_t in_stride, double *out, size_t out_stride,
+                                                        int Mp) {
+    __shared__ double t[64][65];
+    const int dl = blockIdx.z, bi = blockIdx.y * 64, bj = blockIdx.x * 64, tid = threadIdx.x;
+    const double *I = in + (size_t)dl * in_stride;
+    double *O = out + (size_t)dl * out_stride;
+    for (int r = tid >> 6; r < 64; r += 4) t[r][tid & 63] = I[(size_t)(bi + r) * Mp + bj + (tid & 63)];
+    __syncthreads();
+    for (int r = tid >> 6; r < 64; r += 4) O[(size_t)(bj + r) * Mp + bi + (tid & 63)] = t[tid & 63][r];
+}
+void launch_transpose(hipStream_t stream, const double *in, size_t in_stride, double *out, size_t out_stride, int Mp,
+                      int Dl) {
+    hipLaunchKernelGGL(transpose_kernel, dim3(Mp / 64, Mp / 64, Dl), dim3(256), 0, stream, in, in_stride, out,
+                       out_stride, Mp);
+}
+
+// K_fu materialised (only the K_uu + K_uf K_fu / Q route needs it in HBM): out[bz][t][m] = K_d(x_t, Z_m),
+// zero for t >= T or m >= M.  64 x 64 tile per workgroup; thread (tid & 63) owns a column, 16 rows.
+template <int KIND>
+__global__ __launch_bounds__(256) void kfu_build_kernel(ProjectArgs a) {
+    __shared__ double xs[MAXP][64];
+    __shared__ double xx[64];
+    __shared__ double zs[64][MAXP + 1];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int t0 = blockIdx.x * 64, m0 = blockIdx.y * 64, bz = blockIdx.z;
+    const int b = a.b0 + bz, s = b / a.Dl, dl = b % a.Dl;
+    const int P = a.P, Mp = a.Mp;
+    const double var = a.hv.variance[dl];
+    for (int p = tid >> 6; p < P; p += 4) {
+        const int t = t0 + lane;
+        double v = 0.0;
+        if (t < a.T) {
+            v = (p < a.x_cols) ? a.x[(size_t)s * a.x_chain_stride + (size_t)t * a.x_ld + p]
+                               : a.ctrl[(size_t)t * a.C + (p - a.x_cols)];
+            if (KIND == 0) v = v / a.hv.len[(size_t)dl * P + p];
+            else v = v * var;
+        }
+        xs[p][lane] = v;
+        zs[lane][p] = a.hv.Zs[((size_t)dl * Mp + m0 + lane) * P + p];
+    }
+    __syncthreads();
+    if (tid < 64) {
+        double acc = 0.0;
+        if (KIND == 0) for (int p = 0; p < P; ++p) acc += xs[p][tid] * xs[p][tid];
+        xx[tid] = acc;
+    }
+    __syncthreads();
+    const double zzv = a.hv.zz[(size_t)dl * Mp + m0 + lane];
+    double *out = a.F + ((size_t)bz * a.Tp + t0) * Mp + m0 + lane;
+    const bool mok = (m0 + lane) < a.M;
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+        const int r = (tid >> 6) * 16 + i;
+        double dot = 0.0;
+        for (int p = 0; p < P; ++p) dot += xs[p][r] * zs[lane][p];
+        double v = kernel_value<KIND>(dot, xx[r], zzv, var);
+        if (!mok || t0 + r >= a.T) v = 0.0;
+        out[(size_t)r * Mp] = v;
+    }
+}
+void launch_kfu_build(hipStream_t stream, const ProjectArgs &a) {
+    dim3 grid(a.Tp / 64, a.Mp / 64, a.nb);
+    if (a.kind == 0) hipLaunchKernelGGL(kfu_build_kernel<0>, grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(kfu_build_kernel<1>, grid, dim3(256), 0, stream, a);
 }
 
 // Operator-API kernel matrix (one kernel, arbitrary N, N2; no padding).
@@ -582,74 +651,89 @@ void launch_project(hipStream_t stream, const ProjectArgs &a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Gram:  H = F^T F * (Y_N / (batch Q_d)) + I,  extra row Mp = delta^T F * (Y_N / (batch Q_d))
-// (conditionals_multi_output.py:246-248).  Workgroup = 128x128 tile of the lower triangle, 4 wavefronts of 64x64.
+// Gram:  C = A^T A over the rows of A (T x Mp), lower-triangular tiles only, batched.
+//   mode GRAM_F   : H = F^T F * (Y_N / (batch Q_d)) + I            (conditionals_multi_output.py:246)
+//   mode GRAM_KFU : A_d = K_uf K_fu * (Y_N / (batch Q_d)) + (K_uu + jitter I)     (collapsed bound in the
+//                   K_uu + K_uf K_fu / Q form) plus the partial sums of tr(K^-1 K_uf K_fu)
+//   mode GRAM_PLAIN: C = A^T A (used for K^-1 = L^-T L^-1)
+//   with_row != 0 : extra row Mp = delta^T A * (Y_N / (batch Q_d))                 (conditionals_multi_output.py:247-248)
+// Workgroup = 128 x 128 output tile of the lower triangle, 8 wavefronts of 64 x 32 (8 accumulator tiles = 64
+// VGPRs), two workgroups per CU = four resident wavefronts per SIMD -- one fp64 MFMA wavefront can use at most
+// about half of a SIMD's matrix pipe (tools/mfma_probe2), so the pipe only saturates with several MFMA-ready
+// wavefronts per SIMD, and a second workgroup covers the first one's barrier / staging bubbles.
+// (Measured alternatives at M = 512, T = 4096, 128 units: 4 wavefronts of 64x64 3.45 ms; 16 wavefronts of 32x32,
+//  one workgroup per CU 3.36 ms; 128x64 tiles, 8 wavefronts of 32x32 3.27 ms; this layout 2.98 ms.)
 // ---------------------------------------------------------------------------------------------
-constexpr int GT = 16;              // rows of F per LDS chunk
-constexpr int G_LD = 128 + 16;      // LDS row stride (doubles)
+constexpr int GT = 16;              // rows of A per LDS chunk
+constexpr int G_LD = 128 + 16;      // LDS row stride (doubles): lanes l and l+16 land in different bank halves
 
-__global__ __launch_bounds__(256, 2) void gram_kernel(GramArgs a, int n128, int ntiles) {
-    __shared__ double As[2][GT][G_LD];
-    __shared__ double Bs[2][GT][G_LD];
-    __shared__ double dls[2][GT];
+// 64x32 sub-block (row half, column quarter) of each wavefront.  Diagonal tiles only need the 6 sub-blocks that
+// touch the lower triangle; they go to wavefronts 0..5 (SIMDs 0,1 get two, SIMDs 2,3 one); 6 and 7 do the gemv.
+__device__ __constant__ unsigned char GRAM_DIAG_WR[8] = {1, 1, 1, 1, 0, 0, 0, 0};
+__device__ __constant__ unsigned char GRAM_DIAG_WC[8] = {0, 1, 2, 3, 0, 1, 2, 3};
 
-    // XCD-aware mapping: all tiles of one (chain, dim) share blockIdx % 8, i.e. one XCD's L2 (speed only)
-    const int id = blockIdx.x;
-    const int xcd = id & 7, loc = id >> 3;
-    const int bz = (loc / ntiles) * 8 + xcd;
-    if (bz >= a.nb) return;
-    int tile = loc % ntiles;
-    int ti = 0;
-    while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
-    const int tj = tile - ti * (ti + 1) / 2;
-    const bool diag = (ti == tj);
-
+template <bool DIAG>
+__device__ __forceinline__ void gram_body(const GramArgs a, const int bz, const int ti, const int tj, const int tile,
+                                          double (*As)[GT][G_LD], double (*Bs)[GT][G_LD], double (*dls)[GT],
+                                          double *red) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = DIAG ? GRAM_DIAG_WR[wave] : (wave >> 2), wc = DIAG ? GRAM_DIAG_WC[wave] : (wave & 3);
     const int lr = lane & 15, lk = lane >> 4;
-    const int Mp = a.Mp, Tp = a.Tp;
+    const int Mp = a.Mp;
     const int b = a.b0 + bz, s = b / a.Dl, dl = b % a.Dl, dg = a.d_begin + dl;
-    const int I0 = ti * 128 + wr * 64, J0 = tj * 128 + wc * 64;
-    const bool active = (I0 < Mp) && (J0 < Mp) && (J0 <= I0);
+    const int I0 = ti * 128 + wr * 64, J0 = tj * 128 + wc * 32;
+    const bool active = (I0 < Mp) && (J0 < Mp) && (J0 < I0 + 64);
+    const bool gemv = DIAG && a.with_row && tid >= 384;          // wavefronts 6, 7: no sub-block in diagonal tiles
 
-    const double *Fb = a.F + (size_t)bz * Tp * Mp;
-    const double *Xs = a.X + (size_t)s * (a.T + 1) * a.D;
+    const double *Ab = a.A + (size_t)bz * a.a_stride;
+    const double *Xs = a.with_row ? a.X + (size_t)s * (a.T + 1) * a.D : nullptr;
+    // global -> register staging: thread (rowl, lane) moves 16 bytes of rows rowl and rowl + 8 per operand.
+    // Out-of-range columns (odd number of 64-blocks) are read from a clamped valid address and zeroed.
     const int colA = ti * 128 + 2 * lane, colB = tj * 128 + 2 * lane;
-    const int rowl = tid >> 6;   // 0..3
+    const bool okA = colA < Mp, okB = colB < Mp;
+    const int colAc = okA ? colA : 0, colBc = okB ? colB : 0;
+    const int rowl = tid >> 6;   // 0..7
 
-    double2 ra[4], rb[4];
+    double2 ra[2], rb[2];
     double dreg = 0.0;
     auto gload = [&](int c) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const size_t t = (size_t)c * GT + rowl + 4 * i;
-            ra[i] = (colA < Mp) ? *reinterpret_cast<const double2 *>(Fb + t * Mp + colA) : make_double2(0.0, 0.0);
-            if (!diag) rb[i] = (colB < Mp) ? *reinterpret_cast<const double2 *>(Fb + t * Mp + colB) : make_double2(0.0, 0.0);
+        for (int i = 0; i < 2; ++i) {
+            const size_t t = (size_t)c * GT + rowl + 8 * i;
+            const double2 va = *reinterpret_cast<const double2 *>(Ab + t * Mp + colAc);
+            ra[i].x = okA ? va.x : 0.0;
+            ra[i].y = okA ? va.y : 0.0;
+            if (!DIAG) {
+                const double2 vb = *reinterpret_cast<const double2 *>(Ab + t * Mp + colBc);
+                rb[i].x = okB ? vb.x : 0.0;
+                rb[i].y = okB ? vb.y : 0.0;
+            }
         }
-        if (diag && tid < GT) {
-            const int t = c * GT + tid;
-            dreg = (t < a.T) ? Xs[(size_t)(t + 1) * a.D + dg] - Xs[(size_t)t * a.D + dg] : 0.0;   // :247
+        if (DIAG && a.with_row) {
+            const int tt = c * GT + (tid & (GT - 1));
+            const int tc = tt < a.T ? tt : a.T - 1;
+            const double dv = Xs[(size_t)(tc + 1) * a.D + dg] - Xs[(size_t)tc * a.D + dg];   // :247
+            dreg = tt < a.T ? dv : 0.0;
         }
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = rowl + 4 * i;
-            *reinterpret_cast<double2 *>(&As[buf][r][2 * lane]) = ra[i];
-            if (!diag) *reinterpret_cast<double2 *>(&Bs[buf][r][2 * lane]) = rb[i];
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<double2 *>(&As[buf][rowl + 8 * i][2 * lane]) = ra[i];
+            if (!DIAG) *reinterpret_cast<double2 *>(&Bs[buf][rowl + 8 * i][2 * lane]) = rb[i];
         }
-        if (diag && tid < GT) dls[buf][tid] = dreg;
+        if (DIAG && a.with_row && tid < GT) dls[buf][tid] = dreg;
     };
 
-    d4 acc[4][4];
+    d4 acc[4][2];
 #pragma unroll
     for (int x = 0; x < 4; ++x)
 #pragma unroll
-        for (int y = 0; y < 4; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
+        for (int y = 0; y < 2; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
     double bsum = 0.0;
 
-    const int nchunk = Tp / GT;
+    const int nchunk = a.rows / GT;
     gload(0);
     lstore(0);
     __syncthreads();
@@ -657,54 +741,94 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramArgs a, int n128, int 
         const int buf = c & 1;
         if (c + 1 < nchunk) gload(c + 1);
         if (active) {
-            const double(*Bp)[G_LD] = diag ? As[buf] : Bs[buf];
+            const double(*Bp)[G_LD] = DIAG ? As[buf] : Bs[buf];
 #pragma unroll
             for (int ks = 0; ks < GT / 4; ++ks) {
-                double af[4], bf[4];
+                double af[4], bf[2];
 #pragma unroll
-                for (int x = 0; x < 4; ++x) {
-                    af[x] = As[buf][4 * ks + lk][wr * 64 + 16 * x + lr];
-                    bf[x] = Bp[4 * ks + lk][wc * 64 + 16 * x + lr];
-                }
+                for (int x = 0; x < 4; ++x) af[x] = As[buf][4 * ks + lk][wr * 64 + 16 * x + lr];
+#pragma unroll
+                for (int y = 0; y < 2; ++y) bf[y] = Bp[4 * ks + lk][wc * 32 + 16 * y + lr];
 #pragma unroll
                 for (int x = 0; x < 4; ++x)
 #pragma unroll
-                    for (int y = 0; y < 4; ++y) acc[x][y] = mfma_f64(af[x], bf[y], acc[x][y]);
+                    for (int y = 0; y < 2; ++y) acc[x][y] = mfma_f64(af[x], bf[y], acc[x][y]);
             }
         }
-        if (diag && tid < 128) {
+        if (gemv) {
 #pragma unroll
-            for (int r = 0; r < GT; ++r) bsum += As[buf][r][tid] * dls[buf][r];
+            for (int r = 0; r < GT; ++r) bsum += As[buf][r][tid - 384] * dls[buf][r];
         }
         if (c + 1 < nchunk) lstore(buf ^ 1);
         __syncthreads();
     }
 
-    const double scale = a.yn_over_batch / exp(a.log_Q[dg]);
+    const double scale = (a.mode == GRAM_PLAIN) ? 1.0 : a.yn_over_batch / exp(a.log_Q[dg]);
     double *Hb = a.H + (size_t)bz * a.h_stride;
+    const double *Kadd = (a.mode == GRAM_KFU) ? a.Kadd + (size_t)dl * a.kadd_stride : nullptr;
+    const double *Kinv = (a.mode == GRAM_KFU) ? a.Kinv + (size_t)dl * a.kinv_stride : nullptr;
+    double trp = 0.0;
     if (active) {
 #pragma unroll
         for (int x = 0; x < 4; ++x)
 #pragma unroll
-            for (int y = 0; y < 4; ++y)
+            for (int y = 0; y < 2; ++y)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int i = I0 + 16 * x + lk + 4 * q, j = J0 + 16 * y + lr;
-                    Hb[(size_t)i * Mp + j] = acc[x][y][q] * scale + ((i == j) ? 1.0 : 0.0);
+                    const double g = acc[x][y][q];
+                    double v;
+                    if (a.mode == GRAM_F) v = g * scale + ((i == j) ? 1.0 : 0.0);
+                    else if (a.mode == GRAM_KFU) {
+                        v = g * scale + Kadd[(size_t)i * Mp + j];
+                        const double w = (i > j) ? 2.0 : ((i == j) ? 1.0 : 0.0);
+                        trp += w * (Kinv[(size_t)i * Mp + j] * g);
+                    } else v = g;
+                    Hb[(size_t)i * Mp + j] = v;
                 }
     }
-    if (diag && tid < 128) {
-        const int col = ti * 128 + tid;
+    if (gemv) {
+        const int col = ti * 128 + tid - 384;
         if (col < Mp) Hb[(size_t)Mp * Mp + col] = bsum * scale;
+    }
+    if (a.mode == GRAM_KFU) {      // deterministic workgroup reduction of the trace partial
+        red[tid] = trp;
+        __syncthreads();
+        for (int st = 256; st > 0; st >>= 1) {
+            if (tid < st) red[tid] += red[tid + st];
+            __syncthreads();
+        }
+        if (tid == 0) a.trpart[(size_t)b * a.ntiles + tile] = red[0];
     }
 }
 
-void launch_gram(hipStream_t stream, const GramArgs &a) {
-    const int nwt = a.Mp / NB;
-    const int n128 = (nwt + 1) / 2;
-    const int ntiles = n128 * (n128 + 1) / 2;
+__global__ __launch_bounds__(512, 4) void gram_kernel(GramArgs a) {
+    __shared__ double As[2][GT][G_LD];
+    __shared__ double Bs[2][GT][G_LD];
+    __shared__ double dls[2][GT];
+    __shared__ double red[512];
+    // XCD-aware mapping: all tiles of one (chain, dim) share blockIdx % 8, i.e. one XCD's L2 (speed only)
+    const int id = blockIdx.x;
+    const int xcd = id & 7, loc = id >> 3;
+    const int bz = (loc / a.ntiles) * 8 + xcd;
+    if (bz >= a.nb) return;
+    const int tile = loc % a.ntiles;
+    int ti = 0;                       // tile = ti (ti + 1) / 2 + tj,  tj <= ti
+    while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
+    const int tj = tile - ti * (ti + 1) / 2;
+    if (ti == tj) gram_body<true>(a, bz, ti, tj, tile, As, Bs, dls, red);
+    else gram_body<false>(a, bz, ti, tj, tile, As, Bs, dls, red);
+}
+
+int gram_ntiles(int Mp) {
+    const int n128 = (Mp / NB + 1) / 2;
+    return n128 * (n128 + 1) / 2;
+}
+
+void launch_gram(hipStream_t stream, GramArgs a) {
+    a.ntiles = gram_ntiles(a.Mp);
     const int groups = (a.nb + 7) / 8;
-    hipLaunchKernelGGL(gram_kernel, dim3(groups * 8 * ntiles), dim3(256), 0, stream, a, n128, ntiles);
+    hipLaunchKernelGGL(gram_kernel, dim3(groups * 8 * a.ntiles), dim3(512), 0, stream, a);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -762,7 +886,7 @@ __global__ __launch_bounds__(256) void chain_reduce_kernel(ReduceArgs a) {
             const size_t bb = ((size_t)s * a.Dl + dl) * a.ng;
             double rs = 0.0, fm = 0.0;
             for (int g = 0; g < a.ng; ++g) {
-                rs += a.rowsq[(bb + g) * a.Tp + t];
+                if (a.rowsq) rs += a.rowsq[(bb + g) * a.Tp + t];
                 if (a.branch == 0) fm += a.fmean[(bb + g) * a.Tp + t];
             }
             const double kdiag = (a.kind == 0) ? a.variance[dl] : xsq * a.variance[dl];
@@ -886,8 +1010,18 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
             if (a.branch == 1) {
                 double term1 = 0.0, term2 = 0.0;
                 for (int dl = 0; dl < a.Dl; ++dl) {
-                    const double *ht = a.hterms + ((size_t)s * a.Dl + dl) * 2;
-                    term1 += -0.5 * ht[0];                                   // :253
+                    const size_t bb = (size_t)s * a.Dl + dl;
+                    const double *ht = a.hterms + bb * 2;
+                    double logdet = ht[0];
+                    if (a.route == 1) {
+                        // log|I + L^-1 G L^-T / Q| = log|K + G/Q| - log|K|  with K = K_uu + jitter I
+                        logdet -= a.kterms[2 * dl];
+                        // sum_t |F_t|^2 = tr(K^-1 K_uf K_fu): add it back to the trace term (:255)
+                        double fsq = 0.0;
+                        for (int t = 0; t < a.ntiles; ++t) fsq += a.trpart[bb * a.ntiles + t];
+                        terms[3] += -(0.5 * fsq / exp(a.log_Q[a.d_begin + dl])) / Tn;
+                    }
+                    term1 += -0.5 * logdet;                                  // :253
                     term2 += 0.5 * ht[1];                                    // :254
                 }
                 terms[4] = -term1 / Tn;                                      // :257

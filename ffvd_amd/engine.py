@@ -18,15 +18,22 @@ class ElboEngine:
 
     Shapes follow SURVEY.md: X (S, T+1, D); Z (M, D+C); U (M, D); logvariance (D,);
     loglengthscales (D, D+C); log_Q (D,); CC (D, Ydim); DD (Ydim,); log_Rchols (Ydim, Ydim).
+
+    route (collapsed branch only): "reference" forms F = K_fu L^-T and H = F^T F / Q + I in the reference's
+    op order; "gram" evaluates the same bound as log|K_uu + K_uf K_fu / Q| - log|K_uu| (about half the flops,
+    agrees to ~1e-9 relative; see include/ffvd_abi.h FFVD_ROUTE_*).
     """
 
     def __init__(self, T, D, C, M, S, Ydim=1, kernel_type="SquaredExponential", U_collapse=True,
                  prior_type="normal", device=0, d_begin=0, d_count=0, shared_terms=True,
-                 chains_per_pass=0, jitter=1e-5):
+                 chains_per_pass=0, jitter=1e-5, route="reference"):
         if kernel_type not in _lib.KERNEL_KIND:
             raise ValueError("Invalid kernel type")
         if prior_type not in _lib.PRIOR_TYPE:
             raise ValueError("Invalid prior type")           # models.py:41
+        if route not in _lib.ROUTE:
+            raise ValueError("route must be 'reference' or 'gram'")
+        self.route = route
         self.lib = _lib.load()
         self.T, self.D, self.C, self.M, self.S, self.Ydim = int(T), int(D), int(C), int(M), int(S), int(Ydim)
         self.P = self.D + self.C
@@ -38,7 +45,7 @@ class ElboEngine:
             d_count=self.d_count, shared_terms=int(self.shared_terms), dtype=0,
             kernel_kind=_lib.KERNEL_KIND[kernel_type], branch=_lib.BRANCH_B if U_collapse else _lib.BRANCH_A,
             prior_type=_lib.PRIOR_TYPE[prior_type], device_id=int(device), chains_per_pass=int(chains_per_pass),
-            reserved=0, jitter=float(jitter))
+            route=_lib.ROUTE[route], jitter=float(jitter))
         self._h = ct.c_void_p()
         _lib.check(self.lib.ffvd_create(ct.byref(cfg), ct.byref(self._h)), None, "ffvd_create")
         self._keep = {}

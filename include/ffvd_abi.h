@@ -45,6 +45,14 @@ extern "C" {
 #define FFVD_PRIOR_UNIFORM 0    /* Layer.prior_Z dgp_model.py:106-107 */
 #define FFVD_PRIOR_NORMAL  1    /* dgp_model.py:108-109 */
 
+/* How the collapsed bound (branch B) is evaluated.  Both are the same algebra:
+ *   REFERENCE: F = K_fu L^-T, H = F^T F / Q + I, exactly the reference's op order (conditionals_multi_output.py:242-255)
+ *   GRAM     : log|H| = log|K_uu + K_uf K_fu / Q| - log|K_uu|, b^T H^-1 b = g^T (K_uu + K_uf K_fu / Q)^-1 g / Q^2,
+ *              sum_t |F_t|^2 = tr(K_uu^-1 K_uf K_fu); about half the flops, K_fu L^-T is never formed.
+ *              Rounding differs: nll agrees with REFERENCE to ~1e-9 relative on the benchmark workloads.   */
+#define FFVD_ROUTE_REFERENCE 0
+#define FFVD_ROUTE_GRAM      1
+
 #define FFVD_PARAMS_ON_DEVICE 1u
 
 /* indices into the 8-double term vector written by ffvd_elbo*()               */
@@ -75,7 +83,7 @@ typedef struct ffvd_config {
     int32_t prior_type;   /* FFVD_PRIOR_*                                           */
     int32_t device_id;    /* HIP device ordinal                                     */
     int32_t chains_per_pass; /* chains whose T x M projections are resident at once; 0 = auto */
-    int32_t reserved;
+    int32_t route;        /* FFVD_ROUTE_*  (branch B only)                          */
     double  jitter;       /* 1e-5: conditionals_multi_output.py:108,159             */
 } ffvd_config;
 

@@ -75,6 +75,36 @@ def test_model_facade_matches_engine(actuator):
     assert t["later_term1"] == pytest.approx(float(g["B_later_term1"]), rel=RTOL)
 
 
+@pytest.mark.parametrize("name", ["tiny", "small", "ragged", "small_lin"])
+def test_gram_route_matches_golden(name):
+    """route="gram": log|K_uu + K_uf K_fu/Q| - log|K_uu| form of the collapsed bound.  Same algebra, different
+    rounding (error ~ eps * cond(K_uu) instead of eps * sqrt(cond)): nll to 1e-8, terms to 1e-7 relative (the
+    trace term is a cancellation, absolute 1e-9)."""
+    params, Y, c, meta = synthetic.make_named(name)
+    g = load_golden(name)
+    got = run_engine(params, Y, c, meta, collapse=True, route="gram")
+    for n in TERMS_B:
+        r = float(g["B_" + n])
+        assert got[n] == pytest.approx(r, rel=(1e-8 if n == "nll" else 1e-7), abs=1e-9), (n, got[n], r)
+    np.testing.assert_allclose(got["nll_per_chain"], g["B_nll_per_chain"], rtol=1e-8)
+    ref = run_engine(params, Y, c, meta, collapse=True)
+    assert got["nll"] == pytest.approx(ref["nll"], rel=1e-8)
+
+
+def test_gram_route_actuator(actuator):
+    params, Y, c = actuator
+    meta = dict(T=512, D=4, C=1, M=100, kernel_type="SquaredExponential")
+    p = dict(params)
+    p["X"] = params["X"][None]
+    got = run_engine(p, Y, c, meta, collapse=True, route="gram")
+    g = load_golden("actuator")
+    assert got["nll"] == pytest.approx(float(g["B_nll"]), rel=1e-8)
+    for n in TERMS_B:
+        assert got[n] == pytest.approx(float(g["B_" + n]), rel=1e-6, abs=1e-9)
+    with pytest.raises(ValueError):
+        run_engine(p, Y, c, meta, collapse=False, route="gram")     # explicit-U branch has no Gram form
+
+
 def test_chain_and_dim_sharding_sum_to_the_whole():
     """partial sums of chain shards / latent-dim shards add up to the unsharded sums."""
     params, Y, c, meta = synthetic.make_named("small")
@@ -171,6 +201,10 @@ def test_full_size_config2_properties():
         np.testing.assert_allclose(t2["nll_per_chain"], per[perm], rtol=1e-13)
         assert t2["nll"] == pytest.approx(t["nll"], rel=1e-13)
     assert t["nll"] == pytest.approx(per.mean(), rel=1e-13)
+    with ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], 4, route="gram") as e:
+        e.set_data(Y, c)
+        tg = e.nll_terms(params)
+    np.testing.assert_allclose(tg["nll_per_chain"], per, rtol=1e-8)
     for s in (0, 3):
         p = dict(params)
         p["X"] = params["X"][s]

@@ -1,12 +1,14 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import sys
 from ffvd_amd import synthetic
 from ffvd_amd.engine import ElboEngine
-params, Y, c, meta = synthetic.make_named("c2")
-e = ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], meta["S"]); e.set_data(Y, c); e.set_params(params)
-try:
-    e.elbo_sums()
-except Exception as ex: pass
-st=[e.profile_stages() for _ in range(3)][-1]
-print("RES", sys.argv[1:], "project_ms=%.3f gram_ms=%.3f" % (st["project_F"], st["gram_H"]))
+kw = dict(a.split("=") for a in sys.argv[1:] if "=" in a)
+route = kw.get("route", "reference")
+params, Y, c, meta = synthetic.make_named(kw.get("workload", "c2"))
+e = ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], meta["S"], route=route,
+               chains_per_pass=int(kw.get("cpp", 0)))
+e.set_data(Y, c); e.set_params(params)
+nll = e.nll_terms()["nll"]
+for _ in range(3): st = e.profile_stages()
+ms = e.time_elbo(20) / 20
+print("RES", sys.argv[1:], "nll=%.15g" % nll, "ms/iter=%.3f" % ms, {k: round(v, 3) for k, v in st.items()})
