@@ -254,14 +254,14 @@ void launch_kernel_diag(hipStream_t stream, int kind, const double *X, int N, in
 }
 
 // ---------------------------------------------------------------------------------------------
-// Extended blocked Cholesky (right-looking, NB = 64), three launches per block step:
+// Extended blocked Cholesky (right-looking, NB = 64), two launches per block step:
 //   panel(k):  rows below the diagonal block  R <- R * L_kk^{-T}   (forward substitution, lane = row,
 //              L_kk broadcast from LDS; one wavefront per 64 rows)
-//   trail(k):  C(i,j) -= P_i P_j^T for the remaining tiles (one wavefront per 64x64 tile, MFMA)
-//   diag(k+1): factorise the next 64x64 diagonal block
-// The 64x64 diagonal factorisation runs in ONE wavefront (lane = row, row in registers, pivot column broadcast
-// through LDS): no workgroup barrier, and no other workgroup reads a diagonal block before a finished launch
-// has published its factor.
+//   trail(k):  C(i,j) -= P_i P_j^T for the remaining tiles (one workgroup per 64x64 tile, MFMA); the workgroup
+//              of tile (k+1,k+1) goes on to factorise that diagonal block (look-ahead inside the launch)
+// The 64x64 diagonal factorisation runs in ONE workgroup (lane = row, 16 row entries per lane in registers, pivot
+// column broadcast through LDS), and no other workgroup reads a diagonal block before a finished launch has
+// published its factor.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ double readlane_f64(double v, int srclane) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
@@ -276,54 +276,66 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// In: a[k] = A[lane][k] (lower triangle of an SPD 64x64 block referenced).  Out: a[k] = L[lane][k] for k <= lane.
-// col: LDS scratch [2][NB].  Returns 0 or 1 + index of the first non-positive pivot.
-__device__ __forceinline__ int chol64_rows(double (&a)[NB], double (*col)[NB], const int lane) {
-    int bad = 0;
+// 64x64 Cholesky by ONE workgroup of 4 wavefronts: lane = row, wavefront w owns columns k = w (mod 4), so every
+// lane keeps 16 entries of its row in registers.  Per pivot: the owner wavefront scales column j, publishes it
+// through LDS, one workgroup barrier, then every wavefront updates its own columns (right-looking).
+// In: a[c] = A[lane][4c + w].  Out: a[c] = L[lane][4c + w] for 4c + w <= lane.  Returns 0 or 1 + first bad pivot
+// (identical in all threads).  col: LDS scratch [2][NB]; bad_s: LDS int.
+__device__ __forceinline__ int chol64_4w(double (&a)[16], double (*col)[NB], int *bad_s, const int lane, const int w) {
+    if (threadIdx.x == 0) *bad_s = 0;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-        const double ajj = readlane_f64(a[j], j);
-        if (!(ajj > 0.0) && bad == 0) bad = j + 1;
-        const double piv = sqrt(ajj);                       // tf.linalg.cholesky (conditionals_multi_output.py:28,162)
-        const double l = (lane > j) ? a[j] / piv : 0.0;
-        a[j] = (lane == j) ? piv : ((lane > j) ? l : a[j]);
-        col[j & 1][lane] = l;                               // pivot column, zero at and above the diagonal
-        wave_lds_sync();
-        // only k <= lane is meaningful; a scheduling fence every 8 columns keeps few LDS reads in flight
+        if ((j & 3) == w) {                                  // owner of column j (wave-uniform)
+            const double ajj = readlane_f64(a[j >> 2], j);
+            if (!(ajj > 0.0) && lane == 0 && *bad_s == 0) *bad_s = j + 1;
+            const double piv = sqrt(ajj);                   // tf.linalg.cholesky (conditionals_multi_output.py:28,162)
+            const double l = (lane > j) ? a[j >> 2] / piv : 0.0;
+            a[j >> 2] = (lane == j) ? piv : ((lane > j) ? l : a[j >> 2]);
+            col[j & 1][lane] = l;                            // pivot column, zero at and above the diagonal
+        }
+        __syncthreads();
+        const double l = col[j & 1][lane];
 #pragma unroll
-        for (int k = j + 1; k < NB; ++k) {
-            a[k] -= l * col[j & 1][k];
-            if (((k - j) & 7) == 0) __builtin_amdgcn_sched_barrier(0);
+        for (int c = 0; c < 16; ++c) {
+            const int kcol = 4 * c + w;                      // not a compile-time constant; the guard is cheap
+            if (4 * c + 3 > j) {                             // compile-time prune of finished column groups
+                const double lk = col[j & 1][kcol];
+                a[c] -= (kcol > j) ? l * lk : 0.0;           // only kcol <= lane is meaningful
+            }
         }
     }
-    return bad;
+    __syncthreads();
+    return *bad_s;
 }
 
-// Factorise the diagonal block held in LDS tile `Ts` (row-major, stride NB+1) and publish L in place (lower).
-__device__ __forceinline__ void diag_block_finish(double (*Ts)[NB + 1], double (*col)[NB], double *S, int n, int k0,
-                                                   int32_t *info_b, const int lane) {
-    double a[NB];
+// Factorise the diagonal block held in LDS tile `Ts` (row-major, stride NB+1) with all 256 threads of the
+// workgroup and publish L in place (lower triangle of the global block).
+__device__ __forceinline__ void diag_block_finish(double (*Ts)[NB + 1], double (*col)[NB], int *bad_s, double *S, int n,
+                                                   int k0, int32_t *info_b) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double a[16];
 #pragma unroll
-    for (int c = 0; c < NB; ++c) a[c] = Ts[lane][c];
-    const int bad = chol64_rows(a, col, lane);
-    if (bad && lane == 0 && *info_b == 0) *info_b = k0 + bad;
-    wave_lds_sync();
+    for (int c = 0; c < 16; ++c) a[c] = Ts[lane][4 * c + w];
+    const int bad = chol64_4w(a, col, bad_s, lane, w);
+    if (bad && tid == 0 && *info_b == 0) *info_b = k0 + bad;
 #pragma unroll
-    for (int c = 0; c < NB; ++c) Ts[lane][c] = a[c];
-    wave_lds_sync();
-    for (int r = 0; r < NB; ++r)
+    for (int c = 0; c < 16; ++c) Ts[lane][4 * c + w] = a[c];
+    __syncthreads();
+    for (int r = tid >> 6; r < NB; r += 4)
         if (lane <= r) S[(size_t)(k0 + r) * n + k0 + lane] = Ts[r][lane];         // coalesced rows of L
 }
 
-__global__ __launch_bounds__(64) void potrf_diag_kernel(double *A, int n, int k, size_t slab_stride, int32_t *info) {
+__global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, int n, int k, size_t slab_stride, int32_t *info) {
     __shared__ double Ts[NB][NB + 1];
     __shared__ double col[2][NB];
-    const int b = blockIdx.x, lane = threadIdx.x;
+    __shared__ int bad_s;
+    const int b = blockIdx.x, tid = threadIdx.x;
     double *S = A + (size_t)b * slab_stride;
     const int k0 = k * NB;
-    for (int r = 0; r < NB; ++r) Ts[r][lane] = S[(size_t)(k0 + r) * n + k0 + lane];
-    wave_lds_sync();
-    diag_block_finish(Ts, col, S, n, k0, info + b, lane);
+    for (int r = tid >> 6; r < NB; r += 4) Ts[r][tid & 63] = S[(size_t)(k0 + r) * n + k0 + (tid & 63)];
+    __syncthreads();
+    diag_block_finish(Ts, col, &bad_s, S, n, k0, info + b);
 }
 
 // tile bookkeeping shared by the panel and trailing kernels
@@ -369,10 +381,19 @@ __global__ __launch_bounds__(64) void potrf_panel_kernel(double *A, int n, int k
     for (int r = 0; r < NB; ++r) R[(size_t)r * n + lane] = Rs[r][lane];
 }
 
-// Trailing update of step k: one wavefront per 64x64 tile,  C(i,j) -= P_i * P_j^T  with P = solved panel.
+// Trailing update of step k: one workgroup (4 wavefronts, a 32x32 quadrant each) per 64x64 tile,
+// C(i,j) -= P_i * P_j^T with P = solved panel, both panel blocks staged through LDS with wide coalesced loads.
 // Tiles: main lower triangle (k < j <= i < nb) then extra-row tiles (e, j) for j in (k, nb).
-__global__ __launch_bounds__(64) void potrf_trail_kernel(double *A, int n, int k, int nmain_tiles, int n1,
-                                                         size_t slab_stride) {
+// Tile 0 is the next diagonal block (k+1,k+1): wavefront 0 of its workgroup factorises it right away, so the
+// 64-pivot chain of step k+1 overlaps with the rest of step k's trailing update (look-ahead inside one launch).
+constexpr int TR_LD = NB + 2;      // LDS row stride of the staged panel blocks (doubles)
+
+__global__ __launch_bounds__(256) void potrf_trail_kernel(double *A, int n, int k, int nmain_tiles, int n1,
+                                                          size_t slab_stride, int32_t *info) {
+    __shared__ double Pi_s[NB][TR_LD];
+    __shared__ double Pj_s[NB][TR_LD];
+    __shared__ double col[2][NB];
+    __shared__ int bad_s;
     const int b = blockIdx.y;
     const int tile = blockIdx.x;
     double *S = A + (size_t)b * slab_stride;
@@ -390,45 +411,78 @@ __global__ __launch_bounds__(64) void potrf_trail_kernel(double *A, int n, int k
         rowblk0 = n + e * NB;
         colblk = (k + 1 + j) * NB;
     }
-    const int lane = threadIdx.x, lr = lane & 15, lk = lane >> 4;
-    d4 acc[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[a][c] = (d4){0.0, 0.0, 0.0, 0.0};
+    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qr = wave >> 1, qc = wave & 1;          // 32x32 quadrant of the tile
+    const bool same = (rowblk0 == colblk);
     const double *Pi = S + (size_t)rowblk0 * n + k0;
     const double *Pj = S + (size_t)colblk * n + k0;
-#pragma unroll 2
-    for (int ks = 0; ks < NB / 4; ++ks) {
-        double af[4], bf[4];
+    // stage: thread t moves 16 bytes of rows (t >> 5) + 8 i, columns 2 (t & 31)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            af[t] = Pi[(size_t)(16 * t + lr) * n + 4 * ks + lk];   // A[row][k]
-            bf[t] = Pj[(size_t)(16 * t + lr) * n + 4 * ks + lk];   // B[k][col] = P_j[col][k]
+    for (int i = 0; i < 8; ++i) {
+        const int r = (tid >> 5) + 8 * i, c2 = 2 * (tid & 31);
+        const double2 v = *reinterpret_cast<const double2 *>(Pi + (size_t)r * n + c2);
+        Pi_s[r][c2] = v.x; Pi_s[r][c2 + 1] = v.y;
+        if (!same) {
+            const double2 w = *reinterpret_cast<const double2 *>(Pj + (size_t)r * n + c2);
+            Pj_s[r][c2] = w.x; Pj_s[r][c2 + 1] = w.y;
+        }
+    }
+    __syncthreads();
+    const double(*Bp)[TR_LD] = same ? Pi_s : Pj_s;
+    d4 acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int ks = 0; ks < NB / 4; ++ks) {
+        double af[2], bf[2];
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            af[x] = Pi_s[qr * 32 + 16 * x + lr][4 * ks + lk];     // A[row][k]
+            bf[x] = Bp[qc * 32 + 16 * x + lr][4 * ks + lk];       // B[k][col] = P_j[col][k]
         }
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int x = 0; x < 2; ++x)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[a][c] = mfma_f64(af[a], bf[c], acc[a][c]);
+            for (int y = 0; y < 2; ++y) acc[x][y] = mfma_f64(af[x], bf[y], acc[x][y]);
     }
     double *Ct = S + (size_t)rowblk0 * n + colblk;
+    if (tile != 0) {
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+        for (int x = 0; x < 2; ++x)
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+            for (int y = 0; y < 2; ++y)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const size_t off = (size_t)(qr * 32 + 16 * x + lk + 4 * q) * n + qc * 32 + 16 * y + lr;
+                    Ct[off] -= acc[x][y][q];
+                }
+        return;
+    }
+    // tile 0 = next diagonal block: assemble the updated block in LDS (Pj_s is free here), factorise, publish
+    __syncthreads();
+    double(*Ts)[NB + 1] = reinterpret_cast<double(*)[NB + 1]>(&Pj_s[0][0]);     // 64 x 65 <= 64 x 66 doubles
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                size_t off = (size_t)(16 * a + lk + 4 * q) * n + 16 * c + lr;
-                Ct[off] -= acc[a][c][q];
+                const int r = qr * 32 + 16 * x + lk + 4 * q, cc = qc * 32 + 16 * y + lr;
+                Ts[r][cc] = Ct[(size_t)r * n + cc] - acc[x][y][q];
             }
+    __syncthreads();
+    diag_block_finish(Ts, col, &bad_s, S, n, k0 + NB, info + b);
 }
 
 void launch_potrf_ext(hipStream_t stream, double *A, int n, int extra_rows, int identity_extra, int batch,
                       size_t slab_stride, int32_t *info) {
     const int nb = n / NB;
     const int nextra_all = extra_rows / NB;
+    hipLaunchKernelGGL(potrf_diag_kernel, dim3(batch), dim3(256), 0, stream, A, n, 0, slab_stride, info);
     for (int k = 0; k < nb; ++k) {
-        hipLaunchKernelGGL(potrf_diag_kernel, dim3(batch), dim3(64), 0, stream, A, n, k, slab_stride, info);
         const int nmain = nb - k - 1;
         // identity extras: block-row e of L^{-T} is zero in block-columns < e, so only e <= k is live at step k
         const int nextra = identity_extra ? ((k + 1 < nextra_all) ? k + 1 : nextra_all) : nextra_all;
@@ -440,8 +494,8 @@ void launch_potrf_ext(hipStream_t stream, double *A, int n, int extra_rows, int 
         if (n1 > 0) {
             const int nmain_tiles = n1 * (n1 + 1) / 2;
             const int ntiles = nmain_tiles + nextra * n1;
-            hipLaunchKernelGGL(potrf_trail_kernel, dim3(ntiles, batch), dim3(64), 0, stream, A, n, k, nmain_tiles, n1,
-                               slab_stride);
+            hipLaunchKernelGGL(potrf_trail_kernel, dim3(ntiles, batch), dim3(256), 0, stream, A, n, k, nmain_tiles, n1,
+                               slab_stride, info);
         }
     }
 }
