@@ -41,6 +41,7 @@ struct ffvd_handle {
     double *Kuu = nullptr, *F = nullptr, *H = nullptr, *rowsq = nullptr, *fmean = nullptr;
     double *Kcopy = nullptr, *Linv = nullptr, *Kinv = nullptr, *trpart = nullptr, *kterms = nullptr;   // GRAM route
     int ntiles = 0;
+    double *chain_partial = nullptr;
     double *hterms = nullptr, *chain_terms = nullptr, *chain_nll = nullptr, *out_terms = nullptr;
     int32_t *info = nullptr;
     // pinned host staging
@@ -150,6 +151,7 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
     }
     HIP_TRY(dev_alloc(h, &h->hterms, (size_t)h->nbatch * 2));
     HIP_TRY(dev_alloc(h, &h->chain_terms, (size_t)c.S_local * 8));
+    HIP_TRY(dev_alloc(h, &h->chain_partial, (size_t)c.S_local * 32));
     HIP_TRY(dev_alloc(h, &h->chain_nll, (size_t)c.S_local));
     HIP_TRY(dev_alloc(h, &h->out_terms, (size_t)8));
     HIP_TRY(dev_alloc(h, &h->info, (size_t)(Dl + h->nbatch)));
@@ -356,7 +358,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
     ra.S = c.S_local; ra.ng = h->ng; ra.shared_terms = c.shared_terms;
     ra.xk = p.X; ra.xk_chain_stride = (size_t)(c.T + 1) * c.D; ra.xk_ld = c.D; ra.xk_cols = c.D;
     ra.rowsq = gram_route ? nullptr : h->rowsq; ra.fmean = h->fmean; ra.chain_terms = h->chain_terms;
-    launch_chain_reduce(s, ra);
+    launch_chain_reduce(s, ra, h->chain_partial);
     FinalizeArgs fa{};
     fa.kind = c.kernel_kind; fa.branch = c.branch; fa.prior_type = c.prior_type; fa.shared_terms = c.shared_terms;
     fa.T = c.T; fa.D = c.D; fa.P = P; fa.M = c.M; fa.Ydim = c.Ydim; fa.Dl = Dl; fa.d_begin = c.d_begin;
@@ -738,7 +740,9 @@ extern "C" int ffvd_op_collapse(int kind, const double *Lm_inverse_seq, const do
     ra.C = 0; ra.Ydim = 0; ra.Dl = D; ra.d_begin = 0; ra.S = 1; ra.ng = ng; ra.shared_terms = 0;
     ra.xk = dXc; ra.xk_chain_stride = 0; ra.xk_ld = P; ra.xk_cols = P; ra.rowsq = rowsq; ra.fmean = nullptr;
     ra.chain_terms = cterms;
-    launch_chain_reduce(sc.stream, ra);
+    double *cpart = sc.alloc<double>(32);
+    if (!cpart) return set_error(nullptr, FFVD_ENOMEM, "ffvd_op_collapse: device allocation failed");
+    launch_chain_reduce(sc.stream, ra, cpart);
     std::vector<double> ht((size_t)D * 2), ct(8);
     std::vector<int32_t> hinfo(D);
     HIP_TRY(hipMemcpyAsync(ht.data(), hterms, ht.size() * sizeof(double), hipMemcpyDeviceToHost, sc.stream));

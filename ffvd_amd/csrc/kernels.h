@@ -109,7 +109,8 @@ struct ReduceArgs {
     const double *rowsq, *fmean;   // [S*Dl][ng][Tp]
     double *chain_terms;           // [S][8] partial sums per chain
 };
-void launch_chain_reduce(hipStream_t stream, const ReduceArgs &a);
+// partial: scratch of S * 8 * 4 doubles
+void launch_chain_reduce(hipStream_t stream, const ReduceArgs &a, double *partial);
 
 struct FinalizeArgs {
     int kind, branch, prior_type, shared_terms;

@@ -288,8 +288,17 @@ __device__ __forceinline__ int chol64_4w(double (&a)[16], double (*col)[NB], int
         if ((j & 3) == w) {                                  // owner of column j (wave-uniform)
             const double ajj = readlane_f64(a[j >> 2], j);
             if (!(ajj > 0.0) && lane == 0 && *bad_s == 0) *bad_s = j + 1;
-            const double piv = sqrt(ajj);                   // tf.linalg.cholesky (conditionals_multi_output.py:28,162)
-            const double l = (lane > j) ? a[j >> 2] / piv : 0.0;
+            // pivot of tf.linalg.cholesky (conditionals_multi_output.py:28,162): sqrt(ajj) and 1/sqrt(ajj) from the
+            // hardware reciprocal square root + two Newton steps + one correction (about 1 ulp), which is far
+            // shorter than the IEEE sqrt and divide expansions that would sit on the 64-pivot critical path
+            double y = __builtin_amdgcn_rsq(ajj);
+            const double hx = 0.5 * ajj;
+            y = y * (1.5 - hx * y * y);
+            y = y * (1.5 - hx * y * y);
+            double piv = ajj * y;
+            piv = piv + 0.5 * y * (ajj - piv * piv);
+            y = y + y * (1.0 - piv * y);
+            const double l = (lane > j) ? a[j >> 2] * y : 0.0;
             a[j >> 2] = (lane == j) ? piv : ((lane > j) ? l : a[j >> 2]);
             col[j & 1][lane] = l;                            // pivot column, zero at and above the diagonal
         }
@@ -910,13 +919,14 @@ void launch_h_finish(hipStream_t stream, const double *H, int Mp, size_t h_strid
 // Per-chain streaming reductions (likelihoods.py:76-111; dgp_model.py:250-252,283-284,346-351)
 // chain_terms[s] = { lik quadratic sum, transition quadratic sum, trace sum, prior_x_0 }
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void chain_reduce_kernel(ReduceArgs a) {
+constexpr int CR_SPLIT = 8;     // workgroups per chain
+__global__ __launch_bounds__(256) void chain_reduce_kernel(ReduceArgs a, double *partial /*[S][CR_SPLIT][4]*/) {
     __shared__ double scratch[256];
-    const int s = blockIdx.x, tid = threadIdx.x;
+    const int s = blockIdx.x, part = blockIdx.y, tid = threadIdx.x;
     const int T = a.T, D = a.D;
     const double *Xs = a.X + (size_t)s * (T + 1) * D;
     double lik = 0.0, xq = 0.0, tr = 0.0;
-    for (int t = tid; t < T; t += 256) {
+    for (int t = part * 256 + tid; t < T; t += 256 * CR_SPLIT) {
         if (a.shared_terms) {
             for (int j = 0; j < a.Ydim; ++j) {
                 double ym = 0.0;
@@ -956,14 +966,27 @@ __global__ __launch_bounds__(256) void chain_reduce_kernel(ReduceArgs a) {
     xq = block_sum_256(xq, scratch);
     tr = block_sum_256(tr, scratch);
     if (tid == 0) {
-        double px0 = 0.0;
-        for (int d = 0; d < D; ++d) px0 += Xs[d] * Xs[d];
-        double *o = a.chain_terms + (size_t)s * 8;
-        o[0] = lik; o[1] = xq; o[2] = tr; o[3] = -px0 / 2.0;     // prior_x_0 dgp_model.py:252
+        double *o = partial + ((size_t)s * CR_SPLIT + part) * 4;
+        o[0] = lik; o[1] = xq; o[2] = tr;
     }
 }
-void launch_chain_reduce(hipStream_t stream, const ReduceArgs &a) {
-    hipLaunchKernelGGL(chain_reduce_kernel, dim3(a.S), dim3(256), 0, stream, a);
+__global__ void chain_combine_kernel(ReduceArgs a, const double *partial) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= a.S) return;
+    double lik = 0.0, xq = 0.0, tr = 0.0;
+    for (int p = 0; p < CR_SPLIT; ++p) {
+        const double *o = partial + ((size_t)s * CR_SPLIT + p) * 4;
+        lik += o[0]; xq += o[1]; tr += o[2];
+    }
+    const double *Xs = a.X + (size_t)s * (a.T + 1) * a.D;
+    double px0 = 0.0;
+    for (int d = 0; d < a.D; ++d) px0 += Xs[d] * Xs[d];
+    double *o = a.chain_terms + (size_t)s * 8;
+    o[0] = lik; o[1] = xq; o[2] = tr; o[3] = -px0 / 2.0;     // prior_x_0 dgp_model.py:252
+}
+void launch_chain_reduce(hipStream_t stream, const ReduceArgs &a, double *partial) {
+    hipLaunchKernelGGL(chain_reduce_kernel, dim3(a.S, CR_SPLIT), dim3(256), 0, stream, a, partial);
+    hipLaunchKernelGGL(chain_combine_kernel, dim3((a.S + 63) / 64), dim3(64), 0, stream, a, partial);
 }
 
 // conditional() outputs (conditionals_multi_output.py:41,48,120): mean N x D, var N x D
@@ -1048,46 +1071,48 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
         sh[5] = logsqQ;
     }
     __syncthreads();
-    if (tid == 0) {
-        double sums[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int s = 0; s < a.S; ++s) {
-            const double *ct = a.chain_terms + (size_t)s * 8;
-            double terms[7] = {0, 0, 0, 0, 0, 0, 0};
-            double prior = sh[0] + sh[3];
-            if (a.shared_terms) {
-                prior += sh[2] + ct[3] + sh[1];
-                terms[1] = -(ct[0] + Tn * (-sh[4])) / Tn;                  // nll_log_likelihood :264
-            }
-            terms[0] = -prior / Tn;                                          // nll_part_prior :286 / :296
-            terms[2] = -(ct[1] + Tn * (-sh[5])) / Tn;                      // x_t_prior_Q :283-284 / :294
-            terms[3] = -ct[2] / Tn;                                          // trace term :257 / :292
-            if (a.branch == 1) {
-                double term1 = 0.0, term2 = 0.0;
-                for (int dl = 0; dl < a.Dl; ++dl) {
-                    const size_t bb = (size_t)s * a.Dl + dl;
-                    const double *ht = a.hterms + bb * 2;
-                    double logdet = ht[0];
-                    if (a.route == 1) {
-                        // log|I + L^-1 G L^-T / Q| = log|K + G/Q| - log|K|  with K = K_uu + jitter I
-                        logdet -= a.kterms[2 * dl];
-                        // sum_t |F_t|^2 = tr(K^-1 K_uf K_fu): add it back to the trace term (:255)
-                        double fsq = 0.0;
-                        for (int t = 0; t < a.ntiles; ++t) fsq += a.trpart[bb * a.ntiles + t];
-                        terms[3] += -(0.5 * fsq / exp(a.log_Q[a.d_begin + dl])) / Tn;
-                    }
-                    term1 += -0.5 * logdet;                                  // :253
-                    term2 += 0.5 * ht[1];                                    // :254
-                }
-                terms[4] = -term1 / Tn;                                      // :257
-                terms[5] = -term2 / Tn;
-            }
-            terms[6] = terms[0] + terms[1] + terms[2] + terms[3] + terms[4] + terms[5];   // :288 / :297
-            a.chain_nll[s] = terms[6];
-            for (int i = 0; i < 7; ++i) sums[i] += terms[i];
+    // per-chain assembly: one thread per chain (strided), then a fixed-order sum over chains
+    double part[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int s = tid; s < a.S; s += 256) {
+        const double *ct = a.chain_terms + (size_t)s * 8;
+        double terms[7] = {0, 0, 0, 0, 0, 0, 0};
+        double prior = sh[0] + sh[3];
+        if (a.shared_terms) {
+            prior += sh[2] + ct[3] + sh[1];
+            terms[1] = -(ct[0] + Tn * (-sh[4])) / Tn;                  // nll_log_likelihood :264
         }
-        sums[7] = a.shared_terms ? (double)a.S : 0.0;
-        for (int i = 0; i < 8; ++i) a.out_terms[i] = sums[i];
+        terms[0] = -prior / Tn;                                          // nll_part_prior :286 / :296
+        terms[2] = -(ct[1] + Tn * (-sh[5])) / Tn;                      // x_t_prior_Q :283-284 / :294
+        terms[3] = -ct[2] / Tn;                                          // trace term :257 / :292
+        if (a.branch == 1) {
+            double term1 = 0.0, term2 = 0.0;
+            for (int dl = 0; dl < a.Dl; ++dl) {
+                const size_t bb = (size_t)s * a.Dl + dl;
+                const double *ht = a.hterms + bb * 2;
+                double logdet = ht[0];
+                if (a.route == 1) {
+                    // log|I + L^-1 G L^-T / Q| = log|K + G/Q| - log|K|  with K = K_uu + jitter I
+                    logdet -= a.kterms[2 * dl];
+                    // sum_t |F_t|^2 = tr(K^-1 K_uf K_fu): add it back to the trace term (:255)
+                    double fsq = 0.0;
+                    for (int t = 0; t < a.ntiles; ++t) fsq += a.trpart[bb * a.ntiles + t];
+                    terms[3] += -(0.5 * fsq / exp(a.log_Q[a.d_begin + dl])) / Tn;
+                }
+                term1 += -0.5 * logdet;                                  // :253
+                term2 += 0.5 * ht[1];                                    // :254
+            }
+            terms[4] = -term1 / Tn;                                      // :257
+            terms[5] = -term2 / Tn;
+        }
+        terms[6] = terms[0] + terms[1] + terms[2] + terms[3] + terms[4] + terms[5];   // :288 / :297
+        a.chain_nll[s] = terms[6];
+        for (int i = 0; i < 7; ++i) part[i] += terms[i];
     }
+    for (int i = 0; i < 7; ++i) {
+        const double v = block_sum_256(part[i], scratch);
+        if (tid == 0) a.out_terms[i] = v;
+    }
+    if (tid == 0) a.out_terms[7] = a.shared_terms ? (double)a.S : 0.0;
 }
 void launch_finalize(hipStream_t stream, const FinalizeArgs &a) {
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, stream, a);
