@@ -793,3 +793,47 @@ extern "C" int ffvd_op_conditional(int kind, const double *Xnew, int N, const do
     HIP_TRY(hipMemcpyAsync(var, dvar, (size_t)N * D * sizeof(double), hipMemcpyDeviceToHost, sc.stream));
     return check_kuu_info(sc, w, D, "ffvd_op_conditional");
 }
+
+extern "C" int ffvd_op_predict_mean(const double *X_end, int N, int D, const double *CC, const double *DD, int Ydim,
+                                    double *out) {
+    if (!X_end || !CC || !DD || !out || N < 0 || D < 1 || Ydim < 1)
+        return set_error(nullptr, FFVD_EINVAL, "ffvd_op_predict_mean: bad argument");
+    OP_BEGIN("ffvd_op_predict_mean");
+    if (N == 0) return FFVD_OK;
+    double *dX = sc.upload(X_end, (size_t)N * D), *dC = sc.upload(CC, (size_t)D * Ydim), *dD = sc.upload(DD, Ydim);
+    double *dO = sc.alloc<double>((size_t)N * Ydim);
+    if (!dX || !dC || !dD || !dO) return set_error(nullptr, FFVD_ENOMEM, "ffvd_op_predict_mean: device allocation or upload failed");
+    launch_predict_mean(sc.stream, dX, N, D, dC, dD, Ydim, dO);
+    HIP_TRY(hipMemcpyAsync(out, dO, (size_t)N * Ydim * sizeof(double), hipMemcpyDeviceToHost, sc.stream));
+    HIP_TRY(hipStreamSynchronize(sc.stream));
+    return FFVD_OK;
+}
+
+extern "C" int ffvd_op_logdensity_norm_diag(int nonvec, const double *y, const double *ymean, const double *Rchols, int N,
+                                            int J, double *out) {
+    if (!y || !ymean || !Rchols || !out || N < 0 || J < 1)
+        return set_error(nullptr, FFVD_EINVAL, "ffvd_op_logdensity_norm_diag: bad argument");
+    OP_BEGIN("ffvd_op_logdensity_norm_diag");
+    if (N == 0) return FFVD_OK;
+    const size_t nout = nonvec ? (size_t)N * J : (size_t)N;
+    double *dy = sc.upload(y, (size_t)N * J), *dm = sc.upload(ymean, (size_t)N * J), *dR = sc.upload(Rchols, J);
+    double *dO = sc.alloc<double>(nout);
+    if (!dy || !dm || !dR || !dO) return set_error(nullptr, FFVD_ENOMEM, "ffvd_op_logdensity_norm_diag: device allocation or upload failed");
+    launch_logdensity(sc.stream, nonvec ? 1 : 0, dy, dm, dR, N, J, dO);
+    HIP_TRY(hipMemcpyAsync(out, dO, nout * sizeof(double), hipMemcpyDeviceToHost, sc.stream));
+    HIP_TRY(hipStreamSynchronize(sc.stream));
+    return FFVD_OK;
+}
+
+extern "C" int ffvd_op_get_rand(const double *mean, const double *var, const double *eps, int64_t n, double *out) {
+    if (!mean || !var || !eps || !out || n < 0) return set_error(nullptr, FFVD_EINVAL, "ffvd_op_get_rand: bad argument");
+    OP_BEGIN("ffvd_op_get_rand");
+    if (n == 0) return FFVD_OK;
+    double *dm = sc.upload(mean, (size_t)n), *dv = sc.upload(var, (size_t)n), *de = sc.upload(eps, (size_t)n);
+    double *dO = sc.alloc<double>((size_t)n);
+    if (!dm || !dv || !de || !dO) return set_error(nullptr, FFVD_ENOMEM, "ffvd_op_get_rand: device allocation or upload failed");
+    launch_get_rand(sc.stream, dm, dv, de, (size_t)n, dO);
+    HIP_TRY(hipMemcpyAsync(out, dO, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, sc.stream));
+    HIP_TRY(hipStreamSynchronize(sc.stream));
+    return FFVD_OK;
+}

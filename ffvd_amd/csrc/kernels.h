@@ -132,6 +132,13 @@ void launch_conditional_finish(hipStream_t stream, int kind, const double *x, in
                                const double *rowsq, const double *fmean, int ng, int Tp, int D, double *mean,
                                double *var);
 
+// operator-API elementwise kernels
+void launch_predict_mean(hipStream_t stream, const double *X, int N, int D, const double *CC, const double *DD, int J,
+                         double *out);
+void launch_logdensity(hipStream_t stream, int mode, const double *y, const double *ymean, const double *R, int N, int J,
+                       double *out);
+void launch_get_rand(hipStream_t stream, const double *mean, const double *var, const double *eps, size_t n, double *out);
+
 // small utilities
 void launch_fill(hipStream_t stream, double *p, size_t n, double v);
 

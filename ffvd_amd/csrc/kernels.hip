@@ -1018,6 +1018,54 @@ void launch_conditional_finish(hipStream_t stream, int kind, const double *x, in
                        variance, rowsq, fmean, ng, Tp, D, mean, var);
 }
 
+// Operator-API elementwise kernels (likelihoods.py:76-79, 89-111; utils.py:11)
+__global__ void predict_mean_kernel(const double *X, int N, int D, const double *CC, const double *DD, int J, double *out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * J) return;
+    const int n = idx / J, j = idx % J;
+    double v = 0.0;
+    for (int d = 0; d < D; ++d) v += X[(size_t)n * D + d] * CC[(size_t)d * J + j];     // tf.matmul(X_end, CC)
+    out[idx] = v + DD[j];                                                              // + DD
+}
+// mode 0: logdensity_norm_diag (N outputs), mode 1: logdensity_norm_diag_nonvec (N x J outputs)
+__global__ void logdensity_kernel(int mode, const double *y, const double *ymean, const double *R, int N, int J, double *out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (mode == 1) {
+        if (idx >= N * J) return;
+        const int j = idx % J;
+        const double r = (y[idx] - ymean[idx]) / R[j];
+        out[idx] = -0.5 * (r * r) + (-log(R[j]));
+        return;
+    }
+    if (idx >= N) return;
+    double e = 0.0, lr = 0.0;
+    for (int j = 0; j < J; ++j) {
+        const double r = (y[(size_t)idx * J + j] - ymean[(size_t)idx * J + j]) / R[j];
+        e += r * r;
+        lr += log(R[j]);
+    }
+    out[idx] = -0.5 * e + (-lr);
+}
+__global__ void get_rand_kernel(const double *mean, const double *var, const double *eps, size_t n, double *out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = mean[i] + eps[i] * sqrt(var[i]);
+}
+void launch_predict_mean(hipStream_t stream, const double *X, int N, int D, const double *CC, const double *DD, int J,
+                         double *out) {
+    if (N * J == 0) return;
+    hipLaunchKernelGGL(predict_mean_kernel, dim3((N * J + 255) / 256), dim3(256), 0, stream, X, N, D, CC, DD, J, out);
+}
+void launch_logdensity(hipStream_t stream, int mode, const double *y, const double *ymean, const double *R, int N, int J,
+                       double *out) {
+    const int n = mode == 1 ? N * J : N;
+    if (n == 0) return;
+    hipLaunchKernelGGL(logdensity_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, mode, y, ymean, R, N, J, out);
+}
+void launch_get_rand(hipStream_t stream, const double *mean, const double *var, const double *eps, size_t n, double *out) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(get_rand_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, mean, var, eps, n, out);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Priors + nll assembly (dgp_model.py:105-143, 259-297, 326-334)
 // ---------------------------------------------------------------------------------------------

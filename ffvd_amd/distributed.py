@@ -50,7 +50,7 @@ def finish(sums8):
 def all_reduce_sums(tensor, group=None):
     """In-place all-reduce(sum) of the 8-double partial-sum tensor (device tensor under RCCL, CPU under gloo)."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=group)
     return tensor
 

@@ -167,6 +167,15 @@ int  ffvd_op_conditional(int kind, const double *Xnew, int N, const double *Z, i
                          const double *logvariance, const double *loglengthscales, const double *f,
                          double jitter, double *mean, double *var);
 
+/* Gaussian.predict_mean(X_end) = X_end @ CC + DD (likelihoods.py:76-79). X_end: N x D, out: N x Ydim. */
+int  ffvd_op_predict_mean(const double *X_end, int N, int D, const double *CC, const double *DD, int Ydim, double *out);
+/* logdensity_norm_diag (nonvec = 0, out: N; likelihoods.py:96-111) / logdensity_norm_diag_nonvec (nonvec = 1,
+ * out: N x J; likelihoods.py:89-93).  y, ymean: N x J; Rchols: J.  No log(2 pi) constants, as in the reference. */
+int  ffvd_op_logdensity_norm_diag(int nonvec, const double *y, const double *ymean, const double *Rchols, int N, int J,
+                                  double *out);
+/* get_rand (utils.py:11, diagonal case) with the standard-normal draw injected: out = mean + eps * sqrt(var). */
+int  ffvd_op_get_rand(const double *mean, const double *var, const double *eps, int64_t n, double *out);
+
 #ifdef __cplusplus
 }
 #endif

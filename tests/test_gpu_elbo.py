@@ -163,6 +163,47 @@ def test_wide_inputs_and_multi_output():
     assert_terms(got, ref, TERMS_B)
 
 
+@pytest.mark.parametrize("route", ["reference", "gram"])
+def test_more_than_512_inducing_points(route):
+    """M = 600 -> Mp = 640: two column groups in the projection kernel, 15 Gram tiles, 10 Cholesky block steps."""
+    params, Y, c, meta = synthetic.make_workload(T=700, D=2, C=1, M=600, S=2)
+    got = run_engine(params, Y, c, meta, collapse=True, route=route)
+    ref = orc.nll_terms_chains(params, Y, c, U_collapse=True)
+    tol = 1e-9 if route == "reference" else 1e-7
+    # with 600 inducing points for 700 transitions the trace term is ~2e-5, a cancellation of two O(1) numbers:
+    # the Gram route's absolute error (~ eps * cond(K_uu)) is 1e-9 there, i.e. large only relative to that term
+    atol = 1e-10 if route == "reference" else 1e-8
+    for n in TERMS_B:
+        assert got[n] == pytest.approx(ref[n], rel=tol, abs=atol), (n, got[n], ref[n])
+    assert got["nll"] == pytest.approx(ref["nll"], rel=1e-8)
+    if route == "reference":
+        got = run_engine(params, Y, c, meta, collapse=False)
+        ref = orc.nll_terms_chains(params, Y, c, U_collapse=False)
+        assert_terms(got, ref, TERMS_A)
+
+
+def test_rccl_all_reduce_on_the_engine_buffer():
+    """The multi-GPU step on one rank: finalize writes the 8 partial sums into a torch CUDA tensor and RCCL
+    all-reduces that very buffer (world_size 1 exercises init, the pointer hand-off and the collective call)."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from ffvd_amd.distributed import ShardedElbo, finish
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        params, Y, c, meta = synthetic.make_named("small")
+        sh = ShardedElbo(params, Y, c, meta, rank=0, world=1, mode="chains", device=0)
+        t = finish(sh.step())
+        g = load_golden("small")
+        assert t["nll"] == pytest.approx(float(g["B_nll"]), rel=RTOL)
+        t2 = finish(sh.step())
+        assert t2 == t
+    finally:
+        dist.destroy_process_group()
+
+
 def test_not_positive_definite_is_reported():
     params, Y, c, meta = synthetic.make_named("tiny")
     p = dict(params)

@@ -8,6 +8,7 @@ import pytest
 from conftest import GOLDEN
 from ffvd_amd import _lib, synthetic
 from ffvd_amd import conditionals, conditionals_multi_output as cmo
+from ffvd_amd import likelihoods, utils
 from ffvd_amd.kernels import LinearK, SquaredExponential
 from oracle import ffvd_oracle as orc
 
@@ -119,3 +120,24 @@ def test_collapse_matches_oracle():
     ref = orc.collapse_after_kernel_precalculation(list(g["Lm_inverse_seq"]), xc, X0, params["Z"], okern, Q, T, 2 * T)
     out3 = cmo.collapse_after_kernel_precalculation(list(g["Lm_inverse_seq"]), xc, X0, params["Z"], kern, Q, T, 2 * T)
     np.testing.assert_allclose(out3, ref, rtol=1e-9)
+
+
+def test_likelihood_operators_match_oracle():
+    """likelihoods.py:76-111 and utils.py:11 as standalone operators (rows a8-a10, a13 of SURVEY 8a)."""
+    rng = np.random.default_rng(7)
+    N, D, J = 301, 4, 2
+    X = rng.standard_normal((N, D))
+    lik = likelihoods.Gaussian(J, D, CC=rng.standard_normal((D, J)), DD=rng.standard_normal(J),
+                               RR_chol=np.array([[0.4, 0.9], [1.0, 1.0]]))
+    ym = lik.predict_mean(X)
+    np.testing.assert_allclose(ym, orc.predict_mean(X, lik.CC, lik.DD), rtol=1e-14, atol=1e-15)
+    y = rng.standard_normal((N, J))
+    R = lik.Rchols[0]
+    np.testing.assert_allclose(likelihoods.logdensity_norm_diag(y, ym, R), orc.logdensity_norm_diag(y, ym, R), rtol=1e-13)
+    np.testing.assert_allclose(likelihoods.logdensity_norm_diag_nonvec(y, ym, R),
+                               orc.logdensity_norm_diag_nonvec(y, ym, R), rtol=1e-13)
+    assert likelihoods.logdensity_norm_diag(y[:0], ym[:0], R).shape == (0,)
+    mean, var, eps = rng.standard_normal((5, 3)), rng.random((5, 3)), rng.standard_normal((5, 3))
+    np.testing.assert_allclose(utils.get_rand((mean, var), eps), orc.get_rand(mean, var, eps), rtol=1e-15)
+    with pytest.raises(ValueError):
+        lik.predict_mean(X[:, :3])
