@@ -63,7 +63,6 @@ struct ProjectArgs {
     double *rowsq;          // [nbatch_total][ng][Tp] or null   (sum_j F[t][j]^2 per column group)
     double *fmean;          // [nbatch_total][ng][Tp] or null   (sum_j F[t][j] * U[j][d])
     int ng;                 // column groups = ceil(Mp / 512)
-    int dbg;                // ablation switches (timing experiments only)
 };
 // F = K_fu * L^{-T} with K_fu generated on the fly (never stored).
 void launch_project(hipStream_t stream, const ProjectArgs &a);

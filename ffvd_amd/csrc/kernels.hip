@@ -18,7 +18,6 @@
 //   * Cholesky is a blocked right-looking factorisation whose "extra rows" carry a right-hand side through the
 //     same panel/trailing kernels: identity rows become L^{-T}, the row delta^T F / Q becomes L_H^{-1} b.
 #include "kernels.h"
-#include <cstdlib>
 
 namespace ffvd {
 
@@ -531,7 +530,6 @@ __global__ __launch_bounds__(NW * 64) void project_kernel(ProjectArgs a) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lk = lane >> 4;
-    const int dbg = a.dbg;
     const int t0 = blockIdx.x * STRIP;
     const int g = blockIdx.y;
     const int bz = blockIdx.z;                 // index inside this pass
@@ -609,7 +607,7 @@ __global__ __launch_bounds__(NW * 64) void project_kernel(ProjectArgs a) {
     auto loadB = [&](int kglob, double(&bv)[TPW]) {
 #pragma unroll
         for (int r = 0; r < TPW; ++r)
-            bv[r] = (dbg & 2) ? 1.0 : ((tv[r] && kglob < c0[r] + 16) ? Wd[(size_t)(kglob + lk) * Mp + c0[r] + lr] : 0.0);
+            bv[r] = (tv[r] && kglob < c0[r] + 16) ? Wd[(size_t)(kglob + lk) * Mp + c0[r] + lr] : 0.0;
     };
     // SIMD partners (waves w and w+4) alternate roles inside a chunk: one generates the next K_fu chunk on the
     // VALU while the other feeds the matrix pipe, instead of all eight waves doing the same phase in lockstep.
@@ -619,7 +617,7 @@ __global__ __launch_bounds__(NW * 64) void project_kernel(ProjectArgs a) {
     for (int c = 0; c < nchunk; ++c) {
         const int buf = c & 1;
         if (c + 2 < nchunk) load_z(c + 2, buf);        // zs[buf] was consumed by gen(c) before the last barrier
-        if (!(dbg & 1) && gen_first && c + 1 < nchunk) gen(c + 1, buf ^ 1);   // zs[buf^1] was loaded one iteration ago
+        if (gen_first && c + 1 < nchunk) gen(c + 1, buf ^ 1);   // zs[buf^1] was loaded one iteration ago
         double af[4], afn[4];
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) af[rt] = Ks[buf][lk][16 * rt + lr];
@@ -643,12 +641,12 @@ __global__ __launch_bounds__(NW * 64) void project_kernel(ProjectArgs a) {
 #pragma unroll
             for (int rt = 0; rt < 4; ++rt) af[rt] = afn[rt];
         }
-        if (!(dbg & 1) && !gen_first && c + 1 < nchunk) gen(c + 1, buf ^ 1);
-        if (!(dbg & 8)) __syncthreads();
+        if (!gen_first && c + 1 < nchunk) gen(c + 1, buf ^ 1);
+        __syncthreads();
     }
 
     // ---- epilogue ----
-    if (a.F && !(dbg & 4)) {
+    if (a.F) {
         double *Fb = a.F + ((size_t)bz * a.Tp + t0) * Mp;
 #pragma unroll
         for (int r = 0; r < TPW; ++r) {
@@ -701,16 +699,10 @@ __global__ __launch_bounds__(NW * 64) void project_kernel(ProjectArgs a) {
 
 void launch_project(hipStream_t stream, const ProjectArgs &a) {
     dim3 grid(a.Tp / STRIP, a.ng, a.nb);
-    static const int dbgv = [] { const char *e = getenv("FFVD_DBG"); return e ? atoi(e) : 0; }();
-    ProjectArgs a2 = a; a2.dbg = dbgv;
-    static const int nw = [] { const char *e = getenv("FFVD_PROJECT_WAVES"); return e ? atoi(e) : 8; }();
-    if (nw == 16) {
-        if (a.kind == 0) hipLaunchKernelGGL((project_kernel<0, 16>), grid, dim3(1024), 0, stream, a2);
-        else hipLaunchKernelGGL((project_kernel<1, 16>), grid, dim3(1024), 0, stream, a2);
-    } else {
-        if (a.kind == 0) hipLaunchKernelGGL((project_kernel<0, 8>), grid, dim3(512), 0, stream, a2);
-        else hipLaunchKernelGGL((project_kernel<1, 8>), grid, dim3(512), 0, stream, a2);
-    }
+    // 16 wavefronts per workgroup (4 per SIMD, 2 column tiles each) measured 4.1-4.2 ms against 4.6-4.7 ms for
+    // 8 wavefronts with 4 tiles each on config 2: one fp64 MFMA wavefront fills at most half a SIMD's matrix pipe.
+    if (a.kind == 0) hipLaunchKernelGGL((project_kernel<0, 16>), grid, dim3(1024), 0, stream, a);
+    else hipLaunchKernelGGL((project_kernel<1, 16>), grid, dim3(1024), 0, stream, a);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -735,7 +727,7 @@ constexpr int G_LD = 128 + 16;      // LDS row stride (doubles): lanes l and l+1
 __device__ __constant__ unsigned char GRAM_DIAG_WR[8] = {1, 1, 1, 1, 0, 0, 0, 0};
 __device__ __constant__ unsigned char GRAM_DIAG_WC[8] = {0, 1, 2, 3, 0, 1, 2, 3};
 
-template <bool DIAG>
+template <int MODE, bool DIAG>
 __device__ __forceinline__ void gram_body(const GramArgs a, const int bz, const int ti, const int tj, const int tile,
                                           double (*As)[GT][G_LD], double (*Bs)[GT][G_LD], double (*dls)[GT],
                                           double *red) {
@@ -826,10 +818,10 @@ __device__ __forceinline__ void gram_body(const GramArgs a, const int bz, const 
         __syncthreads();
     }
 
-    const double scale = (a.mode == GRAM_PLAIN) ? 1.0 : a.yn_over_batch / exp(a.log_Q[dg]);
+    const double scale = (MODE == GRAM_PLAIN) ? 1.0 : a.yn_over_batch / exp(a.log_Q[dg]);
     double *Hb = a.H + (size_t)bz * a.h_stride;
-    const double *Kadd = (a.mode == GRAM_KFU) ? a.Kadd + (size_t)dl * a.kadd_stride : nullptr;
-    const double *Kinv = (a.mode == GRAM_KFU) ? a.Kinv + (size_t)dl * a.kinv_stride : nullptr;
+    const double *Kadd = (MODE == GRAM_KFU) ? a.Kadd + (size_t)dl * a.kadd_stride : nullptr;
+    const double *Kinv = (MODE == GRAM_KFU) ? a.Kinv + (size_t)dl * a.kinv_stride : nullptr;
     double trp = 0.0;
     if (active) {
 #pragma unroll
@@ -841,8 +833,8 @@ __device__ __forceinline__ void gram_body(const GramArgs a, const int bz, const 
                     const int i = I0 + 16 * x + lk + 4 * q, j = J0 + 16 * y + lr;
                     const double g = acc[x][y][q];
                     double v;
-                    if (a.mode == GRAM_F) v = g * scale + ((i == j) ? 1.0 : 0.0);
-                    else if (a.mode == GRAM_KFU) {
+                    if (MODE == GRAM_F) v = g * scale + ((i == j) ? 1.0 : 0.0);
+                    else if (MODE == GRAM_KFU) {
                         v = g * scale + Kadd[(size_t)i * Mp + j];
                         const double w = (i > j) ? 2.0 : ((i == j) ? 1.0 : 0.0);
                         trp += w * (Kinv[(size_t)i * Mp + j] * g);
@@ -854,7 +846,7 @@ __device__ __forceinline__ void gram_body(const GramArgs a, const int bz, const 
         const int col = ti * 128 + tid - 384;
         if (col < Mp) Hb[(size_t)Mp * Mp + col] = bsum * scale;
     }
-    if (a.mode == GRAM_KFU) {      // deterministic workgroup reduction of the trace partial
+    if (MODE == GRAM_KFU) {      // deterministic workgroup reduction of the trace partial
         red[tid] = trp;
         __syncthreads();
         for (int st = 256; st > 0; st >>= 1) {
@@ -865,6 +857,7 @@ __device__ __forceinline__ void gram_body(const GramArgs a, const int bz, const 
     }
 }
 
+template <int MODE>
 __global__ __launch_bounds__(512, 4) void gram_kernel(GramArgs a) {
     __shared__ double As[2][GT][G_LD];
     __shared__ double Bs[2][GT][G_LD];
@@ -879,8 +872,8 @@ __global__ __launch_bounds__(512, 4) void gram_kernel(GramArgs a) {
     int ti = 0;                       // tile = ti (ti + 1) / 2 + tj,  tj <= ti
     while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
     const int tj = tile - ti * (ti + 1) / 2;
-    if (ti == tj) gram_body<true>(a, bz, ti, tj, tile, As, Bs, dls, red);
-    else gram_body<false>(a, bz, ti, tj, tile, As, Bs, dls, red);
+    if (ti == tj) gram_body<MODE, true>(a, bz, ti, tj, tile, As, Bs, dls, red);
+    else gram_body<MODE, false>(a, bz, ti, tj, tile, As, Bs, dls, red);
 }
 
 int gram_ntiles(int Mp) {
@@ -891,7 +884,10 @@ int gram_ntiles(int Mp) {
 void launch_gram(hipStream_t stream, GramArgs a) {
     a.ntiles = gram_ntiles(a.Mp);
     const int groups = (a.nb + 7) / 8;
-    hipLaunchKernelGGL(gram_kernel, dim3(groups * 8 * a.ntiles), dim3(512), 0, stream, a);
+    const dim3 grid(groups * 8 * a.ntiles);
+    if (a.mode == GRAM_F) hipLaunchKernelGGL(gram_kernel<GRAM_F>, grid, dim3(512), 0, stream, a);
+    else if (a.mode == GRAM_KFU) hipLaunchKernelGGL(gram_kernel<GRAM_KFU>, grid, dim3(512), 0, stream, a);
+    else hipLaunchKernelGGL(gram_kernel<GRAM_PLAIN>, grid, dim3(512), 0, stream, a);
 }
 
 // ---------------------------------------------------------------------------------------------
