@@ -750,35 +750,41 @@ __device__ __forceinline__ void gram_body(const GramArgs a, const int bz, const 
     const int colAc = okA ? colA : 0, colBc = okB ? colB : 0;
     const int rowl = tid >> 6;   // 0..7
 
+    // The loaded registers are only touched again in lstore() (masking included), so the global loads of chunk
+    // c + 1 stay in flight behind the whole MFMA phase of chunk c.
     double2 ra[2], rb[2];
-    double dreg = 0.0;
+    double d1 = 0.0, d0 = 0.0;
+    bool dok = false;
     auto gload = [&](int c) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const size_t t = (size_t)c * GT + rowl + 8 * i;
-            const double2 va = *reinterpret_cast<const double2 *>(Ab + t * Mp + colAc);
-            ra[i].x = okA ? va.x : 0.0;
-            ra[i].y = okA ? va.y : 0.0;
-            if (!DIAG) {
-                const double2 vb = *reinterpret_cast<const double2 *>(Ab + t * Mp + colBc);
-                rb[i].x = okB ? vb.x : 0.0;
-                rb[i].y = okB ? vb.y : 0.0;
-            }
+            ra[i] = *reinterpret_cast<const double2 *>(Ab + t * Mp + colAc);
+            if (!DIAG) rb[i] = *reinterpret_cast<const double2 *>(Ab + t * Mp + colBc);
         }
         if (DIAG && a.with_row) {
             const int tt = c * GT + (tid & (GT - 1));
             const int tc = tt < a.T ? tt : a.T - 1;
-            const double dv = Xs[(size_t)(tc + 1) * a.D + dg] - Xs[(size_t)tc * a.D + dg];   // :247
-            dreg = tt < a.T ? dv : 0.0;
+            d1 = Xs[(size_t)(tc + 1) * a.D + dg];
+            d0 = Xs[(size_t)tc * a.D + dg];
+            dok = tt < a.T;
         }
     };
     auto lstore = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            *reinterpret_cast<double2 *>(&As[buf][rowl + 8 * i][2 * lane]) = ra[i];
-            if (!DIAG) *reinterpret_cast<double2 *>(&Bs[buf][rowl + 8 * i][2 * lane]) = rb[i];
+            double2 va = ra[i];
+            va.x = okA ? va.x : 0.0;
+            va.y = okA ? va.y : 0.0;
+            *reinterpret_cast<double2 *>(&As[buf][rowl + 8 * i][2 * lane]) = va;
+            if (!DIAG) {
+                double2 vb = rb[i];
+                vb.x = okB ? vb.x : 0.0;
+                vb.y = okB ? vb.y : 0.0;
+                *reinterpret_cast<double2 *>(&Bs[buf][rowl + 8 * i][2 * lane]) = vb;
+            }
         }
-        if (DIAG && a.with_row && tid < GT) dls[buf][tid] = dreg;
+        if (DIAG && a.with_row && tid < GT) dls[buf][tid] = dok ? d1 - d0 : 0.0;     // :247
     };
 
     d4 acc[4][2];
@@ -797,17 +803,27 @@ __device__ __forceinline__ void gram_body(const GramArgs a, const int bz, const 
         if (c + 1 < nchunk) gload(c + 1);
         if (active) {
             const double(*Bp)[G_LD] = DIAG ? As[buf] : Bs[buf];
+            double af[4], bf[2], afn[4], bfn[2];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) af[x] = As[buf][lk][wr * 64 + 16 * x + lr];
+#pragma unroll
+            for (int y = 0; y < 2; ++y) bf[y] = Bp[lk][wc * 32 + 16 * y + lr];
 #pragma unroll
             for (int ks = 0; ks < GT / 4; ++ks) {
-                double af[4], bf[2];
+                if (ks + 1 < GT / 4) {       // fragments of the next k-step are requested before this step's MFMAs
 #pragma unroll
-                for (int x = 0; x < 4; ++x) af[x] = As[buf][4 * ks + lk][wr * 64 + 16 * x + lr];
+                    for (int x = 0; x < 4; ++x) afn[x] = As[buf][4 * (ks + 1) + lk][wr * 64 + 16 * x + lr];
 #pragma unroll
-                for (int y = 0; y < 2; ++y) bf[y] = Bp[4 * ks + lk][wc * 32 + 16 * y + lr];
+                    for (int y = 0; y < 2; ++y) bfn[y] = Bp[4 * (ks + 1) + lk][wc * 32 + 16 * y + lr];
+                }
 #pragma unroll
                 for (int x = 0; x < 4; ++x)
 #pragma unroll
                     for (int y = 0; y < 2; ++y) acc[x][y] = mfma_f64(af[x], bf[y], acc[x][y]);
+#pragma unroll
+                for (int x = 0; x < 4; ++x) af[x] = afn[x];
+#pragma unroll
+                for (int y = 0; y < 2; ++y) bf[y] = bfn[y];
             }
         }
         if (gemv) {
