@@ -53,6 +53,10 @@ _SIGNATURES = {
     "ffvd_op_kernel_pre_cal": (C.c_int, [C.c_int, _dp, C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_double, _dp]),
     "ffvd_op_collapse": (C.c_int, [C.c_int, _dp, _dp, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp,
                                    C.c_double, C.c_double, _dp]),
+    "ffvd_op_collapse_u_mean": (C.c_int, [C.c_int, _dp, _dp, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp,
+                                          _dp, _dp]),
+    "ffvd_op_conditional_precalc": (C.c_int, [C.c_int, _dp, _dp, C.c_int, _dp, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp,
+                                              _dp, _dp, _dp]),
     "ffvd_op_predict_mean": (C.c_int, [_dp, C.c_int, C.c_int, _dp, _dp, C.c_int, _dp]),
     "ffvd_op_logdensity_norm_diag": (C.c_int, [C.c_int, _dp, _dp, _dp, C.c_int, C.c_int, _dp]),
     "ffvd_op_get_rand": (C.c_int, [_dp, _dp, _dp, C.c_int64, _dp]),

@@ -788,7 +788,7 @@ extern "C" int ffvd_op_conditional(int kind, const double *Xnew, int N, const do
     pa.W = w.Kuu + (size_t)Mp * Mp; pa.w_stride = (size_t)2 * Mp * Mp; pa.U = dU; pa.u_ld = D; pa.b0 = 0; pa.nb = D;
     pa.F = nullptr; pa.rowsq = rowsq; pa.fmean = fmean; pa.ng = ng;
     launch_project(sc.stream, pa);
-    launch_conditional_finish(sc.stream, kind, dX, N, P, w.variance, rowsq, fmean, ng, Tp, D, dmean, dvar);
+    launch_conditional_finish(sc.stream, kind, dX, N, P, w.variance, rowsq, fmean, ng, Tp, D, dmean, dvar, nullptr);
     HIP_TRY(hipMemcpyAsync(mean, dmean, (size_t)N * D * sizeof(double), hipMemcpyDeviceToHost, sc.stream));
     HIP_TRY(hipMemcpyAsync(var, dvar, (size_t)N * D * sizeof(double), hipMemcpyDeviceToHost, sc.stream));
     return check_kuu_info(sc, w, D, "ffvd_op_conditional");
@@ -834,6 +834,127 @@ extern "C" int ffvd_op_get_rand(const double *mean, const double *var, const dou
     if (!dm || !dv || !de || !dO) return set_error(nullptr, FFVD_ENOMEM, "ffvd_op_get_rand: device allocation or upload failed");
     launch_get_rand(sc.stream, dm, dv, de, (size_t)n, dO);
     HIP_TRY(hipMemcpyAsync(out, dO, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, sc.stream));
+    HIP_TRY(hipStreamSynchronize(sc.stream));
+    return FFVD_OK;
+}
+
+// shared by ffvd_op_collapse_u_mean / ffvd_op_conditional_precalc: pad a caller-supplied stack of D M x M matrices
+static std::vector<double> pad_stack(const double *src, int D, int M, int Mp) {
+    std::vector<double> out((size_t)D * Mp * Mp, 0.0);
+    for (int d = 0; d < D; ++d)
+        for (int i = 0; i < Mp; ++i) {
+            double *row = out.data() + ((size_t)d * Mp + i) * Mp;
+            if (i < M) memcpy(row, src + ((size_t)d * M + i) * M, (size_t)M * sizeof(double));
+            else row[i] = 1.0;
+        }
+    return out;
+}
+
+extern "C" int ffvd_op_collapse_u_mean(int kind, const double *Lm_inverse_seq, const double *X_combine, const double *X,
+                                       const double *Z, int T, int M, int P, int D, const double *logvariance,
+                                       const double *loglengthscales, const double *Q, double *U_mean,
+                                       double *H_inv_sqrt) {
+    if (!Lm_inverse_seq || !X_combine || !X || !Z || !logvariance || !Q || !U_mean || !H_inv_sqrt || T < 1 || M < 1 ||
+        P < 1 || P > MAXP || D < 1 || (kind == FFVD_KERNEL_SE && !loglengthscales))
+        return set_error(nullptr, FFVD_EINVAL, "ffvd_op_collapse_u_mean: bad argument");
+    OP_BEGIN("ffvd_op_collapse_u_mean");
+    const int Mp = round_up(M, NB), Tp = round_up(T, STRIP), ng = (Mp + 511) / 512;
+    std::vector<double> Wp = pad_stack(Lm_inverse_seq, D, M, Mp);
+    std::vector<double> logQ(D);
+    for (int d = 0; d < D; ++d) logQ[d] = log(Q[d]);
+    // slab per dim: rows [0,Mp) H, rows [Mp,2Mp) identity -> L_H^-T, row 2Mp carries b -> L_H^-1 b
+    const size_t hstride = (size_t)(2 * Mp + NB) * Mp;
+    std::vector<double> Hinit((size_t)D * hstride, 0.0);
+    for (int d = 0; d < D; ++d)
+        for (int i = 0; i < Mp; ++i) Hinit[(size_t)d * hstride + (size_t)(Mp + i) * Mp + i] = 1.0;
+    double *dW = sc.upload(Wp.data(), Wp.size());
+    double *dXc = sc.upload(X_combine, (size_t)T * P), *dX = sc.upload(X, (size_t)(T + 1) * D);
+    double *dZ = sc.upload(Z, (size_t)M * P), *dlv = sc.upload(logvariance, D), *dlq = sc.upload(logQ.data(), D);
+    double *dll = sc.alloc<double>((size_t)D * P);
+    double *variance = sc.alloc<double>(D), *len = sc.alloc<double>((size_t)D * P);
+    double *Zs = sc.alloc<double>((size_t)D * Mp * P), *zz = sc.alloc<double>((size_t)D * Mp);
+    double *F = sc.alloc<double>((size_t)D * Tp * Mp), *rowsq = sc.alloc<double>((size_t)D * ng * Tp);
+    double *H = sc.upload(Hinit.data(), Hinit.size());
+    double *dU = sc.alloc<double>((size_t)M * D);
+    int32_t *info = sc.alloc<int32_t>(D);
+    if (!dW || !dXc || !dX || !dZ || !dlv || !dlq || !dll || !variance || !len || !Zs || !zz || !F || !rowsq || !H || !dU || !info)
+        return set_error(nullptr, FFVD_ENOMEM, "ffvd_op_collapse_u_mean: device allocation or upload failed");
+    if (loglengthscales)
+        HIP_TRY(hipMemcpyAsync(dll, loglengthscales, (size_t)D * P * sizeof(double), hipMemcpyHostToDevice, sc.stream));
+    HIP_TRY(hipMemsetAsync(info, 0, D * sizeof(int32_t), sc.stream));
+    launch_prep_hypers(sc.stream, kind, dZ, M, Mp, P, D, 0, dlv, dll, variance, len, Zs, zz);
+    HyperView hv{variance, len, Zs, zz};
+    ProjectArgs pa{};
+    pa.kind = kind; pa.x = dXc; pa.x_chain_stride = 0; pa.x_ld = P; pa.x_cols = P; pa.ctrl = nullptr;
+    pa.T = T; pa.Tp = Tp; pa.C = 0; pa.P = P; pa.M = M; pa.Mp = Mp; pa.Dl = D; pa.d_begin = 0; pa.hv = hv;
+    pa.W = dW; pa.w_stride = (size_t)Mp * Mp; pa.U = nullptr; pa.u_ld = 0; pa.b0 = 0; pa.nb = D; pa.F = F;
+    pa.rowsq = rowsq; pa.fmean = nullptr; pa.ng = ng;
+    launch_project(sc.stream, pa);
+    GramArgs ga{};
+    ga.mode = GRAM_F; ga.A = F; ga.a_stride = (size_t)Tp * Mp; ga.rows = Tp; ga.with_row = 1; ga.brow = 2 * Mp;
+    ga.X = dX; ga.log_Q = dlq; ga.T = T; ga.D = D; ga.Mp = Mp; ga.Dl = D; ga.d_begin = 0;
+    ga.b0 = 0; ga.nb = D; ga.yn_over_batch = 1.0; ga.H = H; ga.h_stride = hstride;     // :215,:217 (no batch rescaling)
+    launch_gram(sc.stream, ga);
+    launch_potrf_ext(sc.stream, H, Mp, Mp + NB, 0, D, hstride, info);
+    // U_mean[:, d] = H^-1 b = L_H^-T (L_H^-1 b)   (tf.linalg.solve, :219)
+    launch_matvec(sc.stream, H + (size_t)Mp * Mp, hstride, H + (size_t)2 * Mp * Mp, hstride, Mp, dU, D, M, D);
+    std::vector<double> hH((size_t)D * hstride);
+    std::vector<int32_t> hinfo(D);
+    HIP_TRY(hipMemcpyAsync(hH.data(), H, hH.size() * sizeof(double), hipMemcpyDeviceToHost, sc.stream));
+    HIP_TRY(hipMemcpyAsync(U_mean, dU, (size_t)M * D * sizeof(double), hipMemcpyDeviceToHost, sc.stream));
+    HIP_TRY(hipMemcpyAsync(hinfo.data(), info, D * sizeof(int32_t), hipMemcpyDeviceToHost, sc.stream));
+    HIP_TRY(hipStreamSynchronize(sc.stream));
+    for (int d = 0; d < D; ++d)
+        if (hinfo[d]) {
+            char msg[160];
+            snprintf(msg, sizeof msg, "ffvd_op_collapse_u_mean: Cholesky of H failed: latent dim %d, pivot %d is not positive", d, hinfo[d] - 1);
+            return set_error(nullptr, FFVD_ENOTPD, msg);
+        }
+    for (int d = 0; d < D; ++d)          // Lm_inverse_dd_seq = L_H^-T (:222)
+        for (int i = 0; i < M; ++i)
+            memcpy(H_inv_sqrt + ((size_t)d * M + i) * M, hH.data() + (size_t)d * hstride + (size_t)(Mp + i) * Mp,
+                   (size_t)M * sizeof(double));
+    return FFVD_OK;
+}
+
+extern "C" int ffvd_op_conditional_precalc(int kind, const double *Lm_inverse_seq, const double *Xnew, int N,
+                                           const double *Z, int M, int P, int D, const double *logvariance,
+                                           const double *loglengthscales, const double *f, const double *q_sqrt,
+                                           double *mean, double *var) {
+    if (!Lm_inverse_seq || !Xnew || !Z || !logvariance || !f || !mean || !var || N < 0 || M < 1 || M > 2048 || P < 1 ||
+        P > MAXP || D < 1 || (kind == FFVD_KERNEL_SE && !loglengthscales))
+        return set_error(nullptr, FFVD_EINVAL, "ffvd_op_conditional_precalc: bad argument");
+    OP_BEGIN("ffvd_op_conditional_precalc");
+    if (N == 0) return FFVD_OK;
+    const int Mp = round_up(M, NB), Tp = round_up(N, STRIP), ng = (Mp + 511) / 512;
+    std::vector<double> Wp = pad_stack(Lm_inverse_seq, D, M, Mp);
+    double *dW = sc.upload(Wp.data(), Wp.size());
+    double *dX = sc.upload(Xnew, (size_t)N * P), *dZ = sc.upload(Z, (size_t)M * P), *dU = sc.upload(f, (size_t)M * D);
+    double *dlv = sc.upload(logvariance, D), *dll = sc.alloc<double>((size_t)D * P);
+    double *variance = sc.alloc<double>(D), *len = sc.alloc<double>((size_t)D * P);
+    double *Zs = sc.alloc<double>((size_t)D * Mp * P), *zz = sc.alloc<double>((size_t)D * Mp);
+    double *F = sc.alloc<double>((size_t)D * Tp * Mp);
+    double *rowsq = sc.alloc<double>((size_t)D * ng * Tp), *fmean = sc.alloc<double>((size_t)D * ng * Tp);
+    double *dmean = sc.alloc<double>((size_t)N * D), *dvar = sc.alloc<double>((size_t)N * D);
+    double *dQs = q_sqrt ? sc.upload(q_sqrt, (size_t)M * M) : nullptr;     // slice d = 0 only (the reference quirk)
+    double *extra = q_sqrt ? sc.alloc<double>((size_t)D * Tp) : nullptr;
+    if (!dW || !dX || !dZ || !dU || !dlv || !dll || !variance || !len || !Zs || !zz || !F || !rowsq || !fmean || !dmean ||
+        !dvar || (q_sqrt && (!dQs || !extra)))
+        return set_error(nullptr, FFVD_ENOMEM, "ffvd_op_conditional_precalc: device allocation or upload failed");
+    if (loglengthscales)
+        HIP_TRY(hipMemcpyAsync(dll, loglengthscales, (size_t)D * P * sizeof(double), hipMemcpyHostToDevice, sc.stream));
+    launch_prep_hypers(sc.stream, kind, dZ, M, Mp, P, D, 0, dlv, dll, variance, len, Zs, zz);
+    HyperView hv{variance, len, Zs, zz};
+    ProjectArgs pa{};
+    pa.kind = kind; pa.x = dX; pa.x_chain_stride = 0; pa.x_ld = P; pa.x_cols = P; pa.ctrl = nullptr;
+    pa.T = N; pa.Tp = Tp; pa.C = 0; pa.P = P; pa.M = M; pa.Mp = Mp; pa.Dl = D; pa.d_begin = 0; pa.hv = hv;
+    pa.W = dW; pa.w_stride = (size_t)Mp * Mp; pa.U = dU; pa.u_ld = D; pa.b0 = 0; pa.nb = D;
+    pa.F = q_sqrt ? F : nullptr; pa.rowsq = rowsq; pa.fmean = fmean; pa.ng = ng;
+    launch_project(sc.stream, pa);                                           // A^T = K_fu L^-T (:349), mean (:365), sum A^2 (:356)
+    if (q_sqrt) launch_qsqrt_inflation(sc.stream, F, (size_t)Tp * Mp, Tp, Mp, M, dQs, extra, N, D);
+    launch_conditional_finish(sc.stream, kind, dX, N, P, variance, rowsq, fmean, ng, Tp, D, dmean, dvar, extra);
+    HIP_TRY(hipMemcpyAsync(mean, dmean, (size_t)N * D * sizeof(double), hipMemcpyDeviceToHost, sc.stream));
+    HIP_TRY(hipMemcpyAsync(var, dvar, (size_t)N * D * sizeof(double), hipMemcpyDeviceToHost, sc.stream));
     HIP_TRY(hipStreamSynchronize(sc.stream));
     return FFVD_OK;
 }

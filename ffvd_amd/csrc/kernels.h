@@ -75,7 +75,8 @@ struct GramArgs {
     const double *A;        // [nb] slabs of rows x Mp (F, K_fu or L^-1), slab stride a_stride doubles
     size_t a_stride;
     int rows;               // rows of A summed over (multiple of 16; Tp for F / K_fu)
-    int with_row;           // 1: also write the extra row Mp = scale * delta^T A (needs X, T, D)
+    int with_row;           // 1: also write the extra row `brow` = scale * delta^T A (needs X, T, D)
+    int brow;               // row index of that extra row in the output slab (0 = default Mp)
     const double *X;        // [S][T+1][D]
     const double *log_Q;    // [D] (global dim index)
     int T, D, Mp, Dl, d_begin;
@@ -129,7 +130,11 @@ void launch_finalize(hipStream_t stream, const FinalizeArgs &a);
 // conditional() epilogue: mean[n][d] = sum_g fmean, var[n][d] = Kdiag(x_n) - sum_g rowsq  (N x D outputs)
 void launch_conditional_finish(hipStream_t stream, int kind, const double *x, int N, int P, const double *variance,
                                const double *rowsq, const double *fmean, int ng, int Tp, int D, double *mean,
-                               double *var);
+                               double *var, const double *extra /* optional [D][Tp] added to var */);
+void launch_matvec(hipStream_t stream, const double *W, size_t w_stride, const double *y, size_t y_stride, int Mp,
+                   double *out, int out_ld, int M, int batch);
+void launch_qsqrt_inflation(hipStream_t stream, const double *F, size_t f_stride, int Tp, int Mp, int M, const double *Qs,
+                            double *extra, int N, int batch);
 
 // operator-API elementwise kernels
 void launch_predict_mean(hipStream_t stream, const double *X, int N, int D, const double *CC, const double *DD, int J,

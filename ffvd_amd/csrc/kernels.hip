@@ -860,7 +860,7 @@ __device__ __forceinline__ void gram_body(const GramArgs a, const int bz, const 
     }
     if (gemv) {
         const int col = ti * 128 + tid - 384;
-        if (col < Mp) Hb[(size_t)Mp * Mp + col] = bsum * scale;
+        if (col < Mp) Hb[(size_t)a.brow * Mp + col] = bsum * scale;
     }
     if (MODE == GRAM_KFU) {      // deterministic workgroup reduction of the trace partial
         red[tid] = trp;
@@ -899,6 +899,7 @@ int gram_ntiles(int Mp) {
 
 void launch_gram(hipStream_t stream, GramArgs a) {
     a.ntiles = gram_ntiles(a.Mp);
+    if (a.brow <= 0) a.brow = a.Mp;
     const int groups = (a.nb + 7) / 8;
     const dim3 grid(groups * 8 * a.ntiles);
     if (a.mode == GRAM_F) hipLaunchKernelGGL(gram_kernel<GRAM_F>, grid, dim3(512), 0, stream, a);
@@ -1004,7 +1005,7 @@ void launch_chain_reduce(hipStream_t stream, const ReduceArgs &a, double *partia
 // conditional() outputs (conditionals_multi_output.py:41,48,120): mean N x D, var N x D
 __global__ void conditional_finish_kernel(int kind, const double *x, int N, int P, const double *variance,
                                           const double *rowsq, const double *fmean, int ng, int Tp, int D,
-                                          double *mean, double *var) {
+                                          double *mean, double *var, const double *extra /*[D][Tp] or null*/) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= N * D) return;
     const int n = idx / D, d = idx % D;
@@ -1021,13 +1022,64 @@ __global__ void conditional_finish_kernel(int kind, const double *x, int N, int 
     }
     mean[idx] = fm;
     var[idx] = kd - rs;
+    if (extra) var[idx] = var[idx] + extra[(size_t)d * Tp + n];     // fvar + reduce_sum(square(LTA), 1)  (:380)
 }
 void launch_conditional_finish(hipStream_t stream, int kind, const double *x, int N, int P, const double *variance,
                                const double *rowsq, const double *fmean, int ng, int Tp, int D, double *mean,
-                               double *var) {
+                               double *var, const double *extra) {
     if (N * D == 0) return;
     hipLaunchKernelGGL(conditional_finish_kernel, dim3((N * D + 255) / 256), dim3(256), 0, stream, kind, x, N, P,
-                       variance, rowsq, fmean, ng, Tp, D, mean, var);
+                       variance, rowsq, fmean, ng, Tp, D, mean, var, extra);
+}
+
+// out[b][i] = sum_j W[b][i][j] * y[b][j]   (posterior mean of the whitened inducing outputs: L_H^-T (L_H^-1 b))
+__global__ __launch_bounds__(256) void matvec_kernel(const double *W, size_t w_stride, const double *y, size_t y_stride,
+                                                     int Mp, double *out, int out_ld, int M) {
+    __shared__ double ys[2048];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const double *Wb = W + (size_t)b * w_stride, *yb = y + (size_t)b * y_stride;
+    for (int j0 = 0; j0 < Mp; j0 += 2048) {     // Mp <= 2048 per tile of y
+        for (int j = tid; j < 2048 && j0 + j < Mp; j += 256) ys[j] = yb[j0 + j];
+        __syncthreads();
+        const int i = blockIdx.x * 256 + tid;
+        if (i < M) {
+            double acc = (j0 == 0) ? 0.0 : out[(size_t)i * out_ld + b];
+            const int jn = (Mp - j0 < 2048) ? Mp - j0 : 2048;
+            for (int j = 0; j < jn; ++j) acc += Wb[(size_t)i * Mp + j0 + j] * ys[j];
+            out[(size_t)i * out_ld + b] = acc;
+        }
+        __syncthreads();
+    }
+}
+void launch_matvec(hipStream_t stream, const double *W, size_t w_stride, const double *y, size_t y_stride, int Mp,
+                   double *out, int out_ld, int M, int batch) {
+    hipLaunchKernelGGL(matvec_kernel, dim3((M + 255) / 256, batch), dim3(256), 0, stream, W, w_stride, y, y_stride, Mp, out,
+                       out_ld, M);
+}
+
+// extra[b][n] = sum_j ( sum_m F[b][n][m] * Qs[m][j] )^2   -- the q_sqrt variance inflation of
+// base_conditional_after_kernel_precalculation (conditionals_multi_output.py:371-380) with LTA^T = F q_sqrt.
+__global__ __launch_bounds__(256) void qsqrt_inflation_kernel(const double *F, size_t f_stride, int Tp, int Mp, int M,
+                                                              const double *Qs /*M x M*/, double *extra) {
+    __shared__ double fr[2048];
+    __shared__ double scratch[256];
+    const int n = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const double *Fr = F + (size_t)b * f_stride + (size_t)n * Mp;
+    for (int m = tid; m < M; m += 256) fr[m] = Fr[m];
+    __syncthreads();
+    double acc = 0.0;
+    for (int j = tid; j < M; j += 256) {
+        double v = 0.0;
+        for (int m = 0; m < M; ++m) v += fr[m] * Qs[(size_t)m * M + j];
+        acc += v * v;
+    }
+    acc = block_sum_256(acc, scratch);
+    if (tid == 0) extra[(size_t)b * Tp + n] = acc;
+}
+void launch_qsqrt_inflation(hipStream_t stream, const double *F, size_t f_stride, int Tp, int Mp, int M, const double *Qs,
+                            double *extra, int N, int batch) {
+    if (N == 0) return;
+    hipLaunchKernelGGL(qsqrt_inflation_kernel, dim3(N, batch), dim3(256), 0, stream, F, f_stride, Tp, Mp, M, Qs, extra);
 }
 
 // Operator-API elementwise kernels (likelihoods.py:76-79, 89-111; utils.py:11)

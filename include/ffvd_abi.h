@@ -167,6 +167,17 @@ int  ffvd_op_conditional(int kind, const double *Xnew, int N, const double *Z, i
                          const double *logvariance, const double *loglengthscales, const double *f,
                          double jitter, double *mean, double *var);
 
+/* collapse_u_mean_after_kernel_precalculation (conditionals_multi_output.py:206-227): posterior mean of the whitened
+ * inducing outputs U_mean (M x D, = H_d^-1 b_d per column) and the stack L_{H_d}^{-T} (D x M x M, upper). */
+int  ffvd_op_collapse_u_mean(int kind, const double *Lm_inverse_seq, const double *X_combine, const double *X,
+                             const double *Z, int T, int M, int P, int D, const double *logvariance,
+                             const double *loglengthscales, const double *Q, double *U_mean, double *H_inv_sqrt);
+/* conditional_after_kernel_precalculation(..., white=True, full_cov=False) (conditionals_multi_output.py:306-387).
+ * q_sqrt: NULL, or the M x M slice d = 0 of the D x M x M stack -- the reference hands the whole stack to every
+ * dim and `[:, :, 0]` (:322) keeps slice 0 for all of them; the caller passes that slice. */
+int  ffvd_op_conditional_precalc(int kind, const double *Lm_inverse_seq, const double *Xnew, int N, const double *Z,
+                                 int M, int P, int D, const double *logvariance, const double *loglengthscales,
+                                 const double *f, const double *q_sqrt, double *mean, double *var);
 /* Gaussian.predict_mean(X_end) = X_end @ CC + DD (likelihoods.py:76-79). X_end: N x D, out: N x Ydim. */
 int  ffvd_op_predict_mean(const double *X_end, int N, int D, const double *CC, const double *DD, int Ydim, double *out);
 /* logdensity_norm_diag (nonvec = 0, out: N; likelihoods.py:96-111) / logdensity_norm_diag_nonvec (nonvec = 1,

@@ -141,3 +141,29 @@ def test_likelihood_operators_match_oracle():
     np.testing.assert_allclose(utils.get_rand((mean, var), eps), orc.get_rand(mean, var, eps), rtol=1e-15)
     with pytest.raises(ValueError):
         lik.predict_mean(X[:, :3])
+
+
+def test_posterior_u_and_precalc_conditional_match_oracle():
+    """collapse_u_mean_after_kernel_precalculation (:206-227) and
+    conditional_after_kernel_precalculation (:306-387) incl. the q_sqrt d=0 quirk."""
+    params, Y, c, meta, X0, xc, kern = tiny()
+    g = np.load(os.path.join(GOLDEN, "ops_tiny.npz"))
+    Q = np.exp(params["log_Q"])
+    W = list(g["Lm_inverse_seq"])
+    Um, Hinv = cmo.collapse_u_mean_after_kernel_precalculation(W, xc, X0, params["Z"], kern, Q)
+    np.testing.assert_allclose(Um, g["U_mean"], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(Hinv, g["H_inv_sqrt"], rtol=1e-8, atol=1e-10)
+    m, v = cmo.conditional_after_kernel_precalculation(W, xc[:7], params["Z"], kern, g["U_mean"], q_sqrt=g["H_inv_sqrt"],
+                                                        white=True)
+    np.testing.assert_allclose(m, g["precalc_mean"], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(v, g["precalc_var"], rtol=1e-8, atol=1e-11)
+    # without q_sqrt it equals conditional() (same L^-T, same arithmetic)
+    m2, v2 = cmo.conditional_after_kernel_precalculation(W, xc, params["Z"], kern, params["U"], white=True)
+    np.testing.assert_allclose(m2, g["cond_mean"], rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(v2, g["cond_var"], rtol=1e-7, atol=1e-10)
+    # one-row input: the rollout call pattern (base_model.py:296)
+    m1, v1 = cmo.conditional_after_kernel_precalculation(W, xc[:1], params["Z"], kern, g["U_mean"],
+                                                          q_sqrt=g["H_inv_sqrt"], white=True)
+    np.testing.assert_allclose(m1, g["precalc_mean"][:1], rtol=1e-9, atol=1e-11)
+    with pytest.raises(NotImplementedError):
+        cmo.conditional_after_kernel_precalculation(W, xc, params["Z"], kern, params["U"], white=False)
