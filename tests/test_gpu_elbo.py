@@ -182,6 +182,38 @@ def test_more_than_512_inducing_points(route):
         assert_terms(got, ref, TERMS_A)
 
 
+def test_config4_shape_m2048():
+    """BASELINE configs[3] shape along M (M = 2048: 4 column groups, 32 Cholesky block steps, 136 Gram tiles) at a
+    T the CPU oracle finishes in seconds; fp64 (the reference's dtype)."""
+    params, Y, c, meta = synthetic.make_workload(T=2304, D=2, C=1, M=2048, S=1)
+    ref = orc.nll_terms_chains(params, Y, c, U_collapse=True)
+    got = run_engine(params, Y, c, meta, collapse=True)
+    for n in TERMS_B:
+        assert got[n] == pytest.approx(ref[n], rel=1e-8, abs=1e-9), (n, got[n], ref[n])
+    got = run_engine(params, Y, c, meta, collapse=True, route="gram")
+    assert got["nll"] == pytest.approx(ref["nll"], rel=1e-7)
+
+
+def test_config5_linear_kernel_dim_shards():
+    """BASELINE configs[4]: LinearK, explicit-U branch, T=4096, x_dim=16, M=512, latent dims sharded 8 ways
+    (here: eight engines on one GPU, partial sums added on the host as the all-reduce would)."""
+    params, Y, c, meta = synthetic.make_named("c5")
+    ref = orc.nll_terms_chains(params, Y, c, U_collapse=False, kernel_type="LinearK")
+    from ffvd_amd.distributed import plan, finish
+    total = np.zeros(8)
+    for r in range(8):
+        pl = plan(meta, 8, r, "dims")
+        with ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], meta["S"], kernel_type="LinearK", U_collapse=False,
+                        d_begin=pl["d_begin"], d_count=pl["d_count"], shared_terms=pl["shared_terms"]) as e:
+            e.set_data(Y, c)
+            total += e.elbo_sums(params)
+    got = finish(total)
+    # K_uu of a linear kernel has rank P = 17 << M: only the 1e-5 jitter makes it positive definite, so the
+    # whitened solve is conditioned like 1e5 * |K|; the terms still agree to 1e-7
+    for n in TERMS_A:
+        assert got[n] == pytest.approx(ref[n], rel=1e-7, abs=1e-9), (n, got[n], ref[n])
+
+
 def test_rccl_all_reduce_on_the_engine_buffer():
     """The multi-GPU step on one rank: finalize writes the 8 partial sums into a torch CUDA tensor and RCCL
     all-reduces that very buffer (world_size 1 exercises init, the pointer hand-off and the collective call)."""
