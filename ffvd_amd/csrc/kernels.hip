@@ -512,7 +512,7 @@ void launch_potrf_ext(hipStream_t stream, double *A, int n, int extra_rows, int 
 // Projection:  F = K_fu * L^{-T}  (conditionals_multi_output.py:240-242), K_fu generated on the fly.
 // One workgroup (8 wavefronts) = 64 rows of one (chain, latent dim) x one column group of <= 512 columns.
 // ---------------------------------------------------------------------------------------------
-constexpr int KC = 16;          // k-chunk (columns of K_fu produced per barrier)
+constexpr int KC = 32;          // k-chunk (columns of K_fu produced per barrier)
 constexpr int KS_LD = STRIP + 16;   // LDS row stride of the K chunk: 80 doubles => lanes l and l+16 hit different bank halves
 
 template <int KIND, int NW>
@@ -604,10 +604,15 @@ __global__ __launch_bounds__(NW * 64) void project_kernel(ProjectArgs a) {
 
     // B fragments (rows of L^{-T}) are prefetched one k-step ahead straight from L2 into registers.
     // L^{-T} is upper triangular: a 16-column tile starting at c0 only needs rows k < c0 + 16.
+    // uniform row base (scalar registers) + 32-bit per-lane offset: lets the load use the saddr form
+    int boff[TPW];
+#pragma unroll
+    for (int r = 0; r < TPW; ++r) boff[r] = lk * Mp + c0[r] + lr;
     auto loadB = [&](int kglob, double(&bv)[TPW]) {
+        const double *Wk = Wd + (size_t)kglob * Mp;
 #pragma unroll
         for (int r = 0; r < TPW; ++r)
-            bv[r] = (tv[r] && kglob < c0[r] + 16) ? Wd[(size_t)(kglob + lk) * Mp + c0[r] + lr] : 0.0;
+            bv[r] = (tv[r] && kglob < c0[r] + 16) ? Wk[boff[r]] : 0.0;
     };
     // SIMD partners (waves w and w+4) alternate roles inside a chunk: one generates the next K_fu chunk on the
     // VALU while the other feeds the matrix pipe, instead of all eight waves doing the same phase in lockstep.
