@@ -1,0 +1,107 @@
+"""Closed-form reverse-mode gradient of `nll` (collapsed-U branch, SE kernel) -- TEST INFRASTRUCTURE ONLY.
+
+The reference obtains d nll / d variables from TensorFlow autodiff (`tf.gradients(nll, vars)`,
+base_model.py:148; `AdamOptimizer.minimize(nll)`, dgp_model.py:303-305).  This module restates that gradient in
+closed form (re-derived in the K_uu + K_uf K_fu / Q form) in NumPy, so that the HIP
+backward kernels have an op-by-op CPU twin; `tests/test_oracle.py` checks it against torch autograd of the
+independent restatement (`oracle/ffvd_oracle_torch.py`).  Parity status: unpinned (see ffvd_oracle.py).
+
+Notation per latent dim d (index dropped):  alpha = 1/Q,  K = K_uu + jitter I,  Kf = K_fu (T x M),
+G = Kf^T Kf,  g = Kf^T delta,  A = K + alpha G,  c = alpha g,  u = A^-1 c,
+l = -1/2 (log|A| - log|K|) + 1/2 c^T u - 1/2 alpha (T sigma^2 - tr(K^-1 G)),   nll contribution = -l / T.
+
+  dl/dG     = Gamma = 1/2 alpha (K^-1 - A^-1 - u u^T)
+  dl/dg     = alpha u
+  dl/dK     = Psi   = 1/2 (K^-1 - A^-1 - u u^T) - 1/2 alpha K^-1 G K^-1
+  dl/dalpha = -1/2 tr(A^-1 G) + u^T g - 1/2 u^T G u - 1/2 (T sigma^2 - tr(K^-1 G))
+  dl/dKf    = 2 Kf Gamma + delta (alpha u)^T ,   dl/ddelta = alpha Kf u
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import ffvd_oracle as orc
+
+
+def _se_chain(E, X1, X2, ell, same):
+    """Chain E = dL/dK o K through K(x, z) = s2 exp(-1/2 sum_p ((x_p - z_p)/ell_p)^2).
+    Returns (dX1, dX2, dlogell, dlogs2).  If `same`, X1 is X2 (K(Z, Z)) and dX1 already holds both roles."""
+    inv2 = 1.0 / ell ** 2
+    r = E.sum(axis=1)                       # row sums
+    cs = E.sum(axis=0)                      # column sums
+    dX1 = -(X1 * r[:, None] - E @ X2) * inv2[None, :]
+    dX2 = (E.T @ X1 - X2 * cs[:, None]) * inv2[None, :]
+    dlogell = ((r[:, None] * X1 ** 2).sum(0) - 2.0 * np.einsum("tm,tp,mp->p", E, X1, X2) + (cs[:, None] * X2 ** 2).sum(0)) * inv2
+    dlogs2 = E.sum()
+    if same:
+        return dX1 + dX2, None, dlogell, dlogs2
+    return dX1, dX2, dlogell, dlogs2
+
+
+def nll_grad(params, Y, control_inputs, jitter=orc.JITTER_MULTI_OUTPUT, prior_type="normal"):
+    """Gradient of the single-chain nll (dgp_model.py:288, collapsed branch, SE kernel, full batch).
+
+    Returns dict with the keys of `params` (X, Z, logvariance, loglengthscales, log_Q, CC, DD, log_Rchols)."""
+    X, Z = params["X"], params["Z"]
+    T, D = X.shape[0] - 1, X.shape[1]
+    M, P = Z.shape
+    c_in = control_inputs[:T] if control_inputs is not None and control_inputs.shape[0] > 0 else np.zeros((T, 0))
+    xc = np.concatenate((X[:-1], c_in), axis=1)
+    Q = np.exp(params["log_Q"])
+    R = np.exp(params["log_Rchols"])[0]
+    CC, DD = params["CC"], params["DD"]
+    g = {k: np.zeros_like(np.asarray(v, dtype=np.float64)) for k, v in params.items() if k != "U"}
+
+    # ---- likelihood (dgp_model.py:248-250,264) -------------------------------------------------
+    r = (Y - (X[1:] @ CC + DD)) / R[None, :]                  # T x Ydim
+    g["X"][1:] += -(r / R[None, :]) @ CC.T / T
+    g["CC"] += -(X[1:].T @ (r / R[None, :])) / T
+    g["DD"] += -(r / R[None, :]).sum(0) / T
+    g["log_Rchols"][0] += -((r ** 2).sum(0) - T) / T
+    # ---- transition prior with Q (dgp_model.py:283-284) ------------------------------------------
+    delta = X[1:] - X[:-1]                                    # T x D
+    g["X"][1:] += delta / Q[None, :] / T
+    g["X"][:-1] -= delta / Q[None, :] / T
+    g["log_Q"] += (0.5 * T - 0.5 * (delta ** 2).sum(0) / Q) / T
+    # ---- priors (dgp_model.py:105-130,252,286,326-334) -------------------------------------------
+    g["loglengthscales"] += params["loglengthscales"] / T
+    g["logvariance"] += (params["logvariance"] - np.log(0.05)) / T
+    if prior_type == "normal":
+        g["Z"] += Z / T
+    g["X"][0] += X[0] / T
+    g["log_Q"] += params["log_Q"] / T
+    g["CC"] += CC / T
+    g["DD"] += DD / T
+    g["log_Rchols"] += params["log_Rchols"] / T
+    # ---- collapsed GP terms (conditionals_multi_output.py:230-257) -------------------------------
+    for d in range(D):
+        ell = np.exp(params["loglengthscales"][d])
+        s2 = np.exp(params["logvariance"][d])
+        kern = orc.SquaredExponential(params["logvariance"][d], params["loglengthscales"][d])
+        alpha = 1.0 / Q[d]
+        Kuu = kern.K(Z)
+        K = Kuu + jitter * np.eye(M)
+        Kf = kern.K(xc, Z)
+        G = Kf.T @ Kf
+        gv = Kf.T @ delta[:, d]
+        A = K + alpha * G
+        Kinv = np.linalg.inv(K)
+        Ainv = np.linalg.inv(A)
+        u = Ainv @ (alpha * gv)
+        Gam = 0.5 * alpha * (Kinv - Ainv - np.outer(u, u))
+        Psi = 0.5 * (Kinv - Ainv - np.outer(u, u)) - 0.5 * alpha * (Kinv @ G @ Kinv)
+        dalpha = (-0.5 * np.sum(Ainv * G) + u @ gv - 0.5 * u @ G @ u - 0.5 * (T * s2 - np.sum(Kinv * G)))
+        dKf = 2.0 * Kf @ Gam + np.outer(delta[:, d], alpha * u)
+        ddelta = alpha * (Kf @ u)
+        # chain rule through the kernel matrices; everything below is d l, the nll gets -1/T of it
+        dxc, dZ1, dll1, dls1 = _se_chain(dKf * Kf, xc, Z, ell, same=False)
+        dZ2, _, dll2, dls2 = _se_chain(Psi * Kuu, Z, Z, ell, same=True)
+        dls = dls1 + dls2 - 0.5 * alpha * T * s2              # Kdiag = sigma^2 enters the trace term directly
+        g["X"][:-1, :] += -dxc[:, :D] / T
+        g["X"][1:, d] += -ddelta / T
+        g["X"][:-1, d] -= -ddelta / T
+        g["Z"] += -(dZ1 + dZ2) / T
+        g["loglengthscales"][d] += -(dll1 + dll2) / T
+        g["logvariance"][d] += -dls / T
+        g["log_Q"][d] += -(dalpha * (-alpha)) / T
+    return g
