@@ -23,12 +23,17 @@ TERM_NAMES = ("nll_part_prior", "nll_log_likelihood", "x_t_prior_Q", "nll_reg_tr
 class FfvdConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "T", "D", "C", "M", "S_local", "Ydim", "d_begin", "d_count", "shared_terms", "dtype",
-        "kernel_kind", "branch", "prior_type", "device_id", "chains_per_pass", "route")] + [("jitter", C.c_double)]
+        "kernel_kind", "branch", "prior_type", "device_id", "chains_per_pass", "route", "grad", "reserved")] + [("jitter", C.c_double)]
 
 
 class FfvdParams(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "X", "Z", "U", "logvariance", "loglengthscales", "log_Q", "CC", "DD", "log_Rchols")]
+
+
+class FfvdGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "X", "Z", "logvariance", "loglengthscales", "log_Q", "CC", "DD", "log_Rchols")]
 
 
 _dp = C.POINTER(C.c_double)
@@ -41,6 +46,7 @@ _SIGNATURES = {
     "ffvd_set_data": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "ffvd_set_params": (C.c_int, [C.c_void_p, C.POINTER(FfvdParams), C.c_int]),
     "ffvd_elbo": (C.c_int, [C.c_void_p, C.POINTER(FfvdParams), C.c_uint32, _dp, _dp]),
+    "ffvd_elbo_grad": (C.c_int, [C.c_void_p, C.POINTER(FfvdParams), C.c_uint32, C.c_int, _dp, _dp, C.POINTER(FfvdGrads)]),
     "ffvd_elbo_async": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ffvd_chain_nll": (C.c_int, [C.c_void_p, _dp]),
     "ffvd_time_elbo": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float)]),

@@ -2,6 +2,7 @@
 // launch sequence of the ELBO, and operator-level entry points used by the Python mirror of the reference API.
 #include "../../include/ffvd_abi.h"
 #include "kernels.h"
+#include "grad.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -42,6 +43,17 @@ struct ffvd_handle {
     double *Kcopy = nullptr, *Linv = nullptr, *Kinv = nullptr, *trpart = nullptr, *kterms = nullptr;   // GRAM route
     int ntiles = 0;
     double *chain_partial = nullptr;
+    // backward-pass workspace (cfg.grad)
+    struct GradWs {
+        double *Acopy = nullptr, *u = nullptr, *LAinv = nullptr, *Gamma = nullptr, *gam_part = nullptr, *uku = nullptr;
+        double *KfT = nullptr, *E = nullptr, *rsum = nullptr, *ez = nullptr, *kfu = nullptr;
+        double *cs_part = nullptr, *etx_part = nullptr, *rx2_part = nullptr, *dz_unit = nullptr, *dll_unit = nullptr, *dls_unit = nullptr;
+        double *Asum = nullptr, *GamSum = nullptr, *Gs = nullptr, *gsum = nullptr, *P1 = nullptr, *KGK = nullptr, *Epsi = nullptr;
+        double *rsum2 = nullptr, *ez2 = nullptr, *cs2 = nullptr, *etx2 = nullptr, *rx22 = nullptr, *dz_kuu = nullptr, *dll_kuu = nullptr, *dls_kuu = nullptr;
+        double *shared_part = nullptr, *dX = nullptr, *dZ = nullptr, *dlogvar = nullptr, *dloglen = nullptr, *dlogQ = nullptr;
+        double *dCC = nullptr, *dDD = nullptr, *dlogR = nullptr;
+        int ngam = 0, sp_stride = 0;
+    } gw;
     double *hterms = nullptr, *chain_terms = nullptr, *chain_nll = nullptr, *out_terms = nullptr;
     int32_t *info = nullptr;
     // pinned host staging
@@ -114,7 +126,7 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
         if (n > (size_t)c.S_local) n = c.S_local;
         h->cpp = (int)n;
     }
-    if (h->cpp > c.S_local) h->cpp = c.S_local;
+    if (h->cpp > c.S_local || c.grad) h->cpp = c.S_local;
     HIP_TRY(hipSetDevice(c.device_id));
     HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIP_TRY(dev_alloc(h, &h->X, (size_t)c.S_local * (c.T + 1) * c.D));
@@ -138,8 +150,9 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
     if (c.branch == FFVD_BRANCH_B) {
         const size_t pass_b = (size_t)h->cpp * Dl;
         HIP_TRY(dev_alloc(h, &h->F, pass_b * Tp * Mp));
-        HIP_TRY(dev_alloc(h, &h->H, pass_b * (Mp + NB) * Mp));
-        HIP_TRY(hipMemsetAsync(h->H, 0, pass_b * (Mp + NB) * Mp * sizeof(double), h->stream));
+        const size_t hrows = c.grad ? 2 * Mp + NB : Mp + NB;     // grad: Mp identity rows (-> L_A^-T) before the b row
+        HIP_TRY(dev_alloc(h, &h->H, pass_b * hrows * Mp));
+        HIP_TRY(hipMemsetAsync(h->H, 0, pass_b * hrows * Mp * sizeof(double), h->stream));
     }
     h->ntiles = gram_ntiles(h->Mp);
     if (c.branch == FFVD_BRANCH_B && c.route == FFVD_ROUTE_GRAM) {
@@ -148,6 +161,34 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
         HIP_TRY(dev_alloc(h, &h->Kinv, Dl * Mp * Mp));
         HIP_TRY(dev_alloc(h, &h->trpart, (size_t)h->nbatch * h->ntiles));
         HIP_TRY(dev_alloc(h, &h->kterms, Dl * 2));
+    }
+    if (c.grad) {
+        ffvd_handle::GradWs &g = h->gw;
+        const size_t nbt = h->nbatch, msq = Mp * Mp, nblk = Tp / 64, nblk2 = Mp / 64, S = c.S_local, J = c.Ydim;
+        g.ngam = atb_ntiles(h->Mp, h->Mp);
+        g.sp_stride = c.D * c.Ydim + 2 * c.Ydim + (int)Dl;
+        HIP_TRY(dev_alloc(h, &g.Acopy, nbt * msq));      HIP_TRY(dev_alloc(h, &g.u, nbt * Mp));
+        HIP_TRY(dev_alloc(h, &g.LAinv, nbt * msq));      HIP_TRY(dev_alloc(h, &g.Gamma, nbt * msq));
+        HIP_TRY(dev_alloc(h, &g.gam_part, nbt * g.ngam)); HIP_TRY(dev_alloc(h, &g.uku, nbt));
+        HIP_TRY(dev_alloc(h, &g.KfT, nbt * Mp * Tp));    HIP_TRY(dev_alloc(h, &g.E, nbt * Tp * Mp));
+        HIP_TRY(dev_alloc(h, &g.rsum, nbt * Tp));        HIP_TRY(dev_alloc(h, &g.ez, nbt * Tp * P));
+        HIP_TRY(dev_alloc(h, &g.kfu, nbt * Tp));
+        HIP_TRY(dev_alloc(h, &g.cs_part, nbt * nblk * Mp)); HIP_TRY(dev_alloc(h, &g.etx_part, nbt * nblk * Mp * P));
+        HIP_TRY(dev_alloc(h, &g.rx2_part, nbt * nblk * P));
+        HIP_TRY(dev_alloc(h, &g.dz_unit, nbt * c.M * P)); HIP_TRY(dev_alloc(h, &g.dll_unit, nbt * P));
+        HIP_TRY(dev_alloc(h, &g.dls_unit, nbt));
+        HIP_TRY(dev_alloc(h, &g.Asum, Dl * msq));  HIP_TRY(dev_alloc(h, &g.GamSum, Dl * msq)); HIP_TRY(dev_alloc(h, &g.Gs, Dl * msq));
+        HIP_TRY(dev_alloc(h, &g.gsum, Dl * msq));  HIP_TRY(dev_alloc(h, &g.P1, Dl * msq));     HIP_TRY(dev_alloc(h, &g.KGK, Dl * msq));
+        HIP_TRY(dev_alloc(h, &g.Epsi, Dl * msq));
+        HIP_TRY(dev_alloc(h, &g.rsum2, Dl * Mp));  HIP_TRY(dev_alloc(h, &g.ez2, Dl * Mp * P));
+        HIP_TRY(dev_alloc(h, &g.cs2, Dl * nblk2 * Mp)); HIP_TRY(dev_alloc(h, &g.etx2, Dl * nblk2 * Mp * P));
+        HIP_TRY(dev_alloc(h, &g.rx22, Dl * nblk2 * P));
+        HIP_TRY(dev_alloc(h, &g.dz_kuu, Dl * c.M * P)); HIP_TRY(dev_alloc(h, &g.dll_kuu, Dl * P)); HIP_TRY(dev_alloc(h, &g.dls_kuu, Dl));
+        HIP_TRY(dev_alloc(h, &g.shared_part, S * g.sp_stride));
+        HIP_TRY(dev_alloc(h, &g.dX, S * (c.T + 1) * c.D));
+        HIP_TRY(dev_alloc(h, &g.dZ, (size_t)c.M * P)); HIP_TRY(dev_alloc(h, &g.dlogvar, (size_t)c.D));
+        HIP_TRY(dev_alloc(h, &g.dloglen, (size_t)c.D * P)); HIP_TRY(dev_alloc(h, &g.dlogQ, (size_t)c.D));
+        HIP_TRY(dev_alloc(h, &g.dCC, (size_t)c.D * J)); HIP_TRY(dev_alloc(h, &g.dDD, J)); HIP_TRY(dev_alloc(h, &g.dlogR, J * J));
     }
     HIP_TRY(dev_alloc(h, &h->hterms, (size_t)h->nbatch * 2));
     HIP_TRY(dev_alloc(h, &h->chain_terms, (size_t)c.S_local * 8));
@@ -191,6 +232,10 @@ extern "C" int ffvd_create(const ffvd_config *cfg, ffvd_handle **out) {
     if (!(cfg->jitter >= 0.0)) return set_error(nullptr, FFVD_EINVAL, "ffvd_create: jitter must be >= 0");
     if (cfg->route != FFVD_ROUTE_REFERENCE && cfg->route != FFVD_ROUTE_GRAM)
         return set_error(nullptr, FFVD_EINVAL, "ffvd_create: unknown route");
+    if (cfg->grad && (cfg->branch != FFVD_BRANCH_B || cfg->route != FFVD_ROUTE_GRAM || cfg->kernel_kind != FFVD_KERNEL_SE ||
+                      (cfg->d_count > 0 && cfg->d_count != cfg->D)))
+        return set_error(nullptr, FFVD_EINVAL,
+                         "ffvd_create: grad = 1 needs the collapsed-U branch, FFVD_ROUTE_GRAM, the SE kernel and all latent dims");
     if (cfg->route == FFVD_ROUTE_GRAM && cfg->branch != FFVD_BRANCH_B)
         return set_error(nullptr, FFVD_EINVAL, "ffvd_create: FFVD_ROUTE_GRAM only applies to the collapsed-U branch");
     int ndev = 0;
@@ -310,14 +355,19 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
     launch_kuu_build(s, c.kernel_kind, hv, c.M, Mp, P, Dl, c.jitter, h->Kuu, gram_route ? h->Kcopy : nullptr);
     const size_t kstride = (size_t)2 * Mp * Mp;
     const size_t msq = (size_t)Mp * Mp;
-    launch_potrf_ext(s, h->Kuu, Mp, Mp, 1, Dl, kstride, h->info);
+    launch_potrf_ext(s, h->Kuu, Mp, Mp, Mp, Dl, kstride, h->info);
     if (gram_route) {
         // K^-1 = L^-T L^-1 (shared by all chains) and log|K|
         launch_transpose(s, h->Kuu + msq, kstride, h->Linv, msq, Mp, Dl);
         GramArgs gk{};
         gk.mode = GRAM_PLAIN; gk.A = h->Linv; gk.a_stride = msq; gk.rows = Mp; gk.with_row = 0; gk.Mp = Mp; gk.Dl = Dl;
         gk.d_begin = c.d_begin; gk.b0 = 0; gk.nb = Dl; gk.yn_over_batch = 1.0; gk.H = h->Kinv; gk.h_stride = msq;
-        launch_gram(s, gk);
+        if (c.grad) {       // the backward pass reads K^-1 everywhere, the Gram kernel only writes lower tiles
+            AtbArgs ak{};
+            ak.mode = ATB_PLAIN; ak.A = h->Linv; ak.a_stride = msq; ak.lda = Mp; ak.nA = Mp; ak.B = h->Linv; ak.b_stride = msq;
+            ak.ldb = Mp; ak.nB = Mp; ak.rows = Mp; ak.C = h->Kinv; ak.c_stride = msq; ak.ldc = Mp; ak.nb = Dl; ak.Dl = Dl;
+            launch_atb(s, ak);
+        } else launch_gram(s, gk);
         launch_h_finish(s, h->Kuu, Mp, kstride, Dl, h->kterms);
     }
     if (st) st->mark(0);
@@ -330,6 +380,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
         pa.d_begin = c.d_begin; pa.hv = hv; pa.W = h->Kuu + msq; pa.w_stride = kstride;
         pa.U = p.U; pa.u_ld = c.D; pa.b0 = s0 * Dl; pa.nb = ns * Dl;
         pa.F = (c.branch == FFVD_BRANCH_B) ? h->F : nullptr;
+        pa.FT = c.grad ? h->gw.KfT : nullptr;
         pa.rowsq = h->rowsq;
         pa.fmean = (c.branch == FFVD_BRANCH_A) ? h->fmean : nullptr;
         pa.ng = h->ng;
@@ -342,12 +393,23 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
             ga.A = h->F; ga.a_stride = (size_t)Tp * Mp; ga.rows = Tp; ga.with_row = 1;
             ga.X = p.X; ga.log_Q = p.log_Q; ga.T = c.T; ga.D = c.D; ga.Mp = Mp; ga.Dl = Dl;
             ga.d_begin = c.d_begin; ga.b0 = s0 * Dl; ga.nb = ns * Dl; ga.yn_over_batch = 1.0;
-            ga.H = h->H; ga.h_stride = (size_t)(Mp + NB) * Mp;
+            ga.H = h->H; ga.h_stride = (size_t)(c.grad ? 2 * Mp + NB : Mp + NB) * Mp;
+            if (c.grad) {       // rows [Mp, 2Mp) <- I (they become L_A^-T), the b row moves to 2 Mp
+                ga.brow = 2 * Mp;
+                launch_set_identity(s, h->H, ga.h_stride, Mp, Mp, ns * Dl);
+            }
             ga.Kadd = h->Kcopy; ga.kadd_stride = msq; ga.Kinv = h->Kinv; ga.kinv_stride = msq; ga.trpart = h->trpart;
             launch_gram(s, ga);
             if (st) st->mark(2);
-            launch_potrf_ext(s, h->H, Mp, NB, 0, ns * Dl, ga.h_stride, h->info + Dl + s0 * Dl);
-            launch_h_finish(s, h->H, Mp, ga.h_stride, ns * Dl, h->hterms + (size_t)2 * s0 * Dl);
+            if (c.grad) {       // keep A = K_uu + K_uf K_fu / Q: the factorisation overwrites it in place
+                HIP_TRY(hipMemcpy2DAsync(h->gw.Acopy, msq * sizeof(double), h->H, ga.h_stride * sizeof(double),
+                                         msq * sizeof(double), (size_t)ns * Dl, hipMemcpyDeviceToDevice, s));
+                launch_potrf_ext(s, h->H, Mp, Mp + NB, Mp, ns * Dl, ga.h_stride, h->info + Dl + s0 * Dl);
+                launch_h_finish(s, h->H, Mp, ga.h_stride, ns * Dl, h->hterms + (size_t)2 * s0 * Dl, 2 * Mp);
+            } else {
+                launch_potrf_ext(s, h->H, Mp, NB, 0, ns * Dl, ga.h_stride, h->info + Dl + s0 * Dl);
+                launch_h_finish(s, h->H, Mp, ga.h_stride, ns * Dl, h->hterms + (size_t)2 * s0 * Dl);
+            }
             if (st) st->mark(3);
         }
     }
@@ -500,6 +562,123 @@ extern "C" int ffvd_stage_times(ffvd_handle *h, double out_ms[8], int32_t out_la
     return FFVD_OK;
 }
 
+// ---- backward pass (see grad.hip); runs on the handle's stream right after the forward kernels ----------
+static int enqueue_grad(ffvd_handle *h, int S_total) {
+    const ffvd_config &c = h->cfg;
+    ffvd_handle::GradWs &g = h->gw;
+    const int Mp = h->Mp, Tp = h->Tp, Dl = h->Dl, P = h->P, nb = h->nbatch, S = c.S_local;
+    const size_t msq = (size_t)Mp * Mp, hstride = (size_t)(2 * Mp + NB) * Mp, fstride = (size_t)Tp * Mp;
+    hipStream_t s = h->stream;
+    const ffvd_params &p = h->cur;
+    // u = A^-1 c = L_A^-T (L_A^-1 c); L_A^-1 for the explicit inverse
+    launch_matvec(s, h->H + msq, hstride, h->H + 2 * msq, hstride, Mp, g.u, 1, Mp, Mp, nb);
+    launch_transpose(s, h->H + msq, hstride, g.LAinv, msq, Mp, nb);
+    AtbArgs ag{};
+    ag.mode = ATB_GAMMA; ag.A = g.LAinv; ag.a_stride = msq; ag.lda = Mp; ag.nA = Mp;
+    ag.B = g.LAinv; ag.b_stride = msq; ag.ldb = Mp; ag.nB = Mp; ag.b_per_dim = 0; ag.rows = Mp;
+    ag.C = g.Gamma; ag.c_stride = msq; ag.ldc = Mp; ag.nb = nb; ag.b0 = 0; ag.Dl = Dl; ag.d_begin = c.d_begin;
+    ag.log_Q = p.log_Q; ag.u = g.u; ag.u_stride = Mp; ag.Kinv = h->Kinv; ag.Kcopy = h->Kcopy; ag.k_stride = msq; ag.ldk = Mp;
+    ag.part = g.gam_part;
+    launch_atb(s, ag);
+    launch_uku(s, g.u, Mp, h->Kcopy, msq, Mp, Dl, nb, g.uku);
+    // E = (2 Kf Gamma + alpha delta u^T) o Kf
+    AtbArgs ae{};
+    ae.mode = ATB_BWD_E; ae.A = g.KfT; ae.a_stride = (size_t)Mp * Tp; ae.lda = Tp; ae.nA = Tp;
+    ae.B = g.Gamma; ae.b_stride = msq; ae.ldb = Mp; ae.nB = Mp; ae.rows = Mp;
+    ae.C = g.E; ae.c_stride = fstride; ae.ldc = Mp; ae.nb = nb; ae.b0 = 0; ae.Dl = Dl; ae.d_begin = c.d_begin;
+    ae.log_Q = p.log_Q; ae.u = g.u; ae.u_stride = Mp; ae.X = p.X; ae.T = c.T; ae.D = c.D;
+    ae.Kf = h->F; ae.kf_stride = fstride; ae.ldkf = Mp;
+    launch_atb(s, ae);
+    EReduceArgs er{};
+    er.E = g.E; er.e_stride = fstride; er.Kf = h->F; er.u = g.u; er.u_stride = Mp; er.x_is_z = 0;
+    er.x = p.X; er.x_chain_stride = (size_t)(c.T + 1) * c.D; er.x_ld = c.D; er.x_cols = c.D; er.ctrl = h->ctrl; er.C = c.C;
+    er.Z = p.Z; er.len = h->len; er.T = c.T; er.Tp = Tp; er.M = c.M; er.Mp = Mp; er.P = P; er.Dl = Dl; er.b0 = 0; er.nb = nb;
+    er.nblk = Tp / 64; er.rsum = g.rsum; er.ez = g.ez; er.kfu = g.kfu; er.cs_part = g.cs_part; er.etx_part = g.etx_part;
+    er.rx2_part = g.rx2_part;
+    launch_e_reduce(s, er);
+    launch_e_finish(s, er, g.dz_unit, g.dll_unit, g.dls_unit);
+    // K_uu side: Psi_d = sum_s Gamma_s / alpha_d - 1/2 K^-1 (sum_s A_s - S K) K^-1
+    launch_chain_sum(s, g.Acopy, msq, S, Dl, msq, g.Asum, msq);
+    launch_symmetrize(s, g.Asum, Mp, Dl);
+    launch_chain_sum(s, g.Gamma, msq, S, Dl, msq, g.GamSum, msq);
+    launch_axpby(s, g.Asum, h->Kcopy, 1.0, -(double)S, p.log_Q, c.d_begin, 0, msq, Dl, g.Gs);
+    launch_axpby(s, g.GamSum, nullptr, 1.0, 0.0, p.log_Q, c.d_begin, 1, msq, Dl, g.gsum);
+    AtbArgs ap{};
+    ap.mode = ATB_PLAIN; ap.A = g.Gs; ap.a_stride = msq; ap.lda = Mp; ap.nA = Mp; ap.B = h->Kinv; ap.b_stride = msq;
+    ap.ldb = Mp; ap.nB = Mp; ap.rows = Mp; ap.C = g.P1; ap.c_stride = msq; ap.ldc = Mp; ap.nb = Dl; ap.Dl = Dl;
+    launch_atb(s, ap);                                  // P1 = Gs^T K^-1 = Gs K^-1
+    ap.A = g.P1; ap.C = g.KGK;
+    launch_atb(s, ap);                                  // P1^T K^-1 = K^-1 Gs K^-1
+    launch_psi_e(s, g.gsum, g.KGK, h->Kcopy, c.M, Mp, Dl, c.jitter, g.Epsi);
+    EReduceArgs ek{};
+    ek.E = g.Epsi; ek.e_stride = msq; ek.Kf = nullptr; ek.u = nullptr; ek.x_is_z = 1; ek.Z = p.Z; ek.len = h->len;
+    ek.T = c.M; ek.Tp = Mp; ek.M = c.M; ek.Mp = Mp; ek.P = P; ek.Dl = Dl; ek.b0 = 0; ek.nb = Dl; ek.nblk = Mp / 64;
+    ek.rsum = g.rsum2; ek.ez = g.ez2; ek.kfu = nullptr; ek.cs_part = g.cs2; ek.etx_part = g.etx2; ek.rx2_part = g.rx22;
+    launch_e_reduce(s, ek);
+    launch_e_finish(s, ek, g.dz_kuu, g.dll_kuu, g.dls_kuu);
+    // latent trajectories and the per-chain partials of the shared parameters
+    DxArgs dx{};
+    dx.X = p.X; dx.Y = h->Y; dx.CC = p.CC; dx.DD = p.DD; dx.log_Rchols = p.log_Rchols; dx.log_Q = p.log_Q; dx.len = h->len;
+    dx.rsum = g.rsum; dx.ez = g.ez; dx.kfu = g.kfu; dx.S = S; dx.S_total = S_total; dx.T = c.T; dx.Tp = Tp; dx.D = c.D;
+    dx.P = P; dx.Ydim = c.Ydim; dx.Dl = Dl; dx.d_begin = c.d_begin; dx.shared_terms = c.shared_terms; dx.dX = g.dX;
+    launch_dx(s, dx);
+    launch_shared_partials(s, dx, g.shared_part, g.sp_stride);
+    GradFinalArgs gf{};
+    gf.T = c.T; gf.D = c.D; gf.P = P; gf.M = c.M; gf.Mp = Mp; gf.Ydim = c.Ydim; gf.Dl = Dl; gf.d_begin = c.d_begin; gf.S = S;
+    gf.S_total = S_total; gf.shared_terms = c.shared_terms; gf.prior_type = c.prior_type;
+    gf.Z = p.Z; gf.logvar = p.logvariance; gf.loglen = p.loglengthscales; gf.log_Q = p.log_Q; gf.CC = p.CC; gf.DD = p.DD;
+    gf.log_Rchols = p.log_Rchols; gf.dz_unit = g.dz_unit; gf.dll_unit = g.dll_unit; gf.dls_unit = g.dls_unit;
+    gf.dz_kuu = g.dz_kuu; gf.dll_kuu = g.dll_kuu; gf.dls_kuu = g.dls_kuu; gf.gam_part = g.gam_part; gf.ngam = g.ngam;
+    gf.trpart = h->trpart; gf.ntr = h->ntiles; gf.hterms = h->hterms; gf.uku = g.uku; gf.shared_part = g.shared_part;
+    gf.sp_stride = g.sp_stride; gf.dZ = g.dZ; gf.dlogvar = g.dlogvar; gf.dloglen = g.dloglen; gf.dlogQ = g.dlogQ;
+    gf.dCC = g.dCC; gf.dDD = g.dDD; gf.dlogR = g.dlogR;
+    launch_grad_finalize(s, gf);
+    HIP_TRY(hipGetLastError());
+    return FFVD_OK;
+}
+
+extern "C" int ffvd_elbo_grad(ffvd_handle *h, const ffvd_params *p, uint32_t flags, int S_total, double out_terms[8],
+                              double *out_nll, const ffvd_grads *gout) {
+    if (!h) return set_error(nullptr, FFVD_EINVAL, "ffvd_elbo_grad: null handle");
+    if (!h->cfg.grad) return set_error(h, FFVD_EINVAL, "ffvd_elbo_grad: the handle was created without grad = 1");
+    if (!gout) return set_error(h, FFVD_EINVAL, "ffvd_elbo_grad: null gradient struct");
+    if (S_total < h->cfg.S_local) return set_error(h, FFVD_EINVAL, "ffvd_elbo_grad: S_total < S_local");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    int rc;
+    if (p) {
+        if (flags & FFVD_PARAMS_ON_DEVICE) {
+            if ((rc = check_params(h, p, "ffvd_elbo_grad"))) return rc;
+            h->cur = *p;
+            if (!h->cur.U) h->cur.U = h->U;
+            if (!h->cur.loglengthscales) h->cur.loglengthscales = h->loglen;
+            h->have_params = true;
+        } else if ((rc = ffvd_set_params(h, p, 0))) return rc;
+    }
+    if ((rc = ready(h, "ffvd_elbo_grad"))) return rc;
+    if ((rc = enqueue_elbo(h, nullptr, nullptr))) return rc;
+    if ((rc = enqueue_grad(h, S_total))) return rc;
+    const ffvd_config &c = h->cfg;
+    ffvd_handle::GradWs &g = h->gw;
+    hipStream_t s = h->stream;
+    HIP_TRY(hipMemcpyAsync(h->h_out, h->out_terms, 8 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(h->h_chain, h->chain_nll, (size_t)c.S_local * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(h->h_info, h->info, (size_t)(h->Dl + h->nbatch) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    const size_t P = h->P, J = c.Ydim;
+    if (gout->X) HIP_TRY(hipMemcpyAsync(gout->X, g.dX, (size_t)c.S_local * (c.T + 1) * c.D * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (gout->Z) HIP_TRY(hipMemcpyAsync(gout->Z, g.dZ, (size_t)c.M * P * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (gout->logvariance) HIP_TRY(hipMemcpyAsync(gout->logvariance, g.dlogvar, (size_t)c.D * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (gout->loglengthscales) HIP_TRY(hipMemcpyAsync(gout->loglengthscales, g.dloglen, (size_t)c.D * P * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (gout->log_Q) HIP_TRY(hipMemcpyAsync(gout->log_Q, g.dlogQ, (size_t)c.D * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (gout->CC) HIP_TRY(hipMemcpyAsync(gout->CC, g.dCC, (size_t)c.D * J * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (gout->DD) HIP_TRY(hipMemcpyAsync(gout->DD, g.dDD, J * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (gout->log_Rchols) HIP_TRY(hipMemcpyAsync(gout->log_Rchols, g.dlogR, J * J * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if ((rc = check_info(h))) return rc;
+    if (out_terms) memcpy(out_terms, h->h_out, 8 * sizeof(double));
+    if (out_nll) *out_nll = h->h_out[FFVD_TERM_NLL] / (double)c.S_local;
+    return FFVD_OK;
+}
+
 // ---- operator-level entry points (temporaries allocated per call; not the hot path) --------------
 namespace {
 struct Scratch {
@@ -638,7 +817,7 @@ static int build_kuu(Scratch &sc, int kind, const double *Z, int M, int P, int D
     launch_prep_hypers(sc.stream, kind, dZ, M, Mp, P, D, 0, w.logvar, w.loglen, w.variance, w.len, w.Zs, w.zz);
     HyperView hv{w.variance, w.len, w.Zs, w.zz};
     launch_kuu_build(sc.stream, kind, hv, M, Mp, P, D, jitter, w.Kuu, nullptr);
-    launch_potrf_ext(sc.stream, w.Kuu, Mp, Mp, 1, D, (size_t)2 * Mp * Mp, w.info);
+    launch_potrf_ext(sc.stream, w.Kuu, Mp, Mp, Mp, D, (size_t)2 * Mp * Mp, w.info);
     if (dZ_out) *dZ_out = dZ;
     return FFVD_OK;
 }
@@ -895,9 +1074,9 @@ extern "C" int ffvd_op_collapse_u_mean(int kind, const double *Lm_inverse_seq, c
     ga.X = dX; ga.log_Q = dlq; ga.T = T; ga.D = D; ga.Mp = Mp; ga.Dl = D; ga.d_begin = 0;
     ga.b0 = 0; ga.nb = D; ga.yn_over_batch = 1.0; ga.H = H; ga.h_stride = hstride;     // :215,:217 (no batch rescaling)
     launch_gram(sc.stream, ga);
-    launch_potrf_ext(sc.stream, H, Mp, Mp + NB, 0, D, hstride, info);
+    launch_potrf_ext(sc.stream, H, Mp, Mp + NB, Mp, D, hstride, info);
     // U_mean[:, d] = H^-1 b = L_H^-T (L_H^-1 b)   (tf.linalg.solve, :219)
-    launch_matvec(sc.stream, H + (size_t)Mp * Mp, hstride, H + (size_t)2 * Mp * Mp, hstride, Mp, dU, D, M, D);
+    launch_matvec(sc.stream, H + (size_t)Mp * Mp, hstride, H + (size_t)2 * Mp * Mp, hstride, Mp, dU, D, 1, M, D);
     std::vector<double> hH((size_t)D * hstride);
     std::vector<int32_t> hinfo(D);
     HIP_TRY(hipMemcpyAsync(hH.data(), H, hH.size() * sizeof(double), hipMemcpyDeviceToHost, sc.stream));

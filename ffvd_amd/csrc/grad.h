@@ -1,0 +1,75 @@
+// Launchers of the backward pass (gradient of the collapsed-U nll); see grad.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ffvd {
+
+enum { ATB_PLAIN = 0, ATB_GAMMA = 1, ATB_BWD_E = 2 };
+struct AtbArgs {
+    int mode;
+    const double *A; size_t a_stride; int lda, nA;     // A: rows x lda, first nA columns used (= output rows)
+    const double *B; size_t b_stride; int ldb, nB;     // B: rows x ldb, first nB columns used (= output columns)
+    int b_per_dim;                                      // 1: B is indexed by latent dim (bz % Dl) instead of unit
+    int rows;                                           // rows summed over (multiple of 16)
+    double *C; size_t c_stride; int ldc;
+    int nb, b0, Dl, d_begin;
+    const double *log_Q;
+    const double *u; size_t u_stride;                   // GAMMA / BWD_E: u = A^-1 c per unit
+    const double *X; int T, D;                          // BWD_E: latent trajectories (delta_t)
+    const double *Kf; size_t kf_stride; int ldkf;       // BWD_E: K_fu (T x M) per unit
+    const double *Kinv, *Kcopy; size_t k_stride; int ldk;   // GAMMA: per latent dim
+    double *part;                                       // GAMMA: [nb][ntiles] partial sums of sum_ij (A^-1)_ij K_ij
+};
+void launch_atb(hipStream_t stream, const AtbArgs &a);
+int atb_ntiles(int nA, int nB);
+
+void launch_uku(hipStream_t stream, const double *u, size_t u_stride, const double *K, size_t k_stride, int Mp, int Dl,
+                int nb, double *out);
+void launch_chain_sum(hipStream_t stream, const double *in, size_t in_stride, int S, int Dl, size_t n, double *out,
+                      size_t out_stride);
+void launch_psi_e(hipStream_t stream, const double *gsum, const double *kgk, const double *Kcopy, int M, int Mp, int Dl,
+                  double jitter, double *Eout);
+void launch_symmetrize(hipStream_t stream, double *A, int Mp, int batch);
+void launch_axpby(hipStream_t stream, const double *x, const double *z, double a, double bcoef, const double *log_Q,
+                  int d_begin, int scale_mode, size_t n, int Dl, double *out);
+
+struct EReduceArgs {
+    const double *E; size_t e_stride;       // [nb] slabs of Tp x Mp
+    const double *Kf;                       // optional, same layout as E: also produce kfu[t] = sum_m Kf_tm u_m
+    const double *u; size_t u_stride;
+    int x_is_z;                             // 1: the rows are the inducing inputs themselves (K_uu side)
+    const double *x; size_t x_chain_stride; int x_ld, x_cols;
+    const double *ctrl; int C;
+    const double *Z;                        // M x P (unscaled)
+    const double *len;                      // [Dl][P]
+    int T, Tp, M, Mp, P, Dl, b0, nb, nblk;  // nblk = Tp / 64
+    double *rsum, *ez, *kfu;                // [nb][Tp], [nb][Tp][P], [nb][Tp]
+    double *cs_part, *etx_part, *rx2_part;  // [nb][nblk][Mp], [nb][nblk][Mp][P], [nb][nblk][P]
+};
+void launch_e_reduce(hipStream_t stream, const EReduceArgs &a);
+void launch_e_finish(hipStream_t stream, const EReduceArgs &a, double *dz_unit, double *dll_unit, double *dls_unit);
+
+struct DxArgs {
+    const double *X, *Y, *CC, *DD, *log_Rchols, *log_Q, *len;
+    const double *rsum, *ez, *kfu;
+    int S, S_total, T, Tp, D, P, Ydim, Dl, d_begin, shared_terms;
+    double *dX;
+};
+void launch_dx(hipStream_t stream, const DxArgs &a);
+void launch_shared_partials(hipStream_t stream, const DxArgs &a, double *out, int stride);
+
+struct GradFinalArgs {
+    int T, D, P, M, Mp, Ydim, Dl, d_begin, S, S_total, shared_terms, prior_type;
+    const double *Z, *logvar, *loglen, *log_Q, *CC, *DD, *log_Rchols;
+    const double *dz_unit, *dll_unit, *dls_unit;      // K_fu side per unit
+    const double *dz_kuu, *dll_kuu, *dls_kuu;          // K_uu side per latent dim
+    const double *gam_part; int ngam;                  // tr(A^-1 K) partials per unit
+    const double *trpart; int ntr;                     // tr(K^-1 G) partials per unit (forward)
+    const double *hterms, *uku;                        // forward {logdet, quad}; u^T K u per unit
+    const double *shared_part; int sp_stride;          // per-chain likelihood / transition partials
+    double *dZ, *dlogvar, *dloglen, *dlogQ, *dCC, *dDD, *dlogR;
+};
+void launch_grad_finalize(hipStream_t stream, const GradFinalArgs &a);
+
+}  // namespace ffvd

@@ -1,0 +1,582 @@
+// Backward pass of the collapsed-U nll (SE kernel, K_uu + K_uf K_fu / Q form) for gfx950, fp64.
+//
+// The reference differentiates `nll` with TensorFlow autodiff (tf.gradients, base_model.py:148;
+// AdamOptimizer.minimize, dgp_model.py:303-305).  Here the gradient is evaluated in closed form
+// (CPU twin: oracle/ffvd_grad_oracle.py).  Per (chain s, latent dim d):
+//   alpha = 1/Q, K = K_uu + jitter I, Kf = K_fu, G = Kf^T Kf, g = Kf^T delta, A = K + alpha G, u = A^-1 (alpha g)
+//   Gamma = 1/2 alpha (K^-1 - A^-1 - u u^T)              (dl/dG)
+//   dl/dKf = 2 Kf Gamma + delta (alpha u)^T,  dl/ddelta = alpha Kf u
+//   Psi = Gamma / alpha - 1/2 alpha K^-1 G K^-1          (dl/dK)
+//   dl/dalpha = -1/2 tr(A^-1 G) + u^T g - 1/2 u^T G u - 1/2 (T sigma^2 - tr(K^-1 G))
+// and E = dl/dK(.,.) o K(.,.) is pushed through the SE kernel:  dx = -(x r - E z)/l^2, dz = (E^T x - z c)/l^2,
+// dlog l = (sum r x^2 - 2 sum z (E^T x) + sum c z^2)/l^2, dlog sigma^2 = sum E   (r, c: row / column sums of E).
+// Dense contractions run on the fp64 MFMA through one general batched C = A^T B kernel.
+#include "kernels.h"
+#include "grad.h"
+
+namespace ffvd {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ double block_sum(double v, double *scratch /*[blockDim.x]*/) {
+    const int tid = threadIdx.x, n = blockDim.x;
+    scratch[tid] = v;
+    __syncthreads();
+    for (int s = n >> 1; s > 0; s >>= 1) {
+        if (tid < s) scratch[tid] += scratch[tid + s];
+        __syncthreads();
+    }
+    const double r = scratch[0];
+    __syncthreads();
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// General batched C = A^T B:  A [rows x lda] (first nA columns), B [rows x ldb] (first nB columns),
+// C [nA x nB] (ld ldc).  128x128 output tile per workgroup, 8 wavefronts of 64x32, two workgroups per CU,
+// register-staged double-buffered LDS (the layout of the forward Gram kernel, full rectangular tiling).
+// Epilogues:
+//   ATB_PLAIN : C = acc
+//   ATB_GAMMA : (A = B = L_A^-1)  C = 1/2 alpha (Kinv - acc - u_i u_j);  partial sums of sum_ij acc * K_ij
+//   ATB_BWD_E : (A = Kf^T, B = Gamma)  C[t][m] = (2 acc + alpha delta_t u_m) * Kf[t][m]
+// ---------------------------------------------------------------------------------------------
+constexpr int AT = 16;
+constexpr int A_LD = 128 + 16;
+
+template <int MODE>
+__global__ __launch_bounds__(512, 4) void atb_kernel(AtbArgs a) {
+    __shared__ double As[2][AT][A_LD];
+    __shared__ double Bs[2][AT][A_LD];
+    __shared__ double red[512];
+    const int bz = blockIdx.y;
+    const int ntj = (a.nB + 127) / 128;
+    const int ti = blockIdx.x / ntj, tj = blockIdx.x % ntj;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int lr = lane & 15, lk = lane >> 4;
+    const int I0 = ti * 128 + wr * 64, J0 = tj * 128 + wc * 32;
+    const bool active = (I0 < a.nA) && (J0 < a.nB);
+    const double *Ab = a.A + (size_t)bz * a.a_stride;
+    const double *Bb = a.B + (size_t)(a.b_per_dim ? (bz % a.Dl) : bz) * a.b_stride;
+    const int colA = ti * 128 + 2 * lane, colB = tj * 128 + 2 * lane;
+    const bool okA = colA < a.nA, okB = colB < a.nB;
+    const int colAc = okA ? colA : 0, colBc = okB ? colB : 0;
+    const int rowl = tid >> 6;
+
+    double2 ra[2], rb[2];
+    auto gload = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const size_t t = (size_t)c * AT + rowl + 8 * i;
+            ra[i] = *reinterpret_cast<const double2 *>(Ab + t * a.lda + colAc);
+            rb[i] = *reinterpret_cast<const double2 *>(Bb + t * a.ldb + colBc);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            double2 va = ra[i], vb = rb[i];
+            va.x = okA ? va.x : 0.0; va.y = okA ? va.y : 0.0;
+            vb.x = okB ? vb.x : 0.0; vb.y = okB ? vb.y : 0.0;
+            *reinterpret_cast<double2 *>(&As[buf][rowl + 8 * i][2 * lane]) = va;
+            *reinterpret_cast<double2 *>(&Bs[buf][rowl + 8 * i][2 * lane]) = vb;
+        }
+    };
+    d4 acc[4][2];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
+    const int nchunk = a.rows / AT;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunk) gload(c + 1);
+        if (active) {
+#pragma unroll
+            for (int ks = 0; ks < AT / 4; ++ks) {
+                double af[4], bf[2];
+#pragma unroll
+                for (int x = 0; x < 4; ++x) af[x] = As[buf][4 * ks + lk][wr * 64 + 16 * x + lr];
+#pragma unroll
+                for (int y = 0; y < 2; ++y) bf[y] = Bs[buf][4 * ks + lk][wc * 32 + 16 * y + lr];
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+#pragma unroll
+                    for (int y = 0; y < 2; ++y) acc[x][y] = mfma_f64(af[x], bf[y], acc[x][y]);
+            }
+        }
+        if (c + 1 < nchunk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    const int b = a.b0 + bz, s = b / a.Dl, dl = b % a.Dl, dg = a.d_begin + dl;
+    double *Cb = a.C + (size_t)bz * a.c_stride;
+    double part = 0.0;
+    if (active) {
+        double alpha = 1.0;
+        if (MODE != ATB_PLAIN) alpha = 1.0 / exp(a.log_Q[dg]);
+        const double *ub = (MODE != ATB_PLAIN) ? a.u + (size_t)bz * a.u_stride : nullptr;
+        const double *Xs = (MODE == ATB_BWD_E) ? a.X + (size_t)s * (a.T + 1) * a.D : nullptr;
+        const double *Kf = (MODE == ATB_BWD_E) ? a.Kf + (size_t)bz * a.kf_stride : nullptr;
+        const double *Kinv = (MODE == ATB_GAMMA) ? a.Kinv + (size_t)dl * a.k_stride : nullptr;
+        const double *Kc = (MODE == ATB_GAMMA) ? a.Kcopy + (size_t)dl * a.k_stride : nullptr;
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = I0 + 16 * x + lk + 4 * q;
+                if (i >= a.nA) continue;
+                double rowv = 0.0;
+                if (MODE == ATB_GAMMA) rowv = ub[i];
+                if (MODE == ATB_BWD_E) rowv = (i < a.T) ? alpha * (Xs[(size_t)(i + 1) * a.D + dg] - Xs[(size_t)i * a.D + dg]) : 0.0;
+#pragma unroll
+                for (int y = 0; y < 2; ++y) {
+                    const int j = J0 + 16 * y + lr;
+                    if (j >= a.nB) continue;
+                    const double g = acc[x][y][q];
+                    double v = g;
+                    if (MODE == ATB_GAMMA) {
+                        v = 0.5 * alpha * (Kinv[(size_t)i * a.ldk + j] - g - rowv * ub[j]);
+                        part += g * Kc[(size_t)i * a.ldk + j];
+                    } else if (MODE == ATB_BWD_E) {
+                        v = (2.0 * g + rowv * ub[j]) * Kf[(size_t)i * a.ldkf + j];
+                    }
+                    Cb[(size_t)i * a.ldc + j] = v;
+                }
+            }
+    }
+    if (MODE == ATB_GAMMA) {
+        red[tid] = part;
+        __syncthreads();
+        for (int st = 256; st > 0; st >>= 1) {
+            if (tid < st) red[tid] += red[tid + st];
+            __syncthreads();
+        }
+        if (tid == 0) a.part[(size_t)bz * gridDim.x + blockIdx.x] = red[0];
+    }
+}
+
+void launch_atb(hipStream_t stream, const AtbArgs &a) {
+    const int nti = (a.nA + 127) / 128, ntj = (a.nB + 127) / 128;
+    dim3 grid(nti * ntj, a.nb);
+    if (a.mode == ATB_PLAIN) hipLaunchKernelGGL(atb_kernel<ATB_PLAIN>, grid, dim3(512), 0, stream, a);
+    else if (a.mode == ATB_GAMMA) hipLaunchKernelGGL(atb_kernel<ATB_GAMMA>, grid, dim3(512), 0, stream, a);
+    else hipLaunchKernelGGL(atb_kernel<ATB_BWD_E>, grid, dim3(512), 0, stream, a);
+}
+int atb_ntiles(int nA, int nB) { return ((nA + 127) / 128) * ((nB + 127) / 128); }
+
+// ---------------------------------------------------------------------------------------------
+// small dense helpers
+// ---------------------------------------------------------------------------------------------
+// out[b] = u_b^T K_d u_b   (K = K_uu + jitter I with identity padding)
+__global__ __launch_bounds__(256) void uku_kernel(const double *u, size_t u_stride, const double *K, size_t k_stride,
+                                                  int Mp, int Dl, double *out) {
+    __shared__ double scratch[256];
+    const int bz = blockIdx.x, tid = threadIdx.x;
+    const double *ub = u + (size_t)bz * u_stride, *Kd = K + (size_t)(bz % Dl) * k_stride;
+    double acc = 0.0;
+    for (int i = tid; i < Mp; i += 256) {
+        double row = 0.0;
+        for (int j = 0; j < Mp; ++j) row += Kd[(size_t)i * Mp + j] * ub[j];
+        acc += ub[i] * row;
+    }
+    acc = block_sum(acc, scratch);
+    if (tid == 0) out[bz] = acc;
+}
+void launch_uku(hipStream_t stream, const double *u, size_t u_stride, const double *K, size_t k_stride, int Mp, int Dl,
+                int nb, double *out) {
+    hipLaunchKernelGGL(uku_kernel, dim3(nb), dim3(256), 0, stream, u, u_stride, K, k_stride, Mp, Dl, out);
+}
+
+// out[dl][e] = sum_s in[(s*Dl + dl)][e]  (fixed order over chains: deterministic)
+__global__ void chain_sum_kernel(const double *in, size_t in_stride, int S, int Dl, size_t n, double *out, size_t out_stride) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int dl = blockIdx.y;
+    if (e >= n) return;
+    double acc = 0.0;
+    for (int s = 0; s < S; ++s) acc += in[(size_t)(s * Dl + dl) * in_stride + e];
+    out[(size_t)dl * out_stride + e] = acc;
+}
+void launch_chain_sum(hipStream_t stream, const double *in, size_t in_stride, int S, int Dl, size_t n, double *out,
+                      size_t out_stride) {
+    hipLaunchKernelGGL(chain_sum_kernel, dim3((unsigned)((n + 255) / 256), Dl), dim3(256), 0, stream, in, in_stride, S,
+                       Dl, n, out, out_stride);
+}
+
+// E'[dl] = ( GamSum/alpha_sum_form - 1/2 Kinv (Asum - S K) Kinv ) o K_uu(no jitter)  where the caller provides
+//   gsum = sum_s Gamma_s / alpha  (already divided),  kgk = Kinv (Asum - S K) Kinv
+__global__ void psi_e_kernel(const double *gsum, const double *kgk, const double *Kcopy, int M, int Mp, double jitter,
+                             double *Eout) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int dl = blockIdx.y;
+    if (idx >= (size_t)Mp * Mp) return;
+    const int i = (int)(idx / Mp), j = (int)(idx % Mp);
+    const size_t o = (size_t)dl * Mp * Mp + idx;
+    double v = 0.0;
+    if (i < M && j < M) {
+        const double kuu = Kcopy[o] - ((i == j) ? jitter : 0.0);
+        v = (gsum[o] - 0.5 * kgk[o]) * kuu;
+    }
+    Eout[o] = v;
+}
+void launch_psi_e(hipStream_t stream, const double *gsum, const double *kgk, const double *Kcopy, int M, int Mp, int Dl,
+                  double jitter, double *Eout) {
+    hipLaunchKernelGGL(psi_e_kernel, dim3((unsigned)(((size_t)Mp * Mp + 255) / 256), Dl), dim3(256), 0, stream, gsum, kgk,
+                       Kcopy, M, Mp, jitter, Eout);
+}
+
+// in-place: upper triangle <- lower triangle (the forward Gram kernel only writes lower-triangular tiles)
+__global__ void symmetrize_kernel(double *A, int Mp) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)Mp * Mp) return;
+    const int i = (int)(idx / Mp), j = (int)(idx % Mp);
+    double *Ad = A + (size_t)blockIdx.y * Mp * Mp;
+    if (j > i) Ad[idx] = Ad[(size_t)j * Mp + i];
+}
+void launch_symmetrize(hipStream_t stream, double *A, int Mp, int batch) {
+    hipLaunchKernelGGL(symmetrize_kernel, dim3((unsigned)(((size_t)Mp * Mp + 255) / 256), batch), dim3(256), 0, stream, A, Mp);
+}
+
+// y = a*x + b*z elementwise on Dl matrices (used for Asum - S K and Gamma sums scaled by 1/alpha_d)
+__global__ void axpby_kernel(const double *x, const double *z, double a, double bcoef, const double *log_Q, int d_begin,
+                             int scale_mode, size_t n, double *out) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int dl = blockIdx.y;
+    if (e >= n) return;
+    double aa = a;
+    if (scale_mode == 1) aa = a * exp(log_Q[d_begin + dl]);      // multiply by Q_d = 1/alpha_d
+    const size_t o = (size_t)dl * n + e;
+    out[o] = aa * x[o] + (z ? bcoef * z[o] : 0.0);
+}
+void launch_axpby(hipStream_t stream, const double *x, const double *z, double a, double bcoef, const double *log_Q,
+                  int d_begin, int scale_mode, size_t n, int Dl, double *out) {
+    hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)((n + 255) / 256), Dl), dim3(256), 0, stream, x, z, a, bcoef, log_Q,
+                       d_begin, scale_mode, n, out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// E-reduction, stage 1: one workgroup per (64-row block, unit).  For its rows t it produces
+//   rsum[t] = sum_m E_tm,  ez[t][p] = sum_m E_tm z_mp,  kfu[t] = sum_m Kf_tm u_m   (kfu only if Kf != null)
+// and the block partials over its rows:  cs[m] = sum_t E_tm,  etx[m][p] = sum_t E_tm x_tp,  rx2[p] = sum_t r_t x_tp^2.
+// x rows: [ x[t][0:x_cols] | ctrl[t][0:C] ] or, for the K_uu side, the inducing inputs themselves.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void e_reduce_kernel(EReduceArgs a) {
+    __shared__ double xs[64][MAXP + 1];
+    __shared__ double racc[64];
+    __shared__ double scratch[256];
+    const int blk = blockIdx.x, bz = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = a.b0 + bz, s = b / a.Dl, dl = b % a.Dl;
+    const int t0 = blk * 64, P = a.P, Mp = a.Mp;
+    const double *E = a.E + (size_t)bz * a.e_stride;
+    const double *Kf = a.Kf ? a.Kf + (size_t)bz * a.e_stride : nullptr;
+    const double *ub = a.u ? a.u + (size_t)bz * a.u_stride : nullptr;
+    const double *Zd = a.Z;                                          // unscaled inducing inputs M x P
+    // stage the x rows of this block
+    for (int idx = tid; idx < 64 * P; idx += 256) {
+        const int r = idx / P, p = idx % P, t = t0 + r;
+        double v = 0.0;
+        if (t < a.T) {
+            if (a.x_is_z) v = Zd[(size_t)t * P + p];
+            else v = (p < a.x_cols) ? a.x[(size_t)s * a.x_chain_stride + (size_t)t * a.x_ld + p] : a.ctrl[(size_t)t * a.C + (p - a.x_cols)];
+        }
+        xs[r][p] = v;
+    }
+    __syncthreads();
+    // rows: each wavefront takes 16 rows; lanes stride over the columns
+    for (int rr = 0; rr < 16; ++rr) {
+        const int r = wave * 16 + rr, t = t0 + r;
+        double rs = 0.0, kf = 0.0;
+        double ez[MAXP];
+#pragma unroll
+        for (int p = 0; p < MAXP; ++p) ez[p] = 0.0;
+        if (t < a.T) {
+            for (int m = lane; m < a.M; m += 64) {
+                const double e = E[(size_t)t * Mp + m];
+                rs += e;
+                if (Kf) kf += Kf[(size_t)t * Mp + m] * ub[m];
+                for (int p = 0; p < P; ++p) ez[p] += e * Zd[(size_t)m * P + p];
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            rs += __shfl_xor(rs, off);
+            kf += __shfl_xor(kf, off);
+        }
+        for (int p = 0; p < P; ++p) {
+            double v = ez[p];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            if (lane == 0 && t < a.Tp) a.ez[((size_t)bz * a.Tp + t) * P + p] = v;
+        }
+        if (lane == 0 && t < a.Tp) {
+            a.rsum[(size_t)bz * a.Tp + t] = rs;
+            if (a.kfu) a.kfu[(size_t)bz * a.Tp + t] = kf;
+            racc[r] = rs;
+        }
+    }
+    __syncthreads();
+    // columns: thread m-strided, sum over the 64 rows of the block
+    const size_t pbase = ((size_t)bz * a.nblk + blk) * Mp;
+    for (int m = tid; m < Mp; m += 256) {
+        double cs = 0.0;
+        double etx[MAXP];
+#pragma unroll
+        for (int p = 0; p < MAXP; ++p) etx[p] = 0.0;
+        if (m < a.M) {
+            for (int r = 0; r < 64; ++r) {
+                const int t = t0 + r;
+                if (t >= a.T) break;
+                const double e = E[(size_t)t * Mp + m];
+                cs += e;
+                for (int p = 0; p < P; ++p) etx[p] += e * xs[r][p];
+            }
+        }
+        a.cs_part[pbase + m] = cs;
+        for (int p = 0; p < P; ++p) a.etx_part[(pbase + m) * P + p] = etx[p];
+    }
+    // rx2[p] = sum_t r_t x_tp^2 over the block
+    for (int p = 0; p < P; ++p) {
+        double v = 0.0;
+        if (tid < 64 && t0 + tid < a.T) v = racc[tid] * xs[tid][p] * xs[tid][p];
+        v = block_sum(v, scratch);
+        if (tid == 0) a.rx2_part[((size_t)bz * a.nblk + blk) * P + p] = v;
+    }
+}
+void launch_e_reduce(hipStream_t stream, const EReduceArgs &a) {
+    hipLaunchKernelGGL(e_reduce_kernel, dim3(a.nblk, a.nb), dim3(256), 0, stream, a);
+}
+
+// E-reduction, stage 2: one workgroup per unit.  Sums the block partials in fixed order and forms
+//   dz[m][p] = (etx[m][p] - z_mp cs_m) / l_p^2,  dlogl[p] = (rx2[p] - 2 sum_m z_mp etx[m][p] + sum_m cs_m z_mp^2) / l_p^2,
+//   dlogs2 = sum_m cs_m,   and (K_uu side, x_is_z) dz += -(z_mp r_m - ez[m][p]) / l_p^2.
+// Outputs are per unit: dz_unit [nb][M][P], dll_unit [nb][P], dls_unit [nb].
+__global__ __launch_bounds__(256) void e_finish_kernel(EReduceArgs a, double *dz_unit, double *dll_unit, double *dls_unit) {
+    __shared__ double scratch[256];
+    __shared__ double dll[MAXP];
+    const int bz = blockIdx.x, tid = threadIdx.x;
+    const int b = a.b0 + bz, dl = b % a.Dl;
+    const int P = a.P, Mp = a.Mp;
+    const double *len = a.len + (size_t)dl * P;
+    if (tid < MAXP) dll[tid] = 0.0;
+    __syncthreads();
+    double dls = 0.0;
+    double llacc[MAXP];
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) llacc[p] = 0.0;
+    for (int m = tid; m < a.M; m += 256) {
+        double cs = 0.0;
+        double etx[MAXP];
+#pragma unroll
+        for (int p = 0; p < MAXP; ++p) etx[p] = 0.0;
+        for (int blk = 0; blk < a.nblk; ++blk) {
+            const size_t pb = ((size_t)bz * a.nblk + blk) * Mp + m;
+            cs += a.cs_part[pb];
+            for (int p = 0; p < P; ++p) etx[p] += a.etx_part[pb * P + p];
+        }
+        dls += cs;
+        for (int p = 0; p < P; ++p) {
+            const double z = a.Z[(size_t)m * P + p], inv2 = 1.0 / (len[p] * len[p]);
+            double dz = (etx[p] - z * cs) * inv2;
+            if (a.x_is_z) dz += -(z * a.rsum[(size_t)bz * a.Tp + m] - a.ez[((size_t)bz * a.Tp + m) * P + p]) * inv2;
+            dz_unit[((size_t)bz * a.M + m) * P + p] = dz;
+            llacc[p] += (-2.0 * z * etx[p] + cs * z * z) * inv2;
+        }
+    }
+    dls = block_sum(dls, scratch);
+    for (int p = 0; p < P; ++p) {
+        double v = block_sum(llacc[p], scratch);
+        if (tid == 0) {
+            double rx2 = 0.0;
+            for (int blk = 0; blk < a.nblk; ++blk) rx2 += a.rx2_part[((size_t)bz * a.nblk + blk) * P + p];
+            dll_unit[(size_t)bz * P + p] = v + rx2 / (len[p] * len[p]);
+        }
+    }
+    if (tid == 0) dls_unit[bz] = dls;
+}
+void launch_e_finish(hipStream_t stream, const EReduceArgs &a, double *dz_unit, double *dll_unit, double *dls_unit) {
+    hipLaunchKernelGGL(e_finish_kernel, dim3(a.nb), dim3(256), 0, stream, a, dz_unit, dll_unit, dls_unit);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Gradient w.r.t. the latent trajectories:  dX[s][t][p]  (everything that touches X, per chain)
+//   likelihood (dgp_model.py:248-250,264), transition prior (:283-284), prior_x_0 (:252),
+//   collapsed terms through x_comb (rows t < T) and through delta_t = x_{t+1,d} - x_{t,d}.
+// One thread per (s, t, p); the sum over the local latent dims is in fixed order.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dx_kernel(DxArgs a) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int T = a.T, D = a.D;
+    const size_t per = (size_t)(T + 1) * D;
+    if (idx >= (size_t)a.S * per) return;
+    const int s = (int)(idx / per), t = (int)((idx % per) / D), p = (int)(idx % D);
+    const double *Xs = a.X + (size_t)s * per;
+    const double Tn = (double)T;
+    double g = 0.0;
+    if (a.shared_terms) {
+        if (t >= 1) {                                   // likelihood: row t-1 of Y sees X[t]
+            double acc = 0.0;
+            for (int j = 0; j < a.Ydim; ++j) {
+                double ym = a.DD[j];
+                for (int d = 0; d < D; ++d) ym += Xs[(size_t)t * D + d] * a.CC[(size_t)d * a.Ydim + j];
+                const double R = exp(a.log_Rchols[j]);
+                const double r = (a.Y[(size_t)(t - 1) * a.Ydim + j] - ym) / R;
+                acc += (r / R) * a.CC[(size_t)p * a.Ydim + j];
+            }
+            g += -acc / Tn;
+        }
+        if (t == 0) g += Xs[p] / Tn;                    // prior_x_0
+    }
+    // terms tied to latent dim p itself (delta_{t,p}) -- only if p is one of this handle's dims
+    const int dl_p = p - a.d_begin;
+    if (dl_p >= 0 && dl_p < a.Dl) {
+        const double Q = exp(a.log_Q[p]);
+        const size_t bb = ((size_t)s * a.Dl + dl_p) * a.Tp;
+        if (t >= 1) {       // x_{t} is the "x_{t+1}" of transition t-1
+            const double dlt = Xs[(size_t)t * D + p] - Xs[(size_t)(t - 1) * D + p];
+            g += dlt / Q / Tn;                                      // transition prior
+            g += -(a.kfu[bb + (t - 1)] / Q) / Tn;                   // -1/T * dl/ddelta_{t-1} (alpha Kf u)
+        }
+        if (t < T) {
+            const double dlt = Xs[(size_t)(t + 1) * D + p] - Xs[(size_t)t * D + p];
+            g -= dlt / Q / Tn;
+            g -= -(a.kfu[bb + t] / Q) / Tn;
+        }
+    }
+    // through the GP inputs x_comb[t][p] (rows t < T), summed over the local dims
+    if (t < T) {
+        double acc = 0.0;
+        for (int dl = 0; dl < a.Dl; ++dl) {
+            const size_t bb = (size_t)s * a.Dl + dl;
+            const double l = a.len[(size_t)dl * a.P + p];
+            acc += -(Xs[(size_t)t * D + p] * a.rsum[bb * a.Tp + t] - a.ez[(bb * a.Tp + t) * a.P + p]) / (l * l);
+        }
+        g += -acc / Tn;
+    }
+    a.dX[idx] = g / (double)a.S_total;
+}
+void launch_dx(hipStream_t stream, const DxArgs &a) {
+    const size_t n = (size_t)a.S * (a.T + 1) * a.D;
+    hipLaunchKernelGGL(dx_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-chain partial sums of the likelihood / transition-prior gradients w.r.t. the shared parameters:
+//   out[s][0 : D*Ydim] dCC, [.. + Ydim] dDD, [.. + Ydim] dlogR(row 0), [.. + D] dlogQ (transition part)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void shared_partials_kernel(DxArgs a, double *out, int stride) {
+    __shared__ double scratch[256];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const int T = a.T, D = a.D, J = a.Ydim;
+    const double *Xs = a.X + (size_t)s * (T + 1) * D;
+    double *o = out + (size_t)s * stride;
+    for (int j = 0; j < J; ++j) {
+        const double R = exp(a.log_Rchols[j]);
+        double dd = 0.0, dr = 0.0;
+        for (int d = 0; d < D; ++d) {
+            double dc = 0.0;
+            for (int t = tid; t < T; t += 256) {
+                double ym = a.DD[j];
+                for (int e = 0; e < D; ++e) ym += Xs[(size_t)(t + 1) * D + e] * a.CC[(size_t)e * J + j];
+                const double r = (a.Y[(size_t)t * J + j] - ym) / R;
+                dc += (r / R) * Xs[(size_t)(t + 1) * D + d];
+                if (d == 0) { dd += r / R; dr += r * r - 1.0; }
+            }
+            dc = block_sum(dc, scratch);
+            if (tid == 0) o[d * J + j] = -dc / (double)T;
+        }
+        dd = block_sum(dd, scratch);
+        dr = block_sum(dr, scratch);
+        if (tid == 0) { o[D * J + j] = -dd / (double)T; o[D * J + J + j] = -dr / (double)T; }
+    }
+    for (int dl = 0; dl < a.Dl; ++dl) {
+        const int d = a.d_begin + dl;
+        const double Q = exp(a.log_Q[d]);
+        double acc = 0.0;
+        for (int t = tid; t < T; t += 256) {
+            const double dlt = Xs[(size_t)(t + 1) * D + d] - Xs[(size_t)t * D + d];
+            acc += 0.5 - 0.5 * dlt * dlt / Q;
+        }
+        acc = block_sum(acc, scratch);
+        if (tid == 0) o[D * J + 2 * J + dl] = acc / (double)T;
+    }
+}
+void launch_shared_partials(hipStream_t stream, const DxArgs &a, double *out, int stride) {
+    hipLaunchKernelGGL(shared_partials_kernel, dim3(a.S), dim3(256), 0, stream, a, out, stride);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Final assembly of the shared-parameter gradients (one workgroup; fixed summation order).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void grad_finalize_kernel(GradFinalArgs a) {
+    const int tid = threadIdx.x;
+    const int D = a.D, P = a.P, M = a.M, J = a.Ydim, Dl = a.Dl, S = a.S;
+    const double Tn = (double)a.T, Sn = (double)a.S_total;
+    // dZ[m][p]: sum over units of the K_fu-side parts (scaled -1/T, mean over chains) + K_uu side + prior
+    for (int idx = tid; idx < M * P; idx += 256) {
+        double acc = 0.0;
+        for (int s = 0; s < S; ++s)
+            for (int dl = 0; dl < Dl; ++dl) acc += a.dz_unit[((size_t)(s * Dl + dl) * M * P) + idx];
+        double kk = 0.0;
+        for (int dl = 0; dl < Dl; ++dl) kk += a.dz_kuu[(size_t)dl * M * P + idx];
+        double g = -(acc + kk) / Tn / Sn;
+        if (a.shared_terms && a.prior_type == 1) g += a.Z[idx] / Tn;
+        a.dZ[idx] = g;
+    }
+    // loglengthscales, logvariance, log_Q for the local dims
+    for (int idx = tid; idx < Dl * P; idx += 256) {
+        const int dl = idx / P, p = idx % P, dg = a.d_begin + dl;
+        double acc = 0.0;
+        for (int s = 0; s < S; ++s) acc += a.dll_unit[(size_t)(s * Dl + dl) * P + p];
+        acc += a.dll_kuu[(size_t)dl * P + p];
+        a.dloglen[(size_t)dg * P + p] = -acc / Tn / Sn + a.loglen[(size_t)dg * P + p] / Tn;
+    }
+    for (int dl = tid; dl < Dl; dl += 256) {
+        const int dg = a.d_begin + dl;
+        const double alpha = 1.0 / exp(a.log_Q[dg]), s2 = exp(a.logvar[dg]);
+        double ls = 0.0, dq = 0.0, tq = 0.0;
+        for (int s = 0; s < S; ++s) {
+            const size_t bb = (size_t)s * Dl + dl;
+            ls += a.dls_unit[bb] - 0.5 * alpha * Tn * s2;            // K_fu side + direct Kdiag term
+            // dl/dalpha = -1/2 tr(A^-1 G) + u^T g - 1/2 u^T G u - 1/2 (T s2 - tr(K^-1 G)),  G = (A - K)/alpha
+            double trAK = 0.0;
+            for (int t = 0; t < a.ngam; ++t) trAK += a.gam_part[bb * a.ngam + t];
+            double fsq = 0.0;
+            for (int t = 0; t < a.ntr; ++t) fsq += a.trpart[bb * a.ntr + t];
+            const double quad = a.hterms[2 * bb + 1];
+            const double trAinvG = ((double)a.Mp - trAK) / alpha;
+            const double uGu = (quad - a.uku[bb]) / alpha;
+            const double dalpha = -0.5 * trAinvG + quad / alpha - 0.5 * uGu - 0.5 * (Tn * s2 - fsq);
+            dq += dalpha * (-alpha);
+            tq += a.shared_part[(size_t)s * a.sp_stride + D * J + 2 * J + dl];
+        }
+        ls += a.dls_kuu[dl];
+        a.dlogvar[dg] = -ls / Tn / Sn + (a.logvar[dg] - log(0.05)) / Tn;
+        a.dlogQ[dg] = -dq / Tn / Sn + tq / Sn + (a.shared_terms ? a.log_Q[dg] / Tn : 0.0);
+    }
+    if (a.shared_terms) {
+        for (int idx = tid; idx < D * J + J; idx += 256) {
+            double acc = 0.0;
+            for (int s = 0; s < S; ++s) acc += a.shared_part[(size_t)s * a.sp_stride + idx];
+            acc /= Sn;
+            if (idx < D * J) a.dCC[idx] = acc + a.CC[idx] / Tn;
+            else a.dDD[idx - D * J] = acc + a.DD[idx - D * J] / Tn;
+        }
+        for (int idx = tid; idx < J * J; idx += 256) {     // only row 0 of log_Rchols enters the likelihood
+            double lik = 0.0;
+            if (idx < J) {
+                for (int s = 0; s < S; ++s) lik += a.shared_part[(size_t)s * a.sp_stride + D * J + J + idx];
+                lik /= Sn;
+            }
+            a.dlogR[idx] = lik + a.log_Rchols[idx] / Tn;
+        }
+    }
+}
+void launch_grad_finalize(hipStream_t stream, const GradFinalArgs &a) {
+    hipLaunchKernelGGL(grad_finalize_kernel, dim3(1), dim3(256), 0, stream, a);
+}
+
+}  // namespace ffvd

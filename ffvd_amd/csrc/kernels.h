@@ -42,8 +42,10 @@ void launch_kernel_diag(hipStream_t stream, int kind, const double *X, int N, in
 // triangle referenced) followed by `extra_rows` further rows R (same ld = n).  On exit the lower triangle holds
 // L and the extra rows hold R * L^{-T}.  identity_extra != 0 declares that R is the n x n identity on entry
 // (so R L^{-T} = L^{-T} is upper triangular and zero blocks are skipped).  info[b] = 0 or 1 + first bad pivot.
-void launch_potrf_ext(hipStream_t stream, double *A, int n, int extra_rows, int identity_extra, int batch,
+// identity_rows: how many of the LEADING extra rows form an identity on entry (multiple of NB, 0 = none).
+void launch_potrf_ext(hipStream_t stream, double *A, int n, int extra_rows, int identity_rows, int batch,
                       size_t slab_stride, int32_t *info);
+void launch_set_identity(hipStream_t stream, double *A, size_t slab_stride, int row0, int n, int batch);
 
 struct ProjectArgs {
     int kind;
@@ -60,6 +62,7 @@ struct ProjectArgs {
     int u_ld;
     int b0, nb;             // batches [b0, b0+nb): b = s*Dl + dl
     double *F;              // [nb][Tp][Mp] or null
+    double *FT;             // kfu_build only: optional transposed copy [nb][Mp][Tp]
     double *rowsq;          // [nbatch_total][ng][Tp] or null   (sum_j F[t][j]^2 per column group)
     double *fmean;          // [nbatch_total][ng][Tp] or null   (sum_j F[t][j] * U[j][d])
     int ng;                 // column groups = ceil(Mp / 512)
@@ -95,7 +98,8 @@ int gram_ntiles(int Mp);
 void launch_gram(hipStream_t stream, GramArgs a);
 
 // hterms[b] = { logdet(H) = 2 sum log diag(L_H),  b^T H^{-1} b = |row Mp|^2 } after launch_potrf_ext on H.
-void launch_h_finish(hipStream_t stream, const double *H, int Mp, size_t h_stride, int nb, double *hterms /*[nb][2]*/);
+void launch_h_finish(hipStream_t stream, const double *H, int Mp, size_t h_stride, int nb, double *hterms /*[nb][2]*/,
+                     int yrow = 0 /* row holding L^-1 b; 0 = Mp */);
 
 struct ReduceArgs {
     int kind, branch;
@@ -131,8 +135,9 @@ void launch_finalize(hipStream_t stream, const FinalizeArgs &a);
 void launch_conditional_finish(hipStream_t stream, int kind, const double *x, int N, int P, const double *variance,
                                const double *rowsq, const double *fmean, int ng, int Tp, int D, double *mean,
                                double *var, const double *extra /* optional [D][Tp] added to var */);
+// out[i * out_ld + b * out_bs] = sum_j W[b][i][j] y[b][j]
 void launch_matvec(hipStream_t stream, const double *W, size_t w_stride, const double *y, size_t y_stride, int Mp,
-                   double *out, int out_ld, int M, int batch);
+                   double *out, int out_ld, int out_bs, int M, int batch);
 void launch_qsqrt_inflation(hipStream_t stream, const double *F, size_t f_stride, int Tp, int Mp, int M, const double *Qs,
                             double *extra, int N, int batch);
 

@@ -162,6 +162,7 @@ __global__ __launch_bounds__(256) void kfu_build_kernel(ProjectArgs a) {
     __shared__ double xs[MAXP][64];
     __shared__ double xx[64];
     __shared__ double zs[64][MAXP + 1];
+    __shared__ double tsq[64][65];
     const int tid = threadIdx.x, lane = tid & 63;
     const int t0 = blockIdx.x * 64, m0 = blockIdx.y * 64, bz = blockIdx.z;
     const int b = a.b0 + bz, s = b / a.Dl, dl = b % a.Dl;
@@ -197,6 +198,14 @@ __global__ __launch_bounds__(256) void kfu_build_kernel(ProjectArgs a) {
         double v = kernel_value<KIND>(dot, xx[r], zzv, var);
         if (!mok || t0 + r >= a.T) v = 0.0;
         out[(size_t)r * Mp] = v;
+        if (a.FT) tsq[r][lane] = v;
+    }
+    if (a.FT) {        // transposed copy K_uf (Mp x Tp), written row-wise through the LDS tile
+        __syncthreads();
+        for (int i = 0; i < 16; ++i) {
+            const int m = (tid >> 6) * 16 + i;
+            a.FT[((size_t)bz * Mp + m0 + m) * a.Tp + t0 + lane] = tsq[lane][m];
+        }
     }
 }
 void launch_kfu_build(hipStream_t stream, const ProjectArgs &a) {
@@ -347,19 +356,23 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, int n, int k
 }
 
 // tile bookkeeping shared by the panel and trailing kernels
-__device__ __forceinline__ int chunk_row0(int chunk, int k, int nmain, int n) {
-    return (chunk < nmain) ? (k + 1 + chunk) * NB : n + (chunk - nmain) * NB;
+// Extra-row blocks: the first `nid` blocks are identity-structured (block e is still zero in block-columns < e,
+// so only e <= k is live at step k: `nlive` of them), the blocks after them are always live.
+__device__ __forceinline__ int extra_block(int e, int nlive, int nid) { return (e < nlive) ? e : nid + (e - nlive); }
+__device__ __forceinline__ int chunk_row0(int chunk, int k, int nmain, int n, int nlive, int nid) {
+    return (chunk < nmain) ? (k + 1 + chunk) * NB : n + extra_block(chunk - nmain, nlive, nid) * NB;
 }
 
 // R <- R * L_kk^{-T} for one 64-row chunk: per row, y_c = (R_c - sum_{j<c} y_j L[c][j]) / L[c][c]
-__global__ __launch_bounds__(64) void potrf_panel_kernel(double *A, int n, int k, int nmain, size_t slab_stride) {
+__global__ __launch_bounds__(64) void potrf_panel_kernel(double *A, int n, int k, int nmain, size_t slab_stride,
+                                                         int nlive, int nid) {
     __shared__ double Ls[NB][NB];          // read with wave-uniform addresses only (broadcast)
     __shared__ double Rs[NB][NB + 1];
     __shared__ double invd[NB];
     const int b = blockIdx.y, lane = threadIdx.x;
     double *S = A + (size_t)b * slab_stride;
     const int k0 = k * NB;
-    const int row0 = chunk_row0(blockIdx.x, k, nmain, n);
+    const int row0 = chunk_row0(blockIdx.x, k, nmain, n, nlive, nid);
     double *R = S + (size_t)row0 * n + k0;
     for (int r = 0; r < NB; ++r) {
         Ls[r][lane] = S[(size_t)(k0 + r) * n + k0 + lane];
@@ -397,7 +410,7 @@ __global__ __launch_bounds__(64) void potrf_panel_kernel(double *A, int n, int k
 constexpr int TR_LD = NB + 2;      // LDS row stride of the staged panel blocks (doubles)
 
 __global__ __launch_bounds__(256) void potrf_trail_kernel(double *A, int n, int k, int nmain_tiles, int n1,
-                                                          size_t slab_stride, int32_t *info) {
+                                                          size_t slab_stride, int32_t *info, int nlive, int nid) {
     __shared__ double Pi_s[NB][TR_LD];
     __shared__ double Pj_s[NB][TR_LD];
     __shared__ double col[2][NB];
@@ -416,7 +429,7 @@ __global__ __launch_bounds__(256) void potrf_trail_kernel(double *A, int n, int 
     } else {
         int t = tile - nmain_tiles;
         int e = t / n1, j = t % n1;
-        rowblk0 = n + e * NB;
+        rowblk0 = n + extra_block(e, nlive, nid) * NB;
         colblk = (k + 1 + j) * NB;
     }
     const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
@@ -485,27 +498,39 @@ __global__ __launch_bounds__(256) void potrf_trail_kernel(double *A, int n, int 
     diag_block_finish(Ts, col, &bad_s, S, n, k0 + NB, info + b);
 }
 
-void launch_potrf_ext(hipStream_t stream, double *A, int n, int extra_rows, int identity_extra, int batch,
+void launch_potrf_ext(hipStream_t stream, double *A, int n, int extra_rows, int identity_rows, int batch,
                       size_t slab_stride, int32_t *info) {
     const int nb = n / NB;
-    const int nextra_all = extra_rows / NB;
+    const int nid = identity_rows / NB, ntail = extra_rows / NB - nid;
     hipLaunchKernelGGL(potrf_diag_kernel, dim3(batch), dim3(256), 0, stream, A, n, 0, slab_stride, info);
     for (int k = 0; k < nb; ++k) {
         const int nmain = nb - k - 1;
-        // identity extras: block-row e of L^{-T} is zero in block-columns < e, so only e <= k is live at step k
-        const int nextra = identity_extra ? ((k + 1 < nextra_all) ? k + 1 : nextra_all) : nextra_all;
+        const int nlive = (k + 1 < nid) ? k + 1 : nid;
+        const int nextra = nlive + ntail;
         const int nchunks = nmain + nextra;
         if (nchunks > 0)
             hipLaunchKernelGGL(potrf_panel_kernel, dim3(nchunks, batch), dim3(64), 0, stream, A, n, k, nmain,
-                               slab_stride);
+                               slab_stride, nlive, nid);
         const int n1 = nmain;
         if (n1 > 0) {
             const int nmain_tiles = n1 * (n1 + 1) / 2;
             const int ntiles = nmain_tiles + nextra * n1;
             hipLaunchKernelGGL(potrf_trail_kernel, dim3(ntiles, batch), dim3(256), 0, stream, A, n, k, nmain_tiles, n1,
-                               slab_stride, info);
+                               slab_stride, info, nlive, nid);
         }
     }
+}
+
+// rows [row0, row0 + n) of every slab <- identity (n x n), used to re-arm the extra rows that become L^-T
+__global__ void set_identity_kernel(double *A, size_t slab_stride, int row0, int n) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)n * n) return;
+    const int i = (int)(idx / n), j = (int)(idx % n);
+    A[(size_t)blockIdx.y * slab_stride + (size_t)(row0 + i) * n + j] = (i == j) ? 1.0 : 0.0;
+}
+void launch_set_identity(hipStream_t stream, double *A, size_t slab_stride, int row0, int n, int batch) {
+    hipLaunchKernelGGL(set_identity_kernel, dim3((unsigned)(((size_t)n * n + 255) / 256), batch), dim3(256), 0, stream, A,
+                       slab_stride, row0, n);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -915,22 +940,22 @@ void launch_gram(hipStream_t stream, GramArgs a) {
 // ---------------------------------------------------------------------------------------------
 // logdet(H) = 2 sum log diag(L_H)  (tf.linalg.logdet, :253);  b H^{-1} b^T = |L_H^{-1} b|^2 (:254)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void h_finish_kernel(const double *H, int Mp, size_t h_stride, double *hterms) {
+__global__ __launch_bounds__(256) void h_finish_kernel(const double *H, int Mp, size_t h_stride, double *hterms, int yrow) {
     __shared__ double scratch[256];
     const int b = blockIdx.x, tid = threadIdx.x;
     const double *Hb = H + (size_t)b * h_stride;
     double ld = 0.0, qd = 0.0;
     for (int i = tid; i < Mp; i += 256) {
         ld += log(Hb[(size_t)i * Mp + i]);
-        const double y = Hb[(size_t)Mp * Mp + i];
+        const double y = Hb[(size_t)yrow * Mp + i];
         qd += y * y;
     }
     ld = block_sum_256(ld, scratch);
     qd = block_sum_256(qd, scratch);
     if (tid == 0) { hterms[2 * b] = 2.0 * ld; hterms[2 * b + 1] = qd; }
 }
-void launch_h_finish(hipStream_t stream, const double *H, int Mp, size_t h_stride, int nb, double *hterms) {
-    hipLaunchKernelGGL(h_finish_kernel, dim3(nb), dim3(256), 0, stream, H, Mp, h_stride, hterms);
+void launch_h_finish(hipStream_t stream, const double *H, int Mp, size_t h_stride, int nb, double *hterms, int yrow) {
+    hipLaunchKernelGGL(h_finish_kernel, dim3(nb), dim3(256), 0, stream, H, Mp, h_stride, hterms, yrow > 0 ? yrow : Mp);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1039,7 +1064,7 @@ void launch_conditional_finish(hipStream_t stream, int kind, const double *x, in
 
 // out[b][i] = sum_j W[b][i][j] * y[b][j]   (posterior mean of the whitened inducing outputs: L_H^-T (L_H^-1 b))
 __global__ __launch_bounds__(256) void matvec_kernel(const double *W, size_t w_stride, const double *y, size_t y_stride,
-                                                     int Mp, double *out, int out_ld, int M) {
+                                                     int Mp, double *out, int out_ld, int out_bs, int M) {
     __shared__ double ys[2048];
     const int b = blockIdx.y, tid = threadIdx.x;
     const double *Wb = W + (size_t)b * w_stride, *yb = y + (size_t)b * y_stride;
@@ -1048,18 +1073,18 @@ __global__ __launch_bounds__(256) void matvec_kernel(const double *W, size_t w_s
         __syncthreads();
         const int i = blockIdx.x * 256 + tid;
         if (i < M) {
-            double acc = (j0 == 0) ? 0.0 : out[(size_t)i * out_ld + b];
+            double acc = (j0 == 0) ? 0.0 : out[(size_t)i * out_ld + (size_t)b * out_bs];
             const int jn = (Mp - j0 < 2048) ? Mp - j0 : 2048;
             for (int j = 0; j < jn; ++j) acc += Wb[(size_t)i * Mp + j0 + j] * ys[j];
-            out[(size_t)i * out_ld + b] = acc;
+            out[(size_t)i * out_ld + (size_t)b * out_bs] = acc;
         }
         __syncthreads();
     }
 }
 void launch_matvec(hipStream_t stream, const double *W, size_t w_stride, const double *y, size_t y_stride, int Mp,
-                   double *out, int out_ld, int M, int batch) {
+                   double *out, int out_ld, int out_bs, int M, int batch) {
     hipLaunchKernelGGL(matvec_kernel, dim3((M + 255) / 256, batch), dim3(256), 0, stream, W, w_stride, y, y_stride, Mp, out,
-                       out_ld, M);
+                       out_ld, out_bs, M);
 }
 
 // extra[b][n] = sum_j ( sum_m F[b][n][m] * Qs[m][j] )^2   -- the q_sqrt variance inflation of

@@ -26,7 +26,7 @@ class ElboEngine:
 
     def __init__(self, T, D, C, M, S, Ydim=1, kernel_type="SquaredExponential", U_collapse=True,
                  prior_type="normal", device=0, d_begin=0, d_count=0, shared_terms=True,
-                 chains_per_pass=0, jitter=1e-5, route="reference"):
+                 chains_per_pass=0, jitter=1e-5, route="reference", grad=False):
         if kernel_type not in _lib.KERNEL_KIND:
             raise ValueError("Invalid kernel type")
         if prior_type not in _lib.PRIOR_TYPE:
@@ -34,6 +34,7 @@ class ElboEngine:
         if route not in _lib.ROUTE:
             raise ValueError("route must be 'reference' or 'gram'")
         self.route = route
+        self.grad = bool(grad)
         self.lib = _lib.load()
         self.T, self.D, self.C, self.M, self.S, self.Ydim = int(T), int(D), int(C), int(M), int(S), int(Ydim)
         self.P = self.D + self.C
@@ -45,7 +46,7 @@ class ElboEngine:
             d_count=self.d_count, shared_terms=int(self.shared_terms), dtype=0,
             kernel_kind=_lib.KERNEL_KIND[kernel_type], branch=_lib.BRANCH_B if U_collapse else _lib.BRANCH_A,
             prior_type=_lib.PRIOR_TYPE[prior_type], device_id=int(device), chains_per_pass=int(chains_per_pass),
-            route=_lib.ROUTE[route], jitter=float(jitter))
+            route=_lib.ROUTE[route], grad=int(bool(grad)), reserved=0, jitter=float(jitter))
         self._h = ct.c_void_p()
         _lib.check(self.lib.ffvd_create(ct.byref(cfg), ct.byref(self._h)), None, "ffvd_create")
         self._keep = {}
@@ -144,6 +145,36 @@ class ElboEngine:
         out = np.zeros(self.S)
         _lib.check(self.lib.ffvd_chain_nll(self._h, _lib.dptr(out)), self._h, "ffvd_chain_nll")
         return out
+
+    def nll_and_grad(self, params=None, S_total=None):
+        """nll terms and the gradient of the mean-over-chains nll w.r.t. every parameter
+        (tf.gradients(nll, vars), base_model.py:148).  Needs grad=True, U_collapse=True, route="gram".
+
+        Returns (terms dict, grads dict with keys X, Z, logvariance, loglengthscales, log_Q, CC, DD, log_Rchols).
+        With chains sharded over ranks pass S_total = chains of the whole job and sum the shared-parameter
+        gradients over the ranks (X gradients are per rank)."""
+        if not self.grad:
+            raise ValueError("engine was created without grad=True")
+        S_total = int(S_total or self.S)
+        g = {
+            "X": np.zeros((self.S, self.T + 1, self.D)), "Z": np.zeros((self.M, self.P)),
+            "logvariance": np.zeros(self.D), "loglengthscales": np.zeros((self.D, self.P)),
+            "log_Q": np.zeros(self.D), "CC": np.zeros((self.D, self.Ydim)), "DD": np.zeros(self.Ydim),
+            "log_Rchols": np.zeros((self.Ydim, self.Ydim)),
+        }
+        gs = _lib.FfvdGrads(**{k: v.ctypes.data for k, v in g.items()})
+        out = np.zeros(8)
+        nll = ct.c_double()
+        if params is not None:
+            p, arrs = self._pack(params)
+            rc = self.lib.ffvd_elbo_grad(self._h, ct.byref(p), 0, S_total, _lib.dptr(out), ct.byref(nll), ct.byref(gs))
+        else:
+            rc = self.lib.ffvd_elbo_grad(self._h, None, 0, S_total, _lib.dptr(out), ct.byref(nll), ct.byref(gs))
+        _lib.check(rc, self._h, "ffvd_elbo_grad")
+        idx = {n: i for i, n in enumerate(_lib.TERM_NAMES)}
+        terms = {n: float(out[idx[n]] / self.S) for n in _lib.TERM_NAMES}
+        terms["nll_per_chain"] = self.chain_nll()
+        return terms, g
 
     def elbo_async(self, out_dev_ptr=None):
         """Enqueue one iteration; the 8 partial sums land in device memory `out_dev_ptr` (int address)."""

@@ -84,6 +84,8 @@ typedef struct ffvd_config {
     int32_t device_id;    /* HIP device ordinal                                     */
     int32_t chains_per_pass; /* chains whose T x M projections are resident at once; 0 = auto */
     int32_t route;        /* FFVD_ROUTE_*  (branch B only)                          */
+    int32_t grad;         /* 1: also allocate the backward-pass workspace (ffvd_elbo_grad) */
+    int32_t reserved;
     double  jitter;       /* 1e-5: conditionals_multi_output.py:108,159             */
 } ffvd_config;
 
@@ -127,6 +129,23 @@ int  ffvd_elbo(ffvd_handle *h, const ffvd_params *p, uint32_t flags, double out_
 /* enqueue only; the 8 doubles are written to device memory `out_terms_dev` (e.g. the buffer a
  * collective library all-reduces).  ffvd_sync() or a later synchronous call reports numerical errors. */
 int  ffvd_elbo_async(ffvd_handle *h, double *out_terms_dev);
+/* Gradient of the mean-over-chains nll w.r.t. every parameter (what the reference gets from tf.gradients(nll, vars),
+ * base_model.py:148, and AdamOptimizer.minimize(nll), dgp_model.py:303-305).  Needs a handle created with
+ * grad = 1, branch B, FFVD_ROUTE_GRAM, the SE kernel and all latent dims (d_count = D).  Host output pointers with
+ * the shapes of ffvd_params; any of them may be NULL.  S_total = number of chains of the whole job (the divisor of
+ * the mean): X gradients are complete per rank, the shared-parameter gradients of several ranks must be summed. */
+typedef struct ffvd_grads {
+    double *X;               /* S_local x (T+1) x D */
+    double *Z;               /* M x P               */
+    double *logvariance;     /* D                   */
+    double *loglengthscales; /* D x P               */
+    double *log_Q;           /* D                   */
+    double *CC;              /* D x Ydim            */
+    double *DD;              /* Ydim                */
+    double *log_Rchols;      /* Ydim x Ydim         */
+} ffvd_grads;
+int  ffvd_elbo_grad(ffvd_handle *h, const ffvd_params *p, uint32_t flags, int S_total, double out_terms[8],
+                    double *out_nll, const ffvd_grads *g);
 /* after a synchronous ffvd_elbo: per-chain nll values (S_local doubles, host) */
 int  ffvd_chain_nll(ffvd_handle *h, double *out_nll_per_chain);
 /* timing helper for benchmarks: run `iters` back-to-back ffvd_elbo_async on the resident inputs,

@@ -33,7 +33,7 @@ def test_exports_every_declared_symbol():
 
 
 def test_struct_layouts_match_header():
-    assert C.sizeof(_lib.FfvdConfig) == 16 * 4 + 8
+    assert C.sizeof(_lib.FfvdConfig) == 18 * 4 + 8
     assert C.sizeof(_lib.FfvdParams) == 9 * C.sizeof(C.c_void_p)
 
 
