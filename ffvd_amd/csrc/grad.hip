@@ -261,24 +261,26 @@ void launch_axpby(hipStream_t stream, const double *x, const double *z, double a
 }
 
 // ---------------------------------------------------------------------------------------------
-// E-reduction, stage 1: one workgroup per (64-row block, unit).  For its rows t it produces
+// E-reduction, stage 1: one workgroup per (64-row block, unit); accumulators stay in registers, the inducing
+// inputs of the current column slice and the x rows of the block sit in LDS.  For its rows t it produces
 //   rsum[t] = sum_m E_tm,  ez[t][p] = sum_m E_tm z_mp,  kfu[t] = sum_m Kf_tm u_m   (kfu only if Kf != null)
 // and the block partials over its rows:  cs[m] = sum_t E_tm,  etx[m][p] = sum_t E_tm x_tp,  rx2[p] = sum_t r_t x_tp^2.
 // x rows: [ x[t][0:x_cols] | ctrl[t][0:C] ] or, for the K_uu side, the inducing inputs themselves.
 // ---------------------------------------------------------------------------------------------
+template <int PM>      // PM: compile-time bound on P (8 or MAXP) so that the per-thread accumulators live in registers
 __global__ __launch_bounds__(256) void e_reduce_kernel(EReduceArgs a) {
-    __shared__ double xs[64][MAXP + 1];
+    __shared__ double xs[64][PM + 1];
+    __shared__ double zsm[256][PM + 1];         // inducing inputs of the current 256-column slice
     __shared__ double racc[64];
     __shared__ double scratch[256];
     const int blk = blockIdx.x, bz = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = a.b0 + bz, s = b / a.Dl, dl = b % a.Dl;
+    const int b = a.b0 + bz, s = b / a.Dl;
     const int t0 = blk * 64, P = a.P, Mp = a.Mp;
     const double *E = a.E + (size_t)bz * a.e_stride;
     const double *Kf = a.Kf ? a.Kf + (size_t)bz * a.e_stride : nullptr;
     const double *ub = a.u ? a.u + (size_t)bz * a.u_stride : nullptr;
     const double *Zd = a.Z;                                          // unscaled inducing inputs M x P
-    // stage the x rows of this block
-    for (int idx = tid; idx < 64 * P; idx += 256) {
+    for (int idx = tid; idx < 64 * P; idx += 256) {                  // x rows of this block
         const int r = idx / P, p = idx % P, t = t0 + r;
         double v = 0.0;
         if (t < a.T) {
@@ -287,59 +289,88 @@ __global__ __launch_bounds__(256) void e_reduce_kernel(EReduceArgs a) {
         }
         xs[r][p] = v;
     }
-    __syncthreads();
-    // rows: each wavefront takes 16 rows; lanes stride over the columns
+    // row accumulators: wavefront w owns rows 16w..16w+15; lane-strided over the columns of each slice
+    double rs[16], kf[16], ez[16][PM];
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+        rs[rr] = 0.0; kf[rr] = 0.0;
+#pragma unroll
+        for (int p = 0; p < PM; ++p) ez[rr][p] = 0.0;
+    }
+    const size_t pbase = ((size_t)bz * a.nblk + blk) * Mp;
+    for (int m0 = 0; m0 < Mp; m0 += 256) {
+        __syncthreads();
+        for (int idx = tid; idx < 256 * P; idx += 256) {
+            const int mm = idx / P, p = idx % P, m = m0 + mm;
+            zsm[mm][p] = (m < a.M) ? Zd[(size_t)m * P + p] : 0.0;
+        }
+        __syncthreads();
+        // ---- rows ----
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            const int t = t0 + wave * 16 + rr;
+            if (t < a.T) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int mm = lane + 64 * q, m = m0 + mm;
+                    if (m < a.M) {
+                        const double e = E[(size_t)t * Mp + m];
+                        rs[rr] += e;
+                        if (Kf) kf[rr] += Kf[(size_t)t * Mp + m] * ub[m];
+#pragma unroll
+                        for (int p = 0; p < PM; ++p)
+                            if (p < P) ez[rr][p] += e * zsm[mm][p];
+                    }
+                }
+            }
+        }
+        // ---- columns: thread tid owns column m0 + tid of this slice ----
+        {
+            const int m = m0 + tid;
+            double cs = 0.0, etx[PM];
+#pragma unroll
+            for (int p = 0; p < PM; ++p) etx[p] = 0.0;
+            if (m < a.M) {
+                for (int r = 0; r < 64; ++r) {
+                    const int t = t0 + r;
+                    if (t >= a.T) break;
+                    const double e = E[(size_t)t * Mp + m];
+                    cs += e;
+#pragma unroll
+                    for (int p = 0; p < PM; ++p)
+                        if (p < P) etx[p] += e * xs[r][p];
+                }
+            }
+            if (m < Mp) {
+                a.cs_part[pbase + m] = cs;
+#pragma unroll
+                for (int p = 0; p < PM; ++p)
+                    if (p < P) a.etx_part[(pbase + m) * P + p] = etx[p];
+            }
+        }
+    }
+    // finish the rows: reduce over the 64 lanes
+#pragma unroll
     for (int rr = 0; rr < 16; ++rr) {
         const int r = wave * 16 + rr, t = t0 + r;
-        double rs = 0.0, kf = 0.0;
-        double ez[MAXP];
+        double v = rs[rr], w = kf[rr];
+        for (int off = 32; off > 0; off >>= 1) { v += __shfl_xor(v, off); w += __shfl_xor(w, off); }
 #pragma unroll
-        for (int p = 0; p < MAXP; ++p) ez[p] = 0.0;
-        if (t < a.T) {
-            for (int m = lane; m < a.M; m += 64) {
-                const double e = E[(size_t)t * Mp + m];
-                rs += e;
-                if (Kf) kf += Kf[(size_t)t * Mp + m] * ub[m];
-                for (int p = 0; p < P; ++p) ez[p] += e * Zd[(size_t)m * P + p];
+        for (int p = 0; p < PM; ++p) {
+            if (p < P) {
+                double z = ez[rr][p];
+                for (int off = 32; off > 0; off >>= 1) z += __shfl_xor(z, off);
+                if (lane == 0) a.ez[((size_t)bz * a.Tp + t) * P + p] = z;
             }
         }
-        for (int off = 32; off > 0; off >>= 1) {
-            rs += __shfl_xor(rs, off);
-            kf += __shfl_xor(kf, off);
-        }
-        for (int p = 0; p < P; ++p) {
-            double v = ez[p];
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-            if (lane == 0 && t < a.Tp) a.ez[((size_t)bz * a.Tp + t) * P + p] = v;
-        }
-        if (lane == 0 && t < a.Tp) {
-            a.rsum[(size_t)bz * a.Tp + t] = rs;
-            if (a.kfu) a.kfu[(size_t)bz * a.Tp + t] = kf;
-            racc[r] = rs;
+        if (lane == 0) {
+            a.rsum[(size_t)bz * a.Tp + t] = v;
+            if (a.kfu) a.kfu[(size_t)bz * a.Tp + t] = w;
+            racc[r] = v;
         }
     }
     __syncthreads();
-    // columns: thread m-strided, sum over the 64 rows of the block
-    const size_t pbase = ((size_t)bz * a.nblk + blk) * Mp;
-    for (int m = tid; m < Mp; m += 256) {
-        double cs = 0.0;
-        double etx[MAXP];
-#pragma unroll
-        for (int p = 0; p < MAXP; ++p) etx[p] = 0.0;
-        if (m < a.M) {
-            for (int r = 0; r < 64; ++r) {
-                const int t = t0 + r;
-                if (t >= a.T) break;
-                const double e = E[(size_t)t * Mp + m];
-                cs += e;
-                for (int p = 0; p < P; ++p) etx[p] += e * xs[r][p];
-            }
-        }
-        a.cs_part[pbase + m] = cs;
-        for (int p = 0; p < P; ++p) a.etx_part[(pbase + m) * P + p] = etx[p];
-    }
-    // rx2[p] = sum_t r_t x_tp^2 over the block
-    for (int p = 0; p < P; ++p) {
+    for (int p = 0; p < P; ++p) {          // rx2[p] = sum_t r_t x_tp^2 over the block
         double v = 0.0;
         if (tid < 64 && t0 + tid < a.T) v = racc[tid] * xs[tid][p] * xs[tid][p];
         v = block_sum(v, scratch);
@@ -347,7 +378,8 @@ __global__ __launch_bounds__(256) void e_reduce_kernel(EReduceArgs a) {
     }
 }
 void launch_e_reduce(hipStream_t stream, const EReduceArgs &a) {
-    hipLaunchKernelGGL(e_reduce_kernel, dim3(a.nblk, a.nb), dim3(256), 0, stream, a);
+    if (a.P <= 8) hipLaunchKernelGGL(e_reduce_kernel<8>, dim3(a.nblk, a.nb), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(e_reduce_kernel<MAXP>, dim3(a.nblk, a.nb), dim3(256), 0, stream, a);
 }
 
 // E-reduction, stage 2: one workgroup per unit.  Sums the block partials in fixed order and forms
