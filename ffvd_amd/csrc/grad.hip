@@ -268,11 +268,12 @@ void launch_axpby(hipStream_t stream, const double *x, const double *z, double a
 // x rows: [ x[t][0:x_cols] | ctrl[t][0:C] ] or, for the K_uu side, the inducing inputs themselves.
 // ---------------------------------------------------------------------------------------------
 template <int PM>      // PM: compile-time bound on P (8 or MAXP) so that the per-thread accumulators live in registers
-__global__ __launch_bounds__(256) void e_reduce_kernel(EReduceArgs a) {
+__global__ __launch_bounds__(512) void e_reduce_kernel(EReduceArgs a) {
+    constexpr int NT = 512, RW = 8;           // threads, rows per wavefront (8 wavefronts x 8 rows = 64 rows)
     __shared__ double xs[64][PM + 1];
-    __shared__ double zsm[256][PM + 1];         // inducing inputs of the current 256-column slice
+    __shared__ double zsm[NT][PM + 1];          // inducing inputs of the current 512-column slice
     __shared__ double racc[64];
-    __shared__ double scratch[256];
+    __shared__ double scratch[NT];
     const int blk = blockIdx.x, bz = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = a.b0 + bz, s = b / a.Dl;
     const int t0 = blk * 64, P = a.P, Mp = a.Mp;
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(256) void e_reduce_kernel(EReduceArgs a) {
     const double *Kf = a.Kf ? a.Kf + (size_t)bz * a.e_stride : nullptr;
     const double *ub = a.u ? a.u + (size_t)bz * a.u_stride : nullptr;
     const double *Zd = a.Z;                                          // unscaled inducing inputs M x P
-    for (int idx = tid; idx < 64 * P; idx += 256) {                  // x rows of this block
+    for (int idx = tid; idx < 64 * P; idx += NT) {                   // x rows of this block
         const int r = idx / P, p = idx % P, t = t0 + r;
         double v = 0.0;
         if (t < a.T) {
@@ -289,29 +290,29 @@ __global__ __launch_bounds__(256) void e_reduce_kernel(EReduceArgs a) {
         }
         xs[r][p] = v;
     }
-    // row accumulators: wavefront w owns rows 16w..16w+15; lane-strided over the columns of each slice
-    double rs[16], kf[16], ez[16][PM];
+    // row accumulators: wavefront w owns rows 8w..8w+7; lane-strided over the columns of each slice
+    double rs[RW], kf[RW], ez[RW][PM];
 #pragma unroll
-    for (int rr = 0; rr < 16; ++rr) {
+    for (int rr = 0; rr < RW; ++rr) {
         rs[rr] = 0.0; kf[rr] = 0.0;
 #pragma unroll
         for (int p = 0; p < PM; ++p) ez[rr][p] = 0.0;
     }
     const size_t pbase = ((size_t)bz * a.nblk + blk) * Mp;
-    for (int m0 = 0; m0 < Mp; m0 += 256) {
+    for (int m0 = 0; m0 < Mp; m0 += NT) {
         __syncthreads();
-        for (int idx = tid; idx < 256 * P; idx += 256) {
+        for (int idx = tid; idx < NT * P; idx += NT) {
             const int mm = idx / P, p = idx % P, m = m0 + mm;
             zsm[mm][p] = (m < a.M) ? Zd[(size_t)m * P + p] : 0.0;
         }
         __syncthreads();
         // ---- rows ----
 #pragma unroll
-        for (int rr = 0; rr < 16; ++rr) {
-            const int t = t0 + wave * 16 + rr;
+        for (int rr = 0; rr < RW; ++rr) {
+            const int t = t0 + wave * RW + rr;
             if (t < a.T) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < NT / 64; ++q) {
                     const int mm = lane + 64 * q, m = m0 + mm;
                     if (m < a.M) {
                         const double e = E[(size_t)t * Mp + m];
@@ -351,8 +352,8 @@ __global__ __launch_bounds__(256) void e_reduce_kernel(EReduceArgs a) {
     }
     // finish the rows: reduce over the 64 lanes
 #pragma unroll
-    for (int rr = 0; rr < 16; ++rr) {
-        const int r = wave * 16 + rr, t = t0 + r;
+    for (int rr = 0; rr < RW; ++rr) {
+        const int r = wave * RW + rr, t = t0 + r;
         double v = rs[rr], w = kf[rr];
         for (int off = 32; off > 0; off >>= 1) { v += __shfl_xor(v, off); w += __shfl_xor(w, off); }
 #pragma unroll
@@ -378,8 +379,8 @@ __global__ __launch_bounds__(256) void e_reduce_kernel(EReduceArgs a) {
     }
 }
 void launch_e_reduce(hipStream_t stream, const EReduceArgs &a) {
-    if (a.P <= 8) hipLaunchKernelGGL(e_reduce_kernel<8>, dim3(a.nblk, a.nb), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(e_reduce_kernel<MAXP>, dim3(a.nblk, a.nb), dim3(256), 0, stream, a);
+    if (a.P <= 8) hipLaunchKernelGGL(e_reduce_kernel<8>, dim3(a.nblk, a.nb), dim3(512), 0, stream, a);
+    else hipLaunchKernelGGL(e_reduce_kernel<MAXP>, dim3(a.nblk, a.nb), dim3(512), 0, stream, a);
 }
 
 // E-reduction, stage 2: one workgroup per unit.  Sums the block partials in fixed order and forms
@@ -547,17 +548,6 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(GradFinalArgs a) {
     const int tid = threadIdx.x;
     const int D = a.D, P = a.P, M = a.M, J = a.Ydim, Dl = a.Dl, S = a.S;
     const double Tn = (double)a.T, Sn = (double)a.S_total;
-    // dZ[m][p]: sum over units of the K_fu-side parts (scaled -1/T, mean over chains) + K_uu side + prior
-    for (int idx = tid; idx < M * P; idx += 256) {
-        double acc = 0.0;
-        for (int s = 0; s < S; ++s)
-            for (int dl = 0; dl < Dl; ++dl) acc += a.dz_unit[((size_t)(s * Dl + dl) * M * P) + idx];
-        double kk = 0.0;
-        for (int dl = 0; dl < Dl; ++dl) kk += a.dz_kuu[(size_t)dl * M * P + idx];
-        double g = -(acc + kk) / Tn / Sn;
-        if (a.shared_terms && a.prior_type == 1) g += a.Z[idx] / Tn;
-        a.dZ[idx] = g;
-    }
     // loglengthscales, logvariance, log_Q for the local dims
     for (int idx = tid; idx < Dl * P; idx += 256) {
         const int dl = idx / P, p = idx % P, dg = a.d_begin + dl;
@@ -607,7 +597,23 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(GradFinalArgs a) {
         }
     }
 }
+// dZ[m][p]: fixed-order sum over units of the K_fu-side parts (scaled -1/T, mean over chains) + K_uu side + prior
+__global__ __launch_bounds__(256) void grad_dz_kernel(GradFinalArgs a) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int M = a.M, P = a.P, Dl = a.Dl, S = a.S;
+    if (idx >= M * P) return;
+    const double Tn = (double)a.T, Sn = (double)a.S_total;
+    double acc = 0.0;
+    for (int s = 0; s < S; ++s)
+        for (int dl = 0; dl < Dl; ++dl) acc += a.dz_unit[((size_t)(s * Dl + dl) * M * P) + idx];
+    double kk = 0.0;
+    for (int dl = 0; dl < Dl; ++dl) kk += a.dz_kuu[(size_t)dl * M * P + idx];
+    double g = -(acc + kk) / Tn / Sn;
+    if (a.shared_terms && a.prior_type == 1) g += a.Z[idx] / Tn;
+    a.dZ[idx] = g;
+}
 void launch_grad_finalize(hipStream_t stream, const GradFinalArgs &a) {
+    hipLaunchKernelGGL(grad_dz_kernel, dim3((a.M * a.P + 255) / 256), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(grad_finalize_kernel, dim3(1), dim3(256), 0, stream, a);
 }
 
