@@ -232,10 +232,9 @@ extern "C" int ffvd_create(const ffvd_config *cfg, ffvd_handle **out) {
     if (!(cfg->jitter >= 0.0)) return set_error(nullptr, FFVD_EINVAL, "ffvd_create: jitter must be >= 0");
     if (cfg->route != FFVD_ROUTE_REFERENCE && cfg->route != FFVD_ROUTE_GRAM)
         return set_error(nullptr, FFVD_EINVAL, "ffvd_create: unknown route");
-    if (cfg->grad && (cfg->branch != FFVD_BRANCH_B || cfg->route != FFVD_ROUTE_GRAM || cfg->kernel_kind != FFVD_KERNEL_SE ||
-                      (cfg->d_count > 0 && cfg->d_count != cfg->D)))
+    if (cfg->grad && (cfg->branch != FFVD_BRANCH_B || cfg->route != FFVD_ROUTE_GRAM || cfg->kernel_kind != FFVD_KERNEL_SE))
         return set_error(nullptr, FFVD_EINVAL,
-                         "ffvd_create: grad = 1 needs the collapsed-U branch, FFVD_ROUTE_GRAM, the SE kernel and all latent dims");
+                         "ffvd_create: grad = 1 needs the collapsed-U branch, FFVD_ROUTE_GRAM and the SE kernel");
     if (cfg->route == FFVD_ROUTE_GRAM && cfg->branch != FFVD_BRANCH_B)
         return set_error(nullptr, FFVD_EINVAL, "ffvd_create: FFVD_ROUTE_GRAM only applies to the collapsed-U branch");
     int ndev = 0;
@@ -632,6 +631,13 @@ static int enqueue_grad(ffvd_handle *h, int S_total) {
     gf.trpart = h->trpart; gf.ntr = h->ntiles; gf.hterms = h->hterms; gf.uku = g.uku; gf.shared_part = g.shared_part;
     gf.sp_stride = g.sp_stride; gf.dZ = g.dZ; gf.dlogvar = g.dlogvar; gf.dloglen = g.dloglen; gf.dlogQ = g.dlogQ;
     gf.dCC = g.dCC; gf.dDD = g.dDD; gf.dlogR = g.dlogR;
+    // entries this handle does not own (other ranks' dims; the shared terms off rank 0) stay zero for the all-reduce
+    HIP_TRY(hipMemsetAsync(g.dlogvar, 0, (size_t)c.D * sizeof(double), s));
+    HIP_TRY(hipMemsetAsync(g.dloglen, 0, (size_t)c.D * P * sizeof(double), s));
+    HIP_TRY(hipMemsetAsync(g.dlogQ, 0, (size_t)c.D * sizeof(double), s));
+    HIP_TRY(hipMemsetAsync(g.dCC, 0, (size_t)c.D * c.Ydim * sizeof(double), s));
+    HIP_TRY(hipMemsetAsync(g.dDD, 0, (size_t)c.Ydim * sizeof(double), s));
+    HIP_TRY(hipMemsetAsync(g.dlogR, 0, (size_t)c.Ydim * c.Ydim * sizeof(double), s));
     launch_grad_finalize(s, gf);
     HIP_TRY(hipGetLastError());
     return FFVD_OK;

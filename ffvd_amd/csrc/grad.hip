@@ -548,13 +548,16 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(GradFinalArgs a) {
     const int tid = threadIdx.x;
     const int D = a.D, P = a.P, M = a.M, J = a.Ydim, Dl = a.Dl, S = a.S;
     const double Tn = (double)a.T, Sn = (double)a.S_total;
+    // prior gradients are weighted by this handle's share of the chains, so that the sum over chain shards
+    // (and over dim shards, where S == S_total and every dim has one owner) is the whole-job gradient
+    const double w = (double)S / Sn;
     // loglengthscales, logvariance, log_Q for the local dims
     for (int idx = tid; idx < Dl * P; idx += 256) {
         const int dl = idx / P, p = idx % P, dg = a.d_begin + dl;
         double acc = 0.0;
         for (int s = 0; s < S; ++s) acc += a.dll_unit[(size_t)(s * Dl + dl) * P + p];
         acc += a.dll_kuu[(size_t)dl * P + p];
-        a.dloglen[(size_t)dg * P + p] = -acc / Tn / Sn + a.loglen[(size_t)dg * P + p] / Tn;
+        a.dloglen[(size_t)dg * P + p] = -acc / Tn / Sn + w * a.loglen[(size_t)dg * P + p] / Tn;
     }
     for (int dl = tid; dl < Dl; dl += 256) {
         const int dg = a.d_begin + dl;
@@ -576,16 +579,16 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(GradFinalArgs a) {
             tq += a.shared_part[(size_t)s * a.sp_stride + D * J + 2 * J + dl];
         }
         ls += a.dls_kuu[dl];
-        a.dlogvar[dg] = -ls / Tn / Sn + (a.logvar[dg] - log(0.05)) / Tn;
-        a.dlogQ[dg] = -dq / Tn / Sn + tq / Sn + (a.shared_terms ? a.log_Q[dg] / Tn : 0.0);
+        a.dlogvar[dg] = -ls / Tn / Sn + w * (a.logvar[dg] - log(0.05)) / Tn;
+        a.dlogQ[dg] = -dq / Tn / Sn + tq / Sn + w * a.log_Q[dg] / Tn;
     }
     if (a.shared_terms) {
         for (int idx = tid; idx < D * J + J; idx += 256) {
             double acc = 0.0;
             for (int s = 0; s < S; ++s) acc += a.shared_part[(size_t)s * a.sp_stride + idx];
             acc /= Sn;
-            if (idx < D * J) a.dCC[idx] = acc + a.CC[idx] / Tn;
-            else a.dDD[idx - D * J] = acc + a.DD[idx - D * J] / Tn;
+            if (idx < D * J) a.dCC[idx] = acc + w * a.CC[idx] / Tn;
+            else a.dDD[idx - D * J] = acc + w * a.DD[idx - D * J] / Tn;
         }
         for (int idx = tid; idx < J * J; idx += 256) {     // only row 0 of log_Rchols enters the likelihood
             double lik = 0.0;
@@ -593,7 +596,7 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(GradFinalArgs a) {
                 for (int s = 0; s < S; ++s) lik += a.shared_part[(size_t)s * a.sp_stride + D * J + J + idx];
                 lik /= Sn;
             }
-            a.dlogR[idx] = lik + a.log_Rchols[idx] / Tn;
+            a.dlogR[idx] = lik + w * a.log_Rchols[idx] / Tn;
         }
     }
 }
@@ -609,7 +612,7 @@ __global__ __launch_bounds__(256) void grad_dz_kernel(GradFinalArgs a) {
     double kk = 0.0;
     for (int dl = 0; dl < Dl; ++dl) kk += a.dz_kuu[(size_t)dl * M * P + idx];
     double g = -(acc + kk) / Tn / Sn;
-    if (a.shared_terms && a.prior_type == 1) g += a.Z[idx] / Tn;
+    if (a.shared_terms && a.prior_type == 1) g += ((double)S / Sn) * a.Z[idx] / Tn;
     a.dZ[idx] = g;
 }
 void launch_grad_finalize(hipStream_t stream, const GradFinalArgs &a) {

@@ -55,6 +55,34 @@ def all_reduce_sums(tensor, group=None):
     return tensor
 
 
+GRAD_KEYS = ("Z", "logvariance", "loglengthscales", "log_Q", "CC", "DD", "log_Rchols")
+
+
+def all_reduce_grads(grads, mode="chains", device=None, group=None):
+    """Sum the per-rank gradient dicts of `ElboEngine.nll_and_grad(S_total=...)` over the ranks.
+
+    The shared parameters (GRAD_KEYS) are packed into ONE flat fp64 buffer and all-reduced in a single call
+    (a few KB: latency-bound, so one collective, not seven).  X gradients: with mode "chains" every rank owns
+    its chains' rows and nothing is exchanged; with mode "dims" every rank holds a partial sum over its latent
+    dims for all chains, so dX joins the same buffer.  Returns a new dict."""
+    import torch
+    import torch.distributed as dist
+    keys = list(GRAD_KEYS) + (["X"] if mode == "dims" else [])
+    flat = np.concatenate([np.asarray(grads[k], dtype=np.float64).ravel() for k in keys])
+    t = torch.from_numpy(flat)
+    if device is not None:
+        t = t.to(device)
+    if dist.is_available() and dist.is_initialized():
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    flat = t.cpu().numpy()
+    out, off = dict(grads), 0
+    for k in keys:
+        n = int(np.asarray(grads[k]).size)
+        out[k] = flat[off: off + n].reshape(np.asarray(grads[k]).shape).copy()
+        off += n
+    return out
+
+
 class ShardedElbo:
     """One rank's share of the ELBO on its own GPU + the scalar all-reduce.
 
@@ -87,3 +115,13 @@ class ShardedElbo:
 
     def nll_terms(self):
         return finish(self.step())
+
+    def nll_and_grad(self):
+        """Whole-job nll terms and gradient (the engine must have been built with grad=True, route="gram"):
+        local backward pass scaled by 1/S_total, then one all-reduce of the 8 sums and one of the packed
+        shared-parameter gradients."""
+        terms, g = self.engine.nll_and_grad(S_total=self.meta["S"])
+        self.sums.copy_(self.torch.from_numpy(terms["sums8"]))
+        all_reduce_sums(self.sums)
+        g = all_reduce_grads(g, self.mode, device=self.sums.device)
+        return finish(self.sums.cpu().numpy()), g

@@ -174,6 +174,7 @@ class ElboEngine:
         idx = {n: i for i, n in enumerate(_lib.TERM_NAMES)}
         terms = {n: float(out[idx[n]] / self.S) for n in _lib.TERM_NAMES}
         terms["nll_per_chain"] = self.chain_nll()
+        terms["sums8"] = out          # raw partial sums + chain count, for the all-reduce of a sharded job
         return terms, g
 
     def elbo_async(self, out_dev_ptr=None):

@@ -131,9 +131,12 @@ int  ffvd_elbo(ffvd_handle *h, const ffvd_params *p, uint32_t flags, double out_
 int  ffvd_elbo_async(ffvd_handle *h, double *out_terms_dev);
 /* Gradient of the mean-over-chains nll w.r.t. every parameter (what the reference gets from tf.gradients(nll, vars),
  * base_model.py:148, and AdamOptimizer.minimize(nll), dgp_model.py:303-305).  Needs a handle created with
- * grad = 1, branch B, FFVD_ROUTE_GRAM, the SE kernel and all latent dims (d_count = D).  Host output pointers with
+ * grad = 1, branch B, FFVD_ROUTE_GRAM, the SE kernel.  Host output pointers with
  * the shapes of ffvd_params; any of them may be NULL.  S_total = number of chains of the whole job (the divisor of
- * the mean): X gradients are complete per rank, the shared-parameter gradients of several ranks must be summed. */
+ * the mean).  Sharded jobs: every output is this handle's ADDITIVE share of the whole-job gradient -- entries of
+ * dims it does not own are zero, prior gradients are weighted S_local / S_total (and the shared ones only added
+ * where shared_terms = 1) -- so summing the shared-parameter gradients over ranks gives the whole-job gradient; X
+ * gradients are complete per rank for chain shards and must be summed too for latent-dim shards. */
 typedef struct ffvd_grads {
     double *X;               /* S_local x (T+1) x D */
     double *Z;               /* M x P               */

@@ -141,6 +141,33 @@ def test_gradient_matches_autograd(name):
         assert err < tol, (k, err)
 
 
+def test_sharded_gradients_sum_to_the_whole():
+    """SURVEY 8(e) for the backward pass: gradients of chain shards / latent-dim shards (each scaled by
+    1/S_total, priors weighted by the shard's share) add up to the unsharded gradient."""
+    params, Y, c, meta = synthetic.make_named("small")
+    S, D = meta["S"], meta["D"]
+
+    def grads(s0, s1, d0, dc, shared):
+        p = dict(params)
+        p["X"] = params["X"][s0:s1]
+        with ElboEngine(meta["T"], D, meta["C"], meta["M"], s1 - s0, d_begin=d0, d_count=dc, shared_terms=shared,
+                        route="gram", grad=True) as e:
+            e.set_data(Y, c)
+            return e.nll_and_grad(p, S_total=S)[1]
+
+    whole = grads(0, S, 0, D, True)
+    a, b = grads(0, 1, 0, D, True), grads(1, S, 0, D, True)
+    for k in GRAD_KEYS[1:]:
+        # the K_uu side (K^-1 - A_s^-1 summed over chains) is a cancellation of eps * cond(K_uu) size: regrouping the
+        # chains moves Z / lengthscale / variance gradients at the 1e-6 level, like the autograd comparison above
+        tol = 5e-6 if k in ("Z", "loglengthscales", "logvariance") else 1e-10
+        np.testing.assert_allclose(a[k] + b[k], whole[k], rtol=0, atol=tol * np.max(np.abs(whole[k])))
+    np.testing.assert_allclose(np.concatenate((a["X"], b["X"])), whole["X"], rtol=1e-9, atol=1e-15)
+    a, b = grads(0, S, 0, 1, True), grads(0, S, 1, D - 1, False)
+    for k in GRAD_KEYS:
+        np.testing.assert_allclose(a[k] + b[k], whole[k], rtol=1e-9, atol=1e-10 * np.max(np.abs(whole[k])) + 1e-300)
+
+
 def test_chain_and_dim_sharding_sum_to_the_whole():
     """partial sums of chain shards / latent-dim shards add up to the unsharded sums."""
     params, Y, c, meta = synthetic.make_named("small")
@@ -268,6 +295,15 @@ def test_rccl_all_reduce_on_the_engine_buffer():
         assert t["nll"] == pytest.approx(float(g["B_nll"]), rel=RTOL)
         t2 = finish(sh.step())
         assert t2 == t
+        # backward pass through the same collective path (packed shared-parameter gradients)
+        shg = ShardedElbo(params, Y, c, meta, rank=0, world=1, mode="chains", device=0, route="gram", grad=True)
+        tg, grads = shg.nll_and_grad()
+        assert tg["nll"] == pytest.approx(float(g["B_nll"]), rel=1e-8)
+        with ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], meta["S"], route="gram", grad=True) as e:
+            e.set_data(Y, c)
+            _, gl = e.nll_and_grad(params)
+        for k in GRAD_KEYS:
+            np.testing.assert_array_equal(grads[k], gl[k])
     finally:
         dist.destroy_process_group()
 

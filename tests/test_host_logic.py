@@ -114,3 +114,49 @@ def test_gloo_world2_chain_sharding(tmp_path, world):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert "OK" in outs[0]
+
+
+GRAD_WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["FFVD_ROOT"])
+import numpy as np, torch.distributed as dist
+from ffvd_amd import synthetic, distributed as dm
+from oracle import ffvd_grad_oracle as gorc
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+params, Y, c, meta = synthetic.make_named("tiny")
+S = meta["S"]
+pl = dm.plan(meta, world, rank, "chains")
+def chain_grad(s):
+    p = dict(params); p["X"] = params["X"][s]
+    return gorc.nll_grad(p, Y, c)
+# rank-local gradient of the mean-over-ALL-chains nll; the closed-form ORACLE stands in for the GPU backward pass
+local = {k: np.zeros_like(np.asarray(params[k], dtype=np.float64)) for k in dm.GRAD_KEYS}
+local["X"] = np.zeros((pl["s_count"],) + params["X"].shape[1:])
+for i, s in enumerate(range(pl["s_begin"], pl["s_begin"] + pl["s_count"])):
+    g = chain_grad(s)
+    local["X"][i] = g["X"] / S
+    for k in dm.GRAD_KEYS:
+        local[k] += g[k] / S
+got = dm.all_reduce_grads(local, "chains")
+ref = {k: sum(chain_grad(s)[k] for s in range(S)) / S for k in dm.GRAD_KEYS}
+for k in dm.GRAD_KEYS:
+    assert got[k].shape == ref[k].shape and np.allclose(got[k], ref[k], rtol=1e-12, atol=1e-15), k
+assert np.array_equal(got["X"], local["X"])              # chain shards keep their own rows
+print("OK")
+dist.destroy_process_group()
+'''
+
+
+def test_gloo_world2_gradient_all_reduce(tmp_path):
+    """world_size-2 rehearsal of the sharded backward pass: one packed all-reduce of the shared-parameter gradients."""
+    import subprocess
+    script = tmp_path / "gworker.py"
+    script.write_text(GRAD_WORKER)
+    env = dict(os.environ, FFVD_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2",
+               OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "OK" in outs[0] and "OK" in outs[1]
