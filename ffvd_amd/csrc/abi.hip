@@ -29,6 +29,9 @@ struct ffvd_handle {
     ffvd_config cfg;
     int P = 0, Mp = 0, Tp = 0, Dl = 0, nbatch = 0, ng = 0, cpp = 0;
     hipStream_t stream = nullptr;
+    double *dinvK = nullptr, *dinvH = nullptr;   // Cholesky scratch (kernels.h DINV_STRIDE per matrix)
+    hipStream_t aux = nullptr;          // side stream: the K_uu chain runs beside the K_fu build (Gram route)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string err;
     std::vector<void *> allocs;
     int64_t ws_bytes = 0;
@@ -102,6 +105,9 @@ extern "C" int ffvd_destroy(ffvd_handle *h) {
     if (h->h_out) hipHostFree(h->h_out);
     if (h->h_chain) hipHostFree(h->h_chain);
     if (h->h_info) hipHostFree(h->h_info);
+    if (h->aux) { hipStreamSynchronize(h->aux); hipStreamDestroy(h->aux); }
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    if (h->ev_join) hipEventDestroy(h->ev_join);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
     return FFVD_OK;
@@ -129,6 +135,13 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
     if (h->cpp > c.S_local || c.grad) h->cpp = c.S_local;
     HIP_TRY(hipSetDevice(c.device_id));
     HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    {   // the side stream carries a short latency-bound chain: give it the highest priority
+        int lo = 0, hi = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIP_TRY(hipStreamCreateWithPriority(&h->aux, hipStreamNonBlocking, hi));
+    }
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     HIP_TRY(dev_alloc(h, &h->X, (size_t)c.S_local * (c.T + 1) * c.D));
     HIP_TRY(dev_alloc(h, &h->Z, (size_t)c.M * P));
     HIP_TRY(dev_alloc(h, &h->U, (size_t)c.M * c.D));
@@ -196,6 +209,8 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
     HIP_TRY(dev_alloc(h, &h->chain_nll, (size_t)c.S_local));
     HIP_TRY(dev_alloc(h, &h->out_terms, (size_t)8));
     HIP_TRY(dev_alloc(h, &h->info, (size_t)(Dl + h->nbatch)));
+    HIP_TRY(dev_alloc(h, &h->dinvK, (size_t)Dl * DINV_STRIDE));
+    HIP_TRY(dev_alloc(h, &h->dinvH, (size_t)(h->nbatch ? h->nbatch : 1) * DINV_STRIDE));
     HIP_TRY(hipHostMalloc((void **)&h->h_out, 8 * sizeof(double)));
     HIP_TRY(hipHostMalloc((void **)&h->h_chain, (size_t)(c.S_local ? c.S_local : 1) * sizeof(double)));
     HIP_TRY(hipHostMalloc((void **)&h->h_info, (size_t)(Dl + h->nbatch) * sizeof(int32_t)));
@@ -351,13 +366,22 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
                        h->variance, h->len, h->Zs, h->zz);
     HyperView hv{h->variance, h->len, h->Zs, h->zz};
     const bool gram_route = (c.branch == FFVD_BRANCH_B && c.route == FFVD_ROUTE_GRAM);
-    launch_kuu_build(s, c.kernel_kind, hv, c.M, Mp, P, Dl, c.jitter, h->Kuu, gram_route ? h->Kcopy : nullptr);
+    // Gram route: nothing of the K_fu build depends on K_uu, so the latency-bound K_uu chain (build, Cholesky with
+    // the L^-T rows, K^-1, log|K|: a handful of workgroups per launch) runs on the side stream beside the
+    // HBM-bound K_fu build of the first pass and joins before the Gram kernel, which adds K_uu and reads K^-1.
+    hipStream_t sk = s;
+    if (gram_route) {
+        sk = h->aux;
+        HIP_TRY(hipEventRecord(h->ev_fork, s));
+        HIP_TRY(hipStreamWaitEvent(sk, h->ev_fork, 0));
+    }
+    launch_kuu_build(sk, c.kernel_kind, hv, c.M, Mp, P, Dl, c.jitter, h->Kuu, gram_route ? h->Kcopy : nullptr);
     const size_t kstride = (size_t)2 * Mp * Mp;
     const size_t msq = (size_t)Mp * Mp;
-    launch_potrf_ext(s, h->Kuu, Mp, Mp, Mp, Dl, kstride, h->info);
+    launch_potrf_ext(sk, h->Kuu, Mp, Mp, Mp, Dl, kstride, h->info, h->dinvK);
     if (gram_route) {
         // K^-1 = L^-T L^-1 (shared by all chains) and log|K|
-        launch_transpose(s, h->Kuu + msq, kstride, h->Linv, msq, Mp, Dl);
+        launch_transpose(sk, h->Kuu + msq, kstride, h->Linv, msq, Mp, Dl);
         GramArgs gk{};
         gk.mode = GRAM_PLAIN; gk.A = h->Linv; gk.a_stride = msq; gk.rows = Mp; gk.with_row = 0; gk.Mp = Mp; gk.Dl = Dl;
         gk.d_begin = c.d_begin; gk.b0 = 0; gk.nb = Dl; gk.yn_over_batch = 1.0; gk.H = h->Kinv; gk.h_stride = msq;
@@ -365,9 +389,10 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
             AtbArgs ak{};
             ak.mode = ATB_PLAIN; ak.A = h->Linv; ak.a_stride = msq; ak.lda = Mp; ak.nA = Mp; ak.B = h->Linv; ak.b_stride = msq;
             ak.ldb = Mp; ak.nB = Mp; ak.rows = Mp; ak.C = h->Kinv; ak.c_stride = msq; ak.ldc = Mp; ak.nb = Dl; ak.Dl = Dl;
-            launch_atb(s, ak);
-        } else launch_gram(s, gk);
-        launch_h_finish(s, h->Kuu, Mp, kstride, Dl, h->kterms);
+            launch_atb(sk, ak);
+        } else launch_gram(sk, gk);
+        launch_h_finish(sk, h->Kuu, Mp, kstride, Dl, h->kterms);
+        HIP_TRY(hipEventRecord(h->ev_join, sk));
     }
     if (st) st->mark(0);
     for (int s0 = 0; s0 < c.S_local; s0 += h->cpp) {
@@ -383,8 +408,10 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
         pa.rowsq = h->rowsq;
         pa.fmean = (c.branch == FFVD_BRANCH_A) ? h->fmean : nullptr;
         pa.ng = h->ng;
-        if (gram_route) launch_kfu_build(s, pa);
-        else launch_project(s, pa);
+        if (gram_route) {
+            launch_kfu_build(s, pa);
+            if (s0 == 0) HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));
+        } else launch_project(s, pa);
         if (st) st->mark(1);
         if (c.branch == FFVD_BRANCH_B) {
             GramArgs ga{};
@@ -403,10 +430,10 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
             if (c.grad) {       // keep A = K_uu + K_uf K_fu / Q: the factorisation overwrites it in place
                 HIP_TRY(hipMemcpy2DAsync(h->gw.Acopy, msq * sizeof(double), h->H, ga.h_stride * sizeof(double),
                                          msq * sizeof(double), (size_t)ns * Dl, hipMemcpyDeviceToDevice, s));
-                launch_potrf_ext(s, h->H, Mp, Mp + NB, Mp, ns * Dl, ga.h_stride, h->info + Dl + s0 * Dl);
+                launch_potrf_ext(s, h->H, Mp, Mp + NB, Mp, ns * Dl, ga.h_stride, h->info + Dl + s0 * Dl, h->dinvH);
                 launch_h_finish(s, h->H, Mp, ga.h_stride, ns * Dl, h->hterms + (size_t)2 * s0 * Dl, 2 * Mp);
             } else {
-                launch_potrf_ext(s, h->H, Mp, NB, 0, ns * Dl, ga.h_stride, h->info + Dl + s0 * Dl);
+                launch_potrf_ext(s, h->H, Mp, NB, 0, ns * Dl, ga.h_stride, h->info + Dl + s0 * Dl, h->dinvH);
                 launch_h_finish(s, h->H, Mp, ga.h_stride, ns * Dl, h->hterms + (size_t)2 * s0 * Dl);
             }
             if (st) st->mark(3);
@@ -775,7 +802,9 @@ extern "C" int ffvd_op_cholesky(const double *A, int n, int batch, double *L, in
     int32_t *dinfo = sc.alloc<int32_t>(batch);
     OP_CHECK(dinfo, "ffvd_op_cholesky");
     HIP_TRY(hipMemsetAsync(dinfo, 0, batch * sizeof(int32_t), sc.stream));
-    launch_potrf_ext(sc.stream, dA, np, 0, 0, batch, slab, dinfo);
+    double *dinv = sc.alloc<double>((size_t)batch * DINV_STRIDE);
+    OP_CHECK(dinv, "ffvd_op_cholesky");
+    launch_potrf_ext(sc.stream, dA, np, 0, 0, batch, slab, dinfo, dinv);
     std::vector<int32_t> hinfo(batch, 0);
     HIP_TRY(hipMemcpyAsync(pad.data(), dA, pad.size() * sizeof(double), hipMemcpyDeviceToHost, sc.stream));
     HIP_TRY(hipMemcpyAsync(hinfo.data(), dinfo, batch * sizeof(int32_t), hipMemcpyDeviceToHost, sc.stream));
@@ -798,7 +827,7 @@ extern "C" int ffvd_op_cholesky(const double *A, int n, int batch, double *L, in
 
 // shared by kernel_pre_cal / conditional: device-side hypers + K_uu + extended Cholesky
 struct KuuWork {
-    double *variance, *len, *Zs, *zz, *Kuu, *logvar, *loglen;
+    double *variance, *len, *Zs, *zz, *Kuu, *logvar, *loglen, *dinv;
     int32_t *info;
     int Mp;
 };
@@ -815,7 +844,8 @@ static int build_kuu(Scratch &sc, int kind, const double *Z, int M, int P, int D
     w.zz = sc.alloc<double>((size_t)D * Mp);
     w.Kuu = sc.alloc<double>((size_t)D * 2 * Mp * Mp);
     w.info = sc.alloc<int32_t>(D);
-    if (!dZ || !w.logvar || !w.loglen || !w.variance || !w.len || !w.Zs || !w.zz || !w.Kuu || !w.info) return FFVD_ENOMEM;
+    w.dinv = sc.alloc<double>((size_t)D * DINV_STRIDE);
+    if (!dZ || !w.logvar || !w.loglen || !w.variance || !w.len || !w.Zs || !w.zz || !w.Kuu || !w.info || !w.dinv) return FFVD_ENOMEM;
     if (loglengthscales &&
         hipMemcpyAsync(w.loglen, loglengthscales, (size_t)D * P * sizeof(double), hipMemcpyHostToDevice, sc.stream) != hipSuccess)
         return FFVD_EDEVICE;
@@ -823,7 +853,7 @@ static int build_kuu(Scratch &sc, int kind, const double *Z, int M, int P, int D
     launch_prep_hypers(sc.stream, kind, dZ, M, Mp, P, D, 0, w.logvar, w.loglen, w.variance, w.len, w.Zs, w.zz);
     HyperView hv{w.variance, w.len, w.Zs, w.zz};
     launch_kuu_build(sc.stream, kind, hv, M, Mp, P, D, jitter, w.Kuu, nullptr);
-    launch_potrf_ext(sc.stream, w.Kuu, Mp, Mp, Mp, D, (size_t)2 * Mp * Mp, w.info);
+    launch_potrf_ext(sc.stream, w.Kuu, Mp, Mp, Mp, D, (size_t)2 * Mp * Mp, w.info, w.dinv);
     if (dZ_out) *dZ_out = dZ;
     return FFVD_OK;
 }
@@ -897,8 +927,9 @@ extern "C" int ffvd_op_collapse(int kind, const double *Lm_inverse_seq, const do
     double *rowsq = sc.alloc<double>((size_t)D * ng * Tp);
     double *hterms = sc.alloc<double>((size_t)D * 2), *cterms = sc.alloc<double>(8);
     int32_t *info = sc.alloc<int32_t>(D);
+    double *dinv = sc.alloc<double>((size_t)D * DINV_STRIDE);
     if (!dW || !dXc || !dX || !dZ || !dlv || !dll || !dlq || !variance || !len || !Zs || !zz || !F || !H || !rowsq ||
-        !hterms || !cterms || !info)
+        !hterms || !cterms || !info || !dinv)
         return set_error(nullptr, FFVD_ENOMEM, "ffvd_op_collapse: device allocation or upload failed");
     if (loglengthscales)
         HIP_TRY(hipMemcpyAsync(dll, loglengthscales, (size_t)D * P * sizeof(double), hipMemcpyHostToDevice, sc.stream));
@@ -917,7 +948,7 @@ extern "C" int ffvd_op_collapse(int kind, const double *Lm_inverse_seq, const do
     ga.X = dX; ga.log_Q = dlq; ga.T = T; ga.D = D; ga.Mp = Mp; ga.Dl = D; ga.d_begin = 0;
     ga.b0 = 0; ga.nb = D; ga.yn_over_batch = Y_N / batch_size; ga.H = H; ga.h_stride = hstride;
     launch_gram(sc.stream, ga);
-    launch_potrf_ext(sc.stream, H, Mp, NB, 0, D, hstride, info);
+    launch_potrf_ext(sc.stream, H, Mp, NB, 0, D, hstride, info, dinv);
     launch_h_finish(sc.stream, H, Mp, hstride, D, hterms);
     ReduceArgs ra{};
     ra.kind = kind; ra.branch = FFVD_BRANCH_B; ra.X = dX; ra.ctrl = nullptr; ra.Y = nullptr; ra.log_Q = dlq;
@@ -1062,7 +1093,8 @@ extern "C" int ffvd_op_collapse_u_mean(int kind, const double *Lm_inverse_seq, c
     double *H = sc.upload(Hinit.data(), Hinit.size());
     double *dU = sc.alloc<double>((size_t)M * D);
     int32_t *info = sc.alloc<int32_t>(D);
-    if (!dW || !dXc || !dX || !dZ || !dlv || !dlq || !dll || !variance || !len || !Zs || !zz || !F || !rowsq || !H || !dU || !info)
+    double *dinv = sc.alloc<double>((size_t)D * DINV_STRIDE);
+    if (!dW || !dXc || !dX || !dZ || !dlv || !dlq || !dll || !variance || !len || !Zs || !zz || !F || !rowsq || !H || !dU || !info || !dinv)
         return set_error(nullptr, FFVD_ENOMEM, "ffvd_op_collapse_u_mean: device allocation or upload failed");
     if (loglengthscales)
         HIP_TRY(hipMemcpyAsync(dll, loglengthscales, (size_t)D * P * sizeof(double), hipMemcpyHostToDevice, sc.stream));
@@ -1080,7 +1112,7 @@ extern "C" int ffvd_op_collapse_u_mean(int kind, const double *Lm_inverse_seq, c
     ga.X = dX; ga.log_Q = dlq; ga.T = T; ga.D = D; ga.Mp = Mp; ga.Dl = D; ga.d_begin = 0;
     ga.b0 = 0; ga.nb = D; ga.yn_over_batch = 1.0; ga.H = H; ga.h_stride = hstride;     // :215,:217 (no batch rescaling)
     launch_gram(sc.stream, ga);
-    launch_potrf_ext(sc.stream, H, Mp, Mp + NB, Mp, D, hstride, info);
+    launch_potrf_ext(sc.stream, H, Mp, Mp + NB, Mp, D, hstride, info, dinv);
     // U_mean[:, d] = H^-1 b = L_H^-T (L_H^-1 b)   (tf.linalg.solve, :219)
     launch_matvec(sc.stream, H + (size_t)Mp * Mp, hstride, H + (size_t)2 * Mp * Mp, hstride, Mp, dU, D, 1, M, D);
     std::vector<double> hH((size_t)D * hstride);

@@ -7,6 +7,7 @@
 namespace ffvd {
 
 constexpr int NB = 64;        // universal block size: M is padded to a multiple of NB (identity padding)
+constexpr int DINV_STRIDE = 4 * 16 * 16;   // Cholesky scratch per matrix: inverses of the four 16x16 diagonal sub-blocks
 constexpr int STRIP = 64;     // rows of K_fu handled by one workgroup of the projection kernel
 constexpr int MAXP = 32;      // largest GP input dimension P = D + C supported by the LDS layout
 
@@ -43,8 +44,9 @@ void launch_kernel_diag(hipStream_t stream, int kind, const double *X, int N, in
 // L and the extra rows hold R * L^{-T}.  identity_extra != 0 declares that R is the n x n identity on entry
 // (so R L^{-T} = L^{-T} is upper triangular and zero blocks are skipped).  info[b] = 0 or 1 + first bad pivot.
 // identity_rows: how many of the LEADING extra rows form an identity on entry (multiple of NB, 0 = none).
+// dinv: device scratch of batch * DINV_STRIDE doubles (inverted 16x16 diagonal sub-blocks of the current block step).
 void launch_potrf_ext(hipStream_t stream, double *A, int n, int extra_rows, int identity_rows, int batch,
-                      size_t slab_stride, int32_t *info);
+                      size_t slab_stride, int32_t *info, double *dinv);
 void launch_set_identity(hipStream_t stream, double *A, size_t slab_stride, int row0, int n, int batch);
 
 struct ProjectArgs {

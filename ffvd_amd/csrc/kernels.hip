@@ -289,75 +289,93 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// 64x64 Cholesky by ONE workgroup of 4 wavefronts: lane = row, wavefront w owns columns k = w (mod 4), so every
-// lane keeps 16 entries of its row in registers.  Per pivot: the owner wavefront scales column j, publishes it
-// through LDS, one workgroup barrier, then every wavefront updates its own columns (right-looking).
-// In: a[c] = A[lane][4c + w].  Out: a[c] = L[lane][4c + w] for 4c + w <= lane.  Returns 0 or 1 + first bad pivot
-// (identical in all threads).  col: LDS scratch [2][NB]; bad_s: LDS int.
-__device__ __forceinline__ int chol64_4w(double (&a)[16], double (*col)[NB], int *bad_s, const int lane, const int w) {
-    if (threadIdx.x == 0) *bad_s = 0;
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        if ((j & 3) == w) {                                  // owner of column j (wave-uniform)
-            const double ajj = readlane_f64(a[j >> 2], j);
-            if (!(ajj > 0.0) && lane == 0 && *bad_s == 0) *bad_s = j + 1;
-            // pivot of tf.linalg.cholesky (conditionals_multi_output.py:28,162): sqrt(ajj) and 1/sqrt(ajj) from the
-            // hardware reciprocal square root + two Newton steps + one correction (about 1 ulp), which is far
-            // shorter than the IEEE sqrt and divide expansions that would sit on the 64-pivot critical path
-            double y = __builtin_amdgcn_rsq(ajj);
-            const double hx = 0.5 * ajj;
-            y = y * (1.5 - hx * y * y);
-            y = y * (1.5 - hx * y * y);
-            double piv = ajj * y;
-            piv = piv + 0.5 * y * (ajj - piv * piv);
-            y = y + y * (1.0 - piv * y);
-            const double l = (lane > j) ? a[j >> 2] * y : 0.0;
-            a[j >> 2] = (lane == j) ? piv : ((lane > j) ? l : a[j >> 2]);
-            col[j & 1][lane] = l;                            // pivot column, zero at and above the diagonal
-        }
-        __syncthreads();
-        const double l = col[j & 1][lane];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            const int kcol = 4 * c + w;                      // not a compile-time constant; the guard is cheap
-            if (4 * c + 3 > j) {                             // compile-time prune of finished column groups
-                const double lk = col[j & 1][kcol];
-                a[c] -= (kcol > j) ? l * lk : 0.0;           // only kcol <= lane is meaningful
-            }
-        }
-    }
-    __syncthreads();
-    return *bad_s;
+// sqrt(x) and 1/sqrt(x) of tf.linalg.cholesky's pivot (conditionals_multi_output.py:28,162) from the hardware
+// reciprocal square root + two Newton steps + one correction each (about 1 ulp): far shorter than the IEEE sqrt
+// and divide expansions that would sit on the 64-pivot critical path.
+__device__ __forceinline__ void pivot_sqrt(const double ajj, double &piv, double &y) {
+    y = __builtin_amdgcn_rsq(ajj);
+    const double hx = 0.5 * ajj;
+    y = y * (1.5 - hx * y * y);
+    y = y * (1.5 - hx * y * y);
+    piv = ajj * y;
+    piv = piv + 0.5 * y * (ajj - piv * piv);
+    y = y + y * (1.0 - piv * y);
 }
 
-// Factorise the diagonal block held in LDS tile `Ts` (row-major, stride NB+1) with all 256 threads of the
-// workgroup and publish L in place (lower triangle of the global block).
-__device__ __forceinline__ void diag_block_finish(double (*Ts)[NB + 1], double (*col)[NB], int *bad_s, double *S, int n,
-                                                   int k0, int32_t *info_b) {
+// 64x64 Cholesky by ONE wavefront with no barriers and no LDS traffic: lane = row, the whole row in registers
+// (a[c] = A[lane][c]), left-looking: column j <- a[j] - sum_{i<j} L[:,i] L[j][i], where row j of L is lane j's own
+// registers, handed to every lane as scalars by v_readlane.  The sums for column j+1 do not depend on pivot j except
+// for their last term, so the sqrt chain of one pivot overlaps with the products of the next column.
+// Entries above the diagonal carry don't-care values.
+// Out: a[c] = L[lane][c] for c <= lane; invd[j] = 1 / L[j][j] (LDS).  Returns 0 or 1 + first bad pivot.
+__device__ __forceinline__ int chol64_1w(double (&a)[NB], double *invd, const int lane) {
+    int bad = 0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        double s0 = a[j], s1 = 0.0;
+#pragma unroll
+        for (int i = 0; i + 1 < j; i += 2) {
+            s0 -= a[i] * readlane_f64(a[i], j);
+            s1 -= a[i + 1] * readlane_f64(a[i + 1], j);
+        }
+        if (j & 1) s0 -= a[j - 1] * readlane_f64(a[j - 1], j);
+        const double v = s0 + s1;
+        const double ajj = readlane_f64(v, j);
+        if (!(ajj > 0.0) && bad == 0) bad = j + 1;
+        double piv, y;
+        pivot_sqrt(ajj, piv, y);
+        a[j] = v * y;                                    // lane j: ajj * y = sqrt(ajj) to an ulp
+        if (lane == 0) invd[j] = y;
+    }
+    return bad;
+}
+
+// Factorise the diagonal block held in LDS tile `Ts` (row-major, stride NB+1): wavefront 0 runs chol64_1w, then
+// all 256 threads publish L in place (lower triangle of the global block) and the four wavefronts invert the four
+// 16x16 diagonal sub-blocks of L (lane = column, 16-step forward substitution) into dinv_b[4][16][16] -- what the
+// panel kernel's blocked substitution multiplies by.
+__device__ __forceinline__ void diag_block_finish(double (*Ts)[NB + 1], double (*col)[NB], double *invd, double *S, int n,
+                                                   int k0, int32_t *info_b, double *dinv_b) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    double a[16];
+    if (w == 0) {
+        double a[NB];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) a[c] = Ts[lane][4 * c + w];
-    const int bad = chol64_4w(a, col, bad_s, lane, w);
-    if (bad && tid == 0 && *info_b == 0) *info_b = k0 + bad;
+        for (int c = 0; c < NB; ++c) a[c] = Ts[lane][c];
+        const int bad = chol64_1w(a, invd, lane);
+        if (bad && lane == 0 && *info_b == 0) *info_b = k0 + bad;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) Ts[lane][4 * c + w] = a[c];
+        for (int c = 0; c < NB; ++c) Ts[lane][c] = a[c];
+    }
     __syncthreads();
     for (int r = tid >> 6; r < NB; r += 4)
         if (lane <= r) S[(size_t)(k0 + r) * n + k0 + lane] = Ts[r][lane];         // coalesced rows of L
+    if (lane < 16) {
+        const int o = 16 * w;
+        double x[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            double acc = (lane == r) ? 1.0 : 0.0;
+#pragma unroll
+            for (int i = 0; i < r; ++i) acc -= Ts[o + r][o + i] * x[i];
+            x[r] = acc * invd[o + r];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dinv_b[(w * 16 + r) * 16 + lane] = x[r];
+    }
 }
 
-__global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, int n, int k, size_t slab_stride, int32_t *info) {
+__global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, int n, int k, size_t slab_stride, int32_t *info,
+                                                         double *dinv) {
     __shared__ double Ts[NB][NB + 1];
     __shared__ double col[2][NB];
-    __shared__ int bad_s;
+    __shared__ double invd[NB];
     const int b = blockIdx.x, tid = threadIdx.x;
     double *S = A + (size_t)b * slab_stride;
     const int k0 = k * NB;
     for (int r = tid >> 6; r < NB; r += 4) Ts[r][tid & 63] = S[(size_t)(k0 + r) * n + k0 + (tid & 63)];
     __syncthreads();
-    diag_block_finish(Ts, col, &bad_s, S, n, k0, info + b);
+    diag_block_finish(Ts, col, invd, S, n, k0, info + b, dinv + (size_t)b * DINV_STRIDE);
 }
 
 // tile bookkeeping shared by the panel and trailing kernels
@@ -368,43 +386,70 @@ __device__ __forceinline__ int chunk_row0(int chunk, int k, int nmain, int n, in
     return (chunk < nmain) ? (k + 1 + chunk) * NB : n + extra_block(chunk - nmain, nlive, nid) * NB;
 }
 
-// R <- R * L_kk^{-T} for one 64-row chunk: per row, y_c = (R_c - sum_{j<c} y_j L[c][j]) / L[c][c]
-__global__ __launch_bounds__(64) void potrf_panel_kernel(double *A, int n, int k, int nmain, size_t slab_stride,
-                                                         int nlive, int nid) {
-    __shared__ double Ls[NB][NB];          // read with wave-uniform addresses only (broadcast)
-    __shared__ double Rs[NB][NB + 1];
-    __shared__ double invd[NB];
-    const int b = blockIdx.y, lane = threadIdx.x;
+constexpr int TR_LD = NB + 2;      // LDS row stride of the staged panel blocks (doubles)
+
+// R <- R * L_kk^{-T} for one 64-row chunk, as a blocked substitution on the matrix cores.  With L_kk cut into 16x16
+// blocks and X = R L_kk^{-T}:   X_s^T = L_ss^{-1} (R_s^T - sum_{m<s} L_sm X_m^T).
+// Wavefront w owns rows 16w..16w+15 of the chunk and keeps the four TRANSPOSED 16x16 blocks R_s^T in the MFMA
+// accumulator layout, which is exactly the B-operand layout of the next product, so the whole chain
+// (4 multiplications by the inverted diagonal blocks from diag_block_finish + 6 block updates) runs register to
+// register with the A operands (-L_ts, L_ss^{-1}) read from LDS: 40 MFMAs per wavefront instead of a 64-step scalar
+// forward substitution.
+constexpr int DV_LD = 17;
+__global__ __launch_bounds__(256) void potrf_panel_kernel(double *A, int n, int k, int nmain, size_t slab_stride,
+                                                          int nlive, int nid, const double *dinv) {
+    __shared__ double Ls[NB][TR_LD];       // -L_kk (only blocks below the block diagonal are read)
+    __shared__ double Dv[4][16][DV_LD];    // inverses of the four 16x16 diagonal blocks of L_kk
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     double *S = A + (size_t)b * slab_stride;
     const int k0 = k * NB;
     const int row0 = chunk_row0(blockIdx.x, k, nmain, n, nlive, nid);
-    double *R = S + (size_t)row0 * n + k0;
-    for (int r = 0; r < NB; ++r) {
-        Ls[r][lane] = S[(size_t)(k0 + r) * n + k0 + lane];
-        Rs[r][lane] = R[(size_t)r * n + lane];
+    // this lane's 16 entries: R[row0 + 16w + lr][k0 + 16s + 4r + lk]  (32-byte runs per row)
+    double *Rl = S + (size_t)(row0 + 16 * w + lr) * n + k0 + lk;
+    d4 Rt[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Rt[s4][r] = Rl[16 * s4 + 4 * r];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = (tid >> 5) + 8 * i, c2 = 2 * (tid & 31);
+        const double2 v = *reinterpret_cast<const double2 *>(S + (size_t)(k0 + r) * n + k0 + c2);
+        Ls[r][c2] = (c2 <= r) ? -v.x : 0.0;              // the block's upper triangle holds don't-care values
+        Ls[r][c2 + 1] = (c2 + 1 <= r) ? -v.y : 0.0;
     }
-    wave_lds_sync();
-    invd[lane] = 1.0 / Ls[lane][lane];
-    double y[NB];
+    {
+        const double *dv = dinv + (size_t)b * DINV_STRIDE;
 #pragma unroll
-    for (int c = 0; c < NB; ++c) y[c] = Rs[lane][c];
-    wave_lds_sync();
-#pragma unroll
-    for (int c = 0; c < NB; ++c) {
-        double s0 = y[c], s1 = 0.0;
-#pragma unroll
-        for (int j = 0; j + 1 < c; j += 2) {
-            s0 -= y[j] * Ls[c][j];
-            s1 -= y[j + 1] * Ls[c][j + 1];
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i;
+            Dv[e >> 8][(e >> 4) & 15][e & 15] = dv[e];
         }
-        if (c & 1) s0 -= y[c - 1] * Ls[c][c - 1];
-        y[c] = (s0 + s1) * invd[c];
     }
-    wave_lds_sync();
+    __syncthreads();
 #pragma unroll
-    for (int c = 0; c < NB; ++c) Rs[lane][c] = y[c];
-    wave_lds_sync();
-    for (int r = 0; r < NB; ++r) R[(size_t)r * n + lane] = Rs[r][lane];
+    for (int s4 = 0; s4 < 4; ++s4) {
+        d4 x = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) x = mfma_f64(Dv[s4][lr][4 * ks + lk], Rt[s4][ks], x);
+        // one step of iterative refinement: multiplying by an explicit inverse is not backward stable, a
+        // substitution is; the residual B - L_ss X brings the product back to substitution accuracy
+        d4 res = Rt[s4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) res = mfma_f64(Ls[16 * s4 + lr][16 * s4 + 4 * ks + lk], x[ks], res);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) x = mfma_f64(Dv[s4][lr][4 * ks + lk], res[ks], x);
+        Rt[s4] = x;
+#pragma unroll
+        for (int t = s4 + 1; t < 4; ++t)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) Rt[t] = mfma_f64(Ls[16 * t + lr][16 * s4 + 4 * ks + lk], x[ks], Rt[t]);
+    }
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Rl[16 * s4 + 4 * r] = Rt[s4][r];
 }
 
 // Trailing update of step k: one workgroup (4 wavefronts, a 32x32 quadrant each) per 64x64 tile,
@@ -412,14 +457,13 @@ __global__ __launch_bounds__(64) void potrf_panel_kernel(double *A, int n, int k
 // Tiles: main lower triangle (k < j <= i < nb) then extra-row tiles (e, j) for j in (k, nb).
 // Tile 0 is the next diagonal block (k+1,k+1): wavefront 0 of its workgroup factorises it right away, so the
 // 64-pivot chain of step k+1 overlaps with the rest of step k's trailing update (look-ahead inside one launch).
-constexpr int TR_LD = NB + 2;      // LDS row stride of the staged panel blocks (doubles)
-
 __global__ __launch_bounds__(256) void potrf_trail_kernel(double *A, int n, int k, int nmain_tiles, int n1,
-                                                          size_t slab_stride, int32_t *info, int nlive, int nid) {
+                                                          size_t slab_stride, int32_t *info, int nlive, int nid,
+                                                          double *dinv) {
     __shared__ double Pi_s[NB][TR_LD];
     __shared__ double Pj_s[NB][TR_LD];
     __shared__ double col[2][NB];
-    __shared__ int bad_s;
+    __shared__ double invd[NB];
     const int b = blockIdx.y;
     const int tile = blockIdx.x;
     double *S = A + (size_t)b * slab_stride;
@@ -500,28 +544,28 @@ __global__ __launch_bounds__(256) void potrf_trail_kernel(double *A, int n, int 
                 Ts[r][cc] = Ct[(size_t)r * n + cc] - acc[x][y][q];
             }
     __syncthreads();
-    diag_block_finish(Ts, col, &bad_s, S, n, k0 + NB, info + b);
+    diag_block_finish(Ts, col, invd, S, n, k0 + NB, info + b, dinv + (size_t)b * DINV_STRIDE);
 }
 
 void launch_potrf_ext(hipStream_t stream, double *A, int n, int extra_rows, int identity_rows, int batch,
-                      size_t slab_stride, int32_t *info) {
+                      size_t slab_stride, int32_t *info, double *dinv) {
     const int nb = n / NB;
     const int nid = identity_rows / NB, ntail = extra_rows / NB - nid;
-    hipLaunchKernelGGL(potrf_diag_kernel, dim3(batch), dim3(256), 0, stream, A, n, 0, slab_stride, info);
+    hipLaunchKernelGGL(potrf_diag_kernel, dim3(batch), dim3(256), 0, stream, A, n, 0, slab_stride, info, dinv);
     for (int k = 0; k < nb; ++k) {
         const int nmain = nb - k - 1;
         const int nlive = (k + 1 < nid) ? k + 1 : nid;
         const int nextra = nlive + ntail;
         const int nchunks = nmain + nextra;
         if (nchunks > 0)
-            hipLaunchKernelGGL(potrf_panel_kernel, dim3(nchunks, batch), dim3(64), 0, stream, A, n, k, nmain,
-                               slab_stride, nlive, nid);
+            hipLaunchKernelGGL(potrf_panel_kernel, dim3(nchunks, batch), dim3(256), 0, stream, A, n, k, nmain,
+                               slab_stride, nlive, nid, dinv);
         const int n1 = nmain;
         if (n1 > 0) {
             const int nmain_tiles = n1 * (n1 + 1) / 2;
             const int ntiles = nmain_tiles + nextra * n1;
             hipLaunchKernelGGL(potrf_trail_kernel, dim3(ntiles, batch), dim3(256), 0, stream, A, n, k, nmain_tiles, n1,
-                               slab_stride, info, nlive, nid);
+                               slab_stride, info, nlive, nid, dinv);
         }
     }
 }

@@ -135,9 +135,10 @@ def test_gradient_matches_autograd(name):
     for k in GRAD_KEYS:
         scale = np.max(np.abs(ref[k])) + 1e-300
         err = np.max(np.abs(g[k] - ref[k])) / scale
-        # Z and the lengthscales go through K_uu^-1 differences: both autograd and the closed form carry
-        # eps * cond(K_uu) there (1e-7 between the two CPU implementations), everything else is at 1e-9
-        tol = 2e-6 if k in ("Z", "loglengthscales", "logvariance") else 1e-7
+        # Z and the lengthscales go through K_uu^-1 - A^-1 differences: autograd, the closed form and the GPU all
+        # carry eps * cond(K_uu) there (the two CPU implementations differ by 1e-7..1e-6 on these shapes, and any
+        # change of summation order moves the GPU value by as much); everything else is at 1e-9
+        tol = 1e-5 if k in ("Z", "loglengthscales", "logvariance") else 1e-7
         assert err < tol, (k, err)
 
 

@@ -4,7 +4,8 @@ from ffvd_amd import synthetic
 from ffvd_amd.engine import ElboEngine
 kw = dict(a.split("=") for a in sys.argv[1:] if "=" in a)
 route = kw.get("route", "reference")
-params, Y, c, meta = synthetic.make_named(kw.get("workload", "c2"))
+ov = {"S": int(kw["S"])} if "S" in kw else {}
+params, Y, c, meta = synthetic.make_named(kw.get("workload", "c2"), **ov)
 e = ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], meta["S"], route=route,
                chains_per_pass=int(kw.get("cpp", 0)))
 e.set_data(Y, c); e.set_params(params)
