@@ -66,9 +66,21 @@ _SIGNATURES = {
     "ffvd_op_predict_mean": (C.c_int, [_dp, C.c_int, C.c_int, _dp, _dp, C.c_int, _dp]),
     "ffvd_op_logdensity_norm_diag": (C.c_int, [C.c_int, _dp, _dp, _dp, C.c_int, C.c_int, _dp]),
     "ffvd_op_get_rand": (C.c_int, [_dp, _dp, _dp, C.c_int64, _dp]),
+    "ffvd_adam_step": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_uint32, _dp,
+                                 C.POINTER(C.c_double)]),
+    "ffvd_optimizer_reset": (C.c_int, [C.c_void_p]),
+    "ffvd_get_params": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ffvd_op_adam_step": (C.c_int, [_dp, _dp, _dp, _dp, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double,
+                                    C.c_int64]),
+    "ffvd_op_sghmc_step": (C.c_int, [_dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_int64, C.c_double, C.c_double, C.c_double,
+                                     C.c_int]),
     "ffvd_op_conditional": (C.c_int, [C.c_int, _dp, C.c_int, _dp, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp,
                                       C.c_double, _dp, _dp]),
 }
+
+TRAIN_BITS = {"X": 1, "Z": 2, "logvariance": 4, "loglengthscales": 8, "log_Q": 16, "CC": 32, "DD": 64,
+              "log_Rchols": 128}
+TRAIN_ALL = 255
 
 _lib = None
 

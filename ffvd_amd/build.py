@@ -9,8 +9,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libffvd_hip.so")
-SOURCES = ["kernels.hip", "grad.hip", "abi.hip"]
-DEPS = SOURCES + ["kernels.h", "grad.h", os.path.join("..", "..", "include", "ffvd_abi.h")]
+SOURCES = ["kernels.hip", "grad.hip", "optim.hip", "abi.hip"]
+DEPS = SOURCES + ["kernels.h", "grad.h", "optim.h", os.path.join("..", "..", "include", "ffvd_abi.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value"]
 
 

@@ -3,6 +3,7 @@
 #include "../../include/ffvd_abi.h"
 #include "kernels.h"
 #include "grad.h"
+#include "optim.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -59,6 +60,10 @@ struct ffvd_handle {
     } gw;
     double *hterms = nullptr, *chain_terms = nullptr, *chain_nll = nullptr, *out_terms = nullptr;
     int32_t *info = nullptr;
+    // Adam state for ffvd_adam_step: first/second moments per parameter array (order of FFVD_TRAIN_* bits), step count
+    double *adam_m[8] = {nullptr}, *adam_v[8] = {nullptr};
+    int64_t adam_t = 0;
+    bool adam_ready = false;
     // pinned host staging
     double *h_out = nullptr, *h_chain = nullptr;
     int32_t *h_info = nullptr;
@@ -712,6 +717,94 @@ extern "C" int ffvd_elbo_grad(ffvd_handle *h, const ffvd_params *p, uint32_t fla
     return FFVD_OK;
 }
 
+// ---- optimiser steps on the resident parameters --------------------------------------
+static void param_table(ffvd_handle *h, double *theta[8], const double *grad[8], size_t n[8]) {
+    const ffvd_config &c = h->cfg;
+    const size_t P = h->P, J = c.Ydim;
+    const ffvd_handle::GradWs &g = h->gw;
+    const ffvd_params &p = h->cur;
+    double *th[8] = {const_cast<double *>(p.X), const_cast<double *>(p.Z), const_cast<double *>(p.logvariance),
+                     const_cast<double *>(p.loglengthscales), const_cast<double *>(p.log_Q), const_cast<double *>(p.CC),
+                     const_cast<double *>(p.DD), const_cast<double *>(p.log_Rchols)};
+    const double *gr[8] = {g.dX, g.dZ, g.dlogvar, g.dloglen, g.dlogQ, g.dCC, g.dDD, g.dlogR};
+    const size_t nn[8] = {(size_t)c.S_local * (c.T + 1) * c.D, (size_t)c.M * P, (size_t)c.D, (size_t)c.D * P, (size_t)c.D,
+                          (size_t)c.D * J, J, J * J};
+    for (int i = 0; i < 8; ++i) { theta[i] = th[i]; grad[i] = gr[i]; n[i] = nn[i]; }
+}
+
+extern "C" int ffvd_optimizer_reset(ffvd_handle *h) {
+    if (!h) return set_error(nullptr, FFVD_EINVAL, "ffvd_optimizer_reset: null handle");
+    if (!h->cfg.grad) return set_error(h, FFVD_EINVAL, "ffvd_optimizer_reset: the handle was created without grad = 1");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    double *theta[8]; const double *grad[8]; size_t n[8];
+    param_table(h, theta, grad, n);
+    for (int i = 0; i < 8; ++i) {
+        if (!h->adam_m[i]) { HIP_TRY(dev_alloc(h, &h->adam_m[i], n[i])); HIP_TRY(dev_alloc(h, &h->adam_v[i], n[i])); }
+        HIP_TRY(hipMemsetAsync(h->adam_m[i], 0, n[i] * sizeof(double), h->stream));
+        HIP_TRY(hipMemsetAsync(h->adam_v[i], 0, n[i] * sizeof(double), h->stream));
+    }
+    h->adam_t = 0;
+    h->adam_ready = true;
+    return FFVD_OK;
+}
+
+extern "C" int ffvd_adam_step(ffvd_handle *h, double lr, double beta1, double beta2, double eps, uint32_t train_mask,
+                              double out_terms[8], double *out_nll) {
+    if (!h) return set_error(nullptr, FFVD_EINVAL, "ffvd_adam_step: null handle");
+    if (!h->cfg.grad) return set_error(h, FFVD_EINVAL, "ffvd_adam_step: the handle was created without grad = 1");
+    if (h->Dl != h->cfg.D)
+        return set_error(h, FFVD_EINVAL, "ffvd_adam_step: a latent-dim shard holds partial gradients; all-reduce them and use ffvd_op_adam_step");
+    if (!(lr > 0.0) || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0) || !(eps >= 0.0))
+        return set_error(h, FFVD_EINVAL, "ffvd_adam_step: bad hyper-parameter");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    int rc;
+    if ((rc = ready(h, "ffvd_adam_step"))) return rc;
+    if (!h->adam_ready && (rc = ffvd_optimizer_reset(h))) return rc;
+    if ((rc = enqueue_elbo(h, nullptr, nullptr))) return rc;
+    if ((rc = enqueue_grad(h, h->cfg.S_local))) return rc;
+    hipStream_t s = h->stream;
+    HIP_TRY(hipMemcpyAsync(h->h_out, h->out_terms, 8 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(h->h_chain, h->chain_nll, (size_t)h->cfg.S_local * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(h->h_info, h->info, (size_t)(h->Dl + h->nbatch) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if ((rc = check_info(h))) return rc;           // a failed factorisation leaves the parameters untouched
+    double *theta[8]; const double *grad[8]; size_t n[8];
+    param_table(h, theta, grad, n);
+    OptTable tab{};
+    for (int i = 0; i < 8; ++i) {
+        if (!(train_mask & (1u << i)) || n[i] == 0) continue;
+        OptTensor &t = tab.t[tab.count++];
+        t.theta = theta[i]; t.grad = grad[i]; t.s0 = h->adam_m[i]; t.s1 = h->adam_v[i]; t.n = (int64_t)n[i];
+    }
+    h->adam_t += 1;
+    const double lr_t = lr * sqrt(1.0 - pow(beta2, (double)h->adam_t)) / (1.0 - pow(beta1, (double)h->adam_t));
+    launch_adam(s, tab, lr_t, beta1, beta2, eps);
+    HIP_TRY(hipGetLastError());
+    if (out_terms) memcpy(out_terms, h->h_out, 8 * sizeof(double));
+    if (out_nll) *out_nll = h->h_out[FFVD_TERM_NLL] / (double)h->cfg.S_local;
+    return FFVD_OK;
+}
+
+extern "C" int ffvd_get_params(ffvd_handle *h, const ffvd_params *out) {
+    if (!h || !out) return set_error(h, FFVD_EINVAL, "ffvd_get_params: null argument");
+    if (!h->have_params) return set_error(h, FFVD_EINVAL, "ffvd_get_params: no parameters bound");
+    const ffvd_config &c = h->cfg;
+    const size_t P = h->P, J = c.Ydim;
+    HIP_TRY(hipSetDevice(c.device_id));
+    hipStream_t s = h->stream;
+    const ffvd_params &p = h->cur;
+    const void *src[9] = {p.X, p.Z, p.U, p.logvariance, p.loglengthscales, p.log_Q, p.CC, p.DD, p.log_Rchols};
+    const void *dst[9] = {out->X, out->Z, out->U, out->logvariance, out->loglengthscales, out->log_Q, out->CC, out->DD,
+                          out->log_Rchols};
+    const size_t n[9] = {(size_t)c.S_local * (c.T + 1) * c.D, (size_t)c.M * P, (size_t)c.M * c.D, (size_t)c.D, (size_t)c.D * P,
+                         (size_t)c.D, (size_t)c.D * J, J, J * J};
+    for (int i = 0; i < 9; ++i)
+        if (dst[i] && src[i] && n[i])
+            HIP_TRY(hipMemcpyAsync(const_cast<void *>(dst[i]), src[i], n[i] * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return FFVD_OK;
+}
+
 // ---- operator-level entry points (temporaries allocated per call; not the hot path) --------------
 namespace {
 struct Scratch {
@@ -1172,6 +1265,54 @@ extern "C" int ffvd_op_conditional_precalc(int kind, const double *Lm_inverse_se
     launch_conditional_finish(sc.stream, kind, dX, N, P, variance, rowsq, fmean, ng, Tp, D, dmean, dvar, extra);
     HIP_TRY(hipMemcpyAsync(mean, dmean, (size_t)N * D * sizeof(double), hipMemcpyDeviceToHost, sc.stream));
     HIP_TRY(hipMemcpyAsync(var, dvar, (size_t)N * D * sizeof(double), hipMemcpyDeviceToHost, sc.stream));
+    HIP_TRY(hipStreamSynchronize(sc.stream));
+    return FFVD_OK;
+}
+
+extern "C" int ffvd_op_adam_step(double *theta, const double *grad, double *m, double *v, int64_t n, double lr,
+                                 double beta1, double beta2, double eps, int64_t t) {
+    if (!theta || !grad || !m || !v || n < 0 || t < 1 || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0))
+        return set_error(nullptr, FFVD_EINVAL, "ffvd_op_adam_step: bad argument");
+    OP_BEGIN("ffvd_op_adam_step");
+    if (n == 0) return FFVD_OK;
+    double *dth = sc.upload(theta, n), *dm = sc.upload(m, n), *dv = sc.upload(v, n);
+    const double *dg = sc.upload(grad, n);
+    if (!dth || !dm || !dv || !dg) return set_error(nullptr, FFVD_ENOMEM, "ffvd_op_adam_step: device allocation or upload failed");
+    OptTable tab{};
+    tab.count = 1;
+    tab.t[0].theta = dth; tab.t[0].grad = dg; tab.t[0].s0 = dm; tab.t[0].s1 = dv; tab.t[0].n = n;
+    const double lr_t = lr * sqrt(1.0 - pow(beta2, (double)t)) / (1.0 - pow(beta1, (double)t));
+    launch_adam(sc.stream, tab, lr_t, beta1, beta2, eps);
+    HIP_TRY(hipMemcpyAsync(theta, dth, n * sizeof(double), hipMemcpyDeviceToHost, sc.stream));
+    HIP_TRY(hipMemcpyAsync(m, dm, n * sizeof(double), hipMemcpyDeviceToHost, sc.stream));
+    HIP_TRY(hipMemcpyAsync(v, dv, n * sizeof(double), hipMemcpyDeviceToHost, sc.stream));
+    HIP_TRY(hipStreamSynchronize(sc.stream));
+    return FFVD_OK;
+}
+
+extern "C" int ffvd_op_sghmc_step(double *theta, const double *grad, double *xi, double *g, double *g2, double *p,
+                                  const double *noise, int64_t n, double epsilon, double mdecay, double X_N, int burn_in) {
+    if (!theta || !grad || !xi || !g || !g2 || !p || !noise || n < 0 || !(X_N > 0.0))
+        return set_error(nullptr, FFVD_EINVAL, "ffvd_op_sghmc_step: bad argument");
+    OP_BEGIN("ffvd_op_sghmc_step");
+    if (n == 0) return FFVD_OK;
+    double *dth = sc.upload(theta, n), *dxi = sc.upload(xi, n), *dg_ = sc.upload(g, n), *dg2 = sc.upload(g2, n);
+    double *dp = sc.upload(p, n);
+    const double *dgrad = sc.upload(grad, n), *dnoise = sc.upload(noise, n);
+    if (!dth || !dxi || !dg_ || !dg2 || !dp || !dgrad || !dnoise)
+        return set_error(nullptr, FFVD_ENOMEM, "ffvd_op_sghmc_step: device allocation or upload failed");
+    OptTable tab{};
+    tab.count = 1;
+    OptTensor &t = tab.t[0];
+    t.theta = dth; t.grad = dgrad; t.s0 = dxi; t.s1 = dg_; t.s2 = dg2; t.s3 = dp; t.noise = dnoise; t.n = n;
+    launch_sghmc(sc.stream, tab, epsilon, mdecay, X_N, burn_in);
+    HIP_TRY(hipMemcpyAsync(theta, dth, n * sizeof(double), hipMemcpyDeviceToHost, sc.stream));
+    HIP_TRY(hipMemcpyAsync(p, dp, n * sizeof(double), hipMemcpyDeviceToHost, sc.stream));
+    if (burn_in) {
+        HIP_TRY(hipMemcpyAsync(xi, dxi, n * sizeof(double), hipMemcpyDeviceToHost, sc.stream));
+        HIP_TRY(hipMemcpyAsync(g, dg_, n * sizeof(double), hipMemcpyDeviceToHost, sc.stream));
+        HIP_TRY(hipMemcpyAsync(g2, dg2, n * sizeof(double), hipMemcpyDeviceToHost, sc.stream));
+    }
     HIP_TRY(hipStreamSynchronize(sc.stream));
     return FFVD_OK;
 }

@@ -74,6 +74,13 @@ class DGPSSM:
                                  U_collapse=self.U_collapse, prior_type=prior_type, device=device, **engine_kw)
         self.engine.set_data(Y, self.control_inputs)
         self._last = None
+        self.epsilon, self.mdecay = epsilon, mdecay
+        # which variables SG-HMC samples and which Adam trains (dgp_model.py:213-244):
+        # case 4 (collapsed U, the default) trains everything with Adam and leaves `vars` empty
+        self.vars = []
+        self.window = []
+        self._resident = False      # device copy of the parameters is current (set by train_hypers)
+        self._host_stale = False    # ... and newer than the NumPy attributes
 
     @property
     def Q(self):
@@ -81,6 +88,9 @@ class DGPSSM:
 
     def set_X(self, X_chains):
         """Latent trajectories to evaluate: (S, T+1, D) (or (T+1, D) for one chain)."""
+        if self._host_stale:
+            self.pull_parameters()
+        self._resident = False
         X = np.asarray(X_chains, dtype=np.float64)
         if X.ndim == 2:
             X = X[None]
@@ -99,7 +109,7 @@ class DGPSSM:
 
     def nll_terms(self):
         """nll and the named component tensors of dgp_model.py:264-297 (mean over chains)."""
-        self._last = self.engine.nll_terms(self.parameters())
+        self._last = self.engine.nll_terms(None if self._resident else self.parameters())
         return self._last
 
     def nll(self):
@@ -112,3 +122,49 @@ class DGPSSM:
             if k != "nll_per_chain":
                 print(f"{k}: {v}")
         return t
+
+    # ---- training loop pieces (models.py:142-182 drives these) -----------------------------------------
+    def get_minibatch(self, global_step=1):
+        """BaseModel.get_minibatch (base_model.py:188-194): full batch, lr = 0.003 * 0.95^(global_step/1000)."""
+        return [0, self.X_N], 0.003 * (0.95 ** (global_step / 1000))
+
+    def nll_and_grad(self):
+        """nll terms + d nll / d variables (what tf.gradients(nll, vars), base_model.py:148, hands the optimisers)."""
+        return self.engine.nll_and_grad(None if self._resident else self.parameters())
+
+    def sghmc_step(self):
+        """BaseModel.sghmc_step (base_model.py:915-933): 1 + 10 x (burn_in_op, sample_op) on `self.vars`, then the
+        current values join the window.  With U collapsed (case 4) `vars` is empty and the ops are no-ops."""
+        if self.vars:
+            raise NotImplementedError("SG-HMC variables (cases 2, 3, 5) are not wired to the engine yet; "
+                                      "ffvd_amd.optim.sghmc_step is the update operator")
+        self.window.append({})
+        if len(self.window) > self.window_size:
+            self.window = self.window[-self.window_size:]
+
+    def train_hypers(self):
+        """BaseModel.train_hypers (base_model.py:944-950): one Adam step on nll w.r.t. every trainable variable
+        (X, Z, kernel hypers, log_Q, C, d, log_Rchols in case 4), forward + backward + update on the device.
+        Returns the nll terms before the update."""
+        if not self._resident:
+            self.engine.set_params(self.parameters())
+            self._resident = True
+        _, lr = self.get_minibatch()
+        t = self.engine.adam_step(lr)
+        self._host_stale = True
+        return t
+
+    def pull_parameters(self):
+        """Copy the trained parameters from the device back into the reference-named attributes."""
+        g = self.engine.get_params()
+        lay = self.layers[-1]
+        self._X_chains = g["X"]
+        lay.X, lay.Z = g["X"][0], g["Z"]
+        for d, k in enumerate(lay.kernel):
+            k.logvariance = np.float64(g["logvariance"][d])
+            if hasattr(k, "loglengthscales"):
+                k.loglengthscales = g["loglengthscales"][d].copy()
+        self.log_Q = g["log_Q"]
+        self.likelihood.CC, self.likelihood.DD, self.likelihood.log_Rchols = g["CC"], g["DD"], g["log_Rchols"]
+        self._host_stale = False
+        return g

@@ -177,6 +177,35 @@ class ElboEngine:
         terms["sums8"] = out          # raw partial sums + chain count, for the all-reduce of a sharded job
         return terms, g
 
+    def adam_step(self, lr, beta1=0.9, beta2=0.999, eps=1e-8, train=None):
+        """One `train_hypers` iteration (base_model.py:944-950) on the device: forward + backward on the resident
+        parameters, then the Adam update (TF defaults) of the arrays named in `train` (default: all).  Returns the
+        nll terms of the parameters BEFORE the update.  Needs grad=True and set_params() first."""
+        if not self.grad:
+            raise ValueError("engine was created without grad=True")
+        mask = _lib.TRAIN_ALL if train is None else sum(_lib.TRAIN_BITS[k] for k in train)
+        out = np.zeros(8)
+        nll = ct.c_double()
+        _lib.check(self.lib.ffvd_adam_step(self._h, float(lr), float(beta1), float(beta2), float(eps), int(mask),
+                                           _lib.dptr(out), ct.byref(nll)), self._h, "ffvd_adam_step")
+        idx = {n: i for i, n in enumerate(_lib.TERM_NAMES)}
+        return {n: float(out[idx[n]] / self.S) for n in _lib.TERM_NAMES}
+
+    def reset_optimizer(self):
+        _lib.check(self.lib.ffvd_optimizer_reset(self._h), self._h, "ffvd_optimizer_reset")
+
+    def get_params(self):
+        """Host copies of the resident parameters (after optimiser steps)."""
+        g = {
+            "X": np.zeros((self.S, self.T + 1, self.D)), "Z": np.zeros((self.M, self.P)), "U": np.zeros((self.M, self.D)),
+            "logvariance": np.zeros(self.D), "loglengthscales": np.zeros((self.D, self.P)),
+            "log_Q": np.zeros(self.D), "CC": np.zeros((self.D, self.Ydim)), "DD": np.zeros(self.Ydim),
+            "log_Rchols": np.zeros((self.Ydim, self.Ydim)),
+        }
+        ps = _lib.FfvdParams(**{k: v.ctypes.data for k, v in g.items()})
+        _lib.check(self.lib.ffvd_get_params(self._h, ct.byref(ps)), self._h, "ffvd_get_params")
+        return g
+
     def elbo_async(self, out_dev_ptr=None):
         """Enqueue one iteration; the 8 partial sums land in device memory `out_dev_ptr` (int address)."""
         _lib.check(self.lib.ffvd_elbo_async(self._h, out_dev_ptr), self._h, "ffvd_elbo_async")

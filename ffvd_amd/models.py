@@ -2,9 +2,10 @@
 
 `RegressionModel(prior_type)` exposes the class-attribute bag `ARGS` that FFVD_Main.py:236-340 fills and a
 `fit(Y_train, ...)` that builds the kernels (models.py:57-62), the Gaussian likelihood (models.py:320) and the
-DGPSSM (models.py:66-74).  The optimiser / sampler loop of models.py:142-182 is the next scope row
-(SURVEY 8f-1/2); `fit` therefore constructs the model and records the initial nll, which is what every
-iteration of that loop evaluates.
+DGPSSM (models.py:66-74), then runs the loop of models.py:142-182: `sghmc_step` (a no-op on the empty SG-HMC
+variable list of the default collapsed case 4) and `train_hypers` (one Adam step on nll, forward + backward +
+update on the device), `ARGS.iterations` x 2 times as the reference does.  `fit(..., iterations=0)` only builds
+the model and records the initial nll.
 """
 from __future__ import annotations
 
@@ -34,7 +35,7 @@ class Model:
         if prior_type not in ("determinantal", "normal", "strauss", "uniform"):
             raise Exception("Invalid prior type")    # models.py:35-41
 
-    def _fit(self, Y_train, lik, kernel_type, kernel_train_flag, **kwargs):
+    def _fit(self, Y_train, lik, kernel_type, kernel_train_flag, iterations=0, **kwargs):
         Y_train = np.asarray(Y_train, dtype=np.float64)
         if Y_train.ndim == 1:
             Y_train = Y_train[:, None]
@@ -62,6 +63,15 @@ class Model:
                                 U_collapse=A.U_collapse, case_val=getattr(A, "case_val", 4), **kwargs)
         self.nll_seq, self.rmse_seq, self.ll_seq, self.running_time_seq = [], [], [], []   # models.py:89-92
         self.nll_seq.append(self.model.nll())
+        self.global_step = 0
+        n_iter = 2 * A.iterations if iterations is None else int(iterations)     # models.py:142 `2*self.ARGS.iterations`
+        for it in range(n_iter):
+            self.global_step += 1
+            self.model.sghmc_step()                                              # models.py:150
+            t = self.model.train_hypers()                                        # models.py:168
+            self.nll_seq.append(t["nll"])
+        if n_iter:
+            self.model.pull_parameters()
         return self
 
 
@@ -71,7 +81,10 @@ class RegressionModel(Model):
 
     def fit(self, Y_train, Y_test=None, tensorboard_savepath="", dataname="", fileid="",
             kernel_type="SquaredExponential", kernel_train_flag=True, likelihood_traning=True, X_train=None,
-            X_test=None, Ystd=None, data_uu=None, epsilon=0.01, **kwargs):
+            X_test=None, Ystd=None, data_uu=None, epsilon=0.01, iterations=0, **kwargs):
+        """`iterations`: number of (sghmc_step, train_hypers) rounds; None = 2 * ARGS.iterations as models.py:142;
+        the default 0 builds the model and evaluates the initial nll only.  Training needs the collapsed branch with
+        SE kernels (the reference's default case 4) and engine keywords route="gram", grad=True."""
         Y_train = np.asarray(Y_train, dtype=np.float64)
         if Y_train.ndim == 1:
             Y_train = Y_train[:, None]
@@ -79,4 +92,4 @@ class RegressionModel(Model):
         lik = Gaussian(Y_train.shape[1], A.x_dims[-1], CC=A.CC, DD=A.DD, RR_chol=A.RR_chol,
                        hyperparameter_sampling=getattr(A, "hyperparameter_sampling", False),
                        likelihood_traning=likelihood_traning)                     # models.py:320
-        return self._fit(Y_train, lik, kernel_type, kernel_train_flag, **kwargs)
+        return self._fit(Y_train, lik, kernel_type, kernel_train_flag, iterations=iterations, **kwargs)

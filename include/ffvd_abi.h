@@ -149,6 +149,28 @@ typedef struct ffvd_grads {
 } ffvd_grads;
 int  ffvd_elbo_grad(ffvd_handle *h, const ffvd_params *p, uint32_t flags, int S_total, double out_terms[8],
                     double *out_nll, const ffvd_grads *g);
+/* ---- optimiser / sampler steps -------------------------------------------------
+ * ffvd_adam_step: one train_hypers iteration (base_model.py:944-950) entirely on the device: forward + backward on
+ * the resident parameters, then tf.compat.v1.train.AdamOptimizer's update (dgp_model.py:303-305; TensorFlow is not
+ * vendored by the reference -- the published rule is  lr_t = lr sqrt(1-b2^t)/(1-b1^t),  m = b1 m + (1-b1) g,
+ * v = b2 v + (1-b2) g^2,  theta -= lr_t m / (sqrt(v) + eps);  TF defaults b1 = 0.9, b2 = 0.999, eps = 1e-8;
+ * lr = 0.003 * 0.95^(1/1000), base_model.py:190) applied in one fused launch to the arrays selected by train_mask.
+ * out_terms / out_nll describe the parameters BEFORE the update.  Needs grad = 1 and all latent dims on the handle;
+ * a failed factorisation returns FFVD_ENOTPD and leaves the parameters untouched.  The handle keeps m, v and t;
+ * ffvd_optimizer_reset zeroes them.  ffvd_get_params copies the resident parameters to host arrays (NULL = skip). */
+#define FFVD_TRAIN_X 1u
+#define FFVD_TRAIN_Z 2u
+#define FFVD_TRAIN_LOGVARIANCE 4u
+#define FFVD_TRAIN_LOGLENGTHSCALES 8u
+#define FFVD_TRAIN_LOG_Q 16u
+#define FFVD_TRAIN_CC 32u
+#define FFVD_TRAIN_DD 64u
+#define FFVD_TRAIN_LOG_RCHOLS 128u
+#define FFVD_TRAIN_ALL 255u
+int  ffvd_adam_step(ffvd_handle *h, double lr, double beta1, double beta2, double eps, uint32_t train_mask,
+                    double out_terms[8], double *out_nll);
+int  ffvd_optimizer_reset(ffvd_handle *h);
+int  ffvd_get_params(ffvd_handle *h, const ffvd_params *out_host);
 /* after a synchronous ffvd_elbo: per-chain nll values (S_local doubles, host) */
 int  ffvd_chain_nll(ffvd_handle *h, double *out_nll_per_chain);
 /* timing helper for benchmarks: run `iters` back-to-back ffvd_elbo_async on the resident inputs,
@@ -208,6 +230,17 @@ int  ffvd_op_logdensity_norm_diag(int nonvec, const double *y, const double *yme
                                   double *out);
 /* get_rand (utils.py:11, diagonal case) with the standard-normal draw injected: out = mean + eps * sqrt(var). */
 int  ffvd_op_get_rand(const double *mean, const double *var, const double *eps, int64_t n, double *out);
+
+/* One Adam update of a flat host array (in place: theta, m, v), t = 1-based step count; same rule as ffvd_adam_step. */
+int  ffvd_op_adam_step(double *theta, const double *grad, double *m, double *v, int64_t n, double lr, double beta1,
+                       double beta2, double eps, int64_t t);
+/* One SG-HMC update, BaseModel.generate_update_step base_model.py:143-179, of a flat host array (in place):
+ * state xi, g, g2 (initialised to ones by the reference) and momentum p (zeros); noise = the standard-normal draw of
+ * :169 (injected); epsilon, mdecay as DGPSSM(epsilon=0.01, mdecay=0.05) dgp_model.py:161; X_N = number of training
+ * rows (:164).  burn_in != 0 = burn_in_op (xi, g, g2, theta, p move), 0 = sample_op (theta, p only).  Every
+ * right-hand side reads the state from before the call. */
+int  ffvd_op_sghmc_step(double *theta, const double *grad, double *xi, double *g, double *g2, double *p,
+                        const double *noise, int64_t n, double epsilon, double mdecay, double X_N, int burn_in);
 
 #ifdef __cplusplus
 }
