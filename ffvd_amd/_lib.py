@@ -74,6 +74,8 @@ _SIGNATURES = {
                                     C.c_int64]),
     "ffvd_op_sghmc_step": (C.c_int, [_dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_int64, C.c_double, C.c_double, C.c_double,
                                      C.c_int]),
+    "ffvd_op_rollout": (C.c_int, [C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_int, _dp,
+                                  C.c_int, C.c_int, _dp, _dp, _dp, _dp]),
     "ffvd_op_conditional": (C.c_int, [C.c_int, _dp, C.c_int, _dp, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp,
                                       C.c_double, _dp, _dp]),
 }

@@ -1316,3 +1316,60 @@ extern "C" int ffvd_op_sghmc_step(double *theta, const double *grad, double *xi,
     HIP_TRY(hipStreamSynchronize(sc.stream));
     return FFVD_OK;
 }
+
+extern "C" int ffvd_op_rollout(int kind, const double *Lm_inverse_seq, const double *Z, int M, int P, int D,
+                               const double *logvariance, const double *loglengthscales, const double *f,
+                               const double *q_sqrt, const double *x_last, int R, const double *ctrl, int C, int steps,
+                               const double *log_Q, const double *eps, double *predict_x, double *predict_var) {
+    if (!Lm_inverse_seq || !Z || !logvariance || !f || !x_last || !log_Q || !eps || !predict_x || !predict_var || R < 1 ||
+        steps < 0 || M < 1 || M > 2048 || D < 1 || C < 0 || P != D + C || P > MAXP || (C > 0 && !ctrl) ||
+        (kind == FFVD_KERNEL_SE && !loglengthscales))
+        return set_error(nullptr, FFVD_EINVAL, "ffvd_op_rollout: bad argument");
+    OP_BEGIN("ffvd_op_rollout");
+    if (steps == 0) return FFVD_OK;
+    const int Mp = round_up(M, NB), Tp = round_up(R, STRIP), ng = (Mp + 511) / 512;
+    std::vector<double> Wp = pad_stack(Lm_inverse_seq, D, M, Mp);
+    std::vector<double> xc0((size_t)R * P);
+    for (int r = 0; r < R; ++r) {
+        for (int d = 0; d < D; ++d) xc0[(size_t)r * P + d] = x_last[d];              // x_t = X[-1] (:226), every rollout
+        for (int c = 0; c < C; ++c) xc0[(size_t)r * P + D + c] = ctrl[c];            // control row of step 0 (:293)
+    }
+    double *dW = sc.upload(Wp.data(), Wp.size());
+    double *dxc = sc.upload(xc0.data(), xc0.size()), *dZ = sc.upload(Z, (size_t)M * P), *dU = sc.upload(f, (size_t)M * D);
+    double *dlv = sc.upload(logvariance, D), *dll = sc.alloc<double>((size_t)D * P), *dlq = sc.upload(log_Q, D);
+    double *deps = sc.upload(eps, (size_t)steps * R * D);
+    double *dctrl = C ? sc.upload(ctrl, (size_t)steps * C) : nullptr;
+    double *variance = sc.alloc<double>(D), *len = sc.alloc<double>((size_t)D * P);
+    double *Zs = sc.alloc<double>((size_t)D * Mp * P), *zz = sc.alloc<double>((size_t)D * Mp);
+    double *F = q_sqrt ? sc.alloc<double>((size_t)D * Tp * Mp) : nullptr;
+    double *rowsq = sc.alloc<double>((size_t)D * ng * Tp), *fmean = sc.alloc<double>((size_t)D * ng * Tp);
+    double *dmean = sc.alloc<double>((size_t)R * D), *dvar = sc.alloc<double>((size_t)R * D);
+    double *dpx = sc.alloc<double>((size_t)R * steps * D), *dpv = sc.alloc<double>((size_t)R * steps * D);
+    double *dQs = q_sqrt ? sc.upload(q_sqrt, (size_t)M * M) : nullptr;     // slice d = 0 only
+    double *extra = q_sqrt ? sc.alloc<double>((size_t)D * Tp) : nullptr;
+    if (!dW || !dxc || !dZ || !dU || !dlv || !dll || !dlq || !deps || (C && !dctrl) || !variance || !len || !Zs || !zz ||
+        !rowsq || !fmean || !dmean || !dvar || !dpx || !dpv || (q_sqrt && (!dQs || !extra || !F)))
+        return set_error(nullptr, FFVD_ENOMEM, "ffvd_op_rollout: device allocation or upload failed");
+    if (loglengthscales)
+        HIP_TRY(hipMemcpyAsync(dll, loglengthscales, (size_t)D * P * sizeof(double), hipMemcpyHostToDevice, sc.stream));
+    launch_prep_hypers(sc.stream, kind, dZ, M, Mp, P, D, 0, dlv, dll, variance, len, Zs, zz);
+    HyperView hv{variance, len, Zs, zz};
+    ProjectArgs pa{};
+    pa.kind = kind; pa.x = dxc; pa.x_chain_stride = 0; pa.x_ld = P; pa.x_cols = P; pa.ctrl = nullptr;
+    pa.T = R; pa.Tp = Tp; pa.C = 0; pa.P = P; pa.M = M; pa.Mp = Mp; pa.Dl = D; pa.d_begin = 0; pa.hv = hv;
+    pa.W = dW; pa.w_stride = (size_t)Mp * Mp; pa.U = dU; pa.u_ld = D; pa.b0 = 0; pa.nb = D;
+    pa.F = F; pa.rowsq = rowsq; pa.fmean = fmean; pa.ng = ng;
+    // the whole loop is enqueued at once: steps x (projection, [q_sqrt inflation], conditional, update), stream-ordered
+    for (int t = 0; t < steps; ++t) {
+        launch_project(sc.stream, pa);                                       // conditional_after_kernel_precalculation (:300)
+        if (q_sqrt) launch_qsqrt_inflation(sc.stream, F, (size_t)Tp * Mp, Tp, Mp, M, dQs, extra, R, D);
+        launch_conditional_finish(sc.stream, kind, dxc, R, P, variance, rowsq, fmean, ng, Tp, D, dmean, dvar, extra);
+        launch_rollout_update(sc.stream, dmean, dvar, dlq, deps + (size_t)t * R * D,
+                              (C && t + 1 < steps) ? dctrl + (size_t)(t + 1) * C : nullptr, R, D, C, t, steps, dxc, dpx, dpv);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(predict_x, dpx, (size_t)R * steps * D * sizeof(double), hipMemcpyDeviceToHost, sc.stream));
+    HIP_TRY(hipMemcpyAsync(predict_var, dpv, (size_t)R * steps * D * sizeof(double), hipMemcpyDeviceToHost, sc.stream));
+    HIP_TRY(hipStreamSynchronize(sc.stream));
+    return FFVD_OK;
+}

@@ -153,4 +153,10 @@ void launch_get_rand(hipStream_t stream, const double *mean, const double *var, 
 // small utilities
 void launch_fill(hipStream_t stream, double *p, size_t n, double v);
 
+// rollout step: x_next = x + f_mu + eps sqrt(f_var + Q) (base_model.py:304-314); xc: R x (D + C) GP input rows,
+// advanced in place; ctrl_next: the C control inputs of the NEXT step or null.
+void launch_rollout_update(hipStream_t stream, const double *mean, const double *var, const double *log_Q,
+                           const double *eps_t, const double *ctrl_next, int R, int D, int C, int t, int steps, double *xc,
+                           double *predict_x, double *predict_var);
+
 }  // namespace ffvd

@@ -1309,4 +1309,34 @@ void launch_finalize(hipStream_t stream, const FinalizeArgs &a) {
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, stream, a);
 }
 
+// One step of the posterior rollout (collect_samples_formal, base_model.py:304-314) for R rollouts side by side:
+//   x_next = x + f_mu + eps * sqrt(f_var + Q);  predict_x[r][t] = x_next;  predict_var[r][t] = f_var + Q;
+// and the GP input row of the next step, xc[r] = [x_next, control_inputs[t + 1]].
+__global__ void rollout_update_kernel(const double *mean, const double *var, const double *log_Q, const double *eps_t,
+                                      const double *ctrl_next, int R, int D, int C, int t, int steps, double *xc,
+                                      double *predict_x, double *predict_var) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int P = D + C;
+    if (idx >= R * P) return;
+    const int r = idx / P, p = idx % P;
+    if (p < D) {
+        const double v = var[r * D + p] + exp(log_Q[p]);
+        const double xn = (mean[r * D + p] + xc[idx]) + eps_t[r * D + p] * sqrt(v);
+        const size_t o = ((size_t)r * steps + t) * D + p;
+        predict_x[o] = xn;
+        predict_var[o] = v;
+        xc[idx] = xn;
+    } else if (ctrl_next) {
+        xc[idx] = ctrl_next[p - D];
+    }
+}
+void launch_rollout_update(hipStream_t stream, const double *mean, const double *var, const double *log_Q,
+                           const double *eps_t, const double *ctrl_next, int R, int D, int C, int t, int steps, double *xc,
+                           double *predict_x, double *predict_var) {
+    const int n = R * (D + C);
+    if (n == 0) return;
+    hipLaunchKernelGGL(rollout_update_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, mean, var, log_Q, eps_t,
+                       ctrl_next, R, D, C, t, steps, xc, predict_x, predict_var);
+}
+
 }  // namespace ffvd

@@ -168,3 +168,42 @@ class DGPSSM:
         self.likelihood.CC, self.likelihood.DD, self.likelihood.log_Rchols = g["CC"], g["DD"], g["log_Rchols"]
         self._host_stale = False
         return g
+
+    def collect_samples_formal(self, num, spacing, control_inputs, test_len, sghmc_var_len=0, U_collapse=None,
+                               Y_test=None, Y_train_std=1.0, Y_train=None, eps=None, seed=None, **_ignored):
+        """BaseModel.collect_samples_formal (base_model.py:197-350) for the SG-HMC-free cases (sghmc_var_len = 0):
+        K_uu factors, posterior U (collapsed branch), `num` rollouts of `test_len` steps from X[-1], predictive
+        y mean / variance and the RMSE over the first 30 test points.  `eps` (test_len, num, D) injects the
+        standard-normal draws of :306; otherwise they come from numpy's default_rng(seed).  Returns a dict and
+        sets the reference's attributes (fit_x, predict_y, predict_y_var, fit_y, RMSE_val)."""
+        from . import conditionals_multi_output as cmo
+        from .prediction import predict_y_summary, rollout
+        if sghmc_var_len:
+            raise NotImplementedError("rollouts interleaved with SG-HMC sample_op (cases 2, 3, 5)")
+        if self._host_stale:
+            self.pull_parameters()
+        U_collapse = self.U_collapse if U_collapse is None else bool(U_collapse)
+        lay = self.layers[-1]
+        D = self.output_dim
+        ci = self.control_inputs if control_inputs is None else np.asarray(control_inputs, dtype=np.float64)
+        T = self.X_N - 1
+        self.fit_x = lay.X.copy()                                                            # :203
+        Lm_inverse_seq = cmo.kernel_pre_cal(lay.Z, lay.kernel)                                # :207
+        if U_collapse:
+            xc = np.concatenate((lay.X[:T], ci[:T]), axis=1) if ci.shape[1] > 0 else lay.X[:-1]    # :243-246
+            U_val, U_chol = cmo.collapse_u_mean_after_kernel_precalculation(Lm_inverse_seq, xc, lay.X, lay.Z,
+                                                                            lay.kernel, self.Q)     # :251
+        else:
+            U_val, U_chol = lay.U, None                                                       # :255-256
+        if eps is None:
+            eps = np.random.default_rng(seed).standard_normal((test_len, num, D))
+        n_train = self.Y.shape[0] if Y_train is None else np.asarray(Y_train).shape[0]
+        px, pv = rollout(Lm_inverse_seq, lay.Z, lay.kernel, U_val, U_chol, lay.X[-1], ci, n_train, test_len, self.Q, eps)
+        out = predict_y_summary(px, pv, self.likelihood.CC, self.likelihood.DD, self.likelihood.log_Rchols, Y_test,
+                                Y_train_std)
+        self.predict_y, self.predict_y_var = out["predict_y"], out["predict_y_var"]
+        self.fit_y = (lay.X[1:] @ self.likelihood.CC + self.likelihood.DD).reshape(-1)         # :344
+        if "RMSE" in out:
+            self.RMSE_val = out["RMSE"]
+        out.update(predict_x=px, predict_x_var=pv, U_val=U_val, fit_y=self.fit_y)
+        return out

@@ -242,6 +242,17 @@ int  ffvd_op_adam_step(double *theta, const double *grad, double *m, double *v, 
 int  ffvd_op_sghmc_step(double *theta, const double *grad, double *xi, double *g, double *g2, double *p,
                         const double *noise, int64_t n, double epsilon, double mdecay, double X_N, int burn_in);
 
+/* The prediction loop of collect_samples_formal (base_model.py:288-314) for R posterior rollouts advanced side by
+ * side on the device: per step, conditional_after_kernel_precalculation at the R current states (:300, q_sqrt = the
+ * d = 0 slice or NULL as in ffvd_op_conditional_precalc), then x_next = x + f_mu + eps * sqrt(f_var + Q) (:304-306).
+ * x_last: D (= layers[-1].X[-1], :226); ctrl: steps x C, row t = control_inputs[Y_train.shape[0] + t] (:293), NULL when
+ * C = 0; f = U_val: M x D; eps: steps x R x D standard-normal draws (injected); outputs R x steps x D:
+ * predict_x (:313) and predict_var = f_var + Q (:314). */
+int  ffvd_op_rollout(int kind, const double *Lm_inverse_seq, const double *Z, int M, int P, int D,
+                     const double *logvariance, const double *loglengthscales, const double *f, const double *q_sqrt,
+                     const double *x_last, int R, const double *ctrl, int C, int steps, const double *log_Q,
+                     const double *eps, double *predict_x, double *predict_var);
+
 #ifdef __cplusplus
 }
 #endif

@@ -241,6 +241,41 @@ def conditional_after_kernel_precalculation(Lm_inverse_seq, Xnew, Z, kern, f, *,
     return np.asarray(f_mu)[:, :, 0].T, np.asarray(f_var)[:, :, 0].T
 
 
+def rollout(Lm_inverse_seq, Z, kern, U_val, q_sqrt, x_last, control_inputs, ctrl_offset, steps, Q, eps):
+    """The prediction loop of collect_samples_formal (base_model.py:288-314) for R = eps.shape[1] posterior
+    rollouts advanced side by side (the reference runs them one after another; they only differ by the noise).
+
+    x_last: (D,) = layers[-1].X[-1] (:226, pre_index = 1); control_inputs: (n, C) with row ctrl_offset + test_i fed
+    at step test_i (:293, ctrl_offset = Y_train.shape[0]); eps: (steps, R, D) replaces tf.random.normal (:304).
+    Returns predict_x (R, steps, D) and predict_x_var (R, steps, D) = f_var + Q (:311)."""
+    steps, R, D = eps.shape
+    x_t = np.repeat(np.asarray(x_last, dtype=np.float64)[None, :], R, axis=0)
+    px, pv = np.zeros((R, steps, D)), np.zeros((R, steps, D))
+    has_c = control_inputs is not None and control_inputs.shape[1] > 0
+    for ti in range(steps):
+        if has_c:                                                                       # :292-295
+            xc = np.concatenate((x_t, np.repeat(control_inputs[ctrl_offset + ti][None, :], R, axis=0)), axis=1)
+        else:
+            xc = x_t
+        f_mu, f_var = conditional_after_kernel_precalculation(Lm_inverse_seq, xc, Z, kern, U_val, q_sqrt=q_sqrt)   # :300
+        f_mu = f_mu + x_t                                                               # :304 identity mean function
+        x_next = f_mu + eps[ti] * np.sqrt(f_var + Q[None, :])                           # :306
+        px[:, ti], pv[:, ti] = x_next, f_var + Q[None, :]                               # :313-314
+        x_t = x_next
+    return px, pv
+
+
+def predict_y_summary(predict_x, predict_x_var, CC, DD, log_Rchols, Y_test=None, Y_train_std=1.0):
+    """base_model.py:330-347: predictive mean / variance of y from the stacked rollouts, RMSE over the first 30."""
+    predict_y = (np.mean(np.einsum("ijk,kl->ijl", predict_x, CC), axis=0) + DD[None, :]).reshape(-1)          # :341
+    predict_y_var = np.mean(np.einsum("ijk,kl->ijl", predict_x_var, CC ** 2), axis=0).reshape(-1) + np.exp(2 * log_Rchols)   # :342
+    out = {"predict_y": predict_y, "predict_y_var": np.asarray(predict_y_var).reshape(-1)}
+    if Y_test is not None:
+        y30, p30 = np.asarray(Y_test)[:30].reshape(-1), predict_y[:30]                                        # :346-347
+        out["RMSE"] = float(np.sqrt(np.mean((y30 - p30) ** 2)) * Y_train_std)                                 # :348
+    return out
+
+
 # --------------------------------------------------------------------------
 # L3: priors + nll assembly (dgp_model.py)
 # --------------------------------------------------------------------------

@@ -167,3 +167,50 @@ def test_posterior_u_and_precalc_conditional_match_oracle():
     np.testing.assert_allclose(m1, g["precalc_mean"][:1], rtol=1e-9, atol=1e-11)
     with pytest.raises(NotImplementedError):
         cmo.conditional_after_kernel_precalculation(W, xc, params["Z"], kern, params["U"], white=False)
+
+
+@pytest.mark.parametrize("name,R,steps,with_q", [("tiny", 3, 7, True), ("ragged", 70, 5, True), ("small", 5, 12, False)])
+def test_rollout_matches_oracle(name, R, steps, with_q):
+    """the prediction loop of collect_samples_formal (base_model.py:288-314), R rollouts side by side,
+    against the CPU restatement with the same injected noise; keeps the d = 0 q_sqrt quirk (a14)."""
+    from ffvd_amd import conditionals_multi_output as cmo
+    from ffvd_amd.prediction import rollout
+    from ffvd_amd.kernels import SquaredExponential
+    params, Y, c, meta = synthetic.make_named(name)
+    D, C, T = meta["D"], meta["C"], meta["T"]
+    X = params["X"][0]
+    Q = np.exp(params["log_Q"])
+    okern = orc.make_kernels(params)
+    kern = [SquaredExponential(D + C, variance=np.exp(params["logvariance"][d]),
+                               lengthscales=np.exp(params["loglengthscales"][d])) for d in range(D)]
+    rng = np.random.default_rng(5)
+    ctrl = np.concatenate((c, rng.standard_normal((steps, C))))          # control inputs continue past the training rows
+    eps = rng.standard_normal((steps, R, D))
+    xc = np.concatenate((X[:-1], c), axis=1)
+    Lo = orc.kernel_pre_cal(params["Z"], okern)
+    Uo, Ho = orc.collapse_u_mean_after_kernel_precalculation(Lo, xc, X, params["Z"], okern, Q)
+    px_o, pv_o = orc.rollout(Lo, params["Z"], okern, Uo, Ho if with_q else None, X[-1], ctrl, T, steps, Q, eps)
+    Lg = cmo.kernel_pre_cal(params["Z"], kern)
+    Ug, Hg = cmo.collapse_u_mean_after_kernel_precalculation(Lg, xc, X, params["Z"], kern, Q)
+    px, pv = rollout(Lg, params["Z"], kern, Ug, Hg if with_q else None, X[-1], ctrl, T, steps, Q, eps)
+    # errors compound along the chain (each step feeds the next); 1e-8 after a dozen steps is eps * cond(K_uu)
+    np.testing.assert_allclose(px, px_o, rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(pv, pv_o, rtol=1e-8, atol=1e-10)
+    assert px.shape == (R, steps, D) and np.all(pv > 0)
+    # every rollout starts from the same state: with equal noise they coincide
+    eps2 = np.repeat(eps[:, :1], R, axis=1)
+    px2, _ = rollout(Lg, params["Z"], kern, Ug, None, X[-1], ctrl, T, steps, Q, eps2)
+    np.testing.assert_array_equal(px2[0], px2[-1])
+
+
+def test_rollout_argument_errors():
+    from ffvd_amd.prediction import rollout
+    from ffvd_amd.kernels import SquaredExponential
+    kern = [SquaredExponential(3, variance=0.5, lengthscales=np.ones(3)) for _ in range(2)]
+    Z = np.zeros((4, 3))
+    with pytest.raises(ValueError):          # control inputs too short for the horizon
+        rollout(np.zeros((2, 4, 4)), Z, kern, np.zeros((4, 2)), None, np.zeros(2), np.zeros((3, 1)), 2, 5, np.ones(2),
+                np.zeros((5, 1, 2)))
+    with pytest.raises(ValueError):          # eps must be (steps, R, D)
+        rollout(np.zeros((2, 4, 4)), Z, kern, np.zeros((4, 2)), None, np.zeros(2), np.zeros((9, 1)), 2, 5, np.ones(2),
+                np.zeros((4, 1, 2)))

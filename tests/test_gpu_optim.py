@@ -141,3 +141,41 @@ def test_fit_runs_the_training_loop(actuator):
     assert m.model.nll() == pytest.approx(after, rel=1e-12)
     assert not np.allclose(m.model.layers[-1].Z, params["Z"])
     assert len(m.model.window) == 5
+
+
+def test_collect_samples_formal_on_actuator(actuator):
+    """Train a few steps, then predict: base_model.py:197-350 end to end (posterior U, rollouts, predictive y, RMSE),
+    compared with the CPU restatement fed with the trained parameters and the same noise."""
+    from ffvd_amd.models import RegressionModel
+    from oracle import ffvd_oracle as orc
+    params, Y, c = actuator
+    n_train, test_len, num = 400, 40, 6
+    m = RegressionModel("normal")
+    A = m.ARGS
+    A.CC, A.DD = params["CC"], params["DD"]
+    A.QQ_chol = np.exp(0.5 * params["log_Q"])
+    A.RR_chol = np.exp(params["log_Rchols"])
+    A.lengthscales, A.variance = np.exp(params["loglengthscales"]), np.exp(params["logvariance"])
+    A.UU_ini, A.XX_0_ini, A.x_initialization = params["U"], params["X"][0], params["X"][1:n_train + 1]
+    A.control_inputs, A.num_inducing, A.x_dims, A.ZZ = c, 100, [4], params["Z"]
+    A.U_collapse, A.kernel_optimization, A.case_val = True, True, 4
+    m.fit(Y[:n_train], kernel_type="SquaredExponential", iterations=2, route="gram", grad=True)
+    eps = np.random.default_rng(11).standard_normal((test_len, num, 4))
+    out = m.model.collect_samples_formal(num, 50, c, test_len, U_collapse=True, Y_test=Y[n_train:n_train + test_len],
+                                         Y_train_std=1.7, Y_train=Y[:n_train], eps=eps)
+    # CPU restatement on the trained parameters
+    p = m.model.parameters()
+    X = p["X"][0]
+    okern = orc.make_kernels(p)
+    Q = np.exp(p["log_Q"])
+    Lo = orc.kernel_pre_cal(p["Z"], okern)
+    Uo, Ho = orc.collapse_u_mean_after_kernel_precalculation(Lo, np.concatenate((X[:-1], c[:n_train]), axis=1), X, p["Z"],
+                                                             okern, Q)
+    px, pv = orc.rollout(Lo, p["Z"], okern, Uo, Ho, X[-1], c, n_train, test_len, Q, eps)
+    ref = orc.predict_y_summary(px, pv, p["CC"], p["DD"], p["log_Rchols"], Y[n_train:n_train + test_len], 1.7)
+    np.testing.assert_allclose(out["U_val"], Uo, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(out["predict_x"], px, rtol=1e-7, atol=1e-8)
+    np.testing.assert_allclose(out["predict_y"], ref["predict_y"], rtol=1e-7, atol=1e-8)
+    np.testing.assert_allclose(out["predict_y_var"], ref["predict_y_var"], rtol=1e-7)
+    assert out["RMSE"] == pytest.approx(ref["RMSE"], rel=1e-7)
+    assert m.model.RMSE_val == out["RMSE"] and m.model.fit_y.shape == (n_train,)
