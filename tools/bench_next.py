@@ -1,0 +1,41 @@
+"""Timings of the SURVEY 8f rows built on top of the ELBO hot path, at the headline shape (config 2):
+backward pass, device-resident Adam step, batched posterior rollouts.  Prints one JSON object."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from ffvd_amd import synthetic, conditionals_multi_output as cmo
+from ffvd_amd.engine import ElboEngine
+from ffvd_amd.kernels import SquaredExponential
+from ffvd_amd.prediction import rollout
+
+params, Y, c, meta = synthetic.make_named("c2")
+T, D, C, M, S = meta["T"], meta["D"], meta["C"], meta["M"], meta["S"]
+out = {"workload": "synthetic T=4096 D=4 C=1 M=512 S=32 fp64 (config 2)"}
+with ElboEngine(T, D, C, M, S, route="gram", grad=True) as e:
+    e.set_data(Y, c); e.set_params(params)
+    e.nll_and_grad()
+    t0 = time.perf_counter()
+    for _ in range(10): e.nll_and_grad()
+    out["fwd_bwd_ms"] = (time.perf_counter() - t0) / 10 * 1e3
+    lr = 0.003 * 0.95 ** 0.001
+    first = e.adam_step(lr)["nll"]
+    t0 = time.perf_counter()
+    for _ in range(20): last = e.adam_step(lr)["nll"]
+    out["adam_step_ms"] = (time.perf_counter() - t0) / 20 * 1e3
+    out["nll_first"], out["nll_after_21_steps"] = first, last
+kern = [SquaredExponential(D + C, variance=np.exp(params["logvariance"][d]), lengthscales=np.exp(params["loglengthscales"][d]))
+        for d in range(D)]
+X = params["X"][0]
+L = cmo.kernel_pre_cal(params["Z"], kern)
+U, H = cmo.collapse_u_mean_after_kernel_precalculation(L, np.concatenate((X[:-1], c), axis=1), X, params["Z"], kern,
+                                                       np.exp(params["log_Q"]))
+rng = np.random.default_rng(0)
+for R, steps in ((32, 200), (100, 200)):
+    ctrl = np.concatenate((c, rng.standard_normal((steps, C))))
+    eps = rng.standard_normal((steps, R, D))
+    rollout(L, params["Z"], kern, U, H, X[-1], ctrl, T, 2, np.exp(params["log_Q"]), eps[:2])
+    t0 = time.perf_counter()
+    rollout(L, params["Z"], kern, U, H, X[-1], ctrl, T, steps, np.exp(params["log_Q"]), eps)
+    dt = time.perf_counter() - t0
+    out[f"rollout_R{R}_us_per_step"] = dt / steps * 1e6
+print(json.dumps(out))
