@@ -375,7 +375,10 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
     // the L^-T rows, K^-1, log|K|: a handful of workgroups per launch) runs on the side stream beside the
     // HBM-bound K_fu build of the first pass and joins before the Gram kernel, which adds K_uu and reads K^-1.
     hipStream_t sk = s;
-    if (gram_route) {
+    // (measured on config 2: 4.41 ms overlapped vs 4.51 ms serial with 128 units per pass; with 16 units the K_fu
+    //  build is shorter than the chain and sharing CUs only slows both: 1.42 vs 1.37 ms -> serial there)
+    const int first_units = ((c.S_local < h->cpp) ? c.S_local : h->cpp) * Dl;
+    if (gram_route && (size_t)first_units * Tp * Mp >= (size_t)64 * 4096 * 512) {
         sk = h->aux;
         HIP_TRY(hipEventRecord(h->ev_fork, s));
         HIP_TRY(hipStreamWaitEvent(sk, h->ev_fork, 0));
@@ -397,7 +400,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
             launch_atb(sk, ak);
         } else launch_gram(sk, gk);
         launch_h_finish(sk, h->Kuu, Mp, kstride, Dl, h->kterms);
-        HIP_TRY(hipEventRecord(h->ev_join, sk));
+        if (sk != s) HIP_TRY(hipEventRecord(h->ev_join, sk));
     }
     if (st) st->mark(0);
     for (int s0 = 0; s0 < c.S_local; s0 += h->cpp) {
@@ -415,7 +418,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
         pa.ng = h->ng;
         if (gram_route) {
             launch_kfu_build(s, pa);
-            if (s0 == 0) HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));
+            if (s0 == 0 && sk != s) HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));
         } else launch_project(s, pa);
         if (st) st->mark(1);
         if (c.branch == FFVD_BRANCH_B) {

@@ -302,39 +302,80 @@ __device__ __forceinline__ void pivot_sqrt(const double ajj, double &piv, double
     y = y + y * (1.0 - piv * y);
 }
 
-// 64x64 Cholesky by ONE wavefront with no barriers and no LDS traffic: lane = row, the whole row in registers
-// (a[c] = A[lane][c]), left-looking: column j <- a[j] - sum_{i<j} L[:,i] L[j][i], where row j of L is lane j's own
-// registers, handed to every lane as scalars by v_readlane.  The sums for column j+1 do not depend on pivot j except
-// for their last term, so the sqrt chain of one pivot overlaps with the products of the next column.
+// 64x64 Cholesky by ONE wavefront with no workgroup barriers: lane = row, the whole row in registers
+// (a[c] = A[lane][c]), left-looking: column j <- a[j] - sum_{i<j} L[:,i] L[j][i].  Row j of L reaches every lane
+// as broadcast LDS reads (16 bytes = two entries per instruction) of the copy Lr that the wavefront extends by one
+// column per pivot.  Software pipeline: while the sqrt chain of pivot j is in flight, the wavefront already sums
+// the terms i <= j-2 of column j+1 (all of them final and visible); when pivot j is done only two terms are
+// missing -- L[j+1][j-1] from LDS and the newest one, L[j+1][j], by v_readlane.  A single wavefront issues in
+// order, so without this interleaving every pivot would pay its full dependent latency.
 // Entries above the diagonal carry don't-care values.
-// Out: a[c] = L[lane][c] for c <= lane; invd[j] = 1 / L[j][j] (LDS).  Returns 0 or 1 + first bad pivot.
-__device__ __forceinline__ int chol64_1w(double (&a)[NB], double *invd, const int lane) {
+// Out: Lr[r][c] = L[r][c] for c <= r (LDS); invd[j] = 1 / L[j][j] (LDS).  Returns 0 or 1 + first bad pivot.
+// PIPE = false drops the software pipeline (plain left-looking sums, the newest term by v_readlane): about 100
+// VGPRs fewer, for launches whose many workgroups care about occupancy more than about one tile's latency.
+constexpr int LR_LD = NB + 2;
+template <bool PIPE>
+__device__ __forceinline__ int chol64_1w(double (&a)[NB], double (*Lr)[LR_LD], double *invd, const int lane) {
     int bad = 0;
+    if (!PIPE) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            double s0 = a[j], s1 = 0.0;
+            if (j >= 2) wave_lds_sync();                     // column j-2 (and older) of Lr is visible
+#pragma unroll
+            for (int i = 0; i + 1 < j - 1 + (j & 1); i += 2) {          // pairs (i, i+1) with i + 1 <= j - 2
+                const double2 lj = *reinterpret_cast<const double2 *>(&Lr[j][i]);
+                s0 -= a[i] * lj.x;
+                s1 -= a[i + 1] * lj.y;
+            }
+            if (j >= 2 && !(j & 1)) s0 -= a[j - 2] * Lr[j][j - 2];
+            if (j >= 1) s1 -= a[j - 1] * readlane_f64(a[j - 1], j);
+            const double v = s0 + s1;
+            const double ajj = readlane_f64(v, j);
+            if (!(ajj > 0.0) && bad == 0) bad = j + 1;
+            double piv, y;
+            pivot_sqrt(ajj, piv, y);
+            a[j] = v * y;
+            Lr[lane][j] = a[j];
+            if (lane == 0) invd[j] = y;
+        }
+        return bad;
+    }
+    double nxt = 0.0;                                    // sum_{i <= j-3} L[:,i] L[j][i], formed during pivot j-1
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-        double s0 = a[j], s1 = 0.0;
-#pragma unroll
-        for (int i = 0; i + 1 < j; i += 2) {
-            s0 -= a[i] * readlane_f64(a[i], j);
-            s1 -= a[i + 1] * readlane_f64(a[i + 1], j);
-        }
-        if (j & 1) s0 -= a[j - 1] * readlane_f64(a[j - 1], j);
-        const double v = s0 + s1;
+        double v = a[j] - nxt;                           // the two newest terms come straight from the registers
+        if (j >= 2) v -= a[j - 2] * readlane_f64(a[j - 2], j);
+        if (j >= 1) v -= a[j - 1] * readlane_f64(a[j - 1], j);
         const double ajj = readlane_f64(v, j);
         if (!(ajj > 0.0) && bad == 0) bad = j + 1;
         double piv, y;
         pivot_sqrt(ajj, piv, y);
+        if (j + 1 < NB) {                                // terms i = 0 .. j-2 of column j+1, independent of pivot j
+            if (j >= 2) wave_lds_sync();                 // columns <= j-2 of Lr (stored >= 1 pivot ago) are visible
+            double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
+#pragma unroll
+            for (int i = 0; i + 1 <= j - 2; i += 2) {
+                const double2 l2 = *reinterpret_cast<const double2 *>(&Lr[j + 1][i]);
+                if (i & 2) { q2 += a[i] * l2.x; q3 += a[i + 1] * l2.y; }
+                else { q0 += a[i] * l2.x; q1 += a[i + 1] * l2.y; }
+            }
+            if (j >= 2 && !(j & 1)) q0 += a[j - 2] * Lr[j + 1][j - 2];        // j-1 terms: odd count when j is even
+            nxt = (q0 + q1) + (q2 + q3);
+        }
         a[j] = v * y;                                    // lane j: ajj * y = sqrt(ajj) to an ulp
+        Lr[lane][j] = a[j];
         if (lane == 0) invd[j] = y;
     }
     return bad;
 }
 
-// Factorise the diagonal block held in LDS tile `Ts` (row-major, stride NB+1): wavefront 0 runs chol64_1w, then
-// all 256 threads publish L in place (lower triangle of the global block) and the four wavefronts invert the four
-// 16x16 diagonal sub-blocks of L (lane = column, 16-step forward substitution) into dinv_b[4][16][16] -- what the
-// panel kernel's blocked substitution multiplies by.
-__device__ __forceinline__ void diag_block_finish(double (*Ts)[NB + 1], double (*col)[NB], double *invd, double *S, int n,
+// Factorise the diagonal block held in LDS tile `Ts` (row-major, stride NB+1): wavefront 0 runs chol64_1w, which
+// leaves L in the LDS tile `Lr`; then all 256 threads publish L in place (lower triangle of the global block) and
+// the four wavefronts invert the four 16x16 diagonal sub-blocks of L (lane = column, 16-step forward substitution)
+// into dinv_b[4][16][16] -- what the panel kernel's blocked substitution multiplies by.
+template <bool PIPE>
+__device__ __forceinline__ void diag_block_finish(double (*Ts)[NB + 1], double (*Lr)[LR_LD], double *invd, double *S, int n,
                                                    int k0, int32_t *info_b, double *dinv_b) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -342,14 +383,12 @@ __device__ __forceinline__ void diag_block_finish(double (*Ts)[NB + 1], double (
         double a[NB];
 #pragma unroll
         for (int c = 0; c < NB; ++c) a[c] = Ts[lane][c];
-        const int bad = chol64_1w(a, invd, lane);
+        const int bad = chol64_1w<PIPE>(a, Lr, invd, lane);
         if (bad && lane == 0 && *info_b == 0) *info_b = k0 + bad;
-#pragma unroll
-        for (int c = 0; c < NB; ++c) Ts[lane][c] = a[c];
     }
     __syncthreads();
     for (int r = tid >> 6; r < NB; r += 4)
-        if (lane <= r) S[(size_t)(k0 + r) * n + k0 + lane] = Ts[r][lane];         // coalesced rows of L
+        if (lane <= r) S[(size_t)(k0 + r) * n + k0 + lane] = Lr[r][lane];         // coalesced rows of L
     if (lane < 16) {
         const int o = 16 * w;
         double x[16];
@@ -357,7 +396,7 @@ __device__ __forceinline__ void diag_block_finish(double (*Ts)[NB + 1], double (
         for (int r = 0; r < 16; ++r) {
             double acc = (lane == r) ? 1.0 : 0.0;
 #pragma unroll
-            for (int i = 0; i < r; ++i) acc -= Ts[o + r][o + i] * x[i];
+            for (int i = 0; i < r; ++i) acc -= Lr[o + r][o + i] * x[i];
             x[r] = acc * invd[o + r];
         }
 #pragma unroll
@@ -368,14 +407,14 @@ __device__ __forceinline__ void diag_block_finish(double (*Ts)[NB + 1], double (
 __global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, int n, int k, size_t slab_stride, int32_t *info,
                                                          double *dinv) {
     __shared__ double Ts[NB][NB + 1];
-    __shared__ double col[2][NB];
+    __shared__ double Lr[NB][LR_LD];
     __shared__ double invd[NB];
     const int b = blockIdx.x, tid = threadIdx.x;
     double *S = A + (size_t)b * slab_stride;
     const int k0 = k * NB;
     for (int r = tid >> 6; r < NB; r += 4) Ts[r][tid & 63] = S[(size_t)(k0 + r) * n + k0 + (tid & 63)];
     __syncthreads();
-    diag_block_finish(Ts, col, invd, S, n, k0, info + b, dinv + (size_t)b * DINV_STRIDE);
+    diag_block_finish<true>(Ts, Lr, invd, S, n, k0, info + b, dinv + (size_t)b * DINV_STRIDE);
 }
 
 // tile bookkeeping shared by the panel and trailing kernels
@@ -457,13 +496,14 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double *A, int n, int 
 // Tiles: main lower triangle (k < j <= i < nb) then extra-row tiles (e, j) for j in (k, nb).
 // Tile 0 is the next diagonal block (k+1,k+1): wavefront 0 of its workgroup factorises it right away, so the
 // 64-pivot chain of step k+1 overlaps with the rest of step k's trailing update (look-ahead inside one launch).
+template <bool PIPE>
 __global__ __launch_bounds__(256) void potrf_trail_kernel(double *A, int n, int k, int nmain_tiles, int n1,
                                                           size_t slab_stride, int32_t *info, int nlive, int nid,
                                                           double *dinv) {
     __shared__ double Pi_s[NB][TR_LD];
     __shared__ double Pj_s[NB][TR_LD];
-    __shared__ double col[2][NB];
     __shared__ double invd[NB];
+    static_assert(TR_LD == LR_LD, "the staged panel block doubles as the factor tile");
     const int b = blockIdx.y;
     const int tile = blockIdx.x;
     double *S = A + (size_t)b * slab_stride;
@@ -544,7 +584,7 @@ __global__ __launch_bounds__(256) void potrf_trail_kernel(double *A, int n, int 
                 Ts[r][cc] = Ct[(size_t)r * n + cc] - acc[x][y][q];
             }
     __syncthreads();
-    diag_block_finish(Ts, col, invd, S, n, k0 + NB, info + b, dinv + (size_t)b * DINV_STRIDE);
+    diag_block_finish<PIPE>(Ts, Pi_s, invd, S, n, k0 + NB, info + b, dinv + (size_t)b * DINV_STRIDE);   // Pi_s is free too
 }
 
 void launch_potrf_ext(hipStream_t stream, double *A, int n, int extra_rows, int identity_rows, int batch,
@@ -564,8 +604,14 @@ void launch_potrf_ext(hipStream_t stream, double *A, int n, int extra_rows, int 
         if (n1 > 0) {
             const int nmain_tiles = n1 * (n1 + 1) / 2;
             const int ntiles = nmain_tiles + nextra * n1;
-            hipLaunchKernelGGL(potrf_trail_kernel, dim3(ntiles, batch), dim3(256), 0, stream, A, n, k, nmain_tiles, n1,
-                               slab_stride, info, nlive, nid, dinv);
+            // few workgroups: the launch lasts as long as tile 0's look-ahead factorisation -> pipelined variant
+            // (256 VGPRs, one workgroup per CU); many: the leaner variant keeps two workgroups per CU
+            if ((size_t)ntiles * batch <= 512)
+                hipLaunchKernelGGL(potrf_trail_kernel<true>, dim3(ntiles, batch), dim3(256), 0, stream, A, n, k,
+                                   nmain_tiles, n1, slab_stride, info, nlive, nid, dinv);
+            else
+                hipLaunchKernelGGL(potrf_trail_kernel<false>, dim3(ntiles, batch), dim3(256), 0, stream, A, n, k,
+                                   nmain_tiles, n1, slab_stride, info, nlive, nid, dinv);
         }
     }
 }
