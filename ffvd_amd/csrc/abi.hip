@@ -31,6 +31,8 @@ struct ffvd_handle {
     int P = 0, Mp = 0, Tp = 0, Dl = 0, nbatch = 0, ng = 0, cpp = 0;
     hipStream_t stream = nullptr;
     double *dinvK = nullptr, *dinvH = nullptr;   // Cholesky scratch (kernels.h DINV_STRIDE per matrix)
+    double *gpart = nullptr;                     // split-K partial tiles of the Gram kernel (few units per pass)
+    int gsplit = 1;
     hipStream_t aux = nullptr;          // side stream: the K_uu chain runs beside the K_fu build (Gram route)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string err;
@@ -214,6 +216,11 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
     HIP_TRY(dev_alloc(h, &h->chain_nll, (size_t)c.S_local));
     HIP_TRY(dev_alloc(h, &h->out_terms, (size_t)8));
     HIP_TRY(dev_alloc(h, &h->info, (size_t)(Dl + h->nbatch)));
+    if (c.branch == FFVD_BRANCH_B) {
+        const int upass = h->cpp * (int)Dl;
+        h->gsplit = gram_ksplit((int)Mp, upass, (int)Tp);
+        if (h->gsplit > 1) HIP_TRY(dev_alloc(h, &h->gpart, gram_part_doubles((int)Mp, upass, h->gsplit)));
+    }
     HIP_TRY(dev_alloc(h, &h->dinvK, (size_t)Dl * DINV_STRIDE));
     HIP_TRY(dev_alloc(h, &h->dinvH, (size_t)(h->nbatch ? h->nbatch : 1) * DINV_STRIDE));
     HIP_TRY(hipHostMalloc((void **)&h->h_out, 8 * sizeof(double)));
@@ -398,7 +405,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
             ak.mode = ATB_PLAIN; ak.A = h->Linv; ak.a_stride = msq; ak.lda = Mp; ak.nA = Mp; ak.B = h->Linv; ak.b_stride = msq;
             ak.ldb = Mp; ak.nB = Mp; ak.rows = Mp; ak.C = h->Kinv; ak.c_stride = msq; ak.ldc = Mp; ak.nb = Dl; ak.Dl = Dl;
             launch_atb(sk, ak);
-        } else launch_gram(sk, gk);
+        } else launch_gram(sk, gk);     // (split-K here was measured slower: 0.42 vs 0.37 ms for the K_uu stage)
         launch_h_finish(sk, h->Kuu, Mp, kstride, Dl, h->kterms);
         if (sk != s) HIP_TRY(hipEventRecord(h->ev_join, sk));
     }
@@ -433,6 +440,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
                 launch_set_identity(s, h->H, ga.h_stride, Mp, Mp, ns * Dl);
             }
             ga.Kadd = h->Kcopy; ga.kadd_stride = msq; ga.Kinv = h->Kinv; ga.kinv_stride = msq; ga.trpart = h->trpart;
+            if (h->gpart && ns == h->cpp) { ga.ksplit = h->gsplit; ga.part = h->gpart; }
             launch_gram(s, ga);
             if (st) st->mark(2);
             if (c.grad) {       // keep A = K_uu + K_uf K_fu / Q: the factorisation overwrites it in place

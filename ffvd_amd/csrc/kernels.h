@@ -95,8 +95,16 @@ struct GramArgs {
     size_t kinv_stride;
     double *trpart;         // GRAM_KFU: [nbatch_total][ntiles] partial sums of tr(K^-1 K_uf K_fu)
     int ntiles;             // filled by launch_gram
+    // split-K for launches with few tiles: the rows are cut into `ksplit` ranges, every range writes its raw partial
+    // sums into its own slab of `part` ([ksplit][nb] slabs of (Mp + 1) x Mp, row Mp = the delta^T A partials), and
+    // gram_combine adds them in fixed order and applies the epilogue.  ksplit <= 1 or part == nullptr: off.
+    int ksplit;
+    double *part;
 };
 int gram_ntiles(int Mp);
+// how many row ranges launch_gram should use for `nb` units (1 = no split), and the doubles `part` then needs
+int gram_ksplit(int Mp, int nb, int rows);
+size_t gram_part_doubles(int Mp, int nb, int ksplit);
 void launch_gram(hipStream_t stream, GramArgs a);
 
 // hterms[b] = { logdet(H) = 2 sum log diag(L_H),  b^T H^{-1} b = |row Mp|^2 } after launch_potrf_ext on H.

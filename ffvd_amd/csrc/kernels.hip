@@ -18,6 +18,7 @@
 //   * Cholesky is a blocked right-looking factorisation whose "extra rows" carry a right-hand side through the
 //     same panel/trailing kernels: identity rows become L^{-T}, the row delta^T F / Q becomes L_H^{-1} b.
 #include "kernels.h"
+#include <cstdlib>
 
 namespace ffvd {
 
@@ -854,8 +855,8 @@ __device__ __constant__ unsigned char GRAM_DIAG_WC[8] = {0, 1, 2, 3, 0, 1, 2, 3}
 
 template <int MODE, bool DIAG>
 __device__ __forceinline__ void gram_body(const GramArgs a, const int bz, const int ti, const int tj, const int tile,
-                                          double (*As)[GT][G_LD], double (*Bs)[GT][G_LD], double (*dls)[GT],
-                                          double *red) {
+                                          const int kpart, const int ksplit, double (*As)[GT][G_LD],
+                                          double (*Bs)[GT][G_LD], double (*dls)[GT], double *red) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = DIAG ? GRAM_DIAG_WR[wave] : (wave >> 2), wc = DIAG ? GRAM_DIAG_WC[wave] : (wave & 3);
@@ -919,11 +920,14 @@ __device__ __forceinline__ void gram_body(const GramArgs a, const int bz, const 
         for (int y = 0; y < 2; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
     double bsum = 0.0;
 
-    const int nchunk = a.rows / GT;
-    gload(0);
-    lstore(0);
+    const int nchunk_all = a.rows / GT;
+    const int per = (nchunk_all + ksplit - 1) / ksplit;
+    const int cbeg = kpart * per;
+    const int nchunk = (cbeg + per <= nchunk_all) ? cbeg + per : nchunk_all;      // this range: chunks [cbeg, nchunk)
+    gload(cbeg);
+    lstore(cbeg & 1);
     __syncthreads();
-    for (int c = 0; c < nchunk; ++c) {
+    for (int c = cbeg; c < nchunk; ++c) {
         const int buf = c & 1;
         if (c + 1 < nchunk) gload(c + 1);
         if (active) {
@@ -959,6 +963,23 @@ __device__ __forceinline__ void gram_body(const GramArgs a, const int bz, const 
         __syncthreads();
     }
 
+    if (ksplit > 1) {            // raw partial sums of this row range; gram_combine finishes the job
+        double *Pb = a.part + ((size_t)kpart * a.nb + bz) * ((size_t)(Mp + 1) * Mp);
+        if (active) {
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        Pb[(size_t)(I0 + 16 * x + lk + 4 * q) * Mp + J0 + 16 * y + lr] = acc[x][y][q];
+        }
+        if (gemv) {
+            const int col = ti * 128 + tid - 384;
+            if (col < Mp) Pb[(size_t)Mp * Mp + col] = bsum;
+        }
+        return;
+    }
     const double scale = (MODE == GRAM_PLAIN) ? 1.0 : a.yn_over_batch / exp(a.log_Q[dg]);
     double *Hb = a.H + (size_t)bz * a.h_stride;
     const double *Kadd = (MODE == GRAM_KFU) ? a.Kadd + (size_t)dl * a.kadd_stride : nullptr;
@@ -1007,14 +1028,73 @@ __global__ __launch_bounds__(512, 4) void gram_kernel(GramArgs a) {
     // XCD-aware mapping: all tiles of one (chain, dim) share blockIdx % 8, i.e. one XCD's L2 (speed only)
     const int id = blockIdx.x;
     const int xcd = id & 7, loc = id >> 3;
-    const int bz = (loc / a.ntiles) * 8 + xcd;
+    const int ksplit = (a.ksplit > 1 && a.part) ? a.ksplit : 1;
+    const int per_unit = a.ntiles * ksplit;
+    const int bz = (loc / per_unit) * 8 + xcd;
     if (bz >= a.nb) return;
-    const int tile = loc % a.ntiles;
+    const int tile = (loc % per_unit) / ksplit, kpart = loc % ksplit;
     int ti = 0;                       // tile = ti (ti + 1) / 2 + tj,  tj <= ti
     while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
     const int tj = tile - ti * (ti + 1) / 2;
-    if (ti == tj) gram_body<MODE, true>(a, bz, ti, tj, tile, As, Bs, dls, red);
-    else gram_body<MODE, false>(a, bz, ti, tj, tile, As, Bs, dls, red);
+    if (ti == tj) gram_body<MODE, true>(a, bz, ti, tj, tile, kpart, ksplit, As, Bs, dls, red);
+    else gram_body<MODE, false>(a, bz, ti, tj, tile, kpart, ksplit, As, Bs, dls, red);
+}
+
+// Second pass of a split-K Gram launch: one workgroup per (unit, tile) adds the `ksplit` partial tiles in fixed
+// order and applies the epilogue of gram_body (scaling, + I / + K_uu, trace partial, the delta^T A row).
+template <int MODE>
+__global__ __launch_bounds__(256) void gram_combine_kernel(GramArgs a) {
+    __shared__ double red[256];
+    const int tid = threadIdx.x;
+    const int bz = blockIdx.y, tile = blockIdx.x;
+    int ti = 0;
+    while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
+    const int tj = tile - ti * (ti + 1) / 2;
+    const int Mp = a.Mp;
+    const int b = a.b0 + bz, dl = b % a.Dl, dg = a.d_begin + dl;
+    const size_t pstride = (size_t)(Mp + 1) * Mp;
+    const double *P0 = a.part + (size_t)bz * pstride;
+    const size_t ks_stride = (size_t)a.nb * pstride;
+    const double scale = (MODE == GRAM_PLAIN) ? 1.0 : a.yn_over_batch / exp(a.log_Q[dg]);
+    double *Hb = a.H + (size_t)bz * a.h_stride;
+    const double *Kadd = (MODE == GRAM_KFU) ? a.Kadd + (size_t)dl * a.kadd_stride : nullptr;
+    const double *Kinv = (MODE == GRAM_KFU) ? a.Kinv + (size_t)dl * a.kinv_stride : nullptr;
+    double trp = 0.0;
+    for (int sb = 0; sb < 8; ++sb) {                  // the 64 x 32 sub-blocks gram_body writes
+        const int wr = sb >> 2, wc = sb & 3;
+        const int I0 = ti * 128 + wr * 64, J0 = tj * 128 + wc * 32;
+        if (!((I0 < Mp) && (J0 < Mp) && (J0 < I0 + 64))) continue;
+        for (int e = tid; e < 64 * 32; e += 256) {
+            const int i = I0 + (e >> 5), j = J0 + (e & 31);
+            double g = 0.0;
+            for (int ks = 0; ks < a.ksplit; ++ks) g += P0[(size_t)ks * ks_stride + (size_t)i * Mp + j];
+            double v;
+            if (MODE == GRAM_F) v = g * scale + ((i == j) ? 1.0 : 0.0);
+            else if (MODE == GRAM_KFU) {
+                v = g * scale + Kadd[(size_t)i * Mp + j];
+                const double w = (i > j) ? 2.0 : ((i == j) ? 1.0 : 0.0);
+                trp += w * (Kinv[(size_t)i * Mp + j] * g);
+            } else v = g;
+            Hb[(size_t)i * Mp + j] = v;
+        }
+    }
+    if (a.with_row && ti == tj && tid < 128) {
+        const int col = ti * 128 + tid;
+        if (col < Mp) {
+            double bs = 0.0;
+            for (int ks = 0; ks < a.ksplit; ++ks) bs += P0[(size_t)ks * ks_stride + (size_t)Mp * Mp + col];
+            Hb[(size_t)a.brow * Mp + col] = bs * scale;
+        }
+    }
+    if (MODE == GRAM_KFU) {
+        red[tid] = trp;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if (tid < st) red[tid] += red[tid + st];
+            __syncthreads();
+        }
+        if (tid == 0) a.trpart[(size_t)b * a.ntiles + tile] = red[0];
+    }
 }
 
 int gram_ntiles(int Mp) {
@@ -1022,14 +1102,38 @@ int gram_ntiles(int Mp) {
     return n128 * (n128 + 1) / 2;
 }
 
+// Few tiles cannot fill the 512 workgroup slots (256 CUs x 2), and 1-2 tiles per slot balance badly (640 tiles take
+// 1.56 x the time of 512).  Measured at M = 512, T = 4096: 160 tiles 0.60 ms unsplit / 0.48 ms in 3 row ranges (one
+// full round) / 0.55-0.62 ms in 2, 4, 6, 8; 320 tiles 1.10 -> 0.86 ms in 3-4 ranges; 640 tiles 1.67 -> 1.52 ms in 2.
+int gram_ksplit(int Mp, int nb, int rows) {
+    const int n = nb * gram_ntiles(Mp);
+    if (const char *e = getenv("FFVD_GSPLIT")) return atoi(e) > 0 ? atoi(e) : 1;       // tuning override
+    if (n <= 0 || n >= 1024) return 1;
+    int ks = (n <= 256) ? 512 / n : (1280 + n / 2) / n;     // one full round, or about 2.5 rounds of short workgroups
+    if (ks > 8) ks = 8;
+    const int nchunk = rows / GT;
+    while (ks > 1 && nchunk / ks < 8) --ks;          // keep at least 128 rows per range
+    return ks;
+}
+size_t gram_part_doubles(int Mp, int nb, int ksplit) {
+    return ksplit > 1 ? (size_t)ksplit * nb * (size_t)(Mp + 1) * Mp : 0;
+}
+
 void launch_gram(hipStream_t stream, GramArgs a) {
     a.ntiles = gram_ntiles(a.Mp);
     if (a.brow <= 0) a.brow = a.Mp;
+    if (!a.part || a.ksplit < 1) a.ksplit = 1;
     const int groups = (a.nb + 7) / 8;
-    const dim3 grid(groups * 8 * a.ntiles);
+    const dim3 grid(groups * 8 * a.ntiles * a.ksplit);
     if (a.mode == GRAM_F) hipLaunchKernelGGL(gram_kernel<GRAM_F>, grid, dim3(512), 0, stream, a);
     else if (a.mode == GRAM_KFU) hipLaunchKernelGGL(gram_kernel<GRAM_KFU>, grid, dim3(512), 0, stream, a);
     else hipLaunchKernelGGL(gram_kernel<GRAM_PLAIN>, grid, dim3(512), 0, stream, a);
+    if (a.ksplit > 1) {
+        const dim3 cgrid(a.ntiles, a.nb);
+        if (a.mode == GRAM_F) hipLaunchKernelGGL(gram_combine_kernel<GRAM_F>, cgrid, dim3(256), 0, stream, a);
+        else if (a.mode == GRAM_KFU) hipLaunchKernelGGL(gram_combine_kernel<GRAM_KFU>, cgrid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL(gram_combine_kernel<GRAM_PLAIN>, cgrid, dim3(256), 0, stream, a);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
