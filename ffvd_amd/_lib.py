@@ -69,6 +69,9 @@ _SIGNATURES = {
     "ffvd_adam_step": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_uint32, _dp,
                                  C.POINTER(C.c_double)]),
     "ffvd_optimizer_reset": (C.c_int, [C.c_void_p]),
+    "ffvd_update_params": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ffvd_sghmc_step": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_uint32, C.c_int, C.c_void_p, _dp,
+                                  C.POINTER(C.c_double)]),
     "ffvd_get_params": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ffvd_op_adam_step": (C.c_int, [_dp, _dp, _dp, _dp, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double,
                                     C.c_int64]),
@@ -91,6 +94,27 @@ class FfvdError(RuntimeError):
     pass
 
 
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch's ROCm wheel bundles its own libamdhip64.so.7 (same SONAME as
+    /opt/rocm's); whichever copy is mapped first serves both libraries.  If libffvd_hip.so pulled in the system copy
+    first, a later `import torch` (RCCL all-reduce of the partial sums, torch CUDA tensors as output buffers) ends up
+    on a runtime it was not built for and reports "no GPUs found".  Mapping torch's copy first -- without importing
+    torch -- makes the order of imports irrelevant."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if not spec or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
 def load():
     """Load libffvd_hip.so (once).  Raises if it has not been built: `python -m ffvd_amd.build`."""
     global _lib
@@ -100,6 +124,7 @@ def load():
         raise FfvdError(
             f"{LIB_PATH} is missing: the HIP extension has not been built (run `python -m ffvd_amd.build` "
             "or `__graft_entry__.build()`); ffvd_amd has no CPU fallback")
+    _preload_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here = ABI/header mismatch: fail loudly

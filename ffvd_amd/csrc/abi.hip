@@ -64,6 +64,8 @@ struct ffvd_handle {
     int32_t *info = nullptr;
     // Adam state for ffvd_adam_step: first/second moments per parameter array (order of FFVD_TRAIN_* bits), step count
     double *adam_m[8] = {nullptr}, *adam_v[8] = {nullptr};
+    double *hmc[8][5] = {{nullptr}};     // SG-HMC state per array: xi, g, g2, p and the uploaded noise
+    bool hmc_ready = false;
     int64_t adam_t = 0;
     bool adam_ready = false;
     // pinned host staging
@@ -813,6 +815,77 @@ extern "C" int ffvd_get_params(ffvd_handle *h, const ffvd_params *out) {
         if (dst[i] && src[i] && n[i])
             HIP_TRY(hipMemcpyAsync(const_cast<void *>(dst[i]), src[i], n[i] * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    return FFVD_OK;
+}
+
+// ffvd_update_params: overwrite some of the bound parameter arrays from host memory (NULL = keep).
+extern "C" int ffvd_update_params(ffvd_handle *h, const ffvd_params *p) {
+    if (!h || !p) return set_error(h, FFVD_EINVAL, "ffvd_update_params: null argument");
+    if (!h->have_params) return set_error(h, FFVD_EINVAL, "ffvd_update_params: no parameters bound yet (ffvd_set_params)");
+    const ffvd_config &c = h->cfg;
+    const size_t P = h->P, J = c.Ydim;
+    HIP_TRY(hipSetDevice(c.device_id));
+    const ffvd_params &cur = h->cur;
+    const void *dst[9] = {cur.X, cur.Z, cur.U, cur.logvariance, cur.loglengthscales, cur.log_Q, cur.CC, cur.DD, cur.log_Rchols};
+    const void *src[9] = {p->X, p->Z, p->U, p->logvariance, p->loglengthscales, p->log_Q, p->CC, p->DD, p->log_Rchols};
+    const size_t n[9] = {(size_t)c.S_local * (c.T + 1) * c.D, (size_t)c.M * P, (size_t)c.M * c.D, (size_t)c.D, (size_t)c.D * P,
+                         (size_t)c.D, (size_t)c.D * J, J, J * J};
+    for (int i = 0; i < 9; ++i)
+        if (src[i] && dst[i] && n[i])
+            HIP_TRY(hipMemcpyAsync(const_cast<void *>(dst[i]), src[i], n[i] * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return FFVD_OK;
+}
+
+extern "C" int ffvd_sghmc_step(ffvd_handle *h, double epsilon, double mdecay, uint32_t sample_mask, int burn_in,
+                               const ffvd_params *noise, double out_terms[8], double *out_nll) {
+    if (!h) return set_error(nullptr, FFVD_EINVAL, "ffvd_sghmc_step: null handle");
+    if (!h->cfg.grad) return set_error(h, FFVD_EINVAL, "ffvd_sghmc_step: the handle was created without grad = 1");
+    if (h->Dl != h->cfg.D)
+        return set_error(h, FFVD_EINVAL, "ffvd_sghmc_step: a latent-dim shard holds partial gradients; use ffvd_op_sghmc_step");
+    if (!noise || !(epsilon > 0.0) || !(mdecay >= 0.0))
+        return set_error(h, FFVD_EINVAL, "ffvd_sghmc_step: bad argument");
+    if (sample_mask & FFVD_TRAIN_X)
+        return set_error(h, FFVD_EINVAL, "ffvd_sghmc_step: X is never an SG-HMC variable (dgp_model.py:213-244)");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    int rc;
+    if ((rc = ready(h, "ffvd_sghmc_step"))) return rc;
+    double *theta[8]; const double *grad[8]; size_t n[8];
+    param_table(h, theta, grad, n);
+    const double *nz[8] = {noise->X, noise->Z, noise->logvariance, noise->loglengthscales, noise->log_Q, noise->CC, noise->DD,
+                           noise->log_Rchols};
+    hipStream_t s = h->stream;
+    for (int i = 1; i < 8; ++i) {
+        if (!(sample_mask & (1u << i)) || n[i] == 0) continue;
+        if (!nz[i]) return set_error(h, FFVD_EINVAL, "ffvd_sghmc_step: a sampled array has no noise array");
+        if (!h->hmc[i][0]) {            // xi, g, g2 <- 1, p <- 0 (base_model.py:151-154)
+            std::vector<double> ones(n[i], 1.0);
+            for (int k = 0; k < 5; ++k) HIP_TRY(dev_alloc(h, &h->hmc[i][k], n[i]));
+            for (int k = 0; k < 3; ++k)
+                HIP_TRY(hipMemcpy(h->hmc[i][k], ones.data(), n[i] * sizeof(double), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemset(h->hmc[i][3], 0, n[i] * sizeof(double)));
+        }
+        HIP_TRY(hipMemcpyAsync(h->hmc[i][4], nz[i], n[i] * sizeof(double), hipMemcpyHostToDevice, s));
+    }
+    if ((rc = enqueue_elbo(h, nullptr, nullptr))) return rc;
+    if ((rc = enqueue_grad(h, h->cfg.S_local))) return rc;
+    HIP_TRY(hipMemcpyAsync(h->h_out, h->out_terms, 8 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(h->h_chain, h->chain_nll, (size_t)h->cfg.S_local * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(h->h_info, h->info, (size_t)(h->Dl + h->nbatch) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if ((rc = check_info(h))) return rc;
+    OptTable tab{};
+    for (int i = 1; i < 8; ++i) {
+        if (!(sample_mask & (1u << i)) || n[i] == 0) continue;
+        OptTensor &t = tab.t[tab.count++];
+        t.theta = theta[i]; t.grad = grad[i]; t.s0 = h->hmc[i][0]; t.s1 = h->hmc[i][1]; t.s2 = h->hmc[i][2];
+        t.s3 = h->hmc[i][3]; t.noise = h->hmc[i][4]; t.n = (int64_t)n[i];
+    }
+    launch_sghmc(s, tab, epsilon, mdecay, (double)(h->cfg.T + 1), burn_in);      // X_N = rows of X (dgp_model.py:203)
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));                   // the noise arrays are the caller's: done with them on return
+    if (out_terms) memcpy(out_terms, h->h_out, 8 * sizeof(double));
+    if (out_nll) *out_nll = h->h_out[FFVD_TERM_NLL] / (double)h->cfg.S_local;
     return FFVD_OK;
 }
 

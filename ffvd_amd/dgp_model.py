@@ -76,8 +76,19 @@ class DGPSSM:
         self._last = None
         self.epsilon, self.mdecay = epsilon, mdecay
         # which variables SG-HMC samples and which Adam trains (dgp_model.py:213-244):
-        # case 4 (collapsed U, the default) trains everything with Adam and leaves `vars` empty
+        # case 4 (collapsed U, kernel/Z optimisation on: what FFVD_Main.py:300-305 sets) leaves `vars` empty
         self.vars = []
+        if not kernel_optimization and kernel_train_flag:                       # :224-232
+            self.vars += ["logvariance", "loglengthscales"] if kernel_type == "SquaredExponential" else ["logvariance"]
+        if not U_optimization and not self.U_collapse:                           # :234-236
+            self.vars += ["U"]
+        if not Z_optimization:                                                   # :240-242
+            self.vars += ["Z"]
+        if hyperparameter_sampling:                                              # :244-246
+            self.vars += ["log_Q", "CC", "DD", "log_Rchols"]
+        self._adam_train = tuple(k for k in ("X", "Z", "logvariance", "loglengthscales", "log_Q", "CC", "DD", "log_Rchols")
+                                 if k not in self.vars)
+        self._rng = np.random.default_rng()
         self.window = []
         self._resident = False      # device copy of the parameters is current (set by train_hypers)
         self._host_stale = False    # ... and newer than the NumPy attributes
@@ -132,25 +143,57 @@ class DGPSSM:
         """nll terms + d nll / d variables (what tf.gradients(nll, vars), base_model.py:148, hands the optimisers)."""
         return self.engine.nll_and_grad(None if self._resident else self.parameters())
 
-    def sghmc_step(self):
-        """BaseModel.sghmc_step (base_model.py:915-933): 1 + 10 x (burn_in_op, sample_op) on `self.vars`, then the
-        current values join the window.  With U collapsed (case 4) `vars` is empty and the ops are no-ops."""
-        if self.vars:
-            raise NotImplementedError("SG-HMC variables (cases 2, 3, 5) are not wired to the engine yet; "
-                                      "ffvd_amd.optim.sghmc_step is the update operator")
-        self.window.append({})
-        if len(self.window) > self.window_size:
-            self.window = self.window[-self.window_size:]
+    def seed(self, seed):
+        """Seed the generator behind the SG-HMC noise draws and the window choice of train_hypers (the reference
+        draws both unseeded, base_model.py:169,948)."""
+        self._rng = np.random.default_rng(seed)
 
-    def train_hypers(self):
-        """BaseModel.train_hypers (base_model.py:944-950): one Adam step on nll w.r.t. every trainable variable
-        (X, Z, kernel hypers, log_Q, C, d, log_Rchols in case 4), forward + backward + update on the device.
-        Returns the nll terms before the update."""
+    def _noise(self):
+        shapes = {"Z": self.layers[-1].Z.shape, "logvariance": (self.output_dim,),
+                  "loglengthscales": (self.output_dim, self.engine.P), "log_Q": (self.output_dim,),
+                  "CC": self.likelihood.CC.shape, "DD": self.likelihood.DD.shape,
+                  "log_Rchols": self.likelihood.log_Rchols.shape}
+        return {k: self._rng.standard_normal(shapes[k]) for k in self.vars}
+
+    def _ensure_resident(self):
         if not self._resident:
             self.engine.set_params(self.parameters())
             self._resident = True
+
+    def sghmc_step(self):
+        """BaseModel.sghmc_step (base_model.py:915-933): burn_in_op, then 10 x (burn_in_op, sample_op) on
+        `self.vars` -- each one forward + backward + SG-HMC update on the device -- and the current values of the
+        variables join the window.  With an empty variable list (case 4) the ops are no-ops."""
+        if "U" in self.vars:
+            raise NotImplementedError("SG-HMC on U needs the gradient of the explicit-U branch (cases 2, 3); "
+                                      "ffvd_amd.optim.sghmc_step is the update operator")
+        if not self.vars:
+            self.window.append({})
+        else:
+            self._ensure_resident()
+            self.engine.sghmc_step(self._noise(), self.epsilon, self.mdecay, burn_in=True)            # :919
+            for _ in range(10):                                                                       # :920-925
+                self.engine.sghmc_step(self._noise(), self.epsilon, self.mdecay, burn_in=True)
+                self.engine.sghmc_step(self._noise(), self.epsilon, self.mdecay, burn_in=False)
+            self._host_stale = True
+            g = self.engine.get_params()
+            self.window.append({k: g[k].copy() for k in self.vars})                                   # :927-930
+        if len(self.window) > self.window_size:
+            self.window = self.window[-self.window_size:]                                             # :931-933
+
+    def train_hypers(self):
+        """BaseModel.train_hypers (base_model.py:944-950): one Adam step on nll w.r.t. every variable that SG-HMC
+        does not sample, with the sampled ones fed from a random window entry for this step only (:948-949);
+        forward + backward + update on the device.  Returns the nll terms before the update."""
+        self._ensure_resident()
         _, lr = self.get_minibatch()
-        t = self.engine.adam_step(lr)
+        fed = self.window[int(self._rng.integers(len(self.window)))] if (self.vars and self.window) else {}
+        if fed:
+            cur = self.engine.get_params()
+            self.engine.update_params(fed)
+        t = self.engine.adam_step(lr, train=self._adam_train)
+        if fed:
+            self.engine.update_params({k: cur[k] for k in fed})        # feed_dict does not assign: restore the chain state
         self._host_stale = True
         return t
 

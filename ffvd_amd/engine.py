@@ -191,6 +191,36 @@ class ElboEngine:
         idx = {n: i for i, n in enumerate(_lib.TERM_NAMES)}
         return {n: float(out[idx[n]] / self.S) for n in _lib.TERM_NAMES}
 
+    def sghmc_step(self, noise, epsilon=0.01, mdecay=0.05, burn_in=True):
+        """One burn_in_op / sample_op (base_model.py:143-179) on the device for the arrays that are keys of `noise`
+        (name -> standard-normal array of the parameter's shape).  Returns the nll terms before the update."""
+        if not self.grad:
+            raise ValueError("engine was created without grad=True")
+        shapes = {"Z": (self.M, self.P), "logvariance": (self.D,), "loglengthscales": (self.D, self.P),
+                  "log_Q": (self.D,), "CC": (self.D, self.Ydim), "DD": (self.Ydim,), "log_Rchols": (self.Ydim, self.Ydim)}
+        arrs, mask = {}, 0
+        for k, v in noise.items():
+            if k not in shapes:
+                raise ValueError(f"sghmc_step: '{k}' cannot be an SG-HMC variable")
+            arrs[k] = _lib.as_f64(v, shapes[k], f"noise[{k}]")
+            mask |= _lib.TRAIN_BITS[k]
+        ps = _lib.FfvdParams(**{k: v.ctypes.data for k, v in arrs.items()})
+        out = np.zeros(8)
+        nll = ct.c_double()
+        _lib.check(self.lib.ffvd_sghmc_step(self._h, float(epsilon), float(mdecay), int(mask), int(bool(burn_in)),
+                                            ct.byref(ps), _lib.dptr(out), ct.byref(nll)), self._h, "ffvd_sghmc_step")
+        idx = {n: i for i, n in enumerate(_lib.TERM_NAMES)}
+        return {n: float(out[idx[n]] / self.S) for n in _lib.TERM_NAMES}
+
+    def update_params(self, arrays):
+        """Overwrite some resident parameter arrays (dict name -> array); the others keep their device values."""
+        shapes = {"X": (self.S, self.T + 1, self.D), "Z": (self.M, self.P), "U": (self.M, self.D),
+                  "logvariance": (self.D,), "loglengthscales": (self.D, self.P), "log_Q": (self.D,),
+                  "CC": (self.D, self.Ydim), "DD": (self.Ydim,), "log_Rchols": (self.Ydim, self.Ydim)}
+        arrs = {k: _lib.as_f64(v, shapes[k], k) for k, v in arrays.items()}
+        ps = _lib.FfvdParams(**{k: v.ctypes.data for k, v in arrs.items()})
+        _lib.check(self.lib.ffvd_update_params(self._h, ct.byref(ps)), self._h, "ffvd_update_params")
+
     def reset_optimizer(self):
         _lib.check(self.lib.ffvd_optimizer_reset(self._h), self._h, "ffvd_optimizer_reset")
 

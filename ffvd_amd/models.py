@@ -60,7 +60,11 @@ class Model:
                                 lengthscales=A.lengthscales, control_inputs=control, kernel_type=kernel_type,
                                 kernel_train_flag=kernel_train_flag, U_ini=A.UU_ini, X_0_ini=A.XX_0_ini,
                                 X_train_ini=A.x_initialization, X_PG=getattr(A, "X_PG", False),
-                                U_collapse=A.U_collapse, case_val=getattr(A, "case_val", 4), **kwargs)
+                                hyperparameter_sampling=getattr(A, "hyperparameter_sampling", False),
+                                kernel_optimization=getattr(A, "kernel_optimization", True),
+                                U_optimization=getattr(A, "U_optimization", False),
+                                Z_optimization=getattr(A, "Z_optimization", True),
+                                U_collapse=A.U_collapse, case_val=getattr(A, "case_val", 4), **kwargs)     # models.py:73-74
         self.nll_seq, self.rmse_seq, self.ll_seq, self.running_time_seq = [], [], [], []   # models.py:89-92
         self.nll_seq.append(self.model.nll())
         self.global_step = 0

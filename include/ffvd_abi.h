@@ -171,6 +171,16 @@ int  ffvd_adam_step(ffvd_handle *h, double lr, double beta1, double beta2, doubl
                     double out_terms[8], double *out_nll);
 int  ffvd_optimizer_reset(ffvd_handle *h);
 int  ffvd_get_params(ffvd_handle *h, const ffvd_params *out_host);
+/* overwrite some of the bound parameter arrays from host memory (NULL members are kept): what feeding a stored
+ * SG-HMC window sample through feed_dict does in train_hypers (base_model.py:948-949). */
+int  ffvd_update_params(ffvd_handle *h, const ffvd_params *p_host);
+/* One burn_in_op (burn_in != 0) or sample_op (0) of BaseModel.generate_update_step (base_model.py:143-179) on the
+ * device: forward + backward on the resident parameters, then the SG-HMC update of the arrays in sample_mask
+ * (FFVD_TRAIN_* bits; X is never sampled, dgp_model.py:213-244) with X_N = T + 1 (dgp_model.py:203).  The handle keeps
+ * xi, g, g2 (ones) and p (zeros) per array.  noise: host arrays of standard-normal draws (base_model.py:169) for
+ * the sampled arrays, other members ignored.  out_terms / out_nll: the nll before the update. */
+int  ffvd_sghmc_step(ffvd_handle *h, double epsilon, double mdecay, uint32_t sample_mask, int burn_in,
+                     const ffvd_params *noise_host, double out_terms[8], double *out_nll);
 /* after a synchronous ffvd_elbo: per-chain nll values (S_local doubles, host) */
 int  ffvd_chain_nll(ffvd_handle *h, double *out_nll_per_chain);
 /* timing helper for benchmarks: run `iters` back-to-back ffvd_elbo_async on the resident inputs,

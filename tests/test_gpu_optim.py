@@ -179,3 +179,64 @@ def test_collect_samples_formal_on_actuator(actuator):
     np.testing.assert_allclose(out["predict_y_var"], ref["predict_y_var"], rtol=1e-7)
     assert out["RMSE"] == pytest.approx(ref["RMSE"], rel=1e-7)
     assert m.model.RMSE_val == out["RMSE"] and m.model.fit_y.shape == (n_train,)
+
+
+def test_device_resident_sghmc_matches_oracle_loop():
+    """burn_in_op, burn_in_op, sample_op (base_model.py:143-179) on the kernel hyper-parameters, on the device, against
+    closed-form gradients + the SG-HMC restatement on the CPU with the same injected noise."""
+    params, Y, c, meta = synthetic.make_named("tiny")
+    keys = ("logvariance", "loglengthscales")
+    rng = np.random.default_rng(3)
+    ref = {k: np.array(params[k], dtype=np.float64) for k in keys}
+    st = {k: [np.ones_like(ref[k]), np.ones_like(ref[k]), np.ones_like(ref[k]), np.zeros_like(ref[k])] for k in keys}
+    with ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], meta["S"], route="gram", grad=True) as e:
+        e.set_data(Y, c)
+        e.set_params(params)
+        for burn in (True, True, False):
+            noise = {k: rng.standard_normal(ref[k].shape) for k in keys}
+            e.sghmc_step(noise, epsilon=0.01, mdecay=0.05, burn_in=burn)
+            g = _oracle_mean_grad(dict(params, **ref), Y, c)
+            for k in keys:
+                out = oo.sghmc_step(ref[k], g[k], *st[k], noise[k], 0.01, 0.05, meta["T"] + 1, burn)
+                ref[k], st[k] = out[0], list(out[1:])
+        got = e.get_params()
+        with pytest.raises(ValueError):
+            e.sghmc_step({"X": np.zeros((meta["S"], meta["T"] + 1, meta["D"]))})
+    for k in keys:
+        np.testing.assert_allclose(got[k], ref[k], rtol=1e-9, atol=1e-12, err_msg=k)
+    np.testing.assert_array_equal(got["Z"], params["Z"])
+
+
+def test_case5_training_loop(actuator):
+    """FFVD_Main.py case 5: collapsed U, SG-HMC on the kernel hyper-parameters, Adam on everything else
+    (models.py:142-182 -> sghmc_step 21 updates, then train_hypers with a window sample fed for that step only)."""
+    from ffvd_amd.models import RegressionModel
+    params, Y, c = actuator
+    m = RegressionModel("normal")
+    A = m.ARGS
+    A.CC, A.DD = params["CC"], params["DD"]
+    A.QQ_chol = np.exp(0.5 * params["log_Q"])
+    A.RR_chol = np.exp(params["log_Rchols"])
+    A.lengthscales, A.variance = np.exp(params["loglengthscales"]), np.exp(params["logvariance"])
+    A.UU_ini, A.XX_0_ini, A.x_initialization = params["U"], params["X"][0], params["X"][1:]
+    A.control_inputs, A.num_inducing, A.x_dims, A.ZZ = c, 100, [4], params["Z"]
+    A.kernel_optimization, A.U_optimization, A.Z_optimization, A.U_collapse, A.case_val = False, False, True, True, 5
+    m.fit(Y, kernel_type="SquaredExponential", iterations=0, route="gram", grad=True)
+    mod = m.model
+    assert mod.vars == ["logvariance", "loglengthscales"] and "Z" in mod._adam_train and "logvariance" not in mod._adam_train
+    mod.seed(123)
+    mod.sghmc_step()
+    assert len(mod.window) == 1 and set(mod.window[0]) == {"logvariance", "loglengthscales"}
+    chain = mod.engine.get_params()
+    assert not np.allclose(chain["logvariance"], params["logvariance"])          # the sampler moved them
+    np.testing.assert_array_equal(chain["Z"], params["Z"])                        # ... and nothing else
+    mod.sghmc_step()
+    chain = mod.engine.get_params()
+    t = mod.train_hypers()
+    after = mod.engine.get_params()
+    assert np.isfinite(t["nll"])
+    for k in mod.vars:                                                            # fed, not assigned (:948-949)
+        np.testing.assert_array_equal(after[k], chain[k])
+    assert not np.array_equal(after["Z"], chain["Z"])                             # Adam moved the rest
+    mod.pull_parameters()
+    assert mod.layers[-1].kernel[0].logvariance == pytest.approx(after["logvariance"][0])
