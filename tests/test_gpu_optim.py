@@ -143,7 +143,7 @@ def test_fit_runs_the_training_loop(actuator):
     assert len(m.model.window) == 5
 
 
-def test_collect_samples_formal_on_actuator(actuator):
+def test_collect_samples_formal_on_actuator(actuator, tmp_path):
     """Train a few steps, then predict: base_model.py:197-350 end to end (posterior U, rollouts, predictive y, RMSE),
     compared with the CPU restatement fed with the trained parameters and the same noise."""
     from ffvd_amd.models import RegressionModel
@@ -179,6 +179,17 @@ def test_collect_samples_formal_on_actuator(actuator):
     np.testing.assert_allclose(out["predict_y_var"], ref["predict_y_var"], rtol=1e-7)
     assert out["RMSE"] == pytest.approx(ref["RMSE"], rel=1e-7)
     assert m.model.RMSE_val == out["RMSE"] and m.model.fit_y.shape == (n_train,)
+    # results file with the reference's keys (base_model.py:512-517)
+    from ffvd_amd import data_io
+    name = data_io.save_results(str(tmp_path / "run"), m.model, Y[n_train:n_train + test_len], Y[:n_train], 1.7,
+                                U_val=out["U_val"])
+    z = np.load(name)
+    for k in ("y_train_vfe", "y_test_vfe", "v_test_vfe_var", "Y_test_data", "Y_train_data", "Y_train_std", "CC_val", "DD_val",
+              "log_R_cholesky", "log_QQ", "Z_val", "U_val", "X_val", "k_lengthscales", "k_log_variances", "case", "ll_seq",
+              "running_time_seq", "PG_num", "mc_posterior_samples"):
+        assert k in z.files, k
+    np.testing.assert_array_equal(z["y_test_vfe"], out["predict_y"])
+    assert z["X_val"].shape == (n_train, 4) and z["k_lengthscales"].shape == (4, 5)
 
 
 def test_device_resident_sghmc_matches_oracle_loop():
