@@ -192,7 +192,7 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
         HIP_TRY(dev_alloc(h, &g.Acopy, nbt * msq));      HIP_TRY(dev_alloc(h, &g.u, nbt * Mp));
         HIP_TRY(dev_alloc(h, &g.LAinv, nbt * msq));      HIP_TRY(dev_alloc(h, &g.Gamma, nbt * msq));
         HIP_TRY(dev_alloc(h, &g.gam_part, nbt * g.ngam)); HIP_TRY(dev_alloc(h, &g.uku, nbt));
-        HIP_TRY(dev_alloc(h, &g.KfT, nbt * Mp * Tp));    HIP_TRY(dev_alloc(h, &g.E, nbt * Tp * Mp));
+        HIP_TRY(dev_alloc(h, &g.E, nbt * Tp * Mp));
         HIP_TRY(dev_alloc(h, &g.rsum, nbt * Tp));        HIP_TRY(dev_alloc(h, &g.ez, nbt * Tp * P));
         HIP_TRY(dev_alloc(h, &g.kfu, nbt * Tp));
         HIP_TRY(dev_alloc(h, &g.cs_part, nbt * nblk * Mp)); HIP_TRY(dev_alloc(h, &g.etx_part, nbt * nblk * Mp * P));
@@ -421,7 +421,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
         pa.d_begin = c.d_begin; pa.hv = hv; pa.W = h->Kuu + msq; pa.w_stride = kstride;
         pa.U = p.U; pa.u_ld = c.D; pa.b0 = s0 * Dl; pa.nb = ns * Dl;
         pa.F = (c.branch == FFVD_BRANCH_B) ? h->F : nullptr;
-        pa.FT = c.grad ? h->gw.KfT : nullptr;
+        pa.FT = nullptr;      // (the backward product reads K_fu row-major: no transposed copy)
         pa.rowsq = h->rowsq;
         pa.fmean = (c.branch == FFVD_BRANCH_A) ? h->fmean : nullptr;
         pa.ng = h->ng;
@@ -627,7 +627,7 @@ static int enqueue_grad(ffvd_handle *h, int S_total) {
     launch_uku(s, g.u, Mp, h->Kcopy, msq, Mp, Dl, nb, g.uku);
     // E = (2 Kf Gamma + alpha delta u^T) o Kf
     AtbArgs ae{};
-    ae.mode = ATB_BWD_E; ae.A = g.KfT; ae.a_stride = (size_t)Mp * Tp; ae.lda = Tp; ae.nA = Tp;
+    ae.mode = ATB_BWD_E; ae.A = h->F; ae.a_stride = fstride; ae.lda = Mp; ae.nA = Tp; ae.a_rowmajor = 1;   // K_fu itself
     ae.B = g.Gamma; ae.b_stride = msq; ae.ldb = Mp; ae.nB = Mp; ae.rows = Mp;
     ae.C = g.E; ae.c_stride = fstride; ae.ldc = Mp; ae.nb = nb; ae.b0 = 0; ae.Dl = Dl; ae.d_begin = c.d_begin;
     ae.log_Q = p.log_Q; ae.u = g.u; ae.u_stride = Mp; ae.X = p.X; ae.T = c.T; ae.D = c.D;

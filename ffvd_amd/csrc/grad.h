@@ -9,6 +9,7 @@ enum { ATB_PLAIN = 0, ATB_GAMMA = 1, ATB_BWD_E = 2 };
 struct AtbArgs {
     int mode;
     const double *A; size_t a_stride; int lda, nA;     // A: rows x lda, first nA columns used (= output rows)
+    int a_rowmajor;                                     // BWD_E only: A is stored [output row][k] (nA x lda) instead
     const double *B; size_t b_stride; int ldb, nB;     // B: rows x ldb, first nB columns used (= output columns)
     int b_per_dim;                                      // 1: B is indexed by latent dim (bz % Dl) instead of unit
     int rows;                                           // rows summed over (multiple of 16)

@@ -45,7 +45,9 @@ __device__ __forceinline__ double block_sum(double v, double *scratch /*[blockDi
 constexpr int AT = 16;
 constexpr int A_LD = 128 + 16;
 
-template <int MODE>
+// AROW: the left operand is stored [i][k] (row-major over the OUTPUT rows, e.g. K_fu itself with i = t) instead of
+// [k][i]; its 128 x 16 chunk is transposed on the way into LDS, so no transposed copy of K_fu has to exist in HBM.
+template <int MODE, bool AROW>
 __global__ __launch_bounds__(512, 4) void atb_kernel(AtbArgs a) {
     __shared__ double As[2][AT][A_LD];
     __shared__ double Bs[2][AT][A_LD];
@@ -67,21 +69,36 @@ __global__ __launch_bounds__(512, 4) void atb_kernel(AtbArgs a) {
     const int rowl = tid >> 6;
 
     double2 ra[2], rb[2];
+    // AROW: thread -> output row ti*128 + (tid >> 2), k-values 4 (tid & 3) .. + 3 of the chunk (32 contiguous bytes)
+    const int arow = ti * 128 + (tid >> 2), aseg = 4 * (tid & 3);
+    const bool okAr = arow < a.nA;
+    const double *Arow = Ab + (size_t)(okAr ? arow : 0) * a.lda + aseg;
     auto gload = [&](int c) {
+        if (AROW) {
+            ra[0] = *reinterpret_cast<const double2 *>(Arow + (size_t)c * AT);
+            ra[1] = *reinterpret_cast<const double2 *>(Arow + (size_t)c * AT + 2);
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const size_t t = (size_t)c * AT + rowl + 8 * i;
-            ra[i] = *reinterpret_cast<const double2 *>(Ab + t * a.lda + colAc);
+            if (!AROW) ra[i] = *reinterpret_cast<const double2 *>(Ab + t * a.lda + colAc);
             rb[i] = *reinterpret_cast<const double2 *>(Bb + t * a.ldb + colBc);
         }
     };
     auto lstore = [&](int buf) {
+        if (AROW) {
+            const int il = tid >> 2;
+            As[buf][aseg + 0][il] = okAr ? ra[0].x : 0.0;
+            As[buf][aseg + 1][il] = okAr ? ra[0].y : 0.0;
+            As[buf][aseg + 2][il] = okAr ? ra[1].x : 0.0;
+            As[buf][aseg + 3][il] = okAr ? ra[1].y : 0.0;
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             double2 va = ra[i], vb = rb[i];
             va.x = okA ? va.x : 0.0; va.y = okA ? va.y : 0.0;
             vb.x = okB ? vb.x : 0.0; vb.y = okB ? vb.y : 0.0;
-            *reinterpret_cast<double2 *>(&As[buf][rowl + 8 * i][2 * lane]) = va;
+            if (!AROW) *reinterpret_cast<double2 *>(&As[buf][rowl + 8 * i][2 * lane]) = va;
             *reinterpret_cast<double2 *>(&Bs[buf][rowl + 8 * i][2 * lane]) = vb;
         }
     };
@@ -165,9 +182,10 @@ __global__ __launch_bounds__(512, 4) void atb_kernel(AtbArgs a) {
 void launch_atb(hipStream_t stream, const AtbArgs &a) {
     const int nti = (a.nA + 127) / 128, ntj = (a.nB + 127) / 128;
     dim3 grid(nti * ntj, a.nb);
-    if (a.mode == ATB_PLAIN) hipLaunchKernelGGL(atb_kernel<ATB_PLAIN>, grid, dim3(512), 0, stream, a);
-    else if (a.mode == ATB_GAMMA) hipLaunchKernelGGL(atb_kernel<ATB_GAMMA>, grid, dim3(512), 0, stream, a);
-    else hipLaunchKernelGGL(atb_kernel<ATB_BWD_E>, grid, dim3(512), 0, stream, a);
+    if (a.mode == ATB_PLAIN) hipLaunchKernelGGL((atb_kernel<ATB_PLAIN, false>), grid, dim3(512), 0, stream, a);
+    else if (a.mode == ATB_GAMMA) hipLaunchKernelGGL((atb_kernel<ATB_GAMMA, false>), grid, dim3(512), 0, stream, a);
+    else if (a.a_rowmajor) hipLaunchKernelGGL((atb_kernel<ATB_BWD_E, true>), grid, dim3(512), 0, stream, a);
+    else hipLaunchKernelGGL((atb_kernel<ATB_BWD_E, false>), grid, dim3(512), 0, stream, a);
 }
 int atb_ntiles(int nA, int nB) { return ((nA + 127) / 128) * ((nB + 127) / 128); }
 
@@ -332,14 +350,21 @@ __global__ __launch_bounds__(512) void e_reduce_kernel(EReduceArgs a) {
 #pragma unroll
             for (int p = 0; p < PM; ++p) etx[p] = 0.0;
             if (m < a.M) {
-                for (int r = 0; r < 64; ++r) {
-                    const int t = t0 + r;
-                    if (t >= a.T) break;
-                    const double e = E[(size_t)t * Mp + m];
-                    cs += e;
+                for (int r0 = 0; r0 < 64; r0 += 8) {        // eight independent loads in flight per thread
+                    double e8[8];
 #pragma unroll
-                    for (int p = 0; p < PM; ++p)
-                        if (p < P) etx[p] += e * xs[r][p];
+                    for (int k = 0; k < 8; ++k) {
+                        const int t = t0 + r0 + k;
+                        e8[k] = E[(size_t)(t < a.T ? t : t0) * Mp + m];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const double e = (t0 + r0 + k < a.T) ? e8[k] : 0.0;
+                        cs += e;
+#pragma unroll
+                        for (int p = 0; p < PM; ++p)
+                            if (p < P) etx[p] += e * xs[r0 + k][p];
+                    }
                 }
             }
             if (m < Mp) {
