@@ -356,3 +356,31 @@ def test_full_size_config2_properties():
         p["X"] = params["X"][s]
         ref = orc.nll_terms(p, Y, c, U_collapse=True)
         assert per[s] == pytest.approx(ref["nll"], rel=1e-8)
+
+
+@pytest.mark.parametrize("branch", ["B", "A"])
+def test_no_control_inputs(branch):
+    """C = 0: the reference concatenates control inputs only when they exist (dgp_model.py:268-271, base_model.py:243-246);
+    P = D, X_combine = X[:-1].  Compared with the oracle on the same seeded inputs (no golden file for this shape)."""
+    params, Y, c, meta = synthetic.make_named("tiny", C=0)
+    assert c.shape == (meta["T"], 0) and params["Z"].shape[1] == meta["D"]
+    collapse = branch == "B"
+    ref = orc.nll_terms_chains(params, Y, c, U_collapse=collapse, kernel_type=meta["kernel_type"])
+    got = run_engine(params, Y, c, meta, collapse=collapse)
+    assert_terms(got, ref, TERMS_B if collapse else TERMS_A)
+    if collapse:
+        g = run_engine(params, Y, c, meta, collapse=True, route="gram")
+        assert g["nll"] == pytest.approx(ref["nll"], rel=1e-8)
+        from oracle import ffvd_grad_oracle as gorc
+        with ElboEngine(meta["T"], meta["D"], 0, meta["M"], meta["S"], route="gram", grad=True) as e:
+            e.set_data(Y, c)
+            _, grads = e.nll_and_grad(params)
+        S = meta["S"]
+        want = np.zeros_like(grads["Z"])
+        for s in range(S):
+            p = dict(params)
+            p["X"] = params["X"][s]
+            want += gorc.nll_grad(p, Y, c)["Z"] / S
+        # cond(K_uu) is 1e6 for these 2-D inducing inputs: the closed form and torch autograd themselves differ by
+        # 1.1e-5 (relative to max|dZ|) on this shape, the GPU sits 2.4e-5 from autograd (tools/c0_check.py)
+        np.testing.assert_allclose(grads["Z"], want, rtol=0, atol=1e-4 * np.max(np.abs(want)))
