@@ -52,7 +52,7 @@ struct ffvd_handle {
     // backward-pass workspace (cfg.grad)
     struct GradWs {
         double *Acopy = nullptr, *u = nullptr, *LAinv = nullptr, *Gamma = nullptr, *gam_part = nullptr, *uku = nullptr;
-        double *KfT = nullptr, *E = nullptr, *rsum = nullptr, *ez = nullptr, *kfu = nullptr;
+        double *KfT = nullptr, *E = nullptr, *rp = nullptr, *rsum = nullptr, *ez = nullptr, *kfu = nullptr;
         double *cs_part = nullptr, *etx_part = nullptr, *rx2_part = nullptr, *dz_unit = nullptr, *dll_unit = nullptr, *dls_unit = nullptr;
         double *Asum = nullptr, *GamSum = nullptr, *Gs = nullptr, *gsum = nullptr, *P1 = nullptr, *KGK = nullptr, *Epsi = nullptr;
         double *rsum2 = nullptr, *ez2 = nullptr, *cs2 = nullptr, *etx2 = nullptr, *rx22 = nullptr, *dz_kuu = nullptr, *dll_kuu = nullptr, *dls_kuu = nullptr;
@@ -192,7 +192,8 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
         HIP_TRY(dev_alloc(h, &g.Acopy, nbt * msq));      HIP_TRY(dev_alloc(h, &g.u, nbt * Mp));
         HIP_TRY(dev_alloc(h, &g.LAinv, nbt * msq));      HIP_TRY(dev_alloc(h, &g.Gamma, nbt * msq));
         HIP_TRY(dev_alloc(h, &g.gam_part, nbt * g.ngam)); HIP_TRY(dev_alloc(h, &g.uku, nbt));
-        HIP_TRY(dev_alloc(h, &g.E, nbt * Tp * Mp));
+        if (P <= 7) HIP_TRY(dev_alloc(h, &g.rp, bwd_fused_rp_doubles((int)Mp, (int)Tp, (int)nbt)));   // fused E reductions
+        else HIP_TRY(dev_alloc(h, &g.E, nbt * Tp * Mp));
         HIP_TRY(dev_alloc(h, &g.rsum, nbt * Tp));        HIP_TRY(dev_alloc(h, &g.ez, nbt * Tp * P));
         HIP_TRY(dev_alloc(h, &g.kfu, nbt * Tp));
         HIP_TRY(dev_alloc(h, &g.cs_part, nbt * nblk * Mp)); HIP_TRY(dev_alloc(h, &g.etx_part, nbt * nblk * Mp * P));
@@ -625,21 +626,32 @@ static int enqueue_grad(ffvd_handle *h, int S_total) {
     ag.part = g.gam_part;
     launch_atb(s, ag);
     launch_uku(s, g.u, Mp, h->Kcopy, msq, Mp, Dl, nb, g.uku);
-    // E = (2 Kf Gamma + alpha delta u^T) o Kf
-    AtbArgs ae{};
-    ae.mode = ATB_BWD_E; ae.A = h->F; ae.a_stride = fstride; ae.lda = Mp; ae.nA = Tp; ae.a_rowmajor = 1;   // K_fu itself
-    ae.B = g.Gamma; ae.b_stride = msq; ae.ldb = Mp; ae.nB = Mp; ae.rows = Mp;
-    ae.C = g.E; ae.c_stride = fstride; ae.ldc = Mp; ae.nb = nb; ae.b0 = 0; ae.Dl = Dl; ae.d_begin = c.d_begin;
-    ae.log_Q = p.log_Q; ae.u = g.u; ae.u_stride = Mp; ae.X = p.X; ae.T = c.T; ae.D = c.D;
-    ae.Kf = h->F; ae.kf_stride = fstride; ae.ldkf = Mp;
-    launch_atb(s, ae);
     EReduceArgs er{};
     er.E = g.E; er.e_stride = fstride; er.Kf = h->F; er.u = g.u; er.u_stride = Mp; er.x_is_z = 0;
     er.x = p.X; er.x_chain_stride = (size_t)(c.T + 1) * c.D; er.x_ld = c.D; er.x_cols = c.D; er.ctrl = h->ctrl; er.C = c.C;
     er.Z = p.Z; er.len = h->len; er.T = c.T; er.Tp = Tp; er.M = c.M; er.Mp = Mp; er.P = P; er.Dl = Dl; er.b0 = 0; er.nb = nb;
     er.nblk = Tp / 64; er.rsum = g.rsum; er.ez = g.ez; er.kfu = g.kfu; er.cs_part = g.cs_part; er.etx_part = g.etx_part;
     er.rx2_part = g.rx2_part;
-    launch_e_reduce(s, er);
+    if (g.rp) {
+        // E = (2 Kf Gamma + alpha delta u^T) o Kf formed and reduced tile by tile: it never reaches HBM
+        BwdFusedArgs bf{};
+        bf.Kf = h->F; bf.kf_stride = fstride; bf.Gamma = g.Gamma; bf.g_stride = msq; bf.u = g.u; bf.u_stride = Mp;
+        bf.X = p.X; bf.ctrl = h->ctrl; bf.Z = p.Z; bf.log_Q = p.log_Q; bf.T = c.T; bf.Tp = Tp; bf.D = c.D; bf.C = c.C;
+        bf.M = c.M; bf.Mp = Mp; bf.P = P; bf.Dl = Dl; bf.d_begin = c.d_begin; bf.b0 = 0; bf.nb = nb; bf.rp = g.rp;
+        bf.cs_part = g.cs_part; bf.etx_part = g.etx_part; bf.rsum = g.rsum; bf.ez = g.ez; bf.kfu = g.kfu;
+        bf.rx2_part = g.rx2_part;
+        launch_bwd_fused(s, bf);
+    } else {
+        // P > 7: materialise E and reduce it in a second kernel
+        AtbArgs ae{};
+        ae.mode = ATB_BWD_E; ae.A = h->F; ae.a_stride = fstride; ae.lda = Mp; ae.nA = Tp; ae.a_rowmajor = 1;   // K_fu itself
+        ae.B = g.Gamma; ae.b_stride = msq; ae.ldb = Mp; ae.nB = Mp; ae.rows = Mp;
+        ae.C = g.E; ae.c_stride = fstride; ae.ldc = Mp; ae.nb = nb; ae.b0 = 0; ae.Dl = Dl; ae.d_begin = c.d_begin;
+        ae.log_Q = p.log_Q; ae.u = g.u; ae.u_stride = Mp; ae.X = p.X; ae.T = c.T; ae.D = c.D;
+        ae.Kf = h->F; ae.kf_stride = fstride; ae.ldkf = Mp;
+        launch_atb(s, ae);
+        launch_e_reduce(s, er);
+    }
     launch_e_finish(s, er, g.dz_unit, g.dll_unit, g.dls_unit);
     // K_uu side: Psi_d = sum_s Gamma_s / alpha_d - 1/2 K^-1 (sum_s A_s - S K) K^-1
     launch_chain_sum(s, g.Acopy, msq, S, Dl, msq, g.Asum, msq);

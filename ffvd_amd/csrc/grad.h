@@ -51,6 +51,23 @@ struct EReduceArgs {
 void launch_e_reduce(hipStream_t stream, const EReduceArgs &a);
 void launch_e_finish(hipStream_t stream, const EReduceArgs &a, double *dz_unit, double *dll_unit, double *dls_unit);
 
+// Backward product with the E reductions fused into its epilogue (P <= 7): E = (2 K_fu Gamma + delta (alpha u)^T) o K_fu
+// is formed tile by tile in the accumulators and never reaches HBM; every reduction of it runs on the matrix cores.
+struct BwdFusedArgs {
+    const double *Kf; size_t kf_stride;         // [nb] Tp x Mp, row-major (K_fu)
+    const double *Gamma; size_t g_stride;       // [nb] Mp x Mp
+    const double *u; size_t u_stride;           // [nb] Mp
+    const double *X; const double *ctrl;        // chains S x (T+1) x D; control inputs T x C
+    const double *Z;                            // M x P
+    const double *log_Q;
+    int T, Tp, D, C, M, Mp, P, Dl, d_begin, b0, nb;
+    double *rp;                                 // [ntj][nb][Tp][8] row partials per column tile: 0 rsum, 1..P ez, 7 kfu
+    double *cs_part, *etx_part;                 // [nb][Tp/64][Mp] and [..][P]: column partials per 64-row block
+    double *rsum, *ez, *kfu, *rx2_part;         // outputs of the row combine: [nb][Tp], [nb][Tp][P], [nb][Tp], [nb][Tp/64][P]
+};
+void launch_bwd_fused(hipStream_t stream, const BwdFusedArgs &a);
+size_t bwd_fused_rp_doubles(int Mp, int Tp, int nb);
+
 struct DxArgs {
     const double *X, *Y, *CC, *DD, *log_Rchols, *log_Q, *len;
     const double *rsum, *ez, *kfu;

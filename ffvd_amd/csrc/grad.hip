@@ -42,6 +42,13 @@ __device__ __forceinline__ double block_sum(double v, double *scratch /*[blockDi
 //   ATB_GAMMA : (A = B = L_A^-1)  C = 1/2 alpha (Kinv - acc - u_i u_j);  partial sums of sum_ij acc * K_ij
 //   ATB_BWD_E : (A = Kf^T, B = Gamma)  C[t][m] = (2 acc + alpha delta_t u_m) * Kf[t][m]
 // ---------------------------------------------------------------------------------------------
+// LDS hand-off between the lanes of ONE wavefront
+__device__ __forceinline__ void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 constexpr int AT = 16;
 constexpr int A_LD = 128 + 16;
 
@@ -188,6 +195,251 @@ void launch_atb(hipStream_t stream, const AtbArgs &a) {
     else hipLaunchKernelGGL((atb_kernel<ATB_BWD_E, false>), grid, dim3(512), 0, stream, a);
 }
 int atb_ntiles(int nA, int nB) { return ((nA + 127) / 128) * ((nB + 127) / 128); }
+
+// ---------------------------------------------------------------------------------------------
+// Fused backward product (see grad.h BwdFusedArgs).  Main loop = atb_kernel<ATB_BWD_E, AROW>: the 128 x 128 tile
+// g = (K_fu Gamma)[t][m] in 8 wavefronts of 64 x 32.  Epilogue, all in registers / LDS:
+//   e = (2 g + alpha delta_t u_m) K_fu[t][m]                         (overwrites the accumulators)
+//   columns: [cs; etx] = [1; x^T] e      -- the accumulator layout of e IS the MFMA B-operand layout (k = rows), so
+//            the column sums and e^T x are 32 more MFMAs per wavefront against a [1, x] fragment from LDS;
+//   rows:    [rsum, ez] = e [1, z]       -- needs e as an A operand: each wavefront transposes its 16 x 32 strips
+//            through a private LDS patch (no workgroup barrier), again 32 MFMAs; the four column-quarter
+//            wavefronts are then added in LDS;  kfu = K_fu u by a 16-lane shuffle reduction.
+// Row partials go out per column tile (rp), column partials per 64-row block; row_combine_kernel adds the former.
+// ---------------------------------------------------------------------------------------------
+constexpr int XW_LD = 128 + 4;
+__global__ __launch_bounds__(512, 4) void bwd_fused_kernel(BwdFusedArgs a) {
+    __shared__ double As[2][AT][A_LD];
+    __shared__ double Bs[2][AT][A_LD];
+    const int bz = blockIdx.y;
+    const int ntj = (a.Mp + 127) / 128;
+    const int ti = blockIdx.x / ntj, tj = blockIdx.x % ntj;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int lr = lane & 15, lk = lane >> 4;
+    const int I0 = ti * 128 + wr * 64, J0 = tj * 128 + wc * 32;
+    const int Mp = a.Mp, Tp = a.Tp, P = a.P;
+    const double *Kfb = a.Kf + (size_t)bz * a.kf_stride;
+    const double *Gb = a.Gamma + (size_t)bz * a.g_stride;
+    const int colB = tj * 128 + 2 * lane;
+    const bool okB = colB < Mp;
+    const int colBc = okB ? colB : 0;
+    const int rowl = tid >> 6;
+    const int arow = ti * 128 + (tid >> 2), aseg = 4 * (tid & 3);       // arow < Tp always (Tp multiple of 128? no: of 64)
+    const bool okAr = arow < Tp;
+    const double *Arow = Kfb + (size_t)(okAr ? arow : 0) * Mp + aseg;
+
+    double2 ra[2], rb[2];
+    auto gload = [&](int c) {
+        ra[0] = *reinterpret_cast<const double2 *>(Arow + (size_t)c * AT);
+        ra[1] = *reinterpret_cast<const double2 *>(Arow + (size_t)c * AT + 2);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const size_t k = (size_t)c * AT + rowl + 8 * i;
+            rb[i] = *reinterpret_cast<const double2 *>(Gb + k * Mp + colBc);
+        }
+    };
+    auto lstore = [&](int buf) {
+        const int il = tid >> 2;
+        As[buf][aseg + 0][il] = okAr ? ra[0].x : 0.0;
+        As[buf][aseg + 1][il] = okAr ? ra[0].y : 0.0;
+        As[buf][aseg + 2][il] = okAr ? ra[1].x : 0.0;
+        As[buf][aseg + 3][il] = okAr ? ra[1].y : 0.0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            double2 vb = rb[i];
+            vb.x = okB ? vb.x : 0.0; vb.y = okB ? vb.y : 0.0;
+            *reinterpret_cast<double2 *>(&Bs[buf][rowl + 8 * i][2 * lane]) = vb;
+        }
+    };
+    d4 acc[4][2];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
+    const int nchunk = Mp / AT;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunk) gload(c + 1);
+#pragma unroll
+        for (int ks = 0; ks < AT / 4; ++ks) {
+            double af[4], bf[2];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) af[x] = As[buf][4 * ks + lk][wr * 64 + 16 * x + lr];
+#pragma unroll
+            for (int y = 0; y < 2; ++y) bf[y] = Bs[buf][4 * ks + lk][wc * 32 + 16 * y + lr];
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y) acc[x][y] = mfma_f64(af[x], bf[y], acc[x][y]);
+        }
+        if (c + 1 < nchunk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---------------- epilogue ----------------
+    const int b = a.b0 + bz, s = b / a.Dl, dl = b % a.Dl, dg = a.d_begin + dl;
+    const double alpha = 1.0 / exp(a.log_Q[dg]);
+    const double *ub = a.u + (size_t)bz * a.u_stride;
+    const double *Xs = a.X + (size_t)s * (a.T + 1) * a.D;
+    double *sm = &As[0][0][0];                 // 4608 doubles: XW [8][XW_LD] | Vs [8][XW_LD] | kfu_s [4][128]
+    double *sb = &Bs[0][0][0];                 // 4608 doubles: per-wavefront transpose patches, then the row partials
+    double *XW = sm, *Vs = sm + 8 * XW_LD, *kfu_s = sm + 16 * XW_LD;
+    for (int idx = tid; idx < 8 * 128; idx += 512) {
+        const int p = idx >> 7, r = idx & 127;
+        const int t = ti * 128 + r, j = tj * 128 + r;
+        double xv = 0.0, zv = 0.0;
+        if (p == 0) { xv = 1.0; zv = 1.0; }
+        else if (p <= P) {
+            const int pp = p - 1;
+            if (t < a.T) xv = (pp < a.D) ? Xs[(size_t)t * a.D + pp] : a.ctrl[(size_t)t * a.C + (pp - a.D)];
+            if (j < a.M) zv = a.Z[(size_t)j * P + pp];
+        }
+        XW[p * XW_LD + r] = xv;
+        Vs[p * XW_LD + r] = zv;
+    }
+    // e in place of g; kfu partial over this wavefront's 32 columns
+    {
+        double kfs[4][4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = I0 + 16 * x + lk + 4 * q;
+                const bool iok = i < Tp;
+                const double rowv = (i < a.T) ? alpha * (Xs[(size_t)(i + 1) * a.D + dg] - Xs[(size_t)i * a.D + dg]) : 0.0;
+                double ks_ = 0.0;
+#pragma unroll
+                for (int y = 0; y < 2; ++y) {
+                    const int j = J0 + 16 * y + lr;
+                    const bool ok = iok && j < Mp;
+                    const double kf = ok ? Kfb[(size_t)i * Mp + j] : 0.0;
+                    const double uj = (j < Mp) ? ub[j] : 0.0;
+                    acc[x][y][q] = (2.0 * acc[x][y][q] + rowv * uj) * kf;
+                    ks_ += kf * uj;
+                }
+                kfs[x][q] = ks_;
+            }
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                double v = kfs[x][q];
+                v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+                if (lr == 0) kfu_s[wc * 128 + wr * 64 + 16 * x + lk + 4 * q] = v;
+            }
+    }
+    __syncthreads();
+    // columns: [cs; etx] for the 64-row block (ti, wr), this wavefront's 32 columns
+    {
+        const int nblk = Tp / 64, blk = ti * 2 + wr;
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            d4 ac = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const double af = (lr < 8) ? XW[lr * XW_LD + wr * 64 + 16 * x + 4 * ks + lk] : 0.0;
+                    ac = mfma_f64(af, acc[x][y][ks], ac);
+                }
+            const int j = J0 + 16 * y + lr;
+            if (j < Mp && blk < nblk) {
+                const size_t pb = ((size_t)bz * nblk + blk) * Mp + j;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int p = lk + 4 * q;
+                    if (p == 0) a.cs_part[pb] = ac[q];
+                    else if (p <= P) a.etx_part[pb * P + (p - 1)] = ac[q];
+                }
+            }
+        }
+    }
+    // rows: [rsum, ez] over this wavefront's 32 columns, strip by strip through a private LDS patch
+    d4 ar[4];
+    {
+        double *Tw = sb + wave * (16 * 33);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Tw[(lk + 4 * q) * 33 + 16 * y + lr] = acc[x][y][q];
+            wave_sync_lds();
+            d4 r4 = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const double af = Tw[lr * 33 + 16 * y + 4 * ks + lk];
+                    const double bf = (lr < 8) ? Vs[lr * XW_LD + wc * 32 + 16 * y + 4 * ks + lk] : 0.0;
+                    r4 = mfma_f64(af, bf, r4);
+                }
+            ar[x] = r4;
+            wave_sync_lds();
+        }
+    }
+    __syncthreads();
+    if (lr < 8) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sb[((size_t)wc * 128 + wr * 64 + 16 * x + lk + 4 * q) * 8 + lr] = ar[x][q];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 128 * 8; idx += 512) {
+        const int row = idx >> 3, c = idx & 7;
+        const int t = ti * 128 + row;
+        if (t >= Tp) continue;
+        double v = 0.0;
+        if (c == 7) { for (int w = 0; w < 4; ++w) v += kfu_s[w * 128 + row]; }
+        else { for (int w = 0; w < 4; ++w) v += sb[((size_t)w * 128 + row) * 8 + c]; }
+        a.rp[(((size_t)tj * a.nb + bz) * Tp + t) * 8 + c] = v;
+    }
+}
+
+// Adds the row partials of the column tiles and forms the per-block sums rx2[p] = sum_t r_t x_tp^2.
+__global__ __launch_bounds__(256) void row_combine_kernel(BwdFusedArgs a) {
+    __shared__ double scratch[256];
+    __shared__ double rs[64];
+    const int blk = blockIdx.x, bz = blockIdx.y, tid = threadIdx.x;
+    const int ntj = (a.Mp + 127) / 128, P = a.P, Tp = a.Tp;
+    const int b = a.b0 + bz, s = b / a.Dl;
+    for (int idx = tid; idx < 64 * 8; idx += 256) {
+        const int r = idx >> 3, c = idx & 7, t = blk * 64 + r;
+        double v = 0.0;
+        for (int j = 0; j < ntj; ++j) v += a.rp[(((size_t)j * a.nb + bz) * Tp + t) * 8 + c];
+        if (c == 0) { a.rsum[(size_t)bz * Tp + t] = v; rs[r] = v; }
+        else if (c <= P) a.ez[((size_t)bz * Tp + t) * P + (c - 1)] = v;
+        else if (c == 7) a.kfu[(size_t)bz * Tp + t] = v;
+    }
+    __syncthreads();
+    const double *Xs = a.X + (size_t)s * (a.T + 1) * a.D;
+    const int nblk = Tp / 64;
+    for (int p = 0; p < P; ++p) {
+        double v = 0.0;
+        if (tid < 64) {
+            const int t = blk * 64 + tid;
+            if (t < a.T) {
+                const double xv = (p < a.D) ? Xs[(size_t)t * a.D + p] : a.ctrl[(size_t)t * a.C + (p - a.D)];
+                v = rs[tid] * xv * xv;
+            }
+        }
+        v = block_sum(v, scratch);
+        if (tid == 0) a.rx2_part[((size_t)bz * nblk + blk) * P + p] = v;
+    }
+}
+
+size_t bwd_fused_rp_doubles(int Mp, int Tp, int nb) { return (size_t)((Mp + 127) / 128) * nb * Tp * 8; }
+void launch_bwd_fused(hipStream_t stream, const BwdFusedArgs &a) {
+    const int nti = (a.Tp + 127) / 128, ntj = (a.Mp + 127) / 128;
+    hipLaunchKernelGGL(bwd_fused_kernel, dim3(nti * ntj, a.nb), dim3(512), 0, stream, a);
+    hipLaunchKernelGGL(row_combine_kernel, dim3(a.Tp / 64, a.nb), dim3(256), 0, stream, a);
+}
 
 // ---------------------------------------------------------------------------------------------
 // small dense helpers
