@@ -192,7 +192,7 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
         HIP_TRY(dev_alloc(h, &g.Acopy, nbt * msq));      HIP_TRY(dev_alloc(h, &g.u, nbt * Mp));
         HIP_TRY(dev_alloc(h, &g.LAinv, nbt * msq));      HIP_TRY(dev_alloc(h, &g.Gamma, nbt * msq));
         HIP_TRY(dev_alloc(h, &g.gam_part, nbt * g.ngam)); HIP_TRY(dev_alloc(h, &g.uku, nbt));
-        if (P <= 7) HIP_TRY(dev_alloc(h, &g.rp, bwd_fused_rp_doubles((int)Mp, (int)Tp, (int)nbt)));   // fused E reductions
+        if (P <= 6) HIP_TRY(dev_alloc(h, &g.rp, bwd_fused_rp_doubles((int)Mp, (int)Tp, (int)nbt)));   // fused E reductions
         else HIP_TRY(dev_alloc(h, &g.E, nbt * Tp * Mp));
         HIP_TRY(dev_alloc(h, &g.rsum, nbt * Tp));        HIP_TRY(dev_alloc(h, &g.ez, nbt * Tp * P));
         HIP_TRY(dev_alloc(h, &g.kfu, nbt * Tp));
@@ -642,7 +642,7 @@ static int enqueue_grad(ffvd_handle *h, int S_total) {
         bf.rx2_part = g.rx2_part;
         launch_bwd_fused(s, bf);
     } else {
-        // P > 7: materialise E and reduce it in a second kernel
+        // P > 6: materialise E and reduce it in a second kernel
         AtbArgs ae{};
         ae.mode = ATB_BWD_E; ae.A = h->F; ae.a_stride = fstride; ae.lda = Mp; ae.nA = Tp; ae.a_rowmajor = 1;   // K_fu itself
         ae.B = g.Gamma; ae.b_stride = msq; ae.ldb = Mp; ae.nB = Mp; ae.rows = Mp;

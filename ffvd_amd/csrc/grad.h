@@ -51,7 +51,7 @@ struct EReduceArgs {
 void launch_e_reduce(hipStream_t stream, const EReduceArgs &a);
 void launch_e_finish(hipStream_t stream, const EReduceArgs &a, double *dz_unit, double *dll_unit, double *dls_unit);
 
-// Backward product with the E reductions fused into its epilogue (P <= 7): E = (2 K_fu Gamma + delta (alpha u)^T) o K_fu
+// Backward product with the E reductions fused into its epilogue (P <= 6: slots 0 rsum, 1..P ez, 7 kfu): E = (2 K_fu Gamma + delta (alpha u)^T) o K_fu
 // is formed tile by tile in the accumulators and never reaches HBM; every reduction of it runs on the matrix cores.
 struct BwdFusedArgs {
     const double *Kf; size_t kf_stride;         // [nb] Tp x Mp, row-major (K_fu)
