@@ -388,7 +388,10 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
     // (measured on config 2: 4.41 ms overlapped vs 4.51 ms serial with 128 units per pass; with 16 units the K_fu
     //  build is shorter than the chain and sharing CUs only slows both: 1.42 vs 1.37 ms -> serial there)
     const int first_units = ((c.S_local < h->cpp) ? c.S_local : h->cpp) * Dl;
-    if (gram_route && (size_t)first_units * Tp * Mp >= (size_t)64 * 4096 * 512) {
+    // split-K first pass: its tile kernel writes raw partials and needs neither K_uu nor K^-1, so the chain may run
+    // beside the K_fu build AND the tile pass and only has to be back for the combine pass
+    const bool late_join = gram_route && h->gpart && first_units == h->cpp * Dl && !getenv("FFVD_NO_LATE_JOIN");
+    if (gram_route && (late_join || (size_t)first_units * Tp * Mp >= (size_t)64 * 4096 * 512)) {
         sk = h->aux;
         HIP_TRY(hipEventRecord(h->ev_fork, s));
         HIP_TRY(hipStreamWaitEvent(sk, h->ev_fork, 0));
@@ -428,7 +431,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
         pa.ng = h->ng;
         if (gram_route) {
             launch_kfu_build(s, pa);
-            if (s0 == 0 && sk != s) HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));
+            if (s0 == 0 && sk != s && !late_join) HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));
         } else launch_project(s, pa);
         if (st) st->mark(1);
         if (c.branch == FFVD_BRANCH_B) {
@@ -444,7 +447,11 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
             }
             ga.Kadd = h->Kcopy; ga.kadd_stride = msq; ga.Kinv = h->Kinv; ga.kinv_stride = msq; ga.trpart = h->trpart;
             if (h->gpart && ns == h->cpp) { ga.ksplit = h->gsplit; ga.part = h->gpart; }
-            launch_gram(s, ga);
+            if (s0 == 0 && late_join) {
+                launch_gram(s, ga, 1);
+                HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));
+                launch_gram(s, ga, 2);
+            } else launch_gram(s, ga);
             if (st) st->mark(2);
             if (c.grad) {       // keep A = K_uu + K_uf K_fu / Q: the factorisation overwrites it in place
                 HIP_TRY(hipMemcpy2DAsync(h->gw.Acopy, msq * sizeof(double), h->H, ga.h_stride * sizeof(double),

@@ -105,7 +105,7 @@ int gram_ntiles(int Mp);
 // how many row ranges launch_gram should use for `nb` units (1 = no split), and the doubles `part` then needs
 int gram_ksplit(int Mp, int nb, int rows);
 size_t gram_part_doubles(int Mp, int nb, int ksplit);
-void launch_gram(hipStream_t stream, GramArgs a);
+void launch_gram(hipStream_t stream, GramArgs a, int phase = 0);
 
 // hterms[b] = { logdet(H) = 2 sum log diag(L_H),  b^T H^{-1} b = |row Mp|^2 } after launch_potrf_ext on H.
 void launch_h_finish(hipStream_t stream, const double *H, int Mp, size_t h_stride, int nb, double *hterms /*[nb][2]*/,

@@ -1119,16 +1119,20 @@ size_t gram_part_doubles(int Mp, int nb, int ksplit) {
     return ksplit > 1 ? (size_t)ksplit * nb * (size_t)(Mp + 1) * Mp : 0;
 }
 
-void launch_gram(hipStream_t stream, GramArgs a) {
+// phase: 0 = everything, 1 = the tile pass only, 2 = the combine pass only (split-K launches: the tile pass writes
+// raw partials and needs neither K_uu nor K^-1, so the caller may run it before those exist and combine afterwards)
+void launch_gram(hipStream_t stream, GramArgs a, int phase) {
     a.ntiles = gram_ntiles(a.Mp);
     if (a.brow <= 0) a.brow = a.Mp;
     if (!a.part || a.ksplit < 1) a.ksplit = 1;
     const int groups = (a.nb + 7) / 8;
     const dim3 grid(groups * 8 * a.ntiles * a.ksplit);
-    if (a.mode == GRAM_F) hipLaunchKernelGGL(gram_kernel<GRAM_F>, grid, dim3(512), 0, stream, a);
-    else if (a.mode == GRAM_KFU) hipLaunchKernelGGL(gram_kernel<GRAM_KFU>, grid, dim3(512), 0, stream, a);
-    else hipLaunchKernelGGL(gram_kernel<GRAM_PLAIN>, grid, dim3(512), 0, stream, a);
-    if (a.ksplit > 1) {
+    if (phase != 2) {
+        if (a.mode == GRAM_F) hipLaunchKernelGGL(gram_kernel<GRAM_F>, grid, dim3(512), 0, stream, a);
+        else if (a.mode == GRAM_KFU) hipLaunchKernelGGL(gram_kernel<GRAM_KFU>, grid, dim3(512), 0, stream, a);
+        else hipLaunchKernelGGL(gram_kernel<GRAM_PLAIN>, grid, dim3(512), 0, stream, a);
+    }
+    if (a.ksplit > 1 && phase != 1) {
         const dim3 cgrid(a.ntiles, a.nb);
         if (a.mode == GRAM_F) hipLaunchKernelGGL(gram_combine_kernel<GRAM_F>, cgrid, dim3(256), 0, stream, a);
         else if (a.mode == GRAM_KFU) hipLaunchKernelGGL(gram_combine_kernel<GRAM_KFU>, cgrid, dim3(256), 0, stream, a);
