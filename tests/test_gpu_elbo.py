@@ -290,7 +290,7 @@ def test_rccl_all_reduce_on_the_engine_buffer():
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
     try:
         params, Y, c, meta = synthetic.make_named("small")
-        sh = ShardedElbo(params, Y, c, meta, rank=0, world=1, mode="chains", device=0)
+        sh = ShardedElbo(params, Y, c, meta, rank=0, world=1, mode="chains", device=0, always_reduce=True)
         t = finish(sh.step())
         g = load_golden("small")
         assert t["nll"] == pytest.approx(float(g["B_nll"]), rel=RTOL)
