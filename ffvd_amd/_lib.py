@@ -68,6 +68,7 @@ _SIGNATURES = {
     "ffvd_op_get_rand": (C.c_int, [_dp, _dp, _dp, C.c_int64, _dp]),
     "ffvd_adam_step": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_uint32, _dp,
                                  C.POINTER(C.c_double)]),
+    "ffvd_get_stream": (C.c_void_p, [C.c_void_p]),
     "ffvd_optimizer_reset": (C.c_int, [C.c_void_p]),
     "ffvd_update_params": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ffvd_sghmc_step": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_uint32, C.c_int, C.c_void_p, _dp,

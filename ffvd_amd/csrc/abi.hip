@@ -543,6 +543,8 @@ extern "C" int ffvd_elbo_async(ffvd_handle *h, double *out_terms_dev) {
     return enqueue_elbo(h, out_terms_dev, nullptr);
 }
 
+extern "C" void *ffvd_get_stream(ffvd_handle *h) { return h ? (void *)h->stream : nullptr; }
+
 extern "C" int ffvd_chain_nll(ffvd_handle *h, double *out) {
     if (!h || !out) return set_error(h, FFVD_EINVAL, "ffvd_chain_nll: null argument");
     memcpy(out, h->h_chain, (size_t)h->cfg.S_local * sizeof(double));

@@ -107,16 +107,22 @@ class ShardedElbo:
         local["X"] = np.ascontiguousarray(params["X"][pl["s_begin"]: pl["s_begin"] + pl["s_count"]])
         self.engine.set_params(local)
         self.sums = torch.zeros(8, dtype=torch.float64, device=f"cuda:{device}")
+        self.ext_stream = torch.cuda.ExternalStream(self.engine.stream_handle(), device=f"cuda:{device}")
 
     def step(self):
         """One ELBO iteration: local kernels -> 8 partial sums in HBM -> all-reduce -> host."""
         if self.world == 1 and not self.always_reduce:
             # nothing to reduce: the engine's own pinned-host copy of the 8 sums (one synchronisation, no torch hop)
             return self.engine.elbo_sums()
-        self.engine.elbo_async(self.sums.data_ptr())
-        self.engine.sync()
-        all_reduce_sums(self.sums)
-        return self.sums.cpu().numpy()
+        # stream-ordered: the finalize kernel, the RCCL all-reduce and the device-to-host copy all follow the engine's
+        # stream (torch sees it as an external stream), so the only host synchronisation is the final copy
+        with self.torch.cuda.stream(self.ext_stream):
+            self.engine.elbo_async(self.sums.data_ptr())
+            all_reduce_sums(self.sums)
+            out = self.sums.cpu().numpy()
+        if not np.all(np.isfinite(out)):
+            self.engine.sync()          # a failed factorisation poisons the sums: fetch the info flags, raise LinAlgError
+        return out
 
     def nll_terms(self):
         return finish(self.step())

@@ -240,6 +240,10 @@ class ElboEngine:
         """Enqueue one iteration; the 8 partial sums land in device memory `out_dev_ptr` (int address)."""
         _lib.check(self.lib.ffvd_elbo_async(self._h, out_dev_ptr), self._h, "ffvd_elbo_async")
 
+    def stream_handle(self):
+        """The engine's hipStream_t as an integer (for torch.cuda.ExternalStream)."""
+        return int(self.lib.ffvd_get_stream(self._h) or 0)
+
     def sync(self):
         _lib.check(self.lib.ffvd_sync(self._h), self._h, "ffvd_sync")
 

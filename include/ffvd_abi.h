@@ -181,6 +181,9 @@ int  ffvd_update_params(ffvd_handle *h, const ffvd_params *p_host);
  * the sampled arrays, other members ignored.  out_terms / out_nll: the nll before the update. */
 int  ffvd_sghmc_step(ffvd_handle *h, double epsilon, double mdecay, uint32_t sample_mask, int burn_in,
                      const ffvd_params *noise_host, double out_terms[8], double *out_nll);
+/* the handle's HIP stream (a hipStream_t), so that a collective library or another framework can order its work after
+ * ffvd_elbo_async without a host synchronisation (e.g. torch.cuda.ExternalStream around the RCCL all-reduce). */
+void *ffvd_get_stream(ffvd_handle *h);
 /* after a synchronous ffvd_elbo: per-chain nll values (S_local doubles, host) */
 int  ffvd_chain_nll(ffvd_handle *h, double *out_nll_per_chain);
 /* timing helper for benchmarks: run `iters` back-to-back ffvd_elbo_async on the resident inputs,
