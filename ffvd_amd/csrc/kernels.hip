@@ -501,10 +501,13 @@ template <bool PIPE>
 __global__ __launch_bounds__(256) void potrf_trail_kernel(double *A, int n, int k, int nmain_tiles, int n1,
                                                           size_t slab_stride, int32_t *info, int nlive, int nid,
                                                           double *dinv) {
-    __shared__ double Pi_s[NB][TR_LD];
-    __shared__ double Pj_s[NB][TR_LD];
+    // One 34.8 KB LDS buffer: the panel blocks are staged in two 32-column halves (Pi half | Pj half), so that three
+    // workgroups fit on a CU; the look-ahead tile later reuses the same memory as its 64 x 66 factor tile.
+    constexpr int HLD = 34;                               // row stride of a staged half (doubles)
+    __shared__ double sm[2 * NB * HLD];
     __shared__ double invd[NB];
-    static_assert(TR_LD == LR_LD, "the staged panel block doubles as the factor tile");
+    static_assert(2 * NB * HLD >= NB * LR_LD, "the staging buffer must hold the factor tile");
+    double *Pi_h = sm, *Pj_h = sm + NB * HLD;
     const int b = blockIdx.y;
     const int tile = blockIdx.x;
     double *S = A + (size_t)b * slab_stride;
@@ -528,36 +531,45 @@ __global__ __launch_bounds__(256) void potrf_trail_kernel(double *A, int n, int 
     const bool same = (rowblk0 == colblk);
     const double *Pi = S + (size_t)rowblk0 * n + k0;
     const double *Pj = S + (size_t)colblk * n + k0;
-    // stage: thread t moves 16 bytes of rows (t >> 5) + 8 i, columns 2 (t & 31)
+    // global -> registers for both halves at once: thread t moves 16 bytes of rows (t >> 4) + 16 i, columns
+    // 32 h + 2 (t & 15) of each operand
+    const int sr = tid >> 4, sc = 2 * (tid & 15);
+    double2 vi[2][4], vj[2][4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int r = (tid >> 5) + 8 * i, c2 = 2 * (tid & 31);
-        const double2 v = *reinterpret_cast<const double2 *>(Pi + (size_t)r * n + c2);
-        Pi_s[r][c2] = v.x; Pi_s[r][c2 + 1] = v.y;
-        if (!same) {
-            const double2 w = *reinterpret_cast<const double2 *>(Pj + (size_t)r * n + c2);
-            Pj_s[r][c2] = w.x; Pj_s[r][c2 + 1] = w.y;
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            vi[h][i] = *reinterpret_cast<const double2 *>(Pi + (size_t)(sr + 16 * i) * n + 32 * h + sc);
+            if (!same) vj[h][i] = *reinterpret_cast<const double2 *>(Pj + (size_t)(sr + 16 * i) * n + 32 * h + sc);
         }
-    }
-    __syncthreads();
-    const double(*Bp)[TR_LD] = same ? Pi_s : Pj_s;
+    const double *Bh = same ? Pi_h : Pj_h;
     d4 acc[2][2];
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
         for (int y = 0; y < 2; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-    for (int ks = 0; ks < NB / 4; ++ks) {
-        double af[2], bf[2];
 #pragma unroll
-        for (int x = 0; x < 2; ++x) {
-            af[x] = Pi_s[qr * 32 + 16 * x + lr][4 * ks + lk];     // A[row][k]
-            bf[x] = Bp[qc * 32 + 16 * x + lr][4 * ks + lk];       // B[k][col] = P_j[col][k]
+    for (int h = 0; h < 2; ++h) {
+        if (h) __syncthreads();                        // everyone is done reading the first half
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            Pi_h[(sr + 16 * i) * HLD + sc] = vi[h][i].x; Pi_h[(sr + 16 * i) * HLD + sc + 1] = vi[h][i].y;
+            if (!same) { Pj_h[(sr + 16 * i) * HLD + sc] = vj[h][i].x; Pj_h[(sr + 16 * i) * HLD + sc + 1] = vj[h][i].y; }
         }
+        __syncthreads();
+#pragma unroll 4
+        for (int ks = 0; ks < NB / 8; ++ks) {
+            double af[2], bf[2];
 #pragma unroll
-        for (int x = 0; x < 2; ++x)
+            for (int x = 0; x < 2; ++x) {
+                af[x] = Pi_h[(qr * 32 + 16 * x + lr) * HLD + 4 * ks + lk];     // A[row][k]
+                bf[x] = Bh[(qc * 32 + 16 * x + lr) * HLD + 4 * ks + lk];       // B[k][col] = P_j[col][k]
+            }
 #pragma unroll
-            for (int y = 0; y < 2; ++y) acc[x][y] = mfma_f64(af[x], bf[y], acc[x][y]);
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y) acc[x][y] = mfma_f64(af[x], bf[y], acc[x][y]);
+        }
     }
     double *Ct = S + (size_t)rowblk0 * n + colblk;
     if (tile != 0) {
@@ -572,9 +584,12 @@ __global__ __launch_bounds__(256) void potrf_trail_kernel(double *A, int n, int 
                 }
         return;
     }
-    // tile 0 = next diagonal block: assemble the updated block in LDS (Pj_s is free here), factorise, publish
+    // tile 0 = next diagonal block: assemble the updated block in LDS, factorise, publish.  The factor tile Lr
+    // (stride 66) reuses the memory of the input tile Ts (stride 65): wavefront 0 has the whole input in registers
+    // before it writes the first column of L.
     __syncthreads();
-    double(*Ts)[NB + 1] = reinterpret_cast<double(*)[NB + 1]>(&Pj_s[0][0]);     // 64 x 65 <= 64 x 66 doubles
+    double(*Ts)[NB + 1] = reinterpret_cast<double(*)[NB + 1]>(sm);
+    double(*Lr)[LR_LD] = reinterpret_cast<double(*)[LR_LD]>(sm);
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -585,7 +600,7 @@ __global__ __launch_bounds__(256) void potrf_trail_kernel(double *A, int n, int 
                 Ts[r][cc] = Ct[(size_t)r * n + cc] - acc[x][y][q];
             }
     __syncthreads();
-    diag_block_finish<PIPE>(Ts, Pi_s, invd, S, n, k0 + NB, info + b, dinv + (size_t)b * DINV_STRIDE);   // Pi_s is free too
+    diag_block_finish<PIPE>(Ts, Lr, invd, S, n, k0 + NB, info + b, dinv + (size_t)b * DINV_STRIDE);
 }
 
 void launch_potrf_ext(hipStream_t stream, double *A, int n, int extra_rows, int identity_rows, int batch,
