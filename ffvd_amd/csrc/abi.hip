@@ -52,7 +52,7 @@ struct ffvd_handle {
     // backward-pass workspace (cfg.grad)
     struct GradWs {
         double *Acopy = nullptr, *u = nullptr, *LAinv = nullptr, *Gamma = nullptr, *gam_part = nullptr, *uku = nullptr;
-        double *KfT = nullptr, *E = nullptr, *rp = nullptr, *rsum = nullptr, *ez = nullptr, *kfu = nullptr;
+        double *E = nullptr, *rp = nullptr, *rsum = nullptr, *ez = nullptr, *kfu = nullptr;
         double *cs_part = nullptr, *etx_part = nullptr, *rx2_part = nullptr, *dz_unit = nullptr, *dll_unit = nullptr, *dls_unit = nullptr;
         double *Asum = nullptr, *GamSum = nullptr, *Gs = nullptr, *gsum = nullptr, *P1 = nullptr, *KGK = nullptr, *Epsi = nullptr;
         double *rsum2 = nullptr, *ez2 = nullptr, *cs2 = nullptr, *etx2 = nullptr, *rx22 = nullptr, *dz_kuu = nullptr, *dll_kuu = nullptr, *dls_kuu = nullptr;
@@ -425,7 +425,6 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
         pa.d_begin = c.d_begin; pa.hv = hv; pa.W = h->Kuu + msq; pa.w_stride = kstride;
         pa.U = p.U; pa.u_ld = c.D; pa.b0 = s0 * Dl; pa.nb = ns * Dl;
         pa.F = (c.branch == FFVD_BRANCH_B) ? h->F : nullptr;
-        pa.FT = nullptr;      // (the backward product reads K_fu row-major: no transposed copy)
         pa.rowsq = h->rowsq;
         pa.fmean = (c.branch == FFVD_BRANCH_A) ? h->fmean : nullptr;
         pa.ng = h->ng;

@@ -64,7 +64,6 @@ struct ProjectArgs {
     int u_ld;
     int b0, nb;             // batches [b0, b0+nb): b = s*Dl + dl
     double *F;              // [nb][Tp][Mp] or null
-    double *FT;             // kfu_build only: optional transposed copy [nb][Mp][Tp]
     double *rowsq;          // [nbatch_total][ng][Tp] or null   (sum_j F[t][j]^2 per column group)
     double *fmean;          // [nbatch_total][ng][Tp] or null   (sum_j F[t][j] * U[j][d])
     int ng;                 // column groups = ceil(Mp / 512)

@@ -158,12 +158,11 @@ void launch_transpose(hipStream_t stream, const double *in, size_t in_stride, do
 
 // K_fu materialised (only the K_uu + K_uf K_fu / Q route needs it in HBM): out[bz][t][m] = K_d(x_t, Z_m),
 // zero for t >= T or m >= M.  64 x 64 tile per workgroup; thread (tid & 63) owns a column, 16 rows.
-template <int KIND, bool TRANS>
+template <int KIND>
 __global__ __launch_bounds__(256) void kfu_build_kernel(ProjectArgs a) {
     __shared__ double xs[MAXP][64];
     __shared__ double xx[64];
     __shared__ double zs[64][MAXP + 1];
-    __shared__ double tsq[TRANS ? 64 : 1][65];
     const int tid = threadIdx.x, lane = tid & 63;
     const int t0 = blockIdx.x * 64, m0 = blockIdx.y * 64, bz = blockIdx.z;
     const int b = a.b0 + bz, s = b / a.Dl, dl = b % a.Dl;
@@ -191,33 +190,26 @@ __global__ __launch_bounds__(256) void kfu_build_kernel(ProjectArgs a) {
     const double zzv = a.hv.zz[(size_t)dl * Mp + m0 + lane];
     double *out = a.F + ((size_t)bz * a.Tp + t0) * Mp + m0 + lane;
     const bool mok = (m0 + lane) < a.M;
+    double zr[8];                               // this thread's inducing input (first 8 components) in registers
+#pragma unroll
+    for (int p = 0; p < 8; ++p) zr[p] = (p < P) ? zs[lane][p] : 0.0;
 #pragma unroll 4
     for (int i = 0; i < 16; ++i) {
         const int r = (tid >> 6) * 16 + i;
         double dot = 0.0;
-        for (int p = 0; p < P; ++p) dot += xs[p][r] * zs[lane][p];
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+            if (p < P) dot += xs[p][r] * zr[p];
+        for (int p = 8; p < P; ++p) dot += xs[p][r] * zs[lane][p];
         double v = kernel_value<KIND>(dot, xx[r], zzv, var);
         if (!mok || t0 + r >= a.T) v = 0.0;
         out[(size_t)r * Mp] = v;
-        if (TRANS) tsq[r][lane] = v;
-    }
-    if (TRANS) {        // transposed copy K_uf (Mp x Tp), written row-wise through the LDS tile
-        __syncthreads();
-        for (int i = 0; i < 16; ++i) {
-            const int m = (tid >> 6) * 16 + i;
-            a.FT[((size_t)bz * Mp + m0 + m) * a.Tp + t0 + lane] = tsq[lane][m];
-        }
     }
 }
 void launch_kfu_build(hipStream_t stream, const ProjectArgs &a) {
     dim3 grid(a.Tp / 64, a.Mp / 64, a.nb);
-    if (a.FT) {
-        if (a.kind == 0) hipLaunchKernelGGL((kfu_build_kernel<0, true>), grid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((kfu_build_kernel<1, true>), grid, dim3(256), 0, stream, a);
-    } else {
-        if (a.kind == 0) hipLaunchKernelGGL((kfu_build_kernel<0, false>), grid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((kfu_build_kernel<1, false>), grid, dim3(256), 0, stream, a);
-    }
+    if (a.kind == 0) hipLaunchKernelGGL(kfu_build_kernel<0>, grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(kfu_build_kernel<1>, grid, dim3(256), 0, stream, a);
 }
 
 // Operator-API kernel matrix (one kernel, arbitrary N, N2; no padding).
