@@ -414,3 +414,19 @@ def test_gradient_on_awkward_shapes(ov):
         # Z (and, more mildly, the lengthscales) carry eps * cond(K_uu): 150 points in 4-D give 7e-5 between GPU and CPU
         tol = 5e-4 if k == "Z" else (1e-6 if k in ("loglengthscales", "logvariance") else 1e-8)
         assert err < tol, (k, err)
+
+
+@pytest.mark.parametrize("route", ["reference", "gram"])
+def test_non_finite_inputs_are_reported_not_propagated(route):
+    """A NaN in a latent trajectory must surface as a numerical error (first non-positive pivot), never as a silent
+    NaN nll or a hang; the handle stays usable."""
+    params, Y, c, meta = synthetic.make_named("tiny")
+    bad = dict(params)
+    bad["X"] = params["X"].copy()
+    bad["X"][1, 7, 0] = np.nan
+    with ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], meta["S"], route=route) as e:
+        e.set_data(Y, c)
+        with pytest.raises(np.linalg.LinAlgError, match="chain 1"):
+            e.nll_terms(bad)
+        ok = e.nll_terms(params)
+        assert np.isfinite(ok["nll"])
