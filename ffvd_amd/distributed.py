@@ -10,6 +10,8 @@ collective; the only exchange is one all-reduce(sum) of the 8-double partial-sum
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 
@@ -114,6 +116,11 @@ class ShardedElbo:
         if self.world == 1 and not self.always_reduce:
             # nothing to reduce: the engine's own pinned-host copy of the 8 sums (one synchronisation, no torch hop)
             return self.engine.elbo_sums()
+        if os.environ.get("FFVD_SYNC_STEP"):            # conservative variant: host sync, collective on torch's stream
+            self.engine.elbo_async(self.sums.data_ptr())
+            self.engine.sync()
+            all_reduce_sums(self.sums)
+            return self.sums.cpu().numpy()
         # stream-ordered: the finalize kernel, the RCCL all-reduce and the device-to-host copy all follow the engine's
         # stream (torch sees it as an external stream), so the only host synchronisation is the final copy
         with self.torch.cuda.stream(self.ext_stream):
