@@ -445,7 +445,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
                 launch_set_identity(s, h->H, ga.h_stride, Mp, Mp, ns * Dl);
             }
             ga.Kadd = h->Kcopy; ga.kadd_stride = msq; ga.Kinv = h->Kinv; ga.kinv_stride = msq; ga.trpart = h->trpart;
-            if (h->gpart && ns == h->cpp) { ga.ksplit = h->gsplit; ga.part = h->gpart; }
+            if (h->gpart) { ga.ksplit = h->gsplit; ga.part = h->gpart; }     // same row ranges in every pass of this handle
             if (s0 == 0 && late_join) {
                 launch_gram(s, ga, 1);
                 HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));
@@ -1477,3 +1477,4 @@ extern "C" int ffvd_op_rollout(int kind, const double *Lm_inverse_seq, const dou
     HIP_TRY(hipStreamSynchronize(sc.stream));
     return FFVD_OK;
 }
+

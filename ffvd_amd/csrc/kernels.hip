@@ -283,16 +283,16 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 
 // sqrt(x) and 1/sqrt(x) of tf.linalg.cholesky's pivot (conditionals_multi_output.py:28,162) from the hardware
-// reciprocal square root + two Newton steps + one correction each (about 1 ulp): far shorter than the IEEE sqrt
-// and divide expansions that would sit on the 64-pivot critical path.
+// reciprocal square root (2^-24 accurate) and ONE cubic (Halley-type) step: with e = 1 - x y^2,
+// y <- y (1 + e/2 + 3 e^2/8) is accurate to 1.4e-16 (tools/rsq_probe.hip; two Newton steps give 2.4e-16) in five
+// dependent operations -- this chain sits 64 times on the critical path of every block step, the IEEE sqrt and
+// divide expansions would be several times longer.  sqrt(x) = x y with one correction, off the critical path.
 __device__ __forceinline__ void pivot_sqrt(const double ajj, double &piv, double &y) {
     y = __builtin_amdgcn_rsq(ajj);
-    const double hx = 0.5 * ajj;
-    y = y * (1.5 - hx * y * y);
-    y = y * (1.5 - hx * y * y);
+    const double e = fma(-(ajj * y), y, 1.0);
+    y = fma(y, e * fma(0.375, e, 0.5), y);
     piv = ajj * y;
-    piv = piv + 0.5 * y * (ajj - piv * piv);
-    y = y + y * (1.0 - piv * y);
+    piv = fma(0.5 * y, fma(-piv, piv, ajj), piv);
 }
 
 // 64x64 Cholesky by ONE wavefront with no workgroup barriers: lane = row, the whole row in registers
