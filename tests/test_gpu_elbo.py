@@ -481,3 +481,29 @@ def test_two_processes_share_the_gpu_and_reduce(tmp_path, mode):
         assert nll1 == nll2
         assert nll1 == pytest.approx(t["nll"], rel=1e-12) and nllg == pytest.approx(t["nll"], rel=1e-12)
         assert zsum == pytest.approx(float(np.abs(g["Z"]).sum()), rel=1e-4)
+
+
+def _random_shapes(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        T = int(rng.integers(5, 200))
+        M = int(rng.integers(3, min(T, 140) + 1))
+        out.append(dict(T=T, M=M, D=int(rng.integers(1, 6)), C=int(rng.integers(0, 4)), S=int(rng.integers(1, 4))))
+    return out
+
+
+@pytest.mark.parametrize("ov", _random_shapes(10, 20230209), ids=lambda o: "T{T}_M{M}_D{D}_C{C}_S{S}".format(**o))
+def test_random_shapes_against_oracle(ov):
+    """Ragged sizes on every axis (T, M not multiples of the 64/128 tiles, one to five latent dims, zero to three
+    control inputs): all three evaluation paths against the oracle on the same seeded inputs."""
+    params, Y, c, meta = synthetic.make_named("tiny", **ov)
+    refB = orc.nll_terms_chains(params, Y, c, U_collapse=True, kernel_type=meta["kernel_type"])
+    refA = orc.nll_terms_chains(params, Y, c, U_collapse=False, kernel_type=meta["kernel_type"])
+    gotB = run_engine(params, Y, c, meta, collapse=True)
+    gotA = run_engine(params, Y, c, meta, collapse=False)
+    gotG = run_engine(params, Y, c, meta, collapse=True, route="gram")
+    assert_terms(gotB, refB, TERMS_B)
+    assert_terms(gotA, refA, TERMS_A)
+    assert gotG["nll"] == pytest.approx(refB["nll"], rel=1e-7)          # Gram route: eps * cond(K_uu)
+    np.testing.assert_allclose(gotB["nll_per_chain"], refB["nll_per_chain"], rtol=RTOL)
