@@ -34,7 +34,7 @@ struct ffvd_handle {
     double *gpart = nullptr;                     // split-K partial tiles of the Gram kernel (few units per pass)
     int gsplit = 1;
     hipStream_t aux = nullptr;          // side stream: the K_uu chain runs beside the K_fu build (Gram route)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
     std::string err;
     std::vector<void *> allocs;
     int64_t ws_bytes = 0;
@@ -117,6 +117,7 @@ extern "C" int ffvd_destroy(ffvd_handle *h) {
     if (h->aux) { hipStreamSynchronize(h->aux); hipStreamDestroy(h->aux); }
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_join) hipEventDestroy(h->ev_join);
+    if (h->ev_join2) hipEventDestroy(h->ev_join2);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
     return FFVD_OK;
@@ -151,6 +152,7 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
     }
     HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming));
     HIP_TRY(dev_alloc(h, &h->X, (size_t)c.S_local * (c.T + 1) * c.D));
     HIP_TRY(dev_alloc(h, &h->Z, (size_t)c.M * P));
     HIP_TRY(dev_alloc(h, &h->U, (size_t)c.M * c.D));
@@ -415,6 +417,20 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
         launch_h_finish(sk, h->Kuu, Mp, kstride, Dl, h->kterms);
         if (sk != s) HIP_TRY(hipEventRecord(h->ev_join, sk));
     }
+    ReduceArgs ra{};
+    ra.kind = c.kernel_kind; ra.branch = c.branch; ra.X = p.X; ra.ctrl = h->ctrl; ra.Y = h->Y;
+    ra.log_Q = p.log_Q; ra.CC = p.CC; ra.DD = p.DD; ra.log_Rchols = p.log_Rchols; ra.variance = h->variance;
+    ra.T = c.T; ra.Tp = Tp; ra.D = c.D; ra.C = c.C; ra.Ydim = c.Ydim; ra.Dl = Dl; ra.d_begin = c.d_begin;
+    ra.S = c.S_local; ra.ng = h->ng; ra.shared_terms = c.shared_terms;
+    ra.xk = p.X; ra.xk_chain_stride = (size_t)(c.T + 1) * c.D; ra.xk_ld = c.D; ra.xk_cols = c.D;
+    ra.rowsq = gram_route ? nullptr : h->rowsq; ra.fmean = h->fmean; ra.chain_terms = h->chain_terms;
+    // the per-chain likelihood / transition reductions depend on the inputs only (Gram route: no row sums of F), so
+    // they ride on the side stream behind the K_uu chain and are back long before finalize needs them
+    const bool reduce_early = gram_route && sk != s;
+    if (reduce_early) {
+        launch_chain_reduce(sk, ra, h->chain_partial);
+        HIP_TRY(hipEventRecord(h->ev_join2, sk));
+    }
     if (st) st->mark(0);
     for (int s0 = 0; s0 < c.S_local; s0 += h->cpp) {
         const int ns = (s0 + h->cpp <= c.S_local) ? h->cpp : c.S_local - s0;
@@ -464,14 +480,8 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
             if (st) st->mark(3);
         }
     }
-    ReduceArgs ra{};
-    ra.kind = c.kernel_kind; ra.branch = c.branch; ra.X = p.X; ra.ctrl = h->ctrl; ra.Y = h->Y;
-    ra.log_Q = p.log_Q; ra.CC = p.CC; ra.DD = p.DD; ra.log_Rchols = p.log_Rchols; ra.variance = h->variance;
-    ra.T = c.T; ra.Tp = Tp; ra.D = c.D; ra.C = c.C; ra.Ydim = c.Ydim; ra.Dl = Dl; ra.d_begin = c.d_begin;
-    ra.S = c.S_local; ra.ng = h->ng; ra.shared_terms = c.shared_terms;
-    ra.xk = p.X; ra.xk_chain_stride = (size_t)(c.T + 1) * c.D; ra.xk_ld = c.D; ra.xk_cols = c.D;
-    ra.rowsq = gram_route ? nullptr : h->rowsq; ra.fmean = h->fmean; ra.chain_terms = h->chain_terms;
-    launch_chain_reduce(s, ra, h->chain_partial);
+    if (!reduce_early) launch_chain_reduce(s, ra, h->chain_partial);
+    else HIP_TRY(hipStreamWaitEvent(s, h->ev_join2, 0));
     FinalizeArgs fa{};
     fa.kind = c.kernel_kind; fa.branch = c.branch; fa.prior_type = c.prior_type; fa.shared_terms = c.shared_terms;
     fa.T = c.T; fa.D = c.D; fa.P = P; fa.M = c.M; fa.Ydim = c.Ydim; fa.Dl = Dl; fa.d_begin = c.d_begin;
