@@ -77,3 +77,38 @@ def test_op_argument_validation_without_gpu():
     # SE kernel without lengthscales is a usage error and must be rejected before any device work
     rc = lib.ffvd_op_kernel_matrix(0, _lib.dptr(x), 2, None, 2, 3, 0.0, None, 0.0, _lib.dptr(out))
     assert rc == _lib.FFVD_EINVAL
+
+
+def _compile_c_demo(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "abi_demo")
+    cmd = ["gcc", "-std=c99", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "examples", "abi_demo.c"), "-o", exe, "-L" + os.path.join(ROOT, "ffvd_amd"), "-lffvd_hip",
+           "-Wl,-rpath," + os.path.join(ROOT, "ffvd_amd"), "-lm"]
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    assert proc.returncode == 0, proc.stderr
+    return exe
+
+
+def test_header_is_plain_c99_and_a_c_host_links(tmp_path):
+    """The boundary is a C ABI: the header must compile as C99 with warnings as errors, and a C program that includes
+    nothing else must link against the shared library (examples/abi_demo.c)."""
+    import subprocess
+    proc = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c",
+                           os.path.join(ROOT, "include", "ffvd_abi.h")], capture_output=True, text=True)
+    assert proc.returncode == 0, proc.stderr
+    _compile_c_demo(tmp_path)
+
+
+@pytest.mark.gpu
+def test_c_host_runs(tmp_path):
+    """examples/abi_demo.c end to end on the GPU: both routes of the collapsed bound from a C main()."""
+    import subprocess
+    exe = _compile_c_demo(tmp_path)
+    proc = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert proc.returncode == 0, proc.stdout + proc.stderr
+    lines = [l.split() for l in proc.stdout.splitlines() if l.startswith("route")]
+    assert len(lines) == 2 and lines[0][1] == "0" and lines[1][1] == "1"
+    nll_ref, nll_gram = float(lines[0][3]), float(lines[1][3])
+    assert np.isfinite(nll_ref) and nll_gram == pytest.approx(nll_ref, rel=1e-8)
+    assert lines[0][4:6] == ["(chains", "2)"]
