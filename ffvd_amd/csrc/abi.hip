@@ -46,6 +46,8 @@ struct ffvd_handle {
     // workspace
     double *variance = nullptr, *len = nullptr, *Zs = nullptr, *zz = nullptr;
     double *Kuu = nullptr, *F = nullptr, *H = nullptr, *rowsq = nullptr, *fmean = nullptr;
+    double *Kf2 = nullptr;          // reference route, branch B: K_fu (input of the projection GEMM); F keeps K_fu L^-T
+    int ngr = 0;                    // row-sum partials per unit in that path (128-column tiles)
     double *Kcopy = nullptr, *Linv = nullptr, *Kinv = nullptr, *trpart = nullptr, *kterms = nullptr;   // GRAM route
     int ntiles = 0;
     double *chain_partial = nullptr;
@@ -169,11 +171,16 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
     HIP_TRY(dev_alloc(h, &h->Zs, Dl * Mp * P));
     HIP_TRY(dev_alloc(h, &h->zz, Dl * Mp));
     HIP_TRY(dev_alloc(h, &h->Kuu, Dl * 2 * Mp * Mp));
-    HIP_TRY(dev_alloc(h, &h->rowsq, (size_t)h->nbatch * h->ng * Tp));
+    // reference route of the collapsed branch: K_fu is built once (kfu_build) and projected by a triangular GEMM,
+    // unless FFVD_FUSED_PROJECT asks for the older kernel that generates K_fu inside the projection
+    const bool proj_gemm = c.branch == FFVD_BRANCH_B && c.route == FFVD_ROUTE_REFERENCE && !getenv("FFVD_FUSED_PROJECT");
+    h->ngr = proj_gemm ? (int)((Mp + 127) / 128) : 0;
+    HIP_TRY(dev_alloc(h, &h->rowsq, (size_t)h->nbatch * (h->ngr > h->ng ? h->ngr : h->ng) * Tp));
     HIP_TRY(dev_alloc(h, &h->fmean, (size_t)h->nbatch * h->ng * Tp));
     if (c.branch == FFVD_BRANCH_B) {
         const size_t pass_b = (size_t)h->cpp * Dl;
         HIP_TRY(dev_alloc(h, &h->F, pass_b * Tp * Mp));
+        if (h->ngr) HIP_TRY(dev_alloc(h, &h->Kf2, pass_b * Tp * Mp));
         const size_t hrows = c.grad ? 2 * Mp + NB : Mp + NB;     // grad: Mp identity rows (-> L_A^-T) before the b row
         HIP_TRY(dev_alloc(h, &h->H, pass_b * hrows * Mp));
         HIP_TRY(hipMemsetAsync(h->H, 0, pass_b * hrows * Mp * sizeof(double), h->stream));
@@ -424,6 +431,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
     ra.S = c.S_local; ra.ng = h->ng; ra.shared_terms = c.shared_terms;
     ra.xk = p.X; ra.xk_chain_stride = (size_t)(c.T + 1) * c.D; ra.xk_ld = c.D; ra.xk_cols = c.D;
     ra.rowsq = gram_route ? nullptr : h->rowsq; ra.fmean = h->fmean; ra.chain_terms = h->chain_terms;
+    if (h->ngr) ra.ng = h->ngr;
     // the per-chain likelihood / transition reductions depend on the inputs only (Gram route: no row sums of F), so
     // they ride on the side stream behind the K_uu chain and are back long before finalize needs them
     const bool reduce_early = gram_route && sk != s;
@@ -447,6 +455,14 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
         if (gram_route) {
             launch_kfu_build(s, pa);
             if (s0 == 0 && sk != s && !late_join) HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));
+        } else if (h->ngr) {
+            pa.F = h->Kf2;
+            launch_kfu_build(s, pa);                                  // K(X_combine, Z)           (:240)
+            ProjGemmArgs pg{};
+            pg.Kf = h->Kf2; pg.kf_stride = (size_t)Tp * Mp; pg.W = h->Kuu + msq; pg.w_stride = kstride;
+            pg.F = h->F; pg.f_stride = (size_t)Tp * Mp; pg.rowsq = h->rowsq; pg.Tp = Tp; pg.Mp = Mp; pg.Dl = Dl;
+            pg.b0 = s0 * Dl; pg.nb = ns * Dl;
+            launch_proj_gemm(s, pg);                                  // tilde_F = Knm Lm^-T, sum F^2  (:242,:255)
         } else launch_project(s, pa);
         if (st) st->mark(1);
         if (c.branch == FFVD_BRANCH_B) {

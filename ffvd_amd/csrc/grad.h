@@ -68,6 +68,18 @@ struct BwdFusedArgs {
 void launch_bwd_fused(hipStream_t stream, const BwdFusedArgs &a);
 size_t bwd_fused_rp_doubles(int Mp, int Tp, int nb);
 
+// Reference-route projection as a GEMM:  F = K_fu W  with W = L^-T upper triangular (conditionals_multi_output.py:242),
+// K_fu read from the kfu_build output, k-range cut at the tile's last column (and per wavefront inside the diagonal
+// block), row sums of F^2 (the trace term, :255) as per-column-tile partials.
+struct ProjGemmArgs {
+    const double *Kf; size_t kf_stride;        // [nb] Tp x Mp row-major
+    const double *W; size_t w_stride;          // [Dl] Mp x Mp (row k, column j), zero below the diagonal
+    double *F; size_t f_stride;                // [nb] Tp x Mp
+    double *rowsq;                             // [nb][ntj][Tp], ntj = ceil(Mp / 128)
+    int Tp, Mp, Dl, b0, nb;
+};
+void launch_proj_gemm(hipStream_t stream, const ProjGemmArgs &a);
+
 struct DxArgs {
     const double *X, *Y, *CC, *DD, *log_Rchols, *log_Q, *len;
     const double *rsum, *ez, *kfu;

@@ -442,6 +442,120 @@ void launch_bwd_fused(hipStream_t stream, const BwdFusedArgs &a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// proj_gemm_kernel (see grad.h ProjGemmArgs): same tiling and staging as the backward product (128 x 128 tile, 8
+// wavefronts of 64 x 32, K_fu chunk transposed into LDS), depth limited to k < (tj + 1) * 128 because W is upper
+// triangular; inside that last block a wavefront stops at its own last column.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 4) void proj_gemm_kernel(ProjGemmArgs a) {
+    __shared__ double As[2][AT][A_LD];
+    __shared__ double Bs[2][AT][A_LD];
+    const int bz = blockIdx.y;
+    const int ntj = (a.Mp + 127) / 128;
+    // heavy column tiles (long k range) first: blockIdx.x / nti counts tj downwards
+    const int nti = (a.Tp + 127) / 128;
+    const int tj = ntj - 1 - (int)(blockIdx.x / nti), ti = blockIdx.x % nti;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int lr = lane & 15, lk = lane >> 4;
+    const int I0 = ti * 128 + wr * 64, J0 = tj * 128 + wc * 32;
+    const int Mp = a.Mp, Tp = a.Tp;
+    const int b = a.b0 + bz, dl = b % a.Dl;
+    const double *Kfb = a.Kf + (size_t)bz * a.kf_stride;
+    const double *Wb = a.W + (size_t)dl * a.w_stride;
+    const int colB = tj * 128 + 2 * lane;
+    const bool okB = colB < Mp;
+    const int colBc = okB ? colB : 0;
+    const int rowl = tid >> 6;
+    const int arow = ti * 128 + (tid >> 2), aseg = 4 * (tid & 3);
+    const bool okAr = arow < Tp;
+    const double *Arow = Kfb + (size_t)(okAr ? arow : 0) * Mp + aseg;
+    double2 ra[2], rb[2];
+    auto gload = [&](int c) {
+        ra[0] = *reinterpret_cast<const double2 *>(Arow + (size_t)c * AT);
+        ra[1] = *reinterpret_cast<const double2 *>(Arow + (size_t)c * AT + 2);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const size_t k = (size_t)c * AT + rowl + 8 * i;
+            rb[i] = *reinterpret_cast<const double2 *>(Wb + k * Mp + colBc);
+        }
+    };
+    auto lstore = [&](int buf) {
+        const int il = tid >> 2;
+        As[buf][aseg + 0][il] = okAr ? ra[0].x : 0.0;
+        As[buf][aseg + 1][il] = okAr ? ra[0].y : 0.0;
+        As[buf][aseg + 2][il] = okAr ? ra[1].x : 0.0;
+        As[buf][aseg + 3][il] = okAr ? ra[1].y : 0.0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            double2 vb = rb[i];
+            vb.x = okB ? vb.x : 0.0; vb.y = okB ? vb.y : 0.0;
+            *reinterpret_cast<double2 *>(&Bs[buf][rowl + 8 * i][2 * lane]) = vb;
+        }
+    };
+    d4 acc[4][2];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
+    const int kend = ((tj + 1) * 128 < Mp) ? (tj + 1) * 128 : Mp;       // W[k][j] = 0 for k > j
+    const int nchunk = kend / AT;
+    const int my_last = (J0 + 31) / AT;                                // last chunk with a non-zero W row for this wavefront
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunk) gload(c + 1);
+        if (c <= my_last) {
+#pragma unroll
+            for (int ks = 0; ks < AT / 4; ++ks) {
+                double af[4], bf[2];
+#pragma unroll
+                for (int x = 0; x < 4; ++x) af[x] = As[buf][4 * ks + lk][wr * 64 + 16 * x + lr];
+#pragma unroll
+                for (int y = 0; y < 2; ++y) bf[y] = Bs[buf][4 * ks + lk][wc * 32 + 16 * y + lr];
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+#pragma unroll
+                    for (int y = 0; y < 2; ++y) acc[x][y] = mfma_f64(af[x], bf[y], acc[x][y]);
+            }
+        }
+        if (c + 1 < nchunk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    // epilogue: F and the row sums of F^2 over this tile's columns
+    double *Fb = a.F + (size_t)bz * a.f_stride;
+    double *rs_s = &As[0][0][0];                     // [4 wc][128 rows]
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = I0 + 16 * x + lk + 4 * q;
+            double v = 0.0;
+#pragma unroll
+            for (int y = 0; y < 2; ++y) {
+                const int j = J0 + 16 * y + lr;
+                const double f = acc[x][y][q];
+                if (i < Tp && j < Mp) Fb[(size_t)i * Mp + j] = f;
+                v += f * f;
+            }
+            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+            if (lr == 0) rs_s[wc * 128 + wr * 64 + 16 * x + lk + 4 * q] = v;
+        }
+    __syncthreads();
+    if (tid < 128) {
+        const int t = ti * 128 + tid;
+        if (t < Tp)
+            a.rowsq[((size_t)b * ntj + tj) * Tp + t] = (rs_s[tid] + rs_s[128 + tid]) + (rs_s[256 + tid] + rs_s[384 + tid]);
+    }
+}
+void launch_proj_gemm(hipStream_t stream, const ProjGemmArgs &a) {
+    const int nti = (a.Tp + 127) / 128, ntj = (a.Mp + 127) / 128;
+    hipLaunchKernelGGL(proj_gemm_kernel, dim3(nti * ntj, a.nb), dim3(512), 0, stream, a);
+}
+
+// ---------------------------------------------------------------------------------------------
 // small dense helpers
 // ---------------------------------------------------------------------------------------------
 // out[b] = u_b^T K_d u_b   (K = K_uu + jitter I with identity padding)
