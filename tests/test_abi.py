@@ -81,6 +81,7 @@ def test_op_argument_validation_without_gpu():
 
 def _compile_c_demo(tmp_path):
     import subprocess
+    build.build()                              # no-op when the library is already there
     exe = str(tmp_path / "abi_demo")
     cmd = ["gcc", "-std=c99", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
            os.path.join(ROOT, "examples", "abi_demo.c"), "-o", exe, "-L" + os.path.join(ROOT, "ffvd_amd"), "-lffvd_hip",
