@@ -33,7 +33,7 @@ class FfvdParams(C.Structure):
 
 class FfvdGrads(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
-        "X", "Z", "logvariance", "loglengthscales", "log_Q", "CC", "DD", "log_Rchols")]
+        "X", "Z", "logvariance", "loglengthscales", "log_Q", "CC", "DD", "log_Rchols", "U")]
 
 
 _dp = C.POINTER(C.c_double)
@@ -85,8 +85,8 @@ _SIGNATURES = {
 }
 
 TRAIN_BITS = {"X": 1, "Z": 2, "logvariance": 4, "loglengthscales": 8, "log_Q": 16, "CC": 32, "DD": 64,
-              "log_Rchols": 128}
-TRAIN_ALL = 255
+              "log_Rchols": 128, "U": 256}
+TRAIN_ALL = 511
 
 _lib = None
 

@@ -60,13 +60,16 @@ struct ffvd_handle {
         double *rsum2 = nullptr, *ez2 = nullptr, *cs2 = nullptr, *etx2 = nullptr, *rx22 = nullptr, *dz_kuu = nullptr, *dll_kuu = nullptr, *dls_kuu = nullptr;
         double *shared_part = nullptr, *dX = nullptr, *dZ = nullptr, *dlogvar = nullptr, *dloglen = nullptr, *dlogQ = nullptr;
         double *dCC = nullptr, *dDD = nullptr, *dlogR = nullptr;
+        // explicit-U branch
+        double *Gu = nullptr, *Gsum = nullptr, *r = nullptr, *dalpha = nullptr, *ucol = nullptr, *beta = nullptr, *du = nullptr;
+        double *GammaA = nullptr, *Lclean = nullptr, *dU = nullptr;
         int ngam = 0, sp_stride = 0;
     } gw;
     double *hterms = nullptr, *chain_terms = nullptr, *chain_nll = nullptr, *out_terms = nullptr;
     int32_t *info = nullptr;
     // Adam state for ffvd_adam_step: first/second moments per parameter array (order of FFVD_TRAIN_* bits), step count
-    double *adam_m[8] = {nullptr}, *adam_v[8] = {nullptr};
-    double *hmc[8][5] = {{nullptr}};     // SG-HMC state per array: xi, g, g2, p and the uploaded noise
+    double *adam_m[9] = {nullptr}, *adam_v[9] = {nullptr};
+    double *hmc[9][5] = {{nullptr}};     // SG-HMC state per array: xi, g, g2, p and the uploaded noise
     bool hmc_ready = false;
     int64_t adam_t = 0;
     bool adam_ready = false;
@@ -186,7 +189,9 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
         HIP_TRY(hipMemsetAsync(h->H, 0, pass_b * hrows * Mp * sizeof(double), h->stream));
     }
     h->ntiles = gram_ntiles(h->Mp);
-    if (c.branch == FFVD_BRANCH_B && c.route == FFVD_ROUTE_GRAM) {
+    const bool grad_a = c.grad && c.branch == FFVD_BRANCH_A;
+    if (grad_a) HIP_TRY(dev_alloc(h, &h->F, (size_t)h->nbatch * Tp * Mp));      // K_fu for the backward pass
+    if ((c.branch == FFVD_BRANCH_B && c.route == FFVD_ROUTE_GRAM) || grad_a) {
         HIP_TRY(dev_alloc(h, &h->Kcopy, Dl * Mp * Mp));
         HIP_TRY(dev_alloc(h, &h->Linv, Dl * Mp * Mp));
         HIP_TRY(dev_alloc(h, &h->Kinv, Dl * Mp * Mp));
@@ -221,6 +226,13 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
         HIP_TRY(dev_alloc(h, &g.dZ, (size_t)c.M * P)); HIP_TRY(dev_alloc(h, &g.dlogvar, (size_t)c.D));
         HIP_TRY(dev_alloc(h, &g.dloglen, (size_t)c.D * P)); HIP_TRY(dev_alloc(h, &g.dlogQ, (size_t)c.D));
         HIP_TRY(dev_alloc(h, &g.dCC, (size_t)c.D * J)); HIP_TRY(dev_alloc(h, &g.dDD, J)); HIP_TRY(dev_alloc(h, &g.dlogR, J * J));
+        if (grad_a) {
+            HIP_TRY(dev_alloc(h, &g.Gu, nbt * (Mp + NB) * Mp));   HIP_TRY(dev_alloc(h, &g.Gsum, Dl * (Mp + NB) * Mp));
+            HIP_TRY(dev_alloc(h, &g.r, nbt * Tp));                HIP_TRY(dev_alloc(h, &g.dalpha, nbt));
+            HIP_TRY(dev_alloc(h, &g.ucol, Dl * Mp));              HIP_TRY(dev_alloc(h, &g.beta, Dl * Mp));
+            HIP_TRY(dev_alloc(h, &g.du, Dl * Mp));                HIP_TRY(dev_alloc(h, &g.GammaA, Dl * msq));
+            HIP_TRY(dev_alloc(h, &g.Lclean, Dl * msq));           HIP_TRY(dev_alloc(h, &g.dU, (size_t)c.M * c.D));
+        }
     }
     HIP_TRY(dev_alloc(h, &h->hterms, (size_t)h->nbatch * 2));
     HIP_TRY(dev_alloc(h, &h->chain_terms, (size_t)c.S_local * 8));
@@ -271,9 +283,11 @@ extern "C" int ffvd_create(const ffvd_config *cfg, ffvd_handle **out) {
     if (!(cfg->jitter >= 0.0)) return set_error(nullptr, FFVD_EINVAL, "ffvd_create: jitter must be >= 0");
     if (cfg->route != FFVD_ROUTE_REFERENCE && cfg->route != FFVD_ROUTE_GRAM)
         return set_error(nullptr, FFVD_EINVAL, "ffvd_create: unknown route");
-    if (cfg->grad && (cfg->branch != FFVD_BRANCH_B || cfg->route != FFVD_ROUTE_GRAM || cfg->kernel_kind != FFVD_KERNEL_SE))
+    if (cfg->grad && (cfg->kernel_kind != FFVD_KERNEL_SE || (cfg->branch == FFVD_BRANCH_B && cfg->route != FFVD_ROUTE_GRAM)))
         return set_error(nullptr, FFVD_EINVAL,
-                         "ffvd_create: grad = 1 needs the collapsed-U branch, FFVD_ROUTE_GRAM and the SE kernel");
+                         "ffvd_create: grad = 1 needs the SE kernel and, in the collapsed-U branch, FFVD_ROUTE_GRAM");
+    if (cfg->grad && cfg->branch == FFVD_BRANCH_A && cfg->D + cfg->C > 6)
+        return set_error(nullptr, FFVD_EINVAL, "ffvd_create: grad = 1 in the explicit-U branch needs P = D + C <= 6");
     if (cfg->route == FFVD_ROUTE_GRAM && cfg->branch != FFVD_BRANCH_B)
         return set_error(nullptr, FFVD_EINVAL, "ffvd_create: FFVD_ROUTE_GRAM only applies to the collapsed-U branch");
     int ndev = 0;
@@ -405,11 +419,12 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
         HIP_TRY(hipEventRecord(h->ev_fork, s));
         HIP_TRY(hipStreamWaitEvent(sk, h->ev_fork, 0));
     }
-    launch_kuu_build(sk, c.kernel_kind, hv, c.M, Mp, P, Dl, c.jitter, h->Kuu, gram_route ? h->Kcopy : nullptr);
+    const bool grad_a = c.grad && c.branch == FFVD_BRANCH_A;
+    launch_kuu_build(sk, c.kernel_kind, hv, c.M, Mp, P, Dl, c.jitter, h->Kuu, (gram_route || grad_a) ? h->Kcopy : nullptr);
     const size_t kstride = (size_t)2 * Mp * Mp;
     const size_t msq = (size_t)Mp * Mp;
     launch_potrf_ext(sk, h->Kuu, Mp, Mp, Mp, Dl, kstride, h->info, h->dinvK);
-    if (gram_route) {
+    if (gram_route || grad_a) {
         // K^-1 = L^-T L^-1 (shared by all chains) and log|K|
         launch_transpose(sk, h->Kuu + msq, kstride, h->Linv, msq, Mp, Dl);
         GramArgs gk{};
@@ -463,7 +478,14 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
             pg.F = h->F; pg.f_stride = (size_t)Tp * Mp; pg.rowsq = h->rowsq; pg.Tp = Tp; pg.Mp = Mp; pg.Dl = Dl;
             pg.b0 = s0 * Dl; pg.nb = ns * Dl;
             launch_proj_gemm(s, pg);                                  // tilde_F = Knm Lm^-T, sum F^2  (:242,:255)
-        } else launch_project(s, pa);
+        } else {
+            if (grad_a) {                       // the backward pass of the explicit-U branch needs K_fu itself
+                pa.F = h->F;
+                launch_kfu_build(s, pa);
+                pa.F = nullptr;
+            }
+            launch_project(s, pa);
+        }
         if (st) st->mark(1);
         if (c.branch == FFVD_BRANCH_B) {
             GramArgs ga{};
@@ -642,7 +664,104 @@ extern "C" int ffvd_stage_times(ffvd_handle *h, double out_ms[8], int32_t out_la
 }
 
 // ---- backward pass (see grad.hip); runs on the handle's stream right after the forward kernels ----------
-static int enqueue_grad(ffvd_handle *h, int S_total) {
+// Backward pass of the explicit-U branch (closed form: oracle/ffvd_grad_oracle.py nll_grad_explicit_u).  The T x M work
+// reuses the collapsed branch's kernels: one Gram pass (G = K_uf K_fu and g_r = K_uf r per unit) and the fused E
+// product with Gamma := alpha K^-1 / 2, delta := r, u := beta = L^-T u; everything else is M x M per latent dim.
+static int enqueue_grad_a(ffvd_handle *h, int S_total) {
+    const ffvd_config &c = h->cfg;
+    ffvd_handle::GradWs &g = h->gw;
+    const int Mp = h->Mp, Tp = h->Tp, Dl = h->Dl, P = h->P, nb = h->nbatch, S = c.S_local;
+    const size_t msq = (size_t)Mp * Mp, kstride = 2 * msq, fstride = (size_t)Tp * Mp, gstride = (size_t)(Mp + NB) * Mp;
+    hipStream_t s = h->stream;
+    const ffvd_params &p = h->cur;
+    const double *W = h->Kuu + msq;                                                     // L^-T rows, per dim stride kstride
+    // beta = W u,  r = delta - mean,  dl/dalpha per unit
+    launch_ucols(s, p.U, c.M, Mp, c.D, c.d_begin, Dl, g.ucol);
+    launch_matvec(s, W, kstride, g.ucol, Mp, Mp, g.beta, 1, Mp, Mp, Dl);
+    launch_resid_a(s, p.X, h->fmean, h->rowsq, h->variance, p.log_Q, c.T, Tp, c.D, Dl, c.d_begin, h->ng, nb, g.r, g.dalpha);
+    // G = K_uf K_fu (lower tiles) and g_r = K_uf r (row Mp) per unit, then summed over the chains
+    GramArgs gg{};
+    gg.mode = GRAM_PLAIN; gg.A = h->F; gg.a_stride = fstride; gg.rows = Tp; gg.with_row = 1; gg.brow = Mp; gg.rvec = g.r;
+    gg.X = p.X; gg.log_Q = p.log_Q; gg.T = c.T; gg.D = c.D; gg.Mp = Mp; gg.Dl = Dl; gg.d_begin = c.d_begin; gg.b0 = 0; gg.nb = nb;
+    gg.yn_over_batch = 1.0; gg.H = g.Gu; gg.h_stride = gstride;
+    launch_gram(s, gg);
+    launch_chain_sum(s, g.Gu, gstride, S, Dl, (size_t)(Mp + 1) * Mp, g.Gsum, gstride);
+    // M x M chain per dim:  dW = alpha (g_r u^T + G W);  P = W dW^T W;  dL = -tril(P);  Phi = sym(tril(L^T dL), diag/2);
+    // dK = W Phi W^T;  E_psi = dK o K_uu.  Temporaries: Asum (G sym), Gs (T1), gsum (dW), P1, KGK, GamSum
+    HIP_TRY(hipMemcpy2DAsync(g.Asum, msq * sizeof(double), g.Gsum, gstride * sizeof(double), msq * sizeof(double), Dl,
+                             hipMemcpyDeviceToDevice, s));
+    launch_symmetrize(s, g.Asum, Mp, Dl);
+    AtbArgs ap{};
+    ap.mode = ATB_PLAIN; ap.lda = Mp; ap.nA = Mp; ap.ldb = Mp; ap.nB = Mp; ap.rows = Mp; ap.ldc = Mp; ap.nb = Dl; ap.Dl = Dl;
+    ap.c_stride = msq;
+    ap.A = g.Asum; ap.a_stride = msq; ap.B = W; ap.b_stride = kstride; ap.C = g.Gs;
+    launch_atb(s, ap);                                                                  // T1 = G W
+    launch_dw_a(s, g.Gs, g.Gsum + msq, gstride, g.ucol, p.log_Q, Mp, Dl, c.d_begin, g.gsum);   // dW
+    ap.A = g.gsum; ap.a_stride = msq; ap.B = W; ap.b_stride = kstride; ap.C = g.P1;
+    launch_atb(s, ap);                                                                  // Q1 = dW^T W
+    ap.A = h->Linv; ap.a_stride = msq; ap.B = g.P1; ap.b_stride = msq; ap.C = g.KGK;
+    launch_atb(s, ap);                                                                  // P = W Q1
+    launch_tril_neg(s, g.KGK, Mp, Dl, g.GamSum);                                        // dL
+    launch_tril_copy(s, h->Kuu, kstride, Mp, Dl, g.Lclean);
+    ap.A = g.Lclean; ap.a_stride = msq; ap.B = g.GamSum; ap.b_stride = msq; ap.C = g.P1;
+    launch_atb(s, ap);                                                                  // S = L^T dL
+    launch_phi(s, g.P1, Mp, Dl, g.KGK);                                                 // Phi
+    ap.A = g.KGK; ap.a_stride = msq; ap.B = h->Linv; ap.b_stride = msq; ap.C = g.P1;
+    launch_atb(s, ap);                                                                  // Q2 = Phi W^T
+    ap.A = h->Linv; ap.a_stride = msq; ap.B = g.P1; ap.b_stride = msq; ap.C = g.KGK;
+    launch_atb(s, ap);                                                                  // dK = W Q2
+    launch_epsi_a(s, g.KGK, h->Kcopy, c.M, Mp, Dl, c.jitter, g.Epsi);
+    EReduceArgs ek{};
+    ek.E = g.Epsi; ek.e_stride = msq; ek.Kf = nullptr; ek.u = nullptr; ek.x_is_z = 1; ek.Z = p.Z; ek.len = h->len;
+    ek.T = c.M; ek.Tp = Mp; ek.M = c.M; ek.Mp = Mp; ek.P = P; ek.Dl = Dl; ek.b0 = 0; ek.nb = Dl; ek.nblk = Mp / 64;
+    ek.rsum = g.rsum2; ek.ez = g.ez2; ek.kfu = nullptr; ek.cs_part = g.cs2; ek.etx_part = g.etx2; ek.rx2_part = g.rx22;
+    launch_e_reduce(s, ek);
+    launch_e_finish(s, ek, g.dz_kuu, g.dll_kuu, g.dls_kuu);
+    // du = W^T g_r (per dim) for dU
+    launch_matvec(s, h->Linv, msq, g.Gsum + msq, gstride, Mp, g.du, 1, Mp, Mp, Dl);
+    // K_fu side: E = (alpha K_fu K^-1 + alpha r beta^T) o K_fu, reduced in the fused kernel
+    launch_scale_kinv(s, h->Kinv, p.log_Q, Mp, Dl, c.d_begin, g.GammaA);
+    EReduceArgs er{};
+    er.E = nullptr; er.e_stride = fstride; er.Kf = h->F; er.u = g.beta; er.u_stride = Mp; er.x_is_z = 0;
+    er.x = p.X; er.x_chain_stride = (size_t)(c.T + 1) * c.D; er.x_ld = c.D; er.x_cols = c.D; er.ctrl = h->ctrl; er.C = c.C;
+    er.Z = p.Z; er.len = h->len; er.T = c.T; er.Tp = Tp; er.M = c.M; er.Mp = Mp; er.P = P; er.Dl = Dl; er.b0 = 0; er.nb = nb;
+    er.nblk = Tp / 64; er.rsum = g.rsum; er.ez = g.ez; er.kfu = g.kfu; er.cs_part = g.cs_part; er.etx_part = g.etx_part;
+    er.rx2_part = g.rx2_part;
+    BwdFusedArgs bf{};
+    bf.Kf = h->F; bf.kf_stride = fstride; bf.Gamma = g.GammaA; bf.g_stride = msq; bf.u = g.beta; bf.u_stride = Mp;
+    bf.per_dim = 1; bf.rvec = g.r;
+    bf.X = p.X; bf.ctrl = h->ctrl; bf.Z = p.Z; bf.log_Q = p.log_Q; bf.T = c.T; bf.Tp = Tp; bf.D = c.D; bf.C = c.C;
+    bf.M = c.M; bf.Mp = Mp; bf.P = P; bf.Dl = Dl; bf.d_begin = c.d_begin; bf.b0 = 0; bf.nb = nb; bf.rp = g.rp;
+    bf.cs_part = g.cs_part; bf.etx_part = g.etx_part; bf.rsum = g.rsum; bf.ez = g.ez; bf.kfu = g.kfu; bf.rx2_part = g.rx2_part;
+    launch_bwd_fused(s, bf);
+    launch_e_finish(s, er, g.dz_unit, g.dll_unit, g.dls_unit);
+    DxArgs dx{};
+    dx.X = p.X; dx.Y = h->Y; dx.CC = p.CC; dx.DD = p.DD; dx.log_Rchols = p.log_Rchols; dx.log_Q = p.log_Q; dx.len = h->len;
+    dx.rsum = g.rsum; dx.ez = g.ez; dx.kfu = g.kfu; dx.S = S; dx.S_total = S_total; dx.T = c.T; dx.Tp = Tp; dx.D = c.D;
+    dx.P = P; dx.Ydim = c.Ydim; dx.Dl = Dl; dx.d_begin = c.d_begin; dx.shared_terms = c.shared_terms; dx.dX = g.dX;
+    launch_dx(s, dx);
+    launch_shared_partials(s, dx, g.shared_part, g.sp_stride);
+    GradFinalArgs gf{};
+    gf.T = c.T; gf.D = c.D; gf.P = P; gf.M = c.M; gf.Mp = Mp; gf.Ydim = c.Ydim; gf.Dl = Dl; gf.d_begin = c.d_begin; gf.S = S;
+    gf.S_total = S_total; gf.shared_terms = c.shared_terms; gf.prior_type = c.prior_type;
+    gf.Z = p.Z; gf.logvar = p.logvariance; gf.loglen = p.loglengthscales; gf.log_Q = p.log_Q; gf.CC = p.CC; gf.DD = p.DD;
+    gf.log_Rchols = p.log_Rchols; gf.dz_unit = g.dz_unit; gf.dll_unit = g.dll_unit; gf.dls_unit = g.dls_unit;
+    gf.dz_kuu = g.dz_kuu; gf.dll_kuu = g.dll_kuu; gf.dls_kuu = g.dls_kuu; gf.shared_part = g.shared_part;
+    gf.sp_stride = g.sp_stride; gf.dZ = g.dZ; gf.dlogvar = g.dlogvar; gf.dloglen = g.dloglen; gf.dlogQ = g.dlogQ;
+    gf.dCC = g.dCC; gf.dDD = g.dDD; gf.dlogR = g.dlogR;
+    gf.branch_a = 1; gf.dalpha_unit = g.dalpha; gf.du_dim = g.du; gf.U = p.U; gf.dU = g.dU;
+    HIP_TRY(hipMemsetAsync(g.dlogvar, 0, (size_t)c.D * sizeof(double), s));
+    HIP_TRY(hipMemsetAsync(g.dloglen, 0, (size_t)c.D * P * sizeof(double), s));
+    HIP_TRY(hipMemsetAsync(g.dlogQ, 0, (size_t)c.D * sizeof(double), s));
+    HIP_TRY(hipMemsetAsync(g.dCC, 0, (size_t)c.D * c.Ydim * sizeof(double), s));
+    HIP_TRY(hipMemsetAsync(g.dDD, 0, (size_t)c.Ydim * sizeof(double), s));
+    HIP_TRY(hipMemsetAsync(g.dlogR, 0, (size_t)c.Ydim * c.Ydim * sizeof(double), s));
+    launch_grad_finalize(s, gf);
+    HIP_TRY(hipGetLastError());
+    return FFVD_OK;
+}
+
+static int enqueue_grad_b(ffvd_handle *h, int S_total) {
     const ffvd_config &c = h->cfg;
     ffvd_handle::GradWs &g = h->gw;
     const int Mp = h->Mp, Tp = h->Tp, Dl = h->Dl, P = h->P, nb = h->nbatch, S = c.S_local;
@@ -734,6 +853,10 @@ static int enqueue_grad(ffvd_handle *h, int S_total) {
     return FFVD_OK;
 }
 
+static int enqueue_grad(ffvd_handle *h, int S_total) {
+    return h->cfg.branch == FFVD_BRANCH_A ? enqueue_grad_a(h, S_total) : enqueue_grad_b(h, S_total);
+}
+
 extern "C" int ffvd_elbo_grad(ffvd_handle *h, const ffvd_params *p, uint32_t flags, int S_total, double out_terms[8],
                               double *out_nll, const ffvd_grads *gout) {
     if (!h) return set_error(nullptr, FFVD_EINVAL, "ffvd_elbo_grad: null handle");
@@ -769,6 +892,10 @@ extern "C" int ffvd_elbo_grad(ffvd_handle *h, const ffvd_params *p, uint32_t fla
     if (gout->CC) HIP_TRY(hipMemcpyAsync(gout->CC, g.dCC, (size_t)c.D * J * sizeof(double), hipMemcpyDeviceToHost, s));
     if (gout->DD) HIP_TRY(hipMemcpyAsync(gout->DD, g.dDD, J * sizeof(double), hipMemcpyDeviceToHost, s));
     if (gout->log_Rchols) HIP_TRY(hipMemcpyAsync(gout->log_Rchols, g.dlogR, J * J * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (gout->U) {
+        if (g.dU) HIP_TRY(hipMemcpyAsync(gout->U, g.dU, (size_t)c.M * c.D * sizeof(double), hipMemcpyDeviceToHost, s));
+        else memset(gout->U, 0, (size_t)c.M * c.D * sizeof(double));        // collapsed branch: U is integrated out
+    }
     HIP_TRY(hipStreamSynchronize(s));
     if ((rc = check_info(h))) return rc;
     if (out_terms) memcpy(out_terms, h->h_out, 8 * sizeof(double));
@@ -777,27 +904,29 @@ extern "C" int ffvd_elbo_grad(ffvd_handle *h, const ffvd_params *p, uint32_t fla
 }
 
 // ---- optimiser steps on the resident parameters --------------------------------------
-static void param_table(ffvd_handle *h, double *theta[8], const double *grad[8], size_t n[8]) {
+static constexpr int NPARAM = 9;       // order of the FFVD_TRAIN_* bits: X, Z, logvariance, loglengthscales, log_Q, CC, DD, log_Rchols, U
+static void param_table(ffvd_handle *h, double *theta[NPARAM], const double *grad[NPARAM], size_t n[NPARAM]) {
     const ffvd_config &c = h->cfg;
     const size_t P = h->P, J = c.Ydim;
     const ffvd_handle::GradWs &g = h->gw;
     const ffvd_params &p = h->cur;
-    double *th[8] = {const_cast<double *>(p.X), const_cast<double *>(p.Z), const_cast<double *>(p.logvariance),
-                     const_cast<double *>(p.loglengthscales), const_cast<double *>(p.log_Q), const_cast<double *>(p.CC),
-                     const_cast<double *>(p.DD), const_cast<double *>(p.log_Rchols)};
-    const double *gr[8] = {g.dX, g.dZ, g.dlogvar, g.dloglen, g.dlogQ, g.dCC, g.dDD, g.dlogR};
-    const size_t nn[8] = {(size_t)c.S_local * (c.T + 1) * c.D, (size_t)c.M * P, (size_t)c.D, (size_t)c.D * P, (size_t)c.D,
-                          (size_t)c.D * J, J, J * J};
-    for (int i = 0; i < 8; ++i) { theta[i] = th[i]; grad[i] = gr[i]; n[i] = nn[i]; }
+    double *th[NPARAM] = {const_cast<double *>(p.X), const_cast<double *>(p.Z), const_cast<double *>(p.logvariance),
+                          const_cast<double *>(p.loglengthscales), const_cast<double *>(p.log_Q), const_cast<double *>(p.CC),
+                          const_cast<double *>(p.DD), const_cast<double *>(p.log_Rchols), const_cast<double *>(p.U)};
+    const double *gr[NPARAM] = {g.dX, g.dZ, g.dlogvar, g.dloglen, g.dlogQ, g.dCC, g.dDD, g.dlogR, g.dU};
+    const size_t nn[NPARAM] = {(size_t)c.S_local * (c.T + 1) * c.D, (size_t)c.M * P, (size_t)c.D, (size_t)c.D * P, (size_t)c.D,
+                               (size_t)c.D * J, J, J * J, g.dU ? (size_t)c.M * c.D : 0};      // U only where it has a gradient
+    for (int i = 0; i < NPARAM; ++i) { theta[i] = th[i]; grad[i] = gr[i]; n[i] = nn[i]; }
 }
 
 extern "C" int ffvd_optimizer_reset(ffvd_handle *h) {
     if (!h) return set_error(nullptr, FFVD_EINVAL, "ffvd_optimizer_reset: null handle");
     if (!h->cfg.grad) return set_error(h, FFVD_EINVAL, "ffvd_optimizer_reset: the handle was created without grad = 1");
     HIP_TRY(hipSetDevice(h->cfg.device_id));
-    double *theta[8]; const double *grad[8]; size_t n[8];
+    double *theta[NPARAM]; const double *grad[NPARAM]; size_t n[NPARAM];
     param_table(h, theta, grad, n);
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NPARAM; ++i) {
+        if (!n[i]) continue;
         if (!h->adam_m[i]) { HIP_TRY(dev_alloc(h, &h->adam_m[i], n[i])); HIP_TRY(dev_alloc(h, &h->adam_v[i], n[i])); }
         HIP_TRY(hipMemsetAsync(h->adam_m[i], 0, n[i] * sizeof(double), h->stream));
         HIP_TRY(hipMemsetAsync(h->adam_v[i], 0, n[i] * sizeof(double), h->stream));
@@ -827,10 +956,10 @@ extern "C" int ffvd_adam_step(ffvd_handle *h, double lr, double beta1, double be
     HIP_TRY(hipMemcpyAsync(h->h_info, h->info, (size_t)(h->Dl + h->nbatch) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     if ((rc = check_info(h))) return rc;           // a failed factorisation leaves the parameters untouched
-    double *theta[8]; const double *grad[8]; size_t n[8];
+    double *theta[NPARAM]; const double *grad[NPARAM]; size_t n[NPARAM];
     param_table(h, theta, grad, n);
     OptTable tab{};
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NPARAM; ++i) {
         if (!(train_mask & (1u << i)) || n[i] == 0) continue;
         OptTensor &t = tab.t[tab.count++];
         t.theta = theta[i]; t.grad = grad[i]; t.s0 = h->adam_m[i]; t.s1 = h->adam_v[i]; t.n = (int64_t)n[i];
@@ -896,12 +1025,12 @@ extern "C" int ffvd_sghmc_step(ffvd_handle *h, double epsilon, double mdecay, ui
     HIP_TRY(hipSetDevice(h->cfg.device_id));
     int rc;
     if ((rc = ready(h, "ffvd_sghmc_step"))) return rc;
-    double *theta[8]; const double *grad[8]; size_t n[8];
+    double *theta[NPARAM]; const double *grad[NPARAM]; size_t n[NPARAM];
     param_table(h, theta, grad, n);
-    const double *nz[8] = {noise->X, noise->Z, noise->logvariance, noise->loglengthscales, noise->log_Q, noise->CC, noise->DD,
-                           noise->log_Rchols};
+    const double *nz[NPARAM] = {noise->X, noise->Z, noise->logvariance, noise->loglengthscales, noise->log_Q, noise->CC,
+                                noise->DD, noise->log_Rchols, noise->U};
     hipStream_t s = h->stream;
-    for (int i = 1; i < 8; ++i) {
+    for (int i = 1; i < NPARAM; ++i) {
         if (!(sample_mask & (1u << i)) || n[i] == 0) continue;
         if (!nz[i]) return set_error(h, FFVD_EINVAL, "ffvd_sghmc_step: a sampled array has no noise array");
         if (!h->hmc[i][0]) {            // xi, g, g2 <- 1, p <- 0 (base_model.py:151-154)
@@ -921,7 +1050,7 @@ extern "C" int ffvd_sghmc_step(ffvd_handle *h, double epsilon, double mdecay, ui
     HIP_TRY(hipStreamSynchronize(s));
     if ((rc = check_info(h))) return rc;
     OptTable tab{};
-    for (int i = 1; i < 8; ++i) {
+    for (int i = 1; i < NPARAM; ++i) {
         if (!(sample_mask & (1u << i)) || n[i] == 0) continue;
         OptTensor &t = tab.t[tab.count++];
         t.theta = theta[i]; t.grad = grad[i]; t.s0 = h->hmc[i][0]; t.s1 = h->hmc[i][1]; t.s2 = h->hmc[i][2];

@@ -55,8 +55,10 @@ void launch_e_finish(hipStream_t stream, const EReduceArgs &a, double *dz_unit, 
 // is formed tile by tile in the accumulators and never reaches HBM; every reduction of it runs on the matrix cores.
 struct BwdFusedArgs {
     const double *Kf; size_t kf_stride;         // [nb] Tp x Mp, row-major (K_fu)
-    const double *Gamma; size_t g_stride;       // [nb] Mp x Mp
-    const double *u; size_t u_stride;           // [nb] Mp
+    const double *Gamma; size_t g_stride;       // [nb] Mp x Mp ([Dl] when per_dim)
+    const double *u; size_t u_stride;           // [nb] Mp ([Dl] when per_dim)
+    int per_dim;                                // explicit-U branch: Gamma and u are indexed by latent dim, not by unit
+    const double *rvec;                         // explicit-U branch: [nb][Tp] residuals used in place of delta
     const double *X; const double *ctrl;        // chains S x (T+1) x D; control inputs T x C
     const double *Z;                            // M x P
     const double *log_Q;
@@ -99,7 +101,25 @@ struct GradFinalArgs {
     const double *hterms, *uku;                        // forward {logdet, quad}; u^T K u per unit
     const double *shared_part; int sp_stride;          // per-chain likelihood / transition partials
     double *dZ, *dlogvar, *dloglen, *dlogQ, *dCC, *dDD, *dlogR;
+    // explicit-U branch (branch_a != 0): dl/dalpha per unit replaces the collapsed formula, the transition part of the
+    // shared partials is not added (it lives in dalpha), and dU is assembled from du_dim = W^T g_r (per dim)
+    int branch_a;
+    const double *dalpha_unit, *du_dim, *U;
+    double *dU;
 };
 void launch_grad_finalize(hipStream_t stream, const GradFinalArgs &a);
+
+// ---- explicit-U branch helpers (see grad.hip) ----
+void launch_ucols(hipStream_t stream, const double *U, int M, int Mp, int D, int d_begin, int Dl, double *ucol);
+void launch_resid_a(hipStream_t stream, const double *X, const double *fmean, const double *rowsq, const double *variance,
+                    const double *log_Q, int T, int Tp, int D, int Dl, int d_begin, int ng, int nb, double *r,
+                    double *dalpha_unit);
+void launch_scale_kinv(hipStream_t stream, const double *Kinv, const double *log_Q, int Mp, int Dl, int d_begin, double *out);
+void launch_dw_a(hipStream_t stream, const double *T1, const double *grs, size_t grs_stride, const double *ucol,
+                 const double *log_Q, int Mp, int Dl, int d_begin, double *dW);
+void launch_tril_neg(hipStream_t stream, const double *P, int Mp, int Dl, double *out);
+void launch_tril_copy(hipStream_t stream, const double *L, size_t l_stride, int Mp, int Dl, double *out);
+void launch_phi(hipStream_t stream, const double *S, int Mp, int Dl, double *Phi);
+void launch_epsi_a(hipStream_t stream, const double *dK, const double *Kcopy, int M, int Mp, int Dl, double jitter, double *E);
 
 }  // namespace ffvd

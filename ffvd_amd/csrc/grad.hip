@@ -221,12 +221,13 @@ __global__ __launch_bounds__(512, 4) void bwd_fused_kernel(BwdFusedArgs a) {
     const int I0 = ti * 128 + wr * 64, J0 = tj * 128 + wc * 32;
     const int Mp = a.Mp, Tp = a.Tp, P = a.P;
     const double *Kfb = a.Kf + (size_t)bz * a.kf_stride;
-    const double *Gb = a.Gamma + (size_t)bz * a.g_stride;
+    const int unit_or_dim = a.per_dim ? (a.b0 + bz) % a.Dl : bz;
+    const double *Gb = a.Gamma + (size_t)unit_or_dim * a.g_stride;
     const int colB = tj * 128 + 2 * lane;
     const bool okB = colB < Mp;
     const int colBc = okB ? colB : 0;
     const int rowl = tid >> 6;
-    const int arow = ti * 128 + (tid >> 2), aseg = 4 * (tid & 3);       // arow < Tp always (Tp multiple of 128? no: of 64)
+    const int arow = ti * 128 + (tid >> 2), aseg = 4 * (tid & 3);
     const bool okAr = arow < Tp;
     const double *Arow = Kfb + (size_t)(okAr ? arow : 0) * Mp + aseg;
 
@@ -284,8 +285,9 @@ __global__ __launch_bounds__(512, 4) void bwd_fused_kernel(BwdFusedArgs a) {
     // ---------------- epilogue ----------------
     const int b = a.b0 + bz, s = b / a.Dl, dl = b % a.Dl, dg = a.d_begin + dl;
     const double alpha = 1.0 / exp(a.log_Q[dg]);
-    const double *ub = a.u + (size_t)bz * a.u_stride;
+    const double *ub = a.u + (size_t)unit_or_dim * a.u_stride;
     const double *Xs = a.X + (size_t)s * (a.T + 1) * a.D;
+    const double *rv = a.rvec ? a.rvec + (size_t)bz * Tp : nullptr;
     double *sm = &As[0][0][0];                 // 4608 doubles: XW [8][XW_LD] | Vs [8][XW_LD] | kfu_s [4][128]
     double *sb = &Bs[0][0][0];                 // 4608 doubles: per-wavefront transpose patches, then the row partials
     double *XW = sm, *Vs = sm + 8 * XW_LD, *kfu_s = sm + 16 * XW_LD;
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(512, 4) void bwd_fused_kernel(BwdFusedArgs a) {
             for (int q = 0; q < 4; ++q) {
                 const int i = I0 + 16 * x + lk + 4 * q;
                 const bool iok = i < Tp;
-                const double rowv = (i < a.T) ? alpha * (Xs[(size_t)(i + 1) * a.D + dg] - Xs[(size_t)i * a.D + dg]) : 0.0;
+                const double rowv = (i < a.T) ? alpha * (rv ? rv[i] : Xs[(size_t)(i + 1) * a.D + dg] - Xs[(size_t)i * a.D + dg]) : 0.0;
                 double ks_ = 0.0;
 #pragma unroll
                 for (int y = 0; y < 2; ++y) {
@@ -957,6 +959,10 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(GradFinalArgs a) {
         for (int s = 0; s < S; ++s) {
             const size_t bb = (size_t)s * Dl + dl;
             ls += a.dls_unit[bb] - 0.5 * alpha * Tn * s2;            // K_fu side + direct Kdiag term
+            if (a.branch_a) {                                        // explicit U: dl/dalpha comes per unit from resid_a
+                dq += a.dalpha_unit[bb] * (-alpha);
+                continue;
+            }
             // dl/dalpha = -1/2 tr(A^-1 G) + u^T g - 1/2 u^T G u - 1/2 (T s2 - tr(K^-1 G)),  G = (A - K)/alpha
             double trAK = 0.0;
             for (int t = 0; t < a.ngam; ++t) trAK += a.gam_part[bb * a.ngam + t];
@@ -971,7 +977,7 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(GradFinalArgs a) {
         }
         ls += a.dls_kuu[dl];
         a.dlogvar[dg] = -ls / Tn / Sn + w * (a.logvar[dg] - log(0.05)) / Tn;
-        a.dlogQ[dg] = -dq / Tn / Sn + tq / Sn + w * a.log_Q[dg] / Tn;
+        a.dlogQ[dg] = -dq / Tn / Sn + (a.branch_a ? 0.0 : tq / Sn) + w * a.log_Q[dg] / Tn;
     }
     if (a.shared_terms) {
         for (int idx = tid; idx < D * J + J; idx += 256) {
@@ -991,6 +997,19 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(GradFinalArgs a) {
         }
     }
 }
+// explicit-U branch: dU[m][d] = -(alpha_d (W^T g_r)[m]) / T / S_total + (S / S_total) U[m][d] / T   (prior_U, choice 1)
+__global__ void grad_du_kernel(GradFinalArgs a) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.M * a.D) return;
+    const int m = idx / a.D, d = idx % a.D, dl = d - a.d_begin;
+    double g = 0.0;
+    if (dl >= 0 && dl < a.Dl) {
+        const double alpha = 1.0 / exp(a.log_Q[d]);
+        g = -(alpha * a.du_dim[(size_t)dl * a.Mp + m]) / (double)a.T / (double)a.S_total
+            + ((double)a.S / (double)a.S_total) * a.U[idx] / (double)a.T;
+    }
+    a.dU[idx] = g;
+}
 // dZ[m][p]: fixed-order sum over units of the K_fu-side parts (scaled -1/T, mean over chains) + K_uu side + prior
 __global__ __launch_bounds__(256) void grad_dz_kernel(GradFinalArgs a) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -1008,7 +1027,127 @@ __global__ __launch_bounds__(256) void grad_dz_kernel(GradFinalArgs a) {
 }
 void launch_grad_finalize(hipStream_t stream, const GradFinalArgs &a) {
     hipLaunchKernelGGL(grad_dz_kernel, dim3((a.M * a.P + 255) / 256), dim3(256), 0, stream, a);
+    if (a.branch_a && a.dU) hipLaunchKernelGGL(grad_du_kernel, dim3((a.M * a.D + 255) / 256), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(grad_finalize_kernel, dim3(1), dim3(256), 0, stream, a);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Explicit-U branch (dgp_model.py:289-297, conditional/base_conditional): small kernels of its backward pass.
+// Closed form and notation: oracle/ffvd_grad_oracle.py nll_grad_explicit_u.
+// ---------------------------------------------------------------------------------------------
+// ucol[dl][m] = U[m][d_begin + dl]  (zero padded to Mp)
+__global__ void ucols_kernel(const double *U, int M, int Mp, int D, int d_begin, double *ucol) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x, dl = blockIdx.y;
+    if (m < Mp) ucol[(size_t)dl * Mp + m] = (m < M) ? U[(size_t)m * D + d_begin + dl] : 0.0;
+}
+void launch_ucols(hipStream_t stream, const double *U, int M, int Mp, int D, int d_begin, int Dl, double *ucol) {
+    hipLaunchKernelGGL(ucols_kernel, dim3((Mp + 255) / 256, Dl), dim3(256), 0, stream, U, M, Mp, D, d_begin, ucol);
+}
+// r[b][t] = delta_t - mean_t (0 for t >= T);  dalpha[b] = -1/2 sum r^2 - 1/2 sum_t (sigma^2 - |F_t|^2) + T / (2 alpha)
+__global__ __launch_bounds__(256) void resid_a_kernel(const double *X, const double *fmean, const double *rowsq,
+                                                      const double *variance, const double *log_Q, int T, int Tp, int D,
+                                                      int Dl, int d_begin, int ng, double *r, double *dalpha_unit) {
+    __shared__ double scratch[256];
+    const int b = blockIdx.x, tid = threadIdx.x, s = b / Dl, dl = b % Dl, dg = d_begin + dl;
+    const double *Xs = X + (size_t)s * (T + 1) * D;
+    const double s2 = variance[dl];
+    double sr = 0.0, sv = 0.0;
+    for (int t = tid; t < Tp; t += 256) {
+        double rt = 0.0;
+        if (t < T) {
+            double fm = 0.0, rs = 0.0;
+            for (int g = 0; g < ng; ++g) {
+                fm += fmean[((size_t)b * ng + g) * Tp + t];
+                rs += rowsq[((size_t)b * ng + g) * Tp + t];
+            }
+            rt = (Xs[(size_t)(t + 1) * D + dg] - Xs[(size_t)t * D + dg]) - fm;
+            sr += rt * rt;
+            sv += s2 - rs;
+        }
+        r[(size_t)b * Tp + t] = rt;
+    }
+    sr = block_sum(sr, scratch);
+    sv = block_sum(sv, scratch);
+    if (tid == 0) dalpha_unit[b] = -0.5 * sr - 0.5 * sv + 0.5 * (double)T * exp(log_Q[dg]);
+}
+void launch_resid_a(hipStream_t stream, const double *X, const double *fmean, const double *rowsq, const double *variance,
+                    const double *log_Q, int T, int Tp, int D, int Dl, int d_begin, int ng, int nb, double *r,
+                    double *dalpha_unit) {
+    hipLaunchKernelGGL(resid_a_kernel, dim3(nb), dim3(256), 0, stream, X, fmean, rowsq, variance, log_Q, T, Tp, D, Dl,
+                       d_begin, ng, r, dalpha_unit);
+}
+// out = 1/2 alpha_d K^-1   (plays the role of Gamma in the fused backward product)
+__global__ void scale_kinv_kernel(const double *Kinv, const double *log_Q, int Mp, int d_begin, double *out) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)Mp * Mp) return;
+    const int dl = blockIdx.y;
+    const size_t o = (size_t)dl * Mp * Mp + idx;
+    out[o] = 0.5 / exp(log_Q[d_begin + dl]) * Kinv[o];
+}
+void launch_scale_kinv(hipStream_t stream, const double *Kinv, const double *log_Q, int Mp, int Dl, int d_begin, double *out) {
+    hipLaunchKernelGGL(scale_kinv_kernel, dim3((unsigned)(((size_t)Mp * Mp + 255) / 256), Dl), dim3(256), 0, stream, Kinv,
+                       log_Q, Mp, d_begin, out);
+}
+// dW[k][j] = alpha (g_r[k] u[j] + (G W)[k][j])
+__global__ void dw_a_kernel(const double *T1, const double *grs, size_t grs_stride, const double *ucol, const double *log_Q,
+                            int Mp, int d_begin, double *dW) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)Mp * Mp) return;
+    const int dl = blockIdx.y, k = (int)(idx / Mp), j = (int)(idx % Mp);
+    const double alpha = 1.0 / exp(log_Q[d_begin + dl]);
+    const size_t o = (size_t)dl * Mp * Mp + idx;
+    dW[o] = alpha * (grs[(size_t)dl * grs_stride + k] * ucol[(size_t)dl * Mp + j] + T1[o]);
+}
+void launch_dw_a(hipStream_t stream, const double *T1, const double *grs, size_t grs_stride, const double *ucol,
+                 const double *log_Q, int Mp, int Dl, int d_begin, double *dW) {
+    hipLaunchKernelGGL(dw_a_kernel, dim3((unsigned)(((size_t)Mp * Mp + 255) / 256), Dl), dim3(256), 0, stream, T1, grs,
+                       grs_stride, ucol, log_Q, Mp, d_begin, dW);
+}
+// out = -tril(P)
+__global__ void tril_neg_kernel(const double *P, int Mp, double *out) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)Mp * Mp) return;
+    const int i = (int)(idx / Mp), j = (int)(idx % Mp);
+    const size_t o = (size_t)blockIdx.y * Mp * Mp + idx;
+    out[o] = (j <= i) ? -P[o] : 0.0;
+}
+void launch_tril_neg(hipStream_t stream, const double *P, int Mp, int Dl, double *out) {
+    hipLaunchKernelGGL(tril_neg_kernel, dim3((unsigned)(((size_t)Mp * Mp + 255) / 256), Dl), dim3(256), 0, stream, P, Mp, out);
+}
+// out = tril(L) from the factor slab (whose upper triangle holds don't-care values)
+__global__ void tril_copy_kernel(const double *L, size_t l_stride, int Mp, double *out) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)Mp * Mp) return;
+    const int i = (int)(idx / Mp), j = (int)(idx % Mp);
+    out[(size_t)blockIdx.y * Mp * Mp + idx] = (j <= i) ? L[(size_t)blockIdx.y * l_stride + idx] : 0.0;
+}
+void launch_tril_copy(hipStream_t stream, const double *L, size_t l_stride, int Mp, int Dl, double *out) {
+    hipLaunchKernelGGL(tril_copy_kernel, dim3((unsigned)(((size_t)Mp * Mp + 255) / 256), Dl), dim3(256), 0, stream, L,
+                       l_stride, Mp, out);
+}
+// Phi = sym(tril(S) with the diagonal halved)   (Cholesky adjoint)
+__global__ void phi_kernel(const double *S, int Mp, double *Phi) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)Mp * Mp) return;
+    const int i = (int)(idx / Mp), j = (int)(idx % Mp);
+    const double *Sd = S + (size_t)blockIdx.y * Mp * Mp;
+    const double lo = (i >= j) ? Sd[(size_t)i * Mp + j] : Sd[(size_t)j * Mp + i];      // tril entry of the pair (i, j)
+    Phi[(size_t)blockIdx.y * Mp * Mp + idx] = 0.5 * lo;       // off-diagonal: (t_ij + 0)/2; diagonal: (s_ii/2 + s_ii/2)/2
+}
+void launch_phi(hipStream_t stream, const double *S, int Mp, int Dl, double *Phi) {
+    hipLaunchKernelGGL(phi_kernel, dim3((unsigned)(((size_t)Mp * Mp + 255) / 256), Dl), dim3(256), 0, stream, S, Mp, Phi);
+}
+// E = dK o K_uu (without the jitter on the diagonal), zero in the padding
+__global__ void epsi_a_kernel(const double *dK, const double *Kcopy, int M, int Mp, double jitter, double *E) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)Mp * Mp) return;
+    const int i = (int)(idx / Mp), j = (int)(idx % Mp);
+    const size_t o = (size_t)blockIdx.y * Mp * Mp + idx;
+    E[o] = (i < M && j < M) ? dK[o] * (Kcopy[o] - ((i == j) ? jitter : 0.0)) : 0.0;
+}
+void launch_epsi_a(hipStream_t stream, const double *dK, const double *Kcopy, int M, int Mp, int Dl, double jitter, double *E) {
+    hipLaunchKernelGGL(epsi_a_kernel, dim3((unsigned)(((size_t)Mp * Mp + 255) / 256), Dl), dim3(256), 0, stream, dK, Kcopy, M,
+                       Mp, jitter, E);
 }
 
 }  // namespace ffvd

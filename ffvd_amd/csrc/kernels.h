@@ -82,6 +82,7 @@ struct GramArgs {
     int with_row;           // 1: also write the extra row `brow` = scale * delta^T A (needs X, T, D)
     int brow;               // row index of that extra row in the output slab (0 = default Mp)
     const double *X;        // [S][T+1][D]
+    const double *rvec;     // optional [nb][rows]: the extra row is rvec^T A instead of delta^T A
     const double *log_Q;    // [D] (global dim index)
     int T, D, Mp, Dl, d_begin;
     int b0, nb;             // batches [b0, b0 + nb): b = s*Dl + dl

@@ -5,7 +5,7 @@
 
 namespace ffvd {
 
-constexpr int OPT_MAX_TENSORS = 8;
+constexpr int OPT_MAX_TENSORS = 10;
 struct OptTensor {
     double *theta;          // parameter, updated in place
     const double *grad;

@@ -86,8 +86,9 @@ class DGPSSM:
             self.vars += ["Z"]
         if hyperparameter_sampling:                                              # :244-246
             self.vars += ["log_Q", "CC", "DD", "log_Rchols"]
-        self._adam_train = tuple(k for k in ("X", "Z", "logvariance", "loglengthscales", "log_Q", "CC", "DD", "log_Rchols")
-                                 if k not in self.vars)
+        self._adam_train = tuple(k for k in ("X", "Z", "logvariance", "loglengthscales", "log_Q", "CC", "DD", "log_Rchols",
+                                             "U")
+                                 if k not in self.vars and not (k == "U" and self.U_collapse))
         self._rng = np.random.default_rng()
         self.window = []
         self._resident = False      # device copy of the parameters is current (set by train_hypers)
@@ -152,7 +153,7 @@ class DGPSSM:
         shapes = {"Z": self.layers[-1].Z.shape, "logvariance": (self.output_dim,),
                   "loglengthscales": (self.output_dim, self.engine.P), "log_Q": (self.output_dim,),
                   "CC": self.likelihood.CC.shape, "DD": self.likelihood.DD.shape,
-                  "log_Rchols": self.likelihood.log_Rchols.shape}
+                  "log_Rchols": self.likelihood.log_Rchols.shape, "U": self.layers[-1].U.shape}
         return {k: self._rng.standard_normal(shapes[k]) for k in self.vars}
 
     def _ensure_resident(self):
@@ -163,10 +164,8 @@ class DGPSSM:
     def sghmc_step(self):
         """BaseModel.sghmc_step (base_model.py:915-933): burn_in_op, then 10 x (burn_in_op, sample_op) on
         `self.vars` -- each one forward + backward + SG-HMC update on the device -- and the current values of the
-        variables join the window.  With an empty variable list (case 4) the ops are no-ops."""
-        if "U" in self.vars:
-            raise NotImplementedError("SG-HMC on U needs the gradient of the explicit-U branch (cases 2, 3); "
-                                      "ffvd_amd.optim.sghmc_step is the update operator")
+        variables join the window.  With an empty variable list (cases 1, 4, 6) the ops are no-ops; cases 2 and 3 sample
+        the kernel hyper-parameters, U (and Z), case 5 the kernel hyper-parameters."""
         if not self.vars:
             self.window.append({})
         else:
@@ -203,6 +202,8 @@ class DGPSSM:
         lay = self.layers[-1]
         self._X_chains = g["X"]
         lay.X, lay.Z = g["X"][0], g["Z"]
+        if not self.U_collapse:
+            lay.U = g["U"]
         for d, k in enumerate(lay.kernel):
             k.logvariance = np.float64(g["logvariance"][d])
             if hasattr(k, "loglengthscales"):

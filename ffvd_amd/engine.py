@@ -148,7 +148,7 @@ class ElboEngine:
 
     def nll_and_grad(self, params=None, S_total=None):
         """nll terms and the gradient of the mean-over-chains nll w.r.t. every parameter
-        (tf.gradients(nll, vars), base_model.py:148).  Needs grad=True, U_collapse=True, route="gram".
+        (tf.gradients(nll, vars), base_model.py:148).  Needs grad=True and SE kernels; collapsed branch: route="gram".
 
         Returns (terms dict, grads dict with keys X, Z, logvariance, loglengthscales, log_Q, CC, DD, log_Rchols).
         With chains sharded over ranks pass S_total = chains of the whole job and sum the shared-parameter
@@ -160,7 +160,7 @@ class ElboEngine:
             "X": np.zeros((self.S, self.T + 1, self.D)), "Z": np.zeros((self.M, self.P)),
             "logvariance": np.zeros(self.D), "loglengthscales": np.zeros((self.D, self.P)),
             "log_Q": np.zeros(self.D), "CC": np.zeros((self.D, self.Ydim)), "DD": np.zeros(self.Ydim),
-            "log_Rchols": np.zeros((self.Ydim, self.Ydim)),
+            "log_Rchols": np.zeros((self.Ydim, self.Ydim)), "U": np.zeros((self.M, self.D)),
         }
         gs = _lib.FfvdGrads(**{k: v.ctypes.data for k, v in g.items()})
         out = np.zeros(8)
@@ -197,7 +197,8 @@ class ElboEngine:
         if not self.grad:
             raise ValueError("engine was created without grad=True")
         shapes = {"Z": (self.M, self.P), "logvariance": (self.D,), "loglengthscales": (self.D, self.P),
-                  "log_Q": (self.D,), "CC": (self.D, self.Ydim), "DD": (self.Ydim,), "log_Rchols": (self.Ydim, self.Ydim)}
+                  "log_Q": (self.D,), "CC": (self.D, self.Ydim), "DD": (self.Ydim,), "log_Rchols": (self.Ydim, self.Ydim),
+                  "U": (self.M, self.D)}
         arrs, mask = {}, 0
         for k, v in noise.items():
             if k not in shapes:

@@ -131,7 +131,7 @@ int  ffvd_elbo(ffvd_handle *h, const ffvd_params *p, uint32_t flags, double out_
 int  ffvd_elbo_async(ffvd_handle *h, double *out_terms_dev);
 /* Gradient of the mean-over-chains nll w.r.t. every parameter (what the reference gets from tf.gradients(nll, vars),
  * base_model.py:148, and AdamOptimizer.minimize(nll), dgp_model.py:303-305).  Needs a handle created with
- * grad = 1, branch B, FFVD_ROUTE_GRAM, the SE kernel.  Host output pointers with
+ * grad = 1 and the SE kernel: the collapsed branch with FFVD_ROUTE_GRAM, or the explicit-U branch (P = D + C <= 6).  Host output pointers with
  * the shapes of ffvd_params; any of them may be NULL.  S_total = number of chains of the whole job (the divisor of
  * the mean).  Sharded jobs: every output is this handle's ADDITIVE share of the whole-job gradient -- entries of
  * dims it does not own are zero, prior gradients are weighted S_local / S_total (and the shared ones only added
@@ -146,6 +146,7 @@ typedef struct ffvd_grads {
     double *CC;              /* D x Ydim            */
     double *DD;              /* Ydim                */
     double *log_Rchols;      /* Ydim x Ydim         */
+    double *U;               /* M x D: explicit-U branch; zeros in the collapsed branch (U integrated out) */
 } ffvd_grads;
 int  ffvd_elbo_grad(ffvd_handle *h, const ffvd_params *p, uint32_t flags, int S_total, double out_terms[8],
                     double *out_nll, const ffvd_grads *g);
@@ -166,7 +167,8 @@ int  ffvd_elbo_grad(ffvd_handle *h, const ffvd_params *p, uint32_t flags, int S_
 #define FFVD_TRAIN_CC 32u
 #define FFVD_TRAIN_DD 64u
 #define FFVD_TRAIN_LOG_RCHOLS 128u
-#define FFVD_TRAIN_ALL 255u
+#define FFVD_TRAIN_U 256u            /* explicit-U branch only; ignored where U is integrated out */
+#define FFVD_TRAIN_ALL 511u
 int  ffvd_adam_step(ffvd_handle *h, double lr, double beta1, double beta2, double eps, uint32_t train_mask,
                     double out_terms[8], double *out_nll);
 int  ffvd_optimizer_reset(ffvd_handle *h);

@@ -105,3 +105,86 @@ def nll_grad(params, Y, control_inputs, jitter=orc.JITTER_MULTI_OUTPUT, prior_ty
         g["logvariance"][d] += -dls / T
         g["log_Q"][d] += -(dalpha * (-alpha)) / T
     return g
+
+
+def nll_grad_explicit_u(params, Y, control_inputs, jitter=orc.JITTER_MULTI_OUTPUT, prior_type="normal"):
+    """Gradient of the single-chain nll of the EXPLICIT-U branch (dgp_model.py:289-297 with regularizer :337-359 and
+    conditional / base_conditional, conditionals_multi_output.py:6-120), SE kernels, full batch -- what
+    tf.gradients(nll, vars) returns in the reference's cases 1, 2, 3, 6.  Returns the keys of nll_grad plus 'U'.
+
+    Per latent dim (index dropped):  alpha = 1/Q,  K = K_uu + jitter I = L L^T,  W = L^-T,  F = K_fu W,
+    mean = F u,  var_t = sigma^2 - |F_t|^2,  r = delta - mean,
+        l = sum_t [ -1/2 alpha r_t^2 - 1/2 alpha var_t ] + T/2 log alpha,      nll contribution = -l / T.
+    With beta = W u,  g_r = K_uf r,  G = K_uf K_fu:
+        dl/dK_fu = alpha (r beta^T + K_fu K^-1)            (same shape as the collapsed branch: Gamma -> alpha K^-1 / 2)
+        dl/dW    = alpha (g_r u^T + G W),   dl/du = alpha W^T g_r,   dl/ddelta = -alpha r
+        dl/dL    = -tril(W (dl/dW)^T W)                    (W = L^-T)
+        dl/dK    = W Phi W^T,  Phi = sym(tril(L^T dl/dL) with its diagonal halved)     (Cholesky adjoint)
+        dl/dalpha = -1/2 sum r^2 - 1/2 sum var + T / (2 alpha)."""
+    X, Z, U = params["X"], params["Z"], params["U"]
+    T, D = X.shape[0] - 1, X.shape[1]
+    M, P = Z.shape
+    c_in = control_inputs[:T] if control_inputs is not None and control_inputs.shape[0] > 0 else np.zeros((T, 0))
+    xc = np.concatenate((X[:-1], c_in), axis=1)
+    Q = np.exp(params["log_Q"])
+    R = np.exp(params["log_Rchols"])[0]
+    CC, DD = params["CC"], params["DD"]
+    g = {k: np.zeros_like(np.asarray(v, dtype=np.float64)) for k, v in params.items()}
+    # likelihood and priors: identical to the collapsed branch, except that the transition prior lives in l below
+    rl = (Y - (X[1:] @ CC + DD)) / R[None, :]
+    g["X"][1:] += -(rl / R[None, :]) @ CC.T / T
+    g["CC"] += -(X[1:].T @ (rl / R[None, :])) / T
+    g["DD"] += -(rl / R[None, :]).sum(0) / T
+    g["log_Rchols"][0] += -((rl ** 2).sum(0) - T) / T
+    g["loglengthscales"] += params["loglengthscales"] / T
+    g["logvariance"] += (params["logvariance"] - np.log(0.05)) / T
+    if prior_type == "normal":
+        g["Z"] += Z / T
+    g["X"][0] += X[0] / T
+    g["log_Q"] += params["log_Q"] / T
+    g["CC"] += CC / T
+    g["DD"] += DD / T
+    g["log_Rchols"] += params["log_Rchols"] / T
+    g["U"] += U / T                                              # prior_U, choice 1 (dgp_model.py:134-135)
+    delta = X[1:] - X[:-1]
+    for d in range(D):
+        ell = np.exp(params["loglengthscales"][d])
+        s2 = np.exp(params["logvariance"][d])
+        kern = orc.SquaredExponential(params["logvariance"][d], params["loglengthscales"][d])
+        alpha = 1.0 / Q[d]
+        Kuu = kern.K(Z)
+        K = Kuu + jitter * np.eye(M)
+        L = np.linalg.cholesky(K)
+        W = np.linalg.inv(L).T
+        Kf = kern.K(xc, Z)
+        F = Kf @ W
+        u = U[:, d]
+        beta = W @ u
+        mean = Kf @ beta
+        r = delta[:, d] - mean
+        var = s2 - (F ** 2).sum(1)
+        gr = Kf.T @ r
+        G = Kf.T @ Kf
+        Kinv = W @ W.T
+        dKf = alpha * (np.outer(r, beta) + Kf @ Kinv)
+        dW = alpha * (np.outer(gr, u) + G @ W)
+        dL = -np.tril(W @ dW.T @ W)
+        S = L.T @ dL
+        Phi = np.tril(S)
+        Phi[np.diag_indices(M)] *= 0.5
+        Phi = 0.5 * (Phi + Phi.T)
+        dK = W @ Phi @ W.T
+        du = alpha * (W.T @ gr)
+        dalpha = -0.5 * np.sum(r ** 2) - 0.5 * np.sum(var) + T / (2.0 * alpha)
+        dxc, dZ1, dll1, dls1 = _se_chain(dKf * Kf, xc, Z, ell, same=False)
+        dZ2, _, dll2, dls2 = _se_chain(dK * Kuu, Z, Z, ell, same=True)
+        dls = dls1 + dls2 - 0.5 * alpha * T * s2
+        g["X"][:-1, :] += -dxc[:, :D] / T
+        g["X"][1:, d] += alpha * r / T                       # d(-l/T)/d delta_t = alpha r_t / T, delta_t = x_{t+1} - x_t
+        g["X"][:-1, d] -= alpha * r / T
+        g["Z"] += -(dZ1 + dZ2) / T
+        g["loglengthscales"][d] += -(dll1 + dll2) / T
+        g["logvariance"][d] += -dls / T
+        g["log_Q"][d] += -(dalpha * (-alpha)) / T
+        g["U"][:, d] += -du / T
+    return g

@@ -252,3 +252,51 @@ def test_case5_training_loop(actuator):
     assert not np.array_equal(after["Z"], chain["Z"])                             # Adam moved the rest
     mod.pull_parameters()
     assert mod.layers[-1].kernel[0].logvariance == pytest.approx(after["logvariance"][0])
+
+
+def _actuator_args(m, params, c, n_train=None):
+    A = m.ARGS
+    A.CC, A.DD = params["CC"], params["DD"]
+    A.QQ_chol = np.exp(0.5 * params["log_Q"])
+    A.RR_chol = np.exp(params["log_Rchols"])
+    A.lengthscales, A.variance = np.exp(params["loglengthscales"]), np.exp(params["logvariance"])
+    A.UU_ini, A.XX_0_ini = params["U"], params["X"][0]
+    A.x_initialization = params["X"][1:] if n_train is None else params["X"][1:n_train + 1]
+    A.control_inputs, A.num_inducing, A.x_dims, A.ZZ = c, 100, [4], params["Z"]
+    return A
+
+
+def test_case1_trains_the_explicit_u_branch(actuator):
+    """FFVD_Main.py case 1: explicit U, everything (U included) trained by Adam; the nll must go down and U must move."""
+    from ffvd_amd.models import RegressionModel
+    params, Y, c = actuator
+    m = RegressionModel("normal")
+    A = _actuator_args(m, params, c)
+    A.kernel_optimization, A.U_optimization, A.Z_optimization, A.U_collapse, A.case_val = True, True, True, False, 1
+    m.fit(Y, kernel_type="SquaredExponential", iterations=6, grad=True)
+    assert m.model.vars == [] and "U" in m.model._adam_train
+    assert m.nll_seq[1] == pytest.approx(m.nll_seq[0], rel=1e-9) and m.nll_seq[-1] < m.nll_seq[1]
+    assert not np.allclose(m.model.layers[-1].U, params["U"])
+    after = m.model.nll()
+    m.model._resident = False
+    assert m.model.nll() == pytest.approx(after, rel=1e-12)
+
+
+def test_case2_samples_hypers_and_u(actuator):
+    """FFVD_Main.py case 2: explicit U; SG-HMC on the kernel hyper-parameters and U, Adam on Z, X, log_Q, C, d, R."""
+    from ffvd_amd.models import RegressionModel
+    params, Y, c = actuator
+    m = RegressionModel("normal")
+    A = _actuator_args(m, params, c)
+    A.kernel_optimization, A.U_optimization, A.Z_optimization, A.U_collapse, A.case_val = False, False, True, False, 2
+    m.fit(Y, kernel_type="SquaredExponential", iterations=0, grad=True)
+    mod = m.model
+    assert mod.vars == ["logvariance", "loglengthscales", "U"] and "U" not in mod._adam_train
+    mod.seed(7)
+    mod.sghmc_step()
+    chain = mod.engine.get_params()
+    assert set(mod.window[0]) == {"logvariance", "loglengthscales", "U"}
+    assert not np.allclose(chain["U"], params["U"]) and np.array_equal(chain["Z"], params["Z"])
+    t = mod.train_hypers()
+    after = mod.engine.get_params()
+    assert np.isfinite(t["nll"]) and np.array_equal(after["U"], chain["U"]) and not np.array_equal(after["Z"], chain["Z"])

@@ -115,3 +115,21 @@ def test_get_rand_is_the_workload_draw():
     var = np.full((3, 2), 0.01)
     eps = np.ones((3, 2))
     np.testing.assert_allclose(orc.get_rand(mean, var, eps), mean + 0.1)
+
+
+def test_explicit_u_closed_form_gradient_matches_autograd():
+    """oracle/ffvd_grad_oracle.nll_grad_explicit_u (Cholesky adjoint in closed form) against torch autograd of the
+    independent restatement: the CPU twin of the HIP backward pass of the explicit-U branch."""
+    from oracle import ffvd_grad_oracle as gorc
+    from oracle import ffvd_oracle_torch as orct
+    from ffvd_amd import synthetic
+    for name, ov in (("tiny", {}), ("tiny", dict(C=0))):
+        params, Y, c, meta = synthetic.make_named(name, **ov)
+        p = dict(params)
+        p["X"] = params["X"][0]
+        keys = ("X", "Z", "U", "logvariance", "loglengthscales", "log_Q", "CC", "DD", "log_Rchols")
+        _, ga = orct.nll_and_grad(p, Y, c, wrt=keys, U_collapse=False)
+        g = gorc.nll_grad_explicit_u(p, Y, c)
+        for k in keys:
+            err = np.max(np.abs(g[k] - ga[k])) / (np.max(np.abs(ga[k])) + 1e-300)
+            assert err < 1e-8, (k, err)
