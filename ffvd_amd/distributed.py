@@ -69,7 +69,7 @@ def all_reduce_grads(grads, mode="chains", device=None, group=None):
     dims for all chains, so dX joins the same buffer.  Returns a new dict."""
     import torch
     import torch.distributed as dist
-    keys = list(GRAD_KEYS) + (["X"] if mode == "dims" else [])
+    keys = list(GRAD_KEYS) + (["U"] if "U" in grads else []) + (["X"] if mode == "dims" else [])
     flat = np.concatenate([np.asarray(grads[k], dtype=np.float64).ravel() for k in keys])
     t = torch.from_numpy(flat)
     if device is not None:

@@ -449,7 +449,12 @@ sh = ShardedElbo(params, Y, c, meta, rank=rank, world=world, mode=mode, device=0
 t = finish(sh.step())
 t2 = finish(sh.step())
 tg, g = sh.nll_and_grad()
-print("RESULT", rank, repr(t["nll"]), repr(t2["nll"]), repr(tg["nll"]), repr(float(np.abs(g["Z"]).sum())), flush=True)
+# explicit-U branch through the same collective path (dU is all-reduced with the other shared gradients)
+meta_a = dict(meta, U_collapse=False)
+sha = ShardedElbo(params, Y, c, meta_a, rank=rank, world=world, mode=mode, device=0, grad=True)
+ta, ga = sha.nll_and_grad()
+print("RESULT", rank, repr(t["nll"]), repr(t2["nll"]), repr(tg["nll"]), repr(float(np.abs(g["Z"]).sum())),
+      repr(ta["nll"]), repr(float(np.abs(ga["U"]).sum())), flush=True)
 dist.destroy_process_group()
 '''
 
@@ -475,12 +480,17 @@ def test_two_processes_share_the_gpu_and_reduce(tmp_path, mode):
     with ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], meta["S"], route="gram", grad=True) as e:
         e.set_data(Y, c)
         t, g = e.nll_and_grad(params)
+    with ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], meta["S"], U_collapse=False, grad=True) as e:
+        e.set_data(Y, c)
+        ta, ga = e.nll_and_grad(params)
     for out in outs:
         line = [l for l in out.splitlines() if l.startswith("RESULT")][0].split()
-        nll1, nll2, nllg, zsum = (float(x) for x in line[2:6])
+        nll1, nll2, nllg, zsum, nlla, usum = (float(x) for x in line[2:8])
         assert nll1 == nll2
         assert nll1 == pytest.approx(t["nll"], rel=1e-12) and nllg == pytest.approx(t["nll"], rel=1e-12)
         assert zsum == pytest.approx(float(np.abs(g["Z"]).sum()), rel=1e-4)
+        assert nlla == pytest.approx(ta["nll"], rel=1e-12)
+        assert usum == pytest.approx(float(np.abs(ga["U"]).sum()), rel=1e-9)
 
 
 def _random_shapes(n, seed):
