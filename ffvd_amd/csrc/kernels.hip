@@ -875,7 +875,7 @@ __device__ __forceinline__ void gram_body(const GramArgs a, const int bz, const 
     const bool gemv = DIAG && a.with_row && tid >= 384;          // wavefronts 6, 7: no sub-block in diagonal tiles
 
     const double *Ab = a.A + (size_t)bz * a.a_stride;
-    const double *Xs = (a.with_row && !a.rvec) ? a.X + (size_t)s * (a.T + 1) * a.D : nullptr;
+    const double *Xs = (a.with_row && !(MODE == GRAM_PLAIN && a.rvec)) ? a.X + (size_t)s * (a.T + 1) * a.D : nullptr;
     // global -> register staging: thread (rowl, lane) moves 16 bytes of rows rowl and rowl + 8 per operand.
     // Out-of-range columns (odd number of 64-blocks) are read from a clamped valid address and zeroed.
     const int colA = ti * 128 + 2 * lane, colB = tj * 128 + 2 * lane;
@@ -897,7 +897,7 @@ __device__ __forceinline__ void gram_body(const GramArgs a, const int bz, const 
         }
         if (DIAG && a.with_row) {
             const int tt = c * GT + (tid & (GT - 1));
-            if (a.rvec) {                                      // a caller-supplied vector (residuals, backward pass)
+            if (MODE == GRAM_PLAIN && a.rvec) {                // a caller-supplied vector (residuals, backward pass)
                 d1 = a.rvec[(size_t)bz * a.rows + tt];
                 d0 = 0.0;
                 dok = true;
