@@ -46,6 +46,7 @@ struct ffvd_handle {
     // workspace
     double *variance = nullptr, *len = nullptr, *Zs = nullptr, *zz = nullptr;
     double *Kuu = nullptr, *F = nullptr, *H = nullptr, *rowsq = nullptr, *fmean = nullptr;
+    double *ucolA = nullptr;        // explicit-U branch: U columns of the local dims, zero padded to Mp
     double *Kf2 = nullptr;          // reference route, branch B: K_fu (input of the projection GEMM); F keeps K_fu L^-T
     int ngr = 0;                    // row-sum partials per unit in that path (128-column tiles)
     double *Kcopy = nullptr, *Linv = nullptr, *Kinv = nullptr, *trpart = nullptr, *kterms = nullptr;   // GRAM route
@@ -176,10 +177,14 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
     HIP_TRY(dev_alloc(h, &h->Kuu, Dl * 2 * Mp * Mp));
     // reference route of the collapsed branch: K_fu is built once (kfu_build) and projected by a triangular GEMM,
     // unless FFVD_FUSED_PROJECT asks for the older kernel that generates K_fu inside the projection
-    const bool proj_gemm = c.branch == FFVD_BRANCH_B && c.route == FFVD_ROUTE_REFERENCE && !getenv("FFVD_FUSED_PROJECT");
+    // (explicit-U branch: only from 64 units of the headline size on -- below that the single fused kernel is quicker:
+    //  1.10 vs 1.21 ms on config 5's 16 units -- or when the backward pass needs K_fu anyway)
+    const bool big_a = (size_t)h->nbatch * Tp * Mp >= (size_t)64 * 4096 * 512 || c.grad;
+    const bool proj_gemm = ((c.branch == FFVD_BRANCH_A && big_a) || (c.branch == FFVD_BRANCH_B && c.route == FFVD_ROUTE_REFERENCE)) &&
+                           !getenv("FFVD_FUSED_PROJECT");
     h->ngr = proj_gemm ? (int)((Mp + 127) / 128) : 0;
     HIP_TRY(dev_alloc(h, &h->rowsq, (size_t)h->nbatch * (h->ngr > h->ng ? h->ngr : h->ng) * Tp));
-    HIP_TRY(dev_alloc(h, &h->fmean, (size_t)h->nbatch * h->ng * Tp));
+    HIP_TRY(dev_alloc(h, &h->fmean, (size_t)h->nbatch * (h->ngr > h->ng ? h->ngr : h->ng) * Tp));
     if (c.branch == FFVD_BRANCH_B) {
         const size_t pass_b = (size_t)h->cpp * Dl;
         HIP_TRY(dev_alloc(h, &h->F, pass_b * Tp * Mp));
@@ -190,7 +195,10 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
     }
     h->ntiles = gram_ntiles(h->Mp);
     const bool grad_a = c.grad && c.branch == FFVD_BRANCH_A;
-    if (grad_a) HIP_TRY(dev_alloc(h, &h->F, (size_t)h->nbatch * Tp * Mp));      // K_fu for the backward pass
+    if (c.branch == FFVD_BRANCH_A && (grad_a || h->ngr)) {                       // K_fu (projection GEMM input, backward pass)
+        HIP_TRY(dev_alloc(h, &h->F, (size_t)(grad_a ? h->nbatch : h->cpp * Dl) * Tp * Mp));
+        HIP_TRY(dev_alloc(h, &h->ucolA, Dl * Mp));
+    }
     if ((c.branch == FFVD_BRANCH_B && c.route == FFVD_ROUTE_GRAM) || grad_a) {
         HIP_TRY(dev_alloc(h, &h->Kcopy, Dl * Mp * Mp));
         HIP_TRY(dev_alloc(h, &h->Linv, Dl * Mp * Mp));
@@ -470,7 +478,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
         if (gram_route) {
             launch_kfu_build(s, pa);
             if (s0 == 0 && sk != s && !late_join) HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));
-        } else if (h->ngr) {
+        } else if (h->ngr && c.branch == FFVD_BRANCH_B) {
             pa.F = h->Kf2;
             launch_kfu_build(s, pa);                                  // K(X_combine, Z)           (:240)
             ProjGemmArgs pg{};
@@ -478,8 +486,18 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
             pg.F = h->F; pg.f_stride = (size_t)Tp * Mp; pg.rowsq = h->rowsq; pg.Tp = Tp; pg.Mp = Mp; pg.Dl = Dl;
             pg.b0 = s0 * Dl; pg.nb = ns * Dl;
             launch_proj_gemm(s, pg);                                  // tilde_F = Knm Lm^-T, sum F^2  (:242,:255)
+        } else if (c.branch == FFVD_BRANCH_A && h->ngr) {
+            // explicit-U branch: K_fu once, then the triangular GEMM with fvar / fmean folded into its epilogue (F unstored)
+            pa.F = h->F + (grad_a ? (size_t)s0 * Dl * Tp * Mp : 0);
+            launch_kfu_build(s, pa);
+            if (s0 == 0) launch_ucols(s, p.U, c.M, Mp, c.D, c.d_begin, Dl, h->ucolA);
+            ProjGemmArgs pg{};
+            pg.Kf = pa.F; pg.kf_stride = (size_t)Tp * Mp; pg.W = h->Kuu + msq; pg.w_stride = kstride;
+            pg.F = nullptr; pg.f_stride = 0; pg.rowsq = h->rowsq; pg.fmean = h->fmean; pg.u = h->ucolA; pg.u_stride = Mp;
+            pg.Tp = Tp; pg.Mp = Mp; pg.Dl = Dl; pg.b0 = s0 * Dl; pg.nb = ns * Dl;
+            launch_proj_gemm(s, pg);
         } else {
-            if (grad_a) {                       // the backward pass of the explicit-U branch needs K_fu itself
+            if (grad_a) {                       // (FFVD_FUSED_PROJECT) the backward pass still needs K_fu itself
                 pa.F = h->F;
                 launch_kfu_build(s, pa);
                 pa.F = nullptr;
@@ -678,7 +696,8 @@ static int enqueue_grad_a(ffvd_handle *h, int S_total) {
     // beta = W u,  r = delta - mean,  dl/dalpha per unit
     launch_ucols(s, p.U, c.M, Mp, c.D, c.d_begin, Dl, g.ucol);
     launch_matvec(s, W, kstride, g.ucol, Mp, Mp, g.beta, 1, Mp, Mp, Dl);
-    launch_resid_a(s, p.X, h->fmean, h->rowsq, h->variance, p.log_Q, c.T, Tp, c.D, Dl, c.d_begin, h->ng, nb, g.r, g.dalpha);
+    launch_resid_a(s, p.X, h->fmean, h->rowsq, h->variance, p.log_Q, c.T, Tp, c.D, Dl, c.d_begin, h->ngr ? h->ngr : h->ng, nb,
+                   g.r, g.dalpha);
     // G = K_uf K_fu (lower tiles) and g_r = K_uf r (row Mp) per unit, then summed over the chains
     GramArgs gg{};
     gg.mode = GRAM_PLAIN; gg.A = h->F; gg.a_stride = fstride; gg.rows = Tp; gg.with_row = 1; gg.brow = Mp; gg.rvec = g.r;

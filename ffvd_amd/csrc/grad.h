@@ -79,6 +79,9 @@ struct ProjGemmArgs {
     double *F; size_t f_stride;                // [nb] Tp x Mp
     double *rowsq;                             // [nb][ntj][Tp], ntj = ceil(Mp / 128)
     int Tp, Mp, Dl, b0, nb;
+    // explicit-U branch: F itself is not needed (F == nullptr), but its product with the inducing outputs is:
+    const double *u; size_t u_stride;          // [Dl] Mp, u_d = U[:, d] (zero padded) or nullptr
+    double *fmean;                             // [nb][ntj][Tp] partials of F u (conditionals_multi_output.py:48)
 };
 void launch_proj_gemm(hipStream_t stream, const ProjGemmArgs &a);
 

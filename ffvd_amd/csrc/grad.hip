@@ -526,30 +526,46 @@ __global__ __launch_bounds__(512, 4) void proj_gemm_kernel(ProjGemmArgs a) {
         if (c + 1 < nchunk) lstore(buf ^ 1);
         __syncthreads();
     }
-    // epilogue: F and the row sums of F^2 over this tile's columns
-    double *Fb = a.F + (size_t)bz * a.f_stride;
+    // epilogue: F (if wanted), the row sums of F^2 and (explicit-U branch) of F u over this tile's columns
+    double *Fb = a.F ? a.F + (size_t)bz * a.f_stride : nullptr;
+    const double *ub = a.u ? a.u + (size_t)dl * a.u_stride : nullptr;
     double *rs_s = &As[0][0][0];                     // [4 wc][128 rows]
+    double *fm_s = &Bs[0][0][0];
+    double uj[2];
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+        const int j = J0 + 16 * y + lr;
+        uj[y] = (ub && j < Mp) ? ub[j] : 0.0;
+    }
 #pragma unroll
     for (int x = 0; x < 4; ++x)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int i = I0 + 16 * x + lk + 4 * q;
-            double v = 0.0;
+            double v = 0.0, w = 0.0;
 #pragma unroll
             for (int y = 0; y < 2; ++y) {
                 const int j = J0 + 16 * y + lr;
                 const double f = acc[x][y][q];
-                if (i < Tp && j < Mp) Fb[(size_t)i * Mp + j] = f;
+                if (Fb && i < Tp && j < Mp) Fb[(size_t)i * Mp + j] = f;
                 v += f * f;
+                w += f * uj[y];
             }
             v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-            if (lr == 0) rs_s[wc * 128 + wr * 64 + 16 * x + lk + 4 * q] = v;
+            if (ub) { w += __shfl_xor(w, 1); w += __shfl_xor(w, 2); w += __shfl_xor(w, 4); w += __shfl_xor(w, 8); }
+            if (lr == 0) {
+                rs_s[wc * 128 + wr * 64 + 16 * x + lk + 4 * q] = v;
+                fm_s[wc * 128 + wr * 64 + 16 * x + lk + 4 * q] = w;
+            }
         }
     __syncthreads();
     if (tid < 128) {
         const int t = ti * 128 + tid;
-        if (t < Tp)
-            a.rowsq[((size_t)b * ntj + tj) * Tp + t] = (rs_s[tid] + rs_s[128 + tid]) + (rs_s[256 + tid] + rs_s[384 + tid]);
+        if (t < Tp) {
+            const size_t o = ((size_t)b * ntj + tj) * Tp + t;
+            a.rowsq[o] = (rs_s[tid] + rs_s[128 + tid]) + (rs_s[256 + tid] + rs_s[384 + tid]);
+            if (a.fmean) a.fmean[o] = (fm_s[tid] + fm_s[128 + tid]) + (fm_s[256 + tid] + fm_s[384 + tid]);
+        }
     }
 }
 void launch_proj_gemm(hipStream_t stream, const ProjGemmArgs &a) {
