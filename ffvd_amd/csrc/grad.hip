@@ -196,8 +196,88 @@ void launch_atb(hipStream_t stream, const AtbArgs &a) {
 }
 int atb_ntiles(int nA, int nB) { return ((nA + 127) / 128) * ((nB + 127) / 128); }
 
+// Shared main loop of the kernels whose left operand is stored row-major over the OUTPUT rows (K_fu itself):
+// acc (128 x 128 tile, 8 wavefronts of 64 x 32) = sum_{k < kend} Arows[i][k] * B[k][j], the 128 x 16 chunk of A
+// transposed on its way into LDS, both operands register-staged one chunk ahead.  `last_chunk` lets a wavefront stop
+// early when B is upper triangular.  Ends with the workgroup synchronised (LDS free for the caller's epilogue).
+struct RowMajorTile {
+    int ti, tj, tid, lane, wr, wc, lr, lk;
+};
+struct TileAcc { d4 v[4][2]; };
+__device__ __forceinline__ TileAcc gemm_rowmajor_a(double (*As)[AT][A_LD], double (*Bs)[AT][A_LD], const RowMajorTile t,
+                                                const double *A, int nrowsA, const double *B, int ld,
+                                                int kend, int last_chunk) {
+    d4 acc[4][2];
+    const int lda = ld, ldb = ld, ncolsB = ld;          // both operands are Mp wide in every caller
+    const int tid = t.tid, lane = t.lane;
+    const int colB = t.tj * 128 + 2 * lane;
+    const bool okB = colB < ncolsB;
+    const int colBc = okB ? colB : 0;
+    const int rowl = tid >> 6;
+    const int arow = t.ti * 128 + (tid >> 2), aseg = 4 * (tid & 3);
+    const bool okAr = arow < nrowsA;
+    const double *Arow = A + (size_t)(okAr ? arow : 0) * lda + aseg;
+    double2 ra[2], rb[2];
+    auto gload = [&](int c) {
+        ra[0] = *reinterpret_cast<const double2 *>(Arow + (size_t)c * AT);
+        ra[1] = *reinterpret_cast<const double2 *>(Arow + (size_t)c * AT + 2);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const size_t k = (size_t)c * AT + rowl + 8 * i;
+            rb[i] = *reinterpret_cast<const double2 *>(B + k * ldb + colBc);
+        }
+    };
+    auto lstore = [&](int buf) {
+        const int il = tid >> 2;
+        As[buf][aseg + 0][il] = okAr ? ra[0].x : 0.0;
+        As[buf][aseg + 1][il] = okAr ? ra[0].y : 0.0;
+        As[buf][aseg + 2][il] = okAr ? ra[1].x : 0.0;
+        As[buf][aseg + 3][il] = okAr ? ra[1].y : 0.0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            double2 vb = rb[i];
+            vb.x = okB ? vb.x : 0.0; vb.y = okB ? vb.y : 0.0;
+            *reinterpret_cast<double2 *>(&Bs[buf][rowl + 8 * i][2 * lane]) = vb;
+        }
+    };
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
+    const int nchunk = kend / AT;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunk) gload(c + 1);
+        if (c <= last_chunk) {
+#pragma unroll
+            for (int ks = 0; ks < AT / 4; ++ks) {
+                double af[4], bf[2];
+#pragma unroll
+                for (int x = 0; x < 4; ++x) af[x] = As[buf][4 * ks + t.lk][t.wr * 64 + 16 * x + t.lr];
+#pragma unroll
+                for (int y = 0; y < 2; ++y) bf[y] = Bs[buf][4 * ks + t.lk][t.wc * 32 + 16 * y + t.lr];
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+#pragma unroll
+                    for (int y = 0; y < 2; ++y) acc[x][y] = mfma_f64(af[x], bf[y], acc[x][y]);
+            }
+        }
+        if (c + 1 < nchunk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    TileAcc r;
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) r.v[x][y] = acc[x][y];
+    return r;
+}
+
 // ---------------------------------------------------------------------------------------------
-// Fused backward product (see grad.h BwdFusedArgs).  Main loop = atb_kernel<ATB_BWD_E, AROW>: the 128 x 128 tile
+// Fused backward product (see grad.h BwdFusedArgs).  Main loop = gemm_rowmajor_a (above): the 128 x 128 tile
 // g = (K_fu Gamma)[t][m] in 8 wavefronts of 64 x 32.  Epilogue, all in registers / LDS:
 //   e = (2 g + alpha delta_t u_m) K_fu[t][m]                         (overwrites the accumulators)
 //   columns: [cs; etx] = [1; x^T] e      -- the accumulator layout of e IS the MFMA B-operand layout (k = rows), so
@@ -223,64 +303,9 @@ __global__ __launch_bounds__(512, 4) void bwd_fused_kernel(BwdFusedArgs a) {
     const double *Kfb = a.Kf + (size_t)bz * a.kf_stride;
     const int unit_or_dim = a.per_dim ? (a.b0 + bz) % a.Dl : bz;
     const double *Gb = a.Gamma + (size_t)unit_or_dim * a.g_stride;
-    const int colB = tj * 128 + 2 * lane;
-    const bool okB = colB < Mp;
-    const int colBc = okB ? colB : 0;
-    const int rowl = tid >> 6;
-    const int arow = ti * 128 + (tid >> 2), aseg = 4 * (tid & 3);
-    const bool okAr = arow < Tp;
-    const double *Arow = Kfb + (size_t)(okAr ? arow : 0) * Mp + aseg;
-
-    double2 ra[2], rb[2];
-    auto gload = [&](int c) {
-        ra[0] = *reinterpret_cast<const double2 *>(Arow + (size_t)c * AT);
-        ra[1] = *reinterpret_cast<const double2 *>(Arow + (size_t)c * AT + 2);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const size_t k = (size_t)c * AT + rowl + 8 * i;
-            rb[i] = *reinterpret_cast<const double2 *>(Gb + k * Mp + colBc);
-        }
-    };
-    auto lstore = [&](int buf) {
-        const int il = tid >> 2;
-        As[buf][aseg + 0][il] = okAr ? ra[0].x : 0.0;
-        As[buf][aseg + 1][il] = okAr ? ra[0].y : 0.0;
-        As[buf][aseg + 2][il] = okAr ? ra[1].x : 0.0;
-        As[buf][aseg + 3][il] = okAr ? ra[1].y : 0.0;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            double2 vb = rb[i];
-            vb.x = okB ? vb.x : 0.0; vb.y = okB ? vb.y : 0.0;
-            *reinterpret_cast<double2 *>(&Bs[buf][rowl + 8 * i][2 * lane]) = vb;
-        }
-    };
-    d4 acc[4][2];
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
-    const int nchunk = Mp / AT;
-    gload(0);
-    lstore(0);
-    __syncthreads();
-    for (int c = 0; c < nchunk; ++c) {
-        const int buf = c & 1;
-        if (c + 1 < nchunk) gload(c + 1);
-#pragma unroll
-        for (int ks = 0; ks < AT / 4; ++ks) {
-            double af[4], bf[2];
-#pragma unroll
-            for (int x = 0; x < 4; ++x) af[x] = As[buf][4 * ks + lk][wr * 64 + 16 * x + lr];
-#pragma unroll
-            for (int y = 0; y < 2; ++y) bf[y] = Bs[buf][4 * ks + lk][wc * 32 + 16 * y + lr];
-#pragma unroll
-            for (int x = 0; x < 4; ++x)
-#pragma unroll
-                for (int y = 0; y < 2; ++y) acc[x][y] = mfma_f64(af[x], bf[y], acc[x][y]);
-        }
-        if (c + 1 < nchunk) lstore(buf ^ 1);
-        __syncthreads();
-    }
+    const RowMajorTile rt{ti, tj, tid, lane, wr, wc, lr, lk};
+    TileAcc res = gemm_rowmajor_a(As, Bs, rt, Kfb, Tp, Gb, Mp, Mp, 1 << 30);
+    d4 (&acc)[4][2] = res.v;
 
     // ---------------- epilogue ----------------
     const int b = a.b0 + bz, s = b / a.Dl, dl = b % a.Dl, dg = a.d_begin + dl;
@@ -465,67 +490,10 @@ __global__ __launch_bounds__(512, 4) void proj_gemm_kernel(ProjGemmArgs a) {
     const int b = a.b0 + bz, dl = b % a.Dl;
     const double *Kfb = a.Kf + (size_t)bz * a.kf_stride;
     const double *Wb = a.W + (size_t)dl * a.w_stride;
-    const int colB = tj * 128 + 2 * lane;
-    const bool okB = colB < Mp;
-    const int colBc = okB ? colB : 0;
-    const int rowl = tid >> 6;
-    const int arow = ti * 128 + (tid >> 2), aseg = 4 * (tid & 3);
-    const bool okAr = arow < Tp;
-    const double *Arow = Kfb + (size_t)(okAr ? arow : 0) * Mp + aseg;
-    double2 ra[2], rb[2];
-    auto gload = [&](int c) {
-        ra[0] = *reinterpret_cast<const double2 *>(Arow + (size_t)c * AT);
-        ra[1] = *reinterpret_cast<const double2 *>(Arow + (size_t)c * AT + 2);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const size_t k = (size_t)c * AT + rowl + 8 * i;
-            rb[i] = *reinterpret_cast<const double2 *>(Wb + k * Mp + colBc);
-        }
-    };
-    auto lstore = [&](int buf) {
-        const int il = tid >> 2;
-        As[buf][aseg + 0][il] = okAr ? ra[0].x : 0.0;
-        As[buf][aseg + 1][il] = okAr ? ra[0].y : 0.0;
-        As[buf][aseg + 2][il] = okAr ? ra[1].x : 0.0;
-        As[buf][aseg + 3][il] = okAr ? ra[1].y : 0.0;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            double2 vb = rb[i];
-            vb.x = okB ? vb.x : 0.0; vb.y = okB ? vb.y : 0.0;
-            *reinterpret_cast<double2 *>(&Bs[buf][rowl + 8 * i][2 * lane]) = vb;
-        }
-    };
-    d4 acc[4][2];
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
     const int kend = ((tj + 1) * 128 < Mp) ? (tj + 1) * 128 : Mp;       // W[k][j] = 0 for k > j
-    const int nchunk = kend / AT;
-    const int my_last = (J0 + 31) / AT;                                // last chunk with a non-zero W row for this wavefront
-    gload(0);
-    lstore(0);
-    __syncthreads();
-    for (int c = 0; c < nchunk; ++c) {
-        const int buf = c & 1;
-        if (c + 1 < nchunk) gload(c + 1);
-        if (c <= my_last) {
-#pragma unroll
-            for (int ks = 0; ks < AT / 4; ++ks) {
-                double af[4], bf[2];
-#pragma unroll
-                for (int x = 0; x < 4; ++x) af[x] = As[buf][4 * ks + lk][wr * 64 + 16 * x + lr];
-#pragma unroll
-                for (int y = 0; y < 2; ++y) bf[y] = Bs[buf][4 * ks + lk][wc * 32 + 16 * y + lr];
-#pragma unroll
-                for (int x = 0; x < 4; ++x)
-#pragma unroll
-                    for (int y = 0; y < 2; ++y) acc[x][y] = mfma_f64(af[x], bf[y], acc[x][y]);
-            }
-        }
-        if (c + 1 < nchunk) lstore(buf ^ 1);
-        __syncthreads();
-    }
+    const RowMajorTile rt{ti, tj, tid, lane, wr, wc, lr, lk};
+    TileAcc res = gemm_rowmajor_a(As, Bs, rt, Kfb, Tp, Wb, Mp, kend, (J0 + 31) / AT);
+    d4 (&acc)[4][2] = res.v;
     // epilogue: F (if wanted), the row sums of F^2 and (explicit-U branch) of F u over this tile's columns
     double *Fb = a.F ? a.F + (size_t)bz * a.f_stride : nullptr;
     const double *ub = a.u ? a.u + (size_t)dl * a.u_stride : nullptr;
