@@ -1056,8 +1056,8 @@ __global__ __launch_bounds__(512, 4) void gram_kernel(GramArgs a) {
 // Second pass of a split-K Gram launch: one workgroup per (unit, tile) adds the `ksplit` partial tiles in fixed
 // order and applies the epilogue of gram_body (scaling, + I / + K_uu, trace partial, the delta^T A row).
 template <int MODE>
-__global__ __launch_bounds__(256) void gram_combine_kernel(GramArgs a) {
-    __shared__ double red[256];
+__global__ __launch_bounds__(1024) void gram_combine_kernel(GramArgs a) {
+    __shared__ double red[16];
     const int tid = threadIdx.x;
     const int bz = blockIdx.y, tile = blockIdx.x;
     int ti = 0;
@@ -1073,23 +1073,36 @@ __global__ __launch_bounds__(256) void gram_combine_kernel(GramArgs a) {
     const double *Kadd = (MODE == GRAM_KFU) ? a.Kadd + (size_t)dl * a.kadd_stride : nullptr;
     const double *Kinv = (MODE == GRAM_KFU) ? a.Kinv + (size_t)dl * a.kinv_stride : nullptr;
     double trp = 0.0;
-    for (int sb = 0; sb < 8; ++sb) {                  // the 64 x 32 sub-blocks gram_body writes
+    // one pair of columns per thread and 64 x 32 sub-block (the sub-blocks gram_body writes): 16-byte accesses, the
+    // eight sub-blocks unrolled so that all their loads are in flight together
+    const int ri = tid >> 4, cj = 2 * (tid & 15);
+#pragma unroll
+    for (int sb = 0; sb < 8; ++sb) {
         const int wr = sb >> 2, wc = sb & 3;
         const int I0 = ti * 128 + wr * 64, J0 = tj * 128 + wc * 32;
         if (!((I0 < Mp) && (J0 < Mp) && (J0 < I0 + 64))) continue;
-        for (int e = tid; e < 64 * 32; e += 256) {
-            const int i = I0 + (e >> 5), j = J0 + (e & 31);
-            double g = 0.0;
-            for (int ks = 0; ks < a.ksplit; ++ks) g += P0[(size_t)ks * ks_stride + (size_t)i * Mp + j];
-            double v;
-            if (MODE == GRAM_F) v = g * scale + ((i == j) ? 1.0 : 0.0);
-            else if (MODE == GRAM_KFU) {
-                v = g * scale + Kadd[(size_t)i * Mp + j];
-                const double w = (i > j) ? 2.0 : ((i == j) ? 1.0 : 0.0);
-                trp += w * (Kinv[(size_t)i * Mp + j] * g);
-            } else v = g;
-            Hb[(size_t)i * Mp + j] = v;
+        const int i = I0 + ri, j = J0 + cj;
+        const size_t off = (size_t)i * Mp + j;
+        double2 g = {0.0, 0.0};
+        for (int ks = 0; ks < a.ksplit; ++ks) {
+            const double2 q = *reinterpret_cast<const double2 *>(P0 + (size_t)ks * ks_stride + off);
+            g.x += q.x; g.y += q.y;
         }
+        double2 v;
+        if (MODE == GRAM_F) {
+            v.x = g.x * scale + ((i == j) ? 1.0 : 0.0);
+            v.y = g.y * scale + ((i == j + 1) ? 1.0 : 0.0);
+        } else if (MODE == GRAM_KFU) {
+            const double2 ka = *reinterpret_cast<const double2 *>(Kadd + off);
+            const double2 ki = *reinterpret_cast<const double2 *>(Kinv + off);
+            v.x = g.x * scale + ka.x;
+            v.y = g.y * scale + ka.y;
+            const double w0 = (i > j) ? 2.0 : ((i == j) ? 1.0 : 0.0);
+            const double w1 = (i > j + 1) ? 2.0 : ((i == j + 1) ? 1.0 : 0.0);
+            trp += w0 * (ki.x * g.x);
+            trp += w1 * (ki.y * g.y);
+        } else v = g;
+        *reinterpret_cast<double2 *>(Hb + off) = v;
     }
     if (a.with_row && ti == tj && tid < 128) {
         const int col = ti * 128 + tid;
@@ -1100,13 +1113,15 @@ __global__ __launch_bounds__(256) void gram_combine_kernel(GramArgs a) {
         }
     }
     if (MODE == GRAM_KFU) {
-        red[tid] = trp;
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) trp += __shfl_xor(trp, m);      // fixed order: reproducible
+        if ((tid & 63) == 0) red[tid >> 6] = trp;
         __syncthreads();
-        for (int st = 128; st > 0; st >>= 1) {
-            if (tid < st) red[tid] += red[tid + st];
-            __syncthreads();
+        if (tid == 0) {
+            double t = 0.0;
+            for (int w = 0; w < 16; ++w) t += red[w];
+            a.trpart[(size_t)b * a.ntiles + tile] = t;
         }
-        if (tid == 0) a.trpart[(size_t)b * a.ntiles + tile] = red[0];
     }
 }
 
@@ -1122,7 +1137,9 @@ int gram_ksplit(int Mp, int nb, int rows) {
     const int n = nb * gram_ntiles(Mp);
     if (const char *e = getenv("FFVD_GSPLIT")) return atoi(e) > 0 ? atoi(e) : 1;       // tuning override
     if (n <= 0 || n >= 1024) return 1;
-    int ks = (n <= 256) ? 512 / n : (1280 + n / 2) / n;     // one full round, or about 2.5 rounds of short workgroups
+    // one full round; three row ranges up to 640 tiles (re-measured with the 1024-thread combine pass: 160 tiles 1.05 ms per
+    // iteration in 3 ranges / 1.08-1.09 in 2, 4; 320 tiles 1.49 in 3 / 1.53 in 2 / 1.58 in 4; 640 tiles 2.46 in 3 / 2.53 in 2)
+    int ks = (n <= 256) ? 512 / n : ((n <= 704) ? 3 : (1280 + n / 2) / n);
     if (ks > 8) ks = 8;
     const int nchunk = rows / GT;
     while (ks > 1 && nchunk / ks < 8) --ks;          // keep at least 128 rows per range
@@ -1147,9 +1164,9 @@ void launch_gram(hipStream_t stream, GramArgs a, int phase) {
     }
     if (a.ksplit > 1 && phase != 1) {
         const dim3 cgrid(a.ntiles, a.nb);
-        if (a.mode == GRAM_F) hipLaunchKernelGGL(gram_combine_kernel<GRAM_F>, cgrid, dim3(256), 0, stream, a);
-        else if (a.mode == GRAM_KFU) hipLaunchKernelGGL(gram_combine_kernel<GRAM_KFU>, cgrid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL(gram_combine_kernel<GRAM_PLAIN>, cgrid, dim3(256), 0, stream, a);
+        if (a.mode == GRAM_F) hipLaunchKernelGGL(gram_combine_kernel<GRAM_F>, cgrid, dim3(1024), 0, stream, a);
+        else if (a.mode == GRAM_KFU) hipLaunchKernelGGL(gram_combine_kernel<GRAM_KFU>, cgrid, dim3(1024), 0, stream, a);
+        else hipLaunchKernelGGL(gram_combine_kernel<GRAM_PLAIN>, cgrid, dim3(1024), 0, stream, a);
     }
 }
 
