@@ -34,7 +34,7 @@ struct ffvd_handle {
     double *gpart = nullptr;                     // split-K partial tiles of the Gram kernel (few units per pass)
     int gsplit = 1;
     hipStream_t aux = nullptr;          // side stream: the K_uu chain runs beside the K_fu build (Gram route)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_kuu = nullptr, ev_tiles = nullptr;
     std::string err;
     std::vector<void *> allocs;
     int64_t ws_bytes = 0;
@@ -124,6 +124,8 @@ extern "C" int ffvd_destroy(ffvd_handle *h) {
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_join) hipEventDestroy(h->ev_join);
     if (h->ev_join2) hipEventDestroy(h->ev_join2);
+    if (h->ev_kuu) hipEventDestroy(h->ev_kuu);
+    if (h->ev_tiles) hipEventDestroy(h->ev_tiles);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
     return FFVD_OK;
@@ -159,6 +161,8 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
     HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_kuu, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_tiles, hipEventDisableTiming));
     HIP_TRY(dev_alloc(h, &h->X, (size_t)c.S_local * (c.T + 1) * c.D));
     HIP_TRY(dev_alloc(h, &h->Z, (size_t)c.M * P));
     HIP_TRY(dev_alloc(h, &h->U, (size_t)c.M * c.D));
@@ -429,6 +433,12 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
     }
     const bool grad_a = c.grad && c.branch == FFVD_BRANCH_A;
     launch_kuu_build(sk, c.kernel_kind, hv, c.M, Mp, P, Dl, c.jitter, h->Kuu, (gram_route || grad_a) ? h->Kcopy : nullptr);
+    // One split-K pass, K_uu chain beside it: at few chains that chain is the critical path (0.54 ms against 0.47 ms of
+    // K_fu build + tile pass at 4 chains), and the only thing the main stream needs from its tail is K^-1 for the trace
+    // partials.  So the combine pass waits for the K_uu copy alone, Cholesky(A) starts at once, and the trace partials
+    // are computed from the same raw partial tiles on the side stream once K^-1 is there.
+    const bool defer_trace = late_join && c.S_local <= h->cpp && !getenv("FFVD_NO_DEFER_TRACE");
+    if (defer_trace) HIP_TRY(hipEventRecord(h->ev_kuu, sk));
     const size_t kstride = (size_t)2 * Mp * Mp;
     const size_t msq = (size_t)Mp * Mp;
     launch_potrf_ext(sk, h->Kuu, Mp, Mp, Mp, Dl, kstride, h->info, h->dinvK);
@@ -520,8 +530,18 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
             if (h->gpart) { ga.ksplit = h->gsplit; ga.part = h->gpart; }     // same row ranges in every pass of this handle
             if (s0 == 0 && late_join) {
                 launch_gram(s, ga, 1);
-                HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));
-                launch_gram(s, ga, 2);
+                if (defer_trace) {
+                    HIP_TRY(hipEventRecord(h->ev_tiles, s));
+                    HIP_TRY(hipStreamWaitEvent(s, h->ev_kuu, 0));
+                    ga.trace_mode = 1;
+                    launch_gram(s, ga, 2);
+                    HIP_TRY(hipStreamWaitEvent(sk, h->ev_tiles, 0));      // K^-1 is already there in side-stream order
+                    launch_gram(sk, ga, 3);
+                    HIP_TRY(hipEventRecord(h->ev_join2, sk));             // supersedes the record after the reductions
+                } else {
+                    HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));
+                    launch_gram(s, ga, 2);
+                }
             } else launch_gram(s, ga);
             if (st) st->mark(2);
             if (c.grad) {       // keep A = K_uu + K_uf K_fu / Q: the factorisation overwrites it in place

@@ -100,11 +100,15 @@ struct GramArgs {
     // gram_combine adds them in fixed order and applies the epilogue.  ksplit <= 1 or part == nullptr: off.
     int ksplit;
     double *part;
+    // combine pass only: 0 = epilogue + trace partials, 1 = epilogue without the trace (K^-1 not read), 2 = trace partials
+    // only (H not written) -- lets the combine run before K^-1 exists and the trace follow on another stream
+    int trace_mode;
 };
 int gram_ntiles(int Mp);
 // how many row ranges launch_gram should use for `nb` units (1 = no split), and the doubles `part` then needs
 int gram_ksplit(int Mp, int nb, int rows);
 size_t gram_part_doubles(int Mp, int nb, int ksplit);
+// phase 0: everything; 1: tile pass only; 2: combine pass only; 3: trace-only combine pass (split-K launches)
 void launch_gram(hipStream_t stream, GramArgs a, int phase = 0);
 
 // hterms[b] = { logdet(H) = 2 sum log diag(L_H),  b^T H^{-1} b = |row Mp|^2 } after launch_potrf_ext on H.

@@ -1073,6 +1073,7 @@ __global__ __launch_bounds__(1024) void gram_combine_kernel(GramArgs a) {
     const double *Kadd = (MODE == GRAM_KFU) ? a.Kadd + (size_t)dl * a.kadd_stride : nullptr;
     const double *Kinv = (MODE == GRAM_KFU) ? a.Kinv + (size_t)dl * a.kinv_stride : nullptr;
     double trp = 0.0;
+    const bool want_tr = (MODE == GRAM_KFU) && a.trace_mode != 1, want_out = a.trace_mode != 2;
     // one pair of columns per thread and 64 x 32 sub-block (the sub-blocks gram_body writes): 16-byte accesses, the
     // eight sub-blocks unrolled so that all their loads are in flight together
     const int ri = tid >> 4, cj = 2 * (tid & 15);
@@ -1088,23 +1089,27 @@ __global__ __launch_bounds__(1024) void gram_combine_kernel(GramArgs a) {
             const double2 q = *reinterpret_cast<const double2 *>(P0 + (size_t)ks * ks_stride + off);
             g.x += q.x; g.y += q.y;
         }
-        double2 v;
+        double2 v = {0.0, 0.0};
         if (MODE == GRAM_F) {
             v.x = g.x * scale + ((i == j) ? 1.0 : 0.0);
             v.y = g.y * scale + ((i == j + 1) ? 1.0 : 0.0);
         } else if (MODE == GRAM_KFU) {
-            const double2 ka = *reinterpret_cast<const double2 *>(Kadd + off);
-            const double2 ki = *reinterpret_cast<const double2 *>(Kinv + off);
-            v.x = g.x * scale + ka.x;
-            v.y = g.y * scale + ka.y;
-            const double w0 = (i > j) ? 2.0 : ((i == j) ? 1.0 : 0.0);
-            const double w1 = (i > j + 1) ? 2.0 : ((i == j + 1) ? 1.0 : 0.0);
-            trp += w0 * (ki.x * g.x);
-            trp += w1 * (ki.y * g.y);
+            if (want_out) {
+                const double2 ka = *reinterpret_cast<const double2 *>(Kadd + off);
+                v.x = g.x * scale + ka.x;
+                v.y = g.y * scale + ka.y;
+            }
+            if (want_tr) {
+                const double2 ki = *reinterpret_cast<const double2 *>(Kinv + off);
+                const double w0 = (i > j) ? 2.0 : ((i == j) ? 1.0 : 0.0);
+                const double w1 = (i > j + 1) ? 2.0 : ((i == j + 1) ? 1.0 : 0.0);
+                trp += w0 * (ki.x * g.x);
+                trp += w1 * (ki.y * g.y);
+            }
         } else v = g;
-        *reinterpret_cast<double2 *>(Hb + off) = v;
+        if (want_out) *reinterpret_cast<double2 *>(Hb + off) = v;
     }
-    if (a.with_row && ti == tj && tid < 128) {
+    if (want_out && a.with_row && ti == tj && tid < 128) {
         const int col = ti * 128 + tid;
         if (col < Mp) {
             double bs = 0.0;
@@ -1112,7 +1117,7 @@ __global__ __launch_bounds__(1024) void gram_combine_kernel(GramArgs a) {
             Hb[(size_t)a.brow * Mp + col] = bs * scale;
         }
     }
-    if (MODE == GRAM_KFU) {
+    if (want_tr) {
 #pragma unroll
         for (int m = 32; m > 0; m >>= 1) trp += __shfl_xor(trp, m);      // fixed order: reproducible
         if ((tid & 63) == 0) red[tid >> 6] = trp;
@@ -1157,11 +1162,12 @@ void launch_gram(hipStream_t stream, GramArgs a, int phase) {
     if (!a.part || a.ksplit < 1) a.ksplit = 1;
     const int groups = (a.nb + 7) / 8;
     const dim3 grid(groups * 8 * a.ntiles * a.ksplit);
-    if (phase != 2) {
+    if (phase != 2 && phase != 3) {
         if (a.mode == GRAM_F) hipLaunchKernelGGL(gram_kernel<GRAM_F>, grid, dim3(512), 0, stream, a);
         else if (a.mode == GRAM_KFU) hipLaunchKernelGGL(gram_kernel<GRAM_KFU>, grid, dim3(512), 0, stream, a);
         else hipLaunchKernelGGL(gram_kernel<GRAM_PLAIN>, grid, dim3(512), 0, stream, a);
     }
+    if (phase == 3) a.trace_mode = 2;
     if (a.ksplit > 1 && phase != 1) {
         const dim3 cgrid(a.ntiles, a.nb);
         if (a.mode == GRAM_F) hipLaunchKernelGGL(gram_combine_kernel<GRAM_F>, cgrid, dim3(1024), 0, stream, a);
