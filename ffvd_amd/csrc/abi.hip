@@ -426,21 +426,58 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
     // split-K first pass: its tile kernel writes raw partials and needs neither K_uu nor K^-1, so the chain may run
     // beside the K_fu build AND the tile pass and only has to be back for the combine pass
     const bool late_join = gram_route && h->gpart && first_units == h->cpp * Dl && !getenv("FFVD_NO_LATE_JOIN");
-    if (gram_route && (late_join || (size_t)first_units * Tp * Mp >= (size_t)64 * 4096 * 512)) {
-        sk = h->aux;
-        HIP_TRY(hipEventRecord(h->ev_fork, s));
-        HIP_TRY(hipStreamWaitEvent(sk, h->ev_fork, 0));
-    }
+    const size_t kstride = (size_t)2 * Mp * Mp;
+    const size_t msq = (size_t)Mp * Mp;
     const bool grad_a = c.grad && c.branch == FFVD_BRANCH_A;
-    launch_kuu_build(sk, c.kernel_kind, hv, c.M, Mp, P, Dl, c.jitter, h->Kuu, (gram_route || grad_a) ? h->Kcopy : nullptr);
+    auto project_args = [&](int s0, int ns) {
+        ProjectArgs pa{};
+        pa.kind = c.kernel_kind;
+        pa.x = p.X; pa.x_chain_stride = (size_t)(c.T + 1) * c.D; pa.x_ld = c.D; pa.x_cols = c.D;
+        pa.ctrl = h->ctrl; pa.T = c.T; pa.Tp = Tp; pa.C = c.C; pa.P = P; pa.M = c.M; pa.Mp = Mp; pa.Dl = Dl;
+        pa.d_begin = c.d_begin; pa.hv = hv; pa.W = h->Kuu + msq; pa.w_stride = kstride;
+        pa.U = p.U; pa.u_ld = c.D; pa.b0 = s0 * Dl; pa.nb = ns * Dl;
+        pa.F = (c.branch == FFVD_BRANCH_B) ? h->F : nullptr;
+        pa.rowsq = h->rowsq;
+        pa.fmean = (c.branch == FFVD_BRANCH_A) ? h->fmean : nullptr;
+        pa.ng = h->ng;
+        return pa;
+    };
+    auto gram_args = [&](int s0, int ns) {
+        GramArgs ga{};
+        ga.mode = gram_route ? GRAM_KFU : GRAM_F;
+        ga.A = h->F; ga.a_stride = (size_t)Tp * Mp; ga.rows = Tp; ga.with_row = 1;
+        ga.X = p.X; ga.log_Q = p.log_Q; ga.T = c.T; ga.D = c.D; ga.Mp = Mp; ga.Dl = Dl;
+        ga.d_begin = c.d_begin; ga.b0 = s0 * Dl; ga.nb = ns * Dl; ga.yn_over_batch = 1.0;
+        ga.H = h->H; ga.h_stride = (size_t)(c.grad ? 2 * Mp + NB : Mp + NB) * Mp;
+        if (c.grad) ga.brow = 2 * Mp;   // rows [Mp, 2Mp) hold I (they become L_A^-T), the b row moves to 2 Mp
+        ga.Kadd = h->Kcopy; ga.kadd_stride = msq; ga.Kinv = h->Kinv; ga.kinv_stride = msq; ga.trpart = h->trpart;
+        if (h->gpart) { ga.ksplit = h->gsplit; ga.part = h->gpart; }     // same row ranges in every pass of this handle
+        return ga;
+    };
     // One split-K pass, K_uu chain beside it: at few chains that chain is the critical path (0.54 ms against 0.47 ms of
     // K_fu build + tile pass at 4 chains), and the only thing the main stream needs from its tail is K^-1 for the trace
     // partials.  So the combine pass waits for the K_uu copy alone, Cholesky(A) starts at once, and the trace partials
     // are computed from the same raw partial tiles on the side stream once K^-1 is there.
     const bool defer_trace = late_join && c.S_local <= h->cpp && !getenv("FFVD_NO_DEFER_TRACE");
+    // ... and with the main stream now the critical one, its K_fu build and tile pass are enqueued BEFORE the ~25
+    // launches of the chain (the caller reads the result back every iteration, so each iteration starts on idle streams)
+    const bool main_first = defer_trace && !getenv("FFVD_NO_MAIN_FIRST");
+    if (gram_route && (late_join || (size_t)first_units * Tp * Mp >= (size_t)64 * 4096 * 512)) {
+        sk = h->aux;
+        HIP_TRY(hipEventRecord(h->ev_fork, s));
+        HIP_TRY(hipStreamWaitEvent(sk, h->ev_fork, 0));
+        if (main_first) {
+            if (st) st->mark(0);
+            launch_kfu_build(s, project_args(0, c.S_local));
+            if (st) st->mark(1);
+            const GramArgs ga = gram_args(0, c.S_local);
+            if (c.grad) launch_set_identity(s, h->H, ga.h_stride, Mp, Mp, c.S_local * Dl);
+            launch_gram(s, ga, 1);
+            HIP_TRY(hipEventRecord(h->ev_tiles, s));
+        }
+    }
+    launch_kuu_build(sk, c.kernel_kind, hv, c.M, Mp, P, Dl, c.jitter, h->Kuu, (gram_route || grad_a) ? h->Kcopy : nullptr);
     if (defer_trace) HIP_TRY(hipEventRecord(h->ev_kuu, sk));
-    const size_t kstride = (size_t)2 * Mp * Mp;
-    const size_t msq = (size_t)Mp * Mp;
     launch_potrf_ext(sk, h->Kuu, Mp, Mp, Mp, Dl, kstride, h->info, h->dinvK);
     if (gram_route || grad_a) {
         // K^-1 = L^-T L^-1 (shared by all chains) and log|K|
@@ -472,21 +509,12 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
         launch_chain_reduce(sk, ra, h->chain_partial);
         HIP_TRY(hipEventRecord(h->ev_join2, sk));
     }
-    if (st) st->mark(0);
+    if (st && !main_first) st->mark(0);
     for (int s0 = 0; s0 < c.S_local; s0 += h->cpp) {
         const int ns = (s0 + h->cpp <= c.S_local) ? h->cpp : c.S_local - s0;
-        ProjectArgs pa{};
-        pa.kind = c.kernel_kind;
-        pa.x = p.X; pa.x_chain_stride = (size_t)(c.T + 1) * c.D; pa.x_ld = c.D; pa.x_cols = c.D;
-        pa.ctrl = h->ctrl; pa.T = c.T; pa.Tp = Tp; pa.C = c.C; pa.P = P; pa.M = c.M; pa.Mp = Mp; pa.Dl = Dl;
-        pa.d_begin = c.d_begin; pa.hv = hv; pa.W = h->Kuu + msq; pa.w_stride = kstride;
-        pa.U = p.U; pa.u_ld = c.D; pa.b0 = s0 * Dl; pa.nb = ns * Dl;
-        pa.F = (c.branch == FFVD_BRANCH_B) ? h->F : nullptr;
-        pa.rowsq = h->rowsq;
-        pa.fmean = (c.branch == FFVD_BRANCH_A) ? h->fmean : nullptr;
-        pa.ng = h->ng;
+        ProjectArgs pa = project_args(s0, ns);
         if (gram_route) {
-            launch_kfu_build(s, pa);
+            if (!main_first) launch_kfu_build(s, pa);
             if (s0 == 0 && sk != s && !late_join) HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));
         } else if (h->ngr && c.branch == FFVD_BRANCH_B) {
             pa.F = h->Kf2;
@@ -514,24 +542,14 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
             }
             launch_project(s, pa);
         }
-        if (st) st->mark(1);
+        if (st && !main_first) st->mark(1);
         if (c.branch == FFVD_BRANCH_B) {
-            GramArgs ga{};
-            ga.mode = gram_route ? GRAM_KFU : GRAM_F;
-            ga.A = h->F; ga.a_stride = (size_t)Tp * Mp; ga.rows = Tp; ga.with_row = 1;
-            ga.X = p.X; ga.log_Q = p.log_Q; ga.T = c.T; ga.D = c.D; ga.Mp = Mp; ga.Dl = Dl;
-            ga.d_begin = c.d_begin; ga.b0 = s0 * Dl; ga.nb = ns * Dl; ga.yn_over_batch = 1.0;
-            ga.H = h->H; ga.h_stride = (size_t)(c.grad ? 2 * Mp + NB : Mp + NB) * Mp;
-            if (c.grad) {       // rows [Mp, 2Mp) <- I (they become L_A^-T), the b row moves to 2 Mp
-                ga.brow = 2 * Mp;
-                launch_set_identity(s, h->H, ga.h_stride, Mp, Mp, ns * Dl);
-            }
-            ga.Kadd = h->Kcopy; ga.kadd_stride = msq; ga.Kinv = h->Kinv; ga.kinv_stride = msq; ga.trpart = h->trpart;
-            if (h->gpart) { ga.ksplit = h->gsplit; ga.part = h->gpart; }     // same row ranges in every pass of this handle
+            GramArgs ga = gram_args(s0, ns);
+            if (c.grad && !main_first) launch_set_identity(s, h->H, ga.h_stride, Mp, Mp, ns * Dl);
             if (s0 == 0 && late_join) {
-                launch_gram(s, ga, 1);
+                if (!main_first) launch_gram(s, ga, 1);
                 if (defer_trace) {
-                    HIP_TRY(hipEventRecord(h->ev_tiles, s));
+                    if (!main_first) HIP_TRY(hipEventRecord(h->ev_tiles, s));
                     HIP_TRY(hipStreamWaitEvent(s, h->ev_kuu, 0));
                     ga.trace_mode = 1;
                     launch_gram(s, ga, 2);
