@@ -33,6 +33,7 @@ struct ffvd_handle {
     double *dinvK = nullptr, *dinvH = nullptr;   // Cholesky scratch (kernels.h DINV_STRIDE per matrix)
     double *gpart = nullptr;                     // split-K partial tiles of the Gram kernel (few units per pass)
     int gsplit = 1;
+    double *graw = nullptr;                      // unsplit first pass: raw Gram tiles for the deferred trace pass
     hipStream_t aux = nullptr;          // side stream: the K_uu chain runs beside the K_fu build (Gram route)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_kuu = nullptr, ev_tiles = nullptr;
     std::string err;
@@ -256,6 +257,8 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
         const int upass = h->cpp * (int)Dl;
         h->gsplit = gram_ksplit((int)Mp, upass, (int)Tp);
         if (h->gsplit > 1) HIP_TRY(dev_alloc(h, &h->gpart, gram_part_doubles((int)Mp, upass, h->gsplit)));
+        else if (c.route == FFVD_ROUTE_GRAM && (size_t)upass * Tp * Mp >= (size_t)64 * 4096 * 512 && !getenv("FFVD_NO_DEFER_TRACE"))
+            HIP_TRY(dev_alloc(h, &h->graw, (size_t)upass * (Mp + 1) * Mp));
     }
     HIP_TRY(dev_alloc(h, &h->dinvK, (size_t)Dl * DINV_STRIDE));
     HIP_TRY(dev_alloc(h, &h->dinvH, (size_t)(h->nbatch ? h->nbatch : 1) * DINV_STRIDE));
@@ -462,6 +465,8 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
     // ... and with the main stream now the critical one, its K_fu build and tile pass are enqueued BEFORE the ~25
     // launches of the chain (the caller reads the result back every iteration, so each iteration starts on idle streams)
     const bool main_first = defer_trace && !getenv("FFVD_NO_MAIN_FIRST");
+    // Unsplit first pass beside the chain: same idea with the raw tiles written by the Gram kernel itself
+    const bool defer_full = gram_route && !late_join && h->graw;
     if (gram_route && (late_join || (size_t)first_units * Tp * Mp >= (size_t)64 * 4096 * 512)) {
         sk = h->aux;
         HIP_TRY(hipEventRecord(h->ev_fork, s));
@@ -477,7 +482,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
         }
     }
     launch_kuu_build(sk, c.kernel_kind, hv, c.M, Mp, P, Dl, c.jitter, h->Kuu, (gram_route || grad_a) ? h->Kcopy : nullptr);
-    if (defer_trace) HIP_TRY(hipEventRecord(h->ev_kuu, sk));
+    if (defer_trace || (defer_full && sk != s)) HIP_TRY(hipEventRecord(h->ev_kuu, sk));
     launch_potrf_ext(sk, h->Kuu, Mp, Mp, Mp, Dl, kstride, h->info, h->dinvK);
     if (gram_route || grad_a) {
         // K^-1 = L^-T L^-1 (shared by all chains) and log|K|
@@ -515,7 +520,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
         ProjectArgs pa = project_args(s0, ns);
         if (gram_route) {
             if (!main_first) launch_kfu_build(s, pa);
-            if (s0 == 0 && sk != s && !late_join) HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));
+            if (s0 == 0 && sk != s && !late_join) HIP_TRY(hipStreamWaitEvent(s, defer_full ? h->ev_kuu : h->ev_join, 0));
         } else if (h->ngr && c.branch == FFVD_BRANCH_B) {
             pa.F = h->Kf2;
             launch_kfu_build(s, pa);                                  // K(X_combine, Z)           (:240)
@@ -560,6 +565,13 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
                     HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));
                     launch_gram(s, ga, 2);
                 }
+            } else if (s0 == 0 && defer_full && sk != s) {
+                ga.mode = GRAM_KFU_RAW; ga.part = h->graw; ga.ksplit = 1;
+                launch_gram(s, ga);
+                HIP_TRY(hipEventRecord(h->ev_tiles, s));
+                HIP_TRY(hipStreamWaitEvent(sk, h->ev_tiles, 0));
+                launch_gram(sk, ga, 3);
+                HIP_TRY(hipEventRecord(h->ev_join2, sk));
             } else launch_gram(s, ga);
             if (st) st->mark(2);
             if (c.grad) {       // keep A = K_uu + K_uf K_fu / Q: the factorisation overwrites it in place

@@ -73,7 +73,9 @@ void launch_project(hipStream_t stream, const ProjectArgs &a);
 // a.F[bz][t][m] = K_fu itself (route K_uu + K_uf K_fu / Q); uses x, ctrl, hv, T, Tp, M, Mp, b0, nb of `a`.
 void launch_kfu_build(hipStream_t stream, const ProjectArgs &a);
 
-enum { GRAM_F = 0, GRAM_KFU = 1, GRAM_PLAIN = 2 };
+// GRAM_KFU_RAW: as GRAM_KFU, but the trace partials are left to a later trace-only pass (phase 3) over the raw tiles
+// this launch also writes into `part` (ksplit = 1 layout) -- K^-1 is not read
+enum { GRAM_F = 0, GRAM_KFU = 1, GRAM_PLAIN = 2, GRAM_KFU_RAW = 3 };
 struct GramArgs {
     int mode;               // GRAM_*
     const double *A;        // [nb] slabs of rows x Mp (F, K_fu or L^-1), slab stride a_stride doubles

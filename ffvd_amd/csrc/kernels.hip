@@ -995,8 +995,9 @@ __device__ __forceinline__ void gram_body(const GramArgs a, const int bz, const 
     }
     const double scale = (MODE == GRAM_PLAIN) ? 1.0 : a.yn_over_batch / exp(a.log_Q[dg]);
     double *Hb = a.H + (size_t)bz * a.h_stride;
-    const double *Kadd = (MODE == GRAM_KFU) ? a.Kadd + (size_t)dl * a.kadd_stride : nullptr;
+    const double *Kadd = (MODE == GRAM_KFU || MODE == GRAM_KFU_RAW) ? a.Kadd + (size_t)dl * a.kadd_stride : nullptr;
     const double *Kinv = (MODE == GRAM_KFU) ? a.Kinv + (size_t)dl * a.kinv_stride : nullptr;
+    double *Rb = (MODE == GRAM_KFU_RAW) ? a.part + (size_t)bz * ((size_t)(Mp + 1) * Mp) : nullptr;
     double trp = 0.0;
     if (active) {
 #pragma unroll
@@ -1009,7 +1010,10 @@ __device__ __forceinline__ void gram_body(const GramArgs a, const int bz, const 
                     const double g = acc[x][y][q];
                     double v;
                     if (MODE == GRAM_F) v = g * scale + ((i == j) ? 1.0 : 0.0);
-                    else if (MODE == GRAM_KFU) {
+                    else if (MODE == GRAM_KFU_RAW) {
+                        v = g * scale + Kadd[(size_t)i * Mp + j];
+                        Rb[(size_t)i * Mp + j] = g;
+                    } else if (MODE == GRAM_KFU) {
                         v = g * scale + Kadd[(size_t)i * Mp + j];
                         const double w = (i > j) ? 2.0 : ((i == j) ? 1.0 : 0.0);
                         trp += w * (Kinv[(size_t)i * Mp + j] * g);
@@ -1165,11 +1169,13 @@ void launch_gram(hipStream_t stream, GramArgs a, int phase) {
     if (phase != 2 && phase != 3) {
         if (a.mode == GRAM_F) hipLaunchKernelGGL(gram_kernel<GRAM_F>, grid, dim3(512), 0, stream, a);
         else if (a.mode == GRAM_KFU) hipLaunchKernelGGL(gram_kernel<GRAM_KFU>, grid, dim3(512), 0, stream, a);
+        else if (a.mode == GRAM_KFU_RAW) hipLaunchKernelGGL(gram_kernel<GRAM_KFU_RAW>, grid, dim3(512), 0, stream, a);
         else hipLaunchKernelGGL(gram_kernel<GRAM_PLAIN>, grid, dim3(512), 0, stream, a);
     }
     if (phase == 3) a.trace_mode = 2;
-    if (a.ksplit > 1 && phase != 1) {
+    if ((a.ksplit > 1 && phase != 1) || phase == 3) {
         const dim3 cgrid(a.ntiles, a.nb);
+        if (a.mode == GRAM_KFU_RAW) a.mode = GRAM_KFU;
         if (a.mode == GRAM_F) hipLaunchKernelGGL(gram_combine_kernel<GRAM_F>, cgrid, dim3(1024), 0, stream, a);
         else if (a.mode == GRAM_KFU) hipLaunchKernelGGL(gram_combine_kernel<GRAM_KFU>, cgrid, dim3(1024), 0, stream, a);
         else hipLaunchKernelGGL(gram_combine_kernel<GRAM_PLAIN>, cgrid, dim3(1024), 0, stream, a);
