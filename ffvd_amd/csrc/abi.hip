@@ -467,14 +467,19 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
     const bool main_first = defer_trace && !getenv("FFVD_NO_MAIN_FIRST");
     // Unsplit first pass beside the chain: same idea with the raw tiles written by the Gram kernel itself
     const bool defer_full = gram_route && !late_join && h->graw;
+    const int ns_first = (h->cpp <= c.S_local) ? h->cpp : c.S_local;
+    bool kfu_first = false;     // the first pass's K_fu build goes to the main stream before the chain is enqueued
     if (gram_route && (late_join || (size_t)first_units * Tp * Mp >= (size_t)64 * 4096 * 512)) {
         sk = h->aux;
         HIP_TRY(hipEventRecord(h->ev_fork, s));
         HIP_TRY(hipStreamWaitEvent(sk, h->ev_fork, 0));
-        if (main_first) {
+        kfu_first = main_first || (defer_full && !getenv("FFVD_NO_KFU_FIRST"));
+        if (kfu_first) {
             if (st) st->mark(0);
-            launch_kfu_build(s, project_args(0, c.S_local));
+            launch_kfu_build(s, project_args(0, ns_first));
             if (st) st->mark(1);
+        }
+        if (main_first) {
             const GramArgs ga = gram_args(0, c.S_local);
             if (c.grad) launch_set_identity(s, h->H, ga.h_stride, Mp, Mp, c.S_local * Dl);
             launch_gram(s, ga, 1);
@@ -514,12 +519,12 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
         launch_chain_reduce(sk, ra, h->chain_partial);
         HIP_TRY(hipEventRecord(h->ev_join2, sk));
     }
-    if (st && !main_first) st->mark(0);
+    if (st && !kfu_first) st->mark(0);
     for (int s0 = 0; s0 < c.S_local; s0 += h->cpp) {
         const int ns = (s0 + h->cpp <= c.S_local) ? h->cpp : c.S_local - s0;
         ProjectArgs pa = project_args(s0, ns);
         if (gram_route) {
-            if (!main_first) launch_kfu_build(s, pa);
+            if (!(kfu_first && s0 == 0)) launch_kfu_build(s, pa);
             if (s0 == 0 && sk != s && !late_join) HIP_TRY(hipStreamWaitEvent(s, defer_full ? h->ev_kuu : h->ev_join, 0));
         } else if (h->ngr && c.branch == FFVD_BRANCH_B) {
             pa.F = h->Kf2;
@@ -547,7 +552,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
             }
             launch_project(s, pa);
         }
-        if (st && !main_first) st->mark(1);
+        if (st && !(kfu_first && s0 == 0)) st->mark(1);
         if (c.branch == FFVD_BRANCH_B) {
             GramArgs ga = gram_args(s0, ns);
             if (c.grad && !main_first) launch_set_identity(s, h->H, ga.h_stride, Mp, Mp, ns * Dl);
