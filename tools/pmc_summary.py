@@ -41,7 +41,8 @@ for k in sorted(set(fetch) | set(write)):
     lines.append(s)
     traffic[k] = b
 open(sys.argv[4], "w").write("\n".join(lines) + "\n")
-gram = max((v for k, v in traffic.items() if k.startswith("gram_kernel<1>")), default=None)
+# <1>: epilogue with the trace partials; <3>: raw tiles kept for the deferred trace pass (the full-batch launch since r01)
+gram = max((v for k, v in traffic.items() if k.startswith("gram_kernel<1>") or k.startswith("gram_kernel<3>")), default=None)
 kfu = max((v for k, v in traffic.items() if k.startswith("kfu_build_kernel")), default=None)
 json.dump({"gram_H": gram, "project_F": kfu,
            "_note": "HBM bytes per launch (largest launch) = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc "
