@@ -499,6 +499,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
             AtbArgs ak{};
             ak.mode = ATB_PLAIN; ak.A = h->Linv; ak.a_stride = msq; ak.lda = Mp; ak.nA = Mp; ak.B = h->Linv; ak.b_stride = msq;
             ak.ldb = Mp; ak.nB = Mp; ak.rows = Mp; ak.C = h->Kinv; ak.c_stride = msq; ak.ldc = Mp; ak.nb = Dl; ak.Dl = Dl;
+            ak.k_lower = 1;                                  // L^-1 is lower triangular
             launch_atb(sk, ak);
         } else launch_gram(sk, gk);     // (split-K here was measured slower: 0.42 vs 0.37 ms for the K_uu stage)
         launch_h_finish(sk, h->Kuu, Mp, kstride, Dl, h->kterms);
@@ -850,7 +851,7 @@ static int enqueue_grad_b(ffvd_handle *h, int S_total) {
     ag.B = g.LAinv; ag.b_stride = msq; ag.ldb = Mp; ag.nB = Mp; ag.b_per_dim = 0; ag.rows = Mp;
     ag.C = g.Gamma; ag.c_stride = msq; ag.ldc = Mp; ag.nb = nb; ag.b0 = 0; ag.Dl = Dl; ag.d_begin = c.d_begin;
     ag.log_Q = p.log_Q; ag.u = g.u; ag.u_stride = Mp; ag.Kinv = h->Kinv; ag.Kcopy = h->Kcopy; ag.k_stride = msq; ag.ldk = Mp;
-    ag.part = g.gam_part;
+    ag.part = g.gam_part; ag.k_lower = 1;               // L_A^-1 is lower triangular
     launch_atb(s, ag);
     launch_uku(s, g.u, Mp, h->Kcopy, msq, Mp, Dl, nb, g.uku);
     EReduceArgs er{};

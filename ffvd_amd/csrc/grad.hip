@@ -115,10 +115,11 @@ __global__ __launch_bounds__(512, 4) void atb_kernel(AtbArgs a) {
 #pragma unroll
         for (int y = 0; y < 2; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
     const int nchunk = a.rows / AT;
-    gload(0);
-    lstore(0);
+    const int c0 = (!AROW && a.k_lower) ? ((ti > tj ? ti : tj) * 128) / AT : 0;
+    gload(c0);
+    lstore(c0 & 1);
     __syncthreads();
-    for (int c = 0; c < nchunk; ++c) {
+    for (int c = c0; c < nchunk; ++c) {
         const int buf = c & 1;
         if (c + 1 < nchunk) gload(c + 1);
         if (active) {
@@ -764,51 +765,82 @@ void launch_e_reduce(hipStream_t stream, const EReduceArgs &a) {
 //   dz[m][p] = (etx[m][p] - z_mp cs_m) / l_p^2,  dlogl[p] = (rx2[p] - 2 sum_m z_mp etx[m][p] + sum_m cs_m z_mp^2) / l_p^2,
 //   dlogs2 = sum_m cs_m,   and (K_uu side, x_is_z) dz += -(z_mp r_m - ez[m][p]) / l_p^2.
 // Outputs are per unit: dz_unit [nb][M][P], dll_unit [nb][P], dls_unit [nb].
-__global__ __launch_bounds__(256) void e_finish_kernel(EReduceArgs a, double *dz_unit, double *dll_unit, double *dls_unit) {
-    __shared__ double scratch[256];
-    __shared__ double dll[MAXP];
+// 256 NG threads: thread (g = tid >> 8, r = tid & 255) sums block partials blk = g, g + NG, ... for rows m = r, r + 256, ...;
+// the NG groups are added in fixed order through LDS (NG = 1 for large P, where that buffer would not fit).  PM bounds P at compile time so the per-thread arrays stay in
+// registers (a run-time-indexed [MAXP] array goes to scratch).
+template <int PM, int NG>
+__global__ __launch_bounds__(256 * NG) void e_finish_kernel(EReduceArgs a, double *dz_unit, double *dll_unit, double *dls_unit) {
+    __shared__ double scratch[256 * NG];
+    __shared__ double grp[NG > 1 ? NG - 1 : 1][NG > 1 ? 256 : 1][PM + 1];
     const int bz = blockIdx.x, tid = threadIdx.x;
+    const int g = tid >> 8, r = tid & 255;
     const int b = a.b0 + bz, dl = b % a.Dl;
     const int P = a.P, Mp = a.Mp;
     const double *len = a.len + (size_t)dl * P;
-    if (tid < MAXP) dll[tid] = 0.0;
-    __syncthreads();
     double dls = 0.0;
-    double llacc[MAXP];
+    double llacc[PM];
 #pragma unroll
-    for (int p = 0; p < MAXP; ++p) llacc[p] = 0.0;
-    for (int m = tid; m < a.M; m += 256) {
+    for (int p = 0; p < PM; ++p) llacc[p] = 0.0;
+    for (int m0 = 0; m0 < a.M; m0 += 256) {
+        const int m = m0 + r;
+        const bool okm = m < a.M;
         double cs = 0.0;
-        double etx[MAXP];
+        double etx[PM];
 #pragma unroll
-        for (int p = 0; p < MAXP; ++p) etx[p] = 0.0;
-        for (int blk = 0; blk < a.nblk; ++blk) {
-            const size_t pb = ((size_t)bz * a.nblk + blk) * Mp + m;
-            cs += a.cs_part[pb];
-            for (int p = 0; p < P; ++p) etx[p] += a.etx_part[pb * P + p];
+        for (int p = 0; p < PM; ++p) etx[p] = 0.0;
+        if (okm) {
+            for (int blk = g; blk < a.nblk; blk += NG) {
+                const size_t pb = ((size_t)bz * a.nblk + blk) * Mp + m;
+                cs += a.cs_part[pb];
+#pragma unroll
+                for (int p = 0; p < PM; ++p)
+                    if (p < P) etx[p] += a.etx_part[pb * P + p];
+            }
         }
-        dls += cs;
-        for (int p = 0; p < P; ++p) {
-            const double z = a.Z[(size_t)m * P + p], inv2 = 1.0 / (len[p] * len[p]);
-            double dz = (etx[p] - z * cs) * inv2;
-            if (a.x_is_z) dz += -(z * a.rsum[(size_t)bz * a.Tp + m] - a.ez[((size_t)bz * a.Tp + m) * P + p]) * inv2;
-            dz_unit[((size_t)bz * a.M + m) * P + p] = dz;
-            llacc[p] += (-2.0 * z * etx[p] + cs * z * z) * inv2;
+        if (NG > 1 && g > 0) {
+            grp[g - 1][r][PM] = cs;
+#pragma unroll
+            for (int p = 0; p < PM; ++p) grp[g - 1][r][p] = etx[p];
         }
+        __syncthreads();
+        if (g == 0 && okm) {
+#pragma unroll
+            for (int q = 0; q < NG - 1; ++q) {
+                cs += grp[q][r][PM];
+#pragma unroll
+                for (int p = 0; p < PM; ++p) etx[p] += grp[q][r][p];
+            }
+            dls += cs;
+#pragma unroll
+            for (int p = 0; p < PM; ++p) {
+                if (p < P) {
+                    const double z = a.Z[(size_t)m * P + p], inv2 = 1.0 / (len[p] * len[p]);
+                    double dz = (etx[p] - z * cs) * inv2;
+                    if (a.x_is_z) dz += -(z * a.rsum[(size_t)bz * a.Tp + m] - a.ez[((size_t)bz * a.Tp + m) * P + p]) * inv2;
+                    dz_unit[((size_t)bz * a.M + m) * P + p] = dz;
+                    llacc[p] += (-2.0 * z * etx[p] + cs * z * z) * inv2;
+                }
+            }
+        }
+        __syncthreads();
     }
     dls = block_sum(dls, scratch);
-    for (int p = 0; p < P; ++p) {
-        double v = block_sum(llacc[p], scratch);
-        if (tid == 0) {
-            double rx2 = 0.0;
-            for (int blk = 0; blk < a.nblk; ++blk) rx2 += a.rx2_part[((size_t)bz * a.nblk + blk) * P + p];
-            dll_unit[(size_t)bz * P + p] = v + rx2 / (len[p] * len[p]);
+#pragma unroll
+    for (int p = 0; p < PM; ++p) {
+        if (p < P) {                                     // uniform across the workgroup
+            double v = block_sum(llacc[p], scratch);
+            if (tid == 0) {
+                double rx2 = 0.0;
+                for (int blk = 0; blk < a.nblk; ++blk) rx2 += a.rx2_part[((size_t)bz * a.nblk + blk) * P + p];
+                dll_unit[(size_t)bz * P + p] = v + rx2 / (len[p] * len[p]);
+            }
         }
     }
     if (tid == 0) dls_unit[bz] = dls;
 }
 void launch_e_finish(hipStream_t stream, const EReduceArgs &a, double *dz_unit, double *dll_unit, double *dls_unit) {
-    hipLaunchKernelGGL(e_finish_kernel, dim3(a.nb), dim3(256), 0, stream, a, dz_unit, dll_unit, dls_unit);
+    if (a.P <= 8) hipLaunchKernelGGL((e_finish_kernel<8, 4>), dim3(a.nb), dim3(1024), 0, stream, a, dz_unit, dll_unit, dls_unit);
+    else hipLaunchKernelGGL((e_finish_kernel<MAXP, 1>), dim3(a.nb), dim3(256), 0, stream, a, dz_unit, dll_unit, dls_unit);
 }
 
 // ---------------------------------------------------------------------------------------------
