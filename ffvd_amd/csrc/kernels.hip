@@ -158,32 +158,40 @@ void launch_transpose(hipStream_t stream, const double *in, size_t in_stride, do
 
 // K_fu materialised (only the K_uu + K_uf K_fu / Q route needs it in HBM): out[bz][t][m] = K_d(x_t, Z_m),
 // zero for t >= T or m >= M.  64 x 64 tile per workgroup; thread (tid & 63) owns a column, 16 rows.
-template <int KIND>
+// SMALLP (P <= 8): x / l is kept row-major and zero-padded to 8 components in LDS, so a row is four 16-byte
+// broadcast reads and the dot product eight unconditional FMAs (with a run-time `p < P` test the compiler emits one
+// LDS round trip and one scalar branch per component: 0.55 instead of 0.40 ms for the 2 GiB of config 2).
+template <int KIND, bool SMALLP>
 __global__ __launch_bounds__(256) void kfu_build_kernel(ProjectArgs a) {
-    __shared__ double xs[MAXP][64];
+    __shared__ double xs[SMALLP ? 1 : MAXP][SMALLP ? 1 : 64];
+    __shared__ __attribute__((aligned(16))) double xr8[SMALLP ? 64 : 1][8];
     __shared__ double xx[64];
-    __shared__ double zs[64][MAXP + 1];
+    __shared__ double zs[64][(SMALLP ? 8 : MAXP) + 1];
     const int tid = threadIdx.x, lane = tid & 63;
     const int t0 = blockIdx.x * 64, m0 = blockIdx.y * 64, bz = blockIdx.z;
     const int b = a.b0 + bz, s = b / a.Dl, dl = b % a.Dl;
     const int P = a.P, Mp = a.Mp;
     const double var = a.hv.variance[dl];
-    for (int p = tid >> 6; p < P; p += 4) {
+    for (int p = tid >> 6; p < (SMALLP ? 8 : P); p += 4) {
         const int t = t0 + lane;
         double v = 0.0;
-        if (t < a.T) {
+        if (t < a.T && p < P) {
             v = (p < a.x_cols) ? a.x[(size_t)s * a.x_chain_stride + (size_t)t * a.x_ld + p]
                                : a.ctrl[(size_t)t * a.C + (p - a.x_cols)];
             if (KIND == 0) v = v / a.hv.len[(size_t)dl * P + p];
             else v = v * var;
         }
-        xs[p][lane] = v;
-        zs[lane][p] = a.hv.Zs[((size_t)dl * Mp + m0 + lane) * P + p];
+        if (SMALLP) xr8[lane][p] = v;
+        else xs[p][lane] = v;
+        zs[lane][p] = (p < P) ? a.hv.Zs[((size_t)dl * Mp + m0 + lane) * P + p] : 0.0;
     }
     __syncthreads();
     if (tid < 64) {
         double acc = 0.0;
-        if (KIND == 0) for (int p = 0; p < P; ++p) acc += xs[p][tid] * xs[p][tid];
+        if (KIND == 0) {
+            if (SMALLP) for (int p = 0; p < 8; ++p) acc += xr8[tid][p] * xr8[tid][p];     // padding adds exact zeros
+            else for (int p = 0; p < P; ++p) acc += xs[p][tid] * xs[p][tid];
+        }
         xx[tid] = acc;
     }
     __syncthreads();
@@ -192,15 +200,25 @@ __global__ __launch_bounds__(256) void kfu_build_kernel(ProjectArgs a) {
     const bool mok = (m0 + lane) < a.M;
     double zr[8];                               // this thread's inducing input (first 8 components) in registers
 #pragma unroll
-    for (int p = 0; p < 8; ++p) zr[p] = (p < P) ? zs[lane][p] : 0.0;
+    for (int p = 0; p < 8; ++p) zr[p] = (SMALLP || p < P) ? zs[lane][p] : 0.0;
+    const int rbase = (tid >> 6) * 16;
 #pragma unroll 4
     for (int i = 0; i < 16; ++i) {
-        const int r = (tid >> 6) * 16 + i;
+        const int r = rbase + i;
         double dot = 0.0;
+        if (SMALLP) {
 #pragma unroll
-        for (int p = 0; p < 8; ++p)
-            if (p < P) dot += xs[p][r] * zr[p];
-        for (int p = 8; p < P; ++p) dot += xs[p][r] * zs[lane][p];
+            for (int q = 0; q < 4; ++q) {
+                const double2 xv = *reinterpret_cast<const double2 *>(&xr8[r][2 * q]);
+                dot += xv.x * zr[2 * q];
+                dot += xv.y * zr[2 * q + 1];
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < 8; ++p)
+                if (p < P) dot += xs[p][r] * zr[p];
+            for (int p = 8; p < P; ++p) dot += xs[p][r] * zs[lane][p];
+        }
         double v = kernel_value<KIND>(dot, xx[r], zzv, var);
         if (!mok || t0 + r >= a.T) v = 0.0;
         out[(size_t)r * Mp] = v;
@@ -208,8 +226,13 @@ __global__ __launch_bounds__(256) void kfu_build_kernel(ProjectArgs a) {
 }
 void launch_kfu_build(hipStream_t stream, const ProjectArgs &a) {
     dim3 grid(a.Tp / 64, a.Mp / 64, a.nb);
-    if (a.kind == 0) hipLaunchKernelGGL(kfu_build_kernel<0>, grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(kfu_build_kernel<1>, grid, dim3(256), 0, stream, a);
+    if (a.P <= 8) {
+        if (a.kind == 0) hipLaunchKernelGGL((kfu_build_kernel<0, true>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((kfu_build_kernel<1, true>), grid, dim3(256), 0, stream, a);
+    } else {
+        if (a.kind == 0) hipLaunchKernelGGL((kfu_build_kernel<0, false>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((kfu_build_kernel<1, false>), grid, dim3(256), 0, stream, a);
+    }
 }
 
 // Operator-API kernel matrix (one kernel, arbitrary N, N2; no padding).
