@@ -558,6 +558,16 @@ __global__ __launch_bounds__(256) void potrf_trail_kernel(double *A, int n, int 
             if (!same) vj[h][i] = *reinterpret_cast<const double2 *>(Pj + (size_t)(sr + 16 * i) * n + 32 * h + sc);
         }
     const double *Bh = same ? Pi_h : Pj_h;
+    // the tile itself is requested now, so that its latency hides behind the staging and the MFMAs
+    double *Ct = S + (size_t)rowblk0 * n + colblk;
+    d4 cold[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                cold[x][y][q] = Ct[(size_t)(qr * 32 + 16 * x + lk + 4 * q) * n + qc * 32 + 16 * y + lr];
     d4 acc[2][2];
 #pragma unroll
     for (int x = 0; x < 2; ++x)
@@ -586,7 +596,6 @@ __global__ __launch_bounds__(256) void potrf_trail_kernel(double *A, int n, int 
                 for (int y = 0; y < 2; ++y) acc[x][y] = mfma_f64(af[x], bf[y], acc[x][y]);
         }
     }
-    double *Ct = S + (size_t)rowblk0 * n + colblk;
     if (tile != 0) {
 #pragma unroll
         for (int x = 0; x < 2; ++x)
@@ -595,7 +604,7 @@ __global__ __launch_bounds__(256) void potrf_trail_kernel(double *A, int n, int 
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const size_t off = (size_t)(qr * 32 + 16 * x + lk + 4 * q) * n + qc * 32 + 16 * y + lr;
-                    Ct[off] -= acc[x][y][q];
+                    Ct[off] = cold[x][y][q] - acc[x][y][q];
                 }
         return;
     }
@@ -612,7 +621,7 @@ __global__ __launch_bounds__(256) void potrf_trail_kernel(double *A, int n, int 
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int r = qr * 32 + 16 * x + lk + 4 * q, cc = qc * 32 + 16 * y + lr;
-                Ts[r][cc] = Ct[(size_t)r * n + cc] - acc[x][y][q];
+                Ts[r][cc] = cold[x][y][q] - acc[x][y][q];
             }
     __syncthreads();
     diag_block_finish<PIPE>(Ts, Lr, invd, S, n, k0 + NB, info + b, dinv + (size_t)b * DINV_STRIDE);
