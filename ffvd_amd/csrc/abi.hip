@@ -76,6 +76,11 @@ struct ffvd_handle {
     int64_t adam_t = 0;
     bool adam_ready = false;
     // pinned host staging
+    // result block: [8 term sums][S_local chain nll][Dl + nbatch info flags], contiguous on the device (resblk) and in
+    // pinned host memory (h_res) so that one copy brings everything back; out_terms / chain_nll / info and h_out /
+    // h_chain / h_info point into the two blocks
+    double *resblk = nullptr, *h_res = nullptr;
+    size_t res_bytes = 0;
     double *h_out = nullptr, *h_chain = nullptr;
     int32_t *h_info = nullptr;
     // optional live stage timing (HIP events on the handle's stream)
@@ -118,9 +123,7 @@ extern "C" int ffvd_destroy(ffvd_handle *h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     for (void *p : h->allocs) hipFree(p);
     for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
-    if (h->h_out) hipHostFree(h->h_out);
-    if (h->h_chain) hipHostFree(h->h_chain);
-    if (h->h_info) hipHostFree(h->h_info);
+    if (h->h_res) hipHostFree(h->h_res);
     if (h->aux) { hipStreamSynchronize(h->aux); hipStreamDestroy(h->aux); }
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_join) hipEventDestroy(h->ev_join);
@@ -250,9 +253,19 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
     HIP_TRY(dev_alloc(h, &h->hterms, (size_t)h->nbatch * 2));
     HIP_TRY(dev_alloc(h, &h->chain_terms, (size_t)c.S_local * 8));
     HIP_TRY(dev_alloc(h, &h->chain_partial, (size_t)c.S_local * 32));
-    HIP_TRY(dev_alloc(h, &h->chain_nll, (size_t)c.S_local));
-    HIP_TRY(dev_alloc(h, &h->out_terms, (size_t)8));
-    HIP_TRY(dev_alloc(h, &h->info, (size_t)(Dl + h->nbatch)));
+    {
+        const size_t nS = (size_t)(c.S_local ? c.S_local : 1), ninfo = (size_t)(Dl + h->nbatch);
+        const size_t ndbl = 8 + nS + (ninfo + 1) / 2;
+        HIP_TRY(dev_alloc(h, &h->resblk, ndbl));
+        h->res_bytes = ndbl * sizeof(double);
+        h->out_terms = h->resblk;
+        h->chain_nll = h->resblk + 8;
+        h->info = reinterpret_cast<int32_t *>(h->resblk + 8 + nS);
+        HIP_TRY(hipHostMalloc((void **)&h->h_res, h->res_bytes));
+        h->h_out = h->h_res;
+        h->h_chain = h->h_res + 8;
+        h->h_info = reinterpret_cast<int32_t *>(h->h_res + 8 + nS);
+    }
     if (c.branch == FFVD_BRANCH_B) {
         const int upass = h->cpp * (int)Dl;
         h->gsplit = gram_ksplit((int)Mp, upass, (int)Tp);
@@ -262,9 +275,6 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
     }
     HIP_TRY(dev_alloc(h, &h->dinvK, (size_t)Dl * DINV_STRIDE));
     HIP_TRY(dev_alloc(h, &h->dinvH, (size_t)(h->nbatch ? h->nbatch : 1) * DINV_STRIDE));
-    HIP_TRY(hipHostMalloc((void **)&h->h_out, 8 * sizeof(double)));
-    HIP_TRY(hipHostMalloc((void **)&h->h_chain, (size_t)(c.S_local ? c.S_local : 1) * sizeof(double)));
-    HIP_TRY(hipHostMalloc((void **)&h->h_info, (size_t)(Dl + h->nbatch) * sizeof(int32_t)));
     HIP_TRY(hipMemsetAsync(h->U, 0, (size_t)(c.M * c.D ? c.M * c.D : 1) * sizeof(double), h->stream));
     HIP_TRY(hipMemsetAsync(h->loglen, 0, (size_t)c.D * P * sizeof(double), h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -414,9 +424,8 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
     hipStream_t s = h->stream;
     const ffvd_params &p = h->cur;
     if (st) st->mark(-1);
-    HIP_TRY(hipMemsetAsync(h->info, 0, (size_t)(Dl + h->nbatch) * sizeof(int32_t), s));
     launch_prep_hypers(s, c.kernel_kind, p.Z, c.M, Mp, P, Dl, c.d_begin, p.logvariance, p.loglengthscales,
-                       h->variance, h->len, h->Zs, h->zz);
+                       h->variance, h->len, h->Zs, h->zz, h->info, Dl + h->nbatch);
     HyperView hv{h->variance, h->len, h->Zs, h->zz};
     const bool gram_route = (c.branch == FFVD_BRANCH_B && c.route == FFVD_ROUTE_GRAM);
     // Gram route: nothing of the K_fu build depends on K_uu, so the latency-bound K_uu chain (build, Cholesky with
@@ -646,9 +655,7 @@ extern "C" int ffvd_elbo(ffvd_handle *h, const ffvd_params *p, uint32_t flags, d
     }
     if ((rc = ready(h, "ffvd_elbo"))) return rc;
     if ((rc = enqueue_elbo(h, nullptr, nullptr))) return rc;
-    HIP_TRY(hipMemcpyAsync(h->h_out, h->out_terms, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipMemcpyAsync(h->h_chain, h->chain_nll, (size_t)h->cfg.S_local * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipMemcpyAsync(h->h_info, h->info, (size_t)(h->Dl + h->nbatch) * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->h_res, h->resblk, h->res_bytes, hipMemcpyDeviceToHost, h->stream));      // terms, chain nll, info flags
     HIP_TRY(hipStreamSynchronize(h->stream));
     if ((rc = check_info(h))) return rc;
     if (out_terms) memcpy(out_terms, h->h_out, 8 * sizeof(double));
@@ -955,9 +962,7 @@ extern "C" int ffvd_elbo_grad(ffvd_handle *h, const ffvd_params *p, uint32_t fla
     const ffvd_config &c = h->cfg;
     ffvd_handle::GradWs &g = h->gw;
     hipStream_t s = h->stream;
-    HIP_TRY(hipMemcpyAsync(h->h_out, h->out_terms, 8 * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(h->h_chain, h->chain_nll, (size_t)c.S_local * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(h->h_info, h->info, (size_t)(h->Dl + h->nbatch) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(h->h_res, h->resblk, h->res_bytes, hipMemcpyDeviceToHost, s));      // terms, chain nll, info flags
     const size_t P = h->P, J = c.Ydim;
     if (gout->X) HIP_TRY(hipMemcpyAsync(gout->X, g.dX, (size_t)c.S_local * (c.T + 1) * c.D * sizeof(double), hipMemcpyDeviceToHost, s));
     if (gout->Z) HIP_TRY(hipMemcpyAsync(gout->Z, g.dZ, (size_t)c.M * P * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -1026,9 +1031,7 @@ extern "C" int ffvd_adam_step(ffvd_handle *h, double lr, double beta1, double be
     if ((rc = enqueue_elbo(h, nullptr, nullptr))) return rc;
     if ((rc = enqueue_grad(h, h->cfg.S_local))) return rc;
     hipStream_t s = h->stream;
-    HIP_TRY(hipMemcpyAsync(h->h_out, h->out_terms, 8 * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(h->h_chain, h->chain_nll, (size_t)h->cfg.S_local * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(h->h_info, h->info, (size_t)(h->Dl + h->nbatch) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(h->h_res, h->resblk, h->res_bytes, hipMemcpyDeviceToHost, s));      // terms, chain nll, info flags
     HIP_TRY(hipStreamSynchronize(s));
     if ((rc = check_info(h))) return rc;           // a failed factorisation leaves the parameters untouched
     double *theta[NPARAM]; const double *grad[NPARAM]; size_t n[NPARAM];
@@ -1119,9 +1122,7 @@ extern "C" int ffvd_sghmc_step(ffvd_handle *h, double epsilon, double mdecay, ui
     }
     if ((rc = enqueue_elbo(h, nullptr, nullptr))) return rc;
     if ((rc = enqueue_grad(h, h->cfg.S_local))) return rc;
-    HIP_TRY(hipMemcpyAsync(h->h_out, h->out_terms, 8 * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(h->h_chain, h->chain_nll, (size_t)h->cfg.S_local * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(h->h_info, h->info, (size_t)(h->Dl + h->nbatch) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(h->h_res, h->resblk, h->res_bytes, hipMemcpyDeviceToHost, s));      // terms, chain nll, info flags
     HIP_TRY(hipStreamSynchronize(s));
     if ((rc = check_info(h))) return rc;
     OptTable tab{};

@@ -24,7 +24,7 @@ struct HyperView {
 // hyp <- exp of the log-parameters; Zs, zz as above.  logvar/loglen are indexed by GLOBAL dim (d_begin + dl).
 void launch_prep_hypers(hipStream_t stream, int kind, const double *Z, int M, int Mp, int P, int Dl, int d_begin,
                         const double *logvar, const double *loglen, double *variance, double *len,
-                        double *Zs, double *zz);
+                        double *Zs, double *zz, int32_t *info = nullptr, int ninfo = 0);   // info: flags to zero
 
 // A[dl] (ld = Mp, rows 0..Mp-1) = K_dl(Z, Z) + jitter*I with identity padding; rows Mp..2Mp-1 = I (the
 // "extra rows" that the extended Cholesky turns into L^{-T}).  A has Dl slabs of 2*Mp*Mp doubles.

@@ -64,9 +64,12 @@ void launch_fill(hipStream_t stream, double *p, size_t n, double v) {
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void prep_hypers_kernel(int kind, const double *Z, int M, int Mp, int P, int d_begin,
                                                           const double *logvar, const double *loglen,
-                                                          double *variance, double *len, double *Zs, double *zz) {
+                                                          double *variance, double *len, double *Zs, double *zz,
+                                                          int32_t *info, int ninfo) {
     __shared__ double ls[MAXP];
     const int dl = blockIdx.x, dg = d_begin + dl, tid = threadIdx.x;
+    if (info && dl == 0)                             // re-arm the factorisation flags of this iteration
+        for (int i = tid; i < ninfo; i += 256) info[i] = 0;
     if (tid == 0) variance[dl] = exp(logvar[dg]);
     if (tid < P) {
         double l = (kind == 0) ? exp(loglen[(size_t)dg * P + tid]) : 1.0;
@@ -86,9 +89,9 @@ __global__ __launch_bounds__(256) void prep_hypers_kernel(int kind, const double
 }
 void launch_prep_hypers(hipStream_t stream, int kind, const double *Z, int M, int Mp, int P, int Dl, int d_begin,
                         const double *logvar, const double *loglen, double *variance, double *len,
-                        double *Zs, double *zz) {
+                        double *Zs, double *zz, int32_t *info, int ninfo) {
     hipLaunchKernelGGL(prep_hypers_kernel, dim3(Dl), dim3(256), 0, stream, kind, Z, M, Mp, P, d_begin, logvar,
-                       loglen, variance, len, Zs, zz);
+                       loglen, variance, len, Zs, zz, info, ninfo);
 }
 
 // K(i,j) of one kernel from pre-scaled rows.  SE: variance * exp(-(-2 x.z + (|x|^2 + |z|^2)) / 2)
@@ -1440,68 +1443,79 @@ void launch_get_rand(hipStream_t stream, const double *mean, const double *var, 
 // ---------------------------------------------------------------------------------------------
 // Priors + nll assembly (dgp_model.py:105-143, 259-297, 326-334)
 // ---------------------------------------------------------------------------------------------
+// N sums over a 256-thread workgroup at once: wavefront shuffles, then the four wavefront partials in fixed order.
+// Every thread returns with the totals in v[].
+template <int N>
+__device__ __forceinline__ void block_sum_multi_256(double (&v)[N], double (*scratch)[N] /*[4][N]*/) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) v[i] += __shfl_xor(v[i], m);
+    }
+    __syncthreads();                                   // a previous use of scratch is over
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) scratch[wave][i] = v[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = ((scratch[0][i] + scratch[1][i]) + scratch[2][i]) + scratch[3][i];
+}
+
 __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
-    __shared__ double scratch[256];
-    __shared__ double sh[8];
+    __shared__ double scratch[4][10];
     const int tid = threadIdx.x;
     const double Tn = (double)a.T;      // batch_size == Y_N == T for the full batch (dgp_model.py:261-262)
-    // shared priors
-    double zsum = 0.0, usum = 0.0;
+    // shared priors and constants: ten small sums, every thread takes a strided share, one reduction for all
+    // 0 |Z|^2  1 |U|^2  2 sum loglen^2  3 sum (logvar - log 0.05)^2  4 |log_Q|^2  5 |C|^2  6 |d|^2  7 |log_Rchols|^2
+    // 8 sum_j log R_j  9 sum_d log sqrt(Q_d)
+    double sm[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) sm[i] = 0.0;
     if (a.shared_terms && a.prior_type == 1)
-        for (int i = tid; i < a.M * a.P; i += 256) zsum += a.Z[i] * a.Z[i];
+        for (int i = tid; i < a.M * a.P; i += 256) sm[0] += a.Z[i] * a.Z[i];
     if (a.branch == 0)
         for (int i = tid; i < a.M * a.Dl; i += 256) {
             const int m = i / a.Dl, dl = i % a.Dl;
             const double u = a.U[(size_t)m * a.D + a.d_begin + dl];
-            usum += u * u;
+            sm[1] += u * u;
         }
-    zsum = block_sum_256(zsum, scratch);
-    usum = block_sum_256(usum, scratch);
-    if (tid == 0) {
-        double prior_hyper = 0.0;       // Layer.prior_hyper dgp_model.py:123-130 over the local dims
-        for (int dl = 0; dl < a.Dl; ++dl) {
-            const int dg = a.d_begin + dl;
-            if (a.kind == 0) {
-                double l2 = 0.0;
-                for (int p = 0; p < a.P; ++p) { double l = a.loglen[(size_t)dg * a.P + p]; l2 += l * l; }
-                prior_hyper += -l2 / 2.0;
-            }
-            const double dv = a.logvar[dg] - log(0.05);
-            prior_hyper += -(dv * dv) / 2.0;
+    if (a.kind == 0)                    // Layer.prior_hyper dgp_model.py:123-130 over the local dims
+        for (int i = tid; i < a.Dl * a.P; i += 256) {
+            const double l = a.loglen[(size_t)a.d_begin * a.P + i];
+            sm[2] += l * l;
         }
-        double hyp = 0.0;               // hypaparameter_prior dgp_model.py:326-334
-        if (a.shared_terms) {
-            double q2 = 0.0, c2 = 0.0, d2 = 0.0, r2 = 0.0;
-            for (int d = 0; d < a.D; ++d) q2 += a.log_Q[d] * a.log_Q[d];
-            for (int i = 0; i < a.D * a.Ydim; ++i) c2 += a.CC[i] * a.CC[i];
-            for (int j = 0; j < a.Ydim; ++j) d2 += a.DD[j] * a.DD[j];
-            for (int i = 0; i < a.Ydim * a.Ydim; ++i) r2 += a.log_Rchols[i] * a.log_Rchols[i];
-            hyp = -q2 / 2.0 - c2 / 2.0 - d2 / 2.0 - r2 / 2.0;
-        }
-        double logR = 0.0;              // -reduce_sum(log(Rchols)) likelihoods.py:101
-        for (int j = 0; j < a.Ydim; ++j) logR += log(exp(a.log_Rchols[j]));
-        double logsqQ = 0.0;            // -sum_d log(Q_d ** 0.5) likelihoods.py:91 / :101
-        for (int dl = 0; dl < a.Dl; ++dl) logsqQ += log(sqrt(exp(a.log_Q[a.d_begin + dl])));
-        sh[0] = prior_hyper;
-        sh[1] = hyp;
-        sh[2] = (a.shared_terms && a.prior_type == 1) ? -zsum / 2.0 : 0.0;   // prior_Z dgp_model.py:108-109
-        sh[3] = (a.branch == 0) ? -0.5 * usum : 0.0;                          // prior_U dgp_model.py:134-135
-        sh[4] = logR;
-        sh[5] = logsqQ;
+    for (int dl = tid; dl < a.Dl; dl += 256) {
+        const double dv = a.logvar[a.d_begin + dl] - log(0.05);
+        sm[3] += dv * dv;
+        sm[9] += log(sqrt(exp(a.log_Q[a.d_begin + dl])));          // -sum_d log(Q_d ** 0.5) likelihoods.py:91 / :101
     }
-    __syncthreads();
+    if (a.shared_terms) {               // hypaparameter_prior dgp_model.py:326-334
+        for (int d = tid; d < a.D; d += 256) sm[4] += a.log_Q[d] * a.log_Q[d];
+        for (int i = tid; i < a.D * a.Ydim; i += 256) sm[5] += a.CC[i] * a.CC[i];
+        for (int j = tid; j < a.Ydim; j += 256) sm[6] += a.DD[j] * a.DD[j];
+        for (int i = tid; i < a.Ydim * a.Ydim; i += 256) sm[7] += a.log_Rchols[i] * a.log_Rchols[i];
+    }
+    for (int j = tid; j < a.Ydim; j += 256) sm[8] += log(exp(a.log_Rchols[j]));    // -reduce_sum(log(Rchols)) likelihoods.py:101
+    block_sum_multi_256<10>(sm, scratch);
+    const double prior_hyper = -sm[2] / 2.0 - sm[3] / 2.0;
+    const double hyp = a.shared_terms ? (-sm[4] / 2.0 - sm[5] / 2.0 - sm[6] / 2.0 - sm[7] / 2.0) : 0.0;
+    const double prior_z = (a.shared_terms && a.prior_type == 1) ? -sm[0] / 2.0 : 0.0;     // prior_Z dgp_model.py:108-109
+    const double prior_u = (a.branch == 0) ? -0.5 * sm[1] : 0.0;                            // prior_U dgp_model.py:134-135
+    const double logR = sm[8], logsqQ = sm[9];
     // per-chain assembly: one thread per chain (strided), then a fixed-order sum over chains
     double part[7] = {0, 0, 0, 0, 0, 0, 0};
     for (int s = tid; s < a.S; s += 256) {
         const double *ct = a.chain_terms + (size_t)s * 8;
         double terms[7] = {0, 0, 0, 0, 0, 0, 0};
-        double prior = sh[0] + sh[3];
+        double prior = prior_hyper + prior_u;
         if (a.shared_terms) {
-            prior += sh[2] + ct[3] + sh[1];
-            terms[1] = -(ct[0] + Tn * (-sh[4])) / Tn;                  // nll_log_likelihood :264
+            prior += prior_z + ct[3] + hyp;
+            terms[1] = -(ct[0] + Tn * (-logR)) / Tn;                   // nll_log_likelihood :264
         }
         terms[0] = -prior / Tn;                                          // nll_part_prior :286 / :296
-        terms[2] = -(ct[1] + Tn * (-sh[5])) / Tn;                      // x_t_prior_Q :283-284 / :294
+        terms[2] = -(ct[1] + Tn * (-logsqQ)) / Tn;                     // x_t_prior_Q :283-284 / :294
         terms[3] = -ct[2] / Tn;                                          // trace term :257 / :292
         if (a.branch == 1) {
             double term1 = 0.0, term2 = 0.0;
@@ -1527,11 +1541,11 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
         a.chain_nll[s] = terms[6];
         for (int i = 0; i < 7; ++i) part[i] += terms[i];
     }
-    for (int i = 0; i < 7; ++i) {
-        const double v = block_sum_256(part[i], scratch);
-        if (tid == 0) a.out_terms[i] = v;
-    }
-    if (tid == 0) a.out_terms[7] = a.shared_terms ? (double)a.S : 0.0;
+    block_sum_multi_256<7>(part, reinterpret_cast<double(*)[7]>(&scratch[0][0]));
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+        if (tid == i) a.out_terms[i] = part[i];
+    if (tid == 7) a.out_terms[7] = a.shared_terms ? (double)a.S : 0.0;
 }
 void launch_finalize(hipStream_t stream, const FinalizeArgs &a) {
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, stream, a);
