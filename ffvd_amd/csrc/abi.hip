@@ -861,6 +861,14 @@ static int enqueue_grad_b(ffvd_handle *h, int S_total) {
     ag.part = g.gam_part; ag.k_lower = 1;               // L_A^-1 is lower triangular
     launch_atb(s, ag);
     launch_uku(s, g.u, Mp, h->Kcopy, msq, Mp, Dl, nb, g.uku);
+    // K_uu side: Psi_d = sum_s Gamma_s / alpha_d - 1/2 K^-1 (sum_s A_s - S K) K^-1.  It needs Gamma and the saved
+    // A-matrices only, so its dozen small launches go to the side stream and run beside the E product
+    // (enqueued after it: the main stream must not wait for their launch overhead).
+    hipStream_t sk = getenv("FFVD_GRAD_SERIAL") ? s : h->aux;
+    if (sk != s) {
+        HIP_TRY(hipEventRecord(h->ev_fork, s));
+        HIP_TRY(hipStreamWaitEvent(sk, h->ev_fork, 0));
+    }
     EReduceArgs er{};
     er.E = g.E; er.e_stride = fstride; er.Kf = h->F; er.u = g.u; er.u_stride = Mp; er.x_is_z = 0;
     er.x = p.X; er.x_chain_stride = (size_t)(c.T + 1) * c.D; er.x_ld = c.D; er.x_cols = c.D; er.ctrl = h->ctrl; er.C = c.C;
@@ -888,25 +896,26 @@ static int enqueue_grad_b(ffvd_handle *h, int S_total) {
         launch_e_reduce(s, er);
     }
     launch_e_finish(s, er, g.dz_unit, g.dll_unit, g.dls_unit);
-    // K_uu side: Psi_d = sum_s Gamma_s / alpha_d - 1/2 K^-1 (sum_s A_s - S K) K^-1
-    launch_chain_sum(s, g.Acopy, msq, S, Dl, msq, g.Asum, msq);
-    launch_symmetrize(s, g.Asum, Mp, Dl);
-    launch_chain_sum(s, g.Gamma, msq, S, Dl, msq, g.GamSum, msq);
-    launch_axpby(s, g.Asum, h->Kcopy, 1.0, -(double)S, p.log_Q, c.d_begin, 0, msq, Dl, g.Gs);
-    launch_axpby(s, g.GamSum, nullptr, 1.0, 0.0, p.log_Q, c.d_begin, 1, msq, Dl, g.gsum);
+    launch_chain_sum(sk, g.Acopy, msq, S, Dl, msq, g.Asum, msq);
+    launch_symmetrize(sk, g.Asum, Mp, Dl);
+    launch_chain_sum(sk, g.Gamma, msq, S, Dl, msq, g.GamSum, msq);
+    launch_axpby(sk, g.Asum, h->Kcopy, 1.0, -(double)S, p.log_Q, c.d_begin, 0, msq, Dl, g.Gs);
+    launch_axpby(sk, g.GamSum, nullptr, 1.0, 0.0, p.log_Q, c.d_begin, 1, msq, Dl, g.gsum);
     AtbArgs ap{};
     ap.mode = ATB_PLAIN; ap.A = g.Gs; ap.a_stride = msq; ap.lda = Mp; ap.nA = Mp; ap.B = h->Kinv; ap.b_stride = msq;
     ap.ldb = Mp; ap.nB = Mp; ap.rows = Mp; ap.C = g.P1; ap.c_stride = msq; ap.ldc = Mp; ap.nb = Dl; ap.Dl = Dl;
-    launch_atb(s, ap);                                  // P1 = Gs^T K^-1 = Gs K^-1
+    launch_atb(sk, ap);                                 // P1 = Gs^T K^-1 = Gs K^-1
     ap.A = g.P1; ap.C = g.KGK;
-    launch_atb(s, ap);                                  // P1^T K^-1 = K^-1 Gs K^-1
-    launch_psi_e(s, g.gsum, g.KGK, h->Kcopy, c.M, Mp, Dl, c.jitter, g.Epsi);
+    launch_atb(sk, ap);                                 // P1^T K^-1 = K^-1 Gs K^-1
+    launch_psi_e(sk, g.gsum, g.KGK, h->Kcopy, c.M, Mp, Dl, c.jitter, g.Epsi);
     EReduceArgs ek{};
     ek.E = g.Epsi; ek.e_stride = msq; ek.Kf = nullptr; ek.u = nullptr; ek.x_is_z = 1; ek.Z = p.Z; ek.len = h->len;
     ek.T = c.M; ek.Tp = Mp; ek.M = c.M; ek.Mp = Mp; ek.P = P; ek.Dl = Dl; ek.b0 = 0; ek.nb = Dl; ek.nblk = Mp / 64;
     ek.rsum = g.rsum2; ek.ez = g.ez2; ek.kfu = nullptr; ek.cs_part = g.cs2; ek.etx_part = g.etx2; ek.rx2_part = g.rx22;
-    launch_e_reduce(s, ek);
-    launch_e_finish(s, ek, g.dz_kuu, g.dll_kuu, g.dls_kuu);
+    launch_e_reduce(sk, ek);
+    launch_e_finish(sk, ek, g.dz_kuu, g.dll_kuu, g.dls_kuu);
+    if (sk != s) HIP_TRY(hipEventRecord(h->ev_join, sk));
+    if (sk != s) HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));
     // latent trajectories and the per-chain partials of the shared parameters
     DxArgs dx{};
     dx.X = p.X; dx.Y = h->Y; dx.CC = p.CC; dx.DD = p.DD; dx.log_Rchols = p.log_Rchols; dx.log_Q = p.log_Q; dx.len = h->len;
