@@ -860,7 +860,6 @@ static int enqueue_grad_b(ffvd_handle *h, int S_total) {
     ag.log_Q = p.log_Q; ag.u = g.u; ag.u_stride = Mp; ag.Kinv = h->Kinv; ag.Kcopy = h->Kcopy; ag.k_stride = msq; ag.ldk = Mp;
     ag.part = g.gam_part; ag.k_lower = 1;               // L_A^-1 is lower triangular
     launch_atb(s, ag);
-    launch_uku(s, g.u, Mp, h->Kcopy, msq, Mp, Dl, nb, g.uku);
     // K_uu side: Psi_d = sum_s Gamma_s / alpha_d - 1/2 K^-1 (sum_s A_s - S K) K^-1.  It needs Gamma and the saved
     // A-matrices only, so its dozen small launches go to the side stream and run beside the E product
     // (enqueued after it: the main stream must not wait for their launch overhead).
@@ -896,6 +895,7 @@ static int enqueue_grad_b(ffvd_handle *h, int S_total) {
         launch_e_reduce(s, er);
     }
     launch_e_finish(s, er, g.dz_unit, g.dll_unit, g.dls_unit);
+    launch_uku(sk, g.u, Mp, h->Kcopy, msq, Mp, Dl, nb, g.uku);      // u^T K u per unit: only grad_finalize reads it
     launch_chain_sum(sk, g.Acopy, msq, S, Dl, msq, g.Asum, msq);
     launch_symmetrize(sk, g.Asum, Mp, Dl);
     launch_chain_sum(sk, g.Gamma, msq, S, Dl, msq, g.GamSum, msq);

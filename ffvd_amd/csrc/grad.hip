@@ -953,30 +953,46 @@ void launch_shared_partials(hipStream_t stream, const DxArgs &a, double *out, in
 // ---------------------------------------------------------------------------------------------
 // Final assembly of the shared-parameter gradients (one workgroup; fixed summation order).
 // ---------------------------------------------------------------------------------------------
+// One workgroup per local latent dim; every sum over the chains is a strided per-thread partial followed by one
+// multi-value workgroup reduction (a single thread walking S x (ngam + ntr) dependent loads took 0.12 ms).
 __global__ __launch_bounds__(256) void grad_finalize_kernel(GradFinalArgs a) {
-    const int tid = threadIdx.x;
-    const int D = a.D, P = a.P, M = a.M, J = a.Ydim, Dl = a.Dl, S = a.S;
+    __shared__ double scratch[4][8];
+    const int tid = threadIdx.x, dl = blockIdx.x, dg = a.d_begin + dl;
+    const int D = a.D, P = a.P, J = a.Ydim, Dl = a.Dl, S = a.S;
     const double Tn = (double)a.T, Sn = (double)a.S_total;
     // prior gradients are weighted by this handle's share of the chains, so that the sum over chain shards
     // (and over dim shards, where S == S_total and every dim has one owner) is the whole-job gradient
     const double w = (double)S / Sn;
-    // loglengthscales, logvariance, log_Q for the local dims
-    for (int idx = tid; idx < Dl * P; idx += 256) {
-        const int dl = idx / P, p = idx % P, dg = a.d_begin + dl;
-        double acc = 0.0;
-        for (int s = 0; s < S; ++s) acc += a.dll_unit[(size_t)(s * Dl + dl) * P + p];
-        acc += a.dll_kuu[(size_t)dl * P + p];
-        a.dloglen[(size_t)dg * P + p] = -acc / Tn / Sn + w * a.loglen[(size_t)dg * P + p] / Tn;
+    // loglengthscales of this dim, eight components at a time
+    for (int p0 = 0; p0 < P; p0 += 8) {
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = 0.0;
+        for (int s = tid; s < S; s += 256) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (p0 + q < P) v[q] += a.dll_unit[(size_t)(s * Dl + dl) * P + p0 + q];
+        }
+        block_sum_multi_256<8>(v, scratch);
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (tid == q && p0 + q < P) {
+                const int p = p0 + q;
+                const double acc = v[q] + a.dll_kuu[(size_t)dl * P + p];
+                a.dloglen[(size_t)dg * P + p] = -acc / Tn / Sn + w * a.loglen[(size_t)dg * P + p] / Tn;
+            }
     }
-    for (int dl = tid; dl < Dl; dl += 256) {
-        const int dg = a.d_begin + dl;
+    // logvariance, log_Q
+    {
         const double alpha = 1.0 / exp(a.log_Q[dg]), s2 = exp(a.logvar[dg]);
-        double ls = 0.0, dq = 0.0, tq = 0.0;
-        for (int s = 0; s < S; ++s) {
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = 0.0;
+        for (int s = tid; s < S; s += 256) {
             const size_t bb = (size_t)s * Dl + dl;
-            ls += a.dls_unit[bb] - 0.5 * alpha * Tn * s2;            // K_fu side + direct Kdiag term
+            v[0] += a.dls_unit[bb] - 0.5 * alpha * Tn * s2;          // K_fu side + direct Kdiag term
             if (a.branch_a) {                                        // explicit U: dl/dalpha comes per unit from resid_a
-                dq += a.dalpha_unit[bb] * (-alpha);
+                v[1] += a.dalpha_unit[bb] * (-alpha);
                 continue;
             }
             // dl/dalpha = -1/2 tr(A^-1 G) + u^T g - 1/2 u^T G u - 1/2 (T s2 - tr(K^-1 G)),  G = (A - K)/alpha
@@ -988,29 +1004,41 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(GradFinalArgs a) {
             const double trAinvG = ((double)a.Mp - trAK) / alpha;
             const double uGu = (quad - a.uku[bb]) / alpha;
             const double dalpha = -0.5 * trAinvG + quad / alpha - 0.5 * uGu - 0.5 * (Tn * s2 - fsq);
-            dq += dalpha * (-alpha);
-            tq += a.shared_part[(size_t)s * a.sp_stride + D * J + 2 * J + dl];
+            v[1] += dalpha * (-alpha);
+            v[2] += a.shared_part[(size_t)s * a.sp_stride + D * J + 2 * J + dl];
         }
-        ls += a.dls_kuu[dl];
-        a.dlogvar[dg] = -ls / Tn / Sn + w * (a.logvar[dg] - log(0.05)) / Tn;
-        a.dlogQ[dg] = -dq / Tn / Sn + (a.branch_a ? 0.0 : tq / Sn) + w * a.log_Q[dg] / Tn;
+        block_sum_multi_256<8>(v, scratch);
+        if (tid == 0) {
+            const double ls = v[0] + a.dls_kuu[dl];
+            a.dlogvar[dg] = -ls / Tn / Sn + w * (a.logvar[dg] - log(0.05)) / Tn;
+            a.dlogQ[dg] = -v[1] / Tn / Sn + (a.branch_a ? 0.0 : v[2] / Sn) + w * a.log_Q[dg] / Tn;
+        }
     }
-    if (a.shared_terms) {
-        for (int idx = tid; idx < D * J + J; idx += 256) {
-            double acc = 0.0;
-            for (int s = 0; s < S; ++s) acc += a.shared_part[(size_t)s * a.sp_stride + idx];
-            acc /= Sn;
-            if (idx < D * J) a.dCC[idx] = acc + w * a.CC[idx] / Tn;
-            else a.dDD[idx - D * J] = acc + w * a.DD[idx - D * J] / Tn;
-        }
-        for (int idx = tid; idx < J * J; idx += 256) {     // only row 0 of log_Rchols enters the likelihood
-            double lik = 0.0;
-            if (idx < J) {
-                for (int s = 0; s < S; ++s) lik += a.shared_part[(size_t)s * a.sp_stride + D * J + J + idx];
-                lik /= Sn;
+    if (a.shared_terms && dl == 0) {
+        // C, d and row 0 of log_Rchols: D J + J + J per-chain partials, eight at a time
+        const int nitem = D * J + 2 * J;
+        for (int i0 = 0; i0 < nitem; i0 += 8) {
+            double v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = 0.0;
+            for (int s = tid; s < S; s += 256) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (i0 + q < nitem) v[q] += a.shared_part[(size_t)s * a.sp_stride + i0 + q];
             }
-            a.dlogR[idx] = lik + w * a.log_Rchols[idx] / Tn;
+            block_sum_multi_256<8>(v, scratch);
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (tid == q && i0 + q < nitem) {
+                    const int idx = i0 + q;
+                    const double acc = v[q] / Sn;
+                    if (idx < D * J) a.dCC[idx] = acc + w * a.CC[idx] / Tn;
+                    else if (idx < D * J + J) a.dDD[idx - D * J] = acc + w * a.DD[idx - D * J] / Tn;
+                    else a.dlogR[idx - D * J - J] = acc + w * a.log_Rchols[idx - D * J - J] / Tn;
+                }
         }
+        for (int idx = J + tid; idx < J * J; idx += 256)       // only row 0 of log_Rchols enters the likelihood
+            a.dlogR[idx] = w * a.log_Rchols[idx] / Tn;
     }
 }
 // explicit-U branch: dU[m][d] = -(alpha_d (W^T g_r)[m]) / T / S_total + (S / S_total) U[m][d] / T   (prior_U, choice 1)
@@ -1044,7 +1072,7 @@ __global__ __launch_bounds__(256) void grad_dz_kernel(GradFinalArgs a) {
 void launch_grad_finalize(hipStream_t stream, const GradFinalArgs &a) {
     hipLaunchKernelGGL(grad_dz_kernel, dim3((a.M * a.P + 255) / 256), dim3(256), 0, stream, a);
     if (a.branch_a && a.dU) hipLaunchKernelGGL(grad_du_kernel, dim3((a.M * a.D + 255) / 256), dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(grad_finalize_kernel, dim3(1), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(grad_finalize_kernel, dim3(a.Dl), dim3(256), 0, stream, a);
 }
 
 // ---------------------------------------------------------------------------------------------

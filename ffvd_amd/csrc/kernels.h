@@ -173,4 +173,24 @@ void launch_rollout_update(hipStream_t stream, const double *mean, const double 
                            const double *eps_t, const double *ctrl_next, int R, int D, int C, int t, int steps, double *xc,
                            double *predict_x, double *predict_var);
 
+// N sums over a 256-thread workgroup at once: wavefront shuffles, then the four wavefront partials in fixed order.
+// Every thread returns with the totals in v[].
+template <int N>
+__device__ __forceinline__ void block_sum_multi_256(double (&v)[N], double (*scratch)[N] /*[4][N]*/) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) v[i] += __shfl_xor(v[i], m);
+    }
+    __syncthreads();                                   // a previous use of scratch is over
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) scratch[wave][i] = v[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = ((scratch[0][i] + scratch[1][i]) + scratch[2][i]) + scratch[3][i];
+}
+
 }  // namespace ffvd

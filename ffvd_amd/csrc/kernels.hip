@@ -1471,26 +1471,6 @@ void launch_get_rand(hipStream_t stream, const double *mean, const double *var, 
 // ---------------------------------------------------------------------------------------------
 // Priors + nll assembly (dgp_model.py:105-143, 259-297, 326-334)
 // ---------------------------------------------------------------------------------------------
-// N sums over a 256-thread workgroup at once: wavefront shuffles, then the four wavefront partials in fixed order.
-// Every thread returns with the totals in v[].
-template <int N>
-__device__ __forceinline__ void block_sum_multi_256(double (&v)[N], double (*scratch)[N] /*[4][N]*/) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-#pragma unroll
-        for (int m = 32; m > 0; m >>= 1) v[i] += __shfl_xor(v[i], m);
-    }
-    __syncthreads();                                   // a previous use of scratch is over
-    if (lane == 0) {
-#pragma unroll
-        for (int i = 0; i < N; ++i) scratch[wave][i] = v[i];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] = ((scratch[0][i] + scratch[1][i]) + scratch[2][i]) + scratch[3][i];
-}
-
 __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
     __shared__ double scratch[4][10];
     const int tid = threadIdx.x;
