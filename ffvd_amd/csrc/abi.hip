@@ -429,11 +429,15 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
     HyperView hv{h->variance, h->len, h->Zs, h->zz};
     const bool gram_route = (c.branch == FFVD_BRANCH_B && c.route == FFVD_ROUTE_GRAM);
     // Gram route: nothing of the K_fu build depends on K_uu, so the latency-bound K_uu chain (build, Cholesky with
-    // the L^-T rows, K^-1, log|K|: a handful of workgroups per launch) runs on the side stream beside the
-    // HBM-bound K_fu build of the first pass and joins before the Gram kernel, which adds K_uu and reads K^-1.
+    // the L^-T rows, K^-1, log|K|: a handful of workgroups per launch) runs on the side stream.  Schedules, by what
+    // the first pass looks like (DESIGN.md section 5 has the measurements):
+    //   unsplit Gram, large pass (defer_full): main = K_fu build, wait for the K_uu COPY, Gram kernel that also keeps
+    //     its raw tiles, Cholesky(A); side = chain, then the trace partials from the raw tiles; join at finalize.
+    //   split-K Gram, one pass (defer_trace): main = K_fu build, tile pass, wait for the K_uu copy, combine without
+    //     the trace, Cholesky(A); side = chain, trace partials from the split-K partial tiles; join at finalize.
+    //   split-K Gram, several passes (late_join only): the combine pass of the first pass waits for the whole chain.
+    //   small unsplit pass without raw-tile buffer: the chain runs first on the main stream (sk == s).
     hipStream_t sk = s;
-    // (measured on config 2: 4.41 ms overlapped vs 4.51 ms serial with 128 units per pass; with 16 units the K_fu
-    //  build is shorter than the chain and sharing CUs only slows both: 1.42 vs 1.37 ms -> serial there)
     const int first_units = ((c.S_local < h->cpp) ? c.S_local : h->cpp) * Dl;
     // split-K first pass: its tile kernel writes raw partials and needs neither K_uu nor K^-1, so the chain may run
     // beside the K_fu build AND the tile pass and only has to be back for the combine pass
