@@ -1675,7 +1675,10 @@ extern "C" int ffvd_op_rollout(int kind, const double *Lm_inverse_seq, const dou
         return set_error(nullptr, FFVD_EINVAL, "ffvd_op_rollout: bad argument");
     OP_BEGIN("ffvd_op_rollout");
     if (steps == 0) return FFVD_OK;
-    const int Mp = round_up(M, NB), Tp = round_up(R, STRIP), ng = (Mp + 511) / 512;
+    // K_fu rows once per step, then the triangular projection GEMM with fvar / fmean in its epilogue (one workgroup
+    // per 128-column tile and dim): 16 workgroups instead of the 4 of the fused projection kernel, whose single
+    // workgroup per dim made a step compute-bound on one CU
+    const int Mp = round_up(M, NB), Tp = round_up(R, STRIP), ng = (Mp + 127) / 128;
     std::vector<double> Wp = pad_stack(Lm_inverse_seq, D, M, Mp);
     std::vector<double> xc0((size_t)R * P);
     for (int r = 0; r < R; ++r) {
@@ -1690,13 +1693,14 @@ extern "C" int ffvd_op_rollout(int kind, const double *Lm_inverse_seq, const dou
     double *variance = sc.alloc<double>(D), *len = sc.alloc<double>((size_t)D * P);
     double *Zs = sc.alloc<double>((size_t)D * Mp * P), *zz = sc.alloc<double>((size_t)D * Mp);
     double *F = q_sqrt ? sc.alloc<double>((size_t)D * Tp * Mp) : nullptr;
+    double *Kf = sc.alloc<double>((size_t)D * Tp * Mp), *ucol = sc.alloc<double>((size_t)D * Mp);
     double *rowsq = sc.alloc<double>((size_t)D * ng * Tp), *fmean = sc.alloc<double>((size_t)D * ng * Tp);
     double *dmean = sc.alloc<double>((size_t)R * D), *dvar = sc.alloc<double>((size_t)R * D);
     double *dpx = sc.alloc<double>((size_t)R * steps * D), *dpv = sc.alloc<double>((size_t)R * steps * D);
     double *dQs = q_sqrt ? sc.upload(q_sqrt, (size_t)M * M) : nullptr;     // slice d = 0 only
     double *extra = q_sqrt ? sc.alloc<double>((size_t)D * Tp) : nullptr;
     if (!dW || !dxc || !dZ || !dU || !dlv || !dll || !dlq || !deps || (C && !dctrl) || !variance || !len || !Zs || !zz ||
-        !rowsq || !fmean || !dmean || !dvar || !dpx || !dpv || (q_sqrt && (!dQs || !extra || !F)))
+        !rowsq || !fmean || !dmean || !dvar || !dpx || !dpv || !Kf || !ucol || (q_sqrt && (!dQs || !extra || !F)))
         return set_error(nullptr, FFVD_ENOMEM, "ffvd_op_rollout: device allocation or upload failed");
     if (loglengthscales)
         HIP_TRY(hipMemcpyAsync(dll, loglengthscales, (size_t)D * P * sizeof(double), hipMemcpyHostToDevice, sc.stream));
@@ -1706,10 +1710,15 @@ extern "C" int ffvd_op_rollout(int kind, const double *Lm_inverse_seq, const dou
     pa.kind = kind; pa.x = dxc; pa.x_chain_stride = 0; pa.x_ld = P; pa.x_cols = P; pa.ctrl = nullptr;
     pa.T = R; pa.Tp = Tp; pa.C = 0; pa.P = P; pa.M = M; pa.Mp = Mp; pa.Dl = D; pa.d_begin = 0; pa.hv = hv;
     pa.W = dW; pa.w_stride = (size_t)Mp * Mp; pa.U = dU; pa.u_ld = D; pa.b0 = 0; pa.nb = D;
-    pa.F = F; pa.rowsq = rowsq; pa.fmean = fmean; pa.ng = ng;
-    // the whole loop is enqueued at once: steps x (projection, [q_sqrt inflation], conditional, update), stream-ordered
+    pa.F = Kf; pa.rowsq = rowsq; pa.fmean = fmean; pa.ng = ng;
+    launch_ucols(sc.stream, dU, M, Mp, D, 0, D, ucol);
+    ProjGemmArgs pg{};
+    pg.Kf = Kf; pg.kf_stride = (size_t)Tp * Mp; pg.W = dW; pg.w_stride = (size_t)Mp * Mp; pg.F = F; pg.f_stride = (size_t)Tp * Mp;
+    pg.rowsq = rowsq; pg.fmean = fmean; pg.u = ucol; pg.u_stride = Mp; pg.Tp = Tp; pg.Mp = Mp; pg.Dl = D; pg.b0 = 0; pg.nb = D;
+    // the whole loop is enqueued at once: steps x (K_fu rows, projection, [q_sqrt inflation], conditional, update)
     for (int t = 0; t < steps; ++t) {
-        launch_project(sc.stream, pa);                                       // conditional_after_kernel_precalculation (:300)
+        launch_kfu_build(sc.stream, pa);                                     // K(x_t, Z) per dim
+        launch_proj_gemm(sc.stream, pg);                                     // conditional_after_kernel_precalculation (:300)
         if (q_sqrt) launch_qsqrt_inflation(sc.stream, F, (size_t)Tp * Mp, Tp, Mp, M, dQs, extra, R, D);
         launch_conditional_finish(sc.stream, kind, dxc, R, P, variance, rowsq, fmean, ng, Tp, D, dmean, dvar, extra);
         launch_rollout_update(sc.stream, dmean, dvar, dlq, deps + (size_t)t * R * D,
