@@ -246,13 +246,14 @@ __device__ __forceinline__ TileAcc gemm_rowmajor_a(double (*As)[AT][A_LD], doubl
 #pragma unroll
         for (int y = 0; y < 2; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
     const int nchunk = kend / AT;
+    const bool rows_live = t.ti * 128 + t.wr * 64 < nrowsA;     // a wavefront whose 64 rows are all padding (few-row launches)
     gload(0);
     lstore(0);
     __syncthreads();
     for (int c = 0; c < nchunk; ++c) {
         const int buf = c & 1;
         if (c + 1 < nchunk) gload(c + 1);
-        if (c <= last_chunk) {
+        if (c <= last_chunk && rows_live) {
 #pragma unroll
             for (int ks = 0; ks < AT / 4; ++ks) {
                 double af[4], bf[2];
