@@ -361,6 +361,82 @@ def test_full_size_config2_properties():
         assert per[s] == pytest.approx(ref["nll"], rel=1e-8)
 
 
+def test_full_batch_schedule_config2(monkeypatch):
+    """The headline launch shape itself (T=4096, M=512, D=4, S=32: 128 units in one unsplit pass).  At this size the
+    Gram kernel keeps its raw tiles and the trace partials tr(K^-1 K_uf K_fu) are formed later on the side stream
+    (DESIGN.md section 5); smaller tests never take that schedule.  Checked without the CPU oracle: every chain's nll
+    must equal the one a 4-chain engine (split-K schedule, verified against the oracle in the test above) computes for
+    it, the reference route must agree, and so must the same engine with the trace back in the Gram epilogue."""
+    params, Y, c, meta = synthetic.make_named("c2")
+    S = meta["S"]
+    assert S == 32
+
+    def chains(route, sel=None):
+        X = params["X"] if sel is None else params["X"][sel]
+        with ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], X.shape[0], route=route) as e:
+            e.set_data(Y, c)
+            t = e.nll_terms(dict(params, X=X))
+            t_again = e.nll_terms(dict(params, X=X))
+        np.testing.assert_array_equal(t["nll_per_chain"], t_again["nll_per_chain"])     # side-stream work is ordered
+        return t
+
+    full = chains("gram")
+    assert full["nll"] == pytest.approx(full["nll_per_chain"].mean(), rel=1e-13)
+    for sel in ([0, 1, 2, 3], [28, 29, 30, 31]):
+        part = chains("gram", sel)
+        np.testing.assert_allclose(full["nll_per_chain"][sel], part["nll_per_chain"], rtol=1e-8)
+    ref = chains("reference")
+    np.testing.assert_allclose(full["nll_per_chain"], ref["nll_per_chain"], rtol=1e-8)
+    for name in ("nll_log_likelihood", "x_t_prior_Q", "later_term1", "later_term2", "nll_part_prior"):
+        assert full[name] == pytest.approx(ref[name], rel=1e-7), name
+    monkeypatch.setenv("FFVD_NO_DEFER_TRACE", "1")
+    plain = chains("gram")
+    np.testing.assert_allclose(full["nll_per_chain"], plain["nll_per_chain"], rtol=1e-9)
+
+
+def test_full_batch_gradient_config2(monkeypatch):
+    """Backward pass at the headline shape (the schedule of test_full_batch_schedule_config2 with the L_A^-T rows and the
+    side-stream K_uu chain of the backward pass).  (1) The same 32-chain gradient with every side-stream schedule switched
+    off must be BITWISE equal wherever the arithmetic is the same (everything but log_Q, which reads the trace partials):
+    a missing event wait shows up here.  (2) The sum of two 16-chain shards, which run the split-K schedule, must
+    reproduce it to the accuracy cond(K_uu) = 1.2e7 allows."""
+    params, Y, c, meta = synthetic.make_named("c2")
+    S = meta["S"]
+
+    def grads(s0, s1):
+        p = dict(params, X=params["X"][s0:s1])
+        with ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], s1 - s0, route="gram", grad=True) as e:
+            e.set_data(Y, c)
+            t, g = e.nll_and_grad(p, S_total=S)
+            t2, g2 = e.nll_and_grad(p, S_total=S)
+        for k in GRAD_KEYS:
+            np.testing.assert_array_equal(g[k], g2[k])
+        return t, g
+
+    tw, whole = grads(0, S)
+    assert all(np.all(np.isfinite(whole[k])) for k in GRAD_KEYS)
+    ta, a = grads(0, S // 2)
+    tb, b = grads(S // 2, S)
+    assert tw["nll"] == pytest.approx(0.5 * (ta["nll"] + tb["nll"]), rel=1e-9)
+    # the two schedules sum the Gram matrices in different orders; through A^-1 and K^-1 that moves dX by 2e-12 absolute
+    # (6e-8 of its largest entry) and the K_uu-side cancellation K^-1 - A_s^-1 behind dZ / dlengthscales / dvariance by
+    # up to 2e-3 of the largest entry (eps * cond * the size of the cancelling terms; 4e-5 at M = 77, tools/grad_check.py)
+    np.testing.assert_allclose(np.concatenate((a["X"], b["X"])), whole["X"], rtol=0, atol=1e-6 * np.max(np.abs(whole["X"])))
+    for k in GRAD_KEYS[1:]:
+        tol = 1e-2 if k in ("Z", "loglengthscales", "logvariance") else 1e-7
+        np.testing.assert_allclose(a[k] + b[k], whole[k], rtol=0, atol=tol * np.max(np.abs(whole[k])), err_msg=k)
+    monkeypatch.setenv("FFVD_NO_DEFER_TRACE", "1")
+    monkeypatch.setenv("FFVD_GRAD_SERIAL", "1")
+    monkeypatch.setenv("FFVD_NO_KFU_FIRST", "1")
+    ts, serial = grads(0, S)
+    for k in GRAD_KEYS:
+        if k == "log_Q":
+            np.testing.assert_allclose(serial[k], whole[k], rtol=1e-7)
+        else:
+            np.testing.assert_array_equal(serial[k], whole[k], err_msg=k)
+    assert ts["nll"] == pytest.approx(tw["nll"], rel=1e-9)
+
+
 @pytest.mark.parametrize("branch", ["B", "A"])
 def test_no_control_inputs(branch):
     """C = 0: the reference concatenates control inputs only when they exist (dgp_model.py:268-271, base_model.py:243-246);
