@@ -110,23 +110,36 @@ class ShardedElbo:
         self.engine.set_params(local)
         self.sums = torch.zeros(8, dtype=torch.float64, device=f"cuda:{device}")
         self.ext_stream = torch.cuda.ExternalStream(self.engine.stream_handle(), device=f"cuda:{device}")
+        self._sync_step = False          # set when the stream-ordered step failed on its FIRST use (see step)
+        self._stream_step_ok = False
 
     def step(self):
         """One ELBO iteration: local kernels -> 8 partial sums in HBM -> all-reduce -> host."""
         if self.world == 1 and not self.always_reduce:
             # nothing to reduce: the engine's own pinned-host copy of the 8 sums (one synchronisation, no torch hop)
             return self.engine.elbo_sums()
-        if os.environ.get("FFVD_SYNC_STEP"):            # conservative variant: host sync, collective on torch's stream
+        if os.environ.get("FFVD_SYNC_STEP") or self._sync_step:   # conservative variant: host sync, collective on torch's stream
             self.engine.elbo_async(self.sums.data_ptr())
             self.engine.sync()
             all_reduce_sums(self.sums)
             return self.sums.cpu().numpy()
         # stream-ordered: the finalize kernel, the RCCL all-reduce and the device-to-host copy all follow the engine's
         # stream (torch sees it as an external stream), so the only host synchronisation is the final copy
-        with self.torch.cuda.stream(self.ext_stream):
-            self.engine.elbo_async(self.sums.data_ptr())
-            all_reduce_sums(self.sums)
-            out = self.sums.cpu().numpy()
+        try:
+            with self.torch.cuda.stream(self.ext_stream):
+                self.engine.elbo_async(self.sums.data_ptr())
+                all_reduce_sums(self.sums)
+                out = self.sums.cpu().numpy()
+        except RuntimeError as exc:
+            # a collective backend that cannot run on an external stream: say so once and keep going the conservative
+            # way (same kernels, same numbers, one more host synchronisation per step)
+            if self._stream_step_ok:
+                raise
+            import warnings
+            warnings.warn(f"stream-ordered collective step failed ({exc}); falling back to the synchronous step")
+            self._sync_step = True
+            return self.step()
+        self._stream_step_ok = True
         if not np.all(np.isfinite(out)):
             self.engine.sync()          # a failed factorisation poisons the sums: fetch the info flags, raise LinAlgError
         return out
