@@ -569,6 +569,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
         if (st && !(kfu_first && s0 == 0)) st->mark(1);
         if (c.branch == FFVD_BRANCH_B) {
             GramArgs ga = gram_args(s0, ns);
+            bool trace_pending = false;
             if (c.grad && !main_first) launch_set_identity(s, h->H, ga.h_stride, Mp, Mp, ns * Dl);
             if (s0 == 0 && late_join) {
                 if (!main_first) launch_gram(s, ga, 1);
@@ -577,9 +578,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
                     HIP_TRY(hipStreamWaitEvent(s, h->ev_kuu, 0));
                     ga.trace_mode = 1;
                     launch_gram(s, ga, 2);
-                    HIP_TRY(hipStreamWaitEvent(sk, h->ev_tiles, 0));      // K^-1 is already there in side-stream order
-                    launch_gram(sk, ga, 3);
-                    HIP_TRY(hipEventRecord(h->ev_join2, sk));             // supersedes the record after the reductions
+                    trace_pending = true;      // enqueued behind the factorisation: the main stream is the critical one
                 } else {
                     HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));
                     launch_gram(s, ga, 2);
@@ -588,9 +587,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
                 ga.mode = GRAM_KFU_RAW; ga.part = h->graw; ga.ksplit = 1;
                 launch_gram(s, ga);
                 HIP_TRY(hipEventRecord(h->ev_tiles, s));
-                HIP_TRY(hipStreamWaitEvent(sk, h->ev_tiles, 0));
-                launch_gram(sk, ga, 3);
-                HIP_TRY(hipEventRecord(h->ev_join2, sk));
+                trace_pending = true;
             } else launch_gram(s, ga);
             if (st) st->mark(2);
             if (c.grad) {       // keep A = K_uu + K_uf K_fu / Q: the factorisation overwrites it in place
@@ -603,6 +600,12 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
                 launch_h_finish(s, h->H, Mp, ga.h_stride, ns * Dl, h->hterms + (size_t)2 * s0 * Dl);
             }
             if (st) st->mark(3);
+            if (trace_pending) {       // trace partials from the raw tiles, on the side stream (K^-1 precedes in its order)
+                HIP_TRY(hipStreamWaitEvent(sk, h->ev_tiles, 0));
+                launch_gram(sk, ga, 3);
+                HIP_TRY(hipEventRecord(h->ev_join2, sk));                 // supersedes the record after the reductions
+                trace_pending = false;
+            }
         }
     }
     if (!reduce_early) launch_chain_reduce(s, ra, h->chain_partial);
