@@ -80,6 +80,8 @@ _SIGNATURES = {
                                      C.c_int]),
     "ffvd_op_rollout": (C.c_int, [C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_int, _dp,
                                   C.c_int, C.c_int, _dp, _dp, _dp, _dp]),
+    "ffvd_op_pg_sweep": (C.c_int, [C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_int, _dp, C.c_int,
+                                   _dp, C.c_int, _dp, _dp, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp, C.c_void_p]),
     "ffvd_op_conditional": (C.c_int, [C.c_int, _dp, C.c_int, _dp, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp,
                                       C.c_double, _dp, _dp]),
 }

@@ -1734,3 +1734,71 @@ extern "C" int ffvd_op_rollout(int kind, const double *Lm_inverse_seq, const dou
     return FFVD_OK;
 }
 
+extern "C" int ffvd_op_pg_sweep(int kind, const double *Lm_inverse_seq, const double *Z, int M, int P, int D,
+                                const double *logvariance, const double *loglengthscales, const double *U,
+                                const double *X_ref, int X_N, const double *Y, int Ydim, const double *ctrl, int C,
+                                const double *CC, const double *DD, const double *Rchols, const double *log_Q, int n_free,
+                                const double *x0, const double *eps, const double *unif, double *particles, int32_t *idx) {
+    if (!Lm_inverse_seq || !Z || !logvariance || !U || !X_ref || !Y || !CC || !DD || !Rchols || !log_Q || !x0 || !eps ||
+        !unif || !particles || !idx || n_free < 1 || n_free + 1 > 1024 || X_N < 1 || M < 1 || M > 2048 || D < 1 || C < 0 ||
+        P != D + C || P > MAXP || Ydim < 1 || Ydim > 8 || (C > 0 && !ctrl) || (kind == FFVD_KERNEL_SE && !loglengthscales))
+        return set_error(nullptr, FFVD_EINVAL, "ffvd_op_pg_sweep: bad argument");
+    for (int j = 0; j < Ydim; ++j)
+        if (!(Rchols[(size_t)j * Ydim + j] > 0.0)) return set_error(nullptr, FFVD_EINVAL, "ffvd_op_pg_sweep: Rchols diagonal must be positive");
+    OP_BEGIN("ffvd_op_pg_sweep");
+    const int R = n_free, steps = X_N - 1;
+    memcpy(particles, x0, (size_t)R * D * sizeof(double));                                   // particles[0] (:87)
+    if (steps == 0) return FFVD_OK;
+    const int Mp = round_up(M, NB), Tp = round_up(R, STRIP), ng = (Mp + 127) / 128;
+    std::vector<double> Wp = pad_stack(Lm_inverse_seq, D, M, Mp);
+    std::vector<double> xc0((size_t)R * P);
+    for (int r = 0; r < R; ++r) {
+        for (int d = 0; d < D; ++d) xc0[(size_t)r * P + d] = x0[(size_t)r * D + d];
+        for (int c = 0; c < C; ++c) xc0[(size_t)r * P + D + c] = ctrl[c];                     // control row of step 0 (:93)
+    }
+    double *dW = sc.upload(Wp.data(), Wp.size());
+    double *dxc = sc.upload(xc0.data(), xc0.size()), *dZ = sc.upload(Z, (size_t)M * P), *dU = sc.upload(U, (size_t)M * D);
+    double *dlv = sc.upload(logvariance, D), *dll = sc.alloc<double>((size_t)D * P), *dlq = sc.upload(log_Q, D);
+    double *deps = sc.upload(eps, (size_t)steps * R * D), *dun = sc.upload(unif, (size_t)steps * R);
+    double *dctrl = C ? sc.upload(ctrl, (size_t)steps * C) : nullptr;
+    double *dXr = sc.upload(X_ref, (size_t)X_N * D), *dY = sc.upload(Y, (size_t)steps * Ydim);
+    double *dCC = sc.upload(CC, (size_t)D * Ydim), *dDD = sc.upload(DD, Ydim), *dR = sc.upload(Rchols, (size_t)Ydim * Ydim);
+    double *variance = sc.alloc<double>(D), *len = sc.alloc<double>((size_t)D * P);
+    double *Zs = sc.alloc<double>((size_t)D * Mp * P), *zz = sc.alloc<double>((size_t)D * Mp);
+    double *Kf = sc.alloc<double>((size_t)D * Tp * Mp), *ucol = sc.alloc<double>((size_t)D * Mp);
+    double *rowsq = sc.alloc<double>((size_t)D * ng * Tp), *fmean = sc.alloc<double>((size_t)D * ng * Tp);
+    double *dmean = sc.alloc<double>((size_t)R * D), *dvar = sc.alloc<double>((size_t)R * D);
+    double *cand = sc.alloc<double>((size_t)(R + 1) * D);
+    double *dparts = sc.alloc<double>((size_t)steps * R * D);
+    int32_t *didx = sc.alloc<int32_t>((size_t)steps * R);
+    if (!dW || !dxc || !dZ || !dU || !dlv || !dll || !dlq || !deps || !dun || (C && !dctrl) || !dXr || !dY || !dCC || !dDD ||
+        !dR || !variance || !len || !Zs || !zz || !Kf || !ucol || !rowsq || !fmean || !dmean || !dvar || !cand || !dparts || !didx)
+        return set_error(nullptr, FFVD_ENOMEM, "ffvd_op_pg_sweep: device allocation or upload failed");
+    if (loglengthscales)
+        HIP_TRY(hipMemcpyAsync(dll, loglengthscales, (size_t)D * P * sizeof(double), hipMemcpyHostToDevice, sc.stream));
+    launch_prep_hypers(sc.stream, kind, dZ, M, Mp, P, D, 0, dlv, dll, variance, len, Zs, zz);
+    HyperView hv{variance, len, Zs, zz};
+    ProjectArgs pa{};
+    pa.kind = kind; pa.x = dxc; pa.x_chain_stride = 0; pa.x_ld = P; pa.x_cols = P; pa.ctrl = nullptr;
+    pa.T = R; pa.Tp = Tp; pa.C = 0; pa.P = P; pa.M = M; pa.Mp = Mp; pa.Dl = D; pa.d_begin = 0; pa.hv = hv;
+    pa.W = dW; pa.w_stride = (size_t)Mp * Mp; pa.U = dU; pa.u_ld = D; pa.b0 = 0; pa.nb = D;
+    pa.F = Kf; pa.rowsq = rowsq; pa.fmean = fmean; pa.ng = ng;
+    launch_ucols(sc.stream, dU, M, Mp, D, 0, D, ucol);
+    ProjGemmArgs pg{};
+    pg.Kf = Kf; pg.kf_stride = (size_t)Tp * Mp; pg.W = dW; pg.w_stride = (size_t)Mp * Mp; pg.F = nullptr; pg.f_stride = 0;
+    pg.rowsq = rowsq; pg.fmean = fmean; pg.u = ucol; pg.u_stride = Mp; pg.Tp = Tp; pg.Mp = Mp; pg.Dl = D; pg.b0 = 0; pg.nb = D;
+    // the whole sweep is enqueued at once: steps x (K_fu rows, projection, conditional, propagate + weight + resample)
+    for (int t = 0; t < steps; ++t) {
+        launch_kfu_build(sc.stream, pa);
+        launch_proj_gemm(sc.stream, pg);                                     // conditional_after_kernel_precalculation (:95-97)
+        launch_conditional_finish(sc.stream, kind, dxc, R, P, variance, rowsq, fmean, ng, Tp, D, dmean, dvar, nullptr);
+        launch_pg_step(sc.stream, dmean, dvar, dlq, deps + (size_t)t * R * D, dun + (size_t)t * R, dY + (size_t)t * Ydim,
+                       dXr + (size_t)(t + 1) * D, dCC, dDD, dR, (C && t + 1 < steps) ? dctrl + (size_t)(t + 1) * C : nullptr,
+                       R, D, C, Ydim, dxc, cand, dparts + (size_t)t * R * D, didx + (size_t)t * R);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(particles + (size_t)R * D, dparts, (size_t)steps * R * D * sizeof(double), hipMemcpyDeviceToHost, sc.stream));
+    HIP_TRY(hipMemcpyAsync(idx, didx, (size_t)steps * R * sizeof(int32_t), hipMemcpyDeviceToHost, sc.stream));
+    HIP_TRY(hipStreamSynchronize(sc.stream));
+    return FFVD_OK;
+}

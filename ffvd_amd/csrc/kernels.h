@@ -173,6 +173,14 @@ void launch_rollout_update(hipStream_t stream, const double *mean, const double 
                            const double *eps_t, const double *ctrl_next, int R, int D, int C, int t, int steps, double *xc,
                            double *predict_x, double *predict_var);
 
+// One particle-Gibbs step for R free particles (base_model.py:99-115, intent; oracle/ffvd_pg_oracle.py): propagate,
+// weight against y_t, draw R ancestors among the R new particles + the reference state, gather.  xc: R x (D + C) GP input
+// rows, advanced in place; cand: (R + 1) x D scratch; parts_next: R x D; idx_out: R.
+void launch_pg_step(hipStream_t stream, const double *mean, const double *var, const double *log_Q, const double *eps_t,
+                    const double *unif_t, const double *y_t, const double *x_ref_next, const double *CC, const double *DD,
+                    const double *Rch, const double *ctrl_next, int R, int D, int C, int Ydim, double *xc, double *cand,
+                    double *parts_next, int32_t *idx_out);
+
 // N sums over a 256-thread workgroup at once: wavefront shuffles, then the four wavefront partials in fixed order.
 // Every thread returns with the totals in v[].
 template <int N>

@@ -1589,4 +1589,82 @@ void launch_rollout_update(hipStream_t stream, const double *mean, const double 
                        ctrl_next, R, D, C, t, steps, xc, predict_x, predict_var);
 }
 
+// One workgroup: thread i < R propagates particle i and forms its log weight, thread R the reference's; the softmax
+// CDF is summed sequentially in index order (as the oracle's cumsum) by one thread; then every thread i < R finds its
+// ancestor by binary search and gathers.
+constexpr int PG_MAXN = 1024, PG_MAXY = 8;
+__global__ __launch_bounds__(PG_MAXN) void pg_step_kernel(const double *mean, const double *var, const double *log_Q,
+                                                          const double *eps_t, const double *unif_t, const double *y_t,
+                                                          const double *x_ref_next, const double *CC, const double *DD,
+                                                          const double *Rch, const double *ctrl_next, int R, int D, int C,
+                                                          int Ydim, double *xc, double *cand, double *parts_next,
+                                                          int32_t *idx_out) {
+    __shared__ double w[PG_MAXN], cdf[PG_MAXN];
+    __shared__ double wmax_s;
+    const int i = threadIdx.x, N = R + 1, P = D + C;
+    if (i < N) {
+        for (int p = 0; p < D; ++p) {
+            double xn;
+            if (i < R) {
+                const double v = var[i * D + p] + exp(log_Q[p]);
+                xn = (mean[i * D + p] + xc[i * P + p]) + eps_t[i * D + p] * sqrt(v);          // :99-101
+            } else xn = x_ref_next[p];                                                         // :111
+            cand[(size_t)i * D + p] = xn;
+        }
+        // logdensity_norm(Y[tt], predict_mean(x), Rchols), likelihoods.py:76-79,114-127
+        double a[PG_MAXY], q = 0.0, ld = 0.0;
+        for (int j = 0; j < Ydim; ++j) {
+            double ym = 0.0;
+            for (int d = 0; d < D; ++d) ym += cand[(size_t)i * D + d] * CC[d * Ydim + j];
+            ym += DD[j];
+            double r = y_t[j] - ym;
+            for (int k = 0; k < j; ++k) r -= Rch[j * Ydim + k] * a[k];
+            a[j] = r / Rch[j * Ydim + j];
+            q += a[j] * a[j];
+            ld += log(Rch[j * Ydim + j]);
+        }
+        w[i] = -0.5 * q + (-ld);
+    }
+    __syncthreads();
+    if (i == 0) {
+        double m = w[0];
+        for (int k = 1; k < N; ++k) m = (w[k] > m) ? w[k] : m;
+        wmax_s = m;
+    }
+    __syncthreads();
+    if (i < N) w[i] = exp(w[i] - wmax_s);
+    __syncthreads();
+    if (i == 0) {
+        double c = 0.0;
+        for (int k = 0; k < N; ++k) { c += w[k]; cdf[k] = c; }
+    }
+    __syncthreads();
+    if (i < R) {
+        const double target = unif_t[i] * cdf[N - 1];
+        int lo = 0, hi = N;                      // first k with cdf[k] > target
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cdf[mid] > target) hi = mid; else lo = mid + 1;
+        }
+        const int k = (lo < N) ? lo : N - 1;
+        idx_out[i] = k;
+        for (int p = 0; p < D; ++p) {
+            const double x = cand[(size_t)k * D + p];
+            parts_next[(size_t)i * D + p] = x;
+            xc[i * P + p] = x;
+        }
+        if (ctrl_next)
+            for (int c = 0; c < C; ++c) xc[i * P + D + c] = ctrl_next[c];
+    }
+}
+void launch_pg_step(hipStream_t stream, const double *mean, const double *var, const double *log_Q, const double *eps_t,
+                    const double *unif_t, const double *y_t, const double *x_ref_next, const double *CC, const double *DD,
+                    const double *Rch, const double *ctrl_next, int R, int D, int C, int Ydim, double *xc, double *cand,
+                    double *parts_next, int32_t *idx_out) {
+    int threads = 64;
+    while (threads < R + 1) threads <<= 1;
+    hipLaunchKernelGGL(pg_step_kernel, dim3(1), dim3(threads), 0, stream, mean, var, log_Q, eps_t, unif_t, y_t, x_ref_next,
+                       CC, DD, Rch, ctrl_next, R, D, C, Ydim, xc, cand, parts_next, idx_out);
+}
+
 }  // namespace ffvd

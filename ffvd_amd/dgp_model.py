@@ -75,6 +75,8 @@ class DGPSSM:
         self.engine.set_data(Y, self.control_inputs)
         self._last = None
         self.epsilon, self.mdecay = epsilon, mdecay
+        self.X_PG, self.PG_particles = bool(X_PG), int(PG_particles)
+        self.PG_mode = "intent"        # "reference" reproduces the reference's no-op (see gp_x_sampling)
         # which variables SG-HMC samples and which Adam trains (dgp_model.py:213-244):
         # case 4 (collapsed U, kernel/Z optimisation on: what FFVD_Main.py:300-305 sets) leaves `vars` empty
         self.vars = []
@@ -195,6 +197,56 @@ class DGPSSM:
             self.engine.update_params({k: cur[k] for k in fed})        # feed_dict does not assign: restore the chain state
         self._host_stale = True
         return t
+
+    def gp_x_sampling(self, mode=None):
+        """`gp_x_sampling()` of the training loop (models.py:156-158) = `pg_x_sampling_op = PG_for_X_speedup(...)`
+        (dgp_model.py:309, base_model.py:78-138).
+
+        mode "reference": exactly what the reference's op does -- nothing: its TensorArray writes are discarded (:115)
+        and the final assign is never run (:137), X stays as it is.
+        mode "intent" (default): one particle-Gibbs sweep per chain on the device (`ffvd_op_pg_sweep`):
+        PG_particles - 1 free particles from N(0, I) (:79) advanced with the explicit-U conditional (:93-101),
+        weighted against Y (:105-109), resampled together with the current trajectory as the conditioned particle
+        (:111-115); a uniformly drawn slot replaces X unless it is the conditioned one (:135-137).
+        Returns the number of chains whose trajectory was replaced."""
+        mode = mode or self.PG_mode
+        if mode == "reference":
+            return 0
+        if mode != "intent":
+            raise ValueError("PG mode must be 'reference' or 'intent'")
+        if self.U_collapse:
+            raise ValueError("PG_for_X_speedup conditions on the explicit U (base_model.py:96): U_collapse must be False")
+        from . import conditionals_multi_output as cmo
+        from .prediction import pg_sweep
+        if self._host_stale:
+            self.pull_parameters()
+        lay = self.layers[-1]
+        n1 = self.PG_particles - 1
+        if n1 < 1:
+            raise ValueError("PG_particles must be at least 2")
+        T, D = self.X_N - 1, self.output_dim
+        Lm = cmo.kernel_pre_cal(lay.Z, lay.kernel)                                             # :81
+        Rch = np.exp(np.asarray(self.likelihood.log_Rchols, dtype=np.float64))                  # likelihood.Rchols
+        Rch = np.tril(Rch) if Rch.shape[0] > 1 else Rch
+        Q = np.exp(self.log_Q)
+        replaced = 0
+        Xc = np.array(self._X_chains, dtype=np.float64, copy=True)
+        for s_ in range(self.num_chains):
+            x0 = self._rng.standard_normal((n1, D))                                           # :79
+            eps = self._rng.standard_normal((T, n1, D))                                       # :101
+            unif = self._rng.random((T, n1))                                                  # :113
+            parts, _ = pg_sweep(Lm, lay.Z, lay.kernel, lay.U, Xc[s_], self.Y, self.control_inputs, self.likelihood.CC,
+                                self.likelihood.DD, Rch, Q, x0, eps, unif)
+            final_index = int(self._rng.integers(self.PG_particles))                          # :135
+            if final_index < n1:                                                              # :136-137
+                Xc[s_] = parts[:, final_index]
+                replaced += 1
+        if replaced:
+            self._X_chains = Xc
+            lay.X = Xc[0]
+            if self._resident:
+                self.engine.update_params({"X": Xc})
+        return replaced
 
     def pull_parameters(self):
         """Copy the trained parameters from the device back into the reference-named attributes."""

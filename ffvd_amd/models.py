@@ -59,7 +59,7 @@ class Model:
                                 output_dim=self.output_dim, QQ_chol=A.QQ_chol, ZZ=A.ZZ, variance=A.variance,
                                 lengthscales=A.lengthscales, control_inputs=control, kernel_type=kernel_type,
                                 kernel_train_flag=kernel_train_flag, U_ini=A.UU_ini, X_0_ini=A.XX_0_ini,
-                                X_train_ini=A.x_initialization, X_PG=getattr(A, "X_PG", False),
+                                X_train_ini=A.x_initialization, X_PG=getattr(A, "X_PG", False), PG_particles=getattr(A, "PG_particles", 100),
                                 hyperparameter_sampling=getattr(A, "hyperparameter_sampling", False),
                                 kernel_optimization=getattr(A, "kernel_optimization", True),
                                 U_optimization=getattr(A, "U_optimization", False),
@@ -72,6 +72,9 @@ class Model:
         for it in range(n_iter):
             self.global_step += 1
             self.model.sghmc_step()                                              # models.py:150
+            if getattr(A, "X_PG", False):
+                self.model.PG_mode = getattr(A, "PG_mode", self.model.PG_mode)
+                self.model.gp_x_sampling()                                       # models.py:156-158
             t = self.model.train_hypers()                                        # models.py:168
             self.nll_seq.append(t["nll"])
         if n_iter:

@@ -268,6 +268,24 @@ int  ffvd_op_rollout(int kind, const double *Lm_inverse_seq, const double *Z, in
                      const double *x_last, int R, const double *ctrl, int C, int steps, const double *log_Q,
                      const double *eps, double *predict_x, double *predict_var);
 
+/* One particle-Gibbs sweep over the latent trajectory: the INTENT of BaseModel.PG_for_X_speedup (base_model.py:78-138;
+ * as written that op never updates X -- discarded TensorArray.write results (:115), an assign that is never run (:137) --
+ * so there is no reference behaviour to match, see oracle/ffvd_pg_oracle.py).  n_free = PG_particles - 1 free particles
+ * start at x0 (n_free x D, the N(0, I) draw of :79, injected) and advance side by side; per step tt < X_N - 1:
+ * conditional_after_kernel_precalculation at [x_t, ctrl[tt]] with the explicit, whitened U (:93-97), x_{t+1} = x_t + f_mu +
+ * eps[tt] * sqrt(f_var + Q) (:99-101), weights logdensity_norm(Y[tt], predict_mean(.), Rchols) of the new particles and of
+ * the reference state X_ref[tt+1] (:105-109), n_free categorical draws (:113; inverse CDF of softmax(w) at the injected
+ * uniforms unif[tt], first index whose cumulative probability exceeds u) and the gather (:111-115).
+ * X_ref: X_N x D; Y: (X_N-1) x Ydim; ctrl: (X_N-1) x C or NULL; Rchols: Ydim x Ydim lower-triangular (= exp(log_Rchols),
+ * likelihood.Rchols), Ydim <= 8; eps: (X_N-1) x n_free x D; unif: (X_N-1) x n_free in [0, 1).
+ * Outputs: particles X_N x n_free x D (resampled_X of :133) and idx (X_N-1) x n_free (int32, value n_free = reference).
+ * The final choice (:135-137) is the caller's: X <- particles[:, final_index] unless final_index == n_free. */
+int  ffvd_op_pg_sweep(int kind, const double *Lm_inverse_seq, const double *Z, int M, int P, int D,
+                      const double *logvariance, const double *loglengthscales, const double *U, const double *X_ref,
+                      int X_N, const double *Y, int Ydim, const double *ctrl, int C, const double *CC, const double *DD,
+                      const double *Rchols, const double *log_Q, int n_free, const double *x0, const double *eps,
+                      const double *unif, double *particles, int32_t *idx);
+
 #ifdef __cplusplus
 }
 #endif

@@ -214,3 +214,63 @@ def test_rollout_argument_errors():
     with pytest.raises(ValueError):          # eps must be (steps, R, D)
         rollout(np.zeros((2, 4, 4)), Z, kern, np.zeros((4, 2)), None, np.zeros(2), np.zeros((9, 1)), 2, 5, np.ones(2),
                 np.zeros((4, 1, 2)))
+
+
+@pytest.mark.parametrize("name,ov,N,Ydim", [("tiny", {}, 12, 1), ("small", {}, 5, 1), ("tiny", dict(C=0), 2, 1),
+                                            ("ragged", {}, 101, 1), ("tiny", {}, 9, 3)])
+def test_pg_sweep_matches_oracle(name, ov, N, Ydim):
+    """one particle-Gibbs sweep (the intent of PG_for_X_speedup, base_model.py:78-138) against the CPU
+    restatement with the same injected draws: identical ancestor indices, particle states to 1e-9 (errors compound along
+    the trajectory).  Ydim = 3 exercises the triangular solve of logdensity_norm with a full lower-triangular Rchols."""
+    from ffvd_amd import conditionals_multi_output as cmo
+    from ffvd_amd.prediction import pg_sweep
+    from ffvd_amd.kernels import SquaredExponential
+    from oracle import ffvd_pg_oracle as pgo
+    params, Y, c, meta = synthetic.make_named(name, **ov)
+    D, C, T = meta["D"], meta["C"], meta["T"]
+    X = params["X"][0]
+    Q = np.exp(params["log_Q"])
+    rng = np.random.default_rng(11)
+    CC, DD, R = params["CC"], params["DD"], np.exp(params["log_Rchols"])
+    if Ydim > 1:                                   # a multi-output observation model for the weights only
+        CC = rng.standard_normal((D, Ydim)) * 0.5
+        DD = rng.standard_normal(Ydim) * 0.1
+        R = np.tril(rng.standard_normal((Ydim, Ydim)) * 0.2) + np.diag(0.4 + rng.random(Ydim))
+        Y = X[1:] @ CC + DD + 0.4 * rng.standard_normal((T, Ydim))
+    okern = orc.make_kernels(params)
+    kern = [SquaredExponential(D + C, variance=np.exp(params["logvariance"][d]),
+                               lengthscales=np.exp(params["loglengthscales"][d])) for d in range(D)]
+    x0, eps, u = rng.standard_normal((N - 1, D)), rng.standard_normal((T, N - 1, D)), rng.random((T, N - 1))
+    Lo = orc.kernel_pre_cal(params["Z"], okern)
+    po, io = pgo.pg_sweep(Lo, params["Z"], okern, params["U"], X, Y, c, CC, DD, R, Q, x0, eps, u)
+    Lg = cmo.kernel_pre_cal(params["Z"], kern)
+    pg, ig = pg_sweep(Lg, params["Z"], kern, params["U"], X, Y, c, CC, DD, R, Q, x0, eps, u)
+    assert pg.shape == (T + 1, N - 1, D) and ig.shape == (T, N - 1)
+    np.testing.assert_array_equal(ig, io)
+    np.testing.assert_allclose(pg, po, rtol=1e-9, atol=1e-10)
+    np.testing.assert_array_equal(pg[0], x0)
+    # a particle that drew the reference's index carries the reference state
+    t, i = np.argwhere(ig == N - 1)[0]
+    np.testing.assert_array_equal(pg[t + 1, i], X[t + 1])
+    # u -> 1 always selects the last candidate (the reference): the sweep then returns X itself from t = 1 on
+    p1, i1 = pg_sweep(Lg, params["Z"], kern, params["U"], X, Y, c, CC, DD, R, Q, x0, eps, np.full_like(u, 1.0 - 1e-16))
+    assert np.all(i1 == N - 1)
+    np.testing.assert_array_equal(p1[1:], np.repeat(X[1:, None, :], N - 1, axis=1))
+
+
+def test_pg_sweep_argument_errors():
+    from ffvd_amd.prediction import pg_sweep
+    from ffvd_amd.kernels import SquaredExponential
+    kern = [SquaredExponential(3, variance=0.5, lengthscales=np.ones(3)) for _ in range(2)]
+    Z, L, U = np.zeros((4, 3)), np.zeros((2, 4, 4)), np.zeros((4, 2))
+    X, Y, c = np.zeros((6, 2)), np.zeros((5, 1)), np.zeros((5, 1))
+    CC, DD, R, Q = np.ones((2, 1)), np.zeros(1), np.ones((1, 1)), np.ones(2)
+    good = dict(x0=np.zeros((3, 2)), eps=np.zeros((5, 3, 2)), unif=np.zeros((5, 3)))
+    with pytest.raises(ValueError):          # uniforms outside [0, 1)
+        pg_sweep(L, Z, kern, U, X, Y, c, CC, DD, R, Q, good["x0"], good["eps"], np.ones((5, 3)))
+    with pytest.raises(ValueError):          # eps must be (X_N - 1, PG_particles - 1, D)
+        pg_sweep(L, Z, kern, U, X, Y, c, CC, DD, R, Q, good["x0"], np.zeros((4, 3, 2)), good["unif"])
+    with pytest.raises(ValueError):          # control inputs too short
+        pg_sweep(L, Z, kern, U, X, Y, c[:3], CC, DD, R, Q, **good)
+    with pytest.raises(ValueError):          # non-positive diagonal of Rchols
+        pg_sweep(L, Z, kern, U, X, Y, c, CC, DD, np.zeros((1, 1)), Q, **good)

@@ -300,3 +300,41 @@ def test_case2_samples_hypers_and_u(actuator):
     t = mod.train_hypers()
     after = mod.engine.get_params()
     assert np.isfinite(t["nll"]) and np.array_equal(after["U"], chain["U"]) and not np.array_equal(after["Z"], chain["Z"])
+
+
+def test_case6_particle_gibbs_in_the_loop(actuator):
+    """FFVD_Main.py case 6 (:317-324): explicit U, X_PG = True.  `gp_x_sampling()` runs between the SG-HMC step and the
+    Adam step (models.py:150-168).  Mode "reference" reproduces what the reference's op does (nothing: Appendix B item 6),
+    mode "intent" runs the particle-Gibbs sweep on the device and installs a new trajectory unless the uniformly drawn slot
+    is the conditioned particle's; the training loop must keep working on the new X."""
+    from ffvd_amd.models import RegressionModel
+    params, Y, c = actuator
+    m = RegressionModel("normal")
+    A = _actuator_args(m, params, c)
+    A.kernel_optimization, A.U_optimization, A.Z_optimization, A.U_collapse, A.case_val = True, True, True, False, 6
+    A.X_PG, A.PG_particles = True, 6
+    m.fit(Y, kernel_type="SquaredExponential", iterations=0, grad=True)
+    mod = m.model
+    assert mod.X_PG and mod.PG_particles == 6
+    mod.seed(3)
+    x_before = mod.layers[-1].X.copy()
+    assert mod.gp_x_sampling(mode="reference") == 0
+    np.testing.assert_array_equal(mod.layers[-1].X, x_before)
+    replaced = 0
+    for _ in range(6):                                   # P(conditioned slot six times in a row) = 6^-6
+        replaced += mod.gp_x_sampling()
+    assert replaced >= 1
+    x_after = mod.layers[-1].X
+    assert x_after.shape == x_before.shape and np.all(np.isfinite(x_after)) and not np.array_equal(x_after, x_before)
+    np.testing.assert_array_equal(mod.engine.get_params()["X"][0] if mod._resident else x_after, x_after)
+    t = mod.train_hypers()                               # the Adam step runs on the resampled trajectory
+    assert np.isfinite(t["nll"])
+    with pytest.raises(ValueError):
+        mod.gp_x_sampling(mode="something")
+    # the whole loop through fit(): sghmc_step (no-op in case 6), gp_x_sampling, train_hypers
+    m2 = RegressionModel("normal")
+    A2 = _actuator_args(m2, params, c)
+    A2.kernel_optimization, A2.U_optimization, A2.Z_optimization, A2.U_collapse, A2.case_val = True, True, True, False, 6
+    A2.X_PG, A2.PG_particles = True, 4
+    m2.fit(Y, kernel_type="SquaredExponential", iterations=3, grad=True)
+    assert len(m2.nll_seq) == 4 and np.all(np.isfinite(m2.nll_seq))

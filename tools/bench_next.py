@@ -38,4 +38,16 @@ for R, steps in ((32, 200), (100, 200)):
     rollout(L, params["Z"], kern, U, H, X[-1], ctrl, T, steps, np.exp(params["log_Q"]), eps)
     dt = time.perf_counter() - t0
     out[f"rollout_R{R}_us_per_step"] = dt / steps * 1e6
+# particle-Gibbs sweep (intent of PG_for_X_speedup): 100 particles over the whole trajectory, explicit U
+from ffvd_amd.prediction import pg_sweep
+N = 100
+x0, eps_pg, un = rng.standard_normal((N - 1, D)), rng.standard_normal((T, N - 1, D)), rng.random((T, N - 1))
+Rch = np.exp(params["log_Rchols"])
+pg_sweep(L, params["Z"], kern, params["U"], X[:33], Y, c, params["CC"], params["DD"], Rch, np.exp(params["log_Q"]), x0, eps_pg[:32], un[:32])
+t0 = time.perf_counter()
+parts, idx = pg_sweep(L, params["Z"], kern, params["U"], X, Y, c, params["CC"], params["DD"], Rch, np.exp(params["log_Q"]), x0, eps_pg, un)
+dt = time.perf_counter() - t0
+out["pg_sweep_N100_ms"] = dt * 1e3
+out["pg_sweep_N100_us_per_step"] = dt / T * 1e6
+out["pg_reference_share"] = float((idx == N - 1).mean())
 print(json.dumps(out))
