@@ -333,7 +333,12 @@ __global__ __launch_bounds__(512, 4) void bwd_fused_kernel(BwdFusedArgs a) {
     }
     // e in place of g; kfu partial over this wavefront's 32 columns
     {
-        double kfs[4][4];
+        double uj[2];
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            const int j = J0 + 16 * y + lr;
+            uj[y] = (j < Mp) ? ub[j] : 0.0;
+        }
 #pragma unroll
         for (int x = 0; x < 4; ++x)
 #pragma unroll
@@ -341,23 +346,17 @@ __global__ __launch_bounds__(512, 4) void bwd_fused_kernel(BwdFusedArgs a) {
                 const int i = I0 + 16 * x + lk + 4 * q;
                 const bool iok = i < Tp;
                 const double rowv = (i < a.T) ? alpha * (rv ? rv[i] : Xs[(size_t)(i + 1) * a.D + dg] - Xs[(size_t)i * a.D + dg]) : 0.0;
-                double ks_ = 0.0;
+                double v = 0.0;
 #pragma unroll
                 for (int y = 0; y < 2; ++y) {
                     const int j = J0 + 16 * y + lr;
                     const bool ok = iok && j < Mp;
                     const double kf = ok ? Kfb[(size_t)i * Mp + j] : 0.0;
-                    const double uj = (j < Mp) ? ub[j] : 0.0;
-                    acc[x][y][q] = (2.0 * acc[x][y][q] + rowv * uj) * kf;
-                    ks_ += kf * uj;
+                    acc[x][y][q] = (2.0 * acc[x][y][q] + rowv * uj[y]) * kf;
+                    v += kf * uj[y];
                 }
-                kfs[x][q] = ks_;
-            }
-#pragma unroll
-        for (int x = 0; x < 4; ++x)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                double v = kfs[x][q];
+                // reduced and parked right away: sixteen partial sums held across the loop cost 32 VGPRs this epilogue
+                // does not have
                 v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
                 if (lr == 0) kfu_s[wc * 128 + wr * 64 + 16 * x + lk + 4 * q] = v;
             }
