@@ -217,7 +217,7 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
     if (c.grad) {
         ffvd_handle::GradWs &g = h->gw;
         const size_t nbt = h->nbatch, msq = Mp * Mp, nblk = Tp / 64, nblk2 = Mp / 64, S = c.S_local, J = c.Ydim;
-        g.ngam = atb_ntiles(h->Mp, h->Mp);
+        g.ngam = atb_ntiles_sym(h->Mp);
         g.sp_stride = c.D * c.Ydim + 2 * c.Ydim + (int)Dl;
         HIP_TRY(dev_alloc(h, &g.Acopy, nbt * msq));      HIP_TRY(dev_alloc(h, &g.u, nbt * Mp));
         HIP_TRY(dev_alloc(h, &g.LAinv, nbt * msq));      HIP_TRY(dev_alloc(h, &g.Gamma, nbt * msq));
@@ -865,7 +865,7 @@ static int enqueue_grad_b(ffvd_handle *h, int S_total) {
     ag.B = g.LAinv; ag.b_stride = msq; ag.ldb = Mp; ag.nB = Mp; ag.b_per_dim = 0; ag.rows = Mp;
     ag.C = g.Gamma; ag.c_stride = msq; ag.ldc = Mp; ag.nb = nb; ag.b0 = 0; ag.Dl = Dl; ag.d_begin = c.d_begin;
     ag.log_Q = p.log_Q; ag.u = g.u; ag.u_stride = Mp; ag.Kinv = h->Kinv; ag.Kcopy = h->Kcopy; ag.k_stride = msq; ag.ldk = Mp;
-    ag.part = g.gam_part; ag.k_lower = 1;               // L_A^-1 is lower triangular
+    ag.part = g.gam_part; ag.k_lower = 1; ag.sym = 1;   // L_A^-1 is lower triangular, A^-1 symmetric
     launch_atb(s, ag);
     // K_uu side: Psi_d = sum_s Gamma_s / alpha_d - 1/2 K^-1 (sum_s A_s - S K) K^-1.  It needs Gamma and the saved
     // A-matrices only, so its dozen small launches go to the side stream and run beside the E product

@@ -21,11 +21,14 @@ struct AtbArgs {
     const double *Kf; size_t kf_stride; int ldkf;       // BWD_E: K_fu (T x M) per unit
     const double *Kinv, *Kcopy; size_t k_stride; int ldk;   // GAMMA: per latent dim
     double *part;                                       // GAMMA: [nb][ntiles] partial sums of sum_ij (A^-1)_ij K_ij
+    int sym;                                            // GAMMA: A == B, the product is symmetric: only tiles tj <= ti are
+                                                        //    launched, off-diagonal ones are also written mirrored
     int k_lower;                                        // 1: A and B are lower triangular as stored ([k][i] = 0 for i > k): the
                                                         //    sum for tile (ti, tj) starts at row 128 max(ti, tj) (exact: skips zeros)
 };
 void launch_atb(hipStream_t stream, const AtbArgs &a);
 int atb_ntiles(int nA, int nB);
+int atb_ntiles_sym(int n);      // tiles of a symmetric product launched with AtbArgs::sym
 
 void launch_uku(hipStream_t stream, const double *u, size_t u_stride, const double *K, size_t k_stride, int Mp, int Dl,
                 int nb, double *out);

@@ -61,7 +61,12 @@ __global__ __launch_bounds__(512, 4) void atb_kernel(AtbArgs a) {
     __shared__ double red[512];
     const int bz = blockIdx.y;
     const int ntj = (a.nB + 127) / 128;
-    const int ti = blockIdx.x / ntj, tj = blockIdx.x % ntj;
+    int ti = blockIdx.x / ntj, tj = blockIdx.x % ntj;
+    if (MODE == ATB_GAMMA && a.sym) {                    // lower-triangular tile list: blockIdx.x = ti (ti + 1) / 2 + tj
+        ti = 0;
+        while ((ti + 1) * (ti + 2) / 2 <= (int)blockIdx.x) ++ti;
+        tj = blockIdx.x - ti * (ti + 1) / 2;
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
@@ -168,7 +173,9 @@ __global__ __launch_bounds__(512, 4) void atb_kernel(AtbArgs a) {
                     double v = g;
                     if (MODE == ATB_GAMMA) {
                         v = 0.5 * alpha * (Kinv[(size_t)i * a.ldk + j] - g - rowv * ub[j]);
-                        part += g * Kc[(size_t)i * a.ldk + j];
+                        const bool mirror = a.sym && ti != tj;
+                        part += (mirror ? 2.0 : 1.0) * (g * Kc[(size_t)i * a.ldk + j]);
+                        if (mirror) Cb[(size_t)j * a.ldc + i] = v;       // K^-1, A^-1, u u^T are all symmetric
                     } else if (MODE == ATB_BWD_E) {
                         v = (2.0 * g + rowv * ub[j]) * Kf[(size_t)i * a.ldkf + j];
                     }
@@ -190,12 +197,14 @@ __global__ __launch_bounds__(512, 4) void atb_kernel(AtbArgs a) {
 void launch_atb(hipStream_t stream, const AtbArgs &a) {
     const int nti = (a.nA + 127) / 128, ntj = (a.nB + 127) / 128;
     dim3 grid(nti * ntj, a.nb);
+    if (a.mode == ATB_GAMMA && a.sym) grid.x = nti * (nti + 1) / 2;
     if (a.mode == ATB_PLAIN) hipLaunchKernelGGL((atb_kernel<ATB_PLAIN, false>), grid, dim3(512), 0, stream, a);
     else if (a.mode == ATB_GAMMA) hipLaunchKernelGGL((atb_kernel<ATB_GAMMA, false>), grid, dim3(512), 0, stream, a);
     else if (a.a_rowmajor) hipLaunchKernelGGL((atb_kernel<ATB_BWD_E, true>), grid, dim3(512), 0, stream, a);
     else hipLaunchKernelGGL((atb_kernel<ATB_BWD_E, false>), grid, dim3(512), 0, stream, a);
 }
 int atb_ntiles(int nA, int nB) { return ((nA + 127) / 128) * ((nB + 127) / 128); }
+int atb_ntiles_sym(int n) { const int nt = (n + 127) / 128; return nt * (nt + 1) / 2; }
 
 // Shared main loop of the kernels whose left operand is stored row-major over the OUTPUT rows (K_fu itself):
 // acc (128 x 128 tile, 8 wavefronts of 64 x 32) = sum_{k < kend} Arows[i][k] * B[k][j], the 128 x 16 chunk of A
