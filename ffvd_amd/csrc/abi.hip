@@ -569,7 +569,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
         if (st && !(kfu_first && s0 == 0)) st->mark(1);
         if (c.branch == FFVD_BRANCH_B) {
             GramArgs ga = gram_args(s0, ns);
-            bool trace_pending = false;
+            bool trace_pending = false, acopy_done = false;      // acopy_done: the Gram kernel stored the copy of A itself
             if (c.grad && !main_first) launch_set_identity(s, h->H, ga.h_stride, Mp, Mp, ns * Dl);
             if (s0 == 0 && late_join) {
                 if (!main_first) launch_gram(s, ga, 1);
@@ -585,14 +585,16 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
                 }
             } else if (s0 == 0 && defer_full && sk != s) {
                 ga.mode = GRAM_KFU_RAW; ga.part = h->graw; ga.ksplit = 1;
+                if (c.grad) { ga.Hcopy = h->gw.Acopy; ga.hcopy_stride = msq; acopy_done = true; }
                 launch_gram(s, ga);
                 HIP_TRY(hipEventRecord(h->ev_tiles, s));
                 trace_pending = true;
             } else launch_gram(s, ga);
             if (st) st->mark(2);
             if (c.grad) {       // keep A = K_uu + K_uf K_fu / Q: the factorisation overwrites it in place
-                HIP_TRY(hipMemcpy2DAsync(h->gw.Acopy, msq * sizeof(double), h->H, ga.h_stride * sizeof(double),
-                                         msq * sizeof(double), (size_t)ns * Dl, hipMemcpyDeviceToDevice, s));
+                if (!acopy_done)
+                    HIP_TRY(hipMemcpy2DAsync(h->gw.Acopy, msq * sizeof(double), h->H, ga.h_stride * sizeof(double),
+                                             msq * sizeof(double), (size_t)ns * Dl, hipMemcpyDeviceToDevice, s));
                 launch_potrf_ext(s, h->H, Mp, Mp + NB, Mp, ns * Dl, ga.h_stride, h->info + Dl + s0 * Dl, h->dinvH);
                 launch_h_finish(s, h->H, Mp, ga.h_stride, ns * Dl, h->hterms + (size_t)2 * s0 * Dl, 2 * Mp);
             } else {

@@ -1061,6 +1061,7 @@ __device__ __forceinline__ void gram_body(const GramArgs a, const int bz, const 
     const double *Kadd = (MODE == GRAM_KFU || MODE == GRAM_KFU_RAW) ? a.Kadd + (size_t)dl * a.kadd_stride : nullptr;
     const double *Kinv = (MODE == GRAM_KFU) ? a.Kinv + (size_t)dl * a.kinv_stride : nullptr;
     double *Rb = (MODE == GRAM_KFU_RAW) ? a.part + (size_t)bz * ((size_t)(Mp + 1) * Mp) : nullptr;
+    double *Cb2 = (MODE == GRAM_KFU_RAW && a.Hcopy) ? a.Hcopy + (size_t)bz * a.hcopy_stride : nullptr;
     double trp = 0.0;
     if (active) {
 #pragma unroll
@@ -1076,6 +1077,7 @@ __device__ __forceinline__ void gram_body(const GramArgs a, const int bz, const 
                     else if (MODE == GRAM_KFU_RAW) {
                         v = g * scale + Kadd[(size_t)i * Mp + j];
                         Rb[(size_t)i * Mp + j] = g;
+                        if (Cb2) Cb2[(size_t)i * Mp + j] = v;
                     } else if (MODE == GRAM_KFU) {
                         v = g * scale + Kadd[(size_t)i * Mp + j];
                         const double w = (i > j) ? 2.0 : ((i == j) ? 1.0 : 0.0);
