@@ -482,6 +482,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
     const bool defer_full = gram_route && !late_join && h->graw;
     const int ns_first = (h->cpp <= c.S_local) ? h->cpp : c.S_local;
     bool kfu_first = false;     // the first pass's K_fu build goes to the main stream before the chain is enqueued
+    bool ident_on_side = false;
     if (gram_route && (late_join || (size_t)first_units * Tp * Mp >= (size_t)64 * 4096 * 512)) {
         sk = h->aux;
         HIP_TRY(hipEventRecord(h->ev_fork, s));
@@ -494,9 +495,15 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
         }
         if (main_first) {
             const GramArgs ga = gram_args(0, c.S_local);
-            if (c.grad) launch_set_identity(s, h->H, ga.h_stride, Mp, Mp, c.S_local * Dl);
             launch_gram(s, ga, 1);
             HIP_TRY(hipEventRecord(h->ev_tiles, s));
+        }
+        // training: the identity rows that become L_A^-T are re-armed on the side stream, ahead of the K_uu build whose
+        // event the main stream waits for anyway (0.05 ms off the critical path at the full batch)
+        ident_on_side = c.grad && (defer_full || defer_trace);
+        if (ident_on_side) {
+            const GramArgs ga = gram_args(0, ns_first);
+            launch_set_identity(sk, h->H, ga.h_stride, Mp, Mp, ns_first * Dl);
         }
     }
     launch_kuu_build(sk, c.kernel_kind, hv, c.M, Mp, P, Dl, c.jitter, h->Kuu, (gram_route || grad_a) ? h->Kcopy : nullptr);
@@ -570,7 +577,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
         if (c.branch == FFVD_BRANCH_B) {
             GramArgs ga = gram_args(s0, ns);
             bool trace_pending = false, acopy_done = false;      // acopy_done: the Gram kernel stored the copy of A itself
-            if (c.grad && !main_first) launch_set_identity(s, h->H, ga.h_stride, Mp, Mp, ns * Dl);
+            if (c.grad && !(ident_on_side && s0 == 0)) launch_set_identity(s, h->H, ga.h_stride, Mp, Mp, ns * Dl);
             if (s0 == 0 && late_join) {
                 if (!main_first) launch_gram(s, ga, 1);
                 if (defer_trace) {
