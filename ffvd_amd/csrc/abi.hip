@@ -911,7 +911,13 @@ static int enqueue_grad_b(ffvd_handle *h, int S_total) {
         launch_e_reduce(s, er);
     }
     launch_e_finish(s, er, g.dz_unit, g.dll_unit, g.dls_unit);
+    // latent trajectories (after the E product) and the per-chain partials of the shared parameters (inputs only: side)
+    DxArgs dx{};
+    dx.X = p.X; dx.Y = h->Y; dx.CC = p.CC; dx.DD = p.DD; dx.log_Rchols = p.log_Rchols; dx.log_Q = p.log_Q; dx.len = h->len;
+    dx.rsum = g.rsum; dx.ez = g.ez; dx.kfu = g.kfu; dx.S = S; dx.S_total = S_total; dx.T = c.T; dx.Tp = Tp; dx.D = c.D;
+    dx.P = P; dx.Ydim = c.Ydim; dx.Dl = Dl; dx.d_begin = c.d_begin; dx.shared_terms = c.shared_terms; dx.dX = g.dX;
     launch_uku(sk, g.u, Mp, h->Kcopy, msq, Mp, Dl, nb, g.uku);      // u^T K u per unit: only grad_finalize reads it
+    launch_shared_partials(sk, dx, g.shared_part, g.sp_stride);
     launch_chain_sum(sk, g.Acopy, msq, S, Dl, msq, g.Asum, msq);
     launch_symmetrize(sk, g.Asum, Mp, Dl);
     launch_chain_sum(sk, g.Gamma, msq, S, Dl, msq, g.GamSum, msq);
@@ -932,13 +938,7 @@ static int enqueue_grad_b(ffvd_handle *h, int S_total) {
     launch_e_finish(sk, ek, g.dz_kuu, g.dll_kuu, g.dls_kuu);
     if (sk != s) HIP_TRY(hipEventRecord(h->ev_join, sk));
     if (sk != s) HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));
-    // latent trajectories and the per-chain partials of the shared parameters
-    DxArgs dx{};
-    dx.X = p.X; dx.Y = h->Y; dx.CC = p.CC; dx.DD = p.DD; dx.log_Rchols = p.log_Rchols; dx.log_Q = p.log_Q; dx.len = h->len;
-    dx.rsum = g.rsum; dx.ez = g.ez; dx.kfu = g.kfu; dx.S = S; dx.S_total = S_total; dx.T = c.T; dx.Tp = Tp; dx.D = c.D;
-    dx.P = P; dx.Ydim = c.Ydim; dx.Dl = Dl; dx.d_begin = c.d_begin; dx.shared_terms = c.shared_terms; dx.dX = g.dX;
     launch_dx(s, dx);
-    launch_shared_partials(s, dx, g.shared_part, g.sp_stride);
     GradFinalArgs gf{};
     gf.T = c.T; gf.D = c.D; gf.P = P; gf.M = c.M; gf.Mp = Mp; gf.Ydim = c.Ydim; gf.Dl = Dl; gf.d_begin = c.d_begin; gf.S = S;
     gf.S_total = S_total; gf.shared_terms = c.shared_terms; gf.prior_type = c.prior_type;
