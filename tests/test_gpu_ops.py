@@ -274,3 +274,23 @@ def test_pg_sweep_argument_errors():
         pg_sweep(L, Z, kern, U, X, Y, c[:3], CC, DD, R, Q, **good)
     with pytest.raises(ValueError):          # non-positive diagonal of Rchols
         pg_sweep(L, Z, kern, U, X, Y, c, CC, DD, np.zeros((1, 1)), Q, **good)
+
+
+def test_pg_sweep_linear_kernel():
+    """The sweep with the D-kernel LinearK list of config 5 (kernels.py:270-281 through the multi-output conditional)."""
+    from ffvd_amd.prediction import pg_sweep
+    from oracle import ffvd_pg_oracle as pgo
+    params, Y, c, meta = synthetic.make_named("small_lin")
+    D, C, T = meta["D"], meta["C"], meta["T"]
+    okern = orc.make_kernels(params, kernel_type=meta["kernel_type"])
+    Lm = orc.kernel_pre_cal(params["Z"], okern)
+    kern = [LinearK(D + C, variance=np.exp(params["logvariance"][d])) for d in range(D)]
+    X = params["X"][0]
+    rng = np.random.default_rng(3)
+    N = 7
+    x0, eps, u = rng.standard_normal((N - 1, D)), rng.standard_normal((T, N - 1, D)), rng.random((T, N - 1))
+    R, Q = np.exp(params["log_Rchols"]), np.exp(params["log_Q"])
+    po, io = pgo.pg_sweep(Lm, params["Z"], okern, params["U"], X, Y, c, params["CC"], params["DD"], R, Q, x0, eps, u)
+    pg, ig = pg_sweep(Lm, params["Z"], kern, params["U"], X, Y, c, params["CC"], params["DD"], R, Q, x0, eps, u)
+    np.testing.assert_array_equal(ig, io)
+    np.testing.assert_allclose(pg, po, rtol=1e-8, atol=1e-9)
