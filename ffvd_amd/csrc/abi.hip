@@ -56,6 +56,10 @@ struct ffvd_handle {
     // backward-pass workspace (cfg.grad)
     struct GradWs {
         double *Acopy = nullptr, *u = nullptr, *LAinv = nullptr, *Gamma = nullptr, *gam_part = nullptr, *uku = nullptr;
+        // whitened backward (collapsed branch): T1 = A W / N' L^-1 scratch, N' = alpha/2 (I - H^-1 - w w^T), w = H^-1 b,
+        // b = W^T c staging, identity matrix, two more per-dim products of the K_uu side
+        double *T1 = nullptr, *Nw = nullptr, *wv = nullptr, *bw = nullptr, *Ident = nullptr, *P2 = nullptr, *P3 = nullptr;
+        bool whitened = false;
         double *E = nullptr, *rp = nullptr, *rsum = nullptr, *ez = nullptr, *kfu = nullptr;
         double *cs_part = nullptr, *etx_part = nullptr, *rx2_part = nullptr, *dz_unit = nullptr, *dll_unit = nullptr, *dls_unit = nullptr;
         double *Asum = nullptr, *GamSum = nullptr, *Gs = nullptr, *gsum = nullptr, *P1 = nullptr, *KGK = nullptr, *Epsi = nullptr;
@@ -233,6 +237,14 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
         HIP_TRY(dev_alloc(h, &g.Asum, Dl * msq));  HIP_TRY(dev_alloc(h, &g.GamSum, Dl * msq)); HIP_TRY(dev_alloc(h, &g.Gs, Dl * msq));
         HIP_TRY(dev_alloc(h, &g.gsum, Dl * msq));  HIP_TRY(dev_alloc(h, &g.P1, Dl * msq));     HIP_TRY(dev_alloc(h, &g.KGK, Dl * msq));
         HIP_TRY(dev_alloc(h, &g.Epsi, Dl * msq));
+        g.whitened = c.branch == FFVD_BRANCH_B && !getenv("FFVD_GRAD_EXPLICIT");
+        if (g.whitened) {
+            HIP_TRY(dev_alloc(h, &g.T1, nbt * msq));   HIP_TRY(dev_alloc(h, &g.Nw, nbt * msq));
+            HIP_TRY(dev_alloc(h, &g.wv, nbt * Mp));    HIP_TRY(dev_alloc(h, &g.bw, nbt * Mp));
+            HIP_TRY(dev_alloc(h, &g.Ident, msq));      HIP_TRY(dev_alloc(h, &g.P2, Dl * msq)); HIP_TRY(dev_alloc(h, &g.P3, Dl * msq));
+            launch_set_identity(h->stream, g.Ident, 0, 0, (int)Mp, 1);
+            HIP_TRY(hipStreamSynchronize(h->stream));
+        }
         HIP_TRY(dev_alloc(h, &g.rsum2, Dl * Mp));  HIP_TRY(dev_alloc(h, &g.ez2, Dl * Mp * P));
         HIP_TRY(dev_alloc(h, &g.cs2, Dl * nblk2 * Mp)); HIP_TRY(dev_alloc(h, &g.etx2, Dl * nblk2 * Mp * P));
         HIP_TRY(dev_alloc(h, &g.rx22, Dl * nblk2 * P));
@@ -602,6 +614,28 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
                 if (!acopy_done)
                     HIP_TRY(hipMemcpy2DAsync(h->gw.Acopy, msq * sizeof(double), h->H, ga.h_stride * sizeof(double),
                                              msq * sizeof(double), (size_t)ns * Dl, hipMemcpyDeviceToDevice, s));
+                if (h->gw.whitened) {
+                    // H = W^T A W (W = L^-T of K_uu) replaces A in the slab, b = W^T c replaces c: the factorisation, the
+                    // explicit inverse and everything the backward pass derives from them then live in the whitened
+                    // variables, where cond(H) is about 1e4 instead of the 1e7 of A
+                    ffvd_handle::GradWs &g = h->gw;
+                    const int nbp = ns * Dl;
+                    if (sk != s) HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));       // W and L^-1 come from the K_uu chain
+                    launch_symmetrize(s, g.Acopy, Mp, nbp);
+                    AtbArgs t1{};
+                    t1.mode = ATB_PLAIN; t1.A = g.Acopy; t1.a_stride = msq; t1.lda = Mp; t1.nA = Mp;
+                    t1.B = h->Kuu + msq; t1.b_stride = kstride; t1.ldb = Mp; t1.nB = Mp; t1.b_per_dim = 1; t1.rows = Mp;
+                    t1.C = g.T1; t1.c_stride = msq; t1.ldc = Mp; t1.nb = nbp; t1.Dl = Dl; t1.krange = 8;      // W upper triangular
+                    launch_atb(s, t1);                                                  // T1 = A W
+                    AtbArgs t2{};
+                    t2.mode = ATB_PLAIN; t2.A = h->Kuu + msq; t2.a_stride = kstride; t2.lda = Mp; t2.nA = Mp; t2.a_per_dim = 1;
+                    t2.B = g.T1; t2.b_stride = msq; t2.ldb = Mp; t2.nB = Mp; t2.rows = Mp;
+                    t2.C = h->H; t2.c_stride = ga.h_stride; t2.ldc = Mp; t2.nb = nbp; t2.Dl = Dl; t2.krange = 4;
+                    launch_atb(s, t2);                                                  // H = W^T T1 into rows [0, Mp)
+                    launch_matvec(s, h->Linv, msq, h->H + 2 * msq, ga.h_stride, Mp, g.bw, 1, Mp, Mp, nbp, Dl);   // b = W^T c
+                    HIP_TRY(hipMemcpy2DAsync(h->H + 2 * msq, ga.h_stride * sizeof(double), g.bw, (size_t)Mp * sizeof(double),
+                                             (size_t)Mp * sizeof(double), (size_t)nbp, hipMemcpyDeviceToDevice, s));
+                }
                 launch_potrf_ext(s, h->H, Mp, Mp + NB, Mp, ns * Dl, ga.h_stride, h->info + Dl + s0 * Dl, h->dinvH);
                 launch_h_finish(s, h->H, Mp, ga.h_stride, ns * Dl, h->hterms + (size_t)2 * s0 * Dl, 2 * Mp);
             } else {
@@ -626,6 +660,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
     fa.log_Q = p.log_Q; fa.CC = p.CC; fa.DD = p.DD; fa.log_Rchols = p.log_Rchols;
     fa.chain_terms = h->chain_terms; fa.hterms = h->hterms; fa.chain_nll = h->chain_nll;
     fa.route = gram_route ? 1 : 0; fa.kterms = h->kterms; fa.trpart = h->trpart; fa.ntiles = h->ntiles;
+    fa.whitened = (c.grad && h->gw.whitened && gram_route) ? 1 : 0;
     fa.out_terms = out_dev ? out_dev : h->out_terms;
     launch_finalize(s, fa);
     if (st) st->mark(4);
@@ -866,16 +901,37 @@ static int enqueue_grad_b(ffvd_handle *h, int S_total) {
     const size_t msq = (size_t)Mp * Mp, hstride = (size_t)(2 * Mp + NB) * Mp, fstride = (size_t)Tp * Mp;
     hipStream_t s = h->stream;
     const ffvd_params &p = h->cur;
-    // u = A^-1 c = L_A^-T (L_A^-1 c); L_A^-1 for the explicit inverse
-    launch_matvec(s, h->H + msq, hstride, h->H + 2 * msq, hstride, Mp, g.u, 1, Mp, Mp, nb);
+    const size_t kstride = (size_t)2 * Mp * Mp;
+    const bool wh = g.whitened;
+    // explicit form: u = A^-1 c = L_A^-T (L_A^-1 c), Gamma = alpha/2 (K^-1 - A^-1 - u u^T) from the explicit inverses.
+    // whitened form (default): the slab holds the factor of H = W^T A W and y = L_H^-1 b, so the same launches give
+    // w = H^-1 b and N' = alpha/2 (I - H^-1 - w w^T) (identity in the place of K^-1 and of K), and then
+    // Gamma = W N' W^T, u = W w: the difference K^-1 - A^-1 is never formed from two inverses of condition 1e7.
+    double *uvec = wh ? g.wv : g.u;
+    launch_matvec(s, h->H + msq, hstride, h->H + 2 * msq, hstride, Mp, uvec, 1, Mp, Mp, nb);
     launch_transpose(s, h->H + msq, hstride, g.LAinv, msq, Mp, nb);
     AtbArgs ag{};
     ag.mode = ATB_GAMMA; ag.A = g.LAinv; ag.a_stride = msq; ag.lda = Mp; ag.nA = Mp;
     ag.B = g.LAinv; ag.b_stride = msq; ag.ldb = Mp; ag.nB = Mp; ag.b_per_dim = 0; ag.rows = Mp;
-    ag.C = g.Gamma; ag.c_stride = msq; ag.ldc = Mp; ag.nb = nb; ag.b0 = 0; ag.Dl = Dl; ag.d_begin = c.d_begin;
-    ag.log_Q = p.log_Q; ag.u = g.u; ag.u_stride = Mp; ag.Kinv = h->Kinv; ag.Kcopy = h->Kcopy; ag.k_stride = msq; ag.ldk = Mp;
-    ag.part = g.gam_part; ag.k_lower = 1; ag.sym = 1;   // L_A^-1 is lower triangular, A^-1 symmetric
+    ag.C = wh ? g.Nw : g.Gamma; ag.c_stride = msq; ag.ldc = Mp; ag.nb = nb; ag.b0 = 0; ag.Dl = Dl; ag.d_begin = c.d_begin;
+    ag.log_Q = p.log_Q; ag.u = uvec; ag.u_stride = Mp; ag.ldk = Mp;
+    if (wh) { ag.Kinv = g.Ident; ag.Kcopy = g.Ident; ag.k_stride = 0; }
+    else { ag.Kinv = h->Kinv; ag.Kcopy = h->Kcopy; ag.k_stride = msq; }
+    ag.part = g.gam_part; ag.k_lower = 1; ag.sym = 1;   // the inverse factor is lower triangular, its Gram symmetric
     launch_atb(s, ag);
+    if (wh) {
+        AtbArgs t1{};
+        t1.mode = ATB_PLAIN; t1.A = g.Nw; t1.a_stride = msq; t1.lda = Mp; t1.nA = Mp;
+        t1.B = h->Linv; t1.b_stride = msq; t1.ldb = Mp; t1.nB = Mp; t1.b_per_dim = 1; t1.rows = Mp;
+        t1.C = g.T1; t1.c_stride = msq; t1.ldc = Mp; t1.nb = nb; t1.Dl = Dl; t1.krange = 2;          // L^-1 lower triangular
+        launch_atb(s, t1);                                                      // T1 = N' W^T
+        AtbArgs t2{};
+        t2.mode = ATB_PLAIN; t2.A = h->Linv; t2.a_stride = msq; t2.lda = Mp; t2.nA = Mp; t2.a_per_dim = 1;
+        t2.B = g.T1; t2.b_stride = msq; t2.ldb = Mp; t2.nB = Mp; t2.rows = Mp;
+        t2.C = g.Gamma; t2.c_stride = msq; t2.ldc = Mp; t2.nb = nb; t2.Dl = Dl; t2.krange = 1;
+        launch_atb(s, t2);                                                      // Gamma = W T1
+        launch_matvec(s, h->Kuu + msq, kstride, g.wv, Mp, Mp, g.u, 1, Mp, Mp, nb, Dl);          // u = W w
+    }
     // K_uu side: Psi_d = sum_s Gamma_s / alpha_d - 1/2 K^-1 (sum_s A_s - S K) K^-1.  It needs Gamma and the saved
     // A-matrices only, so its dozen small launches go to the side stream and run beside the E product
     // (enqueued after it: the main stream must not wait for their launch overhead).
@@ -916,7 +972,8 @@ static int enqueue_grad_b(ffvd_handle *h, int S_total) {
     dx.X = p.X; dx.Y = h->Y; dx.CC = p.CC; dx.DD = p.DD; dx.log_Rchols = p.log_Rchols; dx.log_Q = p.log_Q; dx.len = h->len;
     dx.rsum = g.rsum; dx.ez = g.ez; dx.kfu = g.kfu; dx.S = S; dx.S_total = S_total; dx.T = c.T; dx.Tp = Tp; dx.D = c.D;
     dx.P = P; dx.Ydim = c.Ydim; dx.Dl = Dl; dx.d_begin = c.d_begin; dx.shared_terms = c.shared_terms; dx.dX = g.dX;
-    launch_uku(sk, g.u, Mp, h->Kcopy, msq, Mp, Dl, nb, g.uku);      // u^T K u per unit: only grad_finalize reads it
+    if (wh) launch_uku(sk, g.wv, Mp, g.Ident, 0, Mp, Dl, nb, g.uku);       // u^T K u = w^T w
+    else launch_uku(sk, g.u, Mp, h->Kcopy, msq, Mp, Dl, nb, g.uku);   // u^T K u per unit: only grad_finalize reads it
     launch_shared_partials(sk, dx, g.shared_part, g.sp_stride);
     launch_chain_sum(sk, g.Acopy, msq, S, Dl, msq, g.Asum, msq);
     launch_symmetrize(sk, g.Asum, Mp, Dl);
@@ -924,11 +981,23 @@ static int enqueue_grad_b(ffvd_handle *h, int S_total) {
     launch_axpby(sk, g.Asum, h->Kcopy, 1.0, -(double)S, p.log_Q, c.d_begin, 0, msq, Dl, g.Gs);
     launch_axpby(sk, g.GamSum, nullptr, 1.0, 0.0, p.log_Q, c.d_begin, 1, msq, Dl, g.gsum);
     AtbArgs ap{};
-    ap.mode = ATB_PLAIN; ap.A = g.Gs; ap.a_stride = msq; ap.lda = Mp; ap.nA = Mp; ap.B = h->Kinv; ap.b_stride = msq;
-    ap.ldb = Mp; ap.nB = Mp; ap.rows = Mp; ap.C = g.P1; ap.c_stride = msq; ap.ldc = Mp; ap.nb = Dl; ap.Dl = Dl;
-    launch_atb(sk, ap);                                 // P1 = Gs^T K^-1 = Gs K^-1
-    ap.A = g.P1; ap.C = g.KGK;
-    launch_atb(sk, ap);                                 // P1^T K^-1 = K^-1 Gs K^-1
+    ap.mode = ATB_PLAIN; ap.a_stride = msq; ap.lda = Mp; ap.nA = Mp; ap.b_stride = msq;
+    ap.ldb = Mp; ap.nB = Mp; ap.rows = Mp; ap.c_stride = msq; ap.ldc = Mp; ap.nb = Dl; ap.Dl = Dl;
+    if (wh) {       // K^-1 Gs K^-1 = W (W^T Gs W) W^T, conjugated step by step (Gs and W^T Gs W are symmetric)
+        ap.A = g.Gs; ap.B = h->Kuu + msq; ap.b_stride = kstride; ap.C = g.P1; ap.krange = 8;
+        launch_atb(sk, ap);                             // P1 = Gs W
+        ap.A = h->Kuu + msq; ap.a_stride = kstride; ap.B = g.P1; ap.b_stride = msq; ap.C = g.P2; ap.krange = 4;
+        launch_atb(sk, ap);                             // P2 = W^T Gs W
+        ap.A = g.P2; ap.a_stride = msq; ap.B = h->Linv; ap.C = g.P3; ap.krange = 2;
+        launch_atb(sk, ap);                             // P3 = P2 W^T
+        ap.A = h->Linv; ap.B = g.P3; ap.C = g.KGK; ap.krange = 1;
+        launch_atb(sk, ap);                             // KGK = W P3
+    } else {
+        ap.A = g.Gs; ap.B = h->Kinv; ap.C = g.P1;
+        launch_atb(sk, ap);                             // P1 = Gs^T K^-1 = Gs K^-1
+        ap.A = g.P1; ap.C = g.KGK;
+        launch_atb(sk, ap);                             // P1^T K^-1 = K^-1 Gs K^-1
+    }
     launch_psi_e(sk, g.gsum, g.KGK, h->Kcopy, c.M, Mp, Dl, c.jitter, g.Epsi);
     EReduceArgs ek{};
     ek.E = g.Epsi; ek.e_stride = msq; ek.Kf = nullptr; ek.u = nullptr; ek.x_is_z = 1; ek.Z = p.Z; ek.len = h->len;

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(512, 4) void atb_kernel(AtbArgs a) {
     const int lr = lane & 15, lk = lane >> 4;
     const int I0 = ti * 128 + wr * 64, J0 = tj * 128 + wc * 32;
     const bool active = (I0 < a.nA) && (J0 < a.nB);
-    const double *Ab = a.A + (size_t)bz * a.a_stride;
+    const double *Ab = a.A + (size_t)(a.a_per_dim ? (bz % a.Dl) : bz) * a.a_stride;
     const double *Bb = a.B + (size_t)(a.b_per_dim ? (bz % a.Dl) : bz) * a.b_stride;
     const int colA = ti * 128 + 2 * lane, colB = tj * 128 + 2 * lane;
     const bool okA = colA < a.nA, okB = colB < a.nB;
@@ -119,8 +119,17 @@ __global__ __launch_bounds__(512, 4) void atb_kernel(AtbArgs a) {
     for (int x = 0; x < 4; ++x)
 #pragma unroll
         for (int y = 0; y < 2; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
-    const int nchunk = a.rows / AT;
-    const int c0 = (!AROW && a.k_lower) ? ((ti > tj ? ti : tj) * 128) / AT : 0;
+    int nchunk = a.rows / AT;
+    int c0 = (!AROW && a.k_lower) ? ((ti > tj ? ti : tj) * 128) / AT : 0;
+    if (!AROW && a.krange) {
+        int k0 = 0, k1 = a.rows;
+        if ((a.krange & 1) && ti * 128 > k0) k0 = ti * 128;
+        if ((a.krange & 2) && tj * 128 > k0) k0 = tj * 128;
+        if ((a.krange & 4) && (ti + 1) * 128 < k1) k1 = (ti + 1) * 128;
+        if ((a.krange & 8) && (tj + 1) * 128 < k1) k1 = (tj + 1) * 128;
+        if (k0 / AT > c0) c0 = k0 / AT;
+        if (k1 / AT < nchunk) nchunk = k1 / AT;
+    }
     gload(c0);
     lstore(c0 & 1);
     __syncthreads();

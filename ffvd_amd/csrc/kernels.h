@@ -142,6 +142,8 @@ struct FinalizeArgs {
     const double *hterms;          // [S*Dl][2] (branch B) or null
     int route;                     // 0: F = K_fu L^-T route, 1: K_uu + K_uf K_fu / Q route
     const double *kterms;          // route 1: [Dl][2], kterms[2 dl] = log det (K_uu + jitter I)
+    int whitened;                  // route 1, training: hterms come from H = L^-1 A L^-T, whose log det is already
+                                   //   log|A| - log|K_uu + jitter I|
     const double *trpart;          // route 1: [S*Dl][ntiles] partial sums of tr(K^-1 K_uf K_fu)
     int ntiles;
     double *chain_nll;             // [S]
@@ -155,7 +157,7 @@ void launch_conditional_finish(hipStream_t stream, int kind, const double *x, in
                                double *var, const double *extra /* optional [D][Tp] added to var */);
 // out[i * out_ld + b * out_bs] = sum_j W[b][i][j] y[b][j]
 void launch_matvec(hipStream_t stream, const double *W, size_t w_stride, const double *y, size_t y_stride, int Mp,
-                   double *out, int out_ld, int out_bs, int M, int batch);
+                   double *out, int out_ld, int out_bs, int M, int batch, int w_mod = 0);   // w_mod > 0: W slab index = batch index % w_mod
 void launch_qsqrt_inflation(hipStream_t stream, const double *F, size_t f_stride, int Tp, int Mp, int M, const double *Qs,
                             double *extra, int N, int batch);
 

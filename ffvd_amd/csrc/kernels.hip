@@ -1374,10 +1374,10 @@ void launch_conditional_finish(hipStream_t stream, int kind, const double *x, in
 
 // out[b][i] = sum_j W[b][i][j] * y[b][j]   (posterior mean of the whitened inducing outputs: L_H^-T (L_H^-1 b))
 __global__ __launch_bounds__(256) void matvec_kernel(const double *W, size_t w_stride, const double *y, size_t y_stride,
-                                                     int Mp, double *out, int out_ld, int out_bs, int M) {
+                                                     int Mp, double *out, int out_ld, int out_bs, int M, int w_mod) {
     __shared__ double ys[2048];
     const int b = blockIdx.y, tid = threadIdx.x;
-    const double *Wb = W + (size_t)b * w_stride, *yb = y + (size_t)b * y_stride;
+    const double *Wb = W + (size_t)(w_mod > 0 ? b % w_mod : b) * w_stride, *yb = y + (size_t)b * y_stride;
     for (int j0 = 0; j0 < Mp; j0 += 2048) {     // Mp <= 2048 per tile of y
         for (int j = tid; j < 2048 && j0 + j < Mp; j += 256) ys[j] = yb[j0 + j];
         __syncthreads();
@@ -1392,9 +1392,9 @@ __global__ __launch_bounds__(256) void matvec_kernel(const double *W, size_t w_s
     }
 }
 void launch_matvec(hipStream_t stream, const double *W, size_t w_stride, const double *y, size_t y_stride, int Mp,
-                   double *out, int out_ld, int out_bs, int M, int batch) {
+                   double *out, int out_ld, int out_bs, int M, int batch, int w_mod) {
     hipLaunchKernelGGL(matvec_kernel, dim3((M + 255) / 256, batch), dim3(256), 0, stream, W, w_stride, y, y_stride, Mp, out,
-                       out_ld, out_bs, M);
+                       out_ld, out_bs, M, w_mod);
 }
 
 // extra[b][n] = sum_j ( sum_m F[b][n][m] * Qs[m][j] )^2   -- the q_sqrt variance inflation of
@@ -1535,7 +1535,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
                 double logdet = ht[0];
                 if (a.route == 1) {
                     // log|I + L^-1 G L^-T / Q| = log|K + G/Q| - log|K|  with K = K_uu + jitter I
-                    logdet -= a.kterms[2 * dl];
+                    if (!a.whitened) logdet -= a.kterms[2 * dl];
                     // sum_t |F_t|^2 = tr(K^-1 K_uf K_fu): add it back to the trace term (:255)
                     double fsq = 0.0;
                     for (int t = 0; t < a.ntiles; ++t) fsq += a.trpart[bb * a.ntiles + t];
