@@ -630,7 +630,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
                     AtbArgs t2{};
                     t2.mode = ATB_PLAIN; t2.A = h->Kuu + msq; t2.a_stride = kstride; t2.lda = Mp; t2.nA = Mp; t2.a_per_dim = 1;
                     t2.B = g.T1; t2.b_stride = msq; t2.ldb = Mp; t2.nB = Mp; t2.rows = Mp;
-                    t2.C = h->H; t2.c_stride = ga.h_stride; t2.ldc = Mp; t2.nb = nbp; t2.Dl = Dl; t2.krange = 4;
+                    t2.C = h->H; t2.c_stride = ga.h_stride; t2.ldc = Mp; t2.nb = nbp; t2.Dl = Dl; t2.krange = 4; t2.sym = 1;
                     launch_atb(s, t2);                                                  // H = W^T T1 into rows [0, Mp)
                     launch_matvec(s, h->Linv, msq, h->H + 2 * msq, ga.h_stride, Mp, g.bw, 1, Mp, Mp, nbp, Dl);   // b = W^T c
                     HIP_TRY(hipMemcpy2DAsync(h->H + 2 * msq, ga.h_stride * sizeof(double), g.bw, (size_t)Mp * sizeof(double),
@@ -928,7 +928,7 @@ static int enqueue_grad_b(ffvd_handle *h, int S_total) {
         AtbArgs t2{};
         t2.mode = ATB_PLAIN; t2.A = h->Linv; t2.a_stride = msq; t2.lda = Mp; t2.nA = Mp; t2.a_per_dim = 1;
         t2.B = g.T1; t2.b_stride = msq; t2.ldb = Mp; t2.nB = Mp; t2.rows = Mp;
-        t2.C = g.Gamma; t2.c_stride = msq; t2.ldc = Mp; t2.nb = nb; t2.Dl = Dl; t2.krange = 1;
+        t2.C = g.Gamma; t2.c_stride = msq; t2.ldc = Mp; t2.nb = nb; t2.Dl = Dl; t2.krange = 1; t2.sym = 1;
         launch_atb(s, t2);                                                      // Gamma = W T1
         launch_matvec(s, h->Kuu + msq, kstride, g.wv, Mp, Mp, g.u, 1, Mp, Mp, nb, Dl);          // u = W w
     }

@@ -26,7 +26,7 @@ struct AtbArgs {
     // 128 ti; bit 1: B lower ([k][j] = 0 for k < j): start at 128 tj; bit 2: A upper ([k][i] = 0 for k > i): end at
     // 128 (ti + 1); bit 3: B upper: end at 128 (tj + 1).  k_lower (below) = bits 0 and 1.
     int krange;
-    int sym;                                            // GAMMA: A == B, the product is symmetric: only tiles tj <= ti are
+    int sym;                                            // GAMMA / PLAIN: the product is symmetric: only tiles tj <= ti are
                                                         //    launched, off-diagonal ones are also written mirrored
     int k_lower;                                        // 1: A and B are lower triangular as stored ([k][i] = 0 for i > k): the
                                                         //    sum for tile (ti, tj) starts at row 128 max(ti, tj) (exact: skips zeros)

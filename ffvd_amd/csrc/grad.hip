@@ -62,7 +62,7 @@ __global__ __launch_bounds__(512, 4) void atb_kernel(AtbArgs a) {
     const int bz = blockIdx.y;
     const int ntj = (a.nB + 127) / 128;
     int ti = blockIdx.x / ntj, tj = blockIdx.x % ntj;
-    if (MODE == ATB_GAMMA && a.sym) {                    // lower-triangular tile list: blockIdx.x = ti (ti + 1) / 2 + tj
+    if ((MODE == ATB_GAMMA || MODE == ATB_PLAIN) && a.sym) {   // lower-triangular tile list: blockIdx.x = ti (ti + 1) / 2 + tj
         ti = 0;
         while ((ti + 1) * (ti + 2) / 2 <= (int)blockIdx.x) ++ti;
         tj = blockIdx.x - ti * (ti + 1) / 2;
@@ -187,6 +187,8 @@ __global__ __launch_bounds__(512, 4) void atb_kernel(AtbArgs a) {
                         if (mirror) Cb[(size_t)j * a.ldc + i] = v;       // K^-1, A^-1, u u^T are all symmetric
                     } else if (MODE == ATB_BWD_E) {
                         v = (2.0 * g + rowv * ub[j]) * Kf[(size_t)i * a.ldkf + j];
+                    } else if (MODE == ATB_PLAIN) {
+                        if (a.sym && ti != tj) Cb[(size_t)j * a.ldc + i] = v;      // symmetric product: mirrored tile
                     }
                     Cb[(size_t)i * a.ldc + j] = v;
                 }
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(512, 4) void atb_kernel(AtbArgs a) {
 void launch_atb(hipStream_t stream, const AtbArgs &a) {
     const int nti = (a.nA + 127) / 128, ntj = (a.nB + 127) / 128;
     dim3 grid(nti * ntj, a.nb);
-    if (a.mode == ATB_GAMMA && a.sym) grid.x = nti * (nti + 1) / 2;
+    if ((a.mode == ATB_GAMMA || a.mode == ATB_PLAIN) && a.sym) grid.x = nti * (nti + 1) / 2;
     if (a.mode == ATB_PLAIN) hipLaunchKernelGGL((atb_kernel<ATB_PLAIN, false>), grid, dim3(512), 0, stream, a);
     else if (a.mode == ATB_GAMMA) hipLaunchKernelGGL((atb_kernel<ATB_GAMMA, false>), grid, dim3(512), 0, stream, a);
     else if (a.a_rowmajor) hipLaunchKernelGGL((atb_kernel<ATB_BWD_E, true>), grid, dim3(512), 0, stream, a);
