@@ -10,7 +10,7 @@ Notation per latent dim d (index dropped):  alpha = 1/Q,  K = K_uu + jitter I,  
 G = Kf^T Kf,  g = Kf^T delta,  A = K + alpha G,  c = alpha g,  u = A^-1 c,
 l = -1/2 (log|A| - log|K|) + 1/2 c^T u - 1/2 alpha (T sigma^2 - tr(K^-1 G)),   nll contribution = -l / T.
 
-  dl/dG     = Gamma = 1/2 alpha (K^-1 - A^-1 - u u^T)
+  dl/dG     = Gamma = 1/2 alpha (K^-1 - A^-1 - u u^T)        (evaluated as W N W^T in whitened variables, see nll_grad)
   dl/dg     = alpha u
   dl/dK     = Psi   = 1/2 (K^-1 - A^-1 - u u^T) - 1/2 alpha K^-1 G K^-1
   dl/dalpha = -1/2 tr(A^-1 G) + u^T g - 1/2 u^T G u - 1/2 (T sigma^2 - tr(K^-1 G))
@@ -19,6 +19,7 @@ l = -1/2 (log|A| - log|K|) + 1/2 c^T u - 1/2 alpha (T sigma^2 - tr(K^-1 G)),   n
 from __future__ import annotations
 
 import numpy as np
+from scipy.linalg import cho_factor, cho_solve, solve_triangular
 
 from . import ffvd_oracle as orc
 
@@ -85,12 +86,24 @@ def nll_grad(params, Y, control_inputs, jitter=orc.JITTER_MULTI_OUTPUT, prior_ty
         G = Kf.T @ Kf
         gv = Kf.T @ delta[:, d]
         A = K + alpha * G
-        Kinv = np.linalg.inv(K)
-        Ainv = np.linalg.inv(A)
-        u = Ainv @ (alpha * gv)
-        Gam = 0.5 * alpha * (Kinv - Ainv - np.outer(u, u))
-        Psi = 0.5 * (Kinv - Ainv - np.outer(u, u)) - 0.5 * alpha * (Kinv @ G @ Kinv)
-        dalpha = (-0.5 * np.sum(Ainv * G) + u @ gv - 0.5 * u @ G @ u - 0.5 * (T * s2 - np.sum(Kinv * G)))
+        # The closed form above, evaluated in whitened variables: with K = L L^T, W = L^-T and H = W^T A W (= I + alpha
+        # W^T G W, condition ~1e4 where A and K have ~1e7),  K^-1 - A^-1 = W (I - H^-1) W^T.  Forming that difference from
+        # two explicit inverses loses eps * cond(K) * |K^-1| in the near-null directions of K_uu and costs dZ three
+        # digits at M = 512 (central differences of the nll arbitrate: tools/grad_check_full.py); this order does not.
+        L = np.linalg.cholesky(K)
+        W = solve_triangular(L, np.eye(M), lower=True).T
+        H = W.T @ A @ W
+        H = 0.5 * (H + H.T)
+        cH = cho_factor(H, lower=True)
+        w = cho_solve(cH, alpha * (W.T @ gv))
+        Hinv = cho_solve(cH, np.eye(M))
+        u = W @ w                                               # = A^-1 c
+        Nw = np.eye(M) - Hinv - np.outer(w, w)
+        Gam = 0.5 * alpha * (W @ Nw @ W.T)                      # = 1/2 alpha (K^-1 - A^-1 - u u^T)
+        Psi = 0.5 * (W @ (Nw - (H - np.eye(M))) @ W.T)          # alpha K^-1 G K^-1 = W (H - I) W^T
+        trAinvG = (M - np.trace(Hinv)) / alpha                  # tr(A^-1 G),  G = (A - K) / alpha
+        trKinvG = (np.trace(H) - M) / alpha                     # tr(K^-1 G) = tr(W^T G W)
+        dalpha = (-0.5 * trAinvG + u @ gv - 0.5 * (w @ (H - np.eye(M)) @ w) / alpha - 0.5 * (T * s2 - trKinvG))
         dKf = 2.0 * Kf @ Gam + np.outer(delta[:, d], alpha * u)
         ddelta = alpha * (Kf @ u)
         # chain rule through the kernel matrices; everything below is d l, the nll gets -1/T of it
