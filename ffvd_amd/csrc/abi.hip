@@ -621,7 +621,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
                     ffvd_handle::GradWs &g = h->gw;
                     const int nbp = ns * Dl;
                     if (sk != s) HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));       // W and L^-1 come from the K_uu chain
-                    launch_symmetrize(s, g.Acopy, Mp, nbp);
+                    if (!acopy_done) launch_symmetrize(s, g.Acopy, Mp, nbp);           // the Gram kernel's own copy is symmetric already
                     AtbArgs t1{};
                     t1.mode = ATB_PLAIN; t1.A = g.Acopy; t1.a_stride = msq; t1.lda = Mp; t1.nA = Mp;
                     t1.B = h->Kuu + msq; t1.b_stride = kstride; t1.ldb = Mp; t1.nB = Mp; t1.b_per_dim = 1; t1.rows = Mp;

@@ -1077,7 +1077,10 @@ __device__ __forceinline__ void gram_body(const GramArgs a, const int bz, const 
                     else if (MODE == GRAM_KFU_RAW) {
                         v = g * scale + Kadd[(size_t)i * Mp + j];
                         Rb[(size_t)i * Mp + j] = g;
-                        if (Cb2) Cb2[(size_t)i * Mp + j] = v;
+                        if (Cb2 && j <= i) {                    // the copy is made fully symmetric here (lower triangle + mirror)
+                            Cb2[(size_t)i * Mp + j] = v;
+                            if (j < i) Cb2[(size_t)j * Mp + i] = v;
+                        }
                     } else if (MODE == GRAM_KFU) {
                         v = g * scale + Kadd[(size_t)i * Mp + j];
                         const double w = (i > j) ? 2.0 : ((i == j) ? 1.0 : 0.0);
