@@ -56,9 +56,9 @@ struct ffvd_handle {
     // backward-pass workspace (cfg.grad)
     struct GradWs {
         double *Acopy = nullptr, *u = nullptr, *LAinv = nullptr, *Gamma = nullptr, *gam_part = nullptr, *uku = nullptr;
-        // whitened backward (collapsed branch): T1 = A W / N' L^-1 scratch, N' = alpha/2 (I - H^-1 - w w^T), w = H^-1 b,
-        // b = W^T c staging, identity matrix, two more per-dim products of the K_uu side
-        double *T1 = nullptr, *Nw = nullptr, *wv = nullptr, *bw = nullptr, *Ident = nullptr, *P2 = nullptr, *P3 = nullptr;
+        // whitened backward (collapsed branch): T1 = A W, later B = L_H^-1 L^-1; w = H^-1 b; b = W^T c staging; identity
+        // matrix (w^T w through the u^T K u kernel); two more per-dim products of the K_uu side
+        double *T1 = nullptr, *wv = nullptr, *bw = nullptr, *Ident = nullptr, *P2 = nullptr, *P3 = nullptr;
         bool whitened = false;
         double *E = nullptr, *rp = nullptr, *rsum = nullptr, *ez = nullptr, *kfu = nullptr;
         double *cs_part = nullptr, *etx_part = nullptr, *rx2_part = nullptr, *dz_unit = nullptr, *dll_unit = nullptr, *dls_unit = nullptr;
@@ -239,7 +239,7 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
         HIP_TRY(dev_alloc(h, &g.Epsi, Dl * msq));
         g.whitened = c.branch == FFVD_BRANCH_B && !getenv("FFVD_GRAD_EXPLICIT");
         if (g.whitened) {
-            HIP_TRY(dev_alloc(h, &g.T1, nbt * msq));   HIP_TRY(dev_alloc(h, &g.Nw, nbt * msq));
+            HIP_TRY(dev_alloc(h, &g.T1, nbt * msq));
             HIP_TRY(dev_alloc(h, &g.wv, nbt * Mp));    HIP_TRY(dev_alloc(h, &g.bw, nbt * Mp));
             HIP_TRY(dev_alloc(h, &g.Ident, msq));      HIP_TRY(dev_alloc(h, &g.P2, Dl * msq)); HIP_TRY(dev_alloc(h, &g.P3, Dl * msq));
             launch_set_identity(h->stream, g.Ident, 0, 0, (int)Mp, 1);
@@ -903,35 +903,32 @@ static int enqueue_grad_b(ffvd_handle *h, int S_total) {
     const ffvd_params &p = h->cur;
     const size_t kstride = (size_t)2 * Mp * Mp;
     const bool wh = g.whitened;
-    // explicit form: u = A^-1 c = L_A^-T (L_A^-1 c), Gamma = alpha/2 (K^-1 - A^-1 - u u^T) from the explicit inverses.
-    // whitened form (default): the slab holds the factor of H = W^T A W and y = L_H^-1 b, so the same launches give
-    // w = H^-1 b and N' = alpha/2 (I - H^-1 - w w^T) (identity in the place of K^-1 and of K), and then
-    // Gamma = W N' W^T, u = W w: the difference K^-1 - A^-1 is never formed from two inverses of condition 1e7.
-    double *uvec = wh ? g.wv : g.u;
-    launch_matvec(s, h->H + msq, hstride, h->H + 2 * msq, hstride, Mp, uvec, 1, Mp, Mp, nb);
-    launch_transpose(s, h->H + msq, hstride, g.LAinv, msq, Mp, nb);
+    // explicit form: u = A^-1 c = L_A^-T (L_A^-1 c), Gamma = alpha/2 (K^-1 - A^-1 - u u^T) with A^-1 from the factor of A.
+    // whitened form (default): the slab holds the factor of H = W^T A W and y = L_H^-1 b.  Then w = H^-1 b, u = W w, and
+    // A^-1 = B^T B with B = L_H^-1 L^-1 (a product of two accurate triangular factors; K^-1 = (L^-1)^T L^-1 is formed
+    // the same way in the forward pass), so the same Gamma launch runs on B instead of on the inverse factor of the
+    // ill-conditioned A -- dZ at M = 512 then agrees with central differences to 7 digits instead of 3.
     AtbArgs ag{};
-    ag.mode = ATB_GAMMA; ag.A = g.LAinv; ag.a_stride = msq; ag.lda = Mp; ag.nA = Mp;
-    ag.B = g.LAinv; ag.b_stride = msq; ag.ldb = Mp; ag.nB = Mp; ag.b_per_dim = 0; ag.rows = Mp;
-    ag.C = wh ? g.Nw : g.Gamma; ag.c_stride = msq; ag.ldc = Mp; ag.nb = nb; ag.b0 = 0; ag.Dl = Dl; ag.d_begin = c.d_begin;
-    ag.log_Q = p.log_Q; ag.u = uvec; ag.u_stride = Mp; ag.ldk = Mp;
-    if (wh) { ag.Kinv = g.Ident; ag.Kcopy = g.Ident; ag.k_stride = 0; }
-    else { ag.Kinv = h->Kinv; ag.Kcopy = h->Kcopy; ag.k_stride = msq; }
+    ag.mode = ATB_GAMMA; ag.a_stride = msq; ag.lda = Mp; ag.nA = Mp;
+    ag.b_stride = msq; ag.ldb = Mp; ag.nB = Mp; ag.b_per_dim = 0; ag.rows = Mp;
+    ag.C = g.Gamma; ag.c_stride = msq; ag.ldc = Mp; ag.nb = nb; ag.b0 = 0; ag.Dl = Dl; ag.d_begin = c.d_begin;
+    ag.log_Q = p.log_Q; ag.u = g.u; ag.u_stride = Mp; ag.Kinv = h->Kinv; ag.Kcopy = h->Kcopy; ag.k_stride = msq; ag.ldk = Mp;
     ag.part = g.gam_part; ag.k_lower = 1; ag.sym = 1;   // the inverse factor is lower triangular, its Gram symmetric
-    launch_atb(s, ag);
     if (wh) {
-        AtbArgs t1{};
-        t1.mode = ATB_PLAIN; t1.A = g.Nw; t1.a_stride = msq; t1.lda = Mp; t1.nA = Mp;
-        t1.B = h->Linv; t1.b_stride = msq; t1.ldb = Mp; t1.nB = Mp; t1.b_per_dim = 1; t1.rows = Mp;
-        t1.C = g.T1; t1.c_stride = msq; t1.ldc = Mp; t1.nb = nb; t1.Dl = Dl; t1.krange = 2;          // L^-1 lower triangular
-        launch_atb(s, t1);                                                      // T1 = N' W^T
-        AtbArgs t2{};
-        t2.mode = ATB_PLAIN; t2.A = h->Linv; t2.a_stride = msq; t2.lda = Mp; t2.nA = Mp; t2.a_per_dim = 1;
-        t2.B = g.T1; t2.b_stride = msq; t2.ldb = Mp; t2.nB = Mp; t2.rows = Mp;
-        t2.C = g.Gamma; t2.c_stride = msq; t2.ldc = Mp; t2.nb = nb; t2.Dl = Dl; t2.krange = 1; t2.sym = 1;
-        launch_atb(s, t2);                                                      // Gamma = W T1
-        launch_matvec(s, h->Kuu + msq, kstride, g.wv, Mp, Mp, g.u, 1, Mp, Mp, nb, Dl);          // u = W w
+        launch_matvec(s, h->H + msq, hstride, h->H + 2 * msq, hstride, Mp, g.wv, 1, Mp, Mp, nb);          // w = L_H^-T y
+        launch_matvec(s, h->Kuu + msq, kstride, g.wv, Mp, Mp, g.u, 1, Mp, Mp, nb, Dl);                     // u = W w
+        AtbArgs tb{};       // B[i][j] = sum_k L_H^-T[k][i] L^-1[k][j]: the extension rows as they are, no transpose
+        tb.mode = ATB_PLAIN; tb.A = h->H + msq; tb.a_stride = hstride; tb.lda = Mp; tb.nA = Mp;
+        tb.B = h->Linv; tb.b_stride = msq; tb.ldb = Mp; tb.nB = Mp; tb.b_per_dim = 1; tb.rows = Mp;
+        tb.C = g.T1; tb.c_stride = msq; tb.ldc = Mp; tb.nb = nb; tb.Dl = Dl; tb.krange = 2 | 4;      // k in [128 tj, 128 (ti + 1))
+        launch_atb(s, tb);
+        ag.A = g.T1; ag.B = g.T1;
+    } else {
+        launch_matvec(s, h->H + msq, hstride, h->H + 2 * msq, hstride, Mp, g.u, 1, Mp, Mp, nb);
+        launch_transpose(s, h->H + msq, hstride, g.LAinv, msq, Mp, nb);
+        ag.A = g.LAinv; ag.B = g.LAinv;
     }
+    launch_atb(s, ag);
     // K_uu side: Psi_d = sum_s Gamma_s / alpha_d - 1/2 K^-1 (sum_s A_s - S K) K^-1.  It needs Gamma and the saved
     // A-matrices only, so its dozen small launches go to the side stream and run beside the E product
     // (enqueued after it: the main stream must not wait for their launch overhead).
