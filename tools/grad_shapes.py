@@ -18,4 +18,4 @@ for ov in (dict(T=170, M=150, S=2, D=3, C=1), dict(T=300, M=150, S=1, D=2, C=2),
         ref["X"][s] = a["X"] / S
         for k in a:
             if k != "X": ref[k] += a[k] / S
-    print(ov, " ".join("%s=%.1e" % (k, np.max(np.abs(g[k] - ref[k])) / (np.max(np.abs(ref[k])) + 1e-300)) for k in g))
+    print(ov, " ".join("%s=%.1e" % (k, np.max(np.abs(g[k] - ref[k])) / (np.max(np.abs(ref[k])) + 1e-300)) for k in ref if k in g))
