@@ -59,13 +59,19 @@ __global__ __launch_bounds__(512, 4) void atb_kernel(AtbArgs a) {
     __shared__ double As[2][AT][A_LD];
     __shared__ double Bs[2][AT][A_LD];
     __shared__ double red[512];
-    const int bz = blockIdx.y;
+    // XCD-aware mapping: workgroup ids go round-robin over the 8 XCDs, so all tiles of one unit take ids of the same
+    // residue: the unit's operands (2 x 2 MB at M = 512) are then read through ONE 4 MB L2 instead of all eight
+    // (these M^3-sized batched products are bound by operand re-reads, not by the matrix pipe)
+    const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+    const int bz = (loc / a.ntile) * 8 + xcd;
+    if (bz >= a.nb) return;
+    const int tile = loc % a.ntile;
     const int ntj = (a.nB + 127) / 128;
-    int ti = blockIdx.x / ntj, tj = blockIdx.x % ntj;
-    if ((MODE == ATB_GAMMA || MODE == ATB_PLAIN) && a.sym) {   // lower-triangular tile list: blockIdx.x = ti (ti + 1) / 2 + tj
+    int ti = tile / ntj, tj = tile % ntj;
+    if ((MODE == ATB_GAMMA || MODE == ATB_PLAIN) && a.sym) {   // lower-triangular tile list: tile = ti (ti + 1) / 2 + tj
         ti = 0;
-        while ((ti + 1) * (ti + 2) / 2 <= (int)blockIdx.x) ++ti;
-        tj = blockIdx.x - ti * (ti + 1) / 2;
+        while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
+        tj = tile - ti * (ti + 1) / 2;
     }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -201,14 +207,16 @@ __global__ __launch_bounds__(512, 4) void atb_kernel(AtbArgs a) {
             if (tid < st) red[tid] += red[tid + st];
             __syncthreads();
         }
-        if (tid == 0) a.part[(size_t)bz * gridDim.x + blockIdx.x] = red[0];
+        if (tid == 0) a.part[(size_t)bz * a.ntile + tile] = red[0];
     }
 }
 
-void launch_atb(hipStream_t stream, const AtbArgs &a) {
+void launch_atb(hipStream_t stream, const AtbArgs &a_in) {
+    AtbArgs a = a_in;
     const int nti = (a.nA + 127) / 128, ntj = (a.nB + 127) / 128;
-    dim3 grid(nti * ntj, a.nb);
-    if ((a.mode == ATB_GAMMA || a.mode == ATB_PLAIN) && a.sym) grid.x = nti * (nti + 1) / 2;
+    a.ntile = nti * ntj;
+    if ((a.mode == ATB_GAMMA || a.mode == ATB_PLAIN) && a.sym) a.ntile = nti * (nti + 1) / 2;
+    dim3 grid((unsigned)(((a.nb + 7) / 8) * 8 * a.ntile));
     if (a.mode == ATB_PLAIN) hipLaunchKernelGGL((atb_kernel<ATB_PLAIN, false>), grid, dim3(512), 0, stream, a);
     else if (a.mode == ATB_GAMMA) hipLaunchKernelGGL((atb_kernel<ATB_GAMMA, false>), grid, dim3(512), 0, stream, a);
     else if (a.a_rowmajor) hipLaunchKernelGGL((atb_kernel<ATB_BWD_E, true>), grid, dim3(512), 0, stream, a);
