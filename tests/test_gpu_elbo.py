@@ -638,3 +638,31 @@ def test_explicit_u_gradient_dim_shards_add_up():
     whole, a, b = grads(0, D, True), grads(0, 1, True), grads(1, D - 1, False)
     for k in GRAD_KEYS + ("U",):
         np.testing.assert_allclose(a[k] + b[k], whole[k], rtol=0, atol=1e-10 * np.max(np.abs(whole[k])) + 1e-300)
+
+
+def test_explicit_inverse_backward_switch(monkeypatch):
+    """FFVD_GRAD_EXPLICIT=1 (read when the handle is created) selects the older backward pass that forms K^-1 - A^-1 from
+    two explicit inverses: 20 % faster at the headline shape, eps * cond(K_uu) less accurate on dZ.
+    Both forms must agree with the oracle on a well-conditioned case, the default one more closely."""
+    from oracle import ffvd_grad_oracle as gorc
+    params, Y, c, meta = synthetic.make_named("tiny")
+    S = meta["S"]
+    want = None
+    for s in range(S):
+        a = gorc.nll_grad(dict(params, X=params["X"][s]), Y, c)
+        want = a["Z"] / S if want is None else want + a["Z"] / S
+
+    def dz():
+        with ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], S, route="gram", grad=True) as e:
+            e.set_data(Y, c)
+            t, g = e.nll_and_grad(params)
+        return t["nll"], g["Z"]
+
+    nll_w, z_w = dz()
+    monkeypatch.setenv("FFVD_GRAD_EXPLICIT", "1")
+    nll_e, z_e = dz()
+    scale = np.max(np.abs(want))
+    assert nll_e == pytest.approx(nll_w, rel=1e-9)
+    assert np.max(np.abs(z_w - want)) < 1e-7 * scale
+    assert np.max(np.abs(z_e - want)) < 1e-5 * scale
+    assert not np.array_equal(z_w, z_e)              # the switch really selects another code path
