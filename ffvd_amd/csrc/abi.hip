@@ -620,17 +620,18 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
                     // variables, where cond(H) is about 1e4 instead of the 1e7 of A
                     ffvd_handle::GradWs &g = h->gw;
                     const int nbp = ns * Dl;
+                    const int small = getenv("FFVD_ATB128") ? 0 : 1;
                     if (sk != s) HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));       // W and L^-1 come from the K_uu chain
                     if (!acopy_done) launch_symmetrize(s, g.Acopy, Mp, nbp);           // the Gram kernel's own copy is symmetric already
                     AtbArgs t1{};
                     t1.mode = ATB_PLAIN; t1.A = g.Acopy; t1.a_stride = msq; t1.lda = Mp; t1.nA = Mp;
                     t1.B = h->Kuu + msq; t1.b_stride = kstride; t1.ldb = Mp; t1.nB = Mp; t1.b_per_dim = 1; t1.rows = Mp;
-                    t1.C = g.T1; t1.c_stride = msq; t1.ldc = Mp; t1.nb = nbp; t1.Dl = Dl; t1.krange = 8;      // W upper triangular
+                    t1.C = g.T1; t1.c_stride = msq; t1.ldc = Mp; t1.nb = nbp; t1.Dl = Dl; t1.krange = 8; t1.small_tiles = small;      // W upper triangular
                     launch_atb(s, t1);                                                  // T1 = A W
                     AtbArgs t2{};
                     t2.mode = ATB_PLAIN; t2.A = h->Kuu + msq; t2.a_stride = kstride; t2.lda = Mp; t2.nA = Mp; t2.a_per_dim = 1;
                     t2.B = g.T1; t2.b_stride = msq; t2.ldb = Mp; t2.nB = Mp; t2.rows = Mp;
-                    t2.C = h->H; t2.c_stride = ga.h_stride; t2.ldc = Mp; t2.nb = nbp; t2.Dl = Dl; t2.krange = 4; t2.sym = 1;
+                    t2.C = h->H; t2.c_stride = ga.h_stride; t2.ldc = Mp; t2.nb = nbp; t2.Dl = Dl; t2.krange = 4; t2.sym = 1; t2.small_tiles = small;
                     launch_atb(s, t2);                                                  // H = W^T T1 into rows [0, Mp)
                     launch_matvec(s, h->Linv, msq, h->H + 2 * msq, ga.h_stride, Mp, g.bw, 1, Mp, Mp, nbp, Dl);   // b = W^T c
                     HIP_TRY(hipMemcpy2DAsync(h->H + 2 * msq, ga.h_stride * sizeof(double), g.bw, (size_t)Mp * sizeof(double),
@@ -920,7 +921,7 @@ static int enqueue_grad_b(ffvd_handle *h, int S_total) {
         AtbArgs tb{};       // B[i][j] = sum_k L_H^-T[k][i] L^-1[k][j]: the extension rows as they are, no transpose
         tb.mode = ATB_PLAIN; tb.A = h->H + msq; tb.a_stride = hstride; tb.lda = Mp; tb.nA = Mp;
         tb.B = h->Linv; tb.b_stride = msq; tb.ldb = Mp; tb.nB = Mp; tb.b_per_dim = 1; tb.rows = Mp;
-        tb.C = g.T1; tb.c_stride = msq; tb.ldc = Mp; tb.nb = nb; tb.Dl = Dl; tb.krange = 2 | 4;      // k in [128 tj, 128 (ti + 1))
+        tb.C = g.T1; tb.c_stride = msq; tb.ldc = Mp; tb.nb = nb; tb.Dl = Dl; tb.krange = 2 | 4; tb.small_tiles = getenv("FFVD_ATB128") ? 0 : 1;      // k in [tile tj, tile (ti + 1))
         launch_atb(s, tb);
         ag.A = g.T1; ag.B = g.T1;
     } else {

@@ -21,6 +21,7 @@ struct AtbArgs {
     const double *Kf; size_t kf_stride; int ldkf;       // BWD_E: K_fu (T x M) per unit
     const double *Kinv, *Kcopy; size_t k_stride; int ldk;   // GAMMA: per latent dim
     double *part;                                       // GAMMA: [nb][ntiles] partial sums of sum_ij (A^-1)_ij K_ij
+    int small_tiles;                                    // PLAIN: 64 x 64 tiles, four workgroups per CU (M^3-sized batched products)
     int ntile;                                          // filled by launch_atb: tiles per unit
     int a_per_dim;                                      // 1: A is indexed by latent dim (bz % Dl) instead of unit
     // triangular operands (exact: skipped terms are zeros).  bit 0: A lower as stored ([k][i] = 0 for k < i): start at

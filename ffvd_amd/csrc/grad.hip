@@ -211,8 +211,120 @@ __global__ __launch_bounds__(512, 4) void atb_kernel(AtbArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Small-product variant of the plain A^T B (ATB_PLAIN only): 64 x 64 tile per 256-thread workgroup (four wavefronts of
+// 32 x 32), four workgroups per CU.  The M x M x M products of the whitened backward pass have 8-32 k-chunks per
+// workgroup; with 128 x 128 tiles and two workgroups per CU prologue, epilogue and the lockstep of equal workgroups left
+// the matrix pipe 35-50 % busy.  Four times as many, four times smaller workgroups overlap those phases, and the
+// triangular k-ranges are cut at 64 instead of 128.
+// ---------------------------------------------------------------------------------------------
+constexpr int S_LD = 64 + 8;
+__global__ __launch_bounds__(256, 4) void atb64_kernel(AtbArgs a) {
+    __shared__ double As[2][AT][S_LD];
+    __shared__ double Bs[2][AT][S_LD];
+    const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+    const int bz = (loc / a.ntile) * 8 + xcd;
+    if (bz >= a.nb) return;
+    const int tile = loc % a.ntile;
+    const int ntj = (a.nB + 63) / 64;
+    int ti = tile / ntj, tj = tile % ntj;
+    if (a.sym) {
+        ti = 0;
+        while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
+        tj = tile - ti * (ti + 1) / 2;
+    }
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int lr = lane & 15, lk = lane >> 4;
+    const int I0 = ti * 64 + wr * 32, J0 = tj * 64 + wc * 32;
+    const double *Ab = a.A + (size_t)(a.a_per_dim ? (bz % a.Dl) : bz) * a.a_stride;
+    const double *Bb = a.B + (size_t)(a.b_per_dim ? (bz % a.Dl) : bz) * a.b_stride;
+    // staging: thread t moves 16 bytes of rows (t >> 5) and (t >> 5) + 8, columns 2 (t & 31) of each operand
+    const int srow = tid >> 5, scol = 2 * (tid & 31);
+    const int colA = ti * 64 + scol, colB = tj * 64 + scol;
+    const bool okA = colA < a.nA, okB = colB < a.nB;
+    const int colAc = okA ? colA : 0, colBc = okB ? colB : 0;
+    double2 ra[2], rb[2];
+    auto gload = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const size_t t = (size_t)c * AT + srow + 8 * i;
+            ra[i] = *reinterpret_cast<const double2 *>(Ab + t * a.lda + colAc);
+            rb[i] = *reinterpret_cast<const double2 *>(Bb + t * a.ldb + colBc);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            double2 va = ra[i], vb = rb[i];
+            va.x = okA ? va.x : 0.0; va.y = okA ? va.y : 0.0;
+            vb.x = okB ? vb.x : 0.0; vb.y = okB ? vb.y : 0.0;
+            *reinterpret_cast<double2 *>(&As[buf][srow + 8 * i][scol]) = va;
+            *reinterpret_cast<double2 *>(&Bs[buf][srow + 8 * i][scol]) = vb;
+        }
+    };
+    d4 acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
+    int k0 = 0, k1 = a.rows;
+    if ((a.krange & 1) && ti * 64 > k0) k0 = ti * 64;
+    if ((a.krange & 2) && tj * 64 > k0) k0 = tj * 64;
+    if ((a.krange & 4) && (ti + 1) * 64 < k1) k1 = (ti + 1) * 64;
+    if ((a.krange & 8) && (tj + 1) * 64 < k1) k1 = (tj + 1) * 64;
+    const int c0 = k0 / AT, nchunk = k1 / AT;
+    if (c0 < nchunk) {
+        gload(c0);
+        lstore(c0 & 1);
+        __syncthreads();
+        for (int c = c0; c < nchunk; ++c) {
+            const int buf = c & 1;
+            if (c + 1 < nchunk) gload(c + 1);
+#pragma unroll
+            for (int ks = 0; ks < AT / 4; ++ks) {
+                double af[2], bf[2];
+#pragma unroll
+                for (int x = 0; x < 2; ++x) af[x] = As[buf][4 * ks + lk][wr * 32 + 16 * x + lr];
+#pragma unroll
+                for (int y = 0; y < 2; ++y) bf[y] = Bs[buf][4 * ks + lk][wc * 32 + 16 * y + lr];
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                    for (int y = 0; y < 2; ++y) acc[x][y] = mfma_f64(af[x], bf[y], acc[x][y]);
+            }
+            if (c + 1 < nchunk) lstore(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    double *Cb = a.C + (size_t)bz * a.c_stride;
+    const bool mirror = a.sym && ti != tj;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = I0 + 16 * x + lk + 4 * q;
+            if (i >= a.nA) continue;
+#pragma unroll
+            for (int y = 0; y < 2; ++y) {
+                const int j = J0 + 16 * y + lr;
+                if (j >= a.nB) continue;
+                const double v = acc[x][y][q];
+                Cb[(size_t)i * a.ldc + j] = v;
+                if (mirror) Cb[(size_t)j * a.ldc + i] = v;
+            }
+        }
+}
+
 void launch_atb(hipStream_t stream, const AtbArgs &a_in) {
     AtbArgs a = a_in;
+    if (a.mode == ATB_PLAIN && a.small_tiles) {
+        const int n64i = (a.nA + 63) / 64, n64j = (a.nB + 63) / 64;
+        a.ntile = a.sym ? n64i * (n64i + 1) / 2 : n64i * n64j;
+        hipLaunchKernelGGL(atb64_kernel, dim3((unsigned)(((a.nb + 7) / 8) * 8 * a.ntile)), dim3(256), 0, stream, a);
+        return;
+    }
     const int nti = (a.nA + 127) / 128, ntj = (a.nB + 127) / 128;
     a.ntile = nti * ntj;
     if ((a.mode == ATB_GAMMA || a.mode == ATB_PLAIN) && a.sym) a.ntile = nti * (nti + 1) / 2;
