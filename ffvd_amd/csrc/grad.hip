@@ -319,7 +319,9 @@ __global__ __launch_bounds__(256, 4) void atb64_kernel(AtbArgs a) {
 
 void launch_atb(hipStream_t stream, const AtbArgs &a_in) {
     AtbArgs a = a_in;
-    if (a.mode == ATB_PLAIN && a.small_tiles) {
+    // few units (the per-dim products of the K_uu side): 128 x 128 tiles would leave most CUs without a workgroup
+    const bool few = (size_t)a.nb * ((a.nA + 127) / 128) * ((a.nB + 127) / 128) <= 512;
+    if (a.mode == ATB_PLAIN && (a.small_tiles || few)) {
         const int n64i = (a.nA + 63) / 64, n64j = (a.nB + 63) / 64;
         a.ntile = a.sym ? n64i * (n64i + 1) / 2 : n64i * n64j;
         hipLaunchKernelGGL(atb64_kernel, dim3((unsigned)(((a.nb + 7) / 8) * 8 * a.ntile)), dim3(256), 0, stream, a);
