@@ -221,7 +221,7 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
     if (c.grad) {
         ffvd_handle::GradWs &g = h->gw;
         const size_t nbt = h->nbatch, msq = Mp * Mp, nblk = Tp / 64, nblk2 = Mp / 64, S = c.S_local, J = c.Ydim;
-        g.ngam = atb_ntiles_sym(h->Mp);
+        g.ngam = atb_ntiles_sym64(h->Mp);        // the Gamma launch uses the 64 x 64-tile kernel
         g.sp_stride = c.D * c.Ydim + 2 * c.Ydim + (int)Dl;
         HIP_TRY(dev_alloc(h, &g.Acopy, nbt * msq));      HIP_TRY(dev_alloc(h, &g.u, nbt * Mp));
         HIP_TRY(dev_alloc(h, &g.LAinv, nbt * msq));      HIP_TRY(dev_alloc(h, &g.Gamma, nbt * msq));
@@ -914,7 +914,7 @@ static int enqueue_grad_b(ffvd_handle *h, int S_total) {
     ag.b_stride = msq; ag.ldb = Mp; ag.nB = Mp; ag.b_per_dim = 0; ag.rows = Mp;
     ag.C = g.Gamma; ag.c_stride = msq; ag.ldc = Mp; ag.nb = nb; ag.b0 = 0; ag.Dl = Dl; ag.d_begin = c.d_begin;
     ag.log_Q = p.log_Q; ag.u = g.u; ag.u_stride = Mp; ag.Kinv = h->Kinv; ag.Kcopy = h->Kcopy; ag.k_stride = msq; ag.ldk = Mp;
-    ag.part = g.gam_part; ag.k_lower = 1; ag.sym = 1;   // the inverse factor is lower triangular, its Gram symmetric
+    ag.part = g.gam_part; ag.k_lower = 1; ag.sym = 1; ag.small_tiles = 1;   // inverse factor lower triangular, its Gram symmetric
     if (wh) {
         launch_matvec(s, h->H + msq, hstride, h->H + 2 * msq, hstride, Mp, g.wv, 1, Mp, Mp, nb);          // w = L_H^-T y
         launch_matvec(s, h->Kuu + msq, kstride, g.wv, Mp, Mp, g.u, 1, Mp, Mp, nb, Dl);                     // u = W w

@@ -36,6 +36,7 @@ struct AtbArgs {
 void launch_atb(hipStream_t stream, const AtbArgs &a);
 int atb_ntiles(int nA, int nB);
 int atb_ntiles_sym(int n);      // tiles of a symmetric product launched with AtbArgs::sym
+int atb_ntiles_sym64(int n);    // ... with AtbArgs::small_tiles (64 x 64 tiles)
 
 void launch_uku(hipStream_t stream, const double *u, size_t u_stride, const double *K, size_t k_stride, int Mp, int Dl,
                 int nb, double *out);

@@ -219,9 +219,11 @@ __global__ __launch_bounds__(512, 4) void atb_kernel(AtbArgs a) {
 // triangular k-ranges are cut at 64 instead of 128.
 // ---------------------------------------------------------------------------------------------
 constexpr int S_LD = 64 + 8;
+template <int MODE>
 __global__ __launch_bounds__(256, 4) void atb64_kernel(AtbArgs a) {
     __shared__ double As[2][AT][S_LD];
     __shared__ double Bs[2][AT][S_LD];
+    __shared__ double red64[4];
     const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
     const int bz = (loc / a.ntile) * 8 + xcd;
     if (bz >= a.nb) return;
@@ -274,6 +276,7 @@ __global__ __launch_bounds__(256, 4) void atb64_kernel(AtbArgs a) {
     if ((a.krange & 2) && tj * 64 > k0) k0 = tj * 64;
     if ((a.krange & 4) && (ti + 1) * 64 < k1) k1 = (ti + 1) * 64;
     if ((a.krange & 8) && (tj + 1) * 64 < k1) k1 = (tj + 1) * 64;
+    if (a.k_lower && (ti > tj ? ti : tj) * 64 > k0) k0 = (ti > tj ? ti : tj) * 64;
     const int c0 = k0 / AT, nchunk = k1 / AT;
     if (c0 < nchunk) {
         gload(c0);
@@ -300,6 +303,15 @@ __global__ __launch_bounds__(256, 4) void atb64_kernel(AtbArgs a) {
     }
     double *Cb = a.C + (size_t)bz * a.c_stride;
     const bool mirror = a.sym && ti != tj;
+    double alpha = 1.0, part = 0.0;
+    const double *ub = nullptr, *Kinv = nullptr, *Kc = nullptr;
+    if (MODE == ATB_GAMMA) {
+        const int dl = (a.b0 + bz) % a.Dl;
+        alpha = 1.0 / exp(a.log_Q[a.d_begin + dl]);
+        ub = a.u + (size_t)bz * a.u_stride;
+        Kinv = a.Kinv + (size_t)dl * a.k_stride;
+        Kc = a.Kcopy + (size_t)dl * a.k_stride;
+    }
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -310,11 +322,23 @@ __global__ __launch_bounds__(256, 4) void atb64_kernel(AtbArgs a) {
             for (int y = 0; y < 2; ++y) {
                 const int j = J0 + 16 * y + lr;
                 if (j >= a.nB) continue;
-                const double v = acc[x][y][q];
+                const double g = acc[x][y][q];
+                double v = g;
+                if (MODE == ATB_GAMMA) {
+                    v = 0.5 * alpha * (Kinv[(size_t)i * a.ldk + j] - g - ub[i] * ub[j]);
+                    part += (mirror ? 2.0 : 1.0) * (g * Kc[(size_t)i * a.ldk + j]);
+                }
                 Cb[(size_t)i * a.ldc + j] = v;
                 if (mirror) Cb[(size_t)j * a.ldc + i] = v;
             }
         }
+    if (MODE == ATB_GAMMA) {
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) part += __shfl_xor(part, m);
+        if (lane == 0) red64[wave] = part;
+        __syncthreads();
+        if (tid == 0) a.part[(size_t)bz * a.ntile + tile] = (red64[0] + red64[1]) + (red64[2] + red64[3]);
+    }
 }
 
 void launch_atb(hipStream_t stream, const AtbArgs &a_in) {
@@ -324,7 +348,13 @@ void launch_atb(hipStream_t stream, const AtbArgs &a_in) {
     if (a.mode == ATB_PLAIN && (a.small_tiles || few)) {
         const int n64i = (a.nA + 63) / 64, n64j = (a.nB + 63) / 64;
         a.ntile = a.sym ? n64i * (n64i + 1) / 2 : n64i * n64j;
-        hipLaunchKernelGGL(atb64_kernel, dim3((unsigned)(((a.nb + 7) / 8) * 8 * a.ntile)), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(atb64_kernel<ATB_PLAIN>, dim3((unsigned)(((a.nb + 7) / 8) * 8 * a.ntile)), dim3(256), 0, stream, a);
+        return;
+    }
+    if (a.mode == ATB_GAMMA && a.small_tiles && a.sym) {
+        const int n64 = (a.nA + 63) / 64;
+        a.ntile = n64 * (n64 + 1) / 2;
+        hipLaunchKernelGGL(atb64_kernel<ATB_GAMMA>, dim3((unsigned)(((a.nb + 7) / 8) * 8 * a.ntile)), dim3(256), 0, stream, a);
         return;
     }
     const int nti = (a.nA + 127) / 128, ntj = (a.nB + 127) / 128;
@@ -338,6 +368,7 @@ void launch_atb(hipStream_t stream, const AtbArgs &a_in) {
 }
 int atb_ntiles(int nA, int nB) { return ((nA + 127) / 128) * ((nB + 127) / 128); }
 int atb_ntiles_sym(int n) { const int nt = (n + 127) / 128; return nt * (nt + 1) / 2; }
+int atb_ntiles_sym64(int n) { const int nt = (n + 63) / 64; return nt * (nt + 1) / 2; }
 
 // Shared main loop of the kernels whose left operand is stored row-major over the OUTPUT rows (K_fu itself):
 // acc (128 x 128 tile, 8 wavefronts of 64 x 32) = sum_{k < kend} Arows[i][k] * B[k][j], the 128 x 16 chunk of A
