@@ -15,6 +15,7 @@ KERNEL_KIND = {"SquaredExponential": 0, "LinearK": 1}
 BRANCH_A, BRANCH_B = 0, 1
 PRIOR_TYPE = {"uniform": 0, "normal": 1}
 ROUTE = {"reference": 0, "gram": 1}
+DTYPE = {"f64": 0, "f32c": 1}
 PARAMS_ON_DEVICE = 1
 TERM_NAMES = ("nll_part_prior", "nll_log_likelihood", "x_t_prior_Q", "nll_reg_trace_inverse_Q_B",
               "later_term1", "later_term2", "nll")
@@ -82,6 +83,14 @@ _SIGNATURES = {
                                   C.c_int, C.c_int, _dp, _dp, _dp, _dp]),
     "ffvd_op_pg_sweep": (C.c_int, [C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_int, _dp, C.c_int,
                                    _dp, C.c_int, _dp, _dp, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp, C.c_void_p]),
+    "ffvd_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "ffvd_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "ffvd_comm_destroy": (C.c_int, [C.c_void_p]),
+    "ffvd_comm_get": (C.c_void_p, [C.c_void_p]),
+    "ffvd_elbo_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, _dp, _dp]),
+    "ffvd_elbo_allreduce_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ffvd_allreduce_sum_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    "ffvd_allreduce_sum": (C.c_int, [C.c_void_p, C.c_void_p, _dp, C.c_int64]),
     "ffvd_op_conditional": (C.c_int, [C.c_int, _dp, C.c_int, _dp, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp,
                                       C.c_double, _dp, _dp]),
 }

@@ -1,17 +1,26 @@
-"""Build libffvd_hip.so (gfx950) in-tree with hipcc.  `python -m ffvd_amd.build [--force]`."""
+"""Build libffvd_hip.so (gfx950) in-tree with hipcc.  `python -m ffvd_amd.build [--force]`.
+
+The library is rebuilt whenever the SHA-256 of its sources, headers and flags differs from the one recorded next to
+it (`libffvd_hip.so.hash`) -- not by mtime, so a fresh checkout, or a snapshot whose files were re-stamped, really
+compiles.  Each source is compiled to an object in its own hipcc process (they run side by side), then linked."""
 from __future__ import annotations
 
+import hashlib
 import os
 import shutil
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libffvd_hip.so")
-SOURCES = ["kernels.hip", "grad.hip", "optim.hip", "abi.hip"]
-DEPS = SOURCES + ["kernels.h", "grad.h", "optim.h", os.path.join("..", "..", "include", "ffvd_abi.h")]
-FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value"]
+HASH = LIB + ".hash"
+OBJDIR = os.path.join(HERE, "build")
+SOURCES = ["kernels.hip", "kernels_f32.hip", "grad.hip", "optim.hip", "abi.hip"]
+HEADERS = ["kernels.h", "kernels_f32.h", "grad.h", "optim.h", os.path.join("..", "..", "include", "ffvd_abi.h")]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+LINK = ["-shared", "-fPIC", "--offload-arch=gfx950", "-ldl"]
 
 
 def hipcc_path():
@@ -21,24 +30,53 @@ def hipcc_path():
     raise RuntimeError("hipcc not found: the ROCm toolchain is required to build libffvd_hip.so")
 
 
+def source_hash():
+    h = hashlib.sha256()
+    h.update(" ".join(FLAGS + LINK).encode())
+    for name in SOURCES + HEADERS:
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(name.encode())
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def needs_build():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(HASH):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+    with open(HASH) as f:
+        return f.read().strip() != source_hash()
 
 
 def build(force=False, verbose=False):
     """Compile every HIP source for gfx950 into ffvd_amd/libffvd_hip.so; returns the path."""
     if not force and not needs_build():
+        if verbose:
+            print(f"{LIB}: up to date (source hash {source_hash()[:16]})", flush=True)
         return LIB
-    cmd = [hipcc_path()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + ".tmp"]
+    cc = hipcc_path()
+    os.makedirs(OBJDIR, exist_ok=True)
+
+    def compile_one(src):
+        obj = os.path.join(OBJDIR, src + ".o")
+        cmd = [cc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        proc = subprocess.run(cmd, capture_output=True, text=True)
+        if proc.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n" + proc.stdout + proc.stderr)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as pool:
+        objs = list(pool.map(compile_one, SOURCES))
+    cmd = [cc] + objs + LINK + ["-o", LIB + ".tmp"]
     if verbose:
         print(" ".join(cmd), flush=True)
     proc = subprocess.run(cmd, capture_output=True, text=True)
     if proc.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + proc.stdout + proc.stderr)
+        raise RuntimeError("hipcc link failed:\n" + proc.stdout + proc.stderr)
     os.replace(LIB + ".tmp", LIB)
+    with open(HASH, "w") as f:
+        f.write(source_hash() + "\n")
     return LIB
 
 

@@ -2,9 +2,11 @@
 // launch sequence of the ELBO, and operator-level entry points used by the Python mirror of the reference API.
 #include "../../include/ffvd_abi.h"
 #include "kernels.h"
+#include "kernels_f32.h"
 #include "grad.h"
 #include "optim.h"
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -39,17 +41,32 @@ struct ffvd_handle {
     std::string err;
     std::vector<void *> allocs;
     int64_t ws_bytes = 0;
+    // diagnostic switches, read from the environment ONCE when the handle is created
+    struct Switches {
+        bool fused_project = false, grad_explicit = false, no_defer_trace = false, no_late_join = false;
+        bool no_main_first = false, no_kfu_first = false, atb128 = false, grad_serial = false;
+    } sw;
     // resident parameters / data (handle-owned copies)
     double *X = nullptr, *Z = nullptr, *U = nullptr, *logvar = nullptr, *loglen = nullptr, *logQ = nullptr;
     double *CC = nullptr, *DD = nullptr, *logR = nullptr, *Y = nullptr, *ctrl = nullptr;
     ffvd_params cur{};          // pointers the kernels read (resident copies or caller's device pointers)
     bool have_params = false, have_data = false;
+    void *comm = nullptr;       // RCCL communicator created by ffvd_comm_init (owned by the handle), else null
+    int comm_world = 1, comm_rank = 0;
+    double *stage = nullptr;    // staging buffer of ffvd_allreduce_sum
+    int64_t stage_count = 0;
+    bool info_pending = false;  // an ffvd_elbo_async was enqueued whose Cholesky info flags nobody has looked at yet
     // workspace
     double *variance = nullptr, *len = nullptr, *Zs = nullptr, *zz = nullptr;
     double *Kuu = nullptr, *F = nullptr, *H = nullptr, *rowsq = nullptr, *fmean = nullptr;
     double *ucolA = nullptr;        // explicit-U branch: U columns of the local dims, zero padded to Mp
     double *Kf2 = nullptr;          // reference route, branch B: K_fu (input of the projection GEMM); F keeps K_fu L^-T
     int ngr = 0;                    // row-sum partials per unit in that path (128-column tiles)
+    // fp32-contraction path (cfg.dtype == FFVD_F32C): K_fu, F = K_fu L^-T, L^-1 as fp32 GEMM operands; per-tile and
+    // per-unit sums of F^2 (fp64)
+    float *Kf32 = nullptr, *F32 = nullptr, *Linv32 = nullptr;
+    double *sqpart = nullptr, *sqsum = nullptr;
+    int nsq = 0, gram_flush = 0;
     double *Kcopy = nullptr, *Linv = nullptr, *Kinv = nullptr, *trpart = nullptr, *kterms = nullptr;   // GRAM route
     int ntiles = 0;
     double *chain_partial = nullptr;
@@ -125,6 +142,7 @@ extern "C" int ffvd_destroy(ffvd_handle *h) {
     if (!h) return FFVD_OK;
     hipSetDevice(h->cfg.device_id);
     if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->comm) ffvd_comm_destroy(h);
     for (void *p : h->allocs) hipFree(p);
     for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
     if (h->h_res) hipHostFree(h->h_res);
@@ -141,6 +159,14 @@ extern "C" int ffvd_destroy(ffvd_handle *h) {
 
 static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
     const ffvd_config &c = h->cfg;
+    {
+        auto on = [](const char *name) { const char *e = getenv(name); return e && *e && strcmp(e, "0") != 0; };
+        ffvd_handle::Switches &w = h->sw;
+        w.fused_project = on("FFVD_FUSED_PROJECT");   w.grad_explicit = on("FFVD_GRAD_EXPLICIT");
+        w.no_defer_trace = on("FFVD_NO_DEFER_TRACE"); w.no_late_join = on("FFVD_NO_LATE_JOIN");
+        w.no_main_first = on("FFVD_NO_MAIN_FIRST");   w.no_kfu_first = on("FFVD_NO_KFU_FIRST");
+        w.atb128 = on("FFVD_ATB128");                 w.grad_serial = on("FFVD_GRAD_SERIAL");
+    }
     h->P = c.D + c.C;
     h->Dl = c.d_count > 0 ? c.d_count : c.D;
     h->Mp = round_up(c.M, NB);
@@ -152,7 +178,7 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
     // the Gram grid need >= 1 workgroup per CU); F costs Dl*Tp*Mp*8 bytes per chain, budget 48 GiB of the 288 GB.
     if (c.chains_per_pass > 0) h->cpp = c.chains_per_pass;
     else {
-        const size_t per_chain = Dl * Tp * Mp * sizeof(double);
+        const size_t per_chain = Dl * Tp * Mp * (c.dtype == FFVD_F32C ? sizeof(float) : sizeof(double));
         size_t n = ((size_t)48 << 30) / (per_chain ? per_chain : 1);
         if (n < 1) n = 1;
         if (n > (size_t)c.S_local) n = c.S_local;
@@ -193,14 +219,26 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
     //  1.10 vs 1.21 ms on config 5's 16 units -- or when the backward pass needs K_fu anyway)
     const bool big_a = (size_t)h->nbatch * Tp * Mp >= (size_t)64 * 4096 * 512 || c.grad;
     const bool proj_gemm = ((c.branch == FFVD_BRANCH_A && big_a) || (c.branch == FFVD_BRANCH_B && c.route == FFVD_ROUTE_REFERENCE)) &&
-                           !getenv("FFVD_FUSED_PROJECT");
-    h->ngr = proj_gemm ? (int)((Mp + 127) / 128) : 0;
+                           !h->sw.fused_project;
+    h->ngr = (proj_gemm && c.dtype != FFVD_F32C) ? (int)((Mp + 127) / 128) : 0;
     HIP_TRY(dev_alloc(h, &h->rowsq, (size_t)h->nbatch * (h->ngr > h->ng ? h->ngr : h->ng) * Tp));
     HIP_TRY(dev_alloc(h, &h->fmean, (size_t)h->nbatch * (h->ngr > h->ng ? h->ngr : h->ng) * Tp));
     if (c.branch == FFVD_BRANCH_B) {
         const size_t pass_b = (size_t)h->cpp * Dl;
-        HIP_TRY(dev_alloc(h, &h->F, pass_b * Tp * Mp));
-        if (h->ngr) HIP_TRY(dev_alloc(h, &h->Kf2, pass_b * Tp * Mp));
+        if (c.dtype == FFVD_F32C) {
+            HIP_TRY(dev_alloc(h, &h->Kf32, pass_b * Tp * Mp));
+            HIP_TRY(dev_alloc(h, &h->F32, pass_b * Tp * Mp));
+            HIP_TRY(dev_alloc(h, &h->Linv32, Dl * Mp * Mp));
+            h->nsq = proj_f32_ntiles((int)Tp, (int)Mp);
+            HIP_TRY(dev_alloc(h, &h->sqpart, (size_t)h->nbatch * h->nsq));
+            HIP_TRY(dev_alloc(h, &h->sqsum, (size_t)h->nbatch));
+            // fp32 summation chains of the Gram product are cut every 4096 rows (128 t-tiles); FFVD_F32C_FLUSH overrides
+            h->gram_flush = 128;
+            if (const char *e = getenv("FFVD_F32C_FLUSH")) h->gram_flush = atoi(e);
+        } else {
+            HIP_TRY(dev_alloc(h, &h->F, pass_b * Tp * Mp));
+            if (h->ngr) HIP_TRY(dev_alloc(h, &h->Kf2, pass_b * Tp * Mp));
+        }
         const size_t hrows = c.grad ? 2 * Mp + NB : Mp + NB;     // grad: Mp identity rows (-> L_A^-T) before the b row
         HIP_TRY(dev_alloc(h, &h->H, pass_b * hrows * Mp));
         HIP_TRY(hipMemsetAsync(h->H, 0, pass_b * hrows * Mp * sizeof(double), h->stream));
@@ -237,7 +275,7 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
         HIP_TRY(dev_alloc(h, &g.Asum, Dl * msq));  HIP_TRY(dev_alloc(h, &g.GamSum, Dl * msq)); HIP_TRY(dev_alloc(h, &g.Gs, Dl * msq));
         HIP_TRY(dev_alloc(h, &g.gsum, Dl * msq));  HIP_TRY(dev_alloc(h, &g.P1, Dl * msq));     HIP_TRY(dev_alloc(h, &g.KGK, Dl * msq));
         HIP_TRY(dev_alloc(h, &g.Epsi, Dl * msq));
-        g.whitened = c.branch == FFVD_BRANCH_B && !getenv("FFVD_GRAD_EXPLICIT");
+        g.whitened = c.branch == FFVD_BRANCH_B && !h->sw.grad_explicit;
         if (g.whitened) {
             HIP_TRY(dev_alloc(h, &g.T1, nbt * msq));
             HIP_TRY(dev_alloc(h, &g.wv, nbt * Mp));    HIP_TRY(dev_alloc(h, &g.bw, nbt * Mp));
@@ -278,11 +316,11 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
         h->h_chain = h->h_res + 8;
         h->h_info = reinterpret_cast<int32_t *>(h->h_res + 8 + nS);
     }
-    if (c.branch == FFVD_BRANCH_B) {
+    if (c.branch == FFVD_BRANCH_B && c.dtype != FFVD_F32C) {
         const int upass = h->cpp * (int)Dl;
         h->gsplit = gram_ksplit((int)Mp, upass, (int)Tp);
         if (h->gsplit > 1) HIP_TRY(dev_alloc(h, &h->gpart, gram_part_doubles((int)Mp, upass, h->gsplit)));
-        else if (c.route == FFVD_ROUTE_GRAM && (size_t)upass * Tp * Mp >= (size_t)64 * 4096 * 512 && !getenv("FFVD_NO_DEFER_TRACE"))
+        else if (c.route == FFVD_ROUTE_GRAM && (size_t)upass * Tp * Mp >= (size_t)64 * 4096 * 512 && !h->sw.no_defer_trace)
             HIP_TRY(dev_alloc(h, &h->graw, (size_t)upass * (Mp + 1) * Mp));
     }
     HIP_TRY(dev_alloc(h, &h->dinvK, (size_t)Dl * DINV_STRIDE));
@@ -307,7 +345,10 @@ extern "C" int ffvd_create(const ffvd_config *cfg, ffvd_handle **out) {
         snprintf(msg, sizeof msg, "ffvd_create: GP input dim P = D + C = %d exceeds %d", cfg->D + cfg->C, MAXP);
         return set_error(nullptr, FFVD_EINVAL, msg);
     }
-    if (cfg->dtype != FFVD_F64) return set_error(nullptr, FFVD_EINVAL, "ffvd_create: only FFVD_F64 is implemented");
+    if (cfg->dtype != FFVD_F64 && cfg->dtype != FFVD_F32C) return set_error(nullptr, FFVD_EINVAL, "ffvd_create: unknown dtype");
+    if (cfg->dtype == FFVD_F32C && (cfg->branch != FFVD_BRANCH_B || cfg->route != FFVD_ROUTE_REFERENCE || cfg->grad))
+        return set_error(nullptr, FFVD_EINVAL,
+                         "ffvd_create: FFVD_F32C is the collapsed-U branch on FFVD_ROUTE_REFERENCE without gradient");
     if (cfg->kernel_kind != FFVD_KERNEL_SE && cfg->kernel_kind != FFVD_KERNEL_LINEAR)
         return set_error(nullptr, FFVD_EINVAL, "ffvd_create: unknown kernel_kind");
     if (cfg->branch != FFVD_BRANCH_A && cfg->branch != FFVD_BRANCH_B)
@@ -345,10 +386,18 @@ extern "C" int ffvd_create(const ffvd_config *cfg, ffvd_handle **out) {
     return FFVD_OK;
 }
 
+static int check_info(ffvd_handle *h);
+
 extern "C" int ffvd_sync(ffvd_handle *h) {
     if (!h) return set_error(nullptr, FFVD_EINVAL, "ffvd_sync: null handle");
     HIP_TRY(hipSetDevice(h->cfg.device_id));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->info_pending) {      // report what the _async forms could not: a failed factorisation (include/ffvd_abi.h)
+        h->info_pending = false;
+        HIP_TRY(hipMemcpyAsync(h->h_info, h->info, (size_t)(h->Dl + h->nbatch) * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        return check_info(h);
+    }
     return FFVD_OK;
 }
 
@@ -453,7 +502,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
     const int first_units = ((c.S_local < h->cpp) ? c.S_local : h->cpp) * Dl;
     // split-K first pass: its tile kernel writes raw partials and needs neither K_uu nor K^-1, so the chain may run
     // beside the K_fu build AND the tile pass and only has to be back for the combine pass
-    const bool late_join = gram_route && h->gpart && first_units == h->cpp * Dl && !getenv("FFVD_NO_LATE_JOIN");
+    const bool late_join = gram_route && h->gpart && first_units == h->cpp * Dl && !h->sw.no_late_join;
     const size_t kstride = (size_t)2 * Mp * Mp;
     const size_t msq = (size_t)Mp * Mp;
     const bool grad_a = c.grad && c.branch == FFVD_BRANCH_A;
@@ -486,10 +535,10 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
     // K_fu build + tile pass at 4 chains), and the only thing the main stream needs from its tail is K^-1 for the trace
     // partials.  So the combine pass waits for the K_uu copy alone, Cholesky(A) starts at once, and the trace partials
     // are computed from the same raw partial tiles on the side stream once K^-1 is there.
-    const bool defer_trace = late_join && c.S_local <= h->cpp && !getenv("FFVD_NO_DEFER_TRACE");
+    const bool defer_trace = late_join && c.S_local <= h->cpp && !h->sw.no_defer_trace;
     // ... and with the main stream now the critical one, its K_fu build and tile pass are enqueued BEFORE the ~25
     // launches of the chain (the caller reads the result back every iteration, so each iteration starts on idle streams)
-    const bool main_first = defer_trace && !getenv("FFVD_NO_MAIN_FIRST");
+    const bool main_first = defer_trace && !h->sw.no_main_first;
     // Unsplit first pass beside the chain: same idea with the raw tiles written by the Gram kernel itself
     const bool defer_full = gram_route && !late_join && h->graw;
     const int ns_first = (h->cpp <= c.S_local) ? h->cpp : c.S_local;
@@ -499,7 +548,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
         sk = h->aux;
         HIP_TRY(hipEventRecord(h->ev_fork, s));
         HIP_TRY(hipStreamWaitEvent(sk, h->ev_fork, 0));
-        kfu_first = main_first || (defer_full && !getenv("FFVD_NO_KFU_FIRST"));
+        kfu_first = main_first || (defer_full && !h->sw.no_kfu_first);
         if (kfu_first) {
             if (st) st->mark(0);
             launch_kfu_build(s, project_args(0, ns_first));
@@ -543,7 +592,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
     ra.T = c.T; ra.Tp = Tp; ra.D = c.D; ra.C = c.C; ra.Ydim = c.Ydim; ra.Dl = Dl; ra.d_begin = c.d_begin;
     ra.S = c.S_local; ra.ng = h->ng; ra.shared_terms = c.shared_terms;
     ra.xk = p.X; ra.xk_chain_stride = (size_t)(c.T + 1) * c.D; ra.xk_ld = c.D; ra.xk_cols = c.D;
-    ra.rowsq = gram_route ? nullptr : h->rowsq; ra.fmean = h->fmean; ra.chain_terms = h->chain_terms;
+    ra.rowsq = (gram_route || c.dtype == FFVD_F32C) ? nullptr : h->rowsq; ra.fmean = h->fmean; ra.chain_terms = h->chain_terms;
     if (h->ngr) ra.ng = h->ngr;
     // the per-chain likelihood / transition reductions depend on the inputs only (Gram route: no row sums of F), so
     // they ride on the side stream behind the K_uu chain and are back long before finalize needs them
@@ -559,6 +608,13 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
         if (gram_route) {
             if (!(kfu_first && s0 == 0)) launch_kfu_build(s, pa);
             if (s0 == 0 && sk != s && !late_join) HIP_TRY(hipStreamWaitEvent(s, defer_full ? h->ev_kuu : h->ev_join, 0));
+        } else if (c.dtype == FFVD_F32C) {
+            if (s0 == 0) launch_linv_f32(s, h->Kuu + msq, kstride, h->Linv32, Mp, Dl);     // L^-1 as the fp32 B operand
+            launch_kfu_build_f32(s, pa, h->Kf32);                     // K(X_combine, Z)           (:240)
+            ProjF32Args pg{};
+            pg.Kf = h->Kf32; pg.kf_stride = (size_t)Tp * Mp; pg.LinvT = h->Linv32; pg.F = h->F32; pg.f_stride = (size_t)Tp * Mp;
+            pg.sqpart = h->sqpart; pg.Tp = Tp; pg.Mp = Mp; pg.Dl = Dl; pg.b0 = s0 * Dl; pg.nb = ns * Dl;
+            launch_proj_gemm_f32(s, pg);                              // tilde_F = Knm Lm^-T, sum F^2  (:242,:255)
         } else if (h->ngr && c.branch == FFVD_BRANCH_B) {
             pa.F = h->Kf2;
             launch_kfu_build(s, pa);                                  // K(X_combine, Z)           (:240)
@@ -608,6 +664,13 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
                 launch_gram(s, ga);
                 HIP_TRY(hipEventRecord(h->ev_tiles, s));
                 trace_pending = true;
+            } else if (c.dtype == FFVD_F32C) {
+                GramF32Args gf{};
+                gf.F = h->F32; gf.f_stride = (size_t)Tp * Mp; gf.rows = Tp; gf.with_row = 1; gf.brow = Mp;
+                gf.X = p.X; gf.log_Q = p.log_Q; gf.T = c.T; gf.D = c.D; gf.Mp = Mp; gf.Dl = Dl; gf.d_begin = c.d_begin;
+                gf.b0 = s0 * Dl; gf.nb = ns * Dl; gf.yn_over_batch = 1.0; gf.H = h->H; gf.h_stride = ga.h_stride;
+                gf.flush = h->gram_flush;
+                launch_gram_f32(s, gf);                               // H = F^T F / Q + I, b = delta^T F / Q  (:246-248)
             } else launch_gram(s, ga);
             if (st) st->mark(2);
             if (c.grad) {       // keep A = K_uu + K_uf K_fu / Q: the factorisation overwrites it in place
@@ -620,7 +683,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
                     // variables, where cond(H) is about 1e4 instead of the 1e7 of A
                     ffvd_handle::GradWs &g = h->gw;
                     const int nbp = ns * Dl;
-                    const int small = getenv("FFVD_ATB128") ? 0 : 1;
+                    const int small = h->sw.atb128 ? 0 : 1;
                     if (sk != s) HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));       // W and L^-1 come from the K_uu chain
                     if (!acopy_done) launch_symmetrize(s, g.Acopy, Mp, nbp);           // the Gram kernel's own copy is symmetric already
                     AtbArgs t1{};
@@ -662,6 +725,10 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
     fa.chain_terms = h->chain_terms; fa.hterms = h->hterms; fa.chain_nll = h->chain_nll;
     fa.route = gram_route ? 1 : 0; fa.kterms = h->kterms; fa.trpart = h->trpart; fa.ntiles = h->ntiles;
     fa.whitened = (c.grad && h->gw.whitened && gram_route) ? 1 : 0;
+    if (c.dtype == FFVD_F32C) {           // sum_t |F_t|^2 per unit from the projection's fp64 tile sums
+        launch_sum_partials(s, h->sqpart, h->nsq, h->nbatch, h->sqsum);
+        fa.trpart = h->sqsum; fa.ntiles = 1; fa.fsq_from_trpart = 1;
+    }
     fa.out_terms = out_dev ? out_dev : h->out_terms;
     launch_finalize(s, fa);
     if (st) st->mark(4);
@@ -720,6 +787,7 @@ extern "C" int ffvd_elbo_async(ffvd_handle *h, double *out_terms_dev) {
     HIP_TRY(hipSetDevice(h->cfg.device_id));
     int rc;
     if ((rc = ready(h, "ffvd_elbo_async"))) return rc;
+    h->info_pending = true;
     return enqueue_elbo(h, out_terms_dev, nullptr);
 }
 
@@ -736,18 +804,19 @@ extern "C" int ffvd_time_elbo(ffvd_handle *h, int iters, float *out_ms) {
     HIP_TRY(hipSetDevice(h->cfg.device_id));
     int rc;
     if ((rc = ready(h, "ffvd_time_elbo"))) return rc;
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(hipEventRecord(e0, h->stream));
+    struct EventPair {          // destroyed on every exit path
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~EventPair() { if (e0) hipEventDestroy(e0); if (e1) hipEventDestroy(e1); }
+    } ev;
+    HIP_TRY(hipEventCreate(&ev.e0));
+    HIP_TRY(hipEventCreate(&ev.e1));
+    HIP_TRY(hipEventRecord(ev.e0, h->stream));
     for (int i = 0; i < iters; ++i)
         if ((rc = enqueue_elbo(h, nullptr, nullptr))) return rc;
-    HIP_TRY(hipEventRecord(e1, h->stream));
+    HIP_TRY(hipEventRecord(ev.e1, h->stream));
     HIP_TRY(hipMemcpyAsync(h->h_info, h->info, (size_t)(h->Dl + h->nbatch) * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    HIP_TRY(hipEventElapsedTime(out_ms, e0, e1));
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
+    HIP_TRY(hipEventElapsedTime(out_ms, ev.e0, ev.e1));
     return check_info(h);
 }
 
@@ -921,7 +990,7 @@ static int enqueue_grad_b(ffvd_handle *h, int S_total) {
         AtbArgs tb{};       // B[i][j] = sum_k L_H^-T[k][i] L^-1[k][j]: the extension rows as they are, no transpose
         tb.mode = ATB_PLAIN; tb.A = h->H + msq; tb.a_stride = hstride; tb.lda = Mp; tb.nA = Mp;
         tb.B = h->Linv; tb.b_stride = msq; tb.ldb = Mp; tb.nB = Mp; tb.b_per_dim = 1; tb.rows = Mp;
-        tb.C = g.T1; tb.c_stride = msq; tb.ldc = Mp; tb.nb = nb; tb.Dl = Dl; tb.krange = 2 | 4; tb.small_tiles = getenv("FFVD_ATB128") ? 0 : 1;      // k in [tile tj, tile (ti + 1))
+        tb.C = g.T1; tb.c_stride = msq; tb.ldc = Mp; tb.nb = nb; tb.Dl = Dl; tb.krange = 2 | 4; tb.small_tiles = h->sw.atb128 ? 0 : 1;      // k in [tile tj, tile (ti + 1))
         launch_atb(s, tb);
         ag.A = g.T1; ag.B = g.T1;
     } else {
@@ -933,7 +1002,7 @@ static int enqueue_grad_b(ffvd_handle *h, int S_total) {
     // K_uu side: Psi_d = sum_s Gamma_s / alpha_d - 1/2 K^-1 (sum_s A_s - S K) K^-1.  It needs Gamma and the saved
     // A-matrices only, so its dozen small launches go to the side stream and run beside the E product
     // (enqueued after it: the main stream must not wait for their launch overhead).
-    hipStream_t sk = getenv("FFVD_GRAD_SERIAL") ? s : h->aux;
+    hipStream_t sk = h->sw.grad_serial ? s : h->aux;
     if (sk != s) {
         HIP_TRY(hipEventRecord(h->ev_fork, s));
         HIP_TRY(hipStreamWaitEvent(sk, h->ev_fork, 0));
@@ -1876,5 +1945,160 @@ extern "C" int ffvd_op_pg_sweep(int kind, const double *Lm_inverse_seq, const do
     HIP_TRY(hipMemcpyAsync(particles + (size_t)R * D, dparts, (size_t)steps * R * D * sizeof(double), hipMemcpyDeviceToHost, sc.stream));
     HIP_TRY(hipMemcpyAsync(idx, didx, (size_t)steps * R * sizeof(int32_t), hipMemcpyDeviceToHost, sc.stream));
     HIP_TRY(hipStreamSynchronize(sc.stream));
+    return FFVD_OK;
+}
+
+// ---- native RCCL collectives (SURVEY 8b `ffvd_elbo_allreduce(h, rccl_comm)`, 8e) ---------------------------------
+// The only exchange step of the path is an all-reduce(sum) of the 8 partial sums over xGMI.  librccl is bound at run time
+// (dlopen): the library that is already mapped in the process wins (a host that also runs PyTorch has torch's bundled
+// RCCL mapped, and two RCCL copies in one process must be avoided), then $FFVD_RCCL_LIB, then the system library.  A
+// build box or a host without RCCL therefore still loads libffvd_hip.so; the collective entry points then fail loudly.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+namespace {
+struct RcclApi {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string why;
+};
+RcclApi *rccl_api() {
+    static RcclApi api;
+    static bool tried = false;
+    if (tried) return &api;
+    tried = true;
+    const char *env = getenv("FFVD_RCCL_LIB");
+    const char *names[] = {"librccl.so.1", "librccl.so"};
+    for (const char *n : names)
+        if (!api.lib) api.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);           // whatever the process already runs on
+    if (!api.lib && env && *env) api.lib = dlopen(env, RTLD_NOW | RTLD_GLOBAL);
+    for (const char *n : names)
+        if (!api.lib) api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (!api.lib) api.lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!api.lib) { api.why = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?"); return &api; }
+    api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.lib, "ncclGetUniqueId");
+    api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.lib, "ncclCommInitRank");
+    api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
+    api.AllReduce = (decltype(api.AllReduce))dlsym(api.lib, "ncclAllReduce");
+    api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
+    if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce || !api.GetErrorString) {
+        api.why = "librccl lacks an expected symbol";
+        api.lib = nullptr;
+    }
+    return &api;
+}
+}  // namespace
+
+#define RCCL_TRY(expr)                                                                             \
+    do {                                                                                           \
+        ncclResult_t r_ = (expr);                                                                  \
+        if (r_ != ncclSuccess) {                                                                   \
+            char buf_[512];                                                                        \
+            snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #expr, api->GetErrorString(r_), __FILE__, __LINE__); \
+            return set_error(h, FFVD_EDEVICE, buf_);                                               \
+        }                                                                                          \
+    } while (0)
+
+extern "C" int ffvd_comm_unique_id(void *id_out) {
+    ffvd_handle *h = nullptr;
+    if (!id_out) return set_error(nullptr, FFVD_EINVAL, "ffvd_comm_unique_id: null argument");
+    RcclApi *api = rccl_api();
+    if (!api->lib) return set_error(nullptr, FFVD_EDEVICE, "ffvd_comm_unique_id: " + api->why);
+    ncclUniqueId id;
+    RCCL_TRY(api->GetUniqueId(&id));
+    memcpy(id_out, &id, FFVD_COMM_ID_BYTES);
+    return FFVD_OK;
+}
+
+extern "C" int ffvd_comm_init(ffvd_handle *h, int world, int rank, const void *id) {
+    if (!h || !id || world < 1 || rank < 0 || rank >= world)
+        return set_error(h, FFVD_EINVAL, "ffvd_comm_init: bad argument");
+    if (h->comm) return set_error(h, FFVD_EINVAL, "ffvd_comm_init: the handle already owns a communicator");
+    RcclApi *api = rccl_api();
+    if (!api->lib) return set_error(h, FFVD_EDEVICE, "ffvd_comm_init: " + api->why);
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    ncclUniqueId uid;
+    static_assert(sizeof(uid) == FFVD_COMM_ID_BYTES, "ncclUniqueId size");
+    memcpy(&uid, id, sizeof uid);
+    ncclComm_t comm = nullptr;
+    RCCL_TRY(api->CommInitRank(&comm, world, uid, rank));
+    h->comm = (void *)comm;
+    h->comm_world = world;
+    h->comm_rank = rank;
+    return FFVD_OK;
+}
+
+extern "C" int ffvd_comm_destroy(ffvd_handle *h) {
+    if (!h) return set_error(nullptr, FFVD_EINVAL, "ffvd_comm_destroy: null handle");
+    if (!h->comm) return FFVD_OK;
+    RcclApi *api = rccl_api();
+    hipSetDevice(h->cfg.device_id);
+    hipStreamSynchronize(h->stream);
+    ncclComm_t comm = (ncclComm_t)h->comm;
+    h->comm = nullptr;
+    if (api->lib) RCCL_TRY(api->CommDestroy(comm));
+    return FFVD_OK;
+}
+
+extern "C" void *ffvd_comm_get(ffvd_handle *h) { return h ? h->comm : nullptr; }
+
+extern "C" int ffvd_allreduce_sum_async(ffvd_handle *h, void *rccl_comm, double *buf_dev, int64_t count) {
+    if (!h || !buf_dev || count < 0) return set_error(h, FFVD_EINVAL, "ffvd_allreduce_sum_async: bad argument");
+    void *comm = rccl_comm ? rccl_comm : h->comm;
+    if (!comm) return set_error(h, FFVD_EINVAL, "ffvd_allreduce_sum_async: no communicator (pass one or call ffvd_comm_init)");
+    RcclApi *api = rccl_api();
+    if (!api->lib) return set_error(h, FFVD_EDEVICE, "ffvd_allreduce_sum_async: " + api->why);
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    if (count == 0) return FFVD_OK;
+    RCCL_TRY(api->AllReduce(buf_dev, buf_dev, (size_t)count, ncclDouble, ncclSum, (ncclComm_t)comm, h->stream));
+    return FFVD_OK;
+}
+
+extern "C" int ffvd_allreduce_sum(ffvd_handle *h, void *rccl_comm, double *buf_host, int64_t count) {
+    if (!h || !buf_host || count < 0) return set_error(h, FFVD_EINVAL, "ffvd_allreduce_sum: bad argument");
+    if (count == 0) return FFVD_OK;
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    if (h->stage_count < count) {          // device staging buffer, grown on demand and kept by the handle
+        double *d = nullptr;
+        HIP_TRY(dev_alloc(h, &d, (size_t)count));
+        h->stage = d;
+        h->stage_count = count;
+    }
+    HIP_TRY(hipMemcpyAsync(h->stage, buf_host, (size_t)count * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    int rc = ffvd_allreduce_sum_async(h, rccl_comm, h->stage, count);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(buf_host, h->stage, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return FFVD_OK;
+}
+
+extern "C" int ffvd_elbo_allreduce_async(ffvd_handle *h, void *rccl_comm, double *out_terms_dev) {
+    if (!h) return set_error(nullptr, FFVD_EINVAL, "ffvd_elbo_allreduce_async: null handle");
+    int rc;
+    double *dst = out_terms_dev ? out_terms_dev : h->out_terms;
+    if ((rc = ffvd_elbo_async(h, dst))) return rc;
+    return ffvd_allreduce_sum_async(h, rccl_comm, dst, 8);
+}
+
+extern "C" int ffvd_elbo_allreduce(ffvd_handle *h, void *rccl_comm, double out_terms[8], double *out_nll) {
+    if (!h) return set_error(nullptr, FFVD_EINVAL, "ffvd_elbo_allreduce: null handle");
+    int rc;
+    // kernels -> finalize (8 partial sums in HBM) -> ncclAllReduce on the same stream -> one copy back: the only host
+    // synchronisation of the step is the final one
+    if ((rc = ffvd_elbo_allreduce_async(h, rccl_comm, nullptr))) return rc;
+    h->info_pending = false;
+    HIP_TRY(hipMemcpyAsync(h->h_res, h->resblk, h->res_bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if ((rc = check_info(h))) return rc;              // this rank's factorisations
+    bool finite = true;
+    for (int i = 0; i < 8; ++i) finite = finite && std::isfinite(h->h_out[i]);
+    if (!finite)                                      // a failed factorisation on ANOTHER rank poisons the sums with NaN
+        return set_error(h, FFVD_ENOTPD, "ffvd_elbo_allreduce: non-finite partial sums after the all-reduce (a factorisation failed on another rank)");
+    if (out_terms) memcpy(out_terms, h->h_out, 8 * sizeof(double));
+    if (out_nll) *out_nll = h->h_out[FFVD_TERM_NLL] / h->h_out[FFVD_TERM_COUNT];
     return FFVD_OK;
 }

@@ -146,6 +146,7 @@ struct FinalizeArgs {
                                    //   log|A| - log|K_uu + jitter I|
     const double *trpart;          // route 1: [S*Dl][ntiles] partial sums of tr(K^-1 K_uf K_fu)
     int ntiles;
+    int fsq_from_trpart;           // route 0, fp32-contraction path: trpart[S*Dl][ntiles] = sum_t |F_t|^2 (no row sums)
     double *chain_nll;             // [S]
     double *out_terms;             // [8]
 };

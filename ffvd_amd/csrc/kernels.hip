@@ -1536,10 +1536,10 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
                 const size_t bb = (size_t)s * a.Dl + dl;
                 const double *ht = a.hterms + bb * 2;
                 double logdet = ht[0];
-                if (a.route == 1) {
-                    // log|I + L^-1 G L^-T / Q| = log|K + G/Q| - log|K|  with K = K_uu + jitter I
-                    if (!a.whitened) logdet -= a.kterms[2 * dl];
-                    // sum_t |F_t|^2 = tr(K^-1 K_uf K_fu): add it back to the trace term (:255)
+                // log|I + L^-1 G L^-T / Q| = log|K + G/Q| - log|K|  with K = K_uu + jitter I
+                if (a.route == 1 && !a.whitened) logdet -= a.kterms[2 * dl];
+                if (a.route == 1 || a.fsq_from_trpart) {
+                    // sum_t |F_t|^2 (= tr(K^-1 K_uf K_fu) on route 1): add it back to the trace term (:255)
                     double fsq = 0.0;
                     for (int t = 0; t < a.ntiles; ++t) fsq += a.trpart[bb * a.ntiles + t];
                     terms[3] += -(0.5 * fsq / exp(a.log_Q[a.d_begin + dl])) / Tn;

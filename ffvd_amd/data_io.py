@@ -68,13 +68,20 @@ def apply_init(ARGS, ini, control_inputs, Y_train_std, num_inducing, x_dims):
 
 
 def save_results(save_path_file, model, Y_test, Y_train, Y_train_std, case="C1", ll_seq=(0.0,), running_time_seq=(0.0,),
-                 PG_num=None, U_val=None):
+                 PG_num=None, U_val=None, mc_posterior_samples=None):
     """Write `<save_path_file>_results.npz` with the keys of base_model.py:512-517 from a DGPSSM that has run
-    collect_samples_formal.  Returns the file name."""
+    collect_samples_formal.  Unlike the reference (FFVD_Main.py:328,348: `results/<dataset>/` must pre-exist) the
+    directory is created.  `mc_posterior_samples`: name -> (num, ...) array of the SG-HMC variables recorded per
+    rollout (:239-240); stored as numeric arrays `mc_posterior_samples_<name>` (the reference pickles a list of lists
+    under `mc_posterior_samples`, which needs allow_pickle to read back).  Returns the file name."""
+    import os
     if model._host_stale:
         model.pull_parameters()
     lay = model.layers[-1]
     name = save_path_file + "_results.npz"
+    if os.path.dirname(name):
+        os.makedirs(os.path.dirname(name), exist_ok=True)
+    mc = {f"mc_posterior_samples_{k}": np.asarray(v) for k, v in (mc_posterior_samples or {}).items()}
     np.savez_compressed(
         name, y_train_vfe=model.fit_y, y_test_vfe=model.predict_y, v_test_vfe_var=model.predict_y_var,
         Y_test_data=Y_test, Y_train_data=Y_train, Y_train_std=Y_train_std, CC_val=model.likelihood.CC,
@@ -84,5 +91,5 @@ def save_results(save_path_file, model, Y_test, Y_train, Y_train_std, case="C1",
         else np.zeros(0),
         k_log_variances=np.array([float(k.logvariance) for k in lay.kernel]), case=case, ll_seq=np.asarray(ll_seq),
         running_time_seq=np.asarray(running_time_seq), PG_num=np.asarray(-1 if PG_num is None else PG_num),
-        mc_posterior_samples=np.zeros(0))
+        mc_posterior_samples=np.array(sorted((mc_posterior_samples or {}).keys())), **mc)
     return name

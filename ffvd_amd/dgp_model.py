@@ -88,9 +88,25 @@ class DGPSSM:
             self.vars += ["Z"]
         if hyperparameter_sampling:                                              # :244-246
             self.vars += ["log_Q", "CC", "DD", "log_Rchols"]
-        self._adam_train = tuple(k for k in ("X", "Z", "logvariance", "loglengthscales", "log_Q", "CC", "DD", "log_Rchols",
-                                             "U")
-                                 if k not in self.vars and not (k == "U" and self.U_collapse))
+        # what AdamOptimizer.minimize(nll) (dgp_model.py:303-305) updates = the variables created with trainable=True:
+        # X unless X_PG or case 7 (:62-66); U iff U_optimization (:68), Z iff Z_optimization (:69); the kernel
+        # hyper-parameters iff kernel_optimization (kernels_multi_output.py:156,160); log_Q unless hyperparameter_sampling
+        # or case 7 (:176-184); CC, DD, log_Rchols iff likelihood_traning and not hyperparameter_sampling
+        # (likelihoods.py:14-24,47-55).  A variable that is neither trainable nor in `vars` simply stays put.
+        train = []
+        if not (self.X_PG or case_val == 7):
+            train.append("X")
+        if Z_optimization:
+            train.append("Z")
+        if kernel_optimization:
+            train += ["logvariance", "loglengthscales"]
+        if not hyperparameter_sampling and case_val != 7:
+            train.append("log_Q")
+        if getattr(likelihood, "trainable", True):
+            train += ["CC", "DD", "log_Rchols"]
+        if U_optimization and not self.U_collapse:
+            train.append("U")
+        self._adam_train = tuple(k for k in train if k not in self.vars)
         self._rng = np.random.default_rng()
         self.window = []
         self._resident = False      # device copy of the parameters is current (set by train_hypers)
@@ -265,41 +281,99 @@ class DGPSSM:
         self._host_stale = False
         return g
 
+    def sample_op(self, noise=None):
+        """One `sample_op` of generate_update_step (base_model.py:171-179) on `self.vars`: forward + backward + SG-HMC
+        update of theta and p on the device.  `noise`: name -> standard-normal array (default: the model's generator)."""
+        self._ensure_resident()
+        t = self.engine.sghmc_step(self._noise() if noise is None else noise, self.epsilon, self.mdecay, burn_in=False)
+        self._host_stale = True
+        return t
+
     def collect_samples_formal(self, num, spacing, control_inputs, test_len, sghmc_var_len=0, U_collapse=None,
-                               Y_test=None, Y_train_std=1.0, Y_train=None, eps=None, seed=None, **_ignored):
-        """BaseModel.collect_samples_formal (base_model.py:197-350) for the SG-HMC-free cases (sghmc_var_len = 0):
-        K_uu factors, posterior U (collapsed branch), `num` rollouts of `test_len` steps from X[-1], predictive
-        y mean / variance and the RMSE over the first 30 test points.  `eps` (test_len, num, D) injects the
-        standard-normal draws of :306; otherwise they come from numpy's default_rng(seed).  Returns a dict and
-        sets the reference's attributes (fit_x, predict_y, predict_y_var, fit_y, RMSE_val)."""
+                               Y_test=None, Y_train_std=1.0, save_path_file=None, Y_train=None, case="C1", ll_seq=(0.0,),
+                               running_time_seq=(0.0,), PG_num=None, synthetic_data_function_plot=False, data_uu=None,
+                               eps=None, seed=None, rollout_mode="reference"):
+        """BaseModel.collect_samples_formal (base_model.py:197-517), called as FFVD_Main.py:345-349 does: K_uu factors,
+        posterior U (collapsed branch), `num` rollouts of `test_len` steps from X[-1], predictive y mean / variance, the
+        RMSE over the first 30 test points and, with `save_path_file`, the `_results.npz` of :512-517.
+
+        sghmc_var_len > 0 (cases 2, 3, 5: `len(model.vars)`): before rollout num_i the reference runs `spacing` x
+        `sample_op` (:223-231) and records the variables (:239-240).  rollout_mode:
+          "reference" -- what the reference's graph computes: its rollout tensors are only EVALUATED by the one
+                         session.run at :326-327, after the last sample_op, so every rollout sees the final variable
+                         values; the `num` rollouts differ by their noise only;
+          "intent"    -- rollout num_i uses the variables as they are after its own sample_ops (K_uu factors and
+                         posterior U recomputed per sample), which is what the loop sets out to do.
+        `eps` (test_len, num, D) injects the standard-normal draws of :306 (else numpy's default_rng(seed)); the
+        SG-HMC noise comes from the model's generator (`seed()`).  Returns a dict and sets the reference's attributes
+        (fit_x, predict_y, predict_y_var, fit_y, RMSE_val)."""
         from . import conditionals_multi_output as cmo
         from .prediction import predict_y_summary, rollout
-        if sghmc_var_len:
-            raise NotImplementedError("rollouts interleaved with SG-HMC sample_op (cases 2, 3, 5)")
+        if synthetic_data_function_plot:
+            raise NotImplementedError("synthetic_data_function_plot: plotting aid of the kink toy problem, not on the GP-SSM path")
+        if rollout_mode not in ("reference", "intent"):
+            raise ValueError("rollout_mode must be 'reference' or 'intent'")
+        if sghmc_var_len and sghmc_var_len != len(self.vars):
+            raise ValueError(f"sghmc_var_len = {sghmc_var_len} but the model samples {len(self.vars)} variables")
         if self._host_stale:
             self.pull_parameters()
         U_collapse = self.U_collapse if U_collapse is None else bool(U_collapse)
-        lay = self.layers[-1]
         D = self.output_dim
         ci = self.control_inputs if control_inputs is None else np.asarray(control_inputs, dtype=np.float64)
         T = self.X_N - 1
-        self.fit_x = lay.X.copy()                                                            # :203
-        Lm_inverse_seq = cmo.kernel_pre_cal(lay.Z, lay.kernel)                                # :207
-        if U_collapse:
-            xc = np.concatenate((lay.X[:T], ci[:T]), axis=1) if ci.shape[1] > 0 else lay.X[:-1]    # :243-246
-            U_val, U_chol = cmo.collapse_u_mean_after_kernel_precalculation(Lm_inverse_seq, xc, lay.X, lay.Z,
-                                                                            lay.kernel, self.Q)     # :251
-        else:
-            U_val, U_chol = lay.U, None                                                       # :255-256
+        self.fit_x = self.layers[-1].X.copy()                                                  # :203
         if eps is None:
             eps = np.random.default_rng(seed).standard_normal((test_len, num, D))
+        eps = np.asarray(eps, dtype=np.float64)
         n_train = self.Y.shape[0] if Y_train is None else np.asarray(Y_train).shape[0]
-        px, pv = rollout(Lm_inverse_seq, lay.Z, lay.kernel, U_val, U_chol, lay.X[-1], ci, n_train, test_len, self.Q, eps)
+
+        def posterior():
+            lay = self.layers[-1]
+            Lm = cmo.kernel_pre_cal(lay.Z, lay.kernel)                                          # :207 / :234
+            if U_collapse:
+                xc = np.concatenate((lay.X[:T], ci[:T]), axis=1) if ci.shape[1] > 0 else lay.X[:-1]    # :243-246
+                U_val, U_chol = cmo.collapse_u_mean_after_kernel_precalculation(Lm, xc, lay.X, lay.Z, lay.kernel, self.Q)  # :251
+            else:
+                U_val, U_chol = lay.U, None                                                     # :255-256
+            return Lm, U_val, U_chol
+
+        mc = [[] for _ in self.vars]
+        px_parts, pv_parts = [], []
+        if sghmc_var_len:
+            for num_i in range(num):
+                for _ in range(spacing):                                                        # :225-231
+                    self.sample_op()
+                self.pull_parameters()
+                cur = self.parameters()
+                for i, k in enumerate(self.vars):
+                    mc[i].append(np.array(cur[k], copy=True))                                   # :239-240
+                if rollout_mode == "intent":
+                    Lm, U_val, U_chol = posterior()
+                    lay = self.layers[-1]
+                    px, pv = rollout(Lm, lay.Z, lay.kernel, U_val, U_chol, lay.X[-1], ci, n_train, test_len, self.Q,
+                                     eps[:, num_i:num_i + 1])
+                    px_parts.append(px)
+                    pv_parts.append(pv)
+        if px_parts:
+            px, pv = np.concatenate(px_parts, axis=0), np.concatenate(pv_parts, axis=0)
+            U_val = U_val if U_collapse else self.layers[-1].U
+        else:
+            Lm, U_val, U_chol = posterior()
+            lay = self.layers[-1]
+            px, pv = rollout(Lm, lay.Z, lay.kernel, U_val, U_chol, lay.X[-1], ci, n_train, test_len, self.Q, eps)
+        lay = self.layers[-1]
         out = predict_y_summary(px, pv, self.likelihood.CC, self.likelihood.DD, self.likelihood.log_Rchols, Y_test,
                                 Y_train_std)
         self.predict_y, self.predict_y_var = out["predict_y"], out["predict_y_var"]
-        self.fit_y = (lay.X[1:] @ self.likelihood.CC + self.likelihood.DD).reshape(-1)         # :344
+        self.fit_y = (np.asarray(self.fit_x)[1:] @ self.likelihood.CC + self.likelihood.DD).reshape(-1)   # :344
         if "RMSE" in out:
             self.RMSE_val = out["RMSE"]
-        out.update(predict_x=px, predict_x_var=pv, U_val=U_val, fit_y=self.fit_y)
+            print("RMSE: ", self.RMSE_val)                                                      # :350
+        out.update(predict_x=px, predict_x_var=pv, U_val=U_val, fit_y=self.fit_y,
+                   mc_posterior_samples={k: np.stack(v) for k, v in zip(self.vars, mc) if v})
+        if save_path_file is not None:                                                         # :486-517
+            from .data_io import save_results
+            out["results_file"] = save_results(save_path_file, self, Y_test, Y_train, Y_train_std, case=case, ll_seq=ll_seq,
+                                               running_time_seq=running_time_seq, PG_num=PG_num,
+                                               mc_posterior_samples=out["mc_posterior_samples"])
         return out

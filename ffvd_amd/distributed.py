@@ -85,18 +85,53 @@ def all_reduce_grads(grads, mode="chains", device=None, group=None):
     return out
 
 
+def exchange_unique_id(make_id, rank, world, rendezvous_dir=None, timeout_s=120.0):
+    """Hand rank 0's 128-byte RCCL id (ffvd_comm_unique_id) to every rank.  Host-side plumbing only:
+    with `rendezvous_dir` through a file (written atomically by rank 0, polled by the others), otherwise through the
+    initialised torch.distributed group (any backend; gloo in the launchers of this repo)."""
+    if world == 1:
+        return make_id()
+    if rendezvous_dir:
+        import time
+        path = os.path.join(rendezvous_dir, "rccl_unique_id")
+        if rank == 0:
+            blob = make_id()
+            with open(path + ".tmp", "wb") as f:
+                f.write(blob)
+            os.replace(path + ".tmp", path)
+            return blob
+        t0 = time.monotonic()
+        while not os.path.exists(path):
+            if time.monotonic() - t0 > timeout_s:
+                raise TimeoutError(f"rank {rank}: no RCCL id at {path} after {timeout_s:.0f} s")
+            time.sleep(0.01)
+        with open(path, "rb") as f:
+            return f.read()
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        raise RuntimeError("exchange_unique_id: pass rendezvous_dir or initialise torch.distributed first")
+    box = [make_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return box[0]
+
+
 class ShardedElbo:
     """One rank's share of the ELBO on its own GPU + the scalar all-reduce.
 
-    The 8 partial sums are written by the finalize kernel straight into a torch CUDA tensor (its
-    `data_ptr()` crosses the C ABI as a plain device pointer), which RCCL then all-reduces in place."""
+    collective="rccl" (default): the native path of include/ffvd_abi.h -- `ffvd_comm_init` creates the rank's
+    ncclComm_t, `ffvd_elbo_allreduce` runs kernels -> finalize -> ncclAllReduce(8 doubles) -> one copy back on the
+    engine's stream; no torch tensor or torch stream is involved (torch.distributed, if initialised, only carries the
+    128-byte rendezvous id).
+    collective="torch": the 8 partial sums are written into a torch CUDA tensor and reduced by
+    `torch.distributed.all_reduce` -- for groups RCCL cannot form (two test ranks sharing ONE GPU over gloo)."""
 
     def __init__(self, params, Y, control_inputs, meta, rank=0, world=1, mode="chains", device=0, always_reduce=False,
-                 **engine_kw):
-        import torch
+                 collective="rccl", rendezvous_dir=None, **engine_kw):
         from .engine import ElboEngine
-        self.torch = torch
+        if collective not in ("rccl", "torch"):
+            raise ValueError("collective must be 'rccl' or 'torch'")
         self.meta, self.rank, self.world, self.mode = meta, rank, world, mode
+        self.collective = collective
         self.always_reduce = bool(always_reduce)      # run the collective path even with one rank (tests)
         self.plan = plan(meta, world, rank, mode)
         pl = self.plan
@@ -108,40 +143,41 @@ class ShardedElbo:
         local = dict(params)
         local["X"] = np.ascontiguousarray(params["X"][pl["s_begin"]: pl["s_begin"] + pl["s_count"]])
         self.engine.set_params(local)
-        self.sums = torch.zeros(8, dtype=torch.float64, device=f"cuda:{device}")
-        self.ext_stream = torch.cuda.ExternalStream(self.engine.stream_handle(), device=f"cuda:{device}")
-        self._sync_step = False          # set when the stream-ordered step failed on its FIRST use (see step)
-        self._stream_step_ok = False
+        self.reduces = world > 1 or self.always_reduce
+        if self.reduces and collective == "rccl":
+            blob = exchange_unique_id(self.engine.comm_unique_id, rank, world, rendezvous_dir)
+            self.engine.comm_init(world, rank, blob)
+        elif self.reduces:
+            import torch
+            self.torch = torch
+            self.sums = torch.zeros(8, dtype=torch.float64, device=f"cuda:{device}")
+            self.ext_stream = torch.cuda.ExternalStream(self.engine.stream_handle(), device=f"cuda:{device}")
+
+    def close(self):
+        self.engine.close()
 
     def step(self):
-        """One ELBO iteration: local kernels -> 8 partial sums in HBM -> all-reduce -> host."""
-        if self.world == 1 and not self.always_reduce:
-            # nothing to reduce: the engine's own pinned-host copy of the 8 sums (one synchronisation, no torch hop)
+        """One ELBO iteration: local kernels -> 8 partial sums in HBM -> all-reduce -> host.  Errors are not masked:
+        a failing collective or HIP call raises; a failed factorisation on any rank raises LinAlgError."""
+        if not self.reduces:
+            # nothing to reduce: the engine's own pinned-host copy of the 8 sums (one synchronisation)
             return self.engine.elbo_sums()
-        if os.environ.get("FFVD_SYNC_STEP") or self._sync_step:   # conservative variant: host sync, collective on torch's stream
+        if self.collective == "rccl":
+            return self.engine.elbo_allreduce()
+        if os.environ.get("FFVD_SYNC_STEP"):   # explicit opt-in, conservative variant: host sync, collective on torch's stream
             self.engine.elbo_async(self.sums.data_ptr())
             self.engine.sync()
             all_reduce_sums(self.sums)
             return self.sums.cpu().numpy()
-        # stream-ordered: the finalize kernel, the RCCL all-reduce and the device-to-host copy all follow the engine's
+        # stream-ordered: the finalize kernel, the all-reduce and the device-to-host copy all follow the engine's
         # stream (torch sees it as an external stream), so the only host synchronisation is the final copy
-        try:
-            with self.torch.cuda.stream(self.ext_stream):
-                self.engine.elbo_async(self.sums.data_ptr())
-                all_reduce_sums(self.sums)
-                out = self.sums.cpu().numpy()
-        except RuntimeError as exc:
-            # a collective backend that cannot run on an external stream: say so once and keep going the conservative
-            # way (same kernels, same numbers, one more host synchronisation per step)
-            if self._stream_step_ok:
-                raise
-            import warnings
-            warnings.warn(f"stream-ordered collective step failed ({exc}); falling back to the synchronous step")
-            self._sync_step = True
-            return self.step()
-        self._stream_step_ok = True
+        with self.torch.cuda.stream(self.ext_stream):
+            self.engine.elbo_async(self.sums.data_ptr())
+            all_reduce_sums(self.sums)
+            out = self.sums.cpu().numpy()
+        self.engine.sync()              # reports this rank's Cholesky info flags (LinAlgError)
         if not np.all(np.isfinite(out)):
-            self.engine.sync()          # a failed factorisation poisons the sums: fetch the info flags, raise LinAlgError
+            raise np.linalg.LinAlgError("non-finite partial sums after the all-reduce: a factorisation failed on another rank")
         return out
 
     def nll_terms(self):
@@ -152,6 +188,18 @@ class ShardedElbo:
         local backward pass scaled by 1/S_total, then one all-reduce of the 8 sums and one of the packed
         shared-parameter gradients."""
         terms, g = self.engine.nll_and_grad(S_total=self.meta["S"])
+        if not self.reduces:
+            return finish(terms["sums8"]), g
+        if self.collective == "rccl":
+            keys = list(GRAD_KEYS) + (["U"] if "U" in g else []) + (["X"] if self.mode == "dims" else [])
+            flat = np.concatenate([terms["sums8"]] + [np.asarray(g[k], dtype=np.float64).ravel() for k in keys])
+            flat = self.engine.allreduce_host(flat)          # ONE ncclAllReduce: 8 sums + packed shared gradients
+            out, off = dict(g), 8
+            for k in keys:
+                n = int(np.asarray(g[k]).size)
+                out[k] = flat[off: off + n].reshape(np.asarray(g[k]).shape).copy()
+                off += n
+            return finish(flat[:8]), out
         self.sums.copy_(self.torch.from_numpy(terms["sums8"]))
         all_reduce_sums(self.sums)
         g = all_reduce_grads(g, self.mode, device=self.sums.device)

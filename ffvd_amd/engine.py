@@ -22,18 +22,24 @@ class ElboEngine:
     route (collapsed branch only): "reference" forms F = K_fu L^-T and H = F^T F / Q + I in the reference's
     op order; "gram" evaluates the same bound as log|K_uu + K_uf K_fu / Q| - log|K_uu| (about half the flops,
     agrees to ~1e-9 relative; see include/ffvd_abi.h FFVD_ROUTE_*).
+
+    dtype: "f64" (the reference's) or "f32c" = K_fu and the two T x M x M contractions in fp32 on the matrix cores,
+    everything M x M and every accumulation that feeds the scalar in fp64 (include/ffvd_abi.h FFVD_F32C).
     """
 
     def __init__(self, T, D, C, M, S, Ydim=1, kernel_type="SquaredExponential", U_collapse=True,
                  prior_type="normal", device=0, d_begin=0, d_count=0, shared_terms=True,
-                 chains_per_pass=0, jitter=1e-5, route="reference", grad=False):
+                 chains_per_pass=0, jitter=1e-5, route="reference", grad=False, dtype="f64"):
         if kernel_type not in _lib.KERNEL_KIND:
             raise ValueError("Invalid kernel type")
         if prior_type not in _lib.PRIOR_TYPE:
             raise ValueError("Invalid prior type")           # models.py:41
         if route not in _lib.ROUTE:
             raise ValueError("route must be 'reference' or 'gram'")
+        if dtype not in _lib.DTYPE:
+            raise ValueError("dtype must be 'f64' or 'f32c'")
         self.route = route
+        self.dtype = dtype
         self.grad = bool(grad)
         self.lib = _lib.load()
         self.T, self.D, self.C, self.M, self.S, self.Ydim = int(T), int(D), int(C), int(M), int(S), int(Ydim)
@@ -43,7 +49,7 @@ class ElboEngine:
         self.shared_terms = bool(shared_terms)
         cfg = _lib.FfvdConfig(
             T=self.T, D=self.D, C=self.C, M=self.M, S_local=self.S, Ydim=self.Ydim, d_begin=self.d_begin,
-            d_count=self.d_count, shared_terms=int(self.shared_terms), dtype=0,
+            d_count=self.d_count, shared_terms=int(self.shared_terms), dtype=_lib.DTYPE[dtype],
             kernel_kind=_lib.KERNEL_KIND[kernel_type], branch=_lib.BRANCH_B if U_collapse else _lib.BRANCH_A,
             prior_type=_lib.PRIOR_TYPE[prior_type], device_id=int(device), chains_per_pass=int(chains_per_pass),
             route=_lib.ROUTE[route], grad=int(bool(grad)), reserved=0, jitter=float(jitter))
@@ -240,6 +246,35 @@ class ElboEngine:
     def elbo_async(self, out_dev_ptr=None):
         """Enqueue one iteration; the 8 partial sums land in device memory `out_dev_ptr` (int address)."""
         _lib.check(self.lib.ffvd_elbo_async(self._h, out_dev_ptr), self._h, "ffvd_elbo_async")
+
+    # -- native RCCL collectives (include/ffvd_abi.h "multi-GPU") -------------------------------------
+    def comm_unique_id(self):
+        """The 128-byte RCCL rendezvous id (rank 0 calls this and hands the bytes to the other ranks)."""
+        buf = ct.create_string_buffer(128)
+        _lib.check(self.lib.ffvd_comm_unique_id(buf), None, "ffvd_comm_unique_id")
+        return bytes(buf.raw)
+
+    def comm_init(self, world, rank, unique_id):
+        """ncclCommInitRank on this engine's device (collective over all ranks); the handle owns the communicator."""
+        if len(unique_id) != 128:
+            raise ValueError("unique_id must be the 128 bytes of comm_unique_id()")
+        buf = ct.create_string_buffer(bytes(unique_id), 128)
+        _lib.check(self.lib.ffvd_comm_init(self._h, int(world), int(rank), buf), self._h, "ffvd_comm_init")
+
+    def elbo_allreduce(self, comm=None):
+        """One iteration of this rank's shard + ncclAllReduce of the 8 partial sums; returns the whole-job sums."""
+        out = np.zeros(8)
+        nll = ct.c_double()
+        _lib.check(self.lib.ffvd_elbo_allreduce(self._h, comm, _lib.dptr(out), ct.byref(nll)), self._h,
+                   "ffvd_elbo_allreduce")
+        return out
+
+    def allreduce_host(self, array, comm=None):
+        """all-reduce(sum) of a small host fp64 array through the handle's device staging buffer on the engine's stream
+        (8 sums + shared-parameter gradients of a sharded training step: a few KB).  Returns a new flat array."""
+        a = np.ascontiguousarray(np.asarray(array, dtype=np.float64)).ravel().copy()
+        _lib.check(self.lib.ffvd_allreduce_sum(self._h, comm, _lib.dptr(a), a.size), self._h, "ffvd_allreduce_sum")
+        return a
 
     def stream_handle(self):
         """The engine's hipStream_t as an integer (for torch.cuda.ExternalStream)."""

@@ -4,8 +4,10 @@
 `fit(Y_train, ...)` that builds the kernels (models.py:57-62), the Gaussian likelihood (models.py:320) and the
 DGPSSM (models.py:66-74), then runs the loop of models.py:142-182: `sghmc_step` (a no-op on the empty SG-HMC
 variable list of the default collapsed case 4) and `train_hypers` (one Adam step on nll, forward + backward +
-update on the device), `ARGS.iterations` x 2 times as the reference does.  `fit(..., iterations=0)` only builds
-the model and records the initial nll.
+update on the device), `ARGS.iterations` x 2 times as the reference does (models.py:142) -- `fit(Y_train, ...)`
+called exactly as FFVD_Main.py:343 does trains.  `fit(..., iterations=k)` runs k rounds instead; `iterations=0` only
+builds the model and records the initial nll.  The engine's route and backward-pass workspace are chosen here from
+`U_collapse` and from whether any round will run; callers never pass them.
 """
 from __future__ import annotations
 
@@ -35,12 +37,19 @@ class Model:
         if prior_type not in ("determinantal", "normal", "strauss", "uniform"):
             raise Exception("Invalid prior type")    # models.py:35-41
 
-    def _fit(self, Y_train, lik, kernel_type, kernel_train_flag, iterations=0, **kwargs):
+    def _fit(self, Y_train, lik, kernel_type, kernel_train_flag, iterations=None, epsilon=0.01, **kwargs):
         Y_train = np.asarray(Y_train, dtype=np.float64)
         if Y_train.ndim == 1:
             Y_train = Y_train[:, None]
         A = self.ARGS
+        n_iter = 2 * A.iterations if iterations is None else int(iterations)     # models.py:142 `2*self.ARGS.iterations`
         if not self.model:
+            if n_iter > 0:
+                # training needs the backward-pass workspace; the collapsed bound then runs in its Gram form, the one the
+                # closed-form gradient is written in
+                kwargs.setdefault("grad", True)
+                if A.U_collapse:
+                    kwargs.setdefault("route", "gram")
             control = np.asarray(A.control_inputs, dtype=np.float64)
             D = A.x_dims[-1]
             Z_dim = control.shape[1] + D                                        # models.py:51
@@ -64,11 +73,14 @@ class Model:
                                 kernel_optimization=getattr(A, "kernel_optimization", True),
                                 U_optimization=getattr(A, "U_optimization", False),
                                 Z_optimization=getattr(A, "Z_optimization", True),
-                                U_collapse=A.U_collapse, case_val=getattr(A, "case_val", 4), **kwargs)     # models.py:73-74
+                                U_collapse=A.U_collapse, case_val=getattr(A, "case_val", 4), epsilon=epsilon,
+                                **kwargs)                                                         # models.py:73-74
+        elif n_iter > 0 and not self.model.engine.grad:
+            raise ValueError("this model was built without the backward-pass workspace (fit(..., iterations=0)); "
+                             "build a new RegressionModel to train")
         self.nll_seq, self.rmse_seq, self.ll_seq, self.running_time_seq = [], [], [], []   # models.py:89-92
         self.nll_seq.append(self.model.nll())
         self.global_step = 0
-        n_iter = 2 * A.iterations if iterations is None else int(iterations)     # models.py:142 `2*self.ARGS.iterations`
         for it in range(n_iter):
             self.global_step += 1
             self.model.sghmc_step()                                              # models.py:150
@@ -88,10 +100,10 @@ class RegressionModel(Model):
 
     def fit(self, Y_train, Y_test=None, tensorboard_savepath="", dataname="", fileid="",
             kernel_type="SquaredExponential", kernel_train_flag=True, likelihood_traning=True, X_train=None,
-            X_test=None, Ystd=None, data_uu=None, epsilon=0.01, iterations=0, **kwargs):
-        """`iterations`: number of (sghmc_step, train_hypers) rounds; None = 2 * ARGS.iterations as models.py:142;
-        the default 0 builds the model and evaluates the initial nll only.  Training needs the collapsed branch with
-        SE kernels (the reference's default case 4) and engine keywords route="gram", grad=True."""
+            X_test=None, Ystd=None, data_uu=None, epsilon=0.01, iterations=None, **kwargs):
+        """models.py:319-322.  `iterations`: number of (sghmc_step, [gp_x_sampling,] train_hypers) rounds; the default
+        None = 2 * ARGS.iterations as models.py:142, so the reference's call (FFVD_Main.py:343) trains; 0 builds the model
+        and evaluates the initial nll only."""
         Y_train = np.asarray(Y_train, dtype=np.float64)
         if Y_train.ndim == 1:
             Y_train = Y_train[:, None]
@@ -99,4 +111,4 @@ class RegressionModel(Model):
         lik = Gaussian(Y_train.shape[1], A.x_dims[-1], CC=A.CC, DD=A.DD, RR_chol=A.RR_chol,
                        hyperparameter_sampling=getattr(A, "hyperparameter_sampling", False),
                        likelihood_traning=likelihood_traning)                     # models.py:320
-        return self._fit(Y_train, lik, kernel_type, kernel_train_flag, iterations=iterations, **kwargs)
+        return self._fit(Y_train, lik, kernel_type, kernel_train_flag, iterations=iterations, epsilon=epsilon, **kwargs)

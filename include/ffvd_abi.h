@@ -34,7 +34,14 @@ extern "C" {
 #define FFVD_EDEVICE  (-3)   /* HIP runtime error (message in ffvd_last_error) */
 #define FFVD_ENOTPD     1    /* Cholesky met a non-positive pivot (which matrix/pivot: ffvd_last_error) */
 
-#define FFVD_F64 0
+#define FFVD_F64  0   /* everything in fp64 (the reference's dtype: every variable is tf.float64, dgp_model.py:64-69) */
+/* fp32 CONTRACTIONS (BASELINE configs[3]; SURVEY 7 "Conditioning"): K_fu (conditionals_multi_output.py:240) and the two
+ * T x M x M products F = K_fu L^-T (:242), F^T F (:246) in fp32 on v_mfma_f32_32x32x2_f32; K_uu, every M x M
+ * factorisation and solve (:159-166, :253-254), H from the moment it leaves the matrix cores, delta^T F (:247-248) and
+ * the sum of F^2 in the trace term (:255) in fp64.  All inputs and outputs of the ABI stay fp64.  Collapsed branch,
+ * FFVD_ROUTE_REFERENCE, no gradient (the Gram route's error is eps * cond(K_uu): unusable in fp32).
+ * Measured against the fp64 oracle: nll within 5e-6 relative at T=16384, M=2048 (tests/test_gpu_f32c.py). */
+#define FFVD_F32C 1
 
 #define FFVD_KERNEL_SE      0   /* kernels_multi_output.py:140-247 SquaredExponential (ARD) */
 #define FFVD_KERNEL_LINEAR  1   /* kernels.py:250-281 LinearK, one scalar variance per latent dim */
@@ -77,7 +84,7 @@ typedef struct ffvd_config {
     int32_t d_begin;      /* first latent dim this handle evaluates (shard D: BASELINE config 5) */
     int32_t d_count;      /* number of latent dims evaluated; 0 = all D             */
     int32_t shared_terms; /* 1: also add the terms not tied to a latent dim (likelihood, prior_Z, prior_x_0, hyper prior) */
-    int32_t dtype;        /* FFVD_F64                                               */
+    int32_t dtype;        /* FFVD_F64 or FFVD_F32C                                  */
     int32_t kernel_kind;  /* FFVD_KERNEL_*                                          */
     int32_t branch;       /* FFVD_BRANCH_*                                          */
     int32_t prior_type;   /* FFVD_PRIOR_*                                           */
@@ -183,6 +190,33 @@ int  ffvd_update_params(ffvd_handle *h, const ffvd_params *p_host);
  * the sampled arrays, other members ignored.  out_terms / out_nll: the nll before the update. */
 int  ffvd_sghmc_step(ffvd_handle *h, double epsilon, double mdecay, uint32_t sample_mask, int burn_in,
                      const ffvd_params *noise_host, double out_terms[8], double *out_nll);
+/* ---- multi-GPU: one process per GPU, ONE exchange step ------------------------------------------
+ * The reference is single-process (no collective call sites); this build shards chains or latent
+ * dims over ranks and all-reduces the 8 partial sums with RCCL over xGMI.  librccl is bound at run time (the copy already
+ * mapped in the process, else $FFVD_RCCL_LIB, else the system library); without it these calls return FFVD_EDEVICE.
+ *   ffvd_comm_unique_id   rank 0 creates the 128-byte rendezvous id (ncclGetUniqueId) and hands it to the other ranks by
+ *                         any means the host has (file, socket, MPI, a torch.distributed store ...).
+ *   ffvd_comm_init        every rank: ncclCommInitRank on the handle's device; the handle owns the communicator
+ *                         (ffvd_comm_destroy / ffvd_destroy release it).  Collective: all ranks must call it.
+ *   ffvd_elbo_allreduce   one ELBO iteration of this rank's shard + ncclAllReduce(sum, 8 doubles) on the handle's stream
+ *                         + one copy back.  rccl_comm: a caller-owned ncclComm_t, or NULL = the handle's own.  out_terms =
+ *                         whole-job sums, out_terms[7] = whole-job chain count (only handles with shared_terms = 1 count
+ *                         their chains, so latent-dim shards count each chain once), out_nll = out_terms[6] / out_terms[7].  A failed factorisation on this
+ *                         rank -> FFVD_ENOTPD with the matrix/pivot; on another rank -> FFVD_ENOTPD (NaN in the sums).
+ *   ffvd_elbo_allreduce_async   enqueue only; sums land in out_terms_dev (NULL = the handle's result block).
+ *   ffvd_allreduce_sum_async    in-place ncclAllReduce(sum) of `count` doubles at device pointer buf_dev on the handle's
+ *                         stream (shared-parameter gradients of a sharded training step; Gram tiles of a T-shard). */
+#define FFVD_COMM_ID_BYTES 128
+int  ffvd_comm_unique_id(void *id_out /* FFVD_COMM_ID_BYTES */);
+int  ffvd_comm_init(ffvd_handle *h, int world, int rank, const void *id /* FFVD_COMM_ID_BYTES */);
+int  ffvd_comm_destroy(ffvd_handle *h);
+void *ffvd_comm_get(ffvd_handle *h);   /* the handle's ncclComm_t or NULL */
+int  ffvd_elbo_allreduce(ffvd_handle *h, void *rccl_comm, double out_terms[8], double *out_nll);
+int  ffvd_elbo_allreduce_async(ffvd_handle *h, void *rccl_comm, double *out_terms_dev);
+int  ffvd_allreduce_sum_async(ffvd_handle *h, void *rccl_comm, double *buf_dev, int64_t count);
+/* the same for a HOST array (staged through a device buffer the handle keeps); synchronises */
+int  ffvd_allreduce_sum(ffvd_handle *h, void *rccl_comm, double *buf_host, int64_t count);
+
 /* the handle's HIP stream (a hipStream_t), so that a collective library or another framework can order its work after
  * ffvd_elbo_async without a host synchronisation (e.g. torch.cuda.ExternalStream around the RCCL all-reduce). */
 void *ffvd_get_stream(ffvd_handle *h);

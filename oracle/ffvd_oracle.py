@@ -398,6 +398,43 @@ def nll_terms(params, Y, control_inputs, *, U_collapse=True, kernel_type="Square
     return {k: float(v) for k, v in out.items()}
 
 
+def nll_terms_shard(params, Y, control_inputs, d_begin, d_count, shared_terms, *, U_collapse=True,
+                    kernel_type="SquaredExponential", prior_type="normal"):
+    """One rank's ADDITIVE share of `nll_terms` when the latent dims are sharded (BASELINE config 5): the
+    terms tied to the dims [d_begin, d_begin + d_count) -- every kernel, Cholesky and conditional is per dim,
+    conditionals_multi_output.py:107,158,238 -- plus, where `shared_terms`, the terms that are not (likelihood,
+    prior_Z, prior_x_0, hyper prior).  Summing the shares of a partition of range(D) gives `nll_terms`.
+    Test-side stand-in for a rank's GPU engine in the CPU rehearsals of the multi-GPU path."""
+    X = params["X"]
+    T = X.shape[0] - 1
+    sl = slice(d_begin, d_begin + d_count)
+    kern = make_kernels(params, kernel_type)[sl]
+    Q = np.exp(params["log_Q"])[sl]
+    c_batch = control_inputs[:T] if control_inputs is not None and control_inputs.shape[0] > 0 else None
+    x_comb = np.concatenate((X[:-1], c_batch), axis=1) if c_batch is not None else X[:-1]
+    out = dict.fromkeys(TERM_NAMES_B, 0.0)
+    prior = prior_hyper(kern, kernel_type)
+    if shared_terms:
+        y_mean = predict_mean(X[1:], params["CC"], params["DD"])
+        out["nll_log_likelihood"] = -np.sum(logdensity_norm_diag(Y[:T], y_mean, np.exp(params["log_Rchols"])[0])) / T
+        prior += (prior_Z(params["Z"], prior_type) - np.sum(np.square(X[0])) / 2.0
+                  + hyperparameter_prior(params["log_Q"], params["CC"], params["DD"], params["log_Rchols"]))
+    if U_collapse:
+        Linv = kernel_pre_cal(params["Z"], kern)
+        t1, t2, tr = collapse_after_kernel_precalculation(Linv, x_comb, X[:, sl], params["Z"], kern, Q, float(T), float(T))
+        out["later_term1"], out["later_term2"], out["nll_reg_trace_inverse_Q_B"] = t1, t2, tr
+        out["x_t_prior_Q"] = -np.sum(logdensity_norm_diag_nonvec(X[1:, sl], X[:-1, sl], Q ** 0.5)) / T
+    else:
+        U = params["U"][:, sl]
+        mean, var = conditional(x_comb, params["Z"], kern, U, white=True)
+        out["nll_reg_trace_inverse_Q_B"] = -np.sum(-0.5 * np.sum((Q[None, :] ** (-1)) * var, axis=1)) / T
+        out["x_t_prior_Q"] = -np.sum(logdensity_norm_diag(X[1:, sl], mean + X[:-1, sl], Q ** 0.5)) / T
+        prior += prior_U(U)
+    out["nll_part_prior"] = -prior / T
+    out["nll"] = sum(out[k] for k in TERM_NAMES_B)
+    return {k: float(v) for k, v in out.items()}
+
+
 def nll_terms_chains(params, Y, control_inputs, **kw):
     """Benchmark quantity of SURVEY section 8(d): mean over S chains of nll(X_s).
 

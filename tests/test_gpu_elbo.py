@@ -281,35 +281,79 @@ def test_config5_linear_kernel_dim_shards():
         assert got[n] == pytest.approx(ref[n], rel=1e-7, abs=1e-9), (n, got[n], ref[n])
 
 
-def test_rccl_all_reduce_on_the_engine_buffer():
-    """The multi-GPU step on one rank: finalize writes the 8 partial sums into a torch CUDA tensor and RCCL
-    all-reduces that very buffer (world_size 1 exercises init, the pointer hand-off and the collective call)."""
-    import os
-    import torch
-    import torch.distributed as dist
+def test_native_rccl_all_reduce_one_rank():
+    """The multi-GPU step on one rank through the C ABI alone (no torch): ffvd_comm_unique_id / ffvd_comm_init build a
+    1-rank ncclComm_t, ffvd_elbo_allreduce runs kernels -> finalize -> ncclAllReduce on the handle's stream -> copy back
+    (world_size 1 exercises the RCCL binding, the communicator and the collective call on the result block)."""
     from ffvd_amd.distributed import ShardedElbo, finish
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29577")
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    params, Y, c, meta = synthetic.make_named("small")
+    g = load_golden("small")
+    sh = ShardedElbo(params, Y, c, meta, rank=0, world=1, mode="chains", device=0, always_reduce=True)
     try:
-        params, Y, c, meta = synthetic.make_named("small")
-        sh = ShardedElbo(params, Y, c, meta, rank=0, world=1, mode="chains", device=0, always_reduce=True)
         t = finish(sh.step())
-        g = load_golden("small")
         assert t["nll"] == pytest.approx(float(g["B_nll"]), rel=RTOL)
-        t2 = finish(sh.step())
-        assert t2 == t
-        # backward pass through the same collective path (packed shared-parameter gradients)
-        shg = ShardedElbo(params, Y, c, meta, rank=0, world=1, mode="chains", device=0, route="gram", grad=True)
-        tg, grads = shg.nll_and_grad()
-        assert tg["nll"] == pytest.approx(float(g["B_nll"]), rel=1e-8)
-        with ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], meta["S"], route="gram", grad=True) as e:
-            e.set_data(Y, c)
-            _, gl = e.nll_and_grad(params)
-        for k in GRAD_KEYS:
-            np.testing.assert_array_equal(grads[k], gl[k])
+        assert finish(sh.step()) == t
     finally:
-        dist.destroy_process_group()
+        sh.close()
+    # backward pass through the same collective path (8 sums + packed shared-parameter gradients in one ncclAllReduce)
+    shg = ShardedElbo(params, Y, c, meta, rank=0, world=1, mode="chains", device=0, always_reduce=True, route="gram", grad=True)
+    try:
+        tg, grads = shg.nll_and_grad()
+    finally:
+        shg.close()
+    assert tg["nll"] == pytest.approx(float(g["B_nll"]), rel=1e-8)
+    with ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], meta["S"], route="gram", grad=True) as e:
+        e.set_data(Y, c)
+        _, gl = e.nll_and_grad(params)
+    for k in GRAD_KEYS:
+        np.testing.assert_array_equal(grads[k], gl[k])
+
+
+def test_caller_owned_communicator_and_async_form():
+    """ffvd_elbo_allreduce with a communicator the CALLER owns (`ffvd_elbo_allreduce(h, rccl_comm)`): here the
+    ncclComm_t of a second handle; and the enqueue-only form followed by ffvd_sync."""
+    import ctypes as ct
+    from ffvd_amd import _lib
+    params, Y, c, meta = synthetic.make_named("tiny")
+    g = load_golden("tiny")
+    with ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], meta["S"]) as owner, \
+            ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], meta["S"]) as e:
+        owner.comm_init(1, 0, owner.comm_unique_id())
+        comm = owner.lib.ffvd_comm_get(owner._h)
+        assert comm
+        e.set_data(Y, c)
+        e.set_params(params)
+        sums = e.elbo_allreduce(comm)
+        assert sums[6] / sums[7] == pytest.approx(float(g["B_nll"]), rel=RTOL)
+        with pytest.raises(ValueError, match="communicator"):
+            e.elbo_allreduce(None)                     # this handle has none of its own
+        _lib.check(e.lib.ffvd_elbo_allreduce_async(e._h, comm, None), e._h, "ffvd_elbo_allreduce_async")
+        e.sync()
+
+
+def test_async_step_reports_failed_factorisation():
+    """the _async forms cannot report a non-PD matrix; ffvd_sync() must (include/ffvd_abi.h), and so must the
+    collective step built on them -- never a silent NaN."""
+    from ffvd_amd.distributed import ShardedElbo
+    params, Y, c, meta = synthetic.make_named("tiny")
+    bad = dict(params)
+    bad["X"] = params["X"].copy()
+    bad["X"][1, 7, 0] = np.nan
+    with ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], meta["S"]) as e:
+        e.set_data(Y, c)
+        e.set_params(bad)
+        e.elbo_async()
+        with pytest.raises(np.linalg.LinAlgError, match="chain 1"):
+            e.sync()
+        e.set_params(params)
+        e.elbo_async()
+        e.sync()
+    sh = ShardedElbo(bad, Y, c, meta, rank=0, world=1, device=0, always_reduce=True)
+    try:
+        with pytest.raises(np.linalg.LinAlgError):
+            sh.step()
+    finally:
+        sh.close()
 
 
 def test_not_positive_definite_is_reported():
@@ -522,13 +566,13 @@ rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 mode = sys.argv[1]
 dist.init_process_group("gloo", rank=rank, world_size=world)       # two processes share the one GPU: gloo moves the CUDA tensor
 params, Y, c, meta = synthetic.make_named("small")
-sh = ShardedElbo(params, Y, c, meta, rank=rank, world=world, mode=mode, device=0, route="gram", grad=True)
+sh = ShardedElbo(params, Y, c, meta, rank=rank, world=world, mode=mode, device=0, route="gram", grad=True, collective="torch")
 t = finish(sh.step())
 t2 = finish(sh.step())
 tg, g = sh.nll_and_grad()
 # explicit-U branch through the same collective path (dU is all-reduced with the other shared gradients)
 meta_a = dict(meta, U_collapse=False)
-sha = ShardedElbo(params, Y, c, meta_a, rank=rank, world=world, mode=mode, device=0, grad=True)
+sha = ShardedElbo(params, Y, c, meta_a, rank=rank, world=world, mode=mode, device=0, grad=True, collective="torch")
 ta, ga = sha.nll_and_grad()
 print("RESULT", rank, repr(t["nll"]), repr(t2["nll"]), repr(tg["nll"]), repr(float(np.abs(g["Z"]).sum())),
       repr(ta["nll"]), repr(float(np.abs(ga["U"]).sum())), flush=True)

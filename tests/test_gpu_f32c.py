@@ -1,0 +1,142 @@
+"""GPU parity of the fp32-contraction path (ffvd_config.dtype = FFVD_F32C, BASELINE configs[3]) and BASELINE
+configs[3] at its FULL shape (T=16384, x_dim=8, M=2048, S=64) in both arithmetics.
+
+Tolerances (stated here, measured on MI355X): the fp32 path rounds K_fu, L^-1 (as GEMM
+operand) and F to fp32 and sums the two T x M x M products in fp32 chains of at most 4096 terms; against the fp64
+oracle the nll agrees to 5e-6 relative and every component term to 5e-6 absolute (the terms are O(1e-2..1), the
+trace term is a cancellation).  The north-star acceptance is rtol 1e-4 on the nll."""
+import numpy as np
+import pytest
+
+from ffvd_amd import synthetic
+from ffvd_amd.engine import ElboEngine
+from oracle import ffvd_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TERMS_B = ("nll_part_prior", "nll_log_likelihood", "x_t_prior_Q", "nll_reg_trace_inverse_Q_B", "later_term1",
+           "later_term2", "nll")
+NLL_RTOL_F32C = 5e-6
+TERM_ATOL_F32C = 5e-6
+
+
+def run_engine(params, Y, c, meta, **kw):
+    with ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], params["X"].shape[0], Ydim=Y.shape[1],
+                    kernel_type=meta["kernel_type"], U_collapse=True, **kw) as eng:
+        eng.set_data(Y, c)
+        return eng.nll_terms(params)
+
+
+def check_f32c(got, ref, label=""):
+    errs = {n: abs(got[n] - ref[n]) for n in TERMS_B}
+    print(f"f32c vs fp64 oracle {label}: nll rel.err {errs['nll'] / abs(ref['nll']):.2e}; abs term errors "
+          + ", ".join(f"{n}={e:.1e}" for n, e in errs.items()))
+    assert got["nll"] == pytest.approx(ref["nll"], rel=NLL_RTOL_F32C), (got["nll"], ref["nll"])
+    for n in TERMS_B:
+        assert errs[n] <= TERM_ATOL_F32C + NLL_RTOL_F32C * abs(ref[n]), (n, got[n], ref[n])
+
+
+@pytest.mark.parametrize("ov", [dict(), dict(T=301, M=77, D=3, C=2, S=2), dict(T=700, M=150, D=2, C=0, S=3),
+                                dict(T=40, M=9, D=1, C=1, S=1), dict(T=1000, M=600, D=2, C=1, S=2),
+                                dict(T=257, M=130, D=5, C=8, S=2)],
+                         ids=["small", "ragged", "Mp192_C0", "tiny_D1", "M600", "P13"])
+def test_f32c_against_oracle(ov):
+    """Seeded shapes incl. ragged T/M (Mp = 128, 192, 640), no control input, and P = 13 > 12 (the generic K_fu build)."""
+    params, Y, c, meta = synthetic.make_named("small", **ov)
+    ref = orc.nll_terms_chains(params, Y, c, U_collapse=True)
+    got = run_engine(params, Y, c, meta, dtype="f32c")
+    check_f32c(got, ref, str(ov))
+    np.testing.assert_allclose(got["nll_per_chain"], ref["nll_per_chain"], rtol=NLL_RTOL_F32C)
+
+
+def test_f32c_linear_kernel():
+    """LinearK through the fp32 K_fu build (K_uu of rank P << M: the whitened products are conditioned like 1e5 |K|)."""
+    params, Y, c, meta = synthetic.make_named("small_lin", U_collapse=True, S=2)
+    ref = orc.nll_terms_chains(params, Y, c, U_collapse=True, kernel_type="LinearK")
+    got = run_engine(params, Y, c, meta, dtype="f32c")
+    print("f32c LinearK nll", got["nll"], ref["nll"])
+    assert got["nll"] == pytest.approx(ref["nll"], rel=1e-3)
+
+
+def test_f32c_headline_shape_vs_fp64_engine():
+    """config 2 shape (T=4096, M=512, D=4, S=32) in fp32 contractions vs the fp64 engine, chain by chain; two runs are
+    bitwise equal (no atomics); the accumulator flush period does not matter beyond rounding."""
+    params, Y, c, meta = synthetic.make_named("c2")
+    ref = run_engine(params, Y, c, meta, route="reference")
+    with ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], meta["S"], dtype="f32c") as e:
+        e.set_data(Y, c)
+        got = e.nll_terms(params)
+        again = e.nll_terms(params)
+    np.testing.assert_array_equal(got["nll_per_chain"], again["nll_per_chain"])
+    check_f32c(got, ref, "c2")
+    np.testing.assert_allclose(got["nll_per_chain"], ref["nll_per_chain"], rtol=NLL_RTOL_F32C)
+
+
+def test_f32c_usage_errors():
+    with pytest.raises(ValueError):
+        ElboEngine(64, 2, 1, 16, 1, dtype="f32c", route="gram")
+    with pytest.raises(ValueError):
+        ElboEngine(64, 2, 1, 16, 1, dtype="f32c", U_collapse=False)
+    with pytest.raises(ValueError):
+        ElboEngine(64, 2, 1, 16, 1, dtype="bf16")
+
+
+def test_f32c_not_positive_definite_is_reported():
+    params, Y, c, meta = synthetic.make_named("tiny")
+    bad = dict(params)
+    bad["X"] = params["X"].copy()
+    bad["X"][1, 7, 0] = np.nan
+    with ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], meta["S"], dtype="f32c") as e:
+        e.set_data(Y, c)
+        with pytest.raises(np.linalg.LinAlgError, match="chain 1"):
+            e.nll_terms(bad)
+        assert np.isfinite(e.nll_terms(params)["nll"])
+
+
+# ---- BASELINE configs[3] at its full shape ---------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def c4():
+    return synthetic.make_named("c4")
+
+
+@pytest.fixture(scope="module")
+def c4_chain0_oracle(c4):
+    params, Y, c, meta = c4
+    p = dict(params, X=params["X"][:1])
+    return orc.nll_terms_chains(p, Y, c, U_collapse=True)          # ~30-60 s of CPU: one chain, eight latent dims
+
+
+def test_config4_full_shape_one_chain_vs_oracle(c4, c4_chain0_oracle):
+    """T=16384, x_dim=8, M=2048: chain 0 through all three evaluation paths against the fp64 CPU oracle."""
+    params, Y, c, meta = c4
+    p = dict(params, X=params["X"][:1])
+    ref = c4_chain0_oracle
+    got = run_engine(p, Y, c, meta, route="reference")
+    for n in TERMS_B:
+        assert got[n] == pytest.approx(ref[n], rel=1e-8, abs=1e-9), (n, got[n], ref[n])
+    got = run_engine(p, Y, c, meta, route="gram")
+    assert got["nll"] == pytest.approx(ref["nll"], rel=1e-7)
+    for n in TERMS_B:
+        assert got[n] == pytest.approx(ref[n], rel=1e-6, abs=1e-8), (n, got[n], ref[n])
+    got = run_engine(p, Y, c, meta, dtype="f32c")
+    check_f32c(got, ref, "c4 chain 0")
+
+
+@pytest.mark.parametrize("arith", ["f32c", "f64-gram", "f64-reference"])
+def test_config4_full_shape_all_chains(c4, c4_chain0_oracle, arith):
+    """All 64 chains at the full shape: the batch's chain 0 is the oracle's; a chain's nll does not depend on what else
+    is in the batch (sub-batches, reversed order: bitwise for equal pass layouts, else to rounding); the mean is the mean."""
+    params, Y, c, meta = c4
+    kw = dict(dtype="f32c") if arith == "f32c" else dict(route=arith.split("-")[1])
+    tol = NLL_RTOL_F32C if arith == "f32c" else 1e-7
+    S = meta["S"]
+    full = run_engine(params, Y, c, meta, **kw)
+    assert np.all(np.isfinite(full["nll_per_chain"]))
+    assert full["nll_per_chain"][0] == pytest.approx(c4_chain0_oracle["nll"], rel=tol)
+    assert full["nll"] == pytest.approx(full["nll_per_chain"].mean(), rel=1e-13)
+    sel = [63, 1, 40, 0]
+    sub = run_engine(dict(params, X=params["X"][sel]), Y, c, meta, **kw)
+    np.testing.assert_allclose(sub["nll_per_chain"], full["nll_per_chain"][sel], rtol=1e-9 if arith != "f32c" else 1e-7)
+    if arith == "f32c":
+        rev = run_engine(dict(params, X=params["X"][::-1].copy()), Y, c, meta, **kw)
+        np.testing.assert_allclose(rev["nll_per_chain"][::-1], full["nll_per_chain"], rtol=1e-7)

@@ -84,7 +84,10 @@ sums = np.zeros(8)
 kw = dict(U_collapse=meta["U_collapse"], kernel_type=meta["kernel_type"])
 for s in range(pl["s_begin"], pl["s_begin"] + pl["s_count"]):
     p = dict(params); p["X"] = params["X"][s]
-    t = orc.nll_terms(p, Y, c, **kw)
+    if mode == "dims":
+        t = orc.nll_terms_shard(p, Y, c, pl["d_begin"], pl["d_count"], pl["shared_terms"], **kw)
+    else:
+        t = orc.nll_terms(p, Y, c, **kw)
     for i, n in enumerate(TERM_NAMES):
         sums[i] += t.get(n, 0.0)
     sums[7] += 1.0 if pl["shared_terms"] else 0.0
@@ -101,15 +104,17 @@ dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("world", [2])
-def test_gloo_world2_chain_sharding(tmp_path, world):
-    """world_size-2 rehearsal of mode='chains': shard -> local partial sums -> all-reduce -> mean."""
+@pytest.mark.parametrize("mode,name,port", [("chains", "tiny", "29531"), ("dims", "small_lin", "29535"), ("dims", "tiny", "29536")])
+def test_gloo_world2_sharding(tmp_path, mode, name, port):
+    """world_size-2 rehearsal of both shard modes: shard -> local partial sums -> all-reduce -> mean.
+    'dims' on the LinearK / explicit-U workload is BASELINE config 5's layout, on 'tiny' the collapsed branch's."""
     import subprocess
+    world = 2
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, FFVD_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", WORLD_SIZE=str(world),
+    env = dict(os.environ, FFVD_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, WORLD_SIZE=str(world),
                OMP_NUM_THREADS="2")
-    procs = [subprocess.Popen([sys.executable, str(script), "chains", "tiny"], env=dict(env, RANK=str(r)),
+    procs = [subprocess.Popen([sys.executable, str(script), mode, name], env=dict(env, RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = [p.communicate(timeout=240)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
