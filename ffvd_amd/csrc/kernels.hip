@@ -658,10 +658,219 @@ __global__ __launch_bounds__(256) void potrf_trail_kernel(double *A, int n, int 
     diag_block_finish<PIPE>(Ts, Lr, invd, S, n, k0 + NB, info + b, dinv + (size_t)b * DINV_STRIDE);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Left-looking block column (the default since round 2; north_star: "blocked left-looking Cholesky with wavefront-level
+// trsm").  ONE launch per block column j, one workgroup per 64-row block r of that column (main rows j..nb-1 and the
+// live extra-row blocks), no dependency between the workgroups of a launch:
+//     S_jj   = A(j,j) - sum_{k<j} L(j,k) L(j,k)^T       every workgroup forms and factorises it itself (the 64-pivot
+//                                                       chain is latency, not work: redundant copies run side by side)
+//     X(r,j) = (A(r,j) - sum_{k<j} X(r,k) L(j,k)^T) L_jj^-T    blocked substitution on the matrix cores
+// Each block of the matrix is written ONCE (the right-looking variant re-reads and re-writes the whole trailing matrix at
+// every step: 1.4 GB of tile traffic per factorisation of the 128 A-matrices of config 2 against 0.64 GB here, and two
+// dependent launches per step instead of one).  Both operand tiles of step k sit in LDS whole (stride 66: conflict-free
+// fragment reads), the global loads of step k+1 are issued before the MFMAs of step k.
+// ---------------------------------------------------------------------------------------------
+constexpr int LL_LD = NB + 2;
+template <bool PIPE>
+__global__ __launch_bounds__(256) void potrf_ll_kernel(double *A, int n, int j, int nmain, int nchunks, size_t slab_stride,
+                                                       int32_t *info, int nlive, int nid, int batch) {
+    __shared__ double sm0[NB * LL_LD];      // X(r,k) tiles, later S_jj / the factor tile Lr (then -L with a clean upper triangle)
+    __shared__ double sm1[NB * LL_LD];      // L(j,k) tiles, later T = A(r,j) - sum
+    __shared__ double invd[NB];
+    __shared__ double Dv[4][16][DV_LD];
+    // XCD-aware: all workgroups of one matrix share blockIdx % 8, i.e. one XCD's L2 (they all read row block j)
+    const int id = blockIdx.x, xcd = id & 7, loc = id >> 3;
+    const int b = (loc / nchunks) * 8 + xcd;
+    if (b >= batch) return;
+    const int chunk = loc % nchunks;
+    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qr = wave >> 1, qc = wave & 1;
+    double *S = A + (size_t)b * slab_stride;
+    const int j0 = j * NB;
+    const bool is_diag = (chunk == 0);
+    int row0, k0 = 0;                       // first row of this workgroup's block; first block column with non-zero X(r,k)
+    if (chunk < nmain) row0 = (j + chunk) * NB;
+    else {
+        const int e = extra_block(chunk - nmain, nlive, nid);
+        row0 = n + e * NB;
+        if (e < nid) k0 = e;                // identity-structured rows: block e is zero left of block column e
+    }
+    double (*Xs)[LL_LD] = reinterpret_cast<double(*)[LL_LD]>(sm0);
+    double (*Ls)[LL_LD] = reinterpret_cast<double(*)[LL_LD]>(sm1);
+    // the two output tiles are requested first: their latency hides behind the whole k loop
+    d4 cold_d[2][2], cold_t[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const size_t rr = (size_t)(qr * 32 + 16 * x + lk + 4 * q), cc = (size_t)(qc * 32 + 16 * y + lr);
+                cold_d[x][y][q] = S[(j0 + rr) * n + j0 + cc];
+                cold_t[x][y][q] = is_diag ? 0.0 : S[(row0 + rr) * n + j0 + cc];
+            }
+    d4 acc_t[2][2], acc_d[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) { acc_t[x][y] = (d4){0.0, 0.0, 0.0, 0.0}; acc_d[x][y] = (d4){0.0, 0.0, 0.0, 0.0}; }
+    // staging: thread moves 16 bytes of rows (tid >> 5) + 8 i, columns 2 (tid & 31) of each operand
+    const int sr = tid >> 5, sc = 2 * (tid & 31);
+    double2 vx[8], vl[8];
+    auto gload = [&](int k) {
+        const bool need_x = !is_diag && k >= k0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            vl[i] = *reinterpret_cast<const double2 *>(S + (size_t)(j0 + sr + 8 * i) * n + k * NB + sc);
+            if (need_x) vx[i] = *reinterpret_cast<const double2 *>(S + (size_t)(row0 + sr + 8 * i) * n + k * NB + sc);
+        }
+    };
+    auto lstore = [&](int k) {
+        const bool need_x = !is_diag && k >= k0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            Ls[sr + 8 * i][sc] = vl[i].x; Ls[sr + 8 * i][sc + 1] = vl[i].y;
+            if (need_x) { Xs[sr + 8 * i][sc] = vx[i].x; Xs[sr + 8 * i][sc + 1] = vx[i].y; }
+        }
+    };
+    if (j > 0) gload(0);
+    for (int k = 0; k < j; ++k) {
+        if (k) __syncthreads();                     // everyone is done reading the previous tiles
+        lstore(k);
+        __syncthreads();
+        if (k + 1 < j) gload(k + 1);                // in flight behind this step's MFMAs
+        const bool do_t = !is_diag && k >= k0;
+        const bool do_d = !(qr == 0 && qc == 1);    // the quadrant above the diagonal of S_jj is never read
+#pragma unroll 4
+        for (int ks = 0; ks < NB / 4; ++ks) {
+            double bl[2], al[2], ax[2];
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                bl[x] = Ls[qc * 32 + 16 * x + lr][4 * ks + lk];        // B[k][col] = L(j,k)[col][k]
+                al[x] = Ls[qr * 32 + 16 * x + lr][4 * ks + lk];
+                ax[x] = do_t ? Xs[qr * 32 + 16 * x + lr][4 * ks + lk] : 0.0;
+            }
+            if (do_d) {
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                    for (int y = 0; y < 2; ++y) acc_d[x][y] = mfma_f64(al[x], bl[y], acc_d[x][y]);
+            }
+            if (do_t) {
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                    for (int y = 0; y < 2; ++y) acc_t[x][y] = mfma_f64(ax[x], bl[y], acc_t[x][y]);
+            }
+        }
+    }
+    if (j > 0) __syncthreads();
+    // S_jj into sm0 (input tile of the factorisation, stride NB + 1), T into sm1 (stride LL_LD)
+    double (*Ts)[NB + 1] = reinterpret_cast<double(*)[NB + 1]>(sm0);
+    double (*Lr)[LR_LD] = reinterpret_cast<double(*)[LR_LD]>(sm0);
+    static_assert(LR_LD == LL_LD, "factor tile and staging tile share the stride");
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int rr = qr * 32 + 16 * x + lk + 4 * q, cc = qc * 32 + 16 * y + lr;
+                Ts[rr][cc] = cold_d[x][y][q] - acc_d[x][y][q];
+                if (!is_diag) Ls[rr][cc] = cold_t[x][y][q] - acc_t[x][y][q];
+            }
+    __syncthreads();
+    if (wave == 0) {
+        double a[NB];
+#pragma unroll
+        for (int c = 0; c < NB; ++c) a[c] = Ts[lane][c];
+        const int bad = chol64_1w<PIPE>(a, Lr, invd, lane);       // Lr overlays Ts: the whole input is in registers first
+        if (bad && is_diag && lane == 0 && info[b] == 0) info[b] = j0 + bad;
+    }
+    __syncthreads();
+    if (is_diag) {                                  // this workgroup owns the diagonal block: publish L_jj, done
+        for (int r = tid >> 6; r < NB; r += 4)
+            if (lane <= r) S[(size_t)(j0 + r) * n + j0 + lane] = Lr[r][lane];
+        return;
+    }
+    // inverses of the four 16 x 16 diagonal sub-blocks of L_jj (lane = column, 16-step forward substitution)
+    if (lane < 16) {
+        const int o = 16 * wave;
+        double xv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            double acc = (lane == r) ? 1.0 : 0.0;
+#pragma unroll
+            for (int i = 0; i < r; ++i) acc -= Lr[o + r][o + i] * xv[i];
+            xv[r] = acc * invd[o + r];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Dv[wave][r][lane] = xv[r];
+    }
+    __syncthreads();
+    // -L_jj with an exactly zero upper triangle, in place (the substitution's refinement step reads the diagonal blocks)
+    for (int idx = tid; idx < NB * NB; idx += 256) {
+        const int r = idx >> 6, c = idx & 63;
+        Lr[r][c] = (c <= r) ? -Lr[r][c] : 0.0;
+    }
+    __syncthreads();
+    // X(r,j) = T L_jj^-T: wavefront w owns rows 16w..16w+15, the four transposed 16 x 16 blocks in the MFMA accumulator
+    // layout (potrf_panel_kernel has the derivation): 4 multiplications by the inverted diagonal blocks, one residual
+    // refinement each, 6 block updates
+    d4 Rt[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Rt[s4][r] = Ls[16 * wave + lr][16 * s4 + 4 * r + lk];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        d4 x = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) x = mfma_f64(Dv[s4][lr][4 * ks + lk], Rt[s4][ks], x);
+        d4 res = Rt[s4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) res = mfma_f64(Lr[16 * s4 + lr][16 * s4 + 4 * ks + lk], x[ks], res);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) x = mfma_f64(Dv[s4][lr][4 * ks + lk], res[ks], x);
+        Rt[s4] = x;
+#pragma unroll
+        for (int t = s4 + 1; t < 4; ++t)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) Rt[t] = mfma_f64(Lr[16 * t + lr][16 * s4 + 4 * ks + lk], x[ks], Rt[t]);
+    }
+    double *Rl = S + (size_t)(row0 + 16 * wave + lr) * n + j0 + lk;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Rl[16 * s4 + 4 * r] = Rt[s4][r];
+}
+
+static bool chol_right_looking() {          // diagnostic switch, read once per process: FFVD_CHOL_RIGHT=1 = the round-1 variant
+    static const bool v = [] { const char *e = getenv("FFVD_CHOL_RIGHT"); return e && *e && *e != '0'; }();
+    return v;
+}
+
 void launch_potrf_ext(hipStream_t stream, double *A, int n, int extra_rows, int identity_rows, int batch,
                       size_t slab_stride, int32_t *info, double *dinv) {
     const int nb = n / NB;
     const int nid = identity_rows / NB, ntail = extra_rows / NB - nid;
+    if (!chol_right_looking()) {
+        const int groups = (batch + 7) / 8;
+        for (int j = 0; j < nb; ++j) {
+            const int nmain = nb - j;
+            const int nlive = (j + 1 < nid) ? j + 1 : nid;
+            const int nchunks = nmain + nlive + ntail;
+            // few workgroups: the launch lasts as long as one workgroup's 64-pivot chain -> pipelined factor variant
+            if ((size_t)nchunks * batch <= 512)
+                hipLaunchKernelGGL(potrf_ll_kernel<true>, dim3(groups * 8 * nchunks), dim3(256), 0, stream, A, n, j, nmain,
+                                   nchunks, slab_stride, info, nlive, nid, batch);
+            else
+                hipLaunchKernelGGL(potrf_ll_kernel<false>, dim3(groups * 8 * nchunks), dim3(256), 0, stream, A, n, j, nmain,
+                                   nchunks, slab_stride, info, nlive, nid, batch);
+        }
+        return;
+    }
     hipLaunchKernelGGL(potrf_diag_kernel, dim3(batch), dim3(256), 0, stream, A, n, 0, slab_stride, info, dinv);
     for (int k = 0; k < nb; ++k) {
         const int nmain = nb - k - 1;

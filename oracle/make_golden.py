@@ -52,6 +52,7 @@ def build_actuator_slim():
     Y_mean = np.mean(obs[: lens // 2])                             # :163
     obs = (obs - Y_mean) / Y_std                                   # :165
     Y_train = obs[: lens // 2]                                     # :168
+    Y_test = obs[lens // 2:]                                       # :167
     f = sorted(glob.glob(os.path.join(REF, "Factnonlin_ini", "*actuator*")))[3]
     z = np.load(f, allow_pickle=False)
     x_ini = np.mean(z["x_samples_training"], axis=1)               # FFVD_Main.py:226
@@ -66,7 +67,7 @@ def build_actuator_slim():
         log_Q=2.0 * np.log(z["Q_sqrt_ini"]),                       # dgp_model.py:182
         CC=z["C_val"].T, DD=z["d_val"],                            # FFVD_Main.py:245-246
         log_Rchols=np.log(z["R_chol_val"]),                        # likelihoods.py:54
-        Y=Y_train, control_inputs=control_inputs,
+        Y=Y_train, Y_test=Y_test, control_inputs=control_inputs,
         Y_train_std=Y_std, Y_train_mean=Y_mean,
         source=os.path.basename(f),
     )

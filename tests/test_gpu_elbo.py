@@ -68,7 +68,7 @@ def test_model_facade_matches_engine(actuator):
     A.UU_ini, A.XX_0_ini, A.x_initialization = params["U"], params["X"][0], params["X"][1:]
     A.control_inputs, A.num_inducing, A.x_dims, A.ZZ = c, 100, [4], params["Z"]
     A.U_collapse, A.kernel_optimization, A.case_val = True, True, 4
-    m.fit(Y, kernel_type="SquaredExponential")
+    m.fit(Y, kernel_type="SquaredExponential", iterations=0)
     g = load_golden("actuator")
     assert m.nll_seq[0] == pytest.approx(float(g["B_nll"]), rel=RTOL)
     t = m.model.nll_terms()

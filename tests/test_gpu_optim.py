@@ -338,3 +338,140 @@ def test_case6_particle_gibbs_in_the_loop(actuator):
     A2.X_PG, A2.PG_particles = True, 4
     m2.fit(Y, kernel_type="SquaredExponential", iterations=3, grad=True)
     assert len(m2.nll_seq) == 4 and np.all(np.isfinite(m2.nll_seq))
+
+
+def test_fit_called_exactly_like_the_driver(actuator, tmp_path):
+    """FFVD_Main.py:343 / :345-349 verbatim: `fit` without `iterations`, `route` or `grad` trains 2 * ARGS.iterations
+    rounds (models.py:142); `collect_samples_formal` takes the driver's keyword set and writes the results file."""
+    from ffvd_amd.models import RegressionModel
+    params, Y, c = actuator
+    m = RegressionModel("normal")
+    A = _actuator_args(m, params, c, n_train=400)
+    A.kernel_optimization, A.U_optimization, A.Z_optimization, A.U_collapse, A.case_val = True, False, True, True, 4
+    A.iterations, A.hyperparameter_sampling, A.X_PG = 2, False, False
+    Y_train, Y_test = Y[:400], Y[400:440]
+    m.fit(Y_train, Y_test=Y_test, tensorboard_savepath="results", dataname="actuator", fileid="x",
+          kernel_type="SquaredExponential", kernel_train_flag=True, epsilon=.01)
+    assert len(m.nll_seq) == 1 + 2 * A.iterations and m.nll_seq[-1] < m.nll_seq[1]
+    assert m.model.engine.grad and m.model.engine.route == "gram"
+    path = str(tmp_path / "results" / "actuator" / "C4VFE_result")
+    out = m.model.collect_samples_formal(5, 32, A.control_inputs, test_len=len(Y_test), sghmc_var_len=len(m.model.vars),
+                                         U_collapse=A.U_collapse, Y_test=Y_test, Y_train_std=1.3, save_path_file=path,
+                                         Y_train=Y_train, case="C4", ll_seq=m.ll_seq, running_time_seq=m.running_time_seq,
+                                         PG_num=100)
+    z = np.load(out["results_file"])
+    np.testing.assert_array_equal(z["y_test_vfe"], out["predict_y"])
+    assert str(z["case"]) == "C4" and int(z["PG_num"]) == 100 and np.isfinite(out["RMSE"])
+
+
+def test_adam_set_follows_the_trainable_flags(actuator):
+    """AdamOptimizer.minimize only touches trainable=True variables (dgp_model.py:62-69,176-184,
+    likelihoods.py:14-55, kernels_multi_output.py:156,160).  Case 6 (X_PG): X is not trainable; likelihood_traning=False
+    freezes C, d, R; kernel_optimization=False with kernel_train_flag=False freezes the kernel hyper-parameters."""
+    from ffvd_amd.models import RegressionModel
+    params, Y, c = actuator
+    m = RegressionModel("normal")
+    A = _actuator_args(m, params, c)
+    A.kernel_optimization, A.U_optimization, A.Z_optimization, A.U_collapse, A.case_val = True, True, True, False, 6
+    A.X_PG, A.PG_particles = True, 4
+    m.fit(Y, kernel_type="SquaredExponential", iterations=0, grad=True)
+    mod = m.model
+    assert "X" not in mod._adam_train and "U" in mod._adam_train
+    before = mod.parameters()["X"].copy()
+    mod.train_hypers()
+    after = mod.engine.get_params()
+    np.testing.assert_array_equal(after["X"], before)                 # Adam leaves the PG-sampled trajectory alone
+    assert not np.array_equal(after["Z"], params["Z"])
+    m2 = RegressionModel("normal")
+    A2 = _actuator_args(m2, params, c)
+    A2.kernel_optimization, A2.U_optimization, A2.Z_optimization, A2.U_collapse, A2.case_val = False, False, True, True, 5
+    m2.fit(Y, kernel_type="SquaredExponential", kernel_train_flag=False, likelihood_traning=False, iterations=0,
+           route="gram", grad=True)
+    mod2 = m2.model
+    assert mod2.vars == [] and set(mod2._adam_train) == {"X", "Z", "log_Q"}
+    mod2.train_hypers()
+    after = mod2.engine.get_params()
+    for k in ("logvariance", "loglengthscales", "CC", "DD", "log_Rchols"):
+        np.testing.assert_array_equal(after[k], np.asarray(params[k]).reshape(after[k].shape), err_msg=k)
+    assert not np.array_equal(after["log_Q"], params["log_Q"])
+
+
+@pytest.mark.parametrize("mode", ["intent", "reference"])
+def test_rollouts_interleaved_with_sghmc_sample_op(mode):
+    """collect_samples_formal with sghmc_var_len > 0 (base_model.py:223-240; FFVD_Main cases 2/3/5): `spacing` x
+    sample_op before each rollout.  Against a CPU loop built from the closed-form gradient, the SG-HMC restatement and
+    the rollout restatement with the same injected noise.  "intent": rollout i sees the variables after its own
+    sample_ops; "reference": every rollout sees the final values (the graph is evaluated once, at :326-327)."""
+    from ffvd_amd.dgp_model import DGPSSM
+    from ffvd_amd.kernels import SquaredExponential
+    from ffvd_amd.likelihoods import Gaussian
+    from oracle import ffvd_oracle as orc
+    params, Y, c, meta = synthetic.make_named("tiny", S=1)
+    T, D, M, P = meta["T"], meta["D"], meta["M"], meta["P"]
+    n_train, test_len, num, spacing = T, 6, 3, 2
+    cc = np.concatenate((c, np.random.default_rng(5).standard_normal((test_len, meta["C"]))))
+    kern = [SquaredExponential(P, ARD=True, variance=np.exp(params["logvariance"][d]),
+                               lengthscales=np.exp(params["loglengthscales"][d]), kernel_optimization=False) for d in range(D)]
+    lik = Gaussian(1, D, CC=params["CC"], DD=params["DD"], RR_chol=np.exp(params["log_Rchols"]))
+    X = params["X"][0]
+    mod = DGPSSM(Y, [D], M, [kern], lik, QQ_chol=np.exp(0.5 * params["log_Q"]), ZZ=params["Z"], control_inputs=cc,
+                 U_ini=params["U"], X_0_ini=X[0], X_train_ini=X[1:], kernel_optimization=False, U_optimization=False,
+                 U_collapse=True, Z_optimization=True, case_val=5, prior_type="normal", route="gram", grad=True)
+    assert mod.vars == ["logvariance", "loglengthscales"]
+    mod.seed(42)
+    eps = np.random.default_rng(9).standard_normal((test_len, num, D))
+    out = mod.collect_samples_formal(num, spacing, cc, test_len, sghmc_var_len=2, U_collapse=True, Y_train=Y, eps=eps,
+                                     rollout_mode=mode)
+    # CPU loop
+    rng = np.random.default_rng(42)
+    keys = ("logvariance", "loglengthscales")
+    cur = {k: np.array(params[k], dtype=np.float64) for k in keys}
+    st = {k: [np.ones_like(cur[k]), np.ones_like(cur[k]), np.ones_like(cur[k]), np.zeros_like(cur[k])] for k in keys}
+    Q = np.exp(params["log_Q"])
+
+    def roll(p, e):
+        ok = orc.make_kernels(p)
+        Lo = orc.kernel_pre_cal(p["Z"], ok)
+        Uo, Ho = orc.collapse_u_mean_after_kernel_precalculation(Lo, np.concatenate((X[:-1], cc[:T]), axis=1), X, p["Z"], ok, Q)
+        return orc.rollout(Lo, p["Z"], ok, Uo, Ho, X[-1], cc, n_train, test_len, Q, e)
+
+    px_ref, samples = [], {k: [] for k in keys}
+    for i in range(num):
+        for _ in range(spacing):
+            noise = {k: rng.standard_normal(cur[k].shape) for k in keys}
+            g = _oracle_mean_grad(dict(params, **cur), Y, c)
+            for k in keys:
+                o = oo.sghmc_step(cur[k], g[k], *st[k], noise[k], 0.01, 0.05, T + 1, False)
+                cur[k], st[k] = o[0], list(o[1:])
+        for k in keys:
+            samples[k].append(cur[k].copy())
+        if mode == "intent":
+            px_ref.append(roll(dict(params, **cur), eps[:, i:i + 1])[0])
+    px_ref = np.concatenate(px_ref, axis=0) if mode == "intent" else roll(dict(params, **cur), eps)[0]
+    for k in keys:
+        np.testing.assert_allclose(out["mc_posterior_samples"][k], np.stack(samples[k]), rtol=1e-8, atol=1e-11, err_msg=k)
+    np.testing.assert_allclose(out["predict_x"], px_ref, rtol=1e-6, atol=1e-8)
+    assert out["predict_x"].shape == (num, test_len, D)
+    with pytest.raises(ValueError):
+        mod.collect_samples_formal(num, spacing, cc, test_len, sghmc_var_len=1)
+
+
+def test_driver_example_runs(tmp_path):
+    """examples/ffvd_main_actuator.py = the logic of FFVD_Main.py:192-351 with the import swap, on the committed
+    actuator fixture: the default case 4 and the SG-HMC case 5, a few iterations each."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    import os
+    for case, extra in ((4, []), (5, ["--samples", "2", "--forced_spacing", "2"])):
+        cmd = [sys.executable, os.path.join(ROOT, "examples", "ffvd_main_actuator.py"), "--case_val", str(case),
+               "--iterations", "2", "--test_len", "40", "--results_dir", str(tmp_path / "results")] + extra
+        proc = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-2000:]
+        assert "RMSE:" in proc.stdout
+        files = list((tmp_path / "results" / "actuator").glob(f"C{case}VFE_result_actuator_*_results.npz"))
+        assert len(files) == 1, files
+        z = np.load(files[0])
+        assert z["y_test_vfe"].shape == (40,) and np.all(np.isfinite(z["y_test_vfe"]))
+        if case == 5:
+            assert z["mc_posterior_samples_logvariance"].shape == (2, 4)
