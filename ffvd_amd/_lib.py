@@ -8,7 +8,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libffvd_hip.so")
+# FFVD_LIB: load another build of the same ABI instead (the host-sanitizer build of ffvd_amd/build.py --asan)
+LIB_PATH = os.environ.get("FFVD_LIB") or os.path.join(HERE, "libffvd_hip.so")
 
 FFVD_OK, FFVD_EINVAL, FFVD_ENOMEM, FFVD_EDEVICE, FFVD_ENOTPD = 0, -1, -2, -3, 1
 KERNEL_KIND = {"SquaredExponential": 0, "LinearK": 1}
@@ -24,7 +25,8 @@ TERM_NAMES = ("nll_part_prior", "nll_log_likelihood", "x_t_prior_Q", "nll_reg_tr
 class FfvdConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "T", "D", "C", "M", "S_local", "Ydim", "d_begin", "d_count", "shared_terms", "dtype",
-        "kernel_kind", "branch", "prior_type", "device_id", "chains_per_pass", "route", "grad", "reserved")] + [("jitter", C.c_double)]
+        "kernel_kind", "branch", "prior_type", "device_id", "chains_per_pass", "route", "grad", "T_total", "t_begin",
+        "reserved")] + [("jitter", C.c_double)]
 
 
 class FfvdParams(C.Structure):
@@ -91,6 +93,12 @@ _SIGNATURES = {
     "ffvd_elbo_allreduce_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ffvd_allreduce_sum_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "ffvd_allreduce_sum": (C.c_int, [C.c_void_p, C.c_void_p, _dp, C.c_int64]),
+    "ffvd_elbo_tshard": (C.c_int, [C.c_void_p, C.c_void_p, _dp, _dp]),
+    "ffvd_tshard_local": (C.c_int, [C.c_void_p]),
+    "ffvd_tshard_count": (C.c_int64, [C.c_void_p]),
+    "ffvd_tshard_get": (C.c_int, [C.c_void_p, _dp]),
+    "ffvd_tshard_set": (C.c_int, [C.c_void_p, _dp]),
+    "ffvd_tshard_finish": (C.c_int, [C.c_void_p, _dp, _dp]),
     "ffvd_op_conditional": (C.c_int, [C.c_int, _dp, C.c_int, _dp, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp,
                                       C.c_double, _dp, _dp]),
 }

@@ -80,5 +80,48 @@ def build(force=False, verbose=False):
     return LIB
 
 
+ASAN_LIB = os.path.join(HERE, "libffvd_hip_asan.so")
+ASAN_FLAGS = ["-O1", "-g", "-Xarch_host", "-fsanitize=address,undefined", "-Xarch_host", "-fno-omit-frame-pointer",
+              "-Xarch_host", "-fno-sanitize-recover=undefined"]
+
+
+def asan_runtime():
+    """Path of the AddressSanitizer runtime that must be LD_PRELOADed into an uninstrumented host (python)."""
+    out = subprocess.run([hipcc_path(), "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True)
+    path = out.stdout.strip()
+    if not os.path.isabs(path) or not os.path.exists(path):
+        raise RuntimeError("libclang_rt.asan-x86_64.so not found next to hipcc's clang")
+    return path
+
+
+def build_asan(verbose=False):
+    """Host-side sanitizer build: the SAME sources with AddressSanitizer + UBSan on the HOST code only
+    (handle lifetime, argument validation, staging buffers, error paths of the C ABI); device code is compiled as usual
+    (GPU ASan is not available on this pool).  CPU-box job: tests/test_abi.py runs the no-GPU ABI calls against it."""
+    cc = hipcc_path()
+    flags = [f for f in FLAGS if f != "-O3"] + ASAN_FLAGS
+    os.makedirs(OBJDIR, exist_ok=True)
+
+    def compile_one(src):
+        obj = os.path.join(OBJDIR, src + ".asan.o")
+        proc = subprocess.run([cc] + flags + ["-c", os.path.join(CSRC, src), "-o", obj], capture_output=True, text=True)
+        if proc.returncode != 0:
+            raise RuntimeError(f"hipcc (asan) failed on {src}:\n" + proc.stdout + proc.stderr)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as pool:
+        objs = list(pool.map(compile_one, SOURCES))
+    cmd = [cc] + objs + LINK + ["-fsanitize=address,undefined", "-shared-libsan", "-o", ASAN_LIB]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError("hipcc (asan) link failed:\n" + proc.stdout + proc.stderr)
+    return ASAN_LIB
+
+
 if __name__ == "__main__":
+    if "--asan" in sys.argv:
+        print(build_asan(verbose=True))
+        sys.exit(0)
     print(build(force="--force" in sys.argv, verbose=True))

@@ -53,6 +53,8 @@ struct ffvd_handle {
     bool have_params = false, have_data = false;
     void *comm = nullptr;       // RCCL communicator created by ffvd_comm_init (owned by the handle), else null
     int comm_world = 1, comm_rank = 0;
+    double *tsbuf = nullptr;    // T-shard exchange buffer: [nbatch][(Mp+1) x Mp] raw Gram tiles + delta^T K_fu rows, then [S][8] chain sums
+    int64_t ts_count = 0;
     double *stage = nullptr;    // staging buffer of ffvd_allreduce_sum
     int64_t stage_count = 0;
     bool info_pending = false;  // an ffvd_elbo_async was enqueued whose Cholesky info flags nobody has looked at yet
@@ -301,7 +303,15 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
         }
     }
     HIP_TRY(dev_alloc(h, &h->hterms, (size_t)h->nbatch * 2));
-    HIP_TRY(dev_alloc(h, &h->chain_terms, (size_t)c.S_local * 8));
+    if (c.T_total > 0) {        // the chain sums live at the tail of the exchange buffer: one all-reduce covers both
+        h->cpp = c.S_local;
+        const size_t raw = (size_t)h->nbatch * (Mp + 1) * Mp;
+        h->ts_count = (int64_t)(raw + (size_t)c.S_local * 8);
+        HIP_TRY(dev_alloc(h, &h->tsbuf, (size_t)h->ts_count));
+        HIP_TRY(hipMemsetAsync(h->tsbuf, 0, (size_t)h->ts_count * sizeof(double), h->stream));   // tiles above the diagonal stay 0
+        h->chain_terms = h->tsbuf + raw;
+    } else
+        HIP_TRY(dev_alloc(h, &h->chain_terms, (size_t)c.S_local * 8));
     HIP_TRY(dev_alloc(h, &h->chain_partial, (size_t)c.S_local * 32));
     {
         const size_t nS = (size_t)(c.S_local ? c.S_local : 1), ninfo = (size_t)(Dl + h->nbatch);
@@ -368,6 +378,11 @@ extern "C" int ffvd_create(const ffvd_config *cfg, ffvd_handle **out) {
         return set_error(nullptr, FFVD_EINVAL, "ffvd_create: grad = 1 in the explicit-U branch needs P = D + C <= 6");
     if (cfg->route == FFVD_ROUTE_GRAM && cfg->branch != FFVD_BRANCH_B)
         return set_error(nullptr, FFVD_EINVAL, "ffvd_create: FFVD_ROUTE_GRAM only applies to the collapsed-U branch");
+    if (cfg->T_total < 0 || cfg->t_begin < 0 || (cfg->T_total > 0 && cfg->t_begin + cfg->T > cfg->T_total))
+        return set_error(nullptr, FFVD_EINVAL, "ffvd_create: T-shard [t_begin, t_begin + T) outside [0, T_total)");
+    if (cfg->T_total > 0 && (cfg->branch != FFVD_BRANCH_B || cfg->route != FFVD_ROUTE_GRAM || cfg->dtype != FFVD_F64 || cfg->grad))
+        return set_error(nullptr, FFVD_EINVAL,
+                         "ffvd_create: a T-shard (T_total > 0) is the collapsed-U branch on FFVD_ROUTE_GRAM in fp64, without gradient");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || cfg->device_id < 0 || cfg->device_id >= ndev) {
         snprintf(msg, sizeof msg, "ffvd_create: device %d not available (%d HIP devices visible)", cfg->device_id, ndev);
@@ -1946,6 +1961,139 @@ extern "C" int ffvd_op_pg_sweep(int kind, const double *Lm_inverse_seq, const do
     HIP_TRY(hipMemcpyAsync(idx, didx, (size_t)steps * R * sizeof(int32_t), hipMemcpyDeviceToHost, sc.stream));
     HIP_TRY(hipStreamSynchronize(sc.stream));
     return FFVD_OK;
+}
+
+// ---- T-shard fallback (include/ffvd_abi.h "T-shard") ------------------------------------------------------
+static int tshard_ready(ffvd_handle *h, const char *who) {
+    if (!h) return set_error(nullptr, FFVD_EINVAL, std::string(who) + ": null handle");
+    if (h->cfg.T_total <= 0) return set_error(h, FFVD_EINVAL, std::string(who) + ": the handle is not a T-shard (cfg.T_total = 0)");
+    return ready(h, who);
+}
+
+// this shard's rows: raw Gram tiles K_uf K_fu + delta^T K_fu rows into the exchange buffer, likelihood / transition /
+// trace sums into its tail.  The K_uu chain (identical on every rank) runs first on the same stream.
+static int enqueue_tshard_local(ffvd_handle *h) {
+    const ffvd_config &c = h->cfg;
+    const int Mp = h->Mp, Tp = h->Tp, Dl = h->Dl, P = h->P;
+    hipStream_t s = h->stream;
+    const ffvd_params &p = h->cur;
+    const size_t msq = (size_t)Mp * Mp, kstride = 2 * msq;
+    launch_prep_hypers(s, c.kernel_kind, p.Z, c.M, Mp, P, Dl, c.d_begin, p.logvariance, p.loglengthscales, h->variance, h->len,
+                       h->Zs, h->zz, h->info, Dl + h->nbatch);
+    HyperView hv{h->variance, h->len, h->Zs, h->zz};
+    launch_kuu_build(s, c.kernel_kind, hv, c.M, Mp, P, Dl, c.jitter, h->Kuu, h->Kcopy);
+    launch_potrf_ext(s, h->Kuu, Mp, Mp, Mp, Dl, kstride, h->info, h->dinvK);
+    launch_transpose(s, h->Kuu + msq, kstride, h->Linv, msq, Mp, Dl);
+    GramArgs gk{};
+    gk.mode = GRAM_PLAIN; gk.A = h->Linv; gk.a_stride = msq; gk.rows = Mp; gk.with_row = 0; gk.Mp = Mp; gk.Dl = Dl;
+    gk.d_begin = c.d_begin; gk.b0 = 0; gk.nb = Dl; gk.yn_over_batch = 1.0; gk.H = h->Kinv; gk.h_stride = msq;
+    launch_gram(s, gk);                                                     // K^-1 = L^-T L^-1
+    launch_h_finish(s, h->Kuu, Mp, kstride, Dl, h->kterms);                 // log|K|
+    ProjectArgs pa{};
+    pa.kind = c.kernel_kind;
+    pa.x = p.X; pa.x_chain_stride = (size_t)(c.T + 1) * c.D; pa.x_ld = c.D; pa.x_cols = c.D;
+    pa.ctrl = h->ctrl; pa.T = c.T; pa.Tp = Tp; pa.C = c.C; pa.P = P; pa.M = c.M; pa.Mp = Mp; pa.Dl = Dl;
+    pa.d_begin = c.d_begin; pa.hv = hv; pa.b0 = 0; pa.nb = h->nbatch; pa.F = h->F; pa.ng = h->ng;
+    launch_kfu_build(s, pa);
+    GramArgs gr{};
+    gr.mode = GRAM_PLAIN; gr.A = h->F; gr.a_stride = (size_t)Tp * Mp; gr.rows = Tp; gr.with_row = 1; gr.brow = Mp;
+    gr.X = p.X; gr.log_Q = p.log_Q; gr.T = c.T; gr.D = c.D; gr.Mp = Mp; gr.Dl = Dl; gr.d_begin = c.d_begin; gr.b0 = 0;
+    gr.nb = h->nbatch; gr.yn_over_batch = 1.0; gr.H = h->tsbuf; gr.h_stride = (size_t)(Mp + 1) * Mp;
+    if (h->gpart) { gr.ksplit = h->gsplit; gr.part = h->gpart; }
+    launch_gram(s, gr);                                                     // raw sum over this shard's rows
+    ReduceArgs ra{};
+    ra.kind = c.kernel_kind; ra.branch = c.branch; ra.X = p.X; ra.ctrl = h->ctrl; ra.Y = h->Y;
+    ra.log_Q = p.log_Q; ra.CC = p.CC; ra.DD = p.DD; ra.log_Rchols = p.log_Rchols; ra.variance = h->variance;
+    ra.T = c.T; ra.Tp = Tp; ra.D = c.D; ra.C = c.C; ra.Ydim = c.Ydim; ra.Dl = Dl; ra.d_begin = c.d_begin;
+    ra.S = c.S_local; ra.ng = h->ng; ra.shared_terms = c.shared_terms;
+    ra.xk = p.X; ra.xk_chain_stride = (size_t)(c.T + 1) * c.D; ra.xk_ld = c.D; ra.xk_cols = c.D;
+    ra.rowsq = nullptr; ra.fmean = h->fmean; ra.chain_terms = h->chain_terms;
+    ra.skip_x0 = c.t_begin > 0;
+    launch_chain_reduce(s, ra, h->chain_partial);
+    HIP_TRY(hipGetLastError());
+    return FFVD_OK;
+}
+
+// on the all-reduced sums: A = K_uu + K_uf K_fu / Q, the trace partials, Cholesky(A), the solve, the assembly
+static int enqueue_tshard_finish(ffvd_handle *h) {
+    const ffvd_config &c = h->cfg;
+    const int Mp = h->Mp, Dl = h->Dl, P = h->P;
+    hipStream_t s = h->stream;
+    const ffvd_params &p = h->cur;
+    const size_t msq = (size_t)Mp * Mp;
+    GramArgs ga{};
+    ga.mode = GRAM_KFU; ga.rows = h->Tp; ga.with_row = 1; ga.brow = Mp;
+    ga.X = p.X; ga.log_Q = p.log_Q; ga.T = c.T; ga.D = c.D; ga.Mp = Mp; ga.Dl = Dl; ga.d_begin = c.d_begin; ga.b0 = 0;
+    ga.nb = h->nbatch; ga.yn_over_batch = 1.0; ga.H = h->H; ga.h_stride = (size_t)(Mp + NB) * Mp;
+    ga.Kadd = h->Kcopy; ga.kadd_stride = msq; ga.Kinv = h->Kinv; ga.kinv_stride = msq; ga.trpart = h->trpart;
+    ga.part = h->tsbuf; ga.ksplit = 1;
+    launch_gram(s, ga, 4);
+    launch_potrf_ext(s, h->H, Mp, NB, 0, h->nbatch, ga.h_stride, h->info + Dl, h->dinvH);
+    launch_h_finish(s, h->H, Mp, ga.h_stride, h->nbatch, h->hterms);
+    FinalizeArgs fa{};
+    fa.kind = c.kernel_kind; fa.branch = c.branch; fa.prior_type = c.prior_type; fa.shared_terms = c.shared_terms;
+    fa.T = c.T_total;                                   // every /T of dgp_model.py:261-297 is the whole job's
+    fa.D = c.D; fa.P = P; fa.M = c.M; fa.Ydim = c.Ydim; fa.Dl = Dl; fa.d_begin = c.d_begin;
+    fa.S = c.S_local; fa.Z = p.Z; fa.U = p.U; fa.logvar = p.logvariance; fa.loglen = p.loglengthscales;
+    fa.log_Q = p.log_Q; fa.CC = p.CC; fa.DD = p.DD; fa.log_Rchols = p.log_Rchols;
+    fa.chain_terms = h->chain_terms; fa.hterms = h->hterms; fa.chain_nll = h->chain_nll;
+    fa.route = 1; fa.kterms = h->kterms; fa.trpart = h->trpart; fa.ntiles = h->ntiles;
+    fa.out_terms = h->out_terms;
+    launch_finalize(s, fa);
+    HIP_TRY(hipGetLastError());
+    return FFVD_OK;
+}
+
+extern "C" int64_t ffvd_tshard_count(const ffvd_handle *h) { return h ? h->ts_count : 0; }
+
+extern "C" int ffvd_tshard_local(ffvd_handle *h) {
+    int rc;
+    if ((rc = tshard_ready(h, "ffvd_tshard_local"))) return rc;
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    return enqueue_tshard_local(h);
+}
+
+extern "C" int ffvd_tshard_get(ffvd_handle *h, double *host_out) {
+    int rc;
+    if ((rc = tshard_ready(h, "ffvd_tshard_get"))) return rc;
+    if (!host_out) return set_error(h, FFVD_EINVAL, "ffvd_tshard_get: null output");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    HIP_TRY(hipMemcpyAsync(host_out, h->tsbuf, (size_t)h->ts_count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return FFVD_OK;
+}
+
+extern "C" int ffvd_tshard_set(ffvd_handle *h, const double *host_in) {
+    int rc;
+    if ((rc = tshard_ready(h, "ffvd_tshard_set"))) return rc;
+    if (!host_in) return set_error(h, FFVD_EINVAL, "ffvd_tshard_set: null input");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    HIP_TRY(hipMemcpyAsync(h->tsbuf, host_in, (size_t)h->ts_count * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return FFVD_OK;
+}
+
+extern "C" int ffvd_tshard_finish(ffvd_handle *h, double out_terms[8], double *out_nll) {
+    int rc;
+    if ((rc = tshard_ready(h, "ffvd_tshard_finish"))) return rc;
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    if ((rc = enqueue_tshard_finish(h))) return rc;
+    HIP_TRY(hipMemcpyAsync(h->h_res, h->resblk, h->res_bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if ((rc = check_info(h))) return rc;
+    if (out_terms) memcpy(out_terms, h->h_out, 8 * sizeof(double));
+    if (out_nll) *out_nll = h->h_out[FFVD_TERM_NLL] / (double)h->cfg.S_local;
+    return FFVD_OK;
+}
+
+extern "C" int ffvd_allreduce_sum_async(ffvd_handle *h, void *rccl_comm, double *buf_dev, int64_t count);
+extern "C" int ffvd_elbo_tshard(ffvd_handle *h, void *rccl_comm, double out_terms[8], double *out_nll) {
+    int rc;
+    if ((rc = tshard_ready(h, "ffvd_elbo_tshard"))) return rc;
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    if ((rc = enqueue_tshard_local(h))) return rc;
+    if ((rc = ffvd_allreduce_sum_async(h, rccl_comm, h->tsbuf, h->ts_count))) return rc;      // the ONE exchange step
+    return ffvd_tshard_finish(h, out_terms, out_nll);
 }
 
 // ---- native RCCL collectives (SURVEY 8b `ffvd_elbo_allreduce(h, rccl_comm)`, 8e) ---------------------------------

@@ -7,7 +7,8 @@
 namespace ffvd {
 
 constexpr int NB = 64;        // universal block size: M is padded to a multiple of NB (identity padding)
-constexpr int DINV_STRIDE = 4 * 16 * 16;   // Cholesky scratch per matrix: inverses of the four 16x16 diagonal sub-blocks
+constexpr int DINV_STRIDE = 2 * 4 * 16 * 16;   // Cholesky scratch per matrix: inverses of the four 16x16 diagonal sub-blocks of the current
+                                               // block step, two slots (the look-ahead of step j writes slot (j+1)&1 while step j reads slot j&1)
 constexpr int STRIP = 64;     // rows of K_fu handled by one workgroup of the projection kernel
 constexpr int MAXP = 32;      // largest GP input dimension P = D + C supported by the LDS layout
 
@@ -112,7 +113,8 @@ int gram_ntiles(int Mp);
 // how many row ranges launch_gram should use for `nb` units (1 = no split), and the doubles `part` then needs
 int gram_ksplit(int Mp, int nb, int rows);
 size_t gram_part_doubles(int Mp, int nb, int ksplit);
-// phase 0: everything; 1: tile pass only; 2: combine pass only; 3: trace-only combine pass (split-K launches)
+// phase 0: everything; 1: tile pass only; 2: combine pass only; 3: trace-only combine pass (split-K launches);
+// 4: combine pass (epilogue + trace) over `part` whatever ksplit is (T-shards: the all-reduced raw tiles, ksplit = 1)
 void launch_gram(hipStream_t stream, GramArgs a, int phase = 0);
 
 // hterms[b] = { logdet(H) = 2 sum log diag(L_H),  b^T H^{-1} b = |row Mp|^2 } after launch_potrf_ext on H.
@@ -130,6 +132,7 @@ struct ReduceArgs {
     int xk_ld, xk_cols;
     const double *rowsq, *fmean;   // [S*Dl][ng][Tp]
     double *chain_terms;           // [S][8] partial sums per chain
+    int skip_x0;                   // T-shards other than the first: X[0] is not the job's x_0, leave prior_x_0 out
 };
 // partial: scratch of S * 8 * 4 doubles
 void launch_chain_reduce(hipStream_t stream, const ReduceArgs &a, double *partial);

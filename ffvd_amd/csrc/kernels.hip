@@ -24,6 +24,7 @@
 namespace ffvd {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
 
 // D(16x16) += A(16x4) * B(4x16).  Lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15];
 // it owns D[(l >> 4) + 4 r][l & 15] in element r of the accumulator.
@@ -660,37 +661,43 @@ __global__ __launch_bounds__(256) void potrf_trail_kernel(double *A, int n, int 
 
 // ---------------------------------------------------------------------------------------------
 // Left-looking block column (the default since round 2; north_star: "blocked left-looking Cholesky with wavefront-level
-// trsm").  ONE launch per block column j, one workgroup per 64-row block r of that column (main rows j..nb-1 and the
-// live extra-row blocks), no dependency between the workgroups of a launch:
-//     S_jj   = A(j,j) - sum_{k<j} L(j,k) L(j,k)^T       every workgroup forms and factorises it itself (the 64-pivot
-//                                                       chain is latency, not work: redundant copies run side by side)
-//     X(r,j) = (A(r,j) - sum_{k<j} X(r,k) L(j,k)^T) L_jj^-T    blocked substitution on the matrix cores
+// trsm").  After potrf_diag_kernel has factorised block (0,0): ONE launch per block column j, one workgroup per
+// 64-row block r below the diagonal (main rows j+1..nb-1 and the live extra-row blocks), no dependency between the
+// workgroups of a launch:
+//     X(r,j) = (A(r,j) - sum_{k<j} X(r,k) L(j,k)^T) L_jj^-T        gathered from the finished block columns, then a
+//                                                                  blocked substitution on the matrix cores
+// and the workgroup of row j+1 goes on (look-ahead): it also sums X(j+1,k) X(j+1,k)^T over k <= j, factorises
+// S = A(j+1,j+1) - sum in its first wavefront and publishes L_{j+1,j+1} for the next launch.
 // Each block of the matrix is written ONCE (the right-looking variant re-reads and re-writes the whole trailing matrix at
-// every step: 1.4 GB of tile traffic per factorisation of the 128 A-matrices of config 2 against 0.64 GB here, and two
-// dependent launches per step instead of one).  Both operand tiles of step k sit in LDS whole (stride 66: conflict-free
-// fragment reads), the global loads of step k+1 are issued before the MFMAs of step k.
+// every step: 1.4 GB of tile traffic per factorisation of the 128 A-matrices of config 2 against 0.64 GB here) and a
+// step is one launch instead of two.  Both operand tiles of step k sit in LDS whole (stride 66: conflict-free fragment
+// reads); the global loads of step k+1 are issued before the MFMAs of step k.
+// A first draft let EVERY workgroup factorise S_jj itself (no look-ahead, no diagonal launch): each workgroup then holds
+// its slot for the 13 us pivot chain and the 5632 workgroup executions of one 128-matrix factorisation took 1.14 ms
+// against the right-looking 0.63 ms.
 // ---------------------------------------------------------------------------------------------
 constexpr int LL_LD = NB + 2;
 template <bool PIPE>
 __global__ __launch_bounds__(256) void potrf_ll_kernel(double *A, int n, int j, int nmain, int nchunks, size_t slab_stride,
-                                                       int32_t *info, int nlive, int nid, int batch) {
-    __shared__ double sm0[NB * LL_LD];      // X(r,k) tiles, later S_jj / the factor tile Lr (then -L with a clean upper triangle)
-    __shared__ double sm1[NB * LL_LD];      // L(j,k) tiles, later T = A(r,j) - sum
+                                                       int32_t *info, int nlive, int nid, int batch, double *dinv) {
+    __shared__ double sm0[NB * LL_LD];      // X(r,k) tiles; then T = A(r,j) - sum and the solved X(r,j)
+    __shared__ double sm1[NB * LL_LD];      // L(j,k) tiles; then -L_jj; then (look-ahead) S_{j+1,j+1} and its factor
     __shared__ double invd[NB];
     __shared__ double Dv[4][16][DV_LD];
-    // XCD-aware: all workgroups of one matrix share blockIdx % 8, i.e. one XCD's L2 (they all read row block j)
-    const int id = blockIdx.x, xcd = id & 7, loc = id >> 3;
-    const int b = (loc / nchunks) * 8 + xcd;
+    // chunk-major order: the look-ahead workgroups (chunk 0) of ALL matrices are dispatched first -- their pivot chain is
+    // the tail of the launch.  XCD-aware: the batch is padded to a multiple of 8, so all workgroups of one matrix share
+    // blockIdx % 8, i.e. one XCD's L2 (they all read row block j).
+    const int bpad = (int)(gridDim.x / nchunks);
+    const int chunk = blockIdx.x / bpad, b = blockIdx.x % bpad;
     if (b >= batch) return;
-    const int chunk = loc % nchunks;
     const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qr = wave >> 1, qc = wave & 1;
     double *S = A + (size_t)b * slab_stride;
     const int j0 = j * NB;
-    const bool is_diag = (chunk == 0);
+    const bool look = (chunk == 0 && nmain > 0);        // row block j + 1: also factorises the next diagonal block
     int row0, k0 = 0;                       // first row of this workgroup's block; first block column with non-zero X(r,k)
-    if (chunk < nmain) row0 = (j + chunk) * NB;
+    if (chunk < nmain) row0 = (j + 1 + chunk) * NB;
     else {
         const int e = extra_block(chunk - nmain, nlive, nid);
         row0 = n + e * NB;
@@ -698,8 +705,8 @@ __global__ __launch_bounds__(256) void potrf_ll_kernel(double *A, int n, int j, 
     }
     double (*Xs)[LL_LD] = reinterpret_cast<double(*)[LL_LD]>(sm0);
     double (*Ls)[LL_LD] = reinterpret_cast<double(*)[LL_LD]>(sm1);
-    // the two output tiles are requested first: their latency hides behind the whole k loop
-    d4 cold_d[2][2], cold_t[2][2];
+    // the output tile(s) are requested first: their latency hides behind the whole k loop
+    d4 cold_t[2][2], cold_d[2][2];
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -707,8 +714,8 @@ __global__ __launch_bounds__(256) void potrf_ll_kernel(double *A, int n, int j, 
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const size_t rr = (size_t)(qr * 32 + 16 * x + lk + 4 * q), cc = (size_t)(qc * 32 + 16 * y + lr);
-                cold_d[x][y][q] = S[(j0 + rr) * n + j0 + cc];
-                cold_t[x][y][q] = is_diag ? 0.0 : S[(row0 + rr) * n + j0 + cc];
+                cold_t[x][y][q] = S[(row0 + rr) * n + j0 + cc];
+                cold_d[x][y][q] = look ? S[(row0 + rr) * n + row0 + cc] : 0.0;
             }
     d4 acc_t[2][2], acc_d[2][2];
 #pragma unroll
@@ -717,102 +724,74 @@ __global__ __launch_bounds__(256) void potrf_ll_kernel(double *A, int n, int j, 
         for (int y = 0; y < 2; ++y) { acc_t[x][y] = (d4){0.0, 0.0, 0.0, 0.0}; acc_d[x][y] = (d4){0.0, 0.0, 0.0, 0.0}; }
     // staging: thread moves 16 bytes of rows (tid >> 5) + 8 i, columns 2 (tid & 31) of each operand
     const int sr = tid >> 5, sc = 2 * (tid & 31);
-    double2 vx[8], vl[8];
+    d2 vx[8], vl[8];
     auto gload = [&](int k) {
-        const bool need_x = !is_diag && k >= k0;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            vl[i] = *reinterpret_cast<const double2 *>(S + (size_t)(j0 + sr + 8 * i) * n + k * NB + sc);
-            if (need_x) vx[i] = *reinterpret_cast<const double2 *>(S + (size_t)(row0 + sr + 8 * i) * n + k * NB + sc);
+            vl[i] = *reinterpret_cast<const d2 *>(S + (size_t)(j0 + sr + 8 * i) * n + k * NB + sc);
+            vx[i] = *reinterpret_cast<const d2 *>(S + (size_t)(row0 + sr + 8 * i) * n + k * NB + sc);
         }
     };
-    auto lstore = [&](int k) {
-        const bool need_x = !is_diag && k >= k0;
+    auto lstore = [&]() {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             Ls[sr + 8 * i][sc] = vl[i].x; Ls[sr + 8 * i][sc + 1] = vl[i].y;
-            if (need_x) { Xs[sr + 8 * i][sc] = vx[i].x; Xs[sr + 8 * i][sc + 1] = vx[i].y; }
+            Xs[sr + 8 * i][sc] = vx[i].x; Xs[sr + 8 * i][sc + 1] = vx[i].y;
         }
     };
-    if (j > 0) gload(0);
-    for (int k = 0; k < j; ++k) {
-        if (k) __syncthreads();                     // everyone is done reading the previous tiles
-        lstore(k);
+    const bool do_d = look && !(qr == 0 && qc == 1);    // the quadrant above the diagonal of S is never read
+    if (k0 < j) gload(k0);
+    for (int k = k0; k < j; ++k) {
+        if (k > k0) __syncthreads();                // everyone is done reading the previous tiles
+        lstore();
         __syncthreads();
         if (k + 1 < j) gload(k + 1);                // in flight behind this step's MFMAs
-        const bool do_t = !is_diag && k >= k0;
-        const bool do_d = !(qr == 0 && qc == 1);    // the quadrant above the diagonal of S_jj is never read
 #pragma unroll 4
         for (int ks = 0; ks < NB / 4; ++ks) {
-            double bl[2], al[2], ax[2];
+            double bl[2], ax[2], bx[2];
 #pragma unroll
             for (int x = 0; x < 2; ++x) {
                 bl[x] = Ls[qc * 32 + 16 * x + lr][4 * ks + lk];        // B[k][col] = L(j,k)[col][k]
-                al[x] = Ls[qr * 32 + 16 * x + lr][4 * ks + lk];
-                ax[x] = do_t ? Xs[qr * 32 + 16 * x + lr][4 * ks + lk] : 0.0;
+                ax[x] = Xs[qr * 32 + 16 * x + lr][4 * ks + lk];
+                bx[x] = do_d ? Xs[qc * 32 + 16 * x + lr][4 * ks + lk] : 0.0;
             }
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y) acc_t[x][y] = mfma_f64(ax[x], bl[y], acc_t[x][y]);
             if (do_d) {
 #pragma unroll
                 for (int x = 0; x < 2; ++x)
 #pragma unroll
-                    for (int y = 0; y < 2; ++y) acc_d[x][y] = mfma_f64(al[x], bl[y], acc_d[x][y]);
-            }
-            if (do_t) {
-#pragma unroll
-                for (int x = 0; x < 2; ++x)
-#pragma unroll
-                    for (int y = 0; y < 2; ++y) acc_t[x][y] = mfma_f64(ax[x], bl[y], acc_t[x][y]);
+                    for (int y = 0; y < 2; ++y) acc_d[x][y] = mfma_f64(ax[x], bx[y], acc_d[x][y]);
             }
         }
     }
-    if (j > 0) __syncthreads();
-    // S_jj into sm0 (input tile of the factorisation, stride NB + 1), T into sm1 (stride LL_LD)
-    double (*Ts)[NB + 1] = reinterpret_cast<double(*)[NB + 1]>(sm0);
-    double (*Lr)[LR_LD] = reinterpret_cast<double(*)[LR_LD]>(sm0);
-    static_assert(LR_LD == LL_LD, "factor tile and staging tile share the stride");
+    if (k0 < j) __syncthreads();
+    // T into sm0; -L_jj (exactly zero above the diagonal: the refinement step reads the diagonal blocks) into sm1; the
+    // inverted 16 x 16 diagonal sub-blocks of L_jj, left in the scratch block by the workgroup that factorised it
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
         for (int y = 0; y < 2; ++y)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int rr = qr * 32 + 16 * x + lk + 4 * q, cc = qc * 32 + 16 * y + lr;
-                Ts[rr][cc] = cold_d[x][y][q] - acc_d[x][y][q];
-                if (!is_diag) Ls[rr][cc] = cold_t[x][y][q] - acc_t[x][y][q];
-            }
-    __syncthreads();
-    if (wave == 0) {
-        double a[NB];
+            for (int q = 0; q < 4; ++q)
+                Xs[qr * 32 + 16 * x + lk + 4 * q][qc * 32 + 16 * y + lr] = cold_t[x][y][q] - acc_t[x][y][q];
 #pragma unroll
-        for (int c = 0; c < NB; ++c) a[c] = Ts[lane][c];
-        const int bad = chol64_1w<PIPE>(a, Lr, invd, lane);       // Lr overlays Ts: the whole input is in registers first
-        if (bad && is_diag && lane == 0 && info[b] == 0) info[b] = j0 + bad;
+    for (int i = 0; i < 8; ++i) {
+        const int r = sr + 8 * i;
+        const d2 v = *reinterpret_cast<const d2 *>(S + (size_t)(j0 + r) * n + j0 + sc);
+        Ls[r][sc] = (sc <= r) ? -v.x : 0.0;
+        Ls[r][sc + 1] = (sc + 1 <= r) ? -v.y : 0.0;
     }
-    __syncthreads();
-    if (is_diag) {                                  // this workgroup owns the diagonal block: publish L_jj, done
-        for (int r = tid >> 6; r < NB; r += 4)
-            if (lane <= r) S[(size_t)(j0 + r) * n + j0 + lane] = Lr[r][lane];
-        return;
-    }
-    // inverses of the four 16 x 16 diagonal sub-blocks of L_jj (lane = column, 16-step forward substitution)
-    if (lane < 16) {
-        const int o = 16 * wave;
-        double xv[16];
+    {
+        // slot j & 1: the look-ahead workgroup of THIS launch writes the other slot while late workgroups still read this one
+        const double *dv = dinv + (size_t)b * DINV_STRIDE + (j & 1) * (DINV_STRIDE / 2);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            double acc = (lane == r) ? 1.0 : 0.0;
-#pragma unroll
-            for (int i = 0; i < r; ++i) acc -= Lr[o + r][o + i] * xv[i];
-            xv[r] = acc * invd[o + r];
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i;
+            Dv[e >> 8][(e >> 4) & 15][e & 15] = dv[e];
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) Dv[wave][r][lane] = xv[r];
-    }
-    __syncthreads();
-    // -L_jj with an exactly zero upper triangle, in place (the substitution's refinement step reads the diagonal blocks)
-    for (int idx = tid; idx < NB * NB; idx += 256) {
-        const int r = idx >> 6, c = idx & 63;
-        Lr[r][c] = (c <= r) ? -Lr[r][c] : 0.0;
     }
     __syncthreads();
     // X(r,j) = T L_jj^-T: wavefront w owns rows 16w..16w+15, the four transposed 16 x 16 blocks in the MFMA accumulator
@@ -822,7 +801,7 @@ __global__ __launch_bounds__(256) void potrf_ll_kernel(double *A, int n, int j, 
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Rt[s4][r] = Ls[16 * wave + lr][16 * s4 + 4 * r + lk];
+        for (int r = 0; r < 4; ++r) Rt[s4][r] = Xs[16 * wave + lr][16 * s4 + 4 * r + lk];
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
         d4 x = (d4){0.0, 0.0, 0.0, 0.0};
@@ -830,44 +809,92 @@ __global__ __launch_bounds__(256) void potrf_ll_kernel(double *A, int n, int j, 
         for (int ks = 0; ks < 4; ++ks) x = mfma_f64(Dv[s4][lr][4 * ks + lk], Rt[s4][ks], x);
         d4 res = Rt[s4];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) res = mfma_f64(Lr[16 * s4 + lr][16 * s4 + 4 * ks + lk], x[ks], res);
+        for (int ks = 0; ks < 4; ++ks) res = mfma_f64(Ls[16 * s4 + lr][16 * s4 + 4 * ks + lk], x[ks], res);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) x = mfma_f64(Dv[s4][lr][4 * ks + lk], res[ks], x);
         Rt[s4] = x;
 #pragma unroll
         for (int t = s4 + 1; t < 4; ++t)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) Rt[t] = mfma_f64(Lr[16 * t + lr][16 * s4 + 4 * ks + lk], x[ks], Rt[t]);
+            for (int ks = 0; ks < 4; ++ks) Rt[t] = mfma_f64(Ls[16 * t + lr][16 * s4 + 4 * ks + lk], x[ks], Rt[t]);
     }
     double *Rl = S + (size_t)(row0 + 16 * wave + lr) * n + j0 + lk;
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
         for (int r = 0; r < 4; ++r) Rl[16 * s4 + 4 * r] = Rt[s4][r];
+    if (!look) return;
+    // look-ahead: S = A(j+1,j+1) - sum_{k<=j} X(j+1,k) X(j+1,k)^T; the newest term comes from the tile just solved
+    // (each wavefront rewrites its own 16 rows of sm0, which it alone has read)
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Xs[16 * wave + lr][16 * s4 + 4 * r + lk] = Rt[s4][r];
+    __syncthreads();
+    if (do_d) {
+#pragma unroll 4
+        for (int ks = 0; ks < NB / 4; ++ks) {
+            double ax[2], bx[2];
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                ax[x] = Xs[qr * 32 + 16 * x + lr][4 * ks + lk];
+                bx[x] = Xs[qc * 32 + 16 * x + lr][4 * ks + lk];
+            }
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y) acc_d[x][y] = mfma_f64(ax[x], bx[y], acc_d[x][y]);
+        }
+    }
+    double (*Ts)[NB + 1] = reinterpret_cast<double(*)[NB + 1]>(sm1);     // -L_jj is no longer needed (all past the solve:
+    double (*Lr)[LR_LD] = reinterpret_cast<double(*)[LR_LD]>(sm1);        //  the barrier above)
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                Ts[qr * 32 + 16 * x + lk + 4 * q][qc * 32 + 16 * y + lr] = cold_d[x][y][q] - acc_d[x][y][q];
+    __syncthreads();
+    diag_block_finish<PIPE>(Ts, Lr, invd, S, n, j0 + NB, info + b, dinv + (size_t)b * DINV_STRIDE + ((j + 1) & 1) * (DINV_STRIDE / 2));
 }
 
-static bool chol_right_looking() {          // diagnostic switch, read once per process: FFVD_CHOL_RIGHT=1 = the round-1 variant
-    static const bool v = [] { const char *e = getenv("FFVD_CHOL_RIGHT"); return e && *e && *e != '0'; }();
+// Which blocked variant factorises a batch: the left-looking column kernel pays off where the right-looking one is
+// bandwidth-bound (many matrices: every block written once), the right-looking one where the factorisation is a pure
+// latency chain (few matrices: one block product on the critical path of a step instead of j, and workgroups small enough
+// to slip in beside the Gram kernel when the chain runs on the side stream).  FFVD_CHOL=left|right forces one (read once).
+static int chol_mode() {                    // 0 = auto, 1 = left-looking always, 2 = right-looking always
+    static const int v = [] {
+        const char *e = getenv("FFVD_CHOL");
+        if (!e) return 0;
+        return (e[0] == 'l') ? 1 : ((e[0] == 'r') ? 2 : 0);
+    }();
     return v;
+}
+static bool chol_right_looking(int batch) {
+    const int m = chol_mode();
+    return m == 2 || (m == 0 && batch < 32);
 }
 
 void launch_potrf_ext(hipStream_t stream, double *A, int n, int extra_rows, int identity_rows, int batch,
                       size_t slab_stride, int32_t *info, double *dinv) {
     const int nb = n / NB;
     const int nid = identity_rows / NB, ntail = extra_rows / NB - nid;
-    if (!chol_right_looking()) {
+    if (!chol_right_looking(batch)) {
         const int groups = (batch + 7) / 8;
+        hipLaunchKernelGGL(potrf_diag_kernel, dim3(batch), dim3(256), 0, stream, A, n, 0, slab_stride, info, dinv);
         for (int j = 0; j < nb; ++j) {
-            const int nmain = nb - j;
+            const int nmain = nb - j - 1;
             const int nlive = (j + 1 < nid) ? j + 1 : nid;
             const int nchunks = nmain + nlive + ntail;
-            // few workgroups: the launch lasts as long as one workgroup's 64-pivot chain -> pipelined factor variant
+            if (nchunks == 0) continue;
+            // few workgroups: the launch lasts as long as the look-ahead workgroup's 64-pivot chain -> pipelined factor variant
             if ((size_t)nchunks * batch <= 512)
                 hipLaunchKernelGGL(potrf_ll_kernel<true>, dim3(groups * 8 * nchunks), dim3(256), 0, stream, A, n, j, nmain,
-                                   nchunks, slab_stride, info, nlive, nid, batch);
+                                   nchunks, slab_stride, info, nlive, nid, batch, dinv);
             else
                 hipLaunchKernelGGL(potrf_ll_kernel<false>, dim3(groups * 8 * nchunks), dim3(256), 0, stream, A, n, j, nmain,
-                                   nchunks, slab_stride, info, nlive, nid, batch);
+                                   nchunks, slab_stride, info, nlive, nid, batch, dinv);
         }
         return;
     }
@@ -1443,14 +1470,14 @@ void launch_gram(hipStream_t stream, GramArgs a, int phase) {
     if (!a.part || a.ksplit < 1) a.ksplit = 1;
     const int groups = (a.nb + 7) / 8;
     const dim3 grid(groups * 8 * a.ntiles * a.ksplit);
-    if (phase != 2 && phase != 3) {
+    if (phase != 2 && phase != 3 && phase != 4) {
         if (a.mode == GRAM_F) hipLaunchKernelGGL(gram_kernel<GRAM_F>, grid, dim3(512), 0, stream, a);
         else if (a.mode == GRAM_KFU) hipLaunchKernelGGL(gram_kernel<GRAM_KFU>, grid, dim3(512), 0, stream, a);
         else if (a.mode == GRAM_KFU_RAW) hipLaunchKernelGGL(gram_kernel<GRAM_KFU_RAW>, grid, dim3(512), 0, stream, a);
         else hipLaunchKernelGGL(gram_kernel<GRAM_PLAIN>, grid, dim3(512), 0, stream, a);
     }
     if (phase == 3) a.trace_mode = 2;
-    if ((a.ksplit > 1 && phase != 1) || phase == 3) {
+    if ((a.ksplit > 1 && phase != 1) || phase == 3 || phase == 4) {
         const dim3 cgrid(a.ntiles, a.nb);
         if (a.mode == GRAM_KFU_RAW) a.mode = GRAM_KFU;
         if (a.mode == GRAM_F) hipLaunchKernelGGL(gram_combine_kernel<GRAM_F>, cgrid, dim3(1024), 0, stream, a);
@@ -1547,7 +1574,7 @@ __global__ void chain_combine_kernel(ReduceArgs a, const double *partial) {
     double px0 = 0.0;
     for (int d = 0; d < a.D; ++d) px0 += Xs[d] * Xs[d];
     double *o = a.chain_terms + (size_t)s * 8;
-    o[0] = lik; o[1] = xq; o[2] = tr; o[3] = -px0 / 2.0;     // prior_x_0 dgp_model.py:252
+    o[0] = lik; o[1] = xq; o[2] = tr; o[3] = a.skip_x0 ? 0.0 : -px0 / 2.0;     // prior_x_0 dgp_model.py:252
 }
 void launch_chain_reduce(hipStream_t stream, const ReduceArgs &a, double *partial) {
     hipLaunchKernelGGL(chain_reduce_kernel, dim3(a.S, CR_SPLIT), dim3(256), 0, stream, a, partial);

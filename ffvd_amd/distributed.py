@@ -7,6 +7,11 @@ collective; the only exchange is one all-reduce(sum) of the 8-double partial-sum
   mode "chains": rank r evaluates chains [s_begin, s_begin + s_count) for all latent dims (BASELINE configs 2-4)
   mode "dims"  : rank r evaluates latent dims [d_begin, d_begin + d_count) for all chains; only rank 0 adds
                  the shared terms (likelihood, prior_Z, prior_x_0, hyper prior)          (BASELINE config 5)
+  mode "time"  : fallback when chains x dims < ranks (SURVEY 8e last bullet): rank r evaluates transitions
+                 [t_begin, t_begin + t_count) of every (chain, dim) unit; the exchange is ONE all-reduce of the raw
+                 Gram tiles K_uf K_fu + the per-chain sums (MiB-sized, the only link-bandwidth-bound collective of
+                 this code base), after which every rank finishes the same factorisations
+`plan(..., mode="auto")` picks chains, then dims, then time.
 """
 from __future__ import annotations
 
@@ -27,6 +32,14 @@ def shard_range(n, world, rank):
 def plan(meta, world, rank, mode="chains"):
     """Engine keyword arguments + the slice of X this rank owns."""
     S, D = meta["S"], meta["D"]
+    if mode == "auto":
+        mode = "chains" if S >= world else ("dims" if D >= world else "time")
+    if mode == "time":
+        T = meta["T"]
+        if T < world:
+            raise ValueError(f"cannot shard {T} transitions over {world} ranks")
+        t_begin, t_count = shard_range(T, world, rank)
+        return dict(s_begin=0, s_count=S, d_begin=0, d_count=D, shared_terms=True, t_begin=t_begin, t_count=t_count, mode="time")
     if mode == "chains":
         if S < world:
             raise ValueError(f"cannot shard {S} chains over {world} ranks; use mode='dims'")
@@ -37,7 +50,7 @@ def plan(meta, world, rank, mode="chains"):
             raise ValueError(f"cannot shard {D} latent dims over {world} ranks")
         d_begin, d_count = shard_range(D, world, rank)
         return dict(s_begin=0, s_count=S, d_begin=d_begin, d_count=d_count, shared_terms=(rank == 0))
-    raise ValueError("mode must be 'chains' or 'dims'")
+    raise ValueError("mode must be 'chains', 'dims', 'time' or 'auto'")
 
 
 def finish(sums8):
@@ -135,19 +148,32 @@ class ShardedElbo:
         self.always_reduce = bool(always_reduce)      # run the collective path even with one rank (tests)
         self.plan = plan(meta, world, rank, mode)
         pl = self.plan
-        self.engine = ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], pl["s_count"], Ydim=meta["Ydim"],
-                                 kernel_type=meta["kernel_type"], U_collapse=meta["U_collapse"], device=device,
-                                 d_begin=pl["d_begin"], d_count=pl["d_count"], shared_terms=pl["shared_terms"],
-                                 **engine_kw)
-        self.engine.set_data(Y, control_inputs)
-        local = dict(params)
-        local["X"] = np.ascontiguousarray(params["X"][pl["s_begin"]: pl["s_begin"] + pl["s_count"]])
-        self.engine.set_params(local)
-        self.reduces = world > 1 or self.always_reduce
+        self.time_shard = pl.get("mode") == "time"
+        if self.time_shard:
+            t0, tc = pl["t_begin"], pl["t_count"]
+            engine_kw = dict(engine_kw, route="gram", t_shard=(t0, meta["T"]))
+            self.engine = ElboEngine(tc, meta["D"], meta["C"], meta["M"], pl["s_count"], Ydim=meta["Ydim"],
+                                     kernel_type=meta["kernel_type"], U_collapse=meta["U_collapse"], device=device,
+                                     **engine_kw)
+            ci = np.asarray(control_inputs, dtype=np.float64)[t0: t0 + tc] if meta["C"] > 0 else None
+            self.engine.set_data(np.asarray(Y, dtype=np.float64)[t0: t0 + tc], ci)
+            local = dict(params)
+            local["X"] = np.ascontiguousarray(np.asarray(params["X"])[:, t0: t0 + tc + 1])
+            self.engine.set_params(local)
+        else:
+            self.engine = ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], pl["s_count"], Ydim=meta["Ydim"],
+                                     kernel_type=meta["kernel_type"], U_collapse=meta["U_collapse"], device=device,
+                                     d_begin=pl["d_begin"], d_count=pl["d_count"], shared_terms=pl["shared_terms"],
+                                     **engine_kw)
+            self.engine.set_data(Y, control_inputs)
+            local = dict(params)
+            local["X"] = np.ascontiguousarray(params["X"][pl["s_begin"]: pl["s_begin"] + pl["s_count"]])
+            self.engine.set_params(local)
+        self.reduces = world > 1 or self.always_reduce or self.time_shard
         if self.reduces and collective == "rccl":
             blob = exchange_unique_id(self.engine.comm_unique_id, rank, world, rendezvous_dir)
             self.engine.comm_init(world, rank, blob)
-        elif self.reduces:
+        elif self.reduces and not self.time_shard:
             import torch
             self.torch = torch
             self.sums = torch.zeros(8, dtype=torch.float64, device=f"cuda:{device}")
@@ -159,6 +185,14 @@ class ShardedElbo:
     def step(self):
         """One ELBO iteration: local kernels -> 8 partial sums in HBM -> all-reduce -> host.  Errors are not masked:
         a failing collective or HIP call raises; a failed factorisation on any rank raises LinAlgError."""
+        if self.time_shard:
+            if self.collective == "rccl":
+                return self.engine.elbo_tshard()
+            # host-carried exchange (test groups RCCL cannot form): partial sums -> all-reduce on the CPU -> finish
+            import torch
+            t = torch.from_numpy(self.engine.tshard_local())
+            all_reduce_sums(t)
+            return self.engine.tshard_finish(t.numpy())
         if not self.reduces:
             # nothing to reduce: the engine's own pinned-host copy of the 8 sums (one synchronisation)
             return self.engine.elbo_sums()

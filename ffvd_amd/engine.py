@@ -29,7 +29,7 @@ class ElboEngine:
 
     def __init__(self, T, D, C, M, S, Ydim=1, kernel_type="SquaredExponential", U_collapse=True,
                  prior_type="normal", device=0, d_begin=0, d_count=0, shared_terms=True,
-                 chains_per_pass=0, jitter=1e-5, route="reference", grad=False, dtype="f64"):
+                 chains_per_pass=0, jitter=1e-5, route="reference", grad=False, dtype="f64", t_shard=None):
         if kernel_type not in _lib.KERNEL_KIND:
             raise ValueError("Invalid kernel type")
         if prior_type not in _lib.PRIOR_TYPE:
@@ -40,6 +40,9 @@ class ElboEngine:
             raise ValueError("dtype must be 'f64' or 'f32c'")
         self.route = route
         self.dtype = dtype
+        # t_shard = (t_begin, T_total): this engine holds rows [t_begin, t_begin + T) of a job with T_total transitions
+        # (include/ffvd_abi.h "T-shard"); X then has T + 1 rows starting at global row t_begin
+        self.t_shard = None if t_shard is None else (int(t_shard[0]), int(t_shard[1]))
         self.grad = bool(grad)
         self.lib = _lib.load()
         self.T, self.D, self.C, self.M, self.S, self.Ydim = int(T), int(D), int(C), int(M), int(S), int(Ydim)
@@ -52,7 +55,8 @@ class ElboEngine:
             d_count=self.d_count, shared_terms=int(self.shared_terms), dtype=_lib.DTYPE[dtype],
             kernel_kind=_lib.KERNEL_KIND[kernel_type], branch=_lib.BRANCH_B if U_collapse else _lib.BRANCH_A,
             prior_type=_lib.PRIOR_TYPE[prior_type], device_id=int(device), chains_per_pass=int(chains_per_pass),
-            route=_lib.ROUTE[route], grad=int(bool(grad)), reserved=0, jitter=float(jitter))
+            route=_lib.ROUTE[route], grad=int(bool(grad)), T_total=self.t_shard[1] if self.t_shard else 0,
+            t_begin=self.t_shard[0] if self.t_shard else 0, reserved=0, jitter=float(jitter))
         self._h = ct.c_void_p()
         _lib.check(self.lib.ffvd_create(ct.byref(cfg), ct.byref(self._h)), None, "ffvd_create")
         self._keep = {}
@@ -267,6 +271,30 @@ class ElboEngine:
         nll = ct.c_double()
         _lib.check(self.lib.ffvd_elbo_allreduce(self._h, comm, _lib.dptr(out), ct.byref(nll)), self._h,
                    "ffvd_elbo_allreduce")
+        return out
+
+    # -- T-shard fallback -----------------------------------------------------------------------
+    def elbo_tshard(self, comm=None):
+        """Local rows -> ncclAllReduce of the raw Gram tiles + chain sums -> finish; returns the whole-job 8 sums."""
+        out = np.zeros(8)
+        nll = ct.c_double()
+        _lib.check(self.lib.ffvd_elbo_tshard(self._h, comm, _lib.dptr(out), ct.byref(nll)), self._h, "ffvd_elbo_tshard")
+        return out
+
+    def tshard_local(self):
+        """Enqueue this shard's partial sums and return the exchange buffer as a host array (three-step form)."""
+        _lib.check(self.lib.ffvd_tshard_local(self._h), self._h, "ffvd_tshard_local")
+        buf = np.zeros(int(self.lib.ffvd_tshard_count(self._h)))
+        _lib.check(self.lib.ffvd_tshard_get(self._h, _lib.dptr(buf)), self._h, "ffvd_tshard_get")
+        return buf
+
+    def tshard_finish(self, reduced):
+        """Upload the all-reduced exchange buffer and finish: returns the whole-job 8 sums."""
+        r = _lib.as_f64(reduced, (int(self.lib.ffvd_tshard_count(self._h)),), "reduced")
+        _lib.check(self.lib.ffvd_tshard_set(self._h, _lib.dptr(r)), self._h, "ffvd_tshard_set")
+        out = np.zeros(8)
+        nll = ct.c_double()
+        _lib.check(self.lib.ffvd_tshard_finish(self._h, _lib.dptr(out), ct.byref(nll)), self._h, "ffvd_tshard_finish")
         return out
 
     def allreduce_host(self, array, comm=None):

@@ -92,6 +92,9 @@ typedef struct ffvd_config {
     int32_t chains_per_pass; /* chains whose T x M projections are resident at once; 0 = auto */
     int32_t route;        /* FFVD_ROUTE_*  (branch B only)                          */
     int32_t grad;         /* 1: also allocate the backward-pass workspace (ffvd_elbo_grad) */
+    int32_t T_total;      /* > 0: this handle holds a T-SHARD -- rows [t_begin, t_begin + T) of a job with T_total
+                           * transitions (its X has T + 1 rows starting at global row t_begin); see ffvd_elbo_tshard */
+    int32_t t_begin;      /* first global transition of the shard (T_total > 0)     */
     int32_t reserved;
     double  jitter;       /* 1e-5: conditionals_multi_output.py:108,159             */
 } ffvd_config;
@@ -216,6 +219,22 @@ int  ffvd_elbo_allreduce_async(ffvd_handle *h, void *rccl_comm, double *out_term
 int  ffvd_allreduce_sum_async(ffvd_handle *h, void *rccl_comm, double *buf_dev, int64_t count);
 /* the same for a HOST array (staged through a device buffer the handle keeps); synchronises */
 int  ffvd_allreduce_sum(ffvd_handle *h, void *rccl_comm, double *buf_host, int64_t count);
+
+/* ---- T-shard fallback (SURVEY 8e last bullet, section 5 "long-context"): when chains x latent dims < ranks ---------
+ * T is a pure reduction axis of the collapsed bound: the Gram matrices K_uf K_fu (M x M per unit) and the rows
+ * delta^T K_fu, the likelihood and transition sums are all sums over t.  A T-shard handle (cfg.T = rows of the shard,
+ * cfg.T_total, cfg.t_begin; FFVD_BRANCH_B, FFVD_ROUTE_GRAM, FFVD_F64, no gradient; X = rows t_begin .. t_begin + T of
+ * every chain, Y / control_inputs = the shard's rows) evaluates its rows' share; ONE all-reduce(sum) of the raw Gram
+ * tiles + the per-chain partial sums (S_local * D * (M_p + 1) * M_p + 8 S_local doubles, M_p = M rounded up to 64)
+ * follows, and EVERY rank finishes the same factorisations on the reduced sums, so every rank holds the whole-job
+ * terms (out_terms[7] = S_local).  ffvd_elbo_tshard = local part + ncclAllReduce on the handle's stream + finish.
+ * The three-step form lets a host carry the buffer itself (tests: two ranks on one GPU over gloo). */
+int  ffvd_elbo_tshard(ffvd_handle *h, void *rccl_comm, double out_terms[8], double *out_nll);
+int  ffvd_tshard_local(ffvd_handle *h);                       /* enqueue this shard's partial sums               */
+int64_t ffvd_tshard_count(const ffvd_handle *h);              /* doubles in the exchange buffer                   */
+int  ffvd_tshard_get(ffvd_handle *h, double *host_out);       /* copy the exchange buffer to the host (synchronises) */
+int  ffvd_tshard_set(ffvd_handle *h, const double *host_in);  /* ... and the reduced sums back                    */
+int  ffvd_tshard_finish(ffvd_handle *h, double out_terms[8], double *out_nll);
 
 /* the handle's HIP stream (a hipStream_t), so that a collective library or another framework can order its work after
  * ffvd_elbo_async without a host synchronisation (e.g. torch.cuda.ExternalStream around the RCCL all-reduce). */

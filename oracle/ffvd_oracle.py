@@ -435,6 +435,68 @@ def nll_terms_shard(params, Y, control_inputs, d_begin, d_count, shared_terms, *
     return {k: float(v) for k, v in out.items()}
 
 
+def tshard_partial(params, Y, control_inputs, t_begin, t_count):
+    """One rank's share of the collapsed bound when the TRANSITIONS are sharded (SURVEY 8e last bullet, Appendix A Gram
+    route): everything that is a sum over t, for t in [t_begin, t_begin + t_count) -- per latent dim the Gram matrix
+    K_uf K_fu and the vector K_uf delta, and the likelihood / transition quadratic sums.  A flat vector, so that the
+    exchange is one all-reduce(sum).  Test-side stand-in for a rank's GPU engine in the CPU rehearsals."""
+    X = params["X"]
+    D = X.shape[1]
+    M = params["Z"].shape[0]
+    kern = make_kernels(params)
+    sl = slice(t_begin, t_begin + t_count)
+    c = control_inputs[sl] if control_inputs is not None and control_inputs.shape[0] > 0 else None
+    x_comb = np.concatenate((X[:-1][sl], c), axis=1) if c is not None else X[:-1][sl]
+    out = []
+    for d in range(D):
+        Kfu = kern[d].K(x_comb, params["Z"])                                   # conditionals_multi_output.py:240
+        delta = (X[1:, d] - X[:-1, d])[sl]                                     # :247
+        out += [(Kfu.T @ Kfu).ravel(), Kfu.T @ delta]
+    y_mean = predict_mean(X[1:][sl], params["CC"], params["DD"])
+    R = np.exp(params["log_Rchols"])[0]
+    lik_q = np.sum(-0.5 * np.square((Y[sl] - y_mean) / R))                    # likelihoods.py:100 without the log R part
+    Q = np.exp(params["log_Q"])
+    xq = np.sum(-0.5 * np.square((X[1:][sl] - X[:-1][sl]) / Q ** 0.5))        # likelihoods.py:91
+    out.append(np.array([lik_q, xq, float(t_count)]))
+    assert out[0].size == M * M
+    return np.concatenate(out)
+
+
+def tshard_finish(params, reduced, prior_type="normal"):
+    """The whole-job nll from the all-reduced `tshard_partial` vectors: log|H| = log|K + G/Q| - log|K|,
+    b^T H^-1 b = g^T (K + G/Q)^-1 g / Q^2, sum_t |F_t|^2 = tr(K^-1 G)  (SURVEY Appendix A), K = K_uu + 1e-5 I."""
+    X = params["X"]
+    D = X.shape[1]
+    Z = params["Z"]
+    M = Z.shape[0]
+    kern = make_kernels(params)
+    Q = np.exp(params["log_Q"])
+    lik_q, xq, T = reduced[-3:]
+    t1 = t2 = tr = 0.0
+    for d in range(D):
+        off = d * (M * M + M)
+        G = reduced[off: off + M * M].reshape(M, M)
+        g = reduced[off + M * M: off + M * M + M]
+        K = kern[d].K(Z) + JITTER_MULTI_OUTPUT * np.eye(M)
+        A = K + G / Q[d]
+        LA, LK = np.linalg.cholesky(A), np.linalg.cholesky(K)
+        logdetH = 2.0 * np.sum(np.log(np.diag(LA))) - 2.0 * np.sum(np.log(np.diag(LK)))
+        y = solve_triangular(LA, g / Q[d], lower=True)
+        t1 += -0.5 * logdetH                                                   # :253
+        t2 += 0.5 * (y @ y)                                                    # :254
+        tr += -0.5 * (T * kern[d].variance - np.trace(np.linalg.solve(K, G))) / Q[d]     # :255
+    R = np.exp(params["log_Rchols"])[0]
+    out = {}
+    out["nll_log_likelihood"] = -(lik_q - T * np.sum(np.log(R))) / T
+    out["x_t_prior_Q"] = -(xq - T * np.sum(np.log(Q ** 0.5))) / T
+    out["later_term1"], out["later_term2"], out["nll_reg_trace_inverse_Q_B"] = -t1 / T, -t2 / T, -tr / T
+    prior = (prior_hyper(kern) + prior_Z(Z, prior_type) - np.sum(np.square(X[0])) / 2.0
+             + hyperparameter_prior(params["log_Q"], params["CC"], params["DD"], params["log_Rchols"]))
+    out["nll_part_prior"] = -prior / T
+    out["nll"] = sum(out[k] for k in TERM_NAMES_B)
+    return {k: float(v) for k, v in out.items()}
+
+
 def nll_terms_chains(params, Y, control_inputs, **kw):
     """Benchmark quantity of SURVEY section 8(d): mean over S chains of nll(X_s).
 

@@ -258,7 +258,9 @@ def test_config4_shape_m2048():
     for n in TERMS_B:
         assert got[n] == pytest.approx(ref[n], rel=1e-8, abs=1e-9), (n, got[n], ref[n])
     got = run_engine(params, Y, c, meta, collapse=True, route="gram")
-    assert got["nll"] == pytest.approx(ref["nll"], rel=1e-7)
+    # Gram route at M = 2048, T = 2304: error ~ eps * cond(K_uu); the summation order of the factorisation moves the nll in
+    # the 7th digit (1.35e-7 with the left-looking variant, 0.6e-7 with the right-looking one)
+    assert got["nll"] == pytest.approx(ref["nll"], rel=3e-7)
 
 
 def test_config5_linear_kernel_dim_shards():
@@ -556,6 +558,59 @@ def test_non_finite_inputs_are_reported_not_propagated(route):
         assert np.isfinite(ok["nll"])
 
 
+@pytest.mark.parametrize("name,ov,nshard", [("small", dict(S=1, D=2), 3), ("ragged", dict(S=2, D=1), 4),
+                                             ("small_lin", dict(S=1, D=2, U_collapse=True), 2)])
+def test_time_shards_sum_to_the_single_engine_nll(name, ov, nshard):
+    """SURVEY 8e fallback (S * D < ranks): T-shard engines evaluate disjoint row ranges; their exchange buffers (raw Gram
+    tiles K_uf K_fu, delta^T K_fu rows, chain sums) are added as the all-reduce would, every shard finishes on the sum
+    and must reproduce the unsharded Gram-route nll and the oracle's.  Ragged shard sizes (T not divisible)."""
+    from ffvd_amd.distributed import shard_range
+    params, Y, c, meta = synthetic.make_named(name, **ov)
+    T, S = meta["T"], meta["S"]
+    whole = run_engine(params, Y, c, meta, collapse=True, route="gram")
+    ref = orc.nll_terms_chains(params, Y, c, U_collapse=True, kernel_type=meta["kernel_type"])
+    engines, bufs = [], []
+    try:
+        for r in range(nshard):
+            t0, tc = shard_range(T, nshard, r)
+            e = ElboEngine(tc, meta["D"], meta["C"], meta["M"], S, kernel_type=meta["kernel_type"], route="gram",
+                           t_shard=(t0, T))
+            e.set_data(Y[t0: t0 + tc], c[t0: t0 + tc])
+            e.set_params(dict(params, X=np.ascontiguousarray(params["X"][:, t0: t0 + tc + 1])))
+            engines.append(e)
+            bufs.append(e.tshard_local())
+        total = np.sum(bufs, axis=0)
+        for e in engines:
+            sums = e.tshard_finish(total)
+            assert sums[7] == S
+            assert sums[6] / S == pytest.approx(whole["nll"], rel=1e-10)
+            assert sums[6] / S == pytest.approx(ref["nll"], rel=1e-7)
+            for i, n in enumerate(TERMS_B[:-1]):
+                assert sums[i] / S == pytest.approx(whole[n], rel=1e-9, abs=1e-10), n
+    finally:
+        for e in engines:
+            e.close()
+
+
+def test_time_shard_through_native_rccl_one_rank():
+    """ffvd_elbo_tshard end to end on one rank: local rows -> ncclAllReduce of the exchange buffer on the handle's
+    stream -> finish (world 1: the collective is the identity, everything else is the real path)."""
+    from ffvd_amd.distributed import ShardedElbo, finish
+    params, Y, c, meta = synthetic.make_named("small", S=1, D=2)
+    whole = run_engine(params, Y, c, meta, collapse=True, route="gram")
+    sh = ShardedElbo(params, Y, c, meta, rank=0, world=1, mode="time", device=0)
+    try:
+        t = finish(sh.step())
+        assert finish(sh.step()) == t
+    finally:
+        sh.close()
+    assert t["nll"] == pytest.approx(whole["nll"], rel=1e-12)
+    with pytest.raises(ValueError):
+        ElboEngine(64, 2, 1, 16, 1, route="reference", t_shard=(0, 128))      # the Gram form is what makes T additive
+    with pytest.raises(ValueError):
+        ElboEngine(64, 2, 1, 16, 1, route="gram", t_shard=(100, 128))         # shard outside the job
+
+
 SHARD_WORKER = r'''
 import os, sys
 sys.path.insert(0, os.environ["FFVD_ROOT"])
@@ -565,6 +620,14 @@ from ffvd_amd.distributed import ShardedElbo, finish, all_reduce_grads
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 mode = sys.argv[1]
 dist.init_process_group("gloo", rank=rank, world_size=world)       # two processes share the one GPU: gloo moves the CUDA tensor
+if mode == "time":                                                  # S * D = 1 < world: shard the transitions
+    params, Y, c, meta = synthetic.make_named("small", S=1, D=1)
+    sh = ShardedElbo(params, Y, c, meta, rank=rank, world=world, mode="auto", device=0, collective="torch")
+    assert sh.time_shard
+    t = finish(sh.step())
+    print("RESULT", rank, repr(t["nll"]), repr(finish(sh.step())["nll"]), flush=True)
+    dist.destroy_process_group()
+    sys.exit(0)
 params, Y, c, meta = synthetic.make_named("small")
 sh = ShardedElbo(params, Y, c, meta, rank=rank, world=world, mode=mode, device=0, route="gram", grad=True, collective="torch")
 t = finish(sh.step())
@@ -612,6 +675,28 @@ def test_two_processes_share_the_gpu_and_reduce(tmp_path, mode):
         assert zsum == pytest.approx(float(np.abs(g["Z"]).sum()), rel=1e-4)
         assert nlla == pytest.approx(ta["nll"], rel=1e-12)
         assert usum == pytest.approx(float(np.abs(ga["U"]).sum()), rel=1e-9)
+
+
+def test_two_processes_time_shard(tmp_path):
+    """The T-shard fallback with two real ranks on the one GPU of the test box (S * D = 1): the exchange buffer travels
+    over gloo, both ranks end up with the single-process nll."""
+    import os
+    import subprocess
+    import sys
+    script = tmp_path / "shard_worker.py"
+    script.write_text(SHARD_WORKER)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FFVD_ROOT=root, MASTER_ADDR="127.0.0.1", MASTER_PORT="29543", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), "time"], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    params, Y, c, meta = synthetic.make_named("small", S=1, D=1)
+    whole = run_engine(params, Y, c, meta, collapse=True, route="gram")
+    for out in outs:
+        line = [l for l in out.splitlines() if l.startswith("RESULT")][0].split()
+        assert float(line[2]) == float(line[3])
+        assert float(line[2]) == pytest.approx(whole["nll"], rel=1e-12)
 
 
 def _random_shapes(n, seed):

@@ -63,6 +63,22 @@ def test_cholesky_matches_numpy(n, batch):
     np.testing.assert_allclose(L @ np.swapaxes(L, 1, 2), A, rtol=1e-12, atol=1e-11)   # factorisation property
 
 
+def test_cholesky_more_workgroups_than_the_chip_holds():
+    """3000 matrices of 4 block columns: a block-column launch has up to 12000 workgroups, far more than are resident at
+    once, so late workgroups start long after early ones have finished -- any in-place write another workgroup of the same
+    launch still reads (the diagonal block, round 2's first left-looking draft) shows up here and nowhere in the small cases."""
+    lib = _lib.load()
+    n, batch = 200, 3000
+    rng = np.random.default_rng(17)
+    B = rng.standard_normal((batch, n, n + 2))
+    A = B @ np.swapaxes(B, 1, 2) + 0.5 * np.eye(n)
+    L = np.empty_like(A)
+    info = np.zeros(batch, dtype=np.int32)
+    rc = lib.ffvd_op_cholesky(_lib.dptr(A), n, batch, _lib.dptr(L), info.ctypes.data_as(_lib.C.POINTER(_lib.C.c_int32)))
+    assert rc == 0 and not info.any()
+    np.testing.assert_allclose(L, np.linalg.cholesky(A), rtol=1e-9, atol=1e-10)
+
+
 def test_cholesky_reports_non_pd():
     lib = _lib.load()
     A = np.eye(70)[None].repeat(2, 0).copy()

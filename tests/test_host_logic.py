@@ -121,6 +121,57 @@ def test_gloo_world2_sharding(tmp_path, mode, name, port):
     assert "OK" in outs[0]
 
 
+TIME_WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["FFVD_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+from ffvd_amd import synthetic, distributed as dm
+from oracle import ffvd_oracle as orc
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+params, Y, c, meta = synthetic.make_named("tiny", S=1, D=1)      # one chain, one latent dim: S * D < world
+pl = dm.plan(meta, world, rank, "auto")
+assert pl["mode"] == "time", pl
+p = dict(params, X=params["X"][0])
+t = torch.from_numpy(orc.tshard_partial(p, Y, c, pl["t_begin"], pl["t_count"]))   # the ORACLE stands in for the GPU engine
+dm.all_reduce_sums(t)
+got = orc.tshard_finish(p, t.numpy())
+ref = orc.nll_terms(p, Y, c, U_collapse=True)
+for n, v in ref.items():
+    assert abs(got[n] - v) <= 1e-9 * max(1.0, abs(v)), (n, got[n], v)
+print("OK", got["nll"])
+dist.destroy_process_group()
+'''
+
+
+def test_gloo_world2_time_sharding(tmp_path):
+    """world_size-2 rehearsal of the T-shard fallback (S * D < ranks): partial Gram sums -> one all-reduce -> every rank
+    finishes the factorisations itself and holds the whole-job nll."""
+    import subprocess
+    script = tmp_path / "tworker.py"
+    script.write_text(TIME_WORKER)
+    env = dict(os.environ, FFVD_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29537", WORLD_SIZE="2",
+               OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "OK" in outs[0] and "OK" in outs[1]
+
+
+def test_plan_auto_picks_the_shard_axis():
+    from ffvd_amd.distributed import plan
+    assert "t_begin" not in plan(dict(S=32, D=4, T=4096), 8, 3, "auto")
+    p = plan(dict(S=1, D=16, T=4096), 8, 3, "auto")
+    assert (p["d_begin"], p["d_count"], p["shared_terms"]) == (6, 2, False)
+    p = plan(dict(S=1, D=4, T=4096), 8, 7, "auto")
+    assert p["mode"] == "time" and (p["t_begin"], p["t_count"]) == (3584, 512)
+    covered = sum(plan(dict(S=1, D=1, T=1001), 8, r, "time")["t_count"] for r in range(8))
+    assert covered == 1001
+    with pytest.raises(ValueError):
+        plan(dict(S=1, D=1, T=4), 8, 0, "time")
+
+
 GRAD_WORKER = r'''
 import os, sys
 sys.path.insert(0, os.environ["FFVD_ROOT"])
