@@ -1,9 +1,10 @@
 """Summarise rocprofv3 --pmc passes (csv output) per kernel: HBM bytes per launch and MFMA utilisation.
 
-usage: pmc_summary.py <dir_fetch> <dir_write> <dir_sq> <out_summary.txt> <out_traffic.json>
+usage: pmc_summary.py <dir_fetch> <dir_write> <dir_sq> <out_summary.txt> <traffic.json> <key> <commit> <gram_kernel_prefix> <proj_kernel_prefix>
 Conventions (MI355X_MICROARCH.md, HBM / rocprofv3 section): FETCH_SIZE / WRITE_SIZE are reported in KB; on gfx950 a wide
 coalesced read is counted as 64 B per 128-B request, so bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.  Values are those
-of the LARGEST launch of each kernel."""
+of the LARGEST launch of each kernel.  traffic.json is keyed "<workload>/<dtype>/<route>" and records the commit the
+passes ran on; bench.py only reports `roofline.traffic` for a key it finds there and names the file as the source."""
 import csv, glob, json, os, re, sys
 from collections import defaultdict
 
@@ -18,8 +19,9 @@ def load(d):
 
 
 fetch, write, sq = load(sys.argv[1]), load(sys.argv[2]), load(sys.argv[3])
-lines = ["rocprofv3 --kernel-trace --pmc <counters> --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline "
-         "(gram route); separate passes for FETCH_SIZE, WRITE_SIZE and the SQ/GRBM set",
+key, commit, gram_prefix, proj_prefix = sys.argv[6], sys.argv[7], sys.argv[8], sys.argv[9]
+lines = ["rocprofv3 --kernel-trace --pmc <counters> --output-format csv -- python3 bench.py ... (%s, commit %s); separate passes "
+         "for FETCH_SIZE, WRITE_SIZE and the SQ/GRBM set" % (key, commit),
          "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (rocprofv3 reports KB; gfx950 FETCH_SIZE counts 64 B per 128-B request "
          "for wide coalesced reads)",
          "MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs); values are those of the LARGEST "
@@ -41,10 +43,16 @@ for k in sorted(set(fetch) | set(write)):
     lines.append(s)
     traffic[k] = b
 open(sys.argv[4], "w").write("\n".join(lines) + "\n")
-# <1>: epilogue with the trace partials; <3>: raw tiles kept for the deferred trace pass (the full-batch launch since r01)
-gram = max((v for k, v in traffic.items() if k.startswith("gram_kernel<1>") or k.startswith("gram_kernel<3>")), default=None)
-kfu = max((v for k, v in traffic.items() if k.startswith("kfu_build_kernel")), default=None)
-json.dump({"gram_H": gram, "project_F": kfu,
-           "_note": "HBM bytes per launch (largest launch) = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc "
-                    "passes, see profiles/r01_pmc_summary.txt; gram route"}, open(sys.argv[5], "w"), indent=1)
+gram = max((v for k, v in traffic.items() if k.startswith(gram_prefix)), default=None)
+proj = max((v for k, v in traffic.items() if k.startswith(proj_prefix)), default=None)
+tj = {}
+if os.path.exists(sys.argv[5]):
+    try:
+        tj = json.load(open(sys.argv[5]))
+    except Exception:
+        tj = {}
+tj = {k: v for k, v in tj.items() if isinstance(v, dict)}
+tj[key] = {"gram_H": gram, "project_F": proj, "_commit": commit,
+           "_note": "HBM bytes per launch (largest launch) = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes"}
+json.dump(tj, open(sys.argv[5], "w"), indent=1)
 print("\n".join(lines))
