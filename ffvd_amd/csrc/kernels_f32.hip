@@ -145,7 +145,8 @@ void launch_linv_f32(hipStream_t stream, const double *ext, size_t ext_stride, f
 // contracts k = 8q + s (lanes 0-31) and k = 8q + 4 + s (lanes 32-63), for A and B alike.
 // Workgroup = 128 x 128 tile, 4 wavefronts of 64 x 64 (2 x 2 accumulators of 32 x 32: 64 registers), k-tile 32,
 // register-staged double-buffered LDS with rows padded to 144 B (16 lanes x 16 B hit 16 distinct bank quads).
-// L^-T is upper triangular: column tile tj only contracts k < (tj + 1) 128; heavy column tiles are dispatched first.
+// L^-T is upper triangular: column tile tj only contracts k < (tj + 1) 128 (and a wavefront stops at its own last column
+// inside that last block: 1.03 x the triangular flop count); heavy column tiles are dispatched first.
 // Epilogue: F (fp32) to HBM; sum of F^2 accumulated in fp64 per tile (the trace term's cancellation stays in fp64).
 // ---------------------------------------------------------------------------------------------
 constexpr int PK = 32;               // k-tile
@@ -169,6 +170,8 @@ __global__ __launch_bounds__(256, 2) void proj_gemm_f32_kernel(ProjF32Args a) {
     const float *Wb = a.LinvT + (size_t)dl * Mp * Mp;
     const int kend = ((tj + 1) * 128 < Mp) ? (tj + 1) * 128 : Mp;
     const int nchunk = kend / PK;
+    // inside the diagonal k-block a wavefront stops at its own last column (W[k][j] = 0 for k > j)
+    const int my_chunks = ((tj * 128 + wc * 64 + 64 < kend) ? tj * 128 + wc * 64 + 64 : kend) / PK;
 
     // staging: thread moves 16 bytes of rows (tid >> 3) + 32 i, columns 4 (tid & 7) of each operand
     const int sr = tid >> 3, sc = 4 * (tid & 7);
@@ -203,6 +206,7 @@ __global__ __launch_bounds__(256, 2) void proj_gemm_f32_kernel(ProjF32Args a) {
     for (int c = 0; c < nchunk; ++c) {
         const int buf = c & 1;
         if (c + 1 < nchunk) gload(c + 1);
+        if (c < my_chunks) {
 #pragma unroll
         for (int q = 0; q < PK / 8; ++q) {
             const f4v a0 = *reinterpret_cast<const f4v *>(&As[buf][wr * 64 + lr][8 * q + 4 * lh]);
@@ -216,6 +220,7 @@ __global__ __launch_bounds__(256, 2) void proj_gemm_f32_kernel(ProjF32Args a) {
             acc[1][1] = mfma_f32(a1.C, b1.C, acc[1][1]);
             FFVD_PSTEP(x) FFVD_PSTEP(y) FFVD_PSTEP(z) FFVD_PSTEP(w)
 #undef FFVD_PSTEP
+        }
         }
         if (c + 1 < nchunk) lstore(buf ^ 1);
         __syncthreads();

@@ -696,7 +696,8 @@ def test_two_processes_time_shard(tmp_path):
     for out in outs:
         line = [l for l in out.splitlines() if l.startswith("RESULT")][0].split()
         assert float(line[2]) == float(line[3])
-        assert float(line[2]) == pytest.approx(whole["nll"], rel=1e-12)
+        # two T-ranges summed, then factorised: a different summation order than the unsharded Gram pass (eps * cond(K_uu))
+        assert float(line[2]) == pytest.approx(whole["nll"], rel=1e-9)
 
 
 def _random_shapes(n, seed):

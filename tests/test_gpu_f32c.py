@@ -38,10 +38,10 @@ def check_f32c(got, ref, label=""):
 
 @pytest.mark.parametrize("ov", [dict(), dict(T=301, M=77, D=3, C=2, S=2), dict(T=700, M=150, D=2, C=0, S=3),
                                 dict(T=40, M=9, D=1, C=1, S=1), dict(T=1000, M=600, D=2, C=1, S=2),
-                                dict(T=257, M=130, D=5, C=8, S=2)],
-                         ids=["small", "ragged", "Mp192_C0", "tiny_D1", "M600", "P13"])
+                                dict(T=257, M=130, D=5, C=8, S=2), dict(T=1400, M=1100, D=1, C=1, S=2)],
+                         ids=["small", "ragged", "Mp192_C0", "tiny_D1", "M600", "P13", "M1100"])
 def test_f32c_against_oracle(ov):
-    """Seeded shapes incl. ragged T/M (Mp = 128, 192, 640), no control input, and P = 13 > 12 (the generic K_fu build)."""
+    """Seeded shapes incl. ragged T/M (Mp = 128, 192, 640, 1152), no control input, P = 13 > 12 (the generic K_fu build)."""
     params, Y, c, meta = synthetic.make_named("small", **ov)
     ref = orc.nll_terms_chains(params, Y, c, U_collapse=True)
     got = run_engine(params, Y, c, meta, dtype="f32c")
