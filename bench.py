@@ -144,7 +144,18 @@ def run_rank(args):
     if world > 1:
         import torch.distributed as dist       # host-side plumbing: rendezvous id, barriers, max over ranks (gloo, CPU)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        # gloo announces its connections on the C++ side's stdout; stdout of this program is ONE JSON line, so the
+        # file descriptor points at stderr while the group forms
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
     params, Y, c, meta = synthetic.make_named(args.workload)
     mode = "dims" if meta["S"] < world or args.workload == "c5" else "chains"

@@ -59,6 +59,7 @@ _SIGNATURES = {
     "ffvd_op_kernel_matrix": (C.c_int, [C.c_int, _dp, C.c_int, _dp, C.c_int, C.c_int, C.c_double, _dp, C.c_double, _dp]),
     "ffvd_op_kernel_diag": (C.c_int, [C.c_int, _dp, C.c_int, C.c_int, C.c_double, _dp]),
     "ffvd_op_cholesky": (C.c_int, [_dp, C.c_int, C.c_int, _dp, C.POINTER(C.c_int32)]),
+    "ffvd_op_trsm": (C.c_int, [_dp, C.c_int, _dp, C.c_int, _dp]),
     "ffvd_op_kernel_pre_cal": (C.c_int, [C.c_int, _dp, C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_double, _dp]),
     "ffvd_op_collapse": (C.c_int, [C.c_int, _dp, _dp, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp,
                                    C.c_double, C.c_double, _dp]),

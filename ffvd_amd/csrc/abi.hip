@@ -1476,6 +1476,34 @@ static int check_kuu_info(Scratch &sc, const KuuWork &w, int D, const char *who)
     return FFVD_OK;
 }
 
+extern "C" int ffvd_op_trsm(const double *L, int n, const double *B, int m, double *X) {
+    if (!L || !B || !X || n < 1 || m < 0) return set_error(nullptr, FFVD_EINVAL, "ffvd_op_trsm: bad argument");
+    for (int i = 0; i < n; ++i)
+        if (!(L[(size_t)i * n + i] != 0.0)) return set_error(nullptr, FFVD_EINVAL, "ffvd_op_trsm: zero on the diagonal of L");
+    OP_BEGIN("ffvd_op_trsm");
+    if (m == 0) return FFVD_OK;
+    // slab = [ L (np x np, identity padding) ; R = B^T (mp x np, zero padding) ];  X^T = R L^-T
+    const int np = round_up(n, NB), mp = round_up(m, NB);
+    std::vector<double> slab((size_t)(np + mp) * np, 0.0);
+    for (int i = 0; i < np; ++i) {
+        if (i < n) for (int j = 0; j <= i; ++j) slab[(size_t)i * np + j] = L[(size_t)i * n + j];
+        else slab[(size_t)i * np + i] = 1.0;
+    }
+    for (int c = 0; c < m; ++c)
+        for (int i = 0; i < n; ++i) slab[(size_t)(np + c) * np + i] = B[(size_t)i * m + c];
+    double *dA = sc.upload(slab.data(), slab.size());
+    OP_CHECK(dA, "ffvd_op_trsm");
+    double *dinv = sc.alloc<double>(DINV_STRIDE);
+    OP_CHECK(dinv, "ffvd_op_trsm");
+    launch_trsm_ext(sc.stream, dA, np, mp, 1, slab.size(), dinv);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(slab.data(), dA, slab.size() * sizeof(double), hipMemcpyDeviceToHost, sc.stream));
+    HIP_TRY(hipStreamSynchronize(sc.stream));
+    for (int c = 0; c < m; ++c)
+        for (int i = 0; i < n; ++i) X[(size_t)i * m + c] = slab[(size_t)(np + c) * np + i];
+    return FFVD_OK;
+}
+
 extern "C" int ffvd_op_kernel_pre_cal(int kind, const double *Z, int M, int P, int D, const double *logvariance,
                                       const double *loglengthscales, double jitter, double *Lm_inverse_seq) {
     if (!Z || !logvariance || !Lm_inverse_seq || M < 1 || P < 1 || P > MAXP || D < 1 ||

@@ -49,6 +49,9 @@ void launch_kernel_diag(hipStream_t stream, int kind, const double *X, int N, in
 void launch_potrf_ext(hipStream_t stream, double *A, int n, int extra_rows, int identity_rows, int batch,
                       size_t slab_stride, int32_t *info, double *dinv);
 void launch_set_identity(hipStream_t stream, double *A, size_t slab_stride, int row0, int n, int batch);
+// R <- R L^-T for `extra_rows` rows (multiple of NB) stored below a GIVEN lower-triangular factor L (n x n, ld n) in
+// every slab: the wavefront-level blocked substitution of the Cholesky panel step on its own.
+void launch_trsm_ext(hipStream_t stream, double *A, int n, int extra_rows, int batch, size_t slab_stride, double *dinv);
 
 struct ProjectArgs {
     int kind;

@@ -859,6 +859,46 @@ __global__ __launch_bounds__(256) void potrf_ll_kernel(double *A, int n, int j, 
     diag_block_finish<PIPE>(Ts, Lr, invd, S, n, j0 + NB, info + b, dinv + (size_t)b * DINV_STRIDE + ((j + 1) & 1) * (DINV_STRIDE / 2));
 }
 
+// Inverses of the four 16 x 16 diagonal sub-blocks of the GIVEN factor block L_jj into scratch slot j & 1 (what
+// diag_block_finish leaves behind when it has just factorised the block): lets the block-column kernel run as a plain
+// triangular solve against a factor that already exists (launch_trsm_ext).
+__global__ __launch_bounds__(256) void diag_inv_kernel(const double *A, int n, int j, size_t slab_stride, double *dinv) {
+    __shared__ double Lr[NB][NB + 1];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const double *S = A + (size_t)b * slab_stride;
+    const int j0 = j * NB;
+    for (int r = tid >> 6; r < NB; r += 4) Lr[r][lane] = S[(size_t)(j0 + r) * n + j0 + lane];
+    __syncthreads();
+    if (lane < 16) {
+        const int o = 16 * w;
+        double x[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            double acc = (lane == r) ? 1.0 : 0.0;
+#pragma unroll
+            for (int i = 0; i < r; ++i) acc -= Lr[o + r][o + i] * x[i];
+            x[r] = acc / Lr[o + r][o + r];
+        }
+        double *dv = dinv + (size_t)b * DINV_STRIDE + (j & 1) * (DINV_STRIDE / 2);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dv[(w * 16 + r) * 16 + lane] = x[r];
+    }
+}
+
+// R <- R L^-T for `extra_rows` rows stored below an n x n lower-triangular factor L in every slab (ld n): the
+// block-column kernel without its factorisation part, one launch pair per block column.
+void launch_trsm_ext(hipStream_t stream, double *A, int n, int extra_rows, int batch, size_t slab_stride, double *dinv) {
+    const int nb = n / NB, ntail = extra_rows / NB;
+    if (ntail == 0) return;
+    const int groups = (batch + 7) / 8;
+    for (int j = 0; j < nb; ++j) {
+        hipLaunchKernelGGL(diag_inv_kernel, dim3(batch), dim3(256), 0, stream, A, n, j, slab_stride, dinv);
+        hipLaunchKernelGGL(potrf_ll_kernel<false>, dim3(groups * 8 * ntail), dim3(256), 0, stream, A, n, j, 0, ntail,
+                           slab_stride, (int32_t *)nullptr, 0, 0, batch, dinv);
+    }
+}
+
 // Which blocked variant factorises a batch: the left-looking column kernel pays off where the right-looking one is
 // bandwidth-bound (many matrices: every block written once), the right-looking one where the factorisation is a pure
 // latency chain (few matrices: one block product on the critical path of a step instead of j, and workgroups small enough

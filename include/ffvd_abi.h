@@ -40,7 +40,8 @@ extern "C" {
  * factorisation and solve (:159-166, :253-254), H from the moment it leaves the matrix cores, delta^T F (:247-248) and
  * the sum of F^2 in the trace term (:255) in fp64.  All inputs and outputs of the ABI stay fp64.  Collapsed branch,
  * FFVD_ROUTE_REFERENCE, no gradient (the Gram route's error is eps * cond(K_uu): unusable in fp32).
- * Measured against the fp64 oracle: nll within 5e-6 relative at T=16384, M=2048 (tests/test_gpu_f32c.py). */
+ * Measured against the fp64 oracle: every term and the nll within 1e-5 absolute (worst case 5.5e-6 with M = 1100 inducing
+ * points for T = 1400; 2e-7 relative on the nll at T=16384, M=2048) -- tests/test_gpu_f32c.py. */
 #define FFVD_F32C 1
 
 #define FFVD_KERNEL_SE      0   /* kernels_multi_output.py:140-247 SquaredExponential (ARD) */
@@ -265,6 +266,10 @@ int  ffvd_op_kernel_diag(int kind, const double *X, int N, int P, double logvari
 /* batched lower Cholesky of `batch` n x n SPD matrices (tf.linalg.cholesky, conditionals_multi_output.py:28,162).
  * A and L may alias. info[b] = 0 or 1 + index of the first non-positive pivot. Returns FFVD_ENOTPD if any info != 0. */
 int  ffvd_op_cholesky(const double *A, int n, int batch, double *L, int32_t *info);
+/* The whitened triangular solve of base_conditional: A = Lm^-1 Kmn = tf.linalg.triangular_solve(Lm, Kmn, lower=True)
+ * (conditionals_multi_output.py:34, conditionals.py:30).  L: n x n lower triangular (entries above the diagonal are ignored),
+ * B: n x m, X: n x m = L^-1 B.  Runs the wavefront-level blocked substitution of the Cholesky panel step on its own. */
+int  ffvd_op_trsm(const double *L, int n, const double *B, int m, double *X);
 /* kernel_pre_cal (conditionals_multi_output.py:124-169): for D kernels returns the stack of L_d^{-T} (D x M x M, upper). */
 int  ffvd_op_kernel_pre_cal(int kind, const double *Z, int M, int P, int D, const double *logvariance,
                             const double *loglengthscales, double jitter, double *Lm_inverse_seq);

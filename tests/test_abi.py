@@ -161,6 +161,7 @@ assert lib.ffvd_op_kernel_matrix(5, dp(x), 2, None, 2, 3, 0.0, dp(x), 0.0, dp(o)
 assert lib.ffvd_op_kernel_diag(0, None, 2, 3, 0.0, dp(o)) == E
 assert lib.ffvd_op_cholesky(None, 2, 1, dp(o), i32.ctypes.data_as(C.POINTER(C.c_int32))) == E
 assert lib.ffvd_op_cholesky(dp(o), 0, 1, dp(o), None) == E
+assert lib.ffvd_op_trsm(None, 2, None, 1, None) == E
 assert lib.ffvd_op_kernel_pre_cal(0, None, 2, 3, 1, dp(o), dp(o), 1e-5, dp(o)) == E
 assert lib.ffvd_op_collapse(0, None, None, None, None, 4, 2, 3, 1, None, None, None, 4.0, 4.0, dp(o)) == E
 assert lib.ffvd_op_conditional(0, None, 2, None, 2, 3, 1, None, None, None, 1e-5, None, None) == E
