@@ -87,7 +87,7 @@ struct ffvd_handle {
         double *dCC = nullptr, *dDD = nullptr, *dlogR = nullptr;
         // explicit-U branch
         double *Gu = nullptr, *Gsum = nullptr, *r = nullptr, *dalpha = nullptr, *ucol = nullptr, *beta = nullptr, *du = nullptr;
-        double *GammaA = nullptr, *Lclean = nullptr, *dU = nullptr;
+        double *GammaA = nullptr, *Lclean = nullptr, *dU = nullptr, *xsq = nullptr;
         int ngam = 0, sp_stride = 0;
     } gw;
     double *hterms = nullptr, *chain_terms = nullptr, *chain_nll = nullptr, *out_terms = nullptr;
@@ -297,6 +297,7 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
         if (grad_a) {
             HIP_TRY(dev_alloc(h, &g.Gu, nbt * (Mp + NB) * Mp));   HIP_TRY(dev_alloc(h, &g.Gsum, Dl * (Mp + NB) * Mp));
             HIP_TRY(dev_alloc(h, &g.r, nbt * Tp));                HIP_TRY(dev_alloc(h, &g.dalpha, nbt));
+            HIP_TRY(dev_alloc(h, &g.xsq, nbt));
             HIP_TRY(dev_alloc(h, &g.ucol, Dl * Mp));              HIP_TRY(dev_alloc(h, &g.beta, Dl * Mp));
             HIP_TRY(dev_alloc(h, &g.du, Dl * Mp));                HIP_TRY(dev_alloc(h, &g.GammaA, Dl * msq));
             HIP_TRY(dev_alloc(h, &g.Lclean, Dl * msq));           HIP_TRY(dev_alloc(h, &g.dU, (size_t)c.M * c.D));
@@ -371,11 +372,9 @@ extern "C" int ffvd_create(const ffvd_config *cfg, ffvd_handle **out) {
     if (!(cfg->jitter >= 0.0)) return set_error(nullptr, FFVD_EINVAL, "ffvd_create: jitter must be >= 0");
     if (cfg->route != FFVD_ROUTE_REFERENCE && cfg->route != FFVD_ROUTE_GRAM)
         return set_error(nullptr, FFVD_EINVAL, "ffvd_create: unknown route");
-    if (cfg->grad && (cfg->kernel_kind != FFVD_KERNEL_SE || (cfg->branch == FFVD_BRANCH_B && cfg->route != FFVD_ROUTE_GRAM)))
+    if (cfg->grad && cfg->branch == FFVD_BRANCH_B && (cfg->kernel_kind != FFVD_KERNEL_SE || cfg->route != FFVD_ROUTE_GRAM))
         return set_error(nullptr, FFVD_EINVAL,
-                         "ffvd_create: grad = 1 needs the SE kernel and, in the collapsed-U branch, FFVD_ROUTE_GRAM");
-    if (cfg->grad && cfg->branch == FFVD_BRANCH_A && cfg->D + cfg->C > 6)
-        return set_error(nullptr, FFVD_EINVAL, "ffvd_create: grad = 1 in the explicit-U branch needs P = D + C <= 6");
+                         "ffvd_create: grad = 1 in the collapsed-U branch needs the SE kernel and FFVD_ROUTE_GRAM");
     if (cfg->route == FFVD_ROUTE_GRAM && cfg->branch != FFVD_BRANCH_B)
         return set_error(nullptr, FFVD_EINVAL, "ffvd_create: FFVD_ROUTE_GRAM only applies to the collapsed-U branch");
     if (cfg->T_total < 0 || cfg->t_begin < 0 || (cfg->T_total > 0 && cfg->t_begin + cfg->T > cfg->T_total))
@@ -895,8 +894,9 @@ static int enqueue_grad_a(ffvd_handle *h, int S_total) {
     // beta = W u,  r = delta - mean,  dl/dalpha per unit
     launch_ucols(s, p.U, c.M, Mp, c.D, c.d_begin, Dl, g.ucol);
     launch_matvec(s, W, kstride, g.ucol, Mp, Mp, g.beta, 1, Mp, Mp, Dl);
-    launch_resid_a(s, p.X, h->fmean, h->rowsq, h->variance, p.log_Q, c.T, Tp, c.D, Dl, c.d_begin, h->ngr ? h->ngr : h->ng, nb,
-                   g.r, g.dalpha);
+    const int kind = c.kernel_kind;
+    launch_resid_a(s, kind, p.X, h->ctrl, c.C, h->fmean, h->rowsq, h->variance, p.log_Q, c.T, Tp, c.D, Dl, c.d_begin,
+                   h->ngr ? h->ngr : h->ng, nb, g.r, g.dalpha, g.xsq);
     // G = K_uf K_fu (lower tiles) and g_r = K_uf r (row Mp) per unit, then summed over the chains
     GramArgs gg{};
     gg.mode = GRAM_PLAIN; gg.A = h->F; gg.a_stride = fstride; gg.rows = Tp; gg.with_row = 1; gg.brow = Mp; gg.rvec = g.r;
@@ -928,8 +928,9 @@ static int enqueue_grad_a(ffvd_handle *h, int S_total) {
     launch_atb(s, ap);                                                                  // Q2 = Phi W^T
     ap.A = h->Linv; ap.a_stride = msq; ap.B = g.P1; ap.b_stride = msq; ap.C = g.KGK;
     launch_atb(s, ap);                                                                  // dK = W Q2
-    launch_epsi_a(s, g.KGK, h->Kcopy, c.M, Mp, Dl, c.jitter, g.Epsi);
+    launch_epsi_a(s, kind, g.KGK, h->Kcopy, c.M, Mp, Dl, c.jitter, g.Epsi);
     EReduceArgs ek{};
+    ek.kind = kind; ek.variance = h->variance;
     ek.E = g.Epsi; ek.e_stride = msq; ek.Kf = nullptr; ek.u = nullptr; ek.x_is_z = 1; ek.Z = p.Z; ek.len = h->len;
     ek.T = c.M; ek.Tp = Mp; ek.M = c.M; ek.Mp = Mp; ek.P = P; ek.Dl = Dl; ek.b0 = 0; ek.nb = Dl; ek.nblk = Mp / 64;
     ek.rsum = g.rsum2; ek.ez = g.ez2; ek.kfu = nullptr; ek.cs_part = g.cs2; ek.etx_part = g.etx2; ek.rx2_part = g.rx22;
@@ -940,7 +941,8 @@ static int enqueue_grad_a(ffvd_handle *h, int S_total) {
     // K_fu side: E = (alpha K_fu K^-1 + alpha r beta^T) o K_fu, reduced in the fused kernel
     launch_scale_kinv(s, h->Kinv, p.log_Q, Mp, Dl, c.d_begin, g.GammaA);
     EReduceArgs er{};
-    er.E = nullptr; er.e_stride = fstride; er.Kf = h->F; er.u = g.beta; er.u_stride = Mp; er.x_is_z = 0;
+    er.kind = kind; er.variance = h->variance; er.u_per_dim = 1;
+    er.E = g.E; er.e_stride = fstride; er.Kf = h->F; er.u = g.beta; er.u_stride = Mp; er.x_is_z = 0;
     er.x = p.X; er.x_chain_stride = (size_t)(c.T + 1) * c.D; er.x_ld = c.D; er.x_cols = c.D; er.ctrl = h->ctrl; er.C = c.C;
     er.Z = p.Z; er.len = h->len; er.T = c.T; er.Tp = Tp; er.M = c.M; er.Mp = Mp; er.P = P; er.Dl = Dl; er.b0 = 0; er.nb = nb;
     er.nblk = Tp / 64; er.rsum = g.rsum; er.ez = g.ez; er.kfu = g.kfu; er.cs_part = g.cs_part; er.etx_part = g.etx_part;
@@ -951,9 +953,23 @@ static int enqueue_grad_a(ffvd_handle *h, int S_total) {
     bf.X = p.X; bf.ctrl = h->ctrl; bf.Z = p.Z; bf.log_Q = p.log_Q; bf.T = c.T; bf.Tp = Tp; bf.D = c.D; bf.C = c.C;
     bf.M = c.M; bf.Mp = Mp; bf.P = P; bf.Dl = Dl; bf.d_begin = c.d_begin; bf.b0 = 0; bf.nb = nb; bf.rp = g.rp;
     bf.cs_part = g.cs_part; bf.etx_part = g.etx_part; bf.rsum = g.rsum; bf.ez = g.ez; bf.kfu = g.kfu; bf.rx2_part = g.rx2_part;
-    launch_bwd_fused(s, bf);
+    bf.linear = kind != FFVD_KERNEL_SE;
+    if (g.rp) launch_bwd_fused(s, bf);
+    else {
+        // P > 6 (BASELINE config 5: P = 17): materialise E = alpha (K_fu K^-1 + r beta^T) [o K_fu for the SE kernel] and
+        // reduce it in a second kernel
+        AtbArgs ae{};
+        ae.mode = ATB_BWD_E; ae.A = h->F; ae.a_stride = fstride; ae.lda = Mp; ae.nA = Tp; ae.a_rowmajor = 1;
+        ae.B = g.GammaA; ae.b_stride = msq; ae.ldb = Mp; ae.nB = Mp; ae.b_per_dim = 1; ae.rows = Mp;
+        ae.C = g.E; ae.c_stride = fstride; ae.ldc = Mp; ae.nb = nb; ae.b0 = 0; ae.Dl = Dl; ae.d_begin = c.d_begin;
+        ae.log_Q = p.log_Q; ae.u = g.beta; ae.u_stride = Mp; ae.u_per_dim = 1; ae.X = p.X; ae.T = c.T; ae.D = c.D;
+        ae.Kf = h->F; ae.kf_stride = fstride; ae.ldkf = Mp; ae.rvec = g.r; ae.no_hadamard = kind != FFVD_KERNEL_SE;
+        launch_atb(s, ae);
+        launch_e_reduce(s, er);
+    }
     launch_e_finish(s, er, g.dz_unit, g.dll_unit, g.dls_unit);
     DxArgs dx{};
+    dx.kind = kind; dx.variance = h->variance;
     dx.X = p.X; dx.Y = h->Y; dx.CC = p.CC; dx.DD = p.DD; dx.log_Rchols = p.log_Rchols; dx.log_Q = p.log_Q; dx.len = h->len;
     dx.rsum = g.rsum; dx.ez = g.ez; dx.kfu = g.kfu; dx.S = S; dx.S_total = S_total; dx.T = c.T; dx.Tp = Tp; dx.D = c.D;
     dx.P = P; dx.Ydim = c.Ydim; dx.Dl = Dl; dx.d_begin = c.d_begin; dx.shared_terms = c.shared_terms; dx.dX = g.dX;
@@ -968,6 +984,7 @@ static int enqueue_grad_a(ffvd_handle *h, int S_total) {
     gf.sp_stride = g.sp_stride; gf.dZ = g.dZ; gf.dlogvar = g.dlogvar; gf.dloglen = g.dloglen; gf.dlogQ = g.dlogQ;
     gf.dCC = g.dCC; gf.dDD = g.dDD; gf.dlogR = g.dlogR;
     gf.branch_a = 1; gf.dalpha_unit = g.dalpha; gf.du_dim = g.du; gf.U = p.U; gf.dU = g.dU;
+    gf.kind = kind; gf.xsq_unit = g.xsq;
     HIP_TRY(hipMemsetAsync(g.dlogvar, 0, (size_t)c.D * sizeof(double), s));
     HIP_TRY(hipMemsetAsync(g.dloglen, 0, (size_t)c.D * P * sizeof(double), s));
     HIP_TRY(hipMemsetAsync(g.dlogQ, 0, (size_t)c.D * sizeof(double), s));

@@ -32,6 +32,10 @@ struct AtbArgs {
                                                         //    launched, off-diagonal ones are also written mirrored
     int k_lower;                                        // 1: A and B are lower triangular as stored ([k][i] = 0 for i > k): the
                                                         //    sum for tile (ti, tj) starts at row 128 max(ti, tj) (exact: skips zeros)
+    // BWD_E, explicit-U branch / LinearK: residuals instead of delta ([nb][nA]), u indexed by latent dim, and no
+    // Hadamard product with K_fu (a linear kernel's chain rule multiplies by x and z, not by K)
+    const double *rvec;
+    int u_per_dim, no_hadamard;
 };
 void launch_atb(hipStream_t stream, const AtbArgs &a);
 int atb_ntiles(int nA, int nB);
@@ -53,6 +57,9 @@ struct EReduceArgs {
     const double *Kf;                       // optional, same layout as E: also produce kfu[t] = sum_m Kf_tm u_m
     const double *u; size_t u_stride;
     int x_is_z;                             // 1: the rows are the inducing inputs themselves (K_uu side)
+    int u_per_dim;                          // 1: u is indexed by latent dim (explicit-U branch: beta), else by unit
+    int kind;                               // FFVD_KERNEL_*: e_finish applies the SE or the LinearK chain rule
+    const double *variance;                 // [Dl] exp(logvariance) (LinearK)
     const double *x; size_t x_chain_stride; int x_ld, x_cols;
     const double *ctrl; int C;
     const double *Z;                        // M x P (unscaled)
@@ -72,6 +79,7 @@ struct BwdFusedArgs {
     const double *u; size_t u_stride;           // [nb] Mp ([Dl] when per_dim)
     int per_dim;                                // explicit-U branch: Gamma and u are indexed by latent dim, not by unit
     const double *rvec;                         // explicit-U branch: [nb][Tp] residuals used in place of delta
+    int linear;                                 // LinearK: E = 2 K_fu Gamma + row (alpha u)^T WITHOUT the Hadamard product with K_fu
     const double *X; const double *ctrl;        // chains S x (T+1) x D; control inputs T x C
     const double *Z;                            // M x P
     const double *log_Q;
@@ -99,6 +107,8 @@ struct ProjGemmArgs {
 void launch_proj_gemm(hipStream_t stream, const ProjGemmArgs &a);
 
 struct DxArgs {
+    int kind;                               // FFVD_KERNEL_*
+    const double *variance;                 // [Dl] (LinearK: d/dx of K_fu and of Kdiag = variance |x|^2)
     const double *X, *Y, *CC, *DD, *log_Rchols, *log_Q, *len;
     const double *rsum, *ez, *kfu;
     int S, S_total, T, Tp, D, P, Ydim, Dl, d_begin, shared_terms;
@@ -122,20 +132,23 @@ struct GradFinalArgs {
     int branch_a;
     const double *dalpha_unit, *du_dim, *U;
     double *dU;
+    int kind;                                          // FFVD_KERNEL_*
+    const double *xsq_unit;                            // LinearK: [nb] sum_t |x_comb_t|^2 (Kdiag = variance |x|^2 enters the trace term)
 };
 void launch_grad_finalize(hipStream_t stream, const GradFinalArgs &a);
 
 // ---- explicit-U branch helpers (see grad.hip) ----
 void launch_ucols(hipStream_t stream, const double *U, int M, int Mp, int D, int d_begin, int Dl, double *ucol);
-void launch_resid_a(hipStream_t stream, const double *X, const double *fmean, const double *rowsq, const double *variance,
-                    const double *log_Q, int T, int Tp, int D, int Dl, int d_begin, int ng, int nb, double *r,
-                    double *dalpha_unit);
+void launch_resid_a(hipStream_t stream, int kind, const double *X, const double *ctrl, int C, const double *fmean,
+                    const double *rowsq, const double *variance, const double *log_Q, int T, int Tp, int D, int Dl, int d_begin,
+                    int ng, int nb, double *r, double *dalpha_unit, double *xsq_unit);
 void launch_scale_kinv(hipStream_t stream, const double *Kinv, const double *log_Q, int Mp, int Dl, int d_begin, double *out);
 void launch_dw_a(hipStream_t stream, const double *T1, const double *grs, size_t grs_stride, const double *ucol,
                  const double *log_Q, int Mp, int Dl, int d_begin, double *dW);
 void launch_tril_neg(hipStream_t stream, const double *P, int Mp, int Dl, double *out);
 void launch_tril_copy(hipStream_t stream, const double *L, size_t l_stride, int Mp, int Dl, double *out);
 void launch_phi(hipStream_t stream, const double *S, int Mp, int Dl, double *Phi);
-void launch_epsi_a(hipStream_t stream, const double *dK, const double *Kcopy, int M, int Mp, int Dl, double jitter, double *E);
+void launch_epsi_a(hipStream_t stream, int kind, const double *dK, const double *Kcopy, int M, int Mp, int Dl, double jitter,
+                   double *E);
 
 }  // namespace ffvd

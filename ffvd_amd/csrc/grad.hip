@@ -166,7 +166,8 @@ __global__ __launch_bounds__(512, 4) void atb_kernel(AtbArgs a) {
     if (active) {
         double alpha = 1.0;
         if (MODE != ATB_PLAIN) alpha = 1.0 / exp(a.log_Q[dg]);
-        const double *ub = (MODE != ATB_PLAIN) ? a.u + (size_t)bz * a.u_stride : nullptr;
+        const double *ub = (MODE != ATB_PLAIN) ? a.u + (size_t)((MODE == ATB_BWD_E && a.u_per_dim) ? dl : bz) * a.u_stride : nullptr;
+        const double *rv = (MODE == ATB_BWD_E && a.rvec) ? a.rvec + (size_t)bz * a.nA : nullptr;
         const double *Xs = (MODE == ATB_BWD_E) ? a.X + (size_t)s * (a.T + 1) * a.D : nullptr;
         const double *Kf = (MODE == ATB_BWD_E) ? a.Kf + (size_t)bz * a.kf_stride : nullptr;
         const double *Kinv = (MODE == ATB_GAMMA) ? a.Kinv + (size_t)dl * a.k_stride : nullptr;
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(512, 4) void atb_kernel(AtbArgs a) {
                 if (i >= a.nA) continue;
                 double rowv = 0.0;
                 if (MODE == ATB_GAMMA) rowv = ub[i];
-                if (MODE == ATB_BWD_E) rowv = (i < a.T) ? alpha * (Xs[(size_t)(i + 1) * a.D + dg] - Xs[(size_t)i * a.D + dg]) : 0.0;
+                if (MODE == ATB_BWD_E) rowv = (i < a.T) ? alpha * (rv ? rv[i] : Xs[(size_t)(i + 1) * a.D + dg] - Xs[(size_t)i * a.D + dg]) : 0.0;
 #pragma unroll
                 for (int y = 0; y < 2; ++y) {
                     const int j = J0 + 16 * y + lr;
@@ -192,7 +193,8 @@ __global__ __launch_bounds__(512, 4) void atb_kernel(AtbArgs a) {
                         part += (mirror ? 2.0 : 1.0) * (g * Kc[(size_t)i * a.ldk + j]);
                         if (mirror) Cb[(size_t)j * a.ldc + i] = v;       // K^-1, A^-1, u u^T are all symmetric
                     } else if (MODE == ATB_BWD_E) {
-                        v = (2.0 * g + rowv * ub[j]) * Kf[(size_t)i * a.ldkf + j];
+                        v = 2.0 * g + rowv * ub[j];
+                        if (!a.no_hadamard) v *= Kf[(size_t)i * a.ldkf + j];
                     } else if (MODE == ATB_PLAIN) {
                         if (a.sym && ti != tj) Cb[(size_t)j * a.ldc + i] = v;      // symmetric product: mirrored tile
                     }
@@ -525,7 +527,7 @@ __global__ __launch_bounds__(512, 4) void bwd_fused_kernel(BwdFusedArgs a) {
                     const int j = J0 + 16 * y + lr;
                     const bool ok = iok && j < Mp;
                     const double kf = ok ? Kfb[(size_t)i * Mp + j] : 0.0;
-                    acc[x][y][q] = (2.0 * acc[x][y][q] + rowv * uj[y]) * kf;
+                    acc[x][y][q] = (2.0 * acc[x][y][q] + rowv * uj[y]) * (a.linear ? (ok ? 1.0 : 0.0) : kf);
                     v += kf * uj[y];
                 }
                 // reduced and parked right away: sixteen partial sums held across the loop cost 32 VGPRs this epilogue
@@ -823,7 +825,7 @@ __global__ __launch_bounds__(512) void e_reduce_kernel(EReduceArgs a) {
     const int t0 = blk * 64, P = a.P, Mp = a.Mp;
     const double *E = a.E + (size_t)bz * a.e_stride;
     const double *Kf = a.Kf ? a.Kf + (size_t)bz * a.e_stride : nullptr;
-    const double *ub = a.u ? a.u + (size_t)bz * a.u_stride : nullptr;
+    const double *ub = a.u ? a.u + (size_t)(a.u_per_dim ? b % a.Dl : bz) * a.u_stride : nullptr;
     const double *Zd = a.Z;                                          // unscaled inducing inputs M x P
     for (int idx = tid; idx < 64 * P; idx += NT) {                   // x rows of this block
         const int r = idx / P, p = idx % P, t = t0 + r;
@@ -983,6 +985,20 @@ __global__ __launch_bounds__(256 * NG) void e_finish_kernel(EReduceArgs a, doubl
 #pragma unroll
                 for (int p = 0; p < PM; ++p) etx[p] += grp[q][r][p];
             }
+            if (a.kind != 0) {
+                // LinearK, K = s2 x z^T (kernels.py:276): dz_m = s2 (E^T x)_m (+ s2 (E z)_m on the K_uu side, where both
+                // arguments are Z); d logvariance = sum E o K = s2 sum_mp z_mp (E^T x)_mp (K_fu side) / s2 sum z o (E z) (K_uu side)
+                const double s2 = a.variance[dl];
+#pragma unroll
+                for (int p = 0; p < PM; ++p) {
+                    if (p < P) {
+                        const double z = a.Z[(size_t)m * P + p];
+                        const double ezv = a.x_is_z ? a.ez[((size_t)bz * a.Tp + m) * P + p] : 0.0;
+                        dz_unit[((size_t)bz * a.M + m) * P + p] = s2 * (etx[p] + ezv);
+                        dls += s2 * z * (a.x_is_z ? ezv : etx[p]);
+                    }
+                }
+            } else {
             dls += cs;
 #pragma unroll
             for (int p = 0; p < PM; ++p) {
@@ -993,6 +1009,7 @@ __global__ __launch_bounds__(256 * NG) void e_finish_kernel(EReduceArgs a, doubl
                     dz_unit[((size_t)bz * a.M + m) * P + p] = dz;
                     llacc[p] += (-2.0 * z * etx[p] + cs * z * z) * inv2;
                 }
+            }
             }
         }
         __syncthreads();
@@ -1005,7 +1022,7 @@ __global__ __launch_bounds__(256 * NG) void e_finish_kernel(EReduceArgs a, doubl
             if (tid == 0) {
                 double rx2 = 0.0;
                 for (int blk = 0; blk < a.nblk; ++blk) rx2 += a.rx2_part[((size_t)bz * a.nblk + blk) * P + p];
-                dll_unit[(size_t)bz * P + p] = v + rx2 / (len[p] * len[p]);
+                dll_unit[(size_t)bz * P + p] = (a.kind != 0) ? 0.0 : v + rx2 / (len[p] * len[p]);
             }
         }
     }
@@ -1066,6 +1083,12 @@ __global__ __launch_bounds__(256) void dx_kernel(DxArgs a) {
         double acc = 0.0;
         for (int dl = 0; dl < a.Dl; ++dl) {
             const size_t bb = (size_t)s * a.Dl + dl;
+            if (a.kind != 0) {
+                // LinearK: d K_fu / d x = s2 z, and Kdiag_t = s2 |x_t|^2 sits in the trace term: -1/2 alpha (Kdiag_t - |F_t|^2)
+                const double s2 = a.variance[dl], alpha = 1.0 / exp(a.log_Q[a.d_begin + dl]);
+                acc += s2 * a.ez[(bb * a.Tp + t) * a.P + p] - alpha * s2 * Xs[(size_t)t * D + p];
+                continue;
+            }
             const double l = a.len[(size_t)dl * a.P + p];
             acc += -(Xs[(size_t)t * D + p] * a.rsum[bb * a.Tp + t] - a.ez[(bb * a.Tp + t) * a.P + p]) / (l * l);
         }
@@ -1152,7 +1175,8 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(GradFinalArgs a) {
             if (tid == q && p0 + q < P) {
                 const int p = p0 + q;
                 const double acc = v[q] + a.dll_kuu[(size_t)dl * P + p];
-                a.dloglen[(size_t)dg * P + p] = -acc / Tn / Sn + w * a.loglen[(size_t)dg * P + p] / Tn;
+                // LinearK has no lengthscales: neither a data term nor the prior_hyper term (dgp_model.py:123-130)
+                a.dloglen[(size_t)dg * P + p] = (a.kind != 0) ? 0.0 : -acc / Tn / Sn + w * a.loglen[(size_t)dg * P + p] / Tn;
             }
     }
     // logvariance, log_Q
@@ -1163,7 +1187,8 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(GradFinalArgs a) {
         for (int q = 0; q < 8; ++q) v[q] = 0.0;
         for (int s = tid; s < S; s += 256) {
             const size_t bb = (size_t)s * Dl + dl;
-            v[0] += a.dls_unit[bb] - 0.5 * alpha * Tn * s2;          // K_fu side + direct Kdiag term
+            // K_fu side + direct Kdiag term (SE: Kdiag = s2; LinearK: Kdiag_t = s2 |x_t|^2)
+            v[0] += a.dls_unit[bb] - 0.5 * alpha * s2 * ((a.kind != 0) ? a.xsq_unit[bb] : Tn);
             if (a.branch_a) {                                        // explicit U: dl/dalpha comes per unit from resid_a
                 v[1] += a.dalpha_unit[bb] * (-alpha);
                 continue;
@@ -1260,15 +1285,17 @@ __global__ void ucols_kernel(const double *U, int M, int Mp, int D, int d_begin,
 void launch_ucols(hipStream_t stream, const double *U, int M, int Mp, int D, int d_begin, int Dl, double *ucol) {
     hipLaunchKernelGGL(ucols_kernel, dim3((Mp + 255) / 256, Dl), dim3(256), 0, stream, U, M, Mp, D, d_begin, ucol);
 }
-// r[b][t] = delta_t - mean_t (0 for t >= T);  dalpha[b] = -1/2 sum r^2 - 1/2 sum_t (sigma^2 - |F_t|^2) + T / (2 alpha)
-__global__ __launch_bounds__(256) void resid_a_kernel(const double *X, const double *fmean, const double *rowsq,
-                                                      const double *variance, const double *log_Q, int T, int Tp, int D,
-                                                      int Dl, int d_begin, int ng, double *r, double *dalpha_unit) {
+// r[b][t] = delta_t - mean_t (0 for t >= T);  dalpha[b] = -1/2 sum r^2 - 1/2 sum_t (Kdiag_t - |F_t|^2) + T / (2 alpha);
+// Kdiag_t = sigma^2 (SE) or sigma^2 |x_comb_t|^2 (LinearK, kernels.py:278-281), whose sum over t goes to xsq[b]
+__global__ __launch_bounds__(256) void resid_a_kernel(int kind, const double *X, const double *ctrl, int C, const double *fmean,
+                                                      const double *rowsq, const double *variance, const double *log_Q, int T,
+                                                      int Tp, int D, int Dl, int d_begin, int ng, double *r,
+                                                      double *dalpha_unit, double *xsq_unit) {
     __shared__ double scratch[256];
     const int b = blockIdx.x, tid = threadIdx.x, s = b / Dl, dl = b % Dl, dg = d_begin + dl;
     const double *Xs = X + (size_t)s * (T + 1) * D;
     const double s2 = variance[dl];
-    double sr = 0.0, sv = 0.0;
+    double sr = 0.0, sv = 0.0, sx = 0.0;
     for (int t = tid; t < Tp; t += 256) {
         double rt = 0.0;
         if (t < T) {
@@ -1279,19 +1306,31 @@ __global__ __launch_bounds__(256) void resid_a_kernel(const double *X, const dou
             }
             rt = (Xs[(size_t)(t + 1) * D + dg] - Xs[(size_t)t * D + dg]) - fm;
             sr += rt * rt;
-            sv += s2 - rs;
+            double kd = s2;
+            if (kind != 0) {
+                double xsq = 0.0;
+                for (int p = 0; p < D; ++p) xsq += Xs[(size_t)t * D + p] * Xs[(size_t)t * D + p];
+                for (int p = 0; p < C; ++p) xsq += ctrl[(size_t)t * C + p] * ctrl[(size_t)t * C + p];
+                sx += xsq;
+                kd = xsq * s2;
+            }
+            sv += kd - rs;
         }
         r[(size_t)b * Tp + t] = rt;
     }
     sr = block_sum(sr, scratch);
     sv = block_sum(sv, scratch);
-    if (tid == 0) dalpha_unit[b] = -0.5 * sr - 0.5 * sv + 0.5 * (double)T * exp(log_Q[dg]);
+    sx = block_sum(sx, scratch);
+    if (tid == 0) {
+        dalpha_unit[b] = -0.5 * sr - 0.5 * sv + 0.5 * (double)T * exp(log_Q[dg]);
+        if (xsq_unit) xsq_unit[b] = sx;
+    }
 }
-void launch_resid_a(hipStream_t stream, const double *X, const double *fmean, const double *rowsq, const double *variance,
-                    const double *log_Q, int T, int Tp, int D, int Dl, int d_begin, int ng, int nb, double *r,
-                    double *dalpha_unit) {
-    hipLaunchKernelGGL(resid_a_kernel, dim3(nb), dim3(256), 0, stream, X, fmean, rowsq, variance, log_Q, T, Tp, D, Dl,
-                       d_begin, ng, r, dalpha_unit);
+void launch_resid_a(hipStream_t stream, int kind, const double *X, const double *ctrl, int C, const double *fmean,
+                    const double *rowsq, const double *variance, const double *log_Q, int T, int Tp, int D, int Dl, int d_begin,
+                    int ng, int nb, double *r, double *dalpha_unit, double *xsq_unit) {
+    hipLaunchKernelGGL(resid_a_kernel, dim3(nb), dim3(256), 0, stream, kind, X, ctrl, C, fmean, rowsq, variance, log_Q, T, Tp, D,
+                       Dl, d_begin, ng, r, dalpha_unit, xsq_unit);
 }
 // out = 1/2 alpha_d K^-1   (plays the role of Gamma in the fused backward product)
 __global__ void scale_kinv_kernel(const double *Kinv, const double *log_Q, int Mp, int d_begin, double *out) {
@@ -1354,17 +1393,19 @@ __global__ void phi_kernel(const double *S, int Mp, double *Phi) {
 void launch_phi(hipStream_t stream, const double *S, int Mp, int Dl, double *Phi) {
     hipLaunchKernelGGL(phi_kernel, dim3((unsigned)(((size_t)Mp * Mp + 255) / 256), Dl), dim3(256), 0, stream, S, Mp, Phi);
 }
-// E = dK o K_uu (without the jitter on the diagonal), zero in the padding
-__global__ void epsi_a_kernel(const double *dK, const double *Kcopy, int M, int Mp, double jitter, double *E) {
+// E = dK o K_uu (without the jitter on the diagonal; SE chain rule) or dK itself (LinearK), zero in the padding
+__global__ void epsi_a_kernel(int kind, const double *dK, const double *Kcopy, int M, int Mp, double jitter, double *E) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)Mp * Mp) return;
     const int i = (int)(idx / Mp), j = (int)(idx % Mp);
     const size_t o = (size_t)blockIdx.y * Mp * Mp + idx;
-    E[o] = (i < M && j < M) ? dK[o] * (Kcopy[o] - ((i == j) ? jitter : 0.0)) : 0.0;
+    const double k = (kind != 0) ? 1.0 : Kcopy[o] - ((i == j) ? jitter : 0.0);
+    E[o] = (i < M && j < M) ? dK[o] * k : 0.0;
 }
-void launch_epsi_a(hipStream_t stream, const double *dK, const double *Kcopy, int M, int Mp, int Dl, double jitter, double *E) {
-    hipLaunchKernelGGL(epsi_a_kernel, dim3((unsigned)(((size_t)Mp * Mp + 255) / 256), Dl), dim3(256), 0, stream, dK, Kcopy, M,
-                       Mp, jitter, E);
+void launch_epsi_a(hipStream_t stream, int kind, const double *dK, const double *Kcopy, int M, int Mp, int Dl, double jitter,
+                   double *E) {
+    hipLaunchKernelGGL(epsi_a_kernel, dim3((unsigned)(((size_t)Mp * Mp + 255) / 256), Dl), dim3(256), 0, stream, kind, dK, Kcopy,
+                       M, Mp, jitter, E);
 }
 
 }  // namespace ffvd

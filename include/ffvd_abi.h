@@ -142,7 +142,8 @@ int  ffvd_elbo(ffvd_handle *h, const ffvd_params *p, uint32_t flags, double out_
 int  ffvd_elbo_async(ffvd_handle *h, double *out_terms_dev);
 /* Gradient of the mean-over-chains nll w.r.t. every parameter (what the reference gets from tf.gradients(nll, vars),
  * base_model.py:148, and AdamOptimizer.minimize(nll), dgp_model.py:303-305).  Needs a handle created with
- * grad = 1 and the SE kernel: the collapsed branch with FFVD_ROUTE_GRAM, or the explicit-U branch (P = D + C <= 6).  Host output pointers with
+ * grad = 1: the collapsed branch with the SE kernel and FFVD_ROUTE_GRAM, or the explicit-U branch with either kernel
+ * (LinearK: the loglengthscales gradient is identically zero -- the kernel has none).  Host output pointers with
  * the shapes of ffvd_params; any of them may be NULL.  S_total = number of chains of the whole job (the divisor of
  * the mean).  Sharded jobs: every output is this handle's ADDITIVE share of the whole-job gradient -- entries of
  * dims it does not own are zero, prior gradients are weighted S_local / S_total (and the shared ones only added
