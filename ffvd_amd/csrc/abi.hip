@@ -186,7 +186,7 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
         if (n > (size_t)c.S_local) n = c.S_local;
         h->cpp = (int)n;
     }
-    if (h->cpp > c.S_local || c.grad) h->cpp = c.S_local;
+    if (h->cpp > c.S_local || c.grad || c.T_total > 0) h->cpp = c.S_local;      // backward pass, T-shards: one pass over all chains
     HIP_TRY(hipSetDevice(c.device_id));
     HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     {   // the side stream carries a short latency-bound chain: give it the highest priority
@@ -305,7 +305,6 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
     }
     HIP_TRY(dev_alloc(h, &h->hterms, (size_t)h->nbatch * 2));
     if (c.T_total > 0) {        // the chain sums live at the tail of the exchange buffer: one all-reduce covers both
-        h->cpp = c.S_local;
         const size_t raw = (size_t)h->nbatch * (Mp + 1) * Mp;
         h->ts_count = (int64_t)(raw + (size_t)c.S_local * 8);
         HIP_TRY(dev_alloc(h, &h->tsbuf, (size_t)h->ts_count));
