@@ -149,10 +149,16 @@ void launch_linv_f32(hipStream_t stream, const double *ext, size_t ext_stride, f
 // inside that last block: 1.03 x the triangular flop count); heavy column tiles are dispatched first.
 // Epilogue: F (fp32) to HBM; sum of F^2 accumulated in fp64 per tile (the trace term's cancellation stays in fp64).
 // ---------------------------------------------------------------------------------------------
-constexpr int PK = 32;               // k-tile
+#ifndef FFVD_F32_KT
+#define FFVD_F32_KT 32               // k-tile of both fp32 products (tuning builds: -DFFVD_F32_KT=16 -DFFVD_F32_OCC=3)
+#endif
+#ifndef FFVD_F32_OCC
+#define FFVD_F32_OCC 2               // workgroups per CU the register budget is sized for
+#endif
+constexpr int PK = FFVD_F32_KT;      // k-tile
 constexpr int P_LD = PK + 4;         // LDS row stride in floats (144 B)
 
-__global__ __launch_bounds__(256, 2) void proj_gemm_f32_kernel(ProjF32Args a) {
+__global__ __launch_bounds__(256, FFVD_F32_OCC) void proj_gemm_f32_kernel(ProjF32Args a) {
     __shared__ __attribute__((aligned(16))) float As[2][128][P_LD];
     __shared__ __attribute__((aligned(16))) float Bs[2][128][P_LD];
     __shared__ double red[4];
@@ -173,13 +179,15 @@ __global__ __launch_bounds__(256, 2) void proj_gemm_f32_kernel(ProjF32Args a) {
     // inside the diagonal k-block a wavefront stops at its own last column (W[k][j] = 0 for k > j)
     const int my_chunks = ((tj * 128 + wc * 64 + 64 < kend) ? tj * 128 + wc * 64 + 64 : kend) / PK;
 
-    // staging: thread moves 16 bytes of rows (tid >> 3) + 32 i, columns 4 (tid & 7) of each operand
-    const int sr = tid >> 3, sc = 4 * (tid & 7);
-    f4v ra[4], rb[4];
+    // staging: a row of the k-tile is PK / 4 lanes x 16 bytes; thread moves rows sr + SROWS i, columns sc of each operand
+    constexpr int LPR = PK / 4, SROWS = 256 / LPR, NPASS = 128 / SROWS;
+    static_assert(PK % 8 == 0 && NPASS >= 1, "k-tile must be a multiple of 8 and at most 128");
+    const int sr = tid / LPR, sc = 4 * (tid % LPR);
+    f4v ra[NPASS], rb[NPASS];
     auto gload = [&](int c) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = sr + 32 * i;
+        for (int i = 0; i < NPASS; ++i) {
+            const int row = sr + SROWS * i;
             int ta = ti * 128 + row; ta = ta < Tp ? ta : Tp - 1;          // clamped: rows beyond Tp are never stored
             int jb = tj * 128 + row; jb = jb < Mp ? jb : Mp - 1;
             ra[i] = *reinterpret_cast<const f4v *>(Kfb + (size_t)ta * Mp + c * PK + sc);
@@ -188,9 +196,9 @@ __global__ __launch_bounds__(256, 2) void proj_gemm_f32_kernel(ProjF32Args a) {
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<f4v *>(&As[buf][sr + 32 * i][sc]) = ra[i];
-            *reinterpret_cast<f4v *>(&Bs[buf][sr + 32 * i][sc]) = rb[i];
+        for (int i = 0; i < NPASS; ++i) {
+            *reinterpret_cast<f4v *>(&As[buf][sr + SROWS * i][sc]) = ra[i];
+            *reinterpret_cast<f4v *>(&Bs[buf][sr + SROWS * i][sc]) = rb[i];
         }
     };
     f16v acc[2][2];
@@ -279,7 +287,7 @@ void launch_sum_partials(hipStream_t stream, const double *part, int n, int nb, 
 // delta^T F in fp64 instead.  The fp32 accumulators are flushed into the fp64 tile in HBM every `flush` t-tiles
 // (flush = 0: once at the end), which bounds the length of any fp32 summation chain.
 // ---------------------------------------------------------------------------------------------
-constexpr int GK = 32;               // t-tile
+constexpr int GK = FFVD_F32_KT;      // t-tile
 constexpr int GF_LD = 128;           // LDS row stride in floats
 
 template <bool DIAG>
@@ -297,11 +305,13 @@ __device__ __forceinline__ void gram_f32_body(const GramF32Args &a, const int bz
     const int sr = tid >> 5, sc = 4 * (tid & 31);            // staging: rows sr + 8 i, 16 bytes at column sc
     const int colA = ti * 128 + sc, colB = tj * 128 + sc;
     const bool okA = colA < Mp, okB = colB < Mp;
-    f4v ra[4], rb[4];
+    constexpr int NPASS = GK / 8;
+    static_assert(GK % 8 == 0 && GK <= 256, "t-tile must be a multiple of 8");
+    f4v ra[NPASS], rb[NPASS];
     double dreg = 0.0;
     auto gload = [&](int c) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NPASS; ++i) {
             const size_t t = (size_t)c * GK + sr + 8 * i;
             ra[i] = okA ? *reinterpret_cast<const f4v *>(Fb + t * Mp + colA) : (f4v){0.f, 0.f, 0.f, 0.f};
             if (!DIAG) rb[i] = okB ? *reinterpret_cast<const f4v *>(Fb + t * Mp + colB) : (f4v){0.f, 0.f, 0.f, 0.f};
@@ -313,7 +323,7 @@ __device__ __forceinline__ void gram_f32_body(const GramF32Args &a, const int bz
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NPASS; ++i) {
             *reinterpret_cast<f4v *>(&As[buf][sr + 8 * i][sc]) = ra[i];
             if (!DIAG) *reinterpret_cast<f4v *>(&Bs[buf][sr + 8 * i][sc]) = rb[i];
         }
@@ -334,12 +344,16 @@ __device__ __forceinline__ void gram_f32_body(const GramF32Args &a, const int bz
     // fp64 tile in HBM <- (first ? 0 : tile) + fp32 accumulators; on the last flush the epilogue of :246 is applied
     auto flush = [&](bool first, bool last) {
         if (!active) return;
+        // the 32 tile addresses are loop-invariant; hoisted out of the t loop they would sit in 64 registers for the whole
+        // kernel: keep their computation here by making the base opaque to the optimiser
+        double *hb = Hb + (size_t)(I0 + 8 * lh) * Mp + J0 + 2 * lc;
+        asm volatile("" : "+v"(hb));
 #pragma unroll
         for (int x = 0; x < 2; ++x)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int i = I0 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * lh) + x, j = J0 + 2 * lc;
-                d2v *p = reinterpret_cast<d2v *>(Hb + (size_t)i * Mp + j);
+                d2v *p = reinterpret_cast<d2v *>(hb + (size_t)(2 * ((r & 3) + 8 * (r >> 2)) + x) * Mp);
                 d2v v = first ? (d2v){0.0, 0.0} : *p;
                 v.x += (double)acc[x][0][r];
                 v.y += (double)acc[x][1][r];
@@ -353,7 +367,7 @@ __device__ __forceinline__ void gram_f32_body(const GramF32Args &a, const int bz
             }
     };
     const int nchunk = a.rows / GK;
-    const int fl = a.flush > 0 ? a.flush : nchunk;
+    const int fl = a.flush > 0 ? (a.flush * 32 / GK > 0 ? a.flush * 32 / GK : 1) : nchunk;      // a.flush counts 32-row units
     gload(0);
     lstore(0);
     __syncthreads();
@@ -395,7 +409,7 @@ __device__ __forceinline__ void gram_f32_body(const GramF32Args &a, const int bz
     }
 }
 
-__global__ __launch_bounds__(256, 2) void gram_f32_kernel(GramF32Args a) {
+__global__ __launch_bounds__(256, FFVD_F32_OCC) void gram_f32_kernel(GramF32Args a) {
     __shared__ __attribute__((aligned(16))) float As[2][GK][GF_LD];
     __shared__ __attribute__((aligned(16))) float Bs[2][GK][GF_LD];
     __shared__ double dls[2][GK];
