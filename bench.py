@@ -162,8 +162,30 @@ def run_rank(args):
     eng_kw = dict(route=args.route, dtype=args.dtype)
     if args.chains_per_pass:
         eng_kw["chains_per_pass"] = args.chains_per_pass
-    sh = ShardedElbo(params, Y, c, meta, rank=rank, world=world, mode=mode, device=local_rank,
-                     collective="torch" if rehearsal else "rccl", **eng_kw)
+    collective = "torch" if rehearsal else "rccl"
+    sh, err = None, None
+    try:
+        sh = ShardedElbo(params, Y, c, meta, rank=rank, world=world, mode=mode, device=local_rank, collective=collective,
+                         **eng_kw)
+    except Exception as exc:               # noqa: BLE001 -- reported below, never swallowed
+        err = exc
+    if dist is not None and not rehearsal:
+        # The benchmark must say which exchange it timed.  If the library's own RCCL communicator cannot be formed on
+        # EVERY rank (e.g. no librccl the process can bind), all ranks agree -- loudly, on stderr and in the JSON line -- to
+        # carry the 8 sums through torch.distributed instead; a failure on some ranks only is an error.
+        import torch
+        ok = torch.tensor([0 if err else 1], dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.SUM)
+        if int(ok.item()) == 0:
+            print(f"[bench rank {rank}] native RCCL path unavailable on all ranks ({err}); timing the torch.distributed "
+                  "(gloo) exchange instead", file=sys.stderr, flush=True)
+            collective = "torch"
+            sh = ShardedElbo(params, Y, c, meta, rank=rank, world=world, mode=mode, device=local_rank,
+                             collective=collective, **eng_kw)
+        elif err is not None or int(ok.item()) != world:
+            raise SystemExit(f"rank {rank}: RCCL communicator formed on {int(ok.item())} of {world} ranks only: {err}")
+    elif err is not None:
+        raise err
 
     def barrier():
         sh.engine.sync()
@@ -245,7 +267,9 @@ def run_rank(args):
             "config": {"workload": f"{args.workload}: synthetic T={T} x_dim={D} C={meta['C']} M={M} S={S} {kname} "
                                    f"{'collapsed-U' if collapsed else 'explicit-U'}, seed {meta['seed']}",
                        "parallelism": (f"{'chains' if mode == 'chains' else 'latent dims'} sharded over {world} GPU(s), "
-                                       "one ncclAllReduce of 8 doubles (ffvd_elbo_allreduce)"),
+                                       + ("one ncclAllReduce of 8 doubles issued by the library (ffvd_elbo_allreduce)"
+                                          if collective == "rccl" else
+                                          "8 partial sums all-reduced through torch.distributed/gloo (rehearsal or RCCL unavailable)")),
                        "chains_per_gpu": s_local, "dims_per_gpu": d_local,
                        "arithmetic": ("fp64 throughout" if args.dtype == "f64" else
                                       "K_fu and the two T x M x M products in fp32 (v_mfma_f32_32x32x2_f32); every M x M "
