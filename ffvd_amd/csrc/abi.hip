@@ -2146,6 +2146,7 @@ extern "C" int ffvd_elbo_tshard(ffvd_handle *h, void *rccl_comm, double out_term
 // RCCL mapped, and two RCCL copies in one process must be avoided), then $FFVD_RCCL_LIB, then the system library.  A
 // build box or a host without RCCL therefore still loads libffvd_hip.so; the collective entry points then fail loudly.
 #include <dlfcn.h>
+#include <mutex>
 #include <rccl/rccl.h>
 
 namespace {
@@ -2158,11 +2159,14 @@ struct RcclApi {
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     std::string why;
 };
+void rccl_bind(RcclApi &api);
 RcclApi *rccl_api() {
     static RcclApi api;
-    static bool tried = false;
-    if (tried) return &api;
-    tried = true;
+    static std::once_flag once;             // handles of different threads may ask at the same time
+    std::call_once(once, [] { rccl_bind(api); });
+    return &api;
+}
+void rccl_bind(RcclApi &api) {
     const char *env = getenv("FFVD_RCCL_LIB");
     const char *names[] = {"librccl.so.1", "librccl.so"};
     for (const char *n : names)
@@ -2171,7 +2175,11 @@ RcclApi *rccl_api() {
     for (const char *n : names)
         if (!api.lib) api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
     if (!api.lib) api.lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!api.lib) { api.why = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?"); return &api; }
+    if (!api.lib) {
+        const char *why = dlerror();
+        api.why = std::string("librccl not found: ") + (why ? why : "?");
+        return;
+    }
     api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.lib, "ncclGetUniqueId");
     api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.lib, "ncclCommInitRank");
     api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
@@ -2181,7 +2189,6 @@ RcclApi *rccl_api() {
         api.why = "librccl lacks an expected symbol";
         api.lib = nullptr;
     }
-    return &api;
 }
 }  // namespace
 
