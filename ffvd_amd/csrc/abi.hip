@@ -37,14 +37,14 @@ struct ffvd_handle {
     int gsplit = 1;
     double *graw = nullptr;                      // unsplit first pass: raw Gram tiles for the deferred trace pass
     hipStream_t aux = nullptr;          // side stream: the K_uu chain runs beside the K_fu build (Gram route)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_kuu = nullptr, ev_tiles = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_kuu = nullptr, ev_tiles = nullptr, ev_go = nullptr;
     std::string err;
     std::vector<void *> allocs;
     int64_t ws_bytes = 0;
     // diagnostic switches, read from the environment ONCE when the handle is created
     struct Switches {
         bool fused_project = false, grad_explicit = false, no_defer_trace = false, no_late_join = false;
-        bool no_main_first = false, no_kfu_first = false, atb128 = false, grad_serial = false;
+        bool no_main_first = false, no_kfu_first = false, atb128 = false, grad_serial = false, kuu_flow = true, kinv_gram = false;
     } sw;
     // resident parameters / data (handle-owned copies)
     double *X = nullptr, *Z = nullptr, *U = nullptr, *logvar = nullptr, *loglen = nullptr, *logQ = nullptr;
@@ -57,6 +57,7 @@ struct ffvd_handle {
     int64_t ts_count = 0;
     double *stage = nullptr;    // staging buffer of ffvd_allreduce_sum
     int64_t stage_count = 0;
+    bool kuu_flow_sched = false;   // schedule of the big unsplit Gram pass, decided in ffvd_create (see there)
     bool info_pending = false;  // an ffvd_elbo_async was enqueued whose Cholesky info flags nobody has looked at yet
     // workspace
     double *variance = nullptr, *len = nullptr, *Zs = nullptr, *zz = nullptr;
@@ -154,6 +155,7 @@ extern "C" int ffvd_destroy(ffvd_handle *h) {
     if (h->ev_join2) hipEventDestroy(h->ev_join2);
     if (h->ev_kuu) hipEventDestroy(h->ev_kuu);
     if (h->ev_tiles) hipEventDestroy(h->ev_tiles);
+    if (h->ev_go) hipEventDestroy(h->ev_go);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
     return FFVD_OK;
@@ -167,6 +169,7 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
         w.fused_project = on("FFVD_FUSED_PROJECT");   w.grad_explicit = on("FFVD_GRAD_EXPLICIT");
         w.no_defer_trace = on("FFVD_NO_DEFER_TRACE"); w.no_late_join = on("FFVD_NO_LATE_JOIN");
         w.no_main_first = on("FFVD_NO_MAIN_FIRST");   w.no_kfu_first = on("FFVD_NO_KFU_FIRST");
+        w.kuu_flow = !on("FFVD_NO_KUU_FLOW");   w.kinv_gram = on("FFVD_KINV_GRAM");
         w.atb128 = on("FFVD_ATB128");                 w.grad_serial = on("FFVD_GRAD_SERIAL");
     }
     h->P = c.D + c.C;
@@ -199,6 +202,7 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
     HIP_TRY(hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_kuu, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_tiles, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_go, hipEventDisableTiming));
     HIP_TRY(dev_alloc(h, &h->X, (size_t)c.S_local * (c.T + 1) * c.D));
     HIP_TRY(dev_alloc(h, &h->Z, (size_t)c.M * P));
     HIP_TRY(dev_alloc(h, &h->U, (size_t)c.M * c.D));
@@ -254,6 +258,7 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
     if ((c.branch == FFVD_BRANCH_B && c.route == FFVD_ROUTE_GRAM) || grad_a) {
         HIP_TRY(dev_alloc(h, &h->Kcopy, Dl * Mp * Mp));
         HIP_TRY(dev_alloc(h, &h->Linv, Dl * Mp * Mp));
+        HIP_TRY(hipMemsetAsync(h->Linv, 0, Dl * Mp * Mp * sizeof(double), h->stream));     // blocks above the diagonal stay zero
         HIP_TRY(dev_alloc(h, &h->Kinv, Dl * Mp * Mp));
         HIP_TRY(dev_alloc(h, &h->trpart, (size_t)h->nbatch * h->ntiles));
         HIP_TRY(dev_alloc(h, &h->kterms, Dl * 2));
@@ -330,11 +335,15 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
         const int upass = h->cpp * (int)Dl;
         h->gsplit = gram_ksplit((int)Mp, upass, (int)Tp);
         if (h->gsplit > 1) HIP_TRY(dev_alloc(h, &h->gpart, gram_part_doubles((int)Mp, upass, h->gsplit)));
+        else if (c.route == FFVD_ROUTE_GRAM && h->sw.kuu_flow && (size_t)upass * Tp * Mp >= (size_t)128 * 4096 * 512)
+            // a K_fu build of 0.4 ms or more: the K_uu chain as ONE dataflow launch finishes beside it, the main stream
+            // joins before the Gram kernel, which then forms the trace partials in its own epilogue
+            h->kuu_flow_sched = true;
         else if (c.route == FFVD_ROUTE_GRAM && (size_t)upass * Tp * Mp >= (size_t)64 * 4096 * 512 && !h->sw.no_defer_trace)
-            HIP_TRY(dev_alloc(h, &h->graw, (size_t)upass * (Mp + 1) * Mp));
+            HIP_TRY(dev_alloc(h, &h->graw, (size_t)upass * (Mp + 1) * Mp));   // raw tiles + trace pass beside Cholesky(A)
     }
-    HIP_TRY(dev_alloc(h, &h->dinvK, (size_t)Dl * DINV_STRIDE));
-    HIP_TRY(dev_alloc(h, &h->dinvH, (size_t)(h->nbatch ? h->nbatch : 1) * DINV_STRIDE));
+    HIP_TRY(dev_alloc(h, &h->dinvK, potrf_scratch_doubles((int)Mp, (int)Dl)));
+    HIP_TRY(dev_alloc(h, &h->dinvH, potrf_scratch_doubles((int)Mp, h->nbatch ? h->nbatch : 1)));
     HIP_TRY(hipMemsetAsync(h->U, 0, (size_t)(c.M * c.D ? c.M * c.D : 1) * sizeof(double), h->stream));
     HIP_TRY(hipMemsetAsync(h->loglen, 0, (size_t)c.D * P * sizeof(double), h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -556,11 +565,33 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
     const bool defer_full = gram_route && !late_join && h->graw;
     const int ns_first = (h->cpp <= c.S_local) ? h->cpp : c.S_local;
     bool kfu_first = false;     // the first pass's K_fu build goes to the main stream before the chain is enqueued
-    bool ident_on_side = false;
+    bool ident_on_side = false, kuu_on_main = false, linv_done = false, hwords_zeroed = false;
     if (gram_route && (late_join || (size_t)first_units * Tp * Mp >= (size_t)64 * 4096 * 512)) {
         sk = h->aux;
+        kuu_on_main = h->kuu_flow_sched && !late_join;
+        if (kuu_on_main)
+            launch_kuu_build(s, c.kernel_kind, hv, c.M, Mp, P, Dl, c.jitter, h->Kuu, h->Kcopy);
         HIP_TRY(hipEventRecord(h->ev_fork, s));
         HIP_TRY(hipStreamWaitEvent(sk, h->ev_fork, 0));
+        if (kuu_on_main) {
+            HIP_TRY(hipEventRecord(h->ev_kuu, s));
+            linv_done = potrf_flow_selected((int)Mp, (int)Dl, CHOL_FLOW);      // L^-1 comes out of the factorisation itself
+            if (linv_done) {
+                // The chain's 64-odd row workgroups (76.8 KB of LDS, 256 VGPRs) must be on the chip BEFORE the K_fu build
+                // floods it with small ones, or they wait for that kernel to drain: the main stream resumes one
+                // cross-queue hop after the clear that sits directly in front of the chain's kernel
+                potrf_flow_clear(sk, h->dinvK, (int)Dl);
+                HIP_TRY(hipEventRecord(h->ev_go, sk));
+            }
+            launch_potrf_ext(sk, h->Kuu, Mp, Mp, Mp, Dl, kstride, h->info, h->dinvK, CHOL_FLOW, h->Linv, msq, linv_done);
+            if (linv_done) {
+                HIP_TRY(hipStreamWaitEvent(s, h->ev_go, 0));
+                if (c.S_local <= h->cpp) {          // single pass: the words of Cholesky(A) are cleared here, off the main stream
+                    potrf_flow_clear(sk, h->dinvH, h->nbatch);
+                    hwords_zeroed = true;
+                }
+            }
+        }
         kfu_first = main_first || (defer_full && !h->sw.no_kfu_first);
         if (kfu_first) {
             if (st) st->mark(0);
@@ -580,20 +611,26 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
             launch_set_identity(sk, h->H, ga.h_stride, Mp, Mp, ns_first * Dl);
         }
     }
-    launch_kuu_build(sk, c.kernel_kind, hv, c.M, Mp, P, Dl, c.jitter, h->Kuu, (gram_route || grad_a) ? h->Kcopy : nullptr);
-    if (defer_trace || (defer_full && sk != s)) HIP_TRY(hipEventRecord(h->ev_kuu, sk));
-    launch_potrf_ext(sk, h->Kuu, Mp, Mp, Mp, Dl, kstride, h->info, h->dinvK);
+    if (!kuu_on_main) {
+        launch_kuu_build(sk, c.kernel_kind, hv, c.M, Mp, P, Dl, c.jitter, h->Kuu, (gram_route || grad_a) ? h->Kcopy : nullptr);
+        if (defer_trace || (defer_full && sk != s)) HIP_TRY(hipEventRecord(h->ev_kuu, sk));
+        launch_potrf_ext(sk, h->Kuu, Mp, Mp, Mp, Dl, kstride, h->info, h->dinvK);
+    }
     if (gram_route || grad_a) {
         // K^-1 = L^-T L^-1 (shared by all chains) and log|K|
-        launch_transpose(sk, h->Kuu + msq, kstride, h->Linv, msq, Mp, Dl);
+        if (!linv_done) launch_transpose(sk, h->Kuu + msq, kstride, h->Linv, msq, Mp, Dl);
         GramArgs gk{};
         gk.mode = GRAM_PLAIN; gk.A = h->Linv; gk.a_stride = msq; gk.rows = Mp; gk.with_row = 0; gk.Mp = Mp; gk.Dl = Dl;
         gk.d_begin = c.d_begin; gk.b0 = 0; gk.nb = Dl; gk.yn_over_batch = 1.0; gk.H = h->Kinv; gk.h_stride = msq;
-        if (c.grad) {       // the backward pass reads K^-1 everywhere, the Gram kernel only writes lower tiles
+        if (c.grad || (kuu_on_main && !h->sw.kinv_gram)) {
+            // the backward pass reads K^-1 everywhere, the Gram kernel only writes lower tiles; and beside the K_fu build
+            // (kuu_on_main: the main stream waits for this product) 256-thread workgroups find a slot where the Gram
+            // kernel's 1024-thread ones wait for the build to drain (0.19 against 0.05 ms)
             AtbArgs ak{};
             ak.mode = ATB_PLAIN; ak.A = h->Linv; ak.a_stride = msq; ak.lda = Mp; ak.nA = Mp; ak.B = h->Linv; ak.b_stride = msq;
             ak.ldb = Mp; ak.nB = Mp; ak.rows = Mp; ak.C = h->Kinv; ak.c_stride = msq; ak.ldc = Mp; ak.nb = Dl; ak.Dl = Dl;
             ak.k_lower = 1;                                  // L^-1 is lower triangular
+            ak.small_tiles = kuu_on_main ? 1 : 0;
             launch_atb(sk, ak);
         } else launch_gram(sk, gk);     // (split-K here was measured slower: 0.42 vs 0.37 ms for the K_uu stage)
         launch_h_finish(sk, h->Kuu, Mp, kstride, Dl, h->kterms);
@@ -686,6 +723,15 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
                 launch_gram_f32(s, gf);                               // H = F^T F / Q + I, b = delta^T F / Q  (:246-248)
             } else launch_gram(s, ga);
             if (st) st->mark(2);
+            if (trace_pending) {
+                // trace partials from the raw tiles, on the side stream (K^-1 precedes in its order).  Enqueued AHEAD of the
+                // factorisation: that is one launch whose row workgroups hold every slot of the chip for most of its length,
+                // and a kernel that arrives behind it only starts when they leave (finalize then waited 0.26 ms for this pass)
+                HIP_TRY(hipStreamWaitEvent(sk, h->ev_tiles, 0));
+                launch_gram(sk, ga, 3);
+                HIP_TRY(hipEventRecord(h->ev_join2, sk));                 // supersedes the record after the reductions
+                trace_pending = false;
+            }
             if (c.grad) {       // keep A = K_uu + K_uf K_fu / Q: the factorisation overwrites it in place
                 if (!acopy_done)
                     HIP_TRY(hipMemcpy2DAsync(h->gw.Acopy, msq * sizeof(double), h->H, ga.h_stride * sizeof(double),
@@ -713,19 +759,15 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
                     HIP_TRY(hipMemcpy2DAsync(h->H + 2 * msq, ga.h_stride * sizeof(double), g.bw, (size_t)Mp * sizeof(double),
                                              (size_t)Mp * sizeof(double), (size_t)nbp, hipMemcpyDeviceToDevice, s));
                 }
-                launch_potrf_ext(s, h->H, Mp, Mp + NB, Mp, ns * Dl, ga.h_stride, h->info + Dl + s0 * Dl, h->dinvH);
+                launch_potrf_ext(s, h->H, Mp, Mp + NB, Mp, ns * Dl, ga.h_stride, h->info + Dl + s0 * Dl, h->dinvH, CHOL_FLOW, nullptr, 0,
+                                 hwords_zeroed && s0 == 0);
                 launch_h_finish(s, h->H, Mp, ga.h_stride, ns * Dl, h->hterms + (size_t)2 * s0 * Dl, 2 * Mp);
             } else {
-                launch_potrf_ext(s, h->H, Mp, NB, 0, ns * Dl, ga.h_stride, h->info + Dl + s0 * Dl, h->dinvH);
+                launch_potrf_ext(s, h->H, Mp, NB, 0, ns * Dl, ga.h_stride, h->info + Dl + s0 * Dl, h->dinvH, CHOL_FLOW, nullptr, 0,
+                                 hwords_zeroed && s0 == 0);
                 launch_h_finish(s, h->H, Mp, ga.h_stride, ns * Dl, h->hterms + (size_t)2 * s0 * Dl);
             }
             if (st) st->mark(3);
-            if (trace_pending) {       // trace partials from the raw tiles, on the side stream (K^-1 precedes in its order)
-                HIP_TRY(hipStreamWaitEvent(sk, h->ev_tiles, 0));
-                launch_gram(sk, ga, 3);
-                HIP_TRY(hipEventRecord(h->ev_join2, sk));                 // supersedes the record after the reductions
-                trace_pending = false;
-            }
         }
     }
     if (!reduce_early) launch_chain_reduce(s, ra, h->chain_partial);
@@ -1422,7 +1464,7 @@ extern "C" int ffvd_op_cholesky(const double *A, int n, int batch, double *L, in
     int32_t *dinfo = sc.alloc<int32_t>(batch);
     OP_CHECK(dinfo, "ffvd_op_cholesky");
     HIP_TRY(hipMemsetAsync(dinfo, 0, batch * sizeof(int32_t), sc.stream));
-    double *dinv = sc.alloc<double>((size_t)batch * DINV_STRIDE);
+    double *dinv = sc.alloc<double>(potrf_scratch_doubles(np, batch));
     OP_CHECK(dinv, "ffvd_op_cholesky");
     launch_potrf_ext(sc.stream, dA, np, 0, 0, batch, slab, dinfo, dinv);
     std::vector<int32_t> hinfo(batch, 0);
@@ -1464,7 +1506,7 @@ static int build_kuu(Scratch &sc, int kind, const double *Z, int M, int P, int D
     w.zz = sc.alloc<double>((size_t)D * Mp);
     w.Kuu = sc.alloc<double>((size_t)D * 2 * Mp * Mp);
     w.info = sc.alloc<int32_t>(D);
-    w.dinv = sc.alloc<double>((size_t)D * DINV_STRIDE);
+    w.dinv = sc.alloc<double>(potrf_scratch_doubles(Mp, D));
     if (!dZ || !w.logvar || !w.loglen || !w.variance || !w.len || !w.Zs || !w.zz || !w.Kuu || !w.info || !w.dinv) return FFVD_ENOMEM;
     if (loglengthscales &&
         hipMemcpyAsync(w.loglen, loglengthscales, (size_t)D * P * sizeof(double), hipMemcpyHostToDevice, sc.stream) != hipSuccess)
@@ -1575,7 +1617,7 @@ extern "C" int ffvd_op_collapse(int kind, const double *Lm_inverse_seq, const do
     double *rowsq = sc.alloc<double>((size_t)D * ng * Tp);
     double *hterms = sc.alloc<double>((size_t)D * 2), *cterms = sc.alloc<double>(8);
     int32_t *info = sc.alloc<int32_t>(D);
-    double *dinv = sc.alloc<double>((size_t)D * DINV_STRIDE);
+    double *dinv = sc.alloc<double>(potrf_scratch_doubles(Mp, D));
     if (!dW || !dXc || !dX || !dZ || !dlv || !dll || !dlq || !variance || !len || !Zs || !zz || !F || !H || !rowsq ||
         !hterms || !cterms || !info || !dinv)
         return set_error(nullptr, FFVD_ENOMEM, "ffvd_op_collapse: device allocation or upload failed");
@@ -1741,7 +1783,7 @@ extern "C" int ffvd_op_collapse_u_mean(int kind, const double *Lm_inverse_seq, c
     double *H = sc.upload(Hinit.data(), Hinit.size());
     double *dU = sc.alloc<double>((size_t)M * D);
     int32_t *info = sc.alloc<int32_t>(D);
-    double *dinv = sc.alloc<double>((size_t)D * DINV_STRIDE);
+    double *dinv = sc.alloc<double>(potrf_scratch_doubles(Mp, D));
     if (!dW || !dXc || !dX || !dZ || !dlv || !dlq || !dll || !variance || !len || !Zs || !zz || !F || !rowsq || !H || !dU || !info || !dinv)
         return set_error(nullptr, FFVD_ENOMEM, "ffvd_op_collapse_u_mean: device allocation or upload failed");
     if (loglengthscales)
@@ -2072,7 +2114,7 @@ static int enqueue_tshard_finish(ffvd_handle *h) {
     ga.Kadd = h->Kcopy; ga.kadd_stride = msq; ga.Kinv = h->Kinv; ga.kinv_stride = msq; ga.trpart = h->trpart;
     ga.part = h->tsbuf; ga.ksplit = 1;
     launch_gram(s, ga, 4);
-    launch_potrf_ext(s, h->H, Mp, NB, 0, h->nbatch, ga.h_stride, h->info + Dl, h->dinvH);
+    launch_potrf_ext(s, h->H, Mp, NB, 0, h->nbatch, ga.h_stride, h->info + Dl, h->dinvH, CHOL_FLOW);
     launch_h_finish(s, h->H, Mp, ga.h_stride, h->nbatch, h->hterms);
     FinalizeArgs fa{};
     fa.kind = c.kernel_kind; fa.branch = c.branch; fa.prior_type = c.prior_type; fa.shared_terms = c.shared_terms;

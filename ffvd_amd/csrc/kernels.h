@@ -45,9 +45,22 @@ void launch_kernel_diag(hipStream_t stream, int kind, const double *X, int N, in
 // L and the extra rows hold R * L^{-T}.  identity_extra != 0 declares that R is the n x n identity on entry
 // (so R L^{-T} = L^{-T} is upper triangular and zero blocks are skipped).  info[b] = 0 or 1 + first bad pivot.
 // identity_rows: how many of the LEADING extra rows form an identity on entry (multiple of NB, 0 = none).
-// dinv: device scratch of batch * DINV_STRIDE doubles (inverted 16x16 diagonal sub-blocks of the current block step).
+// dinv: device scratch of potrf_scratch_doubles(n, batch) doubles (inverted 16x16 diagonal sub-blocks of the block steps and,
+// for the one-launch dataflow variant, its progress words).  hint = CHOL_FLOW asks for the dataflow variant whatever the batch
+// (the factorisation is on the caller's critical path); CHOL_AUTO picks by batch size.
+enum { CHOL_AUTO = 0, CHOL_FLOW = 3 };
+size_t potrf_scratch_doubles(int n, int batch);
+// linv_t (optional, honoured by the dataflow variant only -- ask potrf_flow_selected): the identity-structured extra rows
+// are ALSO written transposed, L^-1 as an n x n lower-triangular matrix (ld n) per slab of linv_t_stride doubles; the blocks
+// above its diagonal are left alone (keep them zero).
+bool potrf_flow_selected(int n, int batch, int hint);
 void launch_potrf_ext(hipStream_t stream, double *A, int n, int extra_rows, int identity_rows, int batch,
-                      size_t slab_stride, int32_t *info, double *dinv);
+                      size_t slab_stride, int32_t *info, double *dinv, int hint = CHOL_AUTO, double *linv_t = nullptr,
+                      size_t linv_t_stride = 0, bool words_zeroed = false);
+// The dataflow variant polls progress words at the start of `dinv`; they must be zero when its kernel starts.  The launcher
+// clears them itself (one memset in front of the kernel) unless the caller has done so earlier with potrf_flow_clear on a
+// stream whose order reaches the launch, and says so (words_zeroed).
+void potrf_flow_clear(hipStream_t stream, double *dinv, int batch);
 void launch_set_identity(hipStream_t stream, double *A, size_t slab_stride, int row0, int n, int batch);
 // R <- R L^-T for `extra_rows` rows (multiple of NB) stored below a GIVEN lower-triangular factor L (n x n, ld n) in
 // every slab: the wavefront-level blocked substitution of the Cholesky panel step on its own.

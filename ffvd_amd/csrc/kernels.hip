@@ -431,7 +431,11 @@ __device__ __forceinline__ void diag_block_finish(double (*Ts)[NB + 1], double (
         double a[NB];
 #pragma unroll
         for (int c = 0; c < NB; ++c) a[c] = Ts[lane][c];
+        // the pivot chain is one wavefront's dependent latency: it goes first whenever a wavefront of another workgroup
+        // shares its SIMD
+        __builtin_amdgcn_s_setprio(3);
         const int bad = chol64_1w<PIPE>(a, Lr, invd, lane);
+        __builtin_amdgcn_s_setprio(0);
         if (bad && lane == 0 && *info_b == 0) *info_b = k0 + bad;
     }
     __syncthreads();
@@ -899,28 +903,408 @@ void launch_trsm_ext(hipStream_t stream, double *A, int n, int extra_rows, int b
     }
 }
 
-// Which blocked variant factorises a batch: the left-looking column kernel pays off where the right-looking one is
-// bandwidth-bound (many matrices: every block written once), the right-looking one where the factorisation is a pure
-// latency chain (few matrices: one block product on the critical path of a step instead of j, and workgroups small enough
-// to slip in beside the Gram kernel when the chain runs on the side stream).  FFVD_CHOL=left|right forces one (read once).
-static int chol_mode() {                    // 0 = auto, 1 = left-looking always, 2 = right-looking always
+// ---------------------------------------------------------------------------------------------
+// Dataflow variant: the whole left-looking factorisation of a batch in ONE launch.  One workgroup per 64-row block row of
+// every matrix walks its row from left to right,
+//     for j < r:  X(r,j) = (A(r,j) - sum_{k<j} X(r,k) L(j,k)^T) L_jj^-T        then (main rows)  L_rr = chol(A(r,r) - sum_k X(r,k) X(r,k)^T),
+// and learns from one progress word per (matrix, block row) when the row above it is ready:  prog[j] = j once the panels
+// X(j,0..j-1) are in memory, j + 1 once L_jj and its inverted 16 x 16 diagonal sub-blocks are.  What the per-column launches
+// of potrf_ll_kernel serialised -- the gather of column j (j block products) in front of every diagonal factor -- now runs
+// beside the pivot chain of the block above: the chain of dependent work per block column is one substitution, one block
+// product and the 64-pivot factor.
+// Hand-off (MI355X guide, inter-workgroup visibility): producer = plain stores, every storing wavefront waits for them, a
+// workgroup barrier, ONE lane's agent-scope release, its wait, a relaxed agent-scope store of the word; consumer = ONE lane
+// polls the word relaxed, ONE agent-scope acquire and its wait, a workgroup barrier, then plain loads.  Results never depend on
+// where or when a workgroup runs.  Progress does: a row waits for rows of the same matrix with a lower blockIdx only, which
+// the dispatcher starts first; every spin is bounded all the same (wall clock; a stuck launch sets the abort word, every
+// waiting workgroup leaves, info[b] = -1 says so).
+// Block order (group, row, matrix-in-group): G a multiple of 8, so all rows of a matrix share blockIdx % 8 = one XCD's L2.
+// ---------------------------------------------------------------------------------------------
+constexpr int DF_PS = 64;                         // progress words per matrix (main block rows: n <= 4096)
+constexpr int DF_DINV = 4 * 16 * 16;              // doubles of inverted diagonal sub-blocks per (matrix, block column)
+constexpr long long DF_SPIN_TICKS = 100000000LL;  // bound of one wait: 1 s of the 100 MHz wall clock
+
+struct DfArgs {
+    double *A;
+    int n, nb, next, nid, batch, G;
+    size_t slab_stride;
+    int32_t *info;
+    double *dinv;      // [batch][nb][DF_DINV]
+    int *prog;         // [batch][DF_PS], zeroed before the launch
+    int *abort_w;      // one word, zeroed before the launch
+    double *xt;        // optional: the identity-structured extra rows (R L^-T = L^-T) also land TRANSPOSED here, i.e. L^-1 as
+    size_t xt_stride;  //   an n x n lower-triangular matrix (ld n) per slab; blocks above its diagonal are not written
+};
+
+// Debug build only (-DFFVD_DF_TRACE, tools/df_trace.py): wall-clock stamps of matrix 0's block rows, in a buffer of their own.
+#ifdef FFVD_DF_TRACE
+__device__ long long df_trace_buf[64 * 64];
+#define DF_STAMP(row, slot) do { if ((row) >= 0 && threadIdx.x == 0) df_trace_buf[(row) * 64 + (slot)] = wall_clock64(); } while (0)
+extern "C" int ffvd_debug_df_trace(long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(df_trace_buf), sizeof(long long) * 64 * 64);
+}
+#else
+#define DF_STAMP(row, slot) do { } while (0)
+#endif
+
+// Thread 0 waits until *flag >= need, acquires, and hands the value it saw (or -1: gave up) to the workgroup.
+__device__ __forceinline__ int df_wait(int *flag, int need, int *abort_w, int *slot) {
+    if (threadIdx.x == 0) {
+        int v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v < need) {
+            const long long t0 = wall_clock64();
+            for (;;) {
+                __builtin_amdgcn_s_sleep(2);
+                v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v >= need) break;
+                if (__hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { v = -1; break; }
+                if (wall_clock64() - t0 > DF_SPIN_TICKS) {
+                    __hip_atomic_store(abort_w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    v = -1;
+                    break;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        *slot = v;
+    }
+    __syncthreads();
+    return *slot;
+}
+
+// ONE lane, behind the workgroup barrier that follows every storing wavefront's own wait for its stores.
+__device__ __forceinline__ void df_publish(int *flag, int value) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the compiler may drop the fence's own wait (guide: compiler hazard)
+    __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // a later store to the same word (another wavefront) must not overtake
+}
+
+// One block column of one block row: X(r,j) = (A(r,j) - sum_{k0<=k<j} X(r,k) L(j,k)^T) L_jj^-T.  LAST (the column left of
+// the diagonal of a main row) also loads A(r,r), sums X(r,k) X(r,k)^T over k < j into acc_d beside the gather, and leaves the
+// solved tile in sm0 for the newest term.  Returns false when a wait gave up.
+template <bool LAST>
+__device__ __forceinline__ bool df_column(const DfArgs &a, double *S, int *pg, const double *dvb, const int row0, const int j,
+                                          const int k0, double (*Xs)[LL_LD], double (*Ls)[LL_LD], double (*Dv)[16][DV_LD],
+                                          int *wslot, int &wc, d4 (&cold_d)[2][2], d4 (&acc_d)[2][2], const int trow,
+                                          double *xt_row = nullptr) {
+    const int n = a.n;
+    DF_STAMP(trow, 5 * (j & 7) + 0);
+    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qr = wave >> 1, qc = wave & 1;
+    const int sr = tid >> 5, sc = 2 * (tid & 31);
+    const int j0 = j * NB;
+    const bool do_d = LAST && !(qr == 0 && qc == 1);       // the quadrant above the diagonal of S_rr is never read
+    // this row's own tiles (nobody else writes them): requested first, their latency hides behind the waits and the k loop
+    d4 cold_t[2][2], acc_t[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const size_t rr = (size_t)(row0 + qr * 32 + 16 * x + lk + 4 * q), cc = (size_t)(qc * 32 + 16 * y + lr);
+                cold_t[x][y][q] = S[rr * n + j0 + cc];
+                if (LAST) cold_d[x][y][q] = S[rr * n + row0 + cc];
+            }
+            acc_t[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
+        }
+    int seen = -2;
+    if (j > k0) {
+        seen = df_wait(pg + j, j, a.abort_w, &wslot[wc++ & 1]);          // the panels of block row j are in memory
+        if (seen < 0) return false;
+        DF_STAMP(trow, 5 * (j & 7) + 1);
+        d2 vx[8], vl[8];
+        auto gload = [&](int k) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                vl[i] = *reinterpret_cast<const d2 *>(S + (size_t)(j0 + sr + 8 * i) * n + k * NB + sc);
+                vx[i] = *reinterpret_cast<const d2 *>(S + (size_t)(row0 + sr + 8 * i) * n + k * NB + sc);
+            }
+        };
+        gload(k0);
+        for (int k = k0; k < j; ++k) {
+            if (k > k0) __syncthreads();                    // everyone is done reading the previous tiles
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                Ls[sr + 8 * i][sc] = vl[i].x; Ls[sr + 8 * i][sc + 1] = vl[i].y;
+                Xs[sr + 8 * i][sc] = vx[i].x; Xs[sr + 8 * i][sc + 1] = vx[i].y;
+            }
+            __syncthreads();
+            if (k + 1 < j) gload(k + 1);                    // in flight behind this step's MFMAs
+#pragma unroll 4
+            for (int ks = 0; ks < NB / 4; ++ks) {
+                double bl[2], ax[2], bx[2];
+#pragma unroll
+                for (int x = 0; x < 2; ++x) {
+                    bl[x] = Ls[qc * 32 + 16 * x + lr][4 * ks + lk];            // B[k][col] = L(j,k)[col][k]
+                    ax[x] = Xs[qr * 32 + 16 * x + lr][4 * ks + lk];
+                    bx[x] = do_d ? Xs[qc * 32 + 16 * x + lr][4 * ks + lk] : 0.0;
+                }
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                    for (int y = 0; y < 2; ++y) acc_t[x][y] = mfma_f64(ax[x], bl[y], acc_t[x][y]);
+                if (do_d) {
+#pragma unroll
+                    for (int x = 0; x < 2; ++x)
+#pragma unroll
+                        for (int y = 0; y < 2; ++y) acc_d[x][y] = mfma_f64(ax[x], bx[y], acc_d[x][y]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    DF_STAMP(trow, 5 * (j & 7) + 2);
+    // T into sm0
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                Xs[qr * 32 + 16 * x + lk + 4 * q][qc * 32 + 16 * y + lr] = cold_t[x][y][q] - acc_t[x][y][q];
+    if (seen < j + 1) {                                                       // L_jj and its inverted sub-blocks are in memory
+        seen = df_wait(pg + j, j + 1, a.abort_w, &wslot[wc++ & 1]);
+        if (seen < 0) return false;
+    }
+    DF_STAMP(trow, 5 * (j & 7) + 3);
+    // -L_jj (exactly zero above the diagonal: the refinement step reads the diagonal blocks) into sm1
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = sr + 8 * i;
+        const d2 v = *reinterpret_cast<const d2 *>(S + (size_t)(j0 + r) * n + j0 + sc);
+        Ls[r][sc] = (sc <= r) ? -v.x : 0.0;
+        Ls[r][sc + 1] = (sc + 1 <= r) ? -v.y : 0.0;
+    }
+    {
+        const double *dv = dvb + (size_t)j * DF_DINV;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i;
+            Dv[e >> 8][(e >> 4) & 15][e & 15] = dv[e];
+        }
+    }
+    __syncthreads();
+    DF_STAMP(trow, 52 + (j & 7));
+    // X(r,j) = T L_jj^-T (potrf_panel_kernel has the derivation)
+    d4 Rt[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Rt[s4][r] = Xs[16 * wave + lr][16 * s4 + 4 * r + lk];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        d4 x = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) x = mfma_f64(Dv[s4][lr][4 * ks + lk], Rt[s4][ks], x);
+        d4 res = Rt[s4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) res = mfma_f64(Ls[16 * s4 + lr][16 * s4 + 4 * ks + lk], x[ks], res);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) x = mfma_f64(Dv[s4][lr][4 * ks + lk], res[ks], x);
+        Rt[s4] = x;
+#pragma unroll
+        for (int t = s4 + 1; t < 4; ++t)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) Rt[t] = mfma_f64(Ls[16 * t + lr][16 * s4 + 4 * ks + lk], x[ks], Rt[t]);
+    }
+    double *Rl = S + (size_t)(row0 + 16 * wave + lr) * n + j0 + lk;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Rl[16 * s4 + 4 * r] = Rt[s4][r];
+    if (!LAST && xt_row) {                                 // block (j, e) of L^-1 = X(e,j)^T: 128-byte runs along lr
+        double *Tl = xt_row + (size_t)(j0 + lk) * n + 16 * wave + lr;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Tl[(size_t)(16 * s4 + 4 * r) * n] = Rt[s4][r];
+    }
+    if (LAST) {
+        // the newest term of S_rr comes from the tile just solved (each wavefront rewrites its own 16 rows of sm0, which it
+        // alone has read)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Xs[16 * wave + lr][16 * s4 + 4 * r + lk] = Rt[s4][r];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's panel stores have left it (published below)
+    }
+    __syncthreads();                                       // sm0 / sm1 are free for the next column (LAST: X(r,j) is in sm0)
+    DF_STAMP(trow, 5 * (j & 7) + 4);
+    return true;
+}
+
+template <bool PIPE>
+__global__ __launch_bounds__(256, 2) void potrf_df_kernel(DfArgs a) {
+    __shared__ double sm0[NB * LL_LD];      // X(r,k) tiles; then T = A(r,j) - sum and the solved X(r,j)
+    __shared__ double sm1[NB * LL_LD];      // L(j,k) tiles; then -L_jj; at the end S_rr and its factor
+    __shared__ double invd[NB];
+    __shared__ double Dv[4][16][DV_LD];
+    __shared__ int wslot[2];
+    const int n = a.n, nb = a.nb;
+    const int per_group = (nb + a.next) * a.G;
+    const int grp = blockIdx.x / per_group, rem = blockIdx.x % per_group;
+    const int ri = rem / a.G, b = grp * a.G + rem % a.G;
+    if (b >= a.batch) return;
+    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qr = wave >> 1, qc = wave & 1;
+    double *S = a.A + (size_t)b * a.slab_stride;
+    int *pg = a.prog + (size_t)b * DF_PS;
+    double *dvb = a.dinv + (size_t)b * nb * DF_DINV;
+    const bool main_row = ri < nb;
+    int row0, k0 = 0, ncols;                // first row of the block row; first block column with non-zero X(r,k); columns to solve
+    if (main_row) { row0 = ri * NB; ncols = ri; }
+    else {
+        const int e = ri - nb;
+        row0 = n + e * NB; ncols = nb;
+        if (e < a.nid) k0 = e;              // identity-structured rows: block e is zero left of block column e
+    }
+    double (*Xs)[LL_LD] = reinterpret_cast<double(*)[LL_LD]>(sm0);
+    double (*Ls)[LL_LD] = reinterpret_cast<double(*)[LL_LD]>(sm1);
+    int wc = 0;
+    const int trow = (b == 0) ? ri : -1;
+    DF_STAMP(trow, 51);
+    {
+        const int nplain = main_row ? ncols - 1 : ncols;
+        double *xt_row = (a.xt && !main_row && ri - nb < a.nid) ? a.xt + (size_t)b * a.xt_stride + (size_t)(ri - nb) * NB : nullptr;
+        for (int j = k0; j < nplain; ++j) {
+            d4 unused_c[2][2], unused_a[2][2];
+            if (!df_column<false>(a, S, pg, dvb, row0, j, k0, Xs, Ls, Dv, wslot, wc, unused_c, unused_a, trow, xt_row)) {
+                if (tid == 0) a.info[b] = -1;
+                return;
+            }
+        }
+    }
+    if (!main_row) return;
+    // S_rr = A(r,r) - sum_{k<r} X(r,k) X(r,k)^T
+    d4 cold_d[2][2], acc_d[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc_d[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
+    if (ncols > 0) {
+        if (!df_column<true>(a, S, pg, dvb, row0, ncols - 1, k0, Xs, Ls, Dv, wslot, wc, cold_d, acc_d, trow)) {
+            if (tid == 0) a.info[b] = -1;
+            return;
+        }
+        if (!(qr == 0 && qc == 1)) {
+#pragma unroll 4
+            for (int ks = 0; ks < NB / 4; ++ks) {
+                double ax[2], bx[2];
+#pragma unroll
+                for (int x = 0; x < 2; ++x) {
+                    ax[x] = Xs[qr * 32 + 16 * x + lr][4 * ks + lk];
+                    bx[x] = Xs[qc * 32 + 16 * x + lr][4 * ks + lk];
+                }
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                    for (int y = 0; y < 2; ++y) acc_d[x][y] = mfma_f64(ax[x], bx[y], acc_d[x][y]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    cold_d[x][y][q] = S[(size_t)(row0 + qr * 32 + 16 * x + lk + 4 * q) * n + row0 + qc * 32 + 16 * y + lr];
+    }
+    double (*Ts)[NB + 1] = reinterpret_cast<double(*)[NB + 1]>(sm1);     // -L_jj is no longer needed (all past the solve)
+    double (*Lr)[LR_LD] = reinterpret_cast<double(*)[LR_LD]>(sm1);
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                Ts[qr * 32 + 16 * x + lk + 4 * q][qc * 32 + 16 * y + lr] = cold_d[x][y][q] - acc_d[x][y][q];
+    __syncthreads();
+    DF_STAMP(trow, 48);
+    // the panels of this row are published by wavefront 1 while wavefront 0 runs the pivot chain
+    if (ncols > 0 && tid == 64) df_publish(pg + ri, ri);
+    diag_block_finish<PIPE>(Ts, Lr, invd, S, n, row0, a.info + b, dvb + (size_t)ri * DF_DINV);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    DF_STAMP(trow, 49);
+    if (tid == 0) df_publish(pg + ri, ri + 1);
+    DF_STAMP(trow, 50);
+}
+
+size_t potrf_scratch_doubles(int n, int batch) {
+    const size_t nb = (size_t)(n / NB), bt = (size_t)(batch > 0 ? batch : 1);
+    const size_t flow = ((bt * DF_PS + 4) * sizeof(int) + 15) / 16 * 2 + bt * nb * DF_DINV;
+    const size_t step = bt * DINV_STRIDE;
+    return flow > step ? flow : step;
+}
+
+// Zero the progress words of a dataflow launch for `batch` matrices (they sit at the start of the scratch block, padded to 16
+// bytes).  launch_potrf_ext does this itself unless told that the caller already has (words_zeroed).
+void potrf_flow_clear(hipStream_t stream, double *scratch, int batch) {
+    const size_t words = ((size_t)batch * DF_PS + 4 + 3) / 4 * 4;
+    (void)hipMemsetAsync(scratch, 0, words * sizeof(int), stream);
+}
+
+static void launch_potrf_flow(hipStream_t stream, double *A, int n, int extra_rows, int identity_rows, int batch,
+                              size_t slab_stride, int32_t *info, double *scratch, double *linv_t, size_t linv_t_stride,
+                              bool words_zeroed) {
+    DfArgs a{};
+    a.xt = linv_t; a.xt_stride = linv_t_stride;
+    a.A = A; a.n = n; a.nb = n / NB; a.next = extra_rows / NB; a.nid = identity_rows / NB; a.batch = batch;
+    a.slab_stride = slab_stride; a.info = info;
+    // the polled words sit at the start of the scratch block, padded to 16 bytes, and are zeroed before every launch
+    const size_t words = ((size_t)batch * DF_PS + 4 + 3) / 4 * 4;
+    a.prog = reinterpret_cast<int *>(scratch);
+    a.abort_w = a.prog + (size_t)batch * DF_PS;
+    a.dinv = scratch + words / 2;
+    if (!words_zeroed) potrf_flow_clear(stream, scratch, batch);
+    const int R = a.nb + a.next, bp = (batch + 7) / 8 * 8;
+    // all matrices in lockstep while the grid is a few rounds of the chip (rows leave early and make room); beyond that,
+    // groups of about two chip-fulls of block rows, so that the rows of one matrix run together (they share L(j,k) in L2)
+    a.G = ((size_t)bp * R <= 2048) ? bp : ((1024 / R + 7) / 8 * 8 < 8 ? 8 : (1024 / R + 7) / 8 * 8);
+    if (a.G > bp) a.G = bp;
+    const int groups = (batch + a.G - 1) / a.G;
+    hipLaunchKernelGGL(potrf_df_kernel<true>, dim3((unsigned)((size_t)groups * R * a.G)), dim3(256), 0, stream, a);
+}
+
+// Which blocked variant factorises a batch: the dataflow kernel (one launch, rows handing blocks to each other) wherever the
+// factorisation sits on the critical path; the right-looking launches for the few matrices of the K_uu chain, whose small
+// workgroups slip in beside the Gram kernel when the chain runs on the side stream (the 76.8 KB / 256-VGPR row workgroups of the
+// other two variants would wait for that kernel to drain).  The per-column left-looking launches (round 2's first variant)
+// stay selectable.  FFVD_CHOL=flow|left|right forces one (read once).
+static int chol_mode() {                    // 0 = auto, 1 = left-looking launches, 2 = right-looking launches, 3 = dataflow
     static const int v = [] {
         const char *e = getenv("FFVD_CHOL");
         if (!e) return 0;
-        return (e[0] == 'l') ? 1 : ((e[0] == 'r') ? 2 : 0);
+        return (e[0] == 'l') ? 1 : ((e[0] == 'r') ? 2 : ((e[0] == 'f') ? 3 : 0));
     }();
     return v;
 }
-static bool chol_right_looking(int batch) {
-    const int m = chol_mode();
-    return m == 2 || (m == 0 && batch < 32);
+static int chol_variant(int batch, int nb, int hint);
+bool potrf_flow_selected(int n, int batch, int hint) { return chol_variant(batch, n / NB, hint) == 3; }
+static int chol_variant(int batch, int nb, int hint) {
+    int m = chol_mode();
+    if (m == 0) m = (hint == CHOL_FLOW || batch >= 32) ? 3 : 2;
+    if (m == 3 && nb > DF_PS) m = 1;
+    return m;
 }
 
 void launch_potrf_ext(hipStream_t stream, double *A, int n, int extra_rows, int identity_rows, int batch,
-                      size_t slab_stride, int32_t *info, double *dinv) {
+                      size_t slab_stride, int32_t *info, double *dinv, int hint, double *linv_t, size_t linv_t_stride,
+                      bool words_zeroed) {
     const int nb = n / NB;
     const int nid = identity_rows / NB, ntail = extra_rows / NB - nid;
-    if (!chol_right_looking(batch)) {
+    const int variant = chol_variant(batch, nb, hint);
+    if (variant == 3) {
+        launch_potrf_flow(stream, A, n, extra_rows, identity_rows, batch, slab_stride, info, dinv, linv_t, linv_t_stride, words_zeroed);
+        return;
+    }
+    if (variant == 1) {
         const int groups = (batch + 7) / 8;
         hipLaunchKernelGGL(potrf_diag_kernel, dim3(batch), dim3(256), 0, stream, A, n, 0, slab_stride, info, dinv);
         for (int j = 0; j < nb; ++j) {
