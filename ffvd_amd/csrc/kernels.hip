@@ -337,6 +337,20 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+#ifdef FFVD_DF_TRACE
+__device__ long long df_trace_buf[64 * 64];
+#define DF_STAMP0(slot) do { if (blockIdx.x == 0 && threadIdx.x == 0) df_trace_buf[63 * 64 + (slot)] = wall_clock64(); } while (0)
+#else
+#define DF_STAMP0(slot) do { } while (0)
+#endif
+
+// The same between LDS accesses of ONE wavefront that has global stores in flight: LDS serves a wavefront's accesses in order,
+// so only the compiler needs telling (the fences above also wait for vmcnt(0), i.e. for the stores).
+__device__ __forceinline__ void wave_lds_order() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // sqrt(x) and 1/sqrt(x) of tf.linalg.cholesky's pivot (conditionals_multi_output.py:28,162) from the hardware
 // reciprocal square root (2^-24 accurate) and ONE cubic (Halley-type) step: with e = 1 - x y^2,
 // y <- y (1 + e/2 + 3 e^2/8) is accurate to 1.4e-16 (tools/rsq_probe.hip; two Newton steps give 2.4e-16) in five
@@ -362,6 +376,7 @@ __device__ __forceinline__ void pivot_sqrt(const double ajj, double &piv, double
 // PIPE = false drops the software pipeline (plain left-looking sums, the newest term by v_readlane): about 100
 // VGPRs fewer, for launches whose many workgroups care about occupancy more than about one tile's latency.
 constexpr int LR_LD = NB + 2;
+constexpr int DV_LD = 17;       // row stride of the 16 x 16 inverse / scratch tiles (doubles)
 template <bool PIPE>
 __device__ __forceinline__ int chol64_1w(double (&a)[NB], double (*Lr)[LR_LD], double *invd, const int lane) {
     int bad = 0;
@@ -418,15 +433,118 @@ __device__ __forceinline__ int chol64_1w(double (&a)[NB], double (*Lr)[LR_LD], d
     return bad;
 }
 
+// 64x64 Cholesky by ONE wavefront, blocked 4 x 4 in 16 x 16 tiles, left-looking at tile level: everything but the
+// pivots runs on the matrix cores.  For tile column s:
+//   S_s = T_ss - sum_{k<s} L_sk L_sk^T                        (s tile products, accumulator layout -> LDS -> lane = row)
+//   16-pivot chain on S_s in registers (right-looking, the multipliers by v_readlane); lanes 16..31 carry the rows of the
+//     identity through the same updates and come out as L_ss^-T, which is at once the operand of the tile solves below and the
+//     inverted diagonal sub-block the panel kernels multiply by (dinv_b, no separate substitution pass)
+//   L_is^T = L_ss^-1 (T_is - sum_{k<s} L_ik L_sk^T)^T  for i > s, kept TRANSPOSED in the accumulator layout (= the B-operand
+//     layout of the next product, as in potrf_panel_kernel), one residual refinement against L_ss.
+// The single-wavefront chain above (chol64_1w) issues 2016 dependent-free but in-order FMA + LDS-broadcast pairs for its
+// left-looking sums and is bound by that issue stream (13 us); here those sums are 64 + 48 MFMAs and the four chains have at
+// most 15 terms per pivot.  No workgroup barrier inside: LDS hand-offs are within the wavefront.
+// In: Ts (lower triangle valid).  Out: Lr = L (lower triangle of every tile row, exact zeros above the diagonal inside the
+// diagonal tiles), dinv_b[(16 s + r) * 16 + c] = (L_ss^-1)[r][c] in global memory.  Sc: two 16 x DV_LD scratch tiles.
+// Returns 0 or 1 + first bad pivot.
+__device__ __forceinline__ int chol64_mfma_1w(double (*Ts)[NB + 1], double (*Lr)[LR_LD], double (*Sc)[16][DV_LD],
+                                              double *dinv_b, const int lane) {
+    const int lr = lane & 15, lk = lane >> 4;
+    int bad = 0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int s0 = 16 * s;
+        DF_STAMP0(4 * s + 0);
+        d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < s; ++k)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const double v = Lr[s0 + lr][16 * k + 4 * t + lk];      // A[m][kk] = B[kk][n]^T: the same tile
+                acc = mfma_f64(v, v, acc);
+            }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Sc[0][lk + 4 * r][lr] = Ts[s0 + lk + 4 * r][s0 + lr] - acc[r];
+        wave_lds_order();
+        DF_STAMP0(4 * s + 1);
+        double a[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) a[c] = (lane < 16) ? Sc[0][lr][c] : ((lane < 32 && lr == c) ? 1.0 : 0.0);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const double ajj = readlane_f64(a[j], j);
+            if (!(ajj > 0.0) && bad == 0) bad = s0 + j + 1;
+            double piv, y;
+            pivot_sqrt(ajj, piv, y);
+            a[j] *= y;
+#pragma unroll
+            for (int c = j + 1; c < 16; ++c) a[c] = fma(-a[j], readlane_f64(a[j], c), a[c]);
+        }
+        DF_STAMP0(4 * s + 2);
+        if (lane < 16) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) Lr[s0 + lr][s0 + c] = (c <= lr) ? a[c] : 0.0;
+        } else if (lane < 32) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                Sc[1][lr][c] = a[c];                                    // X = L_ss^-T
+                dinv_b[(s0 + c) * 16 + lr] = a[c];                      // (L_ss^-1)[c][lr] = X[lr][c]
+            }
+        }
+        wave_lds_order();
+        DF_STAMP0(4 * s + 3);
+#pragma unroll
+        for (int i = s + 1; i < 4; ++i) {
+            const int i0 = 16 * i;
+            d4 ac2 = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int k = 0; k < s; ++k)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    ac2 = mfma_f64(Lr[s0 + lr][16 * k + 4 * t + lk], Lr[i0 + lr][16 * k + 4 * t + lk], ac2);
+            d4 Rt;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Rt[r] = Ts[i0 + lr][s0 + lk + 4 * r] - ac2[r];      // (T')^T[m][n] = T'[n][m]
+            d4 x = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) x = mfma_f64(Sc[1][lk + 4 * t][lr], Rt[t], x);       // A = L_ss^-1[m][kk] = X[kk][m]
+            d4 res = Rt;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) res = mfma_f64(-Lr[s0 + lr][s0 + 4 * t + lk], x[t], res);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) x = mfma_f64(Sc[1][lk + 4 * t][lr], res[t], x);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Lr[i0 + lr][s0 + lk + 4 * r] = x[r];                // L_is[n][m]
+        }
+        wave_lds_order();
+    }
+    DF_STAMP0(16);
+    return bad;
+}
+
 // Factorise the diagonal block held in LDS tile `Ts` (row-major, stride NB+1): wavefront 0 runs chol64_1w, which
 // leaves L in the LDS tile `Lr`; then all 256 threads publish L in place (lower triangle of the global block) and
 // the four wavefronts invert the four 16x16 diagonal sub-blocks of L (lane = column, 16-step forward substitution)
 // into dinv_b[4][16][16] -- what the panel kernel's blocked substitution multiplies by.
+// (Sc != nullptr: the blocked matrix-core factor chol64_mfma_1w, which needs Lr and Ts in DIFFERENT memory and two scratch
+// tiles, and leaves the inverted sub-blocks behind itself.)
 template <bool PIPE>
 __device__ __forceinline__ void diag_block_finish(double (*Ts)[NB + 1], double (*Lr)[LR_LD], double *invd, double *S, int n,
-                                                   int k0, int32_t *info_b, double *dinv_b) {
+                                                   int k0, int32_t *info_b, double *dinv_b, double (*Sc)[16][DV_LD] = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (Sc) {
+        if (w == 0) {
+            __builtin_amdgcn_s_setprio(3);
+            const int bad = chol64_mfma_1w(Ts, Lr, Sc, dinv_b, lane);
+            __builtin_amdgcn_s_setprio(0);
+            if (bad && lane == 0 && *info_b == 0) *info_b = k0 + bad;
+        }
+        __syncthreads();
+        for (int r = tid >> 6; r < NB; r += 4)
+            if (lane <= r) S[(size_t)(k0 + r) * n + k0 + lane] = Lr[r][lane];         // coalesced rows of L
+        return;
+    }
     if (w == 0) {
         double a[NB];
 #pragma unroll
@@ -486,7 +604,6 @@ constexpr int TR_LD = NB + 2;      // LDS row stride of the staged panel blocks 
 // (4 multiplications by the inverted diagonal blocks from diag_block_finish + 6 block updates) runs register to
 // register with the A operands (-L_ts, L_ss^{-1}) read from LDS: 40 MFMAs per wavefront instead of a 64-step scalar
 // forward substitution.
-constexpr int DV_LD = 17;
 __global__ __launch_bounds__(256) void potrf_panel_kernel(double *A, int n, int k, int nmain, size_t slab_stride,
                                                           int nlive, int nid, const double *dinv) {
     __shared__ double Ls[NB][TR_LD];       // -L_kk (only blocks below the block diagonal are read)
@@ -920,6 +1037,9 @@ void launch_trsm_ext(hipStream_t stream, double *A, int n, int extra_rows, int b
 // waiting workgroup leaves, info[b] = -1 says so).
 // Block order (group, row, matrix-in-group): G a multiple of 8, so all rows of a matrix share blockIdx % 8 = one XCD's L2.
 // ---------------------------------------------------------------------------------------------
+#ifndef DF_MFMA_FACTOR
+#define DF_MFMA_FACTOR 1
+#endif
 constexpr int DF_PS = 64;                         // progress words per matrix (main block rows: n <= 4096)
 constexpr int DF_DINV = 4 * 16 * 16;              // doubles of inverted diagonal sub-blocks per (matrix, block column)
 constexpr long long DF_SPIN_TICKS = 100000000LL;  // bound of one wait: 1 s of the 100 MHz wall clock
@@ -938,7 +1058,6 @@ struct DfArgs {
 
 // Debug build only (-DFFVD_DF_TRACE, tools/df_trace.py): wall-clock stamps of matrix 0's block rows, in a buffer of their own.
 #ifdef FFVD_DF_TRACE
-__device__ long long df_trace_buf[64 * 64];
 #define DF_STAMP(row, slot) do { if ((row) >= 0 && threadIdx.x == 0) df_trace_buf[(row) * 64 + (slot)] = wall_clock64(); } while (0)
 extern "C" int ffvd_debug_df_trace(long long *out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(df_trace_buf), sizeof(long long) * 64 * 64);
@@ -1130,9 +1249,10 @@ __device__ __forceinline__ bool df_column(const DfArgs &a, double *S, int *pg, c
         for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
             for (int r = 0; r < 4; ++r) Xs[16 * wave + lr][16 * s4 + 4 * r + lk] = Rt[s4][r];
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's panel stores have left it (published below)
-    }
-    __syncthreads();                                       // sm0 / sm1 are free for the next column (LAST: X(r,j) is in sm0)
+        // X(r,j) is in sm0 for everyone; the global stores stay in flight (the caller waits for them in front of the barrier
+        // that publishes them): a barrier that orders the LDS traffic only
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    } else __syncthreads();                                // sm0 / sm1 are free for the next column
     DF_STAMP(trow, 5 * (j & 7) + 4);
     return true;
 }
@@ -1216,7 +1336,6 @@ __global__ __launch_bounds__(256, 2) void potrf_df_kernel(DfArgs a) {
                     cold_d[x][y][q] = S[(size_t)(row0 + qr * 32 + 16 * x + lk + 4 * q) * n + row0 + qc * 32 + 16 * y + lr];
     }
     double (*Ts)[NB + 1] = reinterpret_cast<double(*)[NB + 1]>(sm1);     // -L_jj is no longer needed (all past the solve)
-    double (*Lr)[LR_LD] = reinterpret_cast<double(*)[LR_LD]>(sm1);
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -1224,11 +1343,13 @@ __global__ __launch_bounds__(256, 2) void potrf_df_kernel(DfArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 Ts[qr * 32 + 16 * x + lk + 4 * q][qc * 32 + 16 * y + lr] = cold_d[x][y][q] - acc_d[x][y][q];
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wavefront's panel stores have left it (published below)
+    __syncthreads();                                      // ... and everyone is done with X(r,j) in sm0: the factor goes there
+    double (*Lr)[LR_LD] = reinterpret_cast<double(*)[LR_LD]>(sm0);
     DF_STAMP(trow, 48);
     // the panels of this row are published by wavefront 1 while wavefront 0 runs the pivot chain
     if (ncols > 0 && tid == 64) df_publish(pg + ri, ri);
-    diag_block_finish<PIPE>(Ts, Lr, invd, S, n, row0, a.info + b, dvb + (size_t)ri * DF_DINV);
+    diag_block_finish<PIPE>(Ts, Lr, invd, S, n, row0, a.info + b, dvb + (size_t)ri * DF_DINV, DF_MFMA_FACTOR ? Dv : nullptr);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     DF_STAMP(trow, 49);
@@ -1269,7 +1390,11 @@ static void launch_potrf_flow(hipStream_t stream, double *A, int n, int extra_ro
     a.G = ((size_t)bp * R <= 2048) ? bp : ((1024 / R + 7) / 8 * 8 < 8 ? 8 : (1024 / R + 7) / 8 * 8);
     if (a.G > bp) a.G = bp;
     const int groups = (batch + a.G - 1) / a.G;
-    hipLaunchKernelGGL(potrf_df_kernel<true>, dim3((unsigned)((size_t)groups * R * a.G)), dim3(256), 0, stream, a);
+    // Few matrices (every block row finds a CU of its own): 16 KB of unused dynamic LDS keep a second workgroup off the CU --
+    // a pivot chain that shares its SIMD with another row's MFMA loop takes up to twice as long (tools/df_trace.py)
+    static const int pad_mode = [] { const char *e = getenv("FFVD_DF_PAD"); return e ? atoi(e) : -1; }();
+    const bool alone = (pad_mode >= 0) ? (pad_mode != 0) : ((size_t)batch * R <= 256);
+    hipLaunchKernelGGL(potrf_df_kernel<true>, dim3((unsigned)((size_t)groups * R * a.G)), dim3(256), alone ? 16384 : 0, stream, a);
 }
 
 // Which blocked variant factorises a batch: the dataflow kernel (one launch, rows handing blocks to each other) wherever the

@@ -29,3 +29,10 @@ for r in range(nb + 1):
     if r < nb:
         line += " | %6.1f %6.1f %6.1f" % (t[r, 48] - t0, t[r, 49] - t0, t[r, 50] - t0)
     print(line)
+
+f = t[63, :17]
+if f[16] > 0:
+    print("blocked 64x64 factor of row 0 (us since its start): per 16-column step  [sums done, chain start, chain done, tiles start]")
+    for s4 in range(4):
+        print("   s=%d  " % s4 + "  ".join("%6.2f" % (f[4 * s4 + i] - f[0]) for i in range(4)))
+    print("   end   %6.2f" % (f[16] - f[0]))
