@@ -553,6 +553,18 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
         if (h->gpart) { ga.ksplit = h->gsplit; ga.part = h->gpart; }     // same row ranges in every pass of this handle
         return ga;
     };
+    auto reduce_args = [&]() {
+        ReduceArgs ra{};
+        ra.kind = c.kernel_kind; ra.branch = c.branch; ra.X = p.X; ra.ctrl = h->ctrl; ra.Y = h->Y;
+        ra.log_Q = p.log_Q; ra.CC = p.CC; ra.DD = p.DD; ra.log_Rchols = p.log_Rchols; ra.variance = h->variance;
+        ra.T = c.T; ra.Tp = Tp; ra.D = c.D; ra.C = c.C; ra.Ydim = c.Ydim; ra.Dl = Dl; ra.d_begin = c.d_begin;
+        ra.S = c.S_local; ra.ng = h->ng; ra.shared_terms = c.shared_terms;
+        ra.xk = p.X; ra.xk_chain_stride = (size_t)(c.T + 1) * c.D; ra.xk_ld = c.D; ra.xk_cols = c.D;
+        ra.rowsq = (gram_route || c.dtype == FFVD_F32C) ? nullptr : h->rowsq; ra.fmean = h->fmean; ra.chain_terms = h->chain_terms;
+        if (h->ngr) ra.ng = h->ngr;
+        return ra;
+    };
+    bool reduce_done = false;
     // One split-K pass, K_uu chain beside it: at few chains that chain is the critical path (0.54 ms against 0.47 ms of
     // K_fu build + tile pass at 4 chains), and the only thing the main stream needs from its tail is K^-1 for the trace
     // partials.  So the combine pass waits for the K_uu copy alone, Cholesky(A) starts at once, and the trace partials
@@ -585,6 +597,8 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
             }
             launch_potrf_ext(sk, h->Kuu, Mp, Mp, Mp, Dl, kstride, h->info, h->dinvK, CHOL_FLOW, h->Linv, msq, linv_done);
             if (linv_done) {
+                launch_chain_reduce(s, reduce_args(), h->chain_partial);      // inputs only; fills the wait below
+                reduce_done = true;
                 HIP_TRY(hipStreamWaitEvent(s, h->ev_go, 0));
                 if (c.S_local <= h->cpp) {          // single pass: the words of Cholesky(A) are cleared here, off the main stream
                     potrf_flow_clear(sk, h->dinvH, h->nbatch);
@@ -636,18 +650,12 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
         launch_h_finish(sk, h->Kuu, Mp, kstride, Dl, h->kterms);
         if (sk != s) HIP_TRY(hipEventRecord(h->ev_join, sk));
     }
-    ReduceArgs ra{};
-    ra.kind = c.kernel_kind; ra.branch = c.branch; ra.X = p.X; ra.ctrl = h->ctrl; ra.Y = h->Y;
-    ra.log_Q = p.log_Q; ra.CC = p.CC; ra.DD = p.DD; ra.log_Rchols = p.log_Rchols; ra.variance = h->variance;
-    ra.T = c.T; ra.Tp = Tp; ra.D = c.D; ra.C = c.C; ra.Ydim = c.Ydim; ra.Dl = Dl; ra.d_begin = c.d_begin;
-    ra.S = c.S_local; ra.ng = h->ng; ra.shared_terms = c.shared_terms;
-    ra.xk = p.X; ra.xk_chain_stride = (size_t)(c.T + 1) * c.D; ra.xk_ld = c.D; ra.xk_cols = c.D;
-    ra.rowsq = (gram_route || c.dtype == FFVD_F32C) ? nullptr : h->rowsq; ra.fmean = h->fmean; ra.chain_terms = h->chain_terms;
-    if (h->ngr) ra.ng = h->ngr;
+    const ReduceArgs ra = reduce_args();
     // the per-chain likelihood / transition reductions depend on the inputs only (Gram route: no row sums of F), so
-    // they ride on the side stream behind the K_uu chain and are back long before finalize needs them
+    // they ride on the side stream behind the K_uu chain and are back long before finalize needs them (kuu_on_main: they
+    // already ran on the main stream while it waited for the chain's kernel to be dispatched)
     const bool reduce_early = gram_route && sk != s;
-    if (reduce_early) {
+    if (reduce_early && !reduce_done) {
         launch_chain_reduce(sk, ra, h->chain_partial);
         HIP_TRY(hipEventRecord(h->ev_join2, sk));
     }
@@ -771,7 +779,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
         }
     }
     if (!reduce_early) launch_chain_reduce(s, ra, h->chain_partial);
-    else HIP_TRY(hipStreamWaitEvent(s, h->ev_join2, 0));
+    else if (!reduce_done) HIP_TRY(hipStreamWaitEvent(s, h->ev_join2, 0));
     FinalizeArgs fa{};
     fa.kind = c.kernel_kind; fa.branch = c.branch; fa.prior_type = c.prior_type; fa.shared_terms = c.shared_terms;
     fa.T = c.T; fa.D = c.D; fa.P = P; fa.M = c.M; fa.Ydim = c.Ydim; fa.Dl = Dl; fa.d_begin = c.d_begin;
