@@ -1368,7 +1368,10 @@ size_t potrf_scratch_doubles(int n, int batch) {
 // bytes).  launch_potrf_ext does this itself unless told that the caller already has (words_zeroed).
 void potrf_flow_clear(hipStream_t stream, double *scratch, int batch) {
     const size_t words = ((size_t)batch * DF_PS + 4 + 3) / 4 * 4;
-    (void)hipMemsetAsync(scratch, 0, words * sizeof(int), stream);
+    // our own fill kernel, not hipMemsetAsync: in front of a 16-matrix factorisation the runtime's memset started 40 us after
+    // the kernel before it had finished (tools/prof_timeline.sh, SYNC_S=4)
+    const size_t n = words / 2;
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, scratch, n, 0.0);
 }
 
 static void launch_potrf_flow(hipStream_t stream, double *A, int n, int extra_rows, int identity_rows, int batch,

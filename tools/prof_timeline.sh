@@ -1,11 +1,17 @@
 #!/bin/bash
-# kernel timeline of the last benchmark iteration (start offset, duration, name), config 2 (run on the GPU box)
+# kernel timeline of the last iteration (start offset, duration, name) (run on the GPU box):
+#   tools/prof_timeline.sh <tag> [bench.py args]          config 2 through bench.py
+#   SYNC_S=4 tools/prof_timeline.sh <tag>                 one rank's share (S chains) through tools/sync_step.py
 set -e
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$1
 shift
 mkdir -p $OUT
+if [ -n "$SYNC_S" ]; then
+rocprofv3 --kernel-trace --output-format csv -d $OUT/tl -- python3 $GRAFT_REPO_ROOT/tools/sync_step.py S=$SYNC_S > $OUT/tl.json 2> $OUT/tl.err
+else
 rocprofv3 --kernel-trace --output-format csv -d $OUT/tl -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $OUT/tl.json 2> $OUT/tl.err
+fi
 python3 - <<PY
 import csv, glob
 f = glob.glob("$OUT/tl/**/*kernel_trace.csv", recursive=True)[0]
