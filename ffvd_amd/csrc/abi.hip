@@ -44,7 +44,7 @@ struct ffvd_handle {
     // diagnostic switches, read from the environment ONCE when the handle is created
     struct Switches {
         bool fused_project = false, grad_explicit = false, no_defer_trace = false, no_late_join = false;
-        bool no_main_first = false, no_kfu_first = false, atb128 = false, grad_serial = false, kuu_flow = true, kinv_gram = false;
+        bool no_main_first = false, no_kfu_first = false, atb128 = false, grad_serial = false, kuu_flow = true, kinv_gram = false, chain_rl = false;
     } sw;
     // resident parameters / data (handle-owned copies)
     double *X = nullptr, *Z = nullptr, *U = nullptr, *logvar = nullptr, *loglen = nullptr, *logQ = nullptr;
@@ -169,7 +169,7 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
         w.fused_project = on("FFVD_FUSED_PROJECT");   w.grad_explicit = on("FFVD_GRAD_EXPLICIT");
         w.no_defer_trace = on("FFVD_NO_DEFER_TRACE"); w.no_late_join = on("FFVD_NO_LATE_JOIN");
         w.no_main_first = on("FFVD_NO_MAIN_FIRST");   w.no_kfu_first = on("FFVD_NO_KFU_FIRST");
-        w.kuu_flow = !on("FFVD_NO_KUU_FLOW");   w.kinv_gram = on("FFVD_KINV_GRAM");
+        w.kuu_flow = !on("FFVD_NO_KUU_FLOW");   w.kinv_gram = on("FFVD_KINV_GRAM");   w.chain_rl = on("FFVD_CHAIN_RL");
         w.atb128 = on("FFVD_ATB128");                 w.grad_serial = on("FFVD_GRAD_SERIAL");
     }
     h->P = c.D + c.C;
@@ -628,7 +628,12 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
     if (!kuu_on_main) {
         launch_kuu_build(sk, c.kernel_kind, hv, c.M, Mp, P, Dl, c.jitter, h->Kuu, (gram_route || grad_a) ? h->Kcopy : nullptr);
         if (defer_trace || (defer_full && sk != s)) HIP_TRY(hipEventRecord(h->ev_kuu, sk));
-        launch_potrf_ext(sk, h->Kuu, Mp, Mp, Mp, Dl, kstride, h->info, h->dinvK);
+        // chain on the main stream = on the critical path with nothing beside it: the dataflow launch; on the side stream
+        // (beside the K_fu build / tile pass of a small batch) the right-looking launches, whose workgroups come and go
+        const bool chain_flow = (sk == s) && potrf_flow_selected((int)Mp, (int)Dl, CHOL_FLOW) && !h->sw.chain_rl;
+        if (chain_flow && (gram_route || grad_a)) linv_done = true;
+        launch_potrf_ext(sk, h->Kuu, Mp, Mp, Mp, Dl, kstride, h->info, h->dinvK, chain_flow ? CHOL_FLOW : CHOL_AUTO,
+                         linv_done ? h->Linv : nullptr, msq);
     }
     if (gram_route || grad_a) {
         // K^-1 = L^-T L^-1 (shared by all chains) and log|K|
