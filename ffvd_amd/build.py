@@ -120,7 +120,50 @@ def build_asan(verbose=False):
     return ASAN_LIB
 
 
+def variant_path(name):
+    return os.path.join(HERE, f"libffvd_hip_{name}.so")
+
+
+VARIANTS = {
+    # the dataflow Cholesky with matrix 0 never announcing its first diagonal block: every other block row of that matrix
+    # must give up after the bounded wait instead of hanging (tests/test_gpu_ops.py)
+    "dfstall": ["-DFFVD_DF_TEST_STALL"],
+    # wall-clock stamps inside the dataflow Cholesky (tools/df_trace.py)
+    "dftrace": ["-DFFVD_DF_TRACE"],
+}
+
+
+def build_variant(name, verbose=False):
+    """Test / diagnostic build: kernels.hip recompiled with the variant's defines, every other object shared with the
+    product library (which is built first).  Load it with FFVD_LIB=<path>."""
+    build(force=False, verbose=verbose)
+    out = variant_path(name)
+    stamp = out + ".hash"
+    want = source_hash() + " " + " ".join(VARIANTS[name])
+    if os.path.exists(out) and os.path.exists(stamp) and open(stamp).read().strip() == want:
+        return out
+    cc = hipcc_path()
+    obj = os.path.join(OBJDIR, f"kernels.hip.{name}.o")
+    cmd = [cc] + FLAGS + VARIANTS[name] + ["-c", os.path.join(CSRC, "kernels.hip"), "-o", obj]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError(f"hipcc failed on kernels.hip ({name}):\n" + proc.stdout + proc.stderr)
+    objs = [obj] + [os.path.join(OBJDIR, src + ".o") for src in SOURCES if src != "kernels.hip"]
+    proc = subprocess.run([cc] + objs + LINK + ["-o", out], capture_output=True, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError(f"hipcc link failed ({name}):\n" + proc.stdout + proc.stderr)
+    with open(stamp, "w") as f:
+        f.write(want + "\n")
+    return out
+
+
 if __name__ == "__main__":
+    for v in VARIANTS:
+        if "--" + v in sys.argv:
+            print(build_variant(v, verbose=True))
+            sys.exit(0)
     if "--asan" in sys.argv:
         print(build_asan(verbose=True))
         sys.exit(0)

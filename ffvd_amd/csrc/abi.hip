@@ -813,6 +813,8 @@ static int ready(ffvd_handle *h, const char *who) {
 static int check_info(ffvd_handle *h) {
     const int Dl = h->Dl;
     for (int i = 0; i < Dl + h->nbatch; ++i) {
+        if (h->h_info[i] < 0)          // the dataflow Cholesky bounds every wait (kernels.hip, potrf_df_kernel)
+            return set_error(h, FFVD_EDEVICE, "blocked Cholesky abandoned: a block row waited more than 1 s for the row above it");
         if (h->h_info[i] != 0) {
             char msg[256];
             if (i < Dl)
@@ -1490,6 +1492,8 @@ extern "C" int ffvd_op_cholesky(const double *A, int n, int batch, double *L, in
         for (int i = 0; i < n; ++i)
             for (int j = 0; j < n; ++j) L[((size_t)b * n + i) * n + j] = (j <= i) ? S[(size_t)i * np + j] : 0.0;
         if (info) info[b] = hinfo[b];
+        if (hinfo[b] < 0)
+            return set_error(nullptr, FFVD_EDEVICE, "ffvd_op_cholesky: abandoned, a block row waited more than 1 s for the row above it");
         if (hinfo[b] != 0 && bad < 0) bad = b;
     }
     if (bad >= 0) {

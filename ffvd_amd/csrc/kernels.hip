@@ -1381,6 +1381,9 @@ __global__ __launch_bounds__(256, 2) void potrf_df_kernel(DfArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     DF_STAMP(trow, 49);
+#ifdef FFVD_DF_TEST_STALL
+    if (b == 0 && ri == 0) return;      // test build (tests/test_gpu_ops.py): matrix 0 never announces its first diagonal block
+#endif
     if (tid == 0) df_publish(pg + ri, ri + 1);
     DF_STAMP(trow, 50);
 }

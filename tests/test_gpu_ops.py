@@ -79,6 +79,60 @@ def test_cholesky_more_workgroups_than_the_chip_holds():
     np.testing.assert_allclose(L, np.linalg.cholesky(A), rtol=1e-9, atol=1e-10)
 
 
+_STALL_SCRIPT = r"""
+import sys, time
+import numpy as np
+from ffvd_amd import _lib
+lib = _lib.load()
+n, batch = 200, 40                       # >= 32 matrices: the dataflow launch
+rng = np.random.default_rng(5)
+B = rng.standard_normal((batch, n, n + 2))
+A = B @ np.swapaxes(B, 1, 2) + 0.5 * np.eye(n)
+L = np.empty_like(A)
+info = np.zeros(batch, dtype=np.int32)
+t0 = time.perf_counter()
+rc = lib.ffvd_op_cholesky(_lib.dptr(A), n, batch, _lib.dptr(L), info.ctypes.data_as(_lib.C.POINTER(_lib.C.c_int32)))
+el = time.perf_counter() - t0
+msg = lib.ffvd_last_error(None).decode()
+print("RC", rc, "ELAPSED", round(el, 2), "INFO0", int(info[0]), "MSG", msg)
+"""
+
+
+def test_dataflow_cholesky_gives_up_instead_of_hanging():
+    """Every wait of the one-launch Cholesky is bounded: in the test build `libffvd_hip_dfstall.so` (ffvd_amd/build.py) the first
+    block row of matrix 0 never announces its diagonal block, so the rows below it can never proceed.  They must leave after
+    the 1 s bound, the launch must end, the call must report a device error (not a pivot), and the GPU must stay usable."""
+    import subprocess
+    import sys
+    import time
+    from ffvd_amd import build as fb
+    lib_path = fb.variant_path("dfstall")
+    if not os.path.exists(lib_path):
+        pytest.skip("libffvd_hip_dfstall.so not built (python -m ffvd_amd.build --dfstall)")
+    env = dict(os.environ, FFVD_LIB=lib_path, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env.pop("FFVD_CHOL", None)
+    t0 = time.perf_counter()
+    out = subprocess.run([sys.executable, "-c", _STALL_SCRIPT], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("RC")][0]
+    rc = int(line.split()[1])
+    elapsed = float(line.split()[3])
+    assert rc == -3, line                                  # FFVD_EDEVICE
+    assert "waited more than 1 s" in line
+    assert 0.5 < elapsed < 20.0, line                      # the bound is 1 s per wait; rows give up together via the abort word
+    assert time.perf_counter() - t0 < 100.0
+    # the product library still works on the same GPU afterwards
+    lib = _lib.load()
+    rng = np.random.default_rng(6)
+    B = rng.standard_normal((40, 100, 102))
+    A = B @ np.swapaxes(B, 1, 2) + 0.5 * np.eye(100)
+    L = np.empty_like(A)
+    info = np.zeros(40, dtype=np.int32)
+    rc = lib.ffvd_op_cholesky(_lib.dptr(A), 100, 40, _lib.dptr(L), info.ctypes.data_as(_lib.C.POINTER(_lib.C.c_int32)))
+    assert rc == 0 and not info.any()
+    np.testing.assert_allclose(L, np.linalg.cholesky(A), rtol=1e-9, atol=1e-10)
+
+
 @pytest.mark.parametrize("n,m", [(1, 1), (7, 3), (64, 64), (100, 512), (200, 1), (513, 130)])
 def test_trsm_matches_scipy(n, m):
     """ffvd_op_trsm = tf.linalg.triangular_solve(Lm, Kmn, lower=True) (conditionals_multi_output.py:34): the blocked
