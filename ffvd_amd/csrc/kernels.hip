@@ -1322,7 +1322,7 @@ __global__ __launch_bounds__(256, 2) void potrf_df_kernel(DfArgs a) {
         for (int j = k0; j < nplain; ++j) {
             d4 unused_c[2][2], unused_a[2][2];
             if (!df_column<false>(a, S, pg, dvb, row0, j, k0, Xs, Ls, Dv, wslot, wc, unused_c, unused_a, trow, xt_row)) {
-                if (tid == 0) a.info[b] = -1;
+                if (tid == 0 && a.info) a.info[b] = -1;
                 return;
             }
         }
@@ -1336,7 +1336,7 @@ __global__ __launch_bounds__(256, 2) void potrf_df_kernel(DfArgs a) {
         for (int y = 0; y < 2; ++y) acc_d[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
     if (ncols > 0) {
         if (!df_column<true>(a, S, pg, dvb, row0, ncols - 1, k0, Xs, Ls, Dv, wslot, wc, cold_d, acc_d, trow)) {
-            if (tid == 0) a.info[b] = -1;
+            if (tid == 0 && a.info) a.info[b] = -1;
             return;
         }
         if (!(qr == 0 && qc == 1)) {
