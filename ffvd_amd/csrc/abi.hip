@@ -773,11 +773,11 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
                                              (size_t)Mp * sizeof(double), (size_t)nbp, hipMemcpyDeviceToDevice, s));
                 }
                 launch_potrf_ext(s, h->H, Mp, Mp + NB, Mp, ns * Dl, ga.h_stride, h->info + Dl + s0 * Dl, h->dinvH, CHOL_FLOW, nullptr, 0,
-                                 hwords_zeroed && s0 == 0);
+                                 hwords_zeroed && s0 == 0, true);
                 launch_h_finish(s, h->H, Mp, ga.h_stride, ns * Dl, h->hterms + (size_t)2 * s0 * Dl, 2 * Mp);
             } else {
                 launch_potrf_ext(s, h->H, Mp, NB, 0, ns * Dl, ga.h_stride, h->info + Dl + s0 * Dl, h->dinvH, CHOL_FLOW, nullptr, 0,
-                                 hwords_zeroed && s0 == 0);
+                                 hwords_zeroed && s0 == 0, true);
                 launch_h_finish(s, h->H, Mp, ga.h_stride, ns * Dl, h->hterms + (size_t)2 * s0 * Dl);
             }
             if (st) st->mark(3);
@@ -2131,7 +2131,7 @@ static int enqueue_tshard_finish(ffvd_handle *h) {
     ga.Kadd = h->Kcopy; ga.kadd_stride = msq; ga.Kinv = h->Kinv; ga.kinv_stride = msq; ga.trpart = h->trpart;
     ga.part = h->tsbuf; ga.ksplit = 1;
     launch_gram(s, ga, 4);
-    launch_potrf_ext(s, h->H, Mp, NB, 0, h->nbatch, ga.h_stride, h->info + Dl, h->dinvH, CHOL_FLOW);
+    launch_potrf_ext(s, h->H, Mp, NB, 0, h->nbatch, ga.h_stride, h->info + Dl, h->dinvH, CHOL_FLOW, nullptr, 0, false, true);
     launch_h_finish(s, h->H, Mp, ga.h_stride, h->nbatch, h->hterms);
     FinalizeArgs fa{};
     fa.kind = c.kernel_kind; fa.branch = c.branch; fa.prior_type = c.prior_type; fa.shared_terms = c.shared_terms;

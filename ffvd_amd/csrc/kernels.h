@@ -56,7 +56,9 @@ size_t potrf_scratch_doubles(int n, int batch);
 bool potrf_flow_selected(int n, int batch, int hint);
 void launch_potrf_ext(hipStream_t stream, double *A, int n, int extra_rows, int identity_rows, int batch,
                       size_t slab_stride, int32_t *info, double *dinv, int hint = CHOL_AUTO, double *linv_t = nullptr,
-                      size_t linv_t_stride = 0, bool words_zeroed = false);
+                      size_t linv_t_stride = 0, bool words_zeroed = false, bool tail_is_vector = false);
+// tail_is_vector (dataflow variant only; ignored by the others, which treat every extra row alike): of each 64-row block of
+// extra rows BEHIND the identity rows only the first row is live (the ELBO's row b); the other 63 are neither read nor written.
 // The dataflow variant polls progress words at the start of `dinv`; they must be zero when its kernel starts.  The launcher
 // clears them itself (one memset in front of the kernel) unless the caller has done so earlier with potrf_flow_clear on a
 // stream whose order reaches the launch, and says so (words_zeroed).

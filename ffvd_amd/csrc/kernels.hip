@@ -1082,6 +1082,7 @@ struct DfArgs {
     int *abort_w;      // one word, zeroed before the launch
     double *xt;        // optional: the identity-structured extra rows (R L^-T = L^-T) also land TRANSPOSED here, i.e. L^-1 as
     size_t xt_stride;  //   an n x n lower-triangular matrix (ld n) per slab; blocks above its diagonal are not written
+    int vec_tail;      // the extra-row blocks behind the identity rows carry ONE live row each (their first): df_vector_row
 };
 
 // Debug build only (-DFFVD_DF_TRACE, tools/df_trace.py): wall-clock stamps of matrix 0's block rows, in a buffer of their own.
@@ -1285,6 +1286,68 @@ __device__ __forceinline__ bool df_column(const DfArgs &a, double *S, int *pg, c
     return true;
 }
 
+// An extra-row block of which only the FIRST row is live (the row b of the ELBO: b <- b L^-T, of which the caller reads
+// |b L^-T|^2): a vector walks the block columns instead of a 64-row panel -- per column a few 64 x 64 matrix-vector products
+// (each wavefront a quarter of every term's inner range, partial sums through LDS) and a 64-step forward substitution in one
+// wavefront -- 1/64 of the panel's work and operand traffic.  It keeps up with the diagonal blocks however late its workgroup
+// starts (about 5 us per column), so the launch ends a substitution after the last diagonal factor instead of a 7-term panel
+// gather (30 us at 128 matrices).  The other 63 rows of the block are not touched.
+__device__ __forceinline__ void df_vector_row(const DfArgs &a, double *S, int *pg, const double *dvb, const int row0, const int b,
+                                              double *xv /* [n] */, double (*Ls)[LL_LD], double *part /* [4][64] */,
+                                              double *invd /* [64] */, int *wslot) {
+    const int n = a.n, nb = a.nb, tid = threadIdx.x, c = tid & 63;
+    const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sr = tid >> 5, sc = 2 * (tid & 31);
+    double *v = S + (size_t)row0 * n;
+    int wc = 0;
+    for (int j = 0; j < nb; ++j) {
+        const int j0 = j * NB;
+        const double vj = v[j0 + c];                        // this row is nobody else's
+        double acc = 0.0;
+        int seen = -2;
+        if (j > 0) {
+            seen = df_wait(pg + j, j, a.abort_w, &wslot[wc++ & 1]);          // the panels of block row j are in memory
+            if (seen < 0) { if (tid == 0 && a.info) a.info[b] = -1; return; }
+            const double *Lrow = S + (size_t)(j0 + c) * n + 16 * q;           // row c of block row j, this wavefront's quarter
+            for (int k = 0; k < j; ++k) {
+                const double *xp = xv + k * NB + 16 * q;
+#pragma unroll
+                for (int m = 0; m < 16; m += 2) {
+                    const d2 l = *reinterpret_cast<const d2 *>(Lrow + k * NB + m);
+                    acc = fma(xp[m], l.x, acc);
+                    acc = fma(xp[m + 1], l.y, acc);
+                }
+            }
+        }
+        part[q * 64 + c] = acc;
+        if (seen < j + 1) {                                                   // L_jj and its inverted sub-blocks are in memory
+            seen = df_wait(pg + j, j + 1, a.abort_w, &wslot[wc++ & 1]);
+            if (seen < 0) { if (tid == 0 && a.info) a.info[b] = -1; return; }
+        } else __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = sr + 8 * i;
+            const d2 l = *reinterpret_cast<const d2 *>(S + (size_t)(j0 + r) * n + j0 + sc);
+            Ls[r][sc] = l.x; Ls[r][sc + 1] = l.y;
+        }
+        if (tid < 64) invd[tid] = dvb[(size_t)j * DF_DINV + ((tid >> 4) * 16 + (tid & 15)) * 16 + (tid & 15)];   // 1 / L_jj[c][c]
+        __syncthreads();
+        if (q == 0) {
+            double t = vj - ((part[c] + part[64 + c]) + (part[128 + c] + part[192 + c]));
+            double x = 0.0;
+#pragma unroll
+            for (int m = 0; m < NB; ++m) {
+                const double xm = readlane_f64(t, m) * invd[m];               // lane m's t is final at step m
+                if (c == m) x = xm;
+                if (c > m) t = fma(-xm, Ls[c][m], t);
+            }
+            v[j0 + c] = x;
+            xv[j0 + c] = x;
+        }
+        __syncthreads();
+    }
+}
+
 template <bool PIPE>
 __global__ __launch_bounds__(256, 2) void potrf_df_kernel(DfArgs a) {
     __shared__ double sm0[NB * LL_LD];      // X(r,k) tiles; then T = A(r,j) - sum and the solved X(r,j)
@@ -1313,6 +1376,10 @@ __global__ __launch_bounds__(256, 2) void potrf_df_kernel(DfArgs a) {
     }
     double (*Xs)[LL_LD] = reinterpret_cast<double(*)[LL_LD]>(sm0);
     double (*Ls)[LL_LD] = reinterpret_cast<double(*)[LL_LD]>(sm1);
+    if (!main_row && a.vec_tail && ri - nb >= a.nid) {
+        df_vector_row(a, S, pg, dvb, row0, b, sm0, Ls, &Dv[0][0][0], invd, wslot);
+        return;
+    }
     int wc = 0;
     const int trow = (b == 0) ? ri : -1;
     DF_STAMP(trow, 51);
@@ -1407,9 +1474,10 @@ void potrf_flow_clear(hipStream_t stream, double *scratch, int batch) {
 
 static void launch_potrf_flow(hipStream_t stream, double *A, int n, int extra_rows, int identity_rows, int batch,
                               size_t slab_stride, int32_t *info, double *scratch, double *linv_t, size_t linv_t_stride,
-                              bool words_zeroed) {
+                              bool words_zeroed, bool tail_is_vector) {
     DfArgs a{};
     a.xt = linv_t; a.xt_stride = linv_t_stride;
+    a.vec_tail = tail_is_vector ? 1 : 0;
     a.A = A; a.n = n; a.nb = n / NB; a.next = extra_rows / NB; a.nid = identity_rows / NB; a.batch = batch;
     a.slab_stride = slab_stride; a.info = info;
     // the polled words sit at the start of the scratch block, padded to 16 bytes, and are zeroed before every launch
@@ -1455,12 +1523,13 @@ static int chol_variant(int batch, int nb, int hint) {
 
 void launch_potrf_ext(hipStream_t stream, double *A, int n, int extra_rows, int identity_rows, int batch,
                       size_t slab_stride, int32_t *info, double *dinv, int hint, double *linv_t, size_t linv_t_stride,
-                      bool words_zeroed) {
+                      bool words_zeroed, bool tail_is_vector) {
     const int nb = n / NB;
     const int nid = identity_rows / NB, ntail = extra_rows / NB - nid;
     const int variant = chol_variant(batch, nb, hint);
     if (variant == 3) {
-        launch_potrf_flow(stream, A, n, extra_rows, identity_rows, batch, slab_stride, info, dinv, linv_t, linv_t_stride, words_zeroed);
+        launch_potrf_flow(stream, A, n, extra_rows, identity_rows, batch, slab_stride, info, dinv, linv_t, linv_t_stride, words_zeroed,
+                          tail_is_vector);
         return;
     }
     if (variant == 1) {
