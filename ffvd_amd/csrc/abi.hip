@@ -85,6 +85,7 @@ struct ffvd_handle {
         double *Asum = nullptr, *GamSum = nullptr, *Gs = nullptr, *gsum = nullptr, *P1 = nullptr, *KGK = nullptr, *Epsi = nullptr;
         double *rsum2 = nullptr, *ez2 = nullptr, *cs2 = nullptr, *etx2 = nullptr, *rx22 = nullptr, *dz_kuu = nullptr, *dll_kuu = nullptr, *dls_kuu = nullptr;
         double *shared_part = nullptr, *dX = nullptr, *dZ = nullptr, *dlogvar = nullptr, *dloglen = nullptr, *dlogQ = nullptr;
+        size_t small_count = 0;         // doubles in the block dlogvar | dloglen | dlogQ | dCC | dDD | dlogR (one allocation)
         double *dCC = nullptr, *dDD = nullptr, *dlogR = nullptr;
         // explicit-U branch
         double *Gu = nullptr, *Gsum = nullptr, *r = nullptr, *dalpha = nullptr, *ucol = nullptr, *beta = nullptr, *du = nullptr;
@@ -296,9 +297,13 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
         HIP_TRY(dev_alloc(h, &g.dz_kuu, Dl * c.M * P)); HIP_TRY(dev_alloc(h, &g.dll_kuu, Dl * P)); HIP_TRY(dev_alloc(h, &g.dls_kuu, Dl));
         HIP_TRY(dev_alloc(h, &g.shared_part, S * g.sp_stride));
         HIP_TRY(dev_alloc(h, &g.dX, S * (c.T + 1) * c.D));
-        HIP_TRY(dev_alloc(h, &g.dZ, (size_t)c.M * P)); HIP_TRY(dev_alloc(h, &g.dlogvar, (size_t)c.D));
-        HIP_TRY(dev_alloc(h, &g.dloglen, (size_t)c.D * P)); HIP_TRY(dev_alloc(h, &g.dlogQ, (size_t)c.D));
-        HIP_TRY(dev_alloc(h, &g.dCC, (size_t)c.D * J)); HIP_TRY(dev_alloc(h, &g.dDD, J)); HIP_TRY(dev_alloc(h, &g.dlogR, J * J));
+        HIP_TRY(dev_alloc(h, &g.dZ, (size_t)c.M * P));
+        {   // the six small shared-parameter gradients in ONE block: one fill per backward pass instead of six memsets
+            g.small_count = (size_t)c.D + (size_t)c.D * P + (size_t)c.D + (size_t)c.D * J + J + J * J;
+            HIP_TRY(dev_alloc(h, &g.dlogvar, g.small_count));
+            g.dloglen = g.dlogvar + c.D; g.dlogQ = g.dloglen + (size_t)c.D * P; g.dCC = g.dlogQ + c.D;
+            g.dDD = g.dCC + (size_t)c.D * J; g.dlogR = g.dDD + J;
+        }
         if (grad_a) {
             HIP_TRY(dev_alloc(h, &g.Gu, nbt * (Mp + NB) * Mp));   HIP_TRY(dev_alloc(h, &g.Gsum, Dl * (Mp + NB) * Mp));
             HIP_TRY(dev_alloc(h, &g.r, nbt * Tp));                HIP_TRY(dev_alloc(h, &g.dalpha, nbt));
@@ -577,7 +582,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
     const bool defer_full = gram_route && !late_join && h->graw;
     const int ns_first = (h->cpp <= c.S_local) ? h->cpp : c.S_local;
     bool kfu_first = false;     // the first pass's K_fu build goes to the main stream before the chain is enqueued
-    bool ident_on_side = false, kuu_on_main = false, linv_done = false, hwords_zeroed = false;
+    bool ident_on_side = false, kuu_on_main = false, linv_done = false, hwords_zeroed = false, ident_early = false;
     if (gram_route && (late_join || (size_t)first_units * Tp * Mp >= (size_t)64 * 4096 * 512)) {
         sk = h->aux;
         kuu_on_main = h->kuu_flow_sched && !late_join;
@@ -599,6 +604,13 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
             if (linv_done) {
                 launch_chain_reduce(s, reduce_args(), h->chain_partial);      // inputs only; fills the wait below
                 reduce_done = true;
+                if (c.grad && c.branch == FFVD_BRANCH_B) {
+                    // training: the identity rows that become L_A^-T are re-armed here too (rows the K_fu build and the Gram
+                    // kernel do not touch) instead of between the K_fu build and the Gram kernel
+                    const GramArgs gi = gram_args(0, ns_first);
+                    launch_set_identity(s, h->H, gi.h_stride, Mp, Mp, ns_first * Dl);
+                    ident_early = true;
+                }
                 HIP_TRY(hipStreamWaitEvent(s, h->ev_go, 0));
                 if (c.S_local <= h->cpp) {          // single pass: the words of Cholesky(A) are cleared here, off the main stream
                     potrf_flow_clear(sk, h->dinvH, h->nbatch);
@@ -708,7 +720,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
         if (c.branch == FFVD_BRANCH_B) {
             GramArgs ga = gram_args(s0, ns);
             bool trace_pending = false, acopy_done = false;      // acopy_done: the Gram kernel stored the copy of A itself
-            if (c.grad && !(ident_on_side && s0 == 0)) launch_set_identity(s, h->H, ga.h_stride, Mp, Mp, ns * Dl);
+            if (c.grad && !((ident_on_side || ident_early) && s0 == 0)) launch_set_identity(s, h->H, ga.h_stride, Mp, Mp, ns * Dl);
             if (s0 == 0 && late_join) {
                 if (!main_first) launch_gram(s, ga, 1);
                 if (defer_trace) {
@@ -734,7 +746,11 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
                 gf.b0 = s0 * Dl; gf.nb = ns * Dl; gf.yn_over_batch = 1.0; gf.H = h->H; gf.h_stride = ga.h_stride;
                 gf.flush = h->gram_flush;
                 launch_gram_f32(s, gf);                               // H = F^T F / Q + I, b = delta^T F / Q  (:246-248)
-            } else launch_gram(s, ga);
+            } else {
+                // training: the unsplit Gram kernel stores the symmetric copy of A itself (no copy + symmetrize launches: 0.25 ms)
+                if (c.grad && gram_route && !ga.part) { ga.Hcopy = h->gw.Acopy; ga.hcopy_stride = msq; acopy_done = true; }
+                launch_gram(s, ga);
+            }
             if (st) st->mark(2);
             if (trace_pending) {
                 // trace partials from the raw tiles, on the side stream (K^-1 precedes in its order).  Enqueued AHEAD of the
@@ -1041,12 +1057,7 @@ static int enqueue_grad_a(ffvd_handle *h, int S_total) {
     gf.dCC = g.dCC; gf.dDD = g.dDD; gf.dlogR = g.dlogR;
     gf.branch_a = 1; gf.dalpha_unit = g.dalpha; gf.du_dim = g.du; gf.U = p.U; gf.dU = g.dU;
     gf.kind = kind; gf.xsq_unit = g.xsq;
-    HIP_TRY(hipMemsetAsync(g.dlogvar, 0, (size_t)c.D * sizeof(double), s));
-    HIP_TRY(hipMemsetAsync(g.dloglen, 0, (size_t)c.D * P * sizeof(double), s));
-    HIP_TRY(hipMemsetAsync(g.dlogQ, 0, (size_t)c.D * sizeof(double), s));
-    HIP_TRY(hipMemsetAsync(g.dCC, 0, (size_t)c.D * c.Ydim * sizeof(double), s));
-    HIP_TRY(hipMemsetAsync(g.dDD, 0, (size_t)c.Ydim * sizeof(double), s));
-    HIP_TRY(hipMemsetAsync(g.dlogR, 0, (size_t)c.Ydim * c.Ydim * sizeof(double), s));
+    launch_fill(s, g.dlogvar, g.small_count, 0.0);        // dlogvar | dloglen | dlogQ | dCC | dDD | dlogR
     launch_grad_finalize(s, gf);
     HIP_TRY(hipGetLastError());
     return FFVD_OK;
@@ -1173,12 +1184,7 @@ static int enqueue_grad_b(ffvd_handle *h, int S_total) {
     gf.sp_stride = g.sp_stride; gf.dZ = g.dZ; gf.dlogvar = g.dlogvar; gf.dloglen = g.dloglen; gf.dlogQ = g.dlogQ;
     gf.dCC = g.dCC; gf.dDD = g.dDD; gf.dlogR = g.dlogR;
     // entries this handle does not own (other ranks' dims; the shared terms off rank 0) stay zero for the all-reduce
-    HIP_TRY(hipMemsetAsync(g.dlogvar, 0, (size_t)c.D * sizeof(double), s));
-    HIP_TRY(hipMemsetAsync(g.dloglen, 0, (size_t)c.D * P * sizeof(double), s));
-    HIP_TRY(hipMemsetAsync(g.dlogQ, 0, (size_t)c.D * sizeof(double), s));
-    HIP_TRY(hipMemsetAsync(g.dCC, 0, (size_t)c.D * c.Ydim * sizeof(double), s));
-    HIP_TRY(hipMemsetAsync(g.dDD, 0, (size_t)c.Ydim * sizeof(double), s));
-    HIP_TRY(hipMemsetAsync(g.dlogR, 0, (size_t)c.Ydim * c.Ydim * sizeof(double), s));
+    launch_fill(s, g.dlogvar, g.small_count, 0.0);        // dlogvar | dloglen | dlogQ | dCC | dDD | dlogR
     launch_grad_finalize(s, gf);
     HIP_TRY(hipGetLastError());
     return FFVD_OK;

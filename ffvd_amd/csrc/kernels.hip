@@ -1949,7 +1949,7 @@ __device__ __forceinline__ void gram_body(const GramArgs a, const int bz, const 
     const double *Kadd = (MODE == GRAM_KFU || MODE == GRAM_KFU_RAW) ? a.Kadd + (size_t)dl * a.kadd_stride : nullptr;
     const double *Kinv = (MODE == GRAM_KFU) ? a.Kinv + (size_t)dl * a.kinv_stride : nullptr;
     double *Rb = (MODE == GRAM_KFU_RAW) ? a.part + (size_t)bz * ((size_t)(Mp + 1) * Mp) : nullptr;
-    double *Cb2 = (MODE == GRAM_KFU_RAW && a.Hcopy) ? a.Hcopy + (size_t)bz * a.hcopy_stride : nullptr;
+    double *Cb2 = ((MODE == GRAM_KFU_RAW || MODE == GRAM_KFU) && a.Hcopy) ? a.Hcopy + (size_t)bz * a.hcopy_stride : nullptr;
     double trp = 0.0;
     if (active) {
 #pragma unroll
@@ -1971,6 +1971,10 @@ __device__ __forceinline__ void gram_body(const GramArgs a, const int bz, const 
                         }
                     } else if (MODE == GRAM_KFU) {
                         v = g * scale + Kadd[(size_t)i * Mp + j];
+                        if (Cb2 && j <= i) {                    // second, fully symmetric copy (the backward pass keeps A)
+                            Cb2[(size_t)i * Mp + j] = v;
+                            if (j < i) Cb2[(size_t)j * Mp + i] = v;
+                        }
                         const double w = (i > j) ? 2.0 : ((i == j) ? 1.0 : 0.0);
                         trp += w * (Kinv[(size_t)i * Mp + j] * g);
                     } else v = g;
