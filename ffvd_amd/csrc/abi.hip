@@ -1966,11 +1966,17 @@ extern "C" int ffvd_op_rollout(int kind, const double *Lm_inverse_seq, const dou
     double *Zs = sc.alloc<double>((size_t)D * Mp * P), *zz = sc.alloc<double>((size_t)D * Mp);
     double *F = q_sqrt ? sc.alloc<double>((size_t)D * Tp * Mp) : nullptr;
     double *Kf = sc.alloc<double>((size_t)D * Tp * Mp), *ucol = sc.alloc<double>((size_t)D * Mp);
-    double *rowsq = sc.alloc<double>((size_t)D * ng * Tp), *fmean = sc.alloc<double>((size_t)D * ng * Tp);
+    // few rows per step (R rollouts): the skinny product (kernels.hip) with one partial sum per 16-column slab replaces the
+    // 128 x 128-tile projection GEMM (50 -> 7 us per step) and the per-row q_sqrt kernel (37 us)
+    const bool skinny = R <= 512;
+    const int ngs = skinny ? Mp / 16 : ng;
+    double *rowsq = sc.alloc<double>((size_t)D * ngs * Tp), *fmean = sc.alloc<double>((size_t)D * ngs * Tp);
     double *dmean = sc.alloc<double>((size_t)R * D), *dvar = sc.alloc<double>((size_t)R * D);
     double *dpx = sc.alloc<double>((size_t)R * steps * D), *dpv = sc.alloc<double>((size_t)R * steps * D);
-    double *dQs = q_sqrt ? sc.upload(q_sqrt, (size_t)M * M) : nullptr;     // slice d = 0 only
-    double *extra = q_sqrt ? sc.alloc<double>((size_t)D * Tp) : nullptr;
+    std::vector<double> Qp;
+    if (q_sqrt && skinny) Qp = pad_stack(q_sqrt, 1, M, Mp);                // (F is zero in the padded columns)
+    double *dQs = q_sqrt ? (skinny ? sc.upload(Qp.data(), Qp.size()) : sc.upload(q_sqrt, (size_t)M * M)) : nullptr;   // slice d = 0 only
+    double *extra = q_sqrt ? sc.alloc<double>((size_t)D * (skinny ? ngs : 1) * Tp) : nullptr;
     if (!dW || !dxc || !dZ || !dU || !dlv || !dll || !dlq || !deps || (C && !dctrl) || !variance || !len || !Zs || !zz ||
         !rowsq || !fmean || !dmean || !dvar || !dpx || !dpv || !Kf || !ucol || (q_sqrt && (!dQs || !extra || !F)))
         return set_error(nullptr, FFVD_ENOMEM, "ffvd_op_rollout: device allocation or upload failed");
@@ -1990,9 +1996,17 @@ extern "C" int ffvd_op_rollout(int kind, const double *Lm_inverse_seq, const dou
     // the whole loop is enqueued at once: steps x (K_fu rows, projection, [q_sqrt inflation], conditional, update)
     for (int t = 0; t < steps; ++t) {
         launch_kfu_build(sc.stream, pa);                                     // K(x_t, Z) per dim
-        launch_proj_gemm(sc.stream, pg);                                     // conditional_after_kernel_precalculation (:300)
-        if (q_sqrt) launch_qsqrt_inflation(sc.stream, F, (size_t)Tp * Mp, Tp, Mp, M, dQs, extra, R, D);
-        launch_conditional_finish(sc.stream, kind, dxc, R, P, variance, rowsq, fmean, ng, Tp, D, dmean, dvar, extra);
+        if (skinny) {
+            launch_skinny_gemm(sc.stream, Kf, (size_t)Tp * Mp, Mp, dW, (size_t)Mp * Mp, Mp, 1, R, Mp, Mp, D, Tp,
+                               F, (size_t)Tp * Mp, Mp, ucol, Mp, rowsq, fmean);   // conditional_after_kernel_precalculation (:300)
+            if (q_sqrt) launch_skinny_gemm(sc.stream, F, (size_t)Tp * Mp, Mp, dQs, 0, Mp, 0, R, Mp, Mp, D, Tp,
+                                           nullptr, 0, 0, nullptr, 0, extra, nullptr);        // sum_j (F q_sqrt)_j^2  (:371-380)
+            launch_conditional_finish(sc.stream, kind, dxc, R, P, variance, rowsq, fmean, ngs, Tp, D, dmean, dvar, extra, ngs);
+        } else {
+            launch_proj_gemm(sc.stream, pg);
+            if (q_sqrt) launch_qsqrt_inflation(sc.stream, F, (size_t)Tp * Mp, Tp, Mp, M, dQs, extra, R, D);
+            launch_conditional_finish(sc.stream, kind, dxc, R, P, variance, rowsq, fmean, ng, Tp, D, dmean, dvar, extra);
+        }
         launch_rollout_update(sc.stream, dmean, dvar, dlq, deps + (size_t)t * R * D,
                               (C && t + 1 < steps) ? dctrl + (size_t)(t + 1) * C : nullptr, R, D, C, t, steps, dxc, dpx, dpv);
     }
@@ -2035,7 +2049,9 @@ extern "C" int ffvd_op_pg_sweep(int kind, const double *Lm_inverse_seq, const do
     double *variance = sc.alloc<double>(D), *len = sc.alloc<double>((size_t)D * P);
     double *Zs = sc.alloc<double>((size_t)D * Mp * P), *zz = sc.alloc<double>((size_t)D * Mp);
     double *Kf = sc.alloc<double>((size_t)D * Tp * Mp), *ucol = sc.alloc<double>((size_t)D * Mp);
-    double *rowsq = sc.alloc<double>((size_t)D * ng * Tp), *fmean = sc.alloc<double>((size_t)D * ng * Tp);
+    const bool skinny = R <= 512;                       // see ffvd_op_rollout
+    const int ngs = skinny ? Mp / 16 : ng;
+    double *rowsq = sc.alloc<double>((size_t)D * ngs * Tp), *fmean = sc.alloc<double>((size_t)D * ngs * Tp);
     double *dmean = sc.alloc<double>((size_t)R * D), *dvar = sc.alloc<double>((size_t)R * D);
     double *cand = sc.alloc<double>((size_t)(R + 1) * D);
     double *dparts = sc.alloc<double>((size_t)steps * R * D);
@@ -2059,8 +2075,10 @@ extern "C" int ffvd_op_pg_sweep(int kind, const double *Lm_inverse_seq, const do
     // the whole sweep is enqueued at once: steps x (K_fu rows, projection, conditional, propagate + weight + resample)
     for (int t = 0; t < steps; ++t) {
         launch_kfu_build(sc.stream, pa);
-        launch_proj_gemm(sc.stream, pg);                                     // conditional_after_kernel_precalculation (:95-97)
-        launch_conditional_finish(sc.stream, kind, dxc, R, P, variance, rowsq, fmean, ng, Tp, D, dmean, dvar, nullptr);
+        if (skinny) launch_skinny_gemm(sc.stream, Kf, (size_t)Tp * Mp, Mp, dW, (size_t)Mp * Mp, Mp, 1, R, Mp, Mp, D, Tp,
+                                       nullptr, 0, 0, ucol, Mp, rowsq, fmean);
+        else launch_proj_gemm(sc.stream, pg);                                // conditional_after_kernel_precalculation (:95-97)
+        launch_conditional_finish(sc.stream, kind, dxc, R, P, variance, rowsq, fmean, ngs, Tp, D, dmean, dvar, nullptr);
         launch_pg_step(sc.stream, dmean, dvar, dlq, deps + (size_t)t * R * D, dun + (size_t)t * R, dY + (size_t)t * Ydim,
                        dXr + (size_t)(t + 1) * D, dCC, dDD, dR, (C && t + 1 < steps) ? dctrl + (size_t)(t + 1) * C : nullptr,
                        R, D, C, Ydim, dxc, cand, dparts + (size_t)t * R * D, didx + (size_t)t * R);

@@ -176,7 +176,13 @@ void launch_finalize(hipStream_t stream, const FinalizeArgs &a);
 // conditional() epilogue: mean[n][d] = sum_g fmean, var[n][d] = Kdiag(x_n) - sum_g rowsq  (N x D outputs)
 void launch_conditional_finish(hipStream_t stream, int kind, const double *x, int N, int P, const double *variance,
                                const double *rowsq, const double *fmean, int ng, int Tp, int D, double *mean,
-                               double *var, const double *extra /* optional [D][Tp] added to var */);
+                               double *var, const double *extra /* optional [D][extra_ng][Tp], its groups added to var */,
+                               int extra_ng = 1);
+// C[b] (rows x N) = A[b] (rows x K) B for a FEW rows (step loops), with the per-16-column partial sums of C^2 and C u:
+// sq / dot [nb][N / 16][Tp] (feed launch_conditional_finish with ng = N / 16).  kernels.hip has the details.
+void launch_skinny_gemm(hipStream_t stream, const double *A, size_t a_stride, int lda, const double *B, size_t b_stride, int ldb,
+                        int upper, int rows, int K, int N, int nb, int Tp, double *C, size_t c_stride, int ldc,
+                        const double *u, size_t u_stride, double *sq, double *dot);
 // out[i * out_ld + b * out_bs] = sum_j W[b][i][j] y[b][j]
 void launch_matvec(hipStream_t stream, const double *W, size_t w_stride, const double *y, size_t y_stride, int Mp,
                    double *out, int out_ld, int out_bs, int M, int batch, int w_mod = 0);   // w_mod > 0: W slab index = batch index % w_mod

@@ -2240,7 +2240,8 @@ void launch_chain_reduce(hipStream_t stream, const ReduceArgs &a, double *partia
 // conditional() outputs (conditionals_multi_output.py:41,48,120): mean N x D, var N x D
 __global__ void conditional_finish_kernel(int kind, const double *x, int N, int P, const double *variance,
                                           const double *rowsq, const double *fmean, int ng, int Tp, int D,
-                                          double *mean, double *var, const double *extra /*[D][Tp] or null*/) {
+                                          double *mean, double *var, const double *extra /*[D][extra_ng][Tp] or null*/,
+                                          int extra_ng) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= N * D) return;
     const int n = idx / D, d = idx % D;
@@ -2257,14 +2258,88 @@ __global__ void conditional_finish_kernel(int kind, const double *x, int N, int 
     }
     mean[idx] = fm;
     var[idx] = kd - rs;
-    if (extra) var[idx] = var[idx] + extra[(size_t)d * Tp + n];     // fvar + reduce_sum(square(LTA), 1)  (:380)
+    if (extra) {                                                    // fvar + reduce_sum(square(LTA), 1)  (:380)
+        double ex = 0.0;
+        for (int g = 0; g < extra_ng; ++g) ex += extra[((size_t)d * extra_ng + g) * Tp + n];
+        var[idx] = var[idx] + ex;
+    }
 }
 void launch_conditional_finish(hipStream_t stream, int kind, const double *x, int N, int P, const double *variance,
                                const double *rowsq, const double *fmean, int ng, int Tp, int D, double *mean,
-                               double *var, const double *extra) {
+                               double *var, const double *extra, int extra_ng) {
     if (N * D == 0) return;
     hipLaunchKernelGGL(conditional_finish_kernel, dim3((N * D + 255) / 256), dim3(256), 0, stream, kind, x, N, P,
-                       variance, rowsq, fmean, ng, Tp, D, mean, var, extra);
+                       variance, rowsq, fmean, ng, Tp, D, mean, var, extra, extra_ng);
+}
+
+// Skinny product for the step loops (rollouts, particle Gibbs: at most a few hundred rows per latent dim and step):
+//   C[b] (rows x N) = A[b] (rows x K) * B (K x N),   optionally  sq[b][slab][r] = sum_{n in slab} C[r][n]^2,
+//                                                                dot[b][slab][r] = sum_{n in slab} C[r][n] u[b][n].
+// One workgroup = 32 rows x 16 columns, its four wavefronts a quarter of the k range each (operands straight from L2, no
+// LDS staging: 64 MFMAs per wavefront at K = 512), partial tiles added through LDS in fixed order.  N / 16 x rows / 32 x nb
+// workgroups instead of the handful of 128 x 128 tiles the projection GEMM cuts such a product into: 50 -> 7 us per step at 32 rows.
+// `upper`: B[k][n] = 0 for k > n (L^-T), the k range of a slab ends at its last column.
+struct SkinnyArgs {
+    const double *A; size_t a_stride; int lda;
+    const double *B; size_t b_stride; int ldb;      // b_stride = 0: one B for every unit
+    int upper, rows, K, N, nb, Tp;
+    double *C; size_t c_stride; int ldc;            // or null
+    const double *u; size_t u_stride;               // or null
+    double *sq, *dot;                               // [nb][N / 16][Tp], or null
+};
+__global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
+    __shared__ double red[3][2][4][64];
+    const int n0 = blockIdx.x * 16, r0 = blockIdx.y * 32, b = blockIdx.z;
+    if (r0 >= a.rows) return;
+    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const double *Ab = a.A + (size_t)b * a.a_stride, *Bb = a.B + (size_t)b * a.b_stride;
+    const int kend = (a.upper && n0 + 16 < a.K) ? n0 + 16 : a.K;
+    const int ksteps = kend / 4, per = (ksteps + 3) / 4;
+    const int ks0 = w * per, ks1 = (ks0 + per < ksteps) ? ks0 + per : ksteps;
+    d4 acc[2] = {(d4){0.0, 0.0, 0.0, 0.0}, (d4){0.0, 0.0, 0.0, 0.0}};
+    const double *ap0 = Ab + (size_t)(r0 + lr) * a.lda + lk, *ap1 = ap0 + (size_t)16 * a.lda;
+    const double *bp = Bb + (size_t)lk * a.ldb + n0 + lr;
+#pragma unroll 8
+    for (int ks = ks0; ks < ks1; ++ks) {
+        const double bf = bp[(size_t)(4 * ks) * a.ldb];
+        acc[0] = mfma_f64(ap0[4 * ks], bf, acc[0]);
+        acc[1] = mfma_f64(ap1[4 * ks], bf, acc[1]);
+    }
+    if (w > 0) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) red[w - 1][x][q][lane] = acc[x][q];
+    }
+    __syncthreads();
+    if (w > 0) return;
+    const int slab = blockIdx.x, nslab = a.N / 16;
+    const double un = a.u ? a.u[(size_t)b * a.u_stride + n0 + lr] : 0.0;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double c = ((acc[x][q] + red[0][x][q][lane]) + red[1][x][q][lane]) + red[2][x][q][lane];
+            const int row = r0 + 16 * x + lk + 4 * q;
+            if (a.C) a.C[(size_t)b * a.c_stride + (size_t)row * a.ldc + n0 + lr] = c;
+            double s2 = c * c, du = c * un;
+            s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2); s2 += __shfl_xor(s2, 4); s2 += __shfl_xor(s2, 8);
+            du += __shfl_xor(du, 1); du += __shfl_xor(du, 2); du += __shfl_xor(du, 4); du += __shfl_xor(du, 8);
+            if (lr == 0) {
+                const size_t o = ((size_t)b * nslab + slab) * a.Tp + row;
+                if (a.sq) a.sq[o] = s2;
+                if (a.dot) a.dot[o] = du;
+            }
+        }
+}
+// rows <= Tp (a multiple of 32) rows of A exist; N, K multiples of 16.
+void launch_skinny_gemm(hipStream_t stream, const double *A, size_t a_stride, int lda, const double *B, size_t b_stride, int ldb,
+                        int upper, int rows, int K, int N, int nb, int Tp, double *C, size_t c_stride, int ldc,
+                        const double *u, size_t u_stride, double *sq, double *dot) {
+    if (rows <= 0 || nb <= 0) return;
+    SkinnyArgs a{A, a_stride, lda, B, b_stride, ldb, upper, rows, K, N, nb, Tp, C, c_stride, ldc, u, u_stride, sq, dot};
+    hipLaunchKernelGGL(skinny_gemm_kernel, dim3(N / 16, (rows + 31) / 32, nb), dim3(256), 0, stream, a);
 }
 
 // out[b][i] = sum_j W[b][i][j] * y[b][j]   (posterior mean of the whitened inducing outputs: L_H^-T (L_H^-1 b))
