@@ -2238,18 +2238,25 @@ void launch_chain_reduce(hipStream_t stream, const ReduceArgs &a, double *partia
 }
 
 // conditional() outputs (conditionals_multi_output.py:41,48,120): mean N x D, var N x D
-__global__ void conditional_finish_kernel(int kind, const double *x, int N, int P, const double *variance,
+// One output (n, d) per group of 16 lanes: the lanes share the partial-sum groups (the skinny products of the step loops leave
+// Mp / 16 of them per array) and add them by a shuffle tree -- a thread walking 96 dependent loads per output took 18 us.
+__global__ __launch_bounds__(256) void conditional_finish_kernel(int kind, const double *x, int N, int P, const double *variance,
                                           const double *rowsq, const double *fmean, int ng, int Tp, int D,
                                           double *mean, double *var, const double *extra /*[D][extra_ng][Tp] or null*/,
                                           int extra_ng) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= N * D) return;
-    const int n = idx / D, d = idx % D;
-    double rs = 0.0, fm = 0.0;
-    for (int g = 0; g < ng; ++g) {
+    const int idx = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, l = threadIdx.x & 15;
+    const bool live = idx < N * D;
+    const int n = live ? idx / D : 0, d = live ? idx % D : 0;
+    double rs = 0.0, fm = 0.0, ex = 0.0;
+    for (int g = l; g < ng; g += 16) {
         rs += rowsq[((size_t)d * ng + g) * Tp + n];
         fm += fmean[((size_t)d * ng + g) * Tp + n];
     }
+    if (extra)
+        for (int g = l; g < extra_ng; g += 16) ex += extra[((size_t)d * extra_ng + g) * Tp + n];
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) { rs += __shfl_xor(rs, m); fm += __shfl_xor(fm, m); ex += __shfl_xor(ex, m); }
+    if (!live || l != 0) return;
     double kd = variance[d];
     if (kind == 1) {
         double s = 0.0;
@@ -2258,17 +2265,13 @@ __global__ void conditional_finish_kernel(int kind, const double *x, int N, int 
     }
     mean[idx] = fm;
     var[idx] = kd - rs;
-    if (extra) {                                                    // fvar + reduce_sum(square(LTA), 1)  (:380)
-        double ex = 0.0;
-        for (int g = 0; g < extra_ng; ++g) ex += extra[((size_t)d * extra_ng + g) * Tp + n];
-        var[idx] = var[idx] + ex;
-    }
+    if (extra) var[idx] = var[idx] + ex;                            // fvar + reduce_sum(square(LTA), 1)  (:380)
 }
 void launch_conditional_finish(hipStream_t stream, int kind, const double *x, int N, int P, const double *variance,
                                const double *rowsq, const double *fmean, int ng, int Tp, int D, double *mean,
                                double *var, const double *extra, int extra_ng) {
     if (N * D == 0) return;
-    hipLaunchKernelGGL(conditional_finish_kernel, dim3((N * D + 255) / 256), dim3(256), 0, stream, kind, x, N, P,
+    hipLaunchKernelGGL(conditional_finish_kernel, dim3((N * D * 16 + 255) / 256), dim3(256), 0, stream, kind, x, N, P,
                        variance, rowsq, fmean, ng, Tp, D, mean, var, extra, extra_ng);
 }
 
@@ -2295,16 +2298,24 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const double *Ab = a.A + (size_t)b * a.a_stride, *Bb = a.B + (size_t)b * a.b_stride;
     const int kend = (a.upper && n0 + 16 < a.K) ? n0 + 16 : a.K;
-    const int ksteps = kend / 4, per = (ksteps + 3) / 4;
-    const int ks0 = w * per, ks1 = (ks0 + per < ksteps) ? ks0 + per : ksteps;
+    const int nkb = kend / 16, per = (nkb + 3) / 4;                 // 16-wide k blocks, a quarter of them per wavefront
+    const int kb0 = w * per, kb1 = (kb0 + per < nkb) ? kb0 + per : nkb;
     d4 acc[2] = {(d4){0.0, 0.0, 0.0, 0.0}, (d4){0.0, 0.0, 0.0, 0.0}};
-    const double *ap0 = Ab + (size_t)(r0 + lr) * a.lda + lk, *ap1 = ap0 + (size_t)16 * a.lda;
-    const double *bp = Bb + (size_t)lk * a.ldb + n0 + lr;
-#pragma unroll 8
-    for (int ks = ks0; ks < ks1; ++ks) {
-        const double bf = bp[(size_t)(4 * ks) * a.ldb];
-        acc[0] = mfma_f64(ap0[4 * ks], bf, acc[0]);
-        acc[1] = mfma_f64(ap1[4 * ks], bf, acc[1]);
+    // Inside a k block the four lane groups take k = 4 lk + s in MFMA s (a sum does not care about its order), so a lane reads
+    // four CONSECUTIVE doubles of its A row (two 16-byte loads feed four MFMAs, 128-byte runs per row) instead of four 8-byte ones
+    const double *ap0 = Ab + (size_t)(r0 + lr) * a.lda + 4 * lk, *ap1 = ap0 + (size_t)16 * a.lda;
+    const double *bp = Bb + (size_t)(4 * lk) * a.ldb + n0 + lr;
+#pragma unroll 4
+    for (int kb = kb0; kb < kb1; ++kb) {
+        const int k0 = 16 * kb;
+        const d2 a0l = *reinterpret_cast<const d2 *>(ap0 + k0), a0h = *reinterpret_cast<const d2 *>(ap0 + k0 + 2);
+        const d2 a1l = *reinterpret_cast<const d2 *>(ap1 + k0), a1h = *reinterpret_cast<const d2 *>(ap1 + k0 + 2);
+        const double *bq = bp + (size_t)k0 * a.ldb;
+        const double b0 = bq[0], b1 = bq[a.ldb], b2 = bq[2 * (size_t)a.ldb], b3 = bq[3 * (size_t)a.ldb];
+        acc[0] = mfma_f64(a0l.x, b0, acc[0]); acc[1] = mfma_f64(a1l.x, b0, acc[1]);
+        acc[0] = mfma_f64(a0l.y, b1, acc[0]); acc[1] = mfma_f64(a1l.y, b1, acc[1]);
+        acc[0] = mfma_f64(a0h.x, b2, acc[0]); acc[1] = mfma_f64(a1h.x, b2, acc[1]);
+        acc[0] = mfma_f64(a0h.y, b3, acc[0]); acc[1] = mfma_f64(a1h.y, b3, acc[1]);
     }
     if (w > 0) {
 #pragma unroll
