@@ -2013,8 +2013,17 @@ __global__ __launch_bounds__(512, 4) void gram_kernel(GramArgs a) {
     int ti = 0;                       // tile = ti (ti + 1) / 2 + tj,  tj <= ti
     while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
     const int tj = tile - ti * (ti + 1) / 2;
+#ifdef FFVD_DF_TRACE
+    const long long tw0 = wall_clock64();     // debug build (tools/gram_trace.py): start and end of the tiles of the first 16 units
+#endif
     if (ti == tj) gram_body<MODE, true>(a, bz, ti, tj, tile, kpart, ksplit, As, Bs, dls, red);
     else gram_body<MODE, false>(a, bz, ti, tj, tile, kpart, ksplit, As, Bs, dls, red);
+#ifdef FFVD_DF_TRACE
+    if (threadIdx.x == 0 && bz < 16 && ksplit == 1 && a.ntiles <= 10 && MODE == GRAM_KFU) {
+        df_trace_buf[2048 + (bz * 10 + tile) * 2] = tw0;
+        df_trace_buf[2048 + (bz * 10 + tile) * 2 + 1] = wall_clock64();
+    }
+#endif
 }
 
 // Second pass of a split-K Gram launch: one workgroup per (unit, tile) adds the `ksplit` partial tiles in fixed
