@@ -1,0 +1,68 @@
+"""bench.py's contract with the driver: defaults, ONE JSON line on stdout with the agreed keys, the self-spawning --gpus N form."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_defaults_without_flags():
+    import bench
+    a = bench.parse_args([])
+    assert (a.gpus, a.steps, a.warmup, a.workload, a.dtype, a.route) == (1, 60, 10, "c2", "f64", "gram")
+    c4 = bench.parse_args(["--workload", "c4"])
+    assert (c4.dtype, c4.route, c4.steps, c4.warmup) == ("f32c", "reference", 5, 1)      # BASELINE configs[3]: fp32 contractions
+    assert bench.parse_args(["--workload", "c5"]).route == "reference"
+    assert bench.PEAK_TFLOPS == {"f64": 78.6, "f32c": 157.3}
+
+
+REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline"]
+
+
+def _run(args, env=None):
+    e = dict(os.environ)
+    e.pop("FFVD_LIB", None)
+    if env:
+        e.update(env)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=e, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, "stdout must be exactly one JSON line, got: %r" % lines[:3]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_one_json_line_with_the_agreed_keys():
+    d = _run(["--steps", "4", "--warmup", "1"])
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["metric"].startswith("ELBO iters/sec (T=4096, M=512, x_dim=4, S=32)") and d["unit"] == "iters/sec"
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["dtype"] == "f64" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] * d["ms_per_step"] / 1e3 - 1.0) < 1e-9                        # value = 1 / time per step
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "mfma" and r["peak"] == 78.6 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert 0.0 < r["frac"] < 1.0
+    assert r["traffic"] is None or r["traffic_source"].startswith("profiles/traffic.json")
+    cb = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cb, k
+    assert cb["kind"] == "port" and cb["value"] > 0.0
+
+
+@pytest.mark.gpu
+def test_plain_invocation_with_two_gpus_starts_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher: the parent spawns the ranks itself.  On the one-GPU test box both ranks share
+    device 0 and the eight sums travel over gloo (FFVD_BENCH_REHEARSAL=1); the JSON line says which exchange was timed."""
+    d = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], env={"FFVD_BENCH_REHEARSAL": "1"})
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["chains_per_gpu"] == 16
+    assert "gloo" in d["config"]["parallelism"]
+    assert "cpu_baseline" not in d
