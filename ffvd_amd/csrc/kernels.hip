@@ -216,8 +216,11 @@ void launch_transpose(hipStream_t stream, const double *in, size_t in_stride, do
 // SMALLP (P <= 8): x / l is kept row-major and zero-padded to 8 components in LDS, so a row is four 16-byte
 // broadcast reads and the dot product eight unconditional FMAs (with a run-time `p < P` test the compiler emits one
 // LDS round trip and one scalar branch per component: 0.55 instead of 0.40 ms for the 2 GiB of config 2).
-template <int KIND, bool SMALLP>
+// NQ > 0: the SMALLP form with 2 NQ components (P = 5: six FMAs and three reads per element instead of eight and four -- the
+// build is bound by its fp64 VALU work as much as by the write); NQ = 0: the general form.
+template <int KIND, int NQ>
 __global__ __launch_bounds__(256) void kfu_build_kernel(ProjectArgs a) {
+    constexpr bool SMALLP = NQ > 0;
     __shared__ double xs[SMALLP ? 1 : MAXP][SMALLP ? 1 : 64];
     __shared__ __attribute__((aligned(16))) double xr8[SMALLP ? 64 : 1][8];
     __shared__ double xx[64];
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(256) void kfu_build_kernel(ProjectArgs a) {
             double dot = 0.0;
             if (SMALLP) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < (NQ > 0 ? NQ : 1); ++q) {
                     const double2 xv = *reinterpret_cast<const double2 *>(&xr8[r][2 * q]);
                     dot += xv.x * zr[2 * q];
                     dot += xv.y * zr[2 * q + 1];
@@ -287,11 +290,15 @@ __global__ __launch_bounds__(256) void kfu_build_kernel(ProjectArgs a) {
 void launch_kfu_build(hipStream_t stream, const ProjectArgs &a) {
     dim3 grid(a.Tp / 64, a.Mp / 64, a.nb);
     if (a.P <= 8) {
-        if (a.kind == 0) hipLaunchKernelGGL((kfu_build_kernel<0, true>), grid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((kfu_build_kernel<1, true>), grid, dim3(256), 0, stream, a);
+        const int nq = (a.P + 1) / 2;
+        if (a.kind == 0) {
+            if (nq <= 2) hipLaunchKernelGGL((kfu_build_kernel<0, 2>), grid, dim3(256), 0, stream, a);
+            else if (nq == 3) hipLaunchKernelGGL((kfu_build_kernel<0, 3>), grid, dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL((kfu_build_kernel<0, 4>), grid, dim3(256), 0, stream, a);
+        } else hipLaunchKernelGGL((kfu_build_kernel<1, 4>), grid, dim3(256), 0, stream, a);
     } else {
-        if (a.kind == 0) hipLaunchKernelGGL((kfu_build_kernel<0, false>), grid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((kfu_build_kernel<1, false>), grid, dim3(256), 0, stream, a);
+        if (a.kind == 0) hipLaunchKernelGGL((kfu_build_kernel<0, 0>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((kfu_build_kernel<1, 0>), grid, dim3(256), 0, stream, a);
     }
 }
 
