@@ -583,6 +583,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
     const int ns_first = (h->cpp <= c.S_local) ? h->cpp : c.S_local;
     bool kfu_first = false;     // the first pass's K_fu build goes to the main stream before the chain is enqueued
     bool ident_on_side = false, kuu_on_main = false, linv_done = false, hwords_zeroed = false, ident_early = false;
+    bool kinv_done = false;     // K^-1 came out of the chain's dataflow launch (no product launch)
     if (gram_route && (late_join || (size_t)first_units * Tp * Mp >= (size_t)64 * 4096 * 512)) {
         sk = h->aux;
         kuu_on_main = h->kuu_flow_sched && !late_join;
@@ -600,7 +601,9 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
                 potrf_flow_clear(sk, h->dinvK, (int)Dl);
                 HIP_TRY(hipEventRecord(h->ev_go, sk));
             }
-            launch_potrf_ext(sk, h->Kuu, Mp, Mp, Mp, Dl, kstride, h->info, h->dinvK, CHOL_FLOW, h->Linv, msq, linv_done);
+            kinv_done = linv_done && !h->sw.kinv_gram && potrf_flow_forms_inverse((int)Mp, (int)Dl, CHOL_FLOW);
+            launch_potrf_ext(sk, h->Kuu, Mp, Mp, Mp, Dl, kstride, h->info, h->dinvK, CHOL_FLOW, h->Linv, msq, linv_done, false,
+                             kinv_done ? h->Kinv : nullptr, msq);
             if (linv_done) {
                 launch_chain_reduce(s, reduce_args(), h->chain_partial);      // inputs only; fills the wait below
                 reduce_done = true;
@@ -653,7 +656,9 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
         GramArgs gk{};
         gk.mode = GRAM_PLAIN; gk.A = h->Linv; gk.a_stride = msq; gk.rows = Mp; gk.with_row = 0; gk.Mp = Mp; gk.Dl = Dl;
         gk.d_begin = c.d_begin; gk.b0 = 0; gk.nb = Dl; gk.yn_over_batch = 1.0; gk.H = h->Kinv; gk.h_stride = msq;
-        if (c.grad || (kuu_on_main && !h->sw.kinv_gram)) {
+        if (kinv_done) {
+            // (the identity-row workgroups of the chain's launch have formed it: kernels.hip, df_inverse_tiles)
+        } else if (c.grad || (kuu_on_main && !h->sw.kinv_gram)) {
             // the backward pass reads K^-1 everywhere, the Gram kernel only writes lower tiles; and beside the K_fu build
             // (kuu_on_main: the main stream waits for this product) 256-thread workgroups find a slot where the Gram
             // kernel's 1024-thread ones wait for the build to drain (0.19 against 0.05 ms)

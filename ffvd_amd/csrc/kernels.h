@@ -56,7 +56,11 @@ size_t potrf_scratch_doubles(int n, int batch);
 bool potrf_flow_selected(int n, int batch, int hint);
 void launch_potrf_ext(hipStream_t stream, double *A, int n, int extra_rows, int identity_rows, int batch,
                       size_t slab_stride, int32_t *info, double *dinv, int hint = CHOL_AUTO, double *linv_t = nullptr,
-                      size_t linv_t_stride = 0, bool words_zeroed = false, bool tail_is_vector = false);
+                      size_t linv_t_stride = 0, bool words_zeroed = false, bool tail_is_vector = false, double *kinv = nullptr,
+                      size_t kinv_stride = 0);
+// kinv (dataflow variant with identity_rows == n, i.e. all of L^-T, and n <= 2048 -- ask potrf_flow_forms_inverse): the launch also
+// leaves A^-1 = L^-T L^-1 (n x n, ld n, both triangles) in every slab of kinv.
+bool potrf_flow_forms_inverse(int n, int batch, int hint);
 // tail_is_vector (dataflow variant only; ignored by the others, which treat every extra row alike): of each 64-row block of
 // extra rows BEHIND the identity rows only the first row is live (the ELBO's row b); the other 63 are neither read nor written.
 // The dataflow variant polls progress words at the start of `dinv`; they must be zero when its kernel starts.  The launcher

@@ -1090,6 +1090,8 @@ struct DfArgs {
     double *xt;        // optional: the identity-structured extra rows (R L^-T = L^-T) also land TRANSPOSED here, i.e. L^-1 as
     size_t xt_stride;  //   an n x n lower-triangular matrix (ld n) per slab; blocks above its diagonal are not written
     int vec_tail;      // the extra-row blocks behind the identity rows carry ONE live row each (their first): df_vector_row
+    double *kinv;      // optional (identity rows = all of L^-T): (A)^-1 = L^-T L^-1, full symmetric n x n per slab (ld n), formed by
+    size_t kinv_stride;//   the identity-row workgroups once their rows are complete (df_inverse_tiles)
 };
 
 // Debug build only (-DFFVD_DF_TRACE, tools/df_trace.py): wall-clock stamps of matrix 0's block rows, in a buffer of their own.
@@ -1355,6 +1357,80 @@ __device__ __forceinline__ void df_vector_row(const DfArgs &a, double *S, int *p
     }
 }
 
+// Identity-row workgroup e, its row W(e, e..) = (L^-T)(e, .) complete: announce it, then form the tiles (e, f), f <= e, of
+// A^-1 = L^-T L^-1 = W W^T:  (e,f) = sum_{j >= e} W(e,j) W(f,j)^T  (rows f < e belong to workgroups dispatched earlier).  The
+// same staging loop as the panel gather; both triangles are written.  A separate product launch after the factorisation
+// costs the K_uu chain 0.13-0.17 ms beside the K_fu build (its workgroups queue behind that kernel's), these tiles 0.04.
+__device__ __forceinline__ bool df_inverse_tiles(const DfArgs &a, double *S, int *pg, const int b, const int e,
+                                                 double (*Xs)[LL_LD], double (*Ls)[LL_LD], int *wslot) {
+    const int n = a.n, nb = a.nb;
+    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qr = wave >> 1, qc = wave & 1;
+    const int sr = tid >> 5, sc = 2 * (tid & 31);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wavefront's stores of the row have left it
+    __syncthreads();
+    if (tid == 0) df_publish(pg + nb + e, 1);
+    double *Kb = a.kinv + (size_t)b * a.kinv_stride;
+    const double *We = S + (size_t)(n + e * NB) * n;
+    int wc = 0;
+    for (int f = 0; f <= e; ++f) {
+        if (f < e) {
+            const int seen = df_wait(pg + nb + f, 1, a.abort_w, &wslot[wc++ & 1]);
+            if (seen < 0) return false;
+        }
+        const double *Wf = S + (size_t)(n + f * NB) * n;
+        d4 acc[2][2];
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
+        d2 vx[8], vl[8];
+        auto gload = [&](int j) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                vx[i] = *reinterpret_cast<const d2 *>(We + (size_t)(sr + 8 * i) * n + j * NB + sc);
+                vl[i] = *reinterpret_cast<const d2 *>(Wf + (size_t)(sr + 8 * i) * n + j * NB + sc);
+            }
+        };
+        gload(e);
+        for (int j = e; j < nb; ++j) {
+            __syncthreads();                                // everyone is done reading the previous tiles
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                Xs[sr + 8 * i][sc] = vx[i].x; Xs[sr + 8 * i][sc + 1] = vx[i].y;
+                Ls[sr + 8 * i][sc] = vl[i].x; Ls[sr + 8 * i][sc + 1] = vl[i].y;
+            }
+            __syncthreads();
+            if (j + 1 < nb) gload(j + 1);
+#pragma unroll 4
+            for (int ks = 0; ks < NB / 4; ++ks) {
+                double ax[2], bl[2];
+#pragma unroll
+                for (int x = 0; x < 2; ++x) {
+                    ax[x] = Xs[qr * 32 + 16 * x + lr][4 * ks + lk];
+                    bl[x] = Ls[qc * 32 + 16 * x + lr][4 * ks + lk];
+                }
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                    for (int y = 0; y < 2; ++y) acc[x][y] = mfma_f64(ax[x], bl[y], acc[x][y]);
+            }
+        }
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const size_t i = (size_t)(e * NB + qr * 32 + 16 * x + lk + 4 * q), jj = (size_t)(f * NB + qc * 32 + 16 * y + lr);
+                    Kb[i * n + jj] = acc[x][y][q];
+                    if (f < e) Kb[jj * n + i] = acc[x][y][q];
+                }
+    }
+    return true;
+}
+
 template <bool PIPE>
 __global__ __launch_bounds__(256, 2) void potrf_df_kernel(DfArgs a) {
     __shared__ double sm0[NB * LL_LD];      // X(r,k) tiles; then T = A(r,j) - sum and the solved X(r,j)
@@ -1401,7 +1477,12 @@ __global__ __launch_bounds__(256, 2) void potrf_df_kernel(DfArgs a) {
             }
         }
     }
-    if (!main_row) return;
+    if (!main_row) {
+        if (a.kinv && ri - nb < a.nid && !df_inverse_tiles(a, S, pg, b, ri - nb, Xs, Ls, wslot)) {
+            if (tid == 0 && a.info) a.info[b] = -1;
+        }
+        return;
+    }
     // S_rr = A(r,r) - sum_{k<r} X(r,k) X(r,k)^T
     d4 cold_d[2][2], acc_d[2][2];
 #pragma unroll
@@ -1481,10 +1562,11 @@ void potrf_flow_clear(hipStream_t stream, double *scratch, int batch) {
 
 static void launch_potrf_flow(hipStream_t stream, double *A, int n, int extra_rows, int identity_rows, int batch,
                               size_t slab_stride, int32_t *info, double *scratch, double *linv_t, size_t linv_t_stride,
-                              bool words_zeroed, bool tail_is_vector) {
+                              bool words_zeroed, bool tail_is_vector, double *kinv, size_t kinv_stride) {
     DfArgs a{};
     a.xt = linv_t; a.xt_stride = linv_t_stride;
     a.vec_tail = tail_is_vector ? 1 : 0;
+    if (kinv && identity_rows == n && 2 * (n / NB) <= DF_PS) { a.kinv = kinv; a.kinv_stride = kinv_stride; }
     a.A = A; a.n = n; a.nb = n / NB; a.next = extra_rows / NB; a.nid = identity_rows / NB; a.batch = batch;
     a.slab_stride = slab_stride; a.info = info;
     // the polled words sit at the start of the scratch block, padded to 16 bytes, and are zeroed before every launch
@@ -1521,6 +1603,7 @@ static int chol_mode() {                    // 0 = auto, 1 = left-looking launch
 }
 static int chol_variant(int batch, int nb, int hint);
 bool potrf_flow_selected(int n, int batch, int hint) { return chol_variant(batch, n / NB, hint) == 3; }
+bool potrf_flow_forms_inverse(int n, int batch, int hint) { return potrf_flow_selected(n, batch, hint) && 2 * (n / NB) <= DF_PS; }
 static int chol_variant(int batch, int nb, int hint) {
     int m = chol_mode();
     if (m == 0) m = (hint == CHOL_FLOW || batch >= 32) ? 3 : 2;
@@ -1530,13 +1613,13 @@ static int chol_variant(int batch, int nb, int hint) {
 
 void launch_potrf_ext(hipStream_t stream, double *A, int n, int extra_rows, int identity_rows, int batch,
                       size_t slab_stride, int32_t *info, double *dinv, int hint, double *linv_t, size_t linv_t_stride,
-                      bool words_zeroed, bool tail_is_vector) {
+                      bool words_zeroed, bool tail_is_vector, double *kinv, size_t kinv_stride) {
     const int nb = n / NB;
     const int nid = identity_rows / NB, ntail = extra_rows / NB - nid;
     const int variant = chol_variant(batch, nb, hint);
     if (variant == 3) {
         launch_potrf_flow(stream, A, n, extra_rows, identity_rows, batch, slab_stride, info, dinv, linv_t, linv_t_stride, words_zeroed,
-                          tail_is_vector);
+                          tail_is_vector, kinv, kinv_stride);
         return;
     }
     if (variant == 1) {
