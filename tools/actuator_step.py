@@ -1,0 +1,21 @@
+"""Per-call latency of the forward ELBO and of the device-resident training step at the reference's own experiment size
+(actuator: T=512, M=100, D=4, one chain) -- tools helper, run on the GPU box."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from ffvd_amd.engine import ElboEngine
+z = np.load(os.path.join(ROOT, "tests", "golden", "actuator_slim.npz"), allow_pickle=False)
+params = {k: z[k] for k in ("X","Z","U","logvariance","loglengthscales","log_Q","CC","DD","log_Rchols")}
+Y, c = z["Y"], z["control_inputs"]
+T, D = params["X"].shape[0]-1, params["X"].shape[1]
+M, C = params["Z"].shape[0], c.shape[1]
+params["X"] = params["X"][None]
+for grad in (False, True):
+    e = ElboEngine(T, D, C, M, 1, route="gram", grad=grad)
+    e.set_data(Y, c); e.set_params(params)
+    f = (lambda: e.adam_step(1e-9)) if grad else (lambda: e.nll_terms())
+    for _ in range(10): f()
+    n = 300; t0 = time.perf_counter()
+    for _ in range(n): f()
+    print("actuator T=%d M=%d D=%d %s: %.3f ms per call" % (T, M, D, "adam_step" if grad else "forward", (time.perf_counter()-t0)/n*1e3))
