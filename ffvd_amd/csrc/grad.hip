@@ -1208,7 +1208,7 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(GradFinalArgs a) {
         block_sum_multi_256<8>(v, scratch);
         if (tid == 0) {
             const double ls = v[0] + a.dls_kuu[dl];
-            a.dlogvar[dg] = -ls / Tn / Sn + w * (a.logvar[dg] - log(0.05)) / Tn;
+            a.dlogvar[dg] = -ls / Tn / Sn + w * (a.logvar[dg] - (a.kind == 0 ? LOG_PRIOR_VARIANCE_SE : LOG_PRIOR_VARIANCE_LIN)) / Tn;
             a.dlogQ[dg] = -v[1] / Tn / Sn + (a.branch_a ? 0.0 : v[2] / Sn) + w * a.log_Q[dg] / Tn;
         }
     }

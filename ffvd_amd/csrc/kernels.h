@@ -10,6 +10,11 @@ constexpr int NB = 64;        // universal block size: M is padded to a multiple
 constexpr int DINV_STRIDE = 2 * 4 * 16 * 16;   // Cholesky scratch per matrix: inverses of the four 16x16 diagonal sub-blocks of the current
                                                // block step, two slots (the look-ahead of step j writes slot (j+1)&1 while step j reads slot j&1)
 constexpr int STRIP = 64;     // rows of K_fu handled by one workgroup of the projection kernel
+// Centre of the prior on logvariance (Layer.prior_hyper, dgp_model.py:123-130).  SquaredExponential (:127) writes
+// tf.cast(tf.math.log(0.05), tf.float64): the logarithm is taken in float32 and then widened, i.e. -2.995732307434082
+// (the fp64 logarithm is -2.995732273553991); LinearK (:130) writes np.log(0.05), the fp64 value.
+constexpr double LOG_PRIOR_VARIANCE_SE = -2.995732307434082;     // double(float32 log(float32 0.05)), exactly representable
+constexpr double LOG_PRIOR_VARIANCE_LIN = -2.995732273553991;    // np.log(0.05)
 constexpr int MAXP = 32;      // largest GP input dimension P = D + C supported by the LDS layout
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }

@@ -2576,7 +2576,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
             sm[2] += l * l;
         }
     for (int dl = tid; dl < a.Dl; dl += 256) {
-        const double dv = a.logvar[a.d_begin + dl] - log(0.05);
+        const double dv = a.logvar[a.d_begin + dl] - (a.kind == 0 ? LOG_PRIOR_VARIANCE_SE : LOG_PRIOR_VARIANCE_LIN);
         sm[3] += dv * dv;
         sm[9] += log(sqrt(exp(a.log_Q[a.d_begin + dl])));          // -sum_d log(Q_d ** 0.5) likelihoods.py:91 / :101
     }

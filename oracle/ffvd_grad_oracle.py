@@ -66,7 +66,7 @@ def nll_grad(params, Y, control_inputs, jitter=orc.JITTER_MULTI_OUTPUT, prior_ty
     g["log_Q"] += (0.5 * T - 0.5 * (delta ** 2).sum(0) / Q) / T
     # ---- priors (dgp_model.py:105-130,252,286,326-334) -------------------------------------------
     g["loglengthscales"] += params["loglengthscales"] / T
-    g["logvariance"] += (params["logvariance"] - np.log(0.05)) / T
+    g["logvariance"] += (params["logvariance"] - orc.LOG_PRIOR_VARIANCE_SE) / T
     if prior_type == "normal":
         g["Z"] += Z / T
     g["X"][0] += X[0] / T
@@ -150,7 +150,7 @@ def nll_grad_explicit_u(params, Y, control_inputs, jitter=orc.JITTER_MULTI_OUTPU
     g["DD"] += -(rl / R[None, :]).sum(0) / T
     g["log_Rchols"][0] += -((rl ** 2).sum(0) - T) / T
     g["loglengthscales"] += params["loglengthscales"] / T
-    g["logvariance"] += (params["logvariance"] - np.log(0.05)) / T
+    g["logvariance"] += (params["logvariance"] - orc.LOG_PRIOR_VARIANCE_SE) / T
     if prior_type == "normal":
         g["Z"] += Z / T
     g["X"][0] += X[0] / T

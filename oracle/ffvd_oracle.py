@@ -298,6 +298,13 @@ def prior_Z(Z, prior_type="normal"):
     raise ValueError("Invalid prior type")
 
 
+# dgp_model.py:127 centres the SquaredExponential prior at tf.cast(tf.math.log(0.05), tf.float64): the logarithm of a Python
+# float is taken in float32 (TF's default dtype for it) and only then widened -- -2.995732307434082, not the fp64
+# -2.995732273553991.  The LinearK line (:130) uses np.log(0.05), i.e. the fp64 value.
+LOG_PRIOR_VARIANCE_SE = float(np.float64(np.log(np.float32(0.05))))
+LOG_PRIOR_VARIANCE_LIN = float(np.log(0.05))
+
+
 def prior_hyper(kern, kernel_type="SquaredExponential"):
     """Layer.prior_hyper (dgp_model.py:123-130).  LinearK: the reference indexes a
     single kernel object (broken wiring); the list form sums the same expression
@@ -306,10 +313,10 @@ def prior_hyper(kern, kernel_type="SquaredExponential"):
     if kernel_type == "SquaredExponential":
         for k in kern:
             val += -np.sum(np.square(k.loglengthscales)) / 2.0 \
-                   - np.sum(np.square(k.logvariance - np.log(0.05))) / 2.0
+                   - np.sum(np.square(k.logvariance - LOG_PRIOR_VARIANCE_SE)) / 2.0
         return val
     for k in kern:
-        val += -np.sum(np.square(k.logvariance - np.log(0.05))) / 2.0
+        val += -np.sum(np.square(k.logvariance - LOG_PRIOR_VARIANCE_LIN)) / 2.0
     return val
 
 

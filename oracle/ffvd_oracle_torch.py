@@ -66,7 +66,9 @@ def nll_terms(params, Y, control_inputs, *, U_collapse=True, kernel_type="Square
     hyp = -0.5 * ((params["log_Q"] ** 2).sum() + (params["CC"] ** 2).sum()
                   + (params["DD"] ** 2).sum() + (params["log_Rchols"] ** 2).sum())
     if se:
-        p_hyper = -0.5 * (loglen ** 2).sum() - 0.5 * ((logvar - math.log(0.05)) ** 2).sum()
+        # dgp_model.py:127: tf.cast(tf.math.log(0.05), tf.float64) -- a float32 logarithm, widened
+        c_se = float(torch.log(torch.tensor(0.05, dtype=torch.float32)).double())
+        p_hyper = -0.5 * (loglen ** 2).sum() - 0.5 * ((logvar - c_se) ** 2).sum()
     else:
         p_hyper = -0.5 * ((logvar - math.log(0.05)) ** 2).sum()
     p_Z = -0.5 * (Z ** 2).sum() if prior_type == "normal" else torch.zeros((), dtype=X.dtype)

@@ -26,6 +26,22 @@ def test_actuator_anchors(actuator):
         assert ta[k] == pytest.approx(v, rel=1e-9, abs=1e-13), k
 
 
+def test_prior_centre_is_the_float32_logarithm():
+    """dgp_model.py:127: tf.cast(tf.math.log(0.05), tf.float64) takes the logarithm in float32 and widens it; the LinearK
+    line (:130) uses np.log(0.05).  Both restatements and the HIP kernels (kernels.h) carry exactly these two values."""
+    import re, os, torch
+    assert orc.LOG_PRIOR_VARIANCE_SE == -2.995732307434082 == float(torch.log(torch.tensor(0.05, dtype=torch.float32)))
+    assert orc.LOG_PRIOR_VARIANCE_LIN == -2.995732273553991 == float(np.log(0.05))
+    hdr = open(os.path.join(os.path.dirname(__file__), "..", "ffvd_amd", "csrc", "kernels.h")).read()
+    se = float(re.search(r"LOG_PRIOR_VARIANCE_SE = ([-0-9.e]+);", hdr).group(1))
+    lin = float(re.search(r"LOG_PRIOR_VARIANCE_LIN = ([-0-9.e]+);", hdr).group(1))
+    assert se == orc.LOG_PRIOR_VARIANCE_SE and lin == orc.LOG_PRIOR_VARIANCE_LIN
+    # the effect on the actuator fixture: 3.4e-8 in the constant, 6e-11 in the nll (SURVEY's anchors used the fp64 value)
+    class K:                                        # noqa: D401
+        def __init__(self, lv): self.logvariance = np.array(lv); self.loglengthscales = np.zeros(5)
+    assert abs(orc.prior_hyper([K(-1.0)]) + 0.5 * (-1.0 - orc.LOG_PRIOR_VARIANCE_SE) ** 2) < 1e-16
+
+
 def test_actuator_golden(actuator):
     params, Y, c = actuator
     g = load_golden("actuator")
