@@ -87,6 +87,16 @@ def spawn_ranks(args):
     return rc
 
 
+def parallelism_text(world, collective, reduces):
+    """What the timed step does with the 8 partial sums -- must be TRUE for the run (tests/test_bench_contract.py)."""
+    if not reduces:
+        return "no collective (single rank: the 8 sums are copied to the host as they are)"
+    if collective == "rccl":
+        return ("one ncclAllReduce of 8 doubles issued by the library (ffvd_elbo_allreduce)"
+                + (", here on a 1-rank communicator so that N=1 times the same sequence as N>1" if world == 1 else ""))
+    return "8 partial sums all-reduced through torch.distributed/gloo (rehearsal or RCCL unavailable)"
+
+
 def cpu_baseline(params, Y, c, meta, sample_chains, workload):
     """Time the oracle (NumPy restatement, reference op order) on `sample_chains` chains; extrapolate to S."""
     import numpy as np
@@ -164,15 +174,21 @@ def run_rank(args):
         eng_kw["chains_per_pass"] = args.chains_per_pass
     collective = "torch" if rehearsal else "rccl"
     sh, err = None, None
+    # N = 1 times what N > 1 times: the single rank forms a 1-rank communicator and every step runs
+    # kernels -> finalize -> ncclAllReduce(8 doubles) -> copy back, exactly the sequence of ffvd_elbo_allreduce at N > 1.
+    # If no RCCL can be bound on a one-GPU box the step has no collective, and config.parallelism says so.
+    always = (world == 1 and not rehearsal)
     try:
         sh = ShardedElbo(params, Y, c, meta, rank=rank, world=world, mode=mode, device=local_rank, collective=collective,
-                         **eng_kw)
+                         always_reduce=always, **eng_kw)
     except Exception as exc:               # noqa: BLE001 -- reported below, never swallowed
         err = exc
+    exchange = None                        # what the timed step did with the 8 partial sums (config.parallelism)
     if dist is not None and not rehearsal:
         # The benchmark must say which exchange it timed.  If the library's own RCCL communicator cannot be formed on
         # EVERY rank (e.g. no librccl the process can bind), all ranks agree -- loudly, on stderr and in the JSON line -- to
         # carry the 8 sums through torch.distributed instead; a failure on some ranks only is an error.
+        # (exchange_unique_id delivers a failure of rank 0 to every rank, so this all-reduce lines up on all of them.)
         import torch
         ok = torch.tensor([0 if err else 1], dtype=torch.int32)
         dist.all_reduce(ok, op=dist.ReduceOp.SUM)
@@ -184,8 +200,16 @@ def run_rank(args):
                              collective=collective, **eng_kw)
         elif err is not None or int(ok.item()) != world:
             raise SystemExit(f"rank {rank}: RCCL communicator formed on {int(ok.item())} of {world} ranks only: {err}")
+    elif err is not None and always:
+        print(f"[bench] 1-rank RCCL communicator unavailable ({err}); the timed step has NO collective",
+              file=sys.stderr, flush=True)
+        exchange = f"no collective at N=1 (a 1-rank RCCL communicator could not be formed: {err})"
+        sh = ShardedElbo(params, Y, c, meta, rank=rank, world=world, mode=mode, device=local_rank, collective=collective,
+                         **eng_kw)
     elif err is not None:
         raise err
+    if exchange is None:
+        exchange = parallelism_text(world, collective, sh.reduces)
 
     def barrier():
         sh.engine.sync()
@@ -216,6 +240,15 @@ def run_rank(args):
         sums = sh.step()
     # (1) the headline region: exactly K steps, nothing but the steps inside
     elapsed, per_step, sums = timed(args.steps)
+    # (1b) N = 1 only: the same K steps WITHOUT the 1-rank collective (ffvd_elbo: one copy of the 8 sums), an extra key
+    plain_ms = None
+    if world == 1 and sh.reduces and not sh.time_shard:
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            sh.engine.elbo_sums()
+        barrier()
+        plain_ms = 1e3 * (time.perf_counter() - t0) / args.steps
     # (2) the same K steps again with HIP events recorded around every stage on the engine's stream (roofline numbers)
     sh.engine.stage_timing(True)
     elapsed_ev, _, _ = timed(args.steps)
@@ -266,10 +299,7 @@ def run_rank(args):
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.workload}: synthetic T={T} x_dim={D} C={meta['C']} M={M} S={S} {kname} "
                                    f"{'collapsed-U' if collapsed else 'explicit-U'}, seed {meta['seed']}",
-                       "parallelism": (f"{'chains' if mode == 'chains' else 'latent dims'} sharded over {world} GPU(s), "
-                                       + ("one ncclAllReduce of 8 doubles issued by the library (ffvd_elbo_allreduce)"
-                                          if collective == "rccl" else
-                                          "8 partial sums all-reduced through torch.distributed/gloo (rehearsal or RCCL unavailable)")),
+                       "parallelism": f"{'chains' if mode == 'chains' else 'latent dims'} sharded over {world} GPU(s), " + exchange,
                        "chains_per_gpu": s_local, "dims_per_gpu": d_local,
                        "arithmetic": ("fp64 throughout" if args.dtype == "f64" else
                                       "K_fu and the two T x M x M products in fp32 (v_mfma_f32_32x32x2_f32); every M x M "
@@ -277,6 +307,7 @@ def run_rank(args):
                        "route": ("gram: log|K_uu + K_uf K_fu/Q| - log|K_uu| (SURVEY Appendix A), flops counted as W_gram-style"
                                  if args.route == "gram" else "reference: F = K_fu L^-T, H = F^T F/Q + I")},
             "nll": terms["nll"],
+            "ms_per_step_without_collective": plain_ms,
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_source,
                          "avg_launch_ms": 1e3 * dur_s, "launches_timed": launches,

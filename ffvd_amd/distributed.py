@@ -98,20 +98,46 @@ def all_reduce_grads(grads, mode="chains", device=None, group=None):
     return out
 
 
-def exchange_unique_id(make_id, rank, world, rendezvous_dir=None, timeout_s=120.0):
+_RENDEZVOUS_GENERATION = [0]      # communicators this process has formed through a rendezvous directory
+
+
+def exchange_unique_id(make_id, rank, world, rendezvous_dir=None, timeout_s=120.0, tag=None):
     """Hand rank 0's 128-byte RCCL id (ffvd_comm_unique_id) to every rank.  Host-side plumbing only:
     with `rendezvous_dir` through a file (written atomically by rank 0, polled by the others), otherwise through the
-    initialised torch.distributed group (any backend; gloo in the launchers of this repo)."""
+    initialised torch.distributed group (any backend; gloo in the launchers of this repo).
+
+    A failure of `make_id` on rank 0 (librccl cannot be bound) is DELIVERED to every rank -- rank 0 still takes part in the
+    exchange and sends the error text instead of the id -- so that all ranks raise the same RuntimeError at the same
+    point and a caller's next collective (bench.py's "did every rank get a communicator" all-reduce) lines up.
+    File rendezvous: the file name carries `tag` (default: the count of communicators this process has formed, which is
+    the same on every rank of an SPMD program), so an id left behind by an earlier communicator or an earlier run with
+    another tag is never read; rank 0 removes its file's predecessor before writing."""
     if world == 1:
         return make_id()
+
+    def guarded():
+        try:
+            return bytes(make_id()), None
+        except Exception as exc:        # noqa: BLE001 -- forwarded to every rank below
+            return None, f"{type(exc).__name__}: {exc}"
+
     if rendezvous_dir:
         import time
-        path = os.path.join(rendezvous_dir, "rccl_unique_id")
+        if tag is None:
+            tag = _RENDEZVOUS_GENERATION[0]
+            _RENDEZVOUS_GENERATION[0] += 1
+        path = os.path.join(rendezvous_dir, f"rccl_unique_id.{tag}")
         if rank == 0:
-            blob = make_id()
+            blob, err = guarded()
+            try:
+                os.unlink(path)
+            except FileNotFoundError:
+                pass
             with open(path + ".tmp", "wb") as f:
-                f.write(blob)
+                f.write(b"OK" + blob if err is None else b"ER" + err.encode())
             os.replace(path + ".tmp", path)
+            if err is not None:
+                raise RuntimeError(f"RCCL unique id could not be created on rank 0: {err}")
             return blob
         t0 = time.monotonic()
         while not os.path.exists(path):
@@ -119,13 +145,19 @@ def exchange_unique_id(make_id, rank, world, rendezvous_dir=None, timeout_s=120.
                 raise TimeoutError(f"rank {rank}: no RCCL id at {path} after {timeout_s:.0f} s")
             time.sleep(0.01)
         with open(path, "rb") as f:
-            return f.read()
+            data = f.read()
+        if data[:2] != b"OK":
+            raise RuntimeError(f"RCCL unique id could not be created on rank 0: {data[2:].decode(errors='replace')}")
+        return data[2:]
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         raise RuntimeError("exchange_unique_id: pass rendezvous_dir or initialise torch.distributed first")
-    box = [make_id() if rank == 0 else None]
+    box = [guarded() if rank == 0 else None]
     dist.broadcast_object_list(box, src=0)
-    return box[0]
+    blob, err = box[0]
+    if err is not None:
+        raise RuntimeError(f"RCCL unique id could not be created on rank 0: {err}")
+    return blob
 
 
 class ShardedElbo:
@@ -139,7 +171,7 @@ class ShardedElbo:
     `torch.distributed.all_reduce` -- for groups RCCL cannot form (two test ranks sharing ONE GPU over gloo)."""
 
     def __init__(self, params, Y, control_inputs, meta, rank=0, world=1, mode="chains", device=0, always_reduce=False,
-                 collective="rccl", rendezvous_dir=None, **engine_kw):
+                 collective="rccl", rendezvous_dir=None, rendezvous_tag=None, **engine_kw):
         from .engine import ElboEngine
         if collective not in ("rccl", "torch"):
             raise ValueError("collective must be 'rccl' or 'torch'")
@@ -171,7 +203,7 @@ class ShardedElbo:
             self.engine.set_params(local)
         self.reduces = world > 1 or self.always_reduce or self.time_shard
         if self.reduces and collective == "rccl":
-            blob = exchange_unique_id(self.engine.comm_unique_id, rank, world, rendezvous_dir)
+            blob = exchange_unique_id(self.engine.comm_unique_id, rank, world, rendezvous_dir, tag=rendezvous_tag)
             self.engine.comm_init(world, rank, blob)
         elif self.reduces and not self.time_shard:
             import torch

@@ -20,6 +20,17 @@ def test_defaults_without_flags():
     assert bench.PEAK_TFLOPS == {"f64": 78.6, "f32c": 157.3}
 
 
+def test_parallelism_text_says_what_the_step_does():
+    """with one rank and no communicator the line must not claim an ncclAllReduce."""
+    import bench
+    assert "no collective" in bench.parallelism_text(1, "rccl", False) and "ncclAllReduce" not in bench.parallelism_text(1, "rccl", False)
+    t1 = bench.parallelism_text(1, "rccl", True)
+    assert "ncclAllReduce" in t1 and "1-rank communicator" in t1
+    t8 = bench.parallelism_text(8, "rccl", True)
+    assert "ncclAllReduce" in t8 and "1-rank" not in t8
+    assert "gloo" in bench.parallelism_text(2, "torch", True)
+
+
 REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
             "dtype", "data", "config", "roofline"]
 
@@ -56,6 +67,12 @@ def test_one_json_line_with_the_agreed_keys():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
     assert cb["kind"] == "port" and cb["value"] > 0.0
+    # the N = 1 line times the sequence N > 1 times: the 1-rank ncclAllReduce is inside the step (or the line says it is not)
+    par = d["config"]["parallelism"]
+    if "ncclAllReduce" in par:
+        assert "1-rank communicator" in par and d["ms_per_step_without_collective"] > 0.0
+    else:
+        assert "no collective" in par
 
 
 @pytest.mark.gpu

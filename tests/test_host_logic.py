@@ -216,3 +216,71 @@ def test_gloo_world2_gradient_all_reduce(tmp_path):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert "OK" in outs[0] and "OK" in outs[1]
+
+
+ID_WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["FFVD_ROOT"])
+import torch, torch.distributed as dist
+from ffvd_amd import distributed as dm
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+def broken():
+    raise RuntimeError("librccl.so could not be bound")
+# (1) make_id fails on rank 0: EVERY rank must raise the same error at the same point ...
+err = None
+try:
+    dm.exchange_unique_id(broken, rank, world)
+except RuntimeError as exc:
+    err = str(exc)
+assert err and "librccl.so could not be bound" in err, err
+# ... so that the caller's next collective lines up (bench.py: "did every rank get a communicator")
+ok = torch.tensor([0], dtype=torch.int32)
+dist.all_reduce(ok)
+assert int(ok.item()) == 0
+# (2) a working make_id reaches every rank unchanged
+blob = dm.exchange_unique_id(lambda: bytes(range(128)), rank, world)
+assert blob == bytes(range(128))
+print("OK")
+dist.destroy_process_group()
+'''
+
+
+def test_gloo_world2_failed_unique_id_reaches_every_rank(tmp_path):
+    """ADVICE r2: when rank 0 cannot create the RCCL id, the other ranks used to stay blocked in the broadcast while rank 0
+    moved on to the next collective.  Now the failure travels through the same broadcast."""
+    import subprocess
+    script = tmp_path / "idworker.py"
+    script.write_text(ID_WORKER)
+    env = dict(os.environ, FFVD_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29539", WORLD_SIZE="2", OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "OK" in outs[0] and "OK" in outs[1]
+
+
+def test_file_rendezvous_ignores_stale_ids_and_forwards_failures(tmp_path):
+    """File rendezvous of the RCCL id: the file name carries a tag (generation), a stale file of another tag is never read,
+    and a failure on rank 0 is written into the file so that the polling ranks raise instead of timing out."""
+    d = str(tmp_path)
+    with open(os.path.join(d, "rccl_unique_id"), "wb") as f:        # left behind by an older run / the old file name
+        f.write(b"stale")
+    with open(os.path.join(d, "rccl_unique_id.run7"), "wb") as f:   # an id of THIS tag from an earlier run: replaced by rank 0
+        f.write(b"OKold")
+    good = bytes(range(128))
+    assert dist_mod.exchange_unique_id(lambda: good, 0, 2, rendezvous_dir=d, tag="run7") == good
+    assert dist_mod.exchange_unique_id(None, 1, 2, rendezvous_dir=d, tag="run7") == good
+    with pytest.raises(TimeoutError):
+        dist_mod.exchange_unique_id(None, 1, 2, rendezvous_dir=d, tag="other", timeout_s=0.05)
+
+    def broken():
+        raise OSError("no librccl")
+    with pytest.raises(RuntimeError, match="no librccl"):
+        dist_mod.exchange_unique_id(broken, 0, 2, rendezvous_dir=d, tag="bad")
+    with pytest.raises(RuntimeError, match="no librccl"):
+        dist_mod.exchange_unique_id(None, 1, 2, rendezvous_dir=d, tag="bad")
+    # default tag: the count of communicators this process has formed through a directory
+    g0 = dist_mod._RENDEZVOUS_GENERATION[0]
+    dist_mod.exchange_unique_id(lambda: good, 0, 2, rendezvous_dir=d)
+    assert os.path.exists(os.path.join(d, f"rccl_unique_id.{g0}")) and dist_mod._RENDEZVOUS_GENERATION[0] == g0 + 1
