@@ -72,6 +72,19 @@ _SIGNATURES = {
     "ffvd_op_get_rand": (C.c_int, [_dp, _dp, _dp, C.c_int64, _dp]),
     "ffvd_adam_step": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_uint32, _dp,
                                  C.POINTER(C.c_double)]),
+    "ffvd_adam_step_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
+                                           C.c_uint32, _dp, C.POINTER(C.c_double)]),
+    "ffvd_sghmc_step_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_uint32, C.c_int,
+                                            C.c_void_p, _dp, C.POINTER(C.c_double)]),
+    "ffvd_train_local": (C.c_int, [C.c_void_p, C.c_int]),
+    "ffvd_train_exchange_count": (C.c_int64, [C.c_void_p]),
+    "ffvd_train_exchange_ptr": (C.c_void_p, [C.c_void_p]),
+    "ffvd_train_exchange_get": (C.c_int, [C.c_void_p, _dp]),
+    "ffvd_train_exchange_set": (C.c_int, [C.c_void_p, _dp]),
+    "ffvd_adam_apply": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_uint32, _dp,
+                                  C.POINTER(C.c_double)]),
+    "ffvd_sghmc_apply": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_uint32, C.c_int, C.c_void_p, _dp,
+                                   C.POINTER(C.c_double)]),
     "ffvd_get_stream": (C.c_void_p, [C.c_void_p]),
     "ffvd_optimizer_reset": (C.c_int, [C.c_void_p]),
     "ffvd_update_params": (C.c_int, [C.c_void_p, C.c_void_p]),

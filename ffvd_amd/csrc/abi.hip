@@ -91,6 +91,11 @@ struct ffvd_handle {
         double *Gu = nullptr, *Gsum = nullptr, *r = nullptr, *dalpha = nullptr, *ucol = nullptr, *beta = nullptr, *du = nullptr;
         double *GammaA = nullptr, *Lclean = nullptr, *dU = nullptr, *xsq = nullptr;
         int ngam = 0, sp_stride = 0;
+        // Exchange block of a sharded training step (ffvd_adam_step_allreduce): [8 term sums | dZ | dlogvar..dlogR | dU | dX],
+        // every segment starting on a 256-byte boundary.  The gradient arrays above ARE these segments, so the block is
+        // all-reduced in place with no packing pass; dX comes last because chain shards keep it out of the exchange.
+        double *pack = nullptr;
+        size_t pack_shared = 0, pack_total = 0;     // doubles up to (excluding) dX / including dX
     } gw;
     double *hterms = nullptr, *chain_terms = nullptr, *chain_nll = nullptr, *out_terms = nullptr;
     int32_t *info = nullptr;
@@ -106,8 +111,9 @@ struct ffvd_handle {
     // h_chain / h_info point into the two blocks
     double *resblk = nullptr, *h_res = nullptr;
     size_t res_bytes = 0;
-    double *h_out = nullptr, *h_chain = nullptr;
+    double *h_out = nullptr, *h_chain = nullptr, *h_sums = nullptr;
     int32_t *h_info = nullptr;
+    int train_S_total = 0;      // > 0: ffvd_train_local has left a backward pass (scaled 1 / S_total) in gw.pack
     // optional live stage timing (HIP events on the handle's stream)
     bool timing_on = false;
     std::vector<hipEvent_t> ev_pool;
@@ -296,11 +302,17 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
         HIP_TRY(dev_alloc(h, &g.rx22, Dl * nblk2 * P));
         HIP_TRY(dev_alloc(h, &g.dz_kuu, Dl * c.M * P)); HIP_TRY(dev_alloc(h, &g.dll_kuu, Dl * P)); HIP_TRY(dev_alloc(h, &g.dls_kuu, Dl));
         HIP_TRY(dev_alloc(h, &g.shared_part, S * g.sp_stride));
-        HIP_TRY(dev_alloc(h, &g.dX, S * (c.T + 1) * c.D));
-        HIP_TRY(dev_alloc(h, &g.dZ, (size_t)c.M * P));
-        {   // the six small shared-parameter gradients in ONE block: one fill per backward pass instead of six memsets
+        {   // every parameter gradient lives in ONE block (see GradWs::pack); the six small shared-parameter gradients are
+            // contiguous inside it: one fill per backward pass instead of six memsets
+            auto seg = [](size_t n) { return (n + 31) / 32 * 32; };
             g.small_count = (size_t)c.D + (size_t)c.D * P + (size_t)c.D + (size_t)c.D * J + J + J * J;
-            HIP_TRY(dev_alloc(h, &g.dlogvar, g.small_count));
+            const size_t nZ = (size_t)c.M * P, nU = grad_a ? (size_t)c.M * c.D : 0, nX = S * (c.T + 1) * c.D;
+            const size_t oZ = seg(8), oS = oZ + seg(nZ), oU = oS + seg(g.small_count), oX = oU + seg(nU);
+            g.pack_shared = oX; g.pack_total = oX + seg(nX);
+            HIP_TRY(dev_alloc(h, &g.pack, g.pack_total));
+            HIP_TRY(hipMemsetAsync(g.pack, 0, g.pack_total * sizeof(double), h->stream));     // the padding stays zero
+            g.dZ = g.pack + oZ; g.dlogvar = g.pack + oS; g.dX = g.pack + oX;
+            if (grad_a) g.dU = g.pack + oU;
             g.dloglen = g.dlogvar + c.D; g.dlogQ = g.dloglen + (size_t)c.D * P; g.dCC = g.dlogQ + c.D;
             g.dDD = g.dCC + (size_t)c.D * J; g.dlogR = g.dDD + J;
         }
@@ -310,7 +322,7 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
             HIP_TRY(dev_alloc(h, &g.xsq, nbt));
             HIP_TRY(dev_alloc(h, &g.ucol, Dl * Mp));              HIP_TRY(dev_alloc(h, &g.beta, Dl * Mp));
             HIP_TRY(dev_alloc(h, &g.du, Dl * Mp));                HIP_TRY(dev_alloc(h, &g.GammaA, Dl * msq));
-            HIP_TRY(dev_alloc(h, &g.Lclean, Dl * msq));           HIP_TRY(dev_alloc(h, &g.dU, (size_t)c.M * c.D));
+            HIP_TRY(dev_alloc(h, &g.Lclean, Dl * msq));           // (g.dU: a segment of g.pack)
         }
     }
     HIP_TRY(dev_alloc(h, &h->hterms, (size_t)h->nbatch * 2));
@@ -331,7 +343,8 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
         h->out_terms = h->resblk;
         h->chain_nll = h->resblk + 8;
         h->info = reinterpret_cast<int32_t *>(h->resblk + 8 + nS);
-        HIP_TRY(hipHostMalloc((void **)&h->h_res, h->res_bytes));
+        HIP_TRY(hipHostMalloc((void **)&h->h_res, h->res_bytes + 8 * sizeof(double)));
+        h->h_sums = h->h_res + ndbl;                 // whole-job sums of a sharded training step (behind the result block)
         h->h_out = h->h_res;
         h->h_chain = h->h_res + 8;
         h->h_info = reinterpret_cast<int32_t *>(h->h_res + 8 + nS);
@@ -1276,12 +1289,19 @@ extern "C" int ffvd_optimizer_reset(ffvd_handle *h) {
     return FFVD_OK;
 }
 
+static int adam_update(ffvd_handle *h, double lr, double beta1, double beta2, double eps, uint32_t train_mask);
+static int sghmc_prepare(ffvd_handle *h, uint32_t sample_mask, const ffvd_params *noise, const char *who);
+static int sghmc_update(ffvd_handle *h, double epsilon, double mdecay, uint32_t sample_mask, int burn_in);
+
 extern "C" int ffvd_adam_step(ffvd_handle *h, double lr, double beta1, double beta2, double eps, uint32_t train_mask,
                               double out_terms[8], double *out_nll) {
     if (!h) return set_error(nullptr, FFVD_EINVAL, "ffvd_adam_step: null handle");
     if (!h->cfg.grad) return set_error(h, FFVD_EINVAL, "ffvd_adam_step: the handle was created without grad = 1");
     if (h->Dl != h->cfg.D)
-        return set_error(h, FFVD_EINVAL, "ffvd_adam_step: a latent-dim shard holds partial gradients; all-reduce them and use ffvd_op_adam_step");
+        return set_error(h, FFVD_EINVAL, "ffvd_adam_step: a latent-dim shard holds partial gradients; use ffvd_adam_step_allreduce");
+    if (h->comm_world > 1)
+        return set_error(h, FFVD_EINVAL, "ffvd_adam_step: this handle is one rank of a multi-rank communicator, its gradient is a share of "
+                                         "the job's; use ffvd_adam_step_allreduce");
     if (!(lr > 0.0) || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0) || !(eps >= 0.0))
         return set_error(h, FFVD_EINVAL, "ffvd_adam_step: bad hyper-parameter");
     HIP_TRY(hipSetDevice(h->cfg.device_id));
@@ -1294,18 +1314,7 @@ extern "C" int ffvd_adam_step(ffvd_handle *h, double lr, double beta1, double be
     HIP_TRY(hipMemcpyAsync(h->h_res, h->resblk, h->res_bytes, hipMemcpyDeviceToHost, s));      // terms, chain nll, info flags
     HIP_TRY(hipStreamSynchronize(s));
     if ((rc = check_info(h))) return rc;           // a failed factorisation leaves the parameters untouched
-    double *theta[NPARAM]; const double *grad[NPARAM]; size_t n[NPARAM];
-    param_table(h, theta, grad, n);
-    OptTable tab{};
-    for (int i = 0; i < NPARAM; ++i) {
-        if (!(train_mask & (1u << i)) || n[i] == 0) continue;
-        OptTensor &t = tab.t[tab.count++];
-        t.theta = theta[i]; t.grad = grad[i]; t.s0 = h->adam_m[i]; t.s1 = h->adam_v[i]; t.n = (int64_t)n[i];
-    }
-    h->adam_t += 1;
-    const double lr_t = lr * sqrt(1.0 - pow(beta2, (double)h->adam_t)) / (1.0 - pow(beta1, (double)h->adam_t));
-    launch_adam(s, tab, lr_t, beta1, beta2, eps);
-    HIP_TRY(hipGetLastError());
+    if ((rc = adam_update(h, lr, beta1, beta2, eps, train_mask))) return rc;
     if (out_terms) memcpy(out_terms, h->h_out, 8 * sizeof(double));
     if (out_nll) *out_nll = h->h_out[FFVD_TERM_NLL] / (double)h->cfg.S_local;
     return FFVD_OK;
@@ -1355,7 +1364,10 @@ extern "C" int ffvd_sghmc_step(ffvd_handle *h, double epsilon, double mdecay, ui
     if (!h) return set_error(nullptr, FFVD_EINVAL, "ffvd_sghmc_step: null handle");
     if (!h->cfg.grad) return set_error(h, FFVD_EINVAL, "ffvd_sghmc_step: the handle was created without grad = 1");
     if (h->Dl != h->cfg.D)
-        return set_error(h, FFVD_EINVAL, "ffvd_sghmc_step: a latent-dim shard holds partial gradients; use ffvd_op_sghmc_step");
+        return set_error(h, FFVD_EINVAL, "ffvd_sghmc_step: a latent-dim shard holds partial gradients; use ffvd_sghmc_step_allreduce");
+    if (h->comm_world > 1)
+        return set_error(h, FFVD_EINVAL, "ffvd_sghmc_step: this handle is one rank of a multi-rank communicator, its gradient is a share of "
+                                         "the job's; use ffvd_sghmc_step_allreduce");
     if (!noise || !(epsilon > 0.0) || !(mdecay >= 0.0))
         return set_error(h, FFVD_EINVAL, "ffvd_sghmc_step: bad argument");
     if (sample_mask & FFVD_TRAIN_X)
@@ -1363,14 +1375,145 @@ extern "C" int ffvd_sghmc_step(ffvd_handle *h, double epsilon, double mdecay, ui
     HIP_TRY(hipSetDevice(h->cfg.device_id));
     int rc;
     if ((rc = ready(h, "ffvd_sghmc_step"))) return rc;
+    hipStream_t s = h->stream;
+    if ((rc = sghmc_prepare(h, sample_mask, noise, "ffvd_sghmc_step"))) return rc;
+    if ((rc = enqueue_elbo(h, nullptr, nullptr))) return rc;
+    if ((rc = enqueue_grad(h, h->cfg.S_local))) return rc;
+    HIP_TRY(hipMemcpyAsync(h->h_res, h->resblk, h->res_bytes, hipMemcpyDeviceToHost, s));      // terms, chain nll, info flags
+    HIP_TRY(hipStreamSynchronize(s));
+    if ((rc = check_info(h))) return rc;
+    if ((rc = sghmc_update(h, epsilon, mdecay, sample_mask, burn_in))) return rc;
+    if (out_terms) memcpy(out_terms, h->h_out, 8 * sizeof(double));
+    if (out_nll) *out_nll = h->h_out[FFVD_TERM_NLL] / (double)h->cfg.S_local;
+    return FFVD_OK;
+}
+
+// ---- sharded, device-resident training step (multi-GPU counterpart of adam.minimize(nll), dgp_model.py:303-305 /
+// train_hypers, base_model.py:944-950, and of one burn_in_op / sample_op, base_model.py:143-179) ---------------------------
+// Every rank: forward + backward with the whole job's chain count as the divisor, so that its gradient block is its ADDITIVE
+// share; ONE all-reduce(sum) of [8 term sums | shared-parameter gradients (| dX for latent-dim shards)] in place in HBM;
+// then the fused update from the reduced block.  No gradient crosses PCIe; the only host traffic is the result block.
+static int train_local(ffvd_handle *h, int S_total, const char *who) {
+    if (!h->cfg.grad) return set_error(h, FFVD_EINVAL, std::string(who) + ": the handle was created without grad = 1");
+    if (S_total < h->cfg.S_local) return set_error(h, FFVD_EINVAL, std::string(who) + ": S_total < S_local");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    int rc;
+    if ((rc = ready(h, who))) return rc;
+    h->train_S_total = 0;
+    if ((rc = enqueue_elbo(h, nullptr, nullptr))) return rc;
+    if ((rc = enqueue_grad(h, S_total))) return rc;
+    HIP_TRY(hipMemcpyAsync(h->gw.pack, h->out_terms, 8 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    h->train_S_total = S_total;
+    return FFVD_OK;
+}
+
+// doubles of the block that take part in the exchange: chain shards keep dX (their own chains' rows) out of it
+static size_t train_exchange_count(const ffvd_handle *h) {
+    return (h->Dl != h->cfg.D) ? h->gw.pack_total : h->gw.pack_shared;
+}
+
+// result block + the (reduced) sums to the host, one synchronisation; a failed factorisation anywhere leaves the parameters as they are
+static int train_fetch(ffvd_handle *h, const char *who) {
+    if (h->train_S_total <= 0) return set_error(h, FFVD_EINVAL, std::string(who) + ": no pending backward pass (ffvd_train_local first)");
+    hipStream_t s = h->stream;
+    HIP_TRY(hipMemcpyAsync(h->h_res, h->resblk, h->res_bytes, hipMemcpyDeviceToHost, s));      // this rank's chain nll + info flags
+    HIP_TRY(hipMemcpyAsync(h->h_sums, h->gw.pack, 8 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    h->train_S_total = 0;
+    int rc;
+    if ((rc = check_info(h))) return rc;
+    for (int i = 0; i < 8; ++i)
+        if (!std::isfinite(h->h_sums[i]))
+            return set_error(h, FFVD_ENOTPD, std::string(who) + ": non-finite sums after the exchange (a factorisation failed on another rank); parameters untouched");
+    return FFVD_OK;
+}
+
+static void train_report(ffvd_handle *h, double out_terms[8], double *out_nll) {
+    if (out_terms) memcpy(out_terms, h->h_sums, 8 * sizeof(double));
+    if (out_nll) *out_nll = h->h_sums[FFVD_TERM_NLL] / h->h_sums[FFVD_TERM_COUNT];
+}
+
+static int adam_update(ffvd_handle *h, double lr, double beta1, double beta2, double eps, uint32_t train_mask) {
+    double *theta[NPARAM]; const double *grad[NPARAM]; size_t n[NPARAM];
+    param_table(h, theta, grad, n);
+    OptTable tab{};
+    for (int i = 0; i < NPARAM; ++i) {
+        if (!(train_mask & (1u << i)) || n[i] == 0) continue;
+        OptTensor &t = tab.t[tab.count++];
+        t.theta = theta[i]; t.grad = grad[i]; t.s0 = h->adam_m[i]; t.s1 = h->adam_v[i]; t.n = (int64_t)n[i];
+    }
+    h->adam_t += 1;
+    const double lr_t = lr * sqrt(1.0 - pow(beta2, (double)h->adam_t)) / (1.0 - pow(beta1, (double)h->adam_t));
+    launch_adam(h->stream, tab, lr_t, beta1, beta2, eps);
+    HIP_TRY(hipGetLastError());
+    return FFVD_OK;
+}
+
+extern "C" int ffvd_train_local(ffvd_handle *h, int S_total) {
+    if (!h) return set_error(nullptr, FFVD_EINVAL, "ffvd_train_local: null handle");
+    return train_local(h, S_total, "ffvd_train_local");
+}
+
+extern "C" int64_t ffvd_train_exchange_count(const ffvd_handle *h) { return (h && h->cfg.grad) ? (int64_t)train_exchange_count(h) : 0; }
+
+extern "C" void *ffvd_train_exchange_ptr(ffvd_handle *h) { return (h && h->cfg.grad) ? (void *)h->gw.pack : nullptr; }
+
+extern "C" int ffvd_train_exchange_get(ffvd_handle *h, double *host_out) {
+    if (!h || !host_out || !h->cfg.grad) return set_error(h, FFVD_EINVAL, "ffvd_train_exchange_get: bad argument");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    HIP_TRY(hipMemcpyAsync(host_out, h->gw.pack, train_exchange_count(h) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return FFVD_OK;
+}
+
+extern "C" int ffvd_train_exchange_set(ffvd_handle *h, const double *host_in) {
+    if (!h || !host_in || !h->cfg.grad) return set_error(h, FFVD_EINVAL, "ffvd_train_exchange_set: bad argument");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    HIP_TRY(hipMemcpyAsync(h->gw.pack, host_in, train_exchange_count(h) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));          // the host array is the caller's
+    return FFVD_OK;
+}
+
+extern "C" int ffvd_adam_apply(ffvd_handle *h, double lr, double beta1, double beta2, double eps, uint32_t train_mask,
+                               double out_terms[8], double *out_nll) {
+    if (!h) return set_error(nullptr, FFVD_EINVAL, "ffvd_adam_apply: null handle");
+    if (!h->cfg.grad) return set_error(h, FFVD_EINVAL, "ffvd_adam_apply: the handle was created without grad = 1");
+    if (!(lr > 0.0) || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0) || !(eps >= 0.0))
+        return set_error(h, FFVD_EINVAL, "ffvd_adam_apply: bad hyper-parameter");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    int rc;
+    if (!h->adam_ready && (rc = ffvd_optimizer_reset(h))) return rc;
+    if ((rc = train_fetch(h, "ffvd_adam_apply"))) return rc;
+    if ((rc = adam_update(h, lr, beta1, beta2, eps, train_mask))) return rc;
+    train_report(h, out_terms, out_nll);
+    return FFVD_OK;
+}
+
+extern "C" int ffvd_adam_step_allreduce(ffvd_handle *h, void *rccl_comm, int S_total, double lr, double beta1, double beta2,
+                                        double eps, uint32_t train_mask, double out_terms[8], double *out_nll) {
+    if (!h) return set_error(nullptr, FFVD_EINVAL, "ffvd_adam_step_allreduce: null handle");
+    if (!(lr > 0.0) || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0) || !(eps >= 0.0))
+        return set_error(h, FFVD_EINVAL, "ffvd_adam_step_allreduce: bad hyper-parameter");
+    if (!rccl_comm && !h->comm)
+        return set_error(h, FFVD_EINVAL, "ffvd_adam_step_allreduce: no communicator (pass one or call ffvd_comm_init)");
+    int rc;
+    if (h->cfg.grad && !h->adam_ready && (rc = ffvd_optimizer_reset(h))) return rc;
+    if ((rc = train_local(h, S_total, "ffvd_adam_step_allreduce"))) return rc;
+    if ((rc = ffvd_allreduce_sum_async(h, rccl_comm, h->gw.pack, (int64_t)train_exchange_count(h)))) { h->train_S_total = 0; return rc; }
+    if ((rc = train_fetch(h, "ffvd_adam_step_allreduce"))) return rc;
+    if ((rc = adam_update(h, lr, beta1, beta2, eps, train_mask))) return rc;
+    train_report(h, out_terms, out_nll);
+    return FFVD_OK;
+}
+
+static int sghmc_prepare(ffvd_handle *h, uint32_t sample_mask, const ffvd_params *noise, const char *who) {
     double *theta[NPARAM]; const double *grad[NPARAM]; size_t n[NPARAM];
     param_table(h, theta, grad, n);
     const double *nz[NPARAM] = {noise->X, noise->Z, noise->logvariance, noise->loglengthscales, noise->log_Q, noise->CC,
                                 noise->DD, noise->log_Rchols, noise->U};
-    hipStream_t s = h->stream;
     for (int i = 1; i < NPARAM; ++i) {
         if (!(sample_mask & (1u << i)) || n[i] == 0) continue;
-        if (!nz[i]) return set_error(h, FFVD_EINVAL, "ffvd_sghmc_step: a sampled array has no noise array");
+        if (!nz[i]) return set_error(h, FFVD_EINVAL, std::string(who) + ": a sampled array has no noise array");
         if (!h->hmc[i][0]) {            // xi, g, g2 <- 1, p <- 0 (base_model.py:151-154)
             std::vector<double> ones(n[i], 1.0);
             for (int k = 0; k < 5; ++k) HIP_TRY(dev_alloc(h, &h->hmc[i][k], n[i]));
@@ -1378,13 +1521,14 @@ extern "C" int ffvd_sghmc_step(ffvd_handle *h, double epsilon, double mdecay, ui
                 HIP_TRY(hipMemcpy(h->hmc[i][k], ones.data(), n[i] * sizeof(double), hipMemcpyHostToDevice));
             HIP_TRY(hipMemset(h->hmc[i][3], 0, n[i] * sizeof(double)));
         }
-        HIP_TRY(hipMemcpyAsync(h->hmc[i][4], nz[i], n[i] * sizeof(double), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(h->hmc[i][4], nz[i], n[i] * sizeof(double), hipMemcpyHostToDevice, h->stream));
     }
-    if ((rc = enqueue_elbo(h, nullptr, nullptr))) return rc;
-    if ((rc = enqueue_grad(h, h->cfg.S_local))) return rc;
-    HIP_TRY(hipMemcpyAsync(h->h_res, h->resblk, h->res_bytes, hipMemcpyDeviceToHost, s));      // terms, chain nll, info flags
-    HIP_TRY(hipStreamSynchronize(s));
-    if ((rc = check_info(h))) return rc;
+    return FFVD_OK;
+}
+
+static int sghmc_update(ffvd_handle *h, double epsilon, double mdecay, uint32_t sample_mask, int burn_in) {
+    double *theta[NPARAM]; const double *grad[NPARAM]; size_t n[NPARAM];
+    param_table(h, theta, grad, n);
     OptTable tab{};
     for (int i = 1; i < NPARAM; ++i) {
         if (!(sample_mask & (1u << i)) || n[i] == 0) continue;
@@ -1392,11 +1536,46 @@ extern "C" int ffvd_sghmc_step(ffvd_handle *h, double epsilon, double mdecay, ui
         t.theta = theta[i]; t.grad = grad[i]; t.s0 = h->hmc[i][0]; t.s1 = h->hmc[i][1]; t.s2 = h->hmc[i][2];
         t.s3 = h->hmc[i][3]; t.noise = h->hmc[i][4]; t.n = (int64_t)n[i];
     }
-    launch_sghmc(s, tab, epsilon, mdecay, (double)(h->cfg.T + 1), burn_in);      // X_N = rows of X (dgp_model.py:203)
+    launch_sghmc(h->stream, tab, epsilon, mdecay, (double)(h->cfg.T + 1), burn_in);      // X_N = rows of X (dgp_model.py:203)
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(s));                   // the noise arrays are the caller's: done with them on return
-    if (out_terms) memcpy(out_terms, h->h_out, 8 * sizeof(double));
-    if (out_nll) *out_nll = h->h_out[FFVD_TERM_NLL] / (double)h->cfg.S_local;
+    HIP_TRY(hipStreamSynchronize(h->stream));           // the noise arrays are the caller's: done with them on return
+    return FFVD_OK;
+}
+
+extern "C" int ffvd_sghmc_step_allreduce(ffvd_handle *h, void *rccl_comm, int S_total, double epsilon, double mdecay,
+                                         uint32_t sample_mask, int burn_in, const ffvd_params *noise, double out_terms[8],
+                                         double *out_nll) {
+    if (!h) return set_error(nullptr, FFVD_EINVAL, "ffvd_sghmc_step_allreduce: null handle");
+    if (!h->cfg.grad) return set_error(h, FFVD_EINVAL, "ffvd_sghmc_step_allreduce: the handle was created without grad = 1");
+    if (!noise || !(epsilon > 0.0) || !(mdecay >= 0.0)) return set_error(h, FFVD_EINVAL, "ffvd_sghmc_step_allreduce: bad argument");
+    if (sample_mask & FFVD_TRAIN_X)
+        return set_error(h, FFVD_EINVAL, "ffvd_sghmc_step_allreduce: X is never an SG-HMC variable (dgp_model.py:213-244)");
+    if (!rccl_comm && !h->comm)
+        return set_error(h, FFVD_EINVAL, "ffvd_sghmc_step_allreduce: no communicator (pass one or call ffvd_comm_init)");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    int rc;
+    if ((rc = ready(h, "ffvd_sghmc_step_allreduce"))) return rc;
+    if ((rc = sghmc_prepare(h, sample_mask, noise, "ffvd_sghmc_step_allreduce"))) return rc;
+    if ((rc = train_local(h, S_total, "ffvd_sghmc_step_allreduce"))) return rc;
+    if ((rc = ffvd_allreduce_sum_async(h, rccl_comm, h->gw.pack, (int64_t)train_exchange_count(h)))) { h->train_S_total = 0; return rc; }
+    if ((rc = train_fetch(h, "ffvd_sghmc_step_allreduce"))) return rc;
+    if ((rc = sghmc_update(h, epsilon, mdecay, sample_mask, burn_in))) return rc;
+    train_report(h, out_terms, out_nll);
+    return FFVD_OK;
+}
+
+extern "C" int ffvd_sghmc_apply(ffvd_handle *h, double epsilon, double mdecay, uint32_t sample_mask, int burn_in,
+                                const ffvd_params *noise, double out_terms[8], double *out_nll) {
+    if (!h) return set_error(nullptr, FFVD_EINVAL, "ffvd_sghmc_apply: null handle");
+    if (!h->cfg.grad) return set_error(h, FFVD_EINVAL, "ffvd_sghmc_apply: the handle was created without grad = 1");
+    if (!noise || !(epsilon > 0.0) || !(mdecay >= 0.0)) return set_error(h, FFVD_EINVAL, "ffvd_sghmc_apply: bad argument");
+    if (sample_mask & FFVD_TRAIN_X) return set_error(h, FFVD_EINVAL, "ffvd_sghmc_apply: X is never an SG-HMC variable (dgp_model.py:213-244)");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    int rc;
+    if ((rc = sghmc_prepare(h, sample_mask, noise, "ffvd_sghmc_apply"))) return rc;
+    if ((rc = train_fetch(h, "ffvd_sghmc_apply"))) return rc;
+    if ((rc = sghmc_update(h, epsilon, mdecay, sample_mask, burn_in))) return rc;
+    train_report(h, out_terms, out_nll);
     return FFVD_OK;
 }
 

@@ -202,6 +202,7 @@ class ShardedElbo:
             local["X"] = np.ascontiguousarray(params["X"][pl["s_begin"]: pl["s_begin"] + pl["s_count"]])
             self.engine.set_params(local)
         self.reduces = world > 1 or self.always_reduce or self.time_shard
+        self.engine.shard_of = world          # plain ElboEngine.adam_step would train on this rank's share only
         if self.reduces and collective == "rccl":
             blob = exchange_unique_id(self.engine.comm_unique_id, rank, world, rendezvous_dir, tag=rendezvous_tag)
             self.engine.comm_init(world, rank, blob)
@@ -270,3 +271,42 @@ class ShardedElbo:
         all_reduce_sums(self.sums)
         g = all_reduce_grads(g, self.mode, device=self.sums.device)
         return finish(self.sums.cpu().numpy()), g
+
+    # -- device-resident sharded training (dgp_model.py:303-305, base_model.py:944-950 / :143-179 across ranks) -----------
+    def _host_reduce(self, block):
+        import torch
+        t = torch.from_numpy(block)
+        all_reduce_sums(t)
+        return t.numpy()
+
+    def adam_step(self, lr, beta1=0.9, beta2=0.999, eps=1e-8, train=None):
+        """One Adam step of the WHOLE job: every rank's forward + backward, ONE all-reduce of the gradient block
+        [8 sums | shared-parameter gradients (| dX for latent-dim shards)], fused update on the device.  With the native
+        collective nothing but the 8 sums reaches the host; groups RCCL cannot form (collective="torch": two test ranks on
+        one GPU) carry the block through torch.distributed.  Returns the whole-job terms before the update."""
+        if self.time_shard:
+            raise ValueError("T-shard handles have no backward pass")
+        S = self.meta["S"]
+        if not self.reduces:
+            self.engine.shard_of = 1
+            try:
+                t = self.engine.adam_step(lr, beta1, beta2, eps, train)
+            finally:
+                self.engine.shard_of = self.world
+            return {k: v for k, v in t.items()}
+        if self.collective == "rccl":
+            return finish(self.engine.adam_step_allreduce(S, lr, beta1, beta2, eps, train))
+        block = self._host_reduce(self.engine.train_local(S))
+        return finish(self.engine.adam_apply(block, lr, beta1, beta2, eps, train))
+
+    def sghmc_step(self, noise, epsilon=0.01, mdecay=0.05, burn_in=True):
+        """One burn_in_op / sample_op of the whole job; `noise` must be identical on every rank."""
+        if self.time_shard:
+            raise ValueError("T-shard handles have no backward pass")
+        S = self.meta["S"]
+        if not self.reduces:
+            return self.engine.sghmc_step(noise, epsilon, mdecay, burn_in)
+        if self.collective == "rccl":
+            return finish(self.engine.sghmc_step_allreduce(S, noise, epsilon, mdecay, burn_in))
+        block = self._host_reduce(self.engine.train_local(S))
+        return finish(self.engine.sghmc_apply(block, noise, epsilon, mdecay, burn_in))

@@ -193,6 +193,8 @@ class ElboEngine:
         nll terms of the parameters BEFORE the update.  Needs grad=True and set_params() first."""
         if not self.grad:
             raise ValueError("engine was created without grad=True")
+        if getattr(self, "shard_of", 1) > 1:
+            raise ValueError("adam_step: this engine holds one shard of a multi-rank job; use ShardedElbo.adam_step")
         mask = _lib.TRAIN_ALL if train is None else sum(_lib.TRAIN_BITS[k] for k in train)
         out = np.zeros(8)
         nll = ct.c_double()
@@ -222,6 +224,71 @@ class ElboEngine:
                                             ct.byref(ps), _lib.dptr(out), ct.byref(nll)), self._h, "ffvd_sghmc_step")
         idx = {n: i for i, n in enumerate(_lib.TERM_NAMES)}
         return {n: float(out[idx[n]] / self.S) for n in _lib.TERM_NAMES}
+
+    # -- sharded, device-resident training steps (include/ffvd_abi.h "sharded training step") -------------------
+    def _noise_struct(self, noise, who):
+        shapes = {"Z": (self.M, self.P), "logvariance": (self.D,), "loglengthscales": (self.D, self.P),
+                  "log_Q": (self.D,), "CC": (self.D, self.Ydim), "DD": (self.Ydim,), "log_Rchols": (self.Ydim, self.Ydim),
+                  "U": (self.M, self.D)}
+        arrs, mask = {}, 0
+        for k, v in noise.items():
+            if k not in shapes:
+                raise ValueError(f"{who}: '{k}' cannot be an SG-HMC variable")
+            arrs[k] = _lib.as_f64(v, shapes[k], f"noise[{k}]")
+            mask |= _lib.TRAIN_BITS[k]
+        return _lib.FfvdParams(**{k: v.ctypes.data for k, v in arrs.items()}), mask, arrs
+
+    def adam_step_allreduce(self, S_total, lr, beta1=0.9, beta2=0.999, eps=1e-8, train=None, comm=None):
+        """One sharded `train_hypers` iteration: this rank's forward + backward (divisor S_total), ONE ncclAllReduce of the
+        gradient block in HBM, fused Adam update from the reduced block.  Returns the whole-job 8 sums (before the update)."""
+        mask = _lib.TRAIN_ALL if train is None else sum(_lib.TRAIN_BITS[k] for k in train)
+        out = np.zeros(8)
+        nll = ct.c_double()
+        _lib.check(self.lib.ffvd_adam_step_allreduce(self._h, comm, int(S_total), float(lr), float(beta1), float(beta2), float(eps),
+                                                     int(mask), _lib.dptr(out), ct.byref(nll)), self._h, "ffvd_adam_step_allreduce")
+        return out
+
+    def sghmc_step_allreduce(self, S_total, noise, epsilon=0.01, mdecay=0.05, burn_in=True, comm=None):
+        """One sharded burn_in_op / sample_op; `noise` must be the same on every rank.  Returns the whole-job 8 sums."""
+        ps, mask, keep = self._noise_struct(noise, "sghmc_step_allreduce")
+        out = np.zeros(8)
+        nll = ct.c_double()
+        _lib.check(self.lib.ffvd_sghmc_step_allreduce(self._h, comm, int(S_total), float(epsilon), float(mdecay), int(mask),
+                                                      int(bool(burn_in)), ct.byref(ps), _lib.dptr(out), ct.byref(nll)),
+                   self._h, "ffvd_sghmc_step_allreduce")
+        del keep
+        return out
+
+    def train_local(self, S_total):
+        """Three-step form, step 1: forward + backward (divisor S_total); returns the exchange block as a host array."""
+        _lib.check(self.lib.ffvd_train_local(self._h, int(S_total)), self._h, "ffvd_train_local")
+        buf = np.zeros(int(self.lib.ffvd_train_exchange_count(self._h)))
+        _lib.check(self.lib.ffvd_train_exchange_get(self._h, _lib.dptr(buf)), self._h, "ffvd_train_exchange_get")
+        return buf
+
+    def _train_set(self, reduced):
+        r = _lib.as_f64(reduced, (int(self.lib.ffvd_train_exchange_count(self._h)),), "reduced")
+        _lib.check(self.lib.ffvd_train_exchange_set(self._h, _lib.dptr(r)), self._h, "ffvd_train_exchange_set")
+
+    def adam_apply(self, reduced, lr, beta1=0.9, beta2=0.999, eps=1e-8, train=None):
+        """Three-step form, steps 2-3: upload the all-reduced block, then the Adam update from it.  Returns the 8 sums."""
+        self._train_set(reduced)
+        mask = _lib.TRAIN_ALL if train is None else sum(_lib.TRAIN_BITS[k] for k in train)
+        out = np.zeros(8)
+        nll = ct.c_double()
+        _lib.check(self.lib.ffvd_adam_apply(self._h, float(lr), float(beta1), float(beta2), float(eps), int(mask),
+                                            _lib.dptr(out), ct.byref(nll)), self._h, "ffvd_adam_apply")
+        return out
+
+    def sghmc_apply(self, reduced, noise, epsilon=0.01, mdecay=0.05, burn_in=True):
+        self._train_set(reduced)
+        ps, mask, keep = self._noise_struct(noise, "sghmc_apply")
+        out = np.zeros(8)
+        nll = ct.c_double()
+        _lib.check(self.lib.ffvd_sghmc_apply(self._h, float(epsilon), float(mdecay), int(mask), int(bool(burn_in)), ct.byref(ps),
+                                             _lib.dptr(out), ct.byref(nll)), self._h, "ffvd_sghmc_apply")
+        del keep
+        return out
 
     def update_params(self, arrays):
         """Overwrite some resident parameter arrays (dict name -> array); the others keep their device values."""

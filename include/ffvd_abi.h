@@ -168,7 +168,8 @@ int  ffvd_elbo_grad(ffvd_handle *h, const ffvd_params *p, uint32_t flags, int S_
  * vendored by the reference -- the published rule is  lr_t = lr sqrt(1-b2^t)/(1-b1^t),  m = b1 m + (1-b1) g,
  * v = b2 v + (1-b2) g^2,  theta -= lr_t m / (sqrt(v) + eps);  TF defaults b1 = 0.9, b2 = 0.999, eps = 1e-8;
  * lr = 0.003 * 0.95^(1/1000), base_model.py:190) applied in one fused launch to the arrays selected by train_mask.
- * out_terms / out_nll describe the parameters BEFORE the update.  Needs grad = 1 and all latent dims on the handle;
+ * out_terms / out_nll describe the parameters BEFORE the update.  Needs grad = 1, all latent dims on the handle and a handle
+ * that is not one rank of a multi-rank communicator (those use ffvd_adam_step_allreduce below);
  * a failed factorisation returns FFVD_ENOTPD and leaves the parameters untouched.  The handle keeps m, v and t;
  * ffvd_optimizer_reset zeroes them.  ffvd_get_params copies the resident parameters to host arrays (NULL = skip). */
 #define FFVD_TRAIN_X 1u
@@ -195,6 +196,40 @@ int  ffvd_update_params(ffvd_handle *h, const ffvd_params *p_host);
  * the sampled arrays, other members ignored.  out_terms / out_nll: the nll before the update. */
 int  ffvd_sghmc_step(ffvd_handle *h, double epsilon, double mdecay, uint32_t sample_mask, int burn_in,
                      const ffvd_params *noise_host, double out_terms[8], double *out_nll);
+/* ---- sharded training step, device resident (the multi-GPU counterpart of adam.minimize(nll), dgp_model.py:303-305 /
+ * train_hypers, base_model.py:944-950, and of burn_in_op / sample_op, base_model.py:143-179) ---------------------------------
+ * Every rank runs forward + backward on its shard with S_total (the job's chain count) as the divisor of the mean, which
+ * leaves its ADDITIVE share of the job's gradient in ONE device block  [8 term sums | dZ | dlogvariance dloglengthscales
+ * dlog_Q dCC dDD dlog_Rchols | dU | dX]  (every segment on a 256-byte boundary; the gradient arrays of ffvd_elbo_grad ARE
+ * these segments, nothing is packed).  ONE ncclAllReduce(sum) of the block -- without dX for chain shards, whose rows of X
+ * are their own; with it for latent-dim shards, where every rank holds a partial sum for all chains -- then the fused
+ * update reads the reduced block.  No gradient crosses PCIe.  out_terms = whole-job sums (out_terms[7] = chains counted),
+ * out_nll = their mean, both for the parameters BEFORE the update.  A failed factorisation on any rank makes the sums
+ * non-finite on every rank: all return FFVD_ENOTPD and all leave their parameters untouched, so the replicas stay equal.
+ * The Adam moments / SG-HMC state live on the handle as for ffvd_adam_step / ffvd_sghmc_step; SG-HMC noise must be the same
+ * on every rank (the shared parameters are replicated).  rccl_comm = NULL: the handle's own communicator (ffvd_comm_init).
+ * Once a handle belongs to a communicator of more than one rank, plain ffvd_adam_step / ffvd_sghmc_step refuse it
+ * (FFVD_EINVAL): they would silently train on the local share only.
+ * Three-step form for hosts that carry the exchange themselves (tests: two ranks on ONE GPU over gloo; MPI):
+ *   ffvd_train_local(h, S_total)           forward + backward + the 8 sums into the block (enqueue only)
+ *   ffvd_train_exchange_count / _ptr       doubles that take part in the exchange / device pointer of the block
+ *   ffvd_train_exchange_get / _set         copy the block to / from the host (synchronise)
+ *   ffvd_adam_apply / ffvd_sghmc_apply     info + finiteness check, then the update from the block                      */
+int  ffvd_adam_step_allreduce(ffvd_handle *h, void *rccl_comm, int S_total, double lr, double beta1, double beta2, double eps,
+                              uint32_t train_mask, double out_terms[8], double *out_nll);
+int  ffvd_sghmc_step_allreduce(ffvd_handle *h, void *rccl_comm, int S_total, double epsilon, double mdecay,
+                               uint32_t sample_mask, int burn_in, const ffvd_params *noise_host, double out_terms[8],
+                               double *out_nll);
+int  ffvd_train_local(ffvd_handle *h, int S_total);
+int64_t ffvd_train_exchange_count(const ffvd_handle *h);
+void *ffvd_train_exchange_ptr(ffvd_handle *h);
+int  ffvd_train_exchange_get(ffvd_handle *h, double *host_out);
+int  ffvd_train_exchange_set(ffvd_handle *h, const double *host_in);
+int  ffvd_adam_apply(ffvd_handle *h, double lr, double beta1, double beta2, double eps, uint32_t train_mask,
+                     double out_terms[8], double *out_nll);
+int  ffvd_sghmc_apply(ffvd_handle *h, double epsilon, double mdecay, uint32_t sample_mask, int burn_in,
+                      const ffvd_params *noise_host, double out_terms[8], double *out_nll);
+
 /* ---- multi-GPU: one process per GPU, ONE exchange step ------------------------------------------
  * The reference is single-process (no collective call sites); this build shards chains or latent
  * dims over ranks and all-reduces the 8 partial sums with RCCL over xGMI.  librccl is bound at run time (the copy already

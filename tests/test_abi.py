@@ -150,9 +150,15 @@ for rc in (lib.ffvd_sync(None), lib.ffvd_set_data(None, None, None, 0), lib.ffvd
            lib.ffvd_stage_timing(None, 1), lib.ffvd_stage_times(None, _lib.dptr(out8), n8.ctypes.data_as(C.POINTER(C.c_int32))),
            lib.ffvd_comm_unique_id(None), lib.ffvd_comm_init(None, 1, 0, None), lib.ffvd_comm_destroy(None),
            lib.ffvd_elbo_allreduce(None, None, _lib.dptr(out8), C.byref(nll)), lib.ffvd_elbo_allreduce_async(None, None, None),
-           lib.ffvd_allreduce_sum_async(None, None, None, 8), lib.ffvd_allreduce_sum(None, None, None, 8)):
+           lib.ffvd_allreduce_sum_async(None, None, None, 8), lib.ffvd_allreduce_sum(None, None, None, 8),
+           lib.ffvd_adam_step_allreduce(None, None, 4, 0.1, 0.9, 0.999, 1e-8, 511, _lib.dptr(out8), C.byref(nll)),
+           lib.ffvd_sghmc_step_allreduce(None, None, 4, 0.01, 0.05, 2, 1, None, _lib.dptr(out8), C.byref(nll)),
+           lib.ffvd_train_local(None, 4), lib.ffvd_train_exchange_get(None, None), lib.ffvd_train_exchange_set(None, None),
+           lib.ffvd_adam_apply(None, 0.1, 0.9, 0.999, 1e-8, 511, _lib.dptr(out8), C.byref(nll)),
+           lib.ffvd_sghmc_apply(None, 0.01, 0.05, 2, 1, None, _lib.dptr(out8), C.byref(nll))):
     assert rc == E, rc
 assert lib.ffvd_get_stream(None) is None and lib.ffvd_comm_get(None) is None and lib.ffvd_workspace_bytes(None) == 0
+assert lib.ffvd_train_exchange_count(None) == 0 and lib.ffvd_train_exchange_ptr(None) is None
 # operator entry points: argument validation happens before any device work
 x = np.zeros((2, 3)); o = np.zeros(4); i32 = np.zeros(2, dtype=np.int32)
 dp = _lib.dptr

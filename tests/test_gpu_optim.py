@@ -475,3 +475,150 @@ def test_driver_example_runs(tmp_path):
         assert z["y_test_vfe"].shape == (40,) and np.all(np.isfinite(z["y_test_vfe"]))
         if case == 5:
             assert z["mc_posterior_samples_logvariance"].shape == (2, 4)
+
+
+# ---- sharded, device-resident training step (dgp_model.py:303-305, base_model.py:944-950 across ranks) ----
+
+def _single_engine_trajectory(params, Y, c, meta, steps, lr, collapse=True, noise=None):
+    kw = dict(route="gram") if collapse else {}
+    with ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], meta["S"], U_collapse=collapse, grad=True, **kw) as e:
+        e.set_data(Y, c)
+        e.set_params(params)
+        nlls = [e.adam_step(lr)["nll"] for _ in range(steps)]
+        if noise is not None:
+            nlls.append(e.sghmc_step(noise)["nll"])
+        return nlls, e.get_params()
+
+
+def test_sharded_training_step_one_rank_native_rccl():
+    """ffvd_adam_step_allreduce / ffvd_sghmc_step_allreduce on a 1-rank communicator: the real binding, the real
+    ncclAllReduce of the gradient block in HBM, the update from the reduced block -- bit-equal to the plain steps."""
+    from ffvd_amd.distributed import ShardedElbo
+    params, Y, c, meta = synthetic.make_named("tiny")
+    lr = optim.decayed_learning_rate()
+    rng = np.random.default_rng(5)
+    noise = {"logvariance": rng.standard_normal(meta["D"]), "loglengthscales": rng.standard_normal((meta["D"], meta["P"]))}
+    ref_nll, ref = _single_engine_trajectory(params, Y, c, meta, 4, lr, noise=noise)
+    sh = ShardedElbo(params, Y, c, meta, rank=0, world=1, mode="chains", device=0, always_reduce=True, route="gram", grad=True)
+    try:
+        nlls = [sh.adam_step(lr)["nll"] for _ in range(4)]
+        nlls.append(sh.sghmc_step(noise)["nll"])
+        got = sh.engine.get_params()
+    finally:
+        sh.close()
+    assert nlls == ref_nll
+    for k in ref:
+        np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
+
+
+@pytest.mark.parametrize("collapse,mode", [(True, "chains"), (True, "dims"), (False, "dims"), (False, "chains")])
+def test_two_shards_three_step_form_equals_single_engine(collapse, mode):
+    """Two shard handles on the one GPU, the exchange carried by the host (ffvd_train_local / _exchange_get / _set /
+    ffvd_adam_apply): after 4 steps every shard holds the single-engine parameters (1e-9), chain shards their own rows of X,
+    latent-dim shards all of X; then one sharded sample_op."""
+    from ffvd_amd import distributed as dm
+    params, Y, c, meta = synthetic.make_named("small")
+    S, D = meta["S"], meta["D"]
+    lr = optim.decayed_learning_rate()
+    rng = np.random.default_rng(6)
+    noise = {"log_Q": rng.standard_normal(D)}
+    ref_nll, ref = _single_engine_trajectory(params, Y, c, meta, 4, lr, collapse=collapse, noise=noise)
+    kw = dict(route="gram") if collapse else {}
+    engines, plans = [], []
+    try:
+        for r in range(2):
+            pl = dm.plan(meta, 2, r, mode)
+            e = ElboEngine(meta["T"], D, meta["C"], meta["M"], pl["s_count"], U_collapse=collapse, grad=True,
+                           d_begin=pl["d_begin"], d_count=pl["d_count"], shared_terms=pl["shared_terms"], **kw)
+            e.set_data(Y, c)
+            e.set_params(dict(params, X=params["X"][pl["s_begin"]: pl["s_begin"] + pl["s_count"]]))
+            engines.append(e)
+            plans.append(pl)
+        nlls = []
+        for step in range(5):
+            blocks = [e.train_local(S) for e in engines]
+            assert blocks[0].shape == blocks[1].shape
+            red = blocks[0] + blocks[1]
+            if step < 4:
+                outs = [e.adam_apply(red, lr) for e in engines]
+            else:
+                outs = [e.sghmc_apply(red, noise) for e in engines]
+            np.testing.assert_array_equal(outs[0], outs[1])
+            nlls.append(dm.finish(outs[0])["nll"])
+        got = [e.get_params() for e in engines]
+    finally:
+        for e in engines:
+            e.close()
+    np.testing.assert_allclose(nlls, ref_nll, rtol=1e-9)
+    for r, (g, pl) in enumerate(zip(got, plans)):
+        for k in ref:
+            want = ref[k][pl["s_begin"]: pl["s_begin"] + pl["s_count"]] if k == "X" else ref[k]
+            np.testing.assert_allclose(g[k], want, rtol=0, atol=1e-9 * max(1.0, float(np.max(np.abs(want)))), err_msg=f"rank {r} {k}")
+
+
+def test_plain_steps_refuse_a_shard():
+    """A handle that was told it is a shard must not train on its share alone."""
+    from ffvd_amd.distributed import ShardedElbo
+    params, Y, c, meta = synthetic.make_named("tiny")
+    sh = ShardedElbo(params, Y, c, meta, rank=0, world=1, mode="chains", device=0, always_reduce=True, route="gram", grad=True)
+    try:
+        sh.engine.shard_of = 2                  # what ShardedElbo(world=2) records on its engine
+        with pytest.raises(ValueError, match="shard"):
+            sh.engine.adam_step(0.01)
+    finally:
+        sh.close()
+    pl = dict(d_begin=0, d_count=1)
+    with ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], meta["S"], route="gram", grad=True, **pl) as e:
+        e.set_data(Y, c)
+        e.set_params(params)
+        with pytest.raises(ValueError, match="ffvd_adam_step_allreduce"):
+            e.adam_step(0.01)
+        with pytest.raises(ValueError, match="no pending backward pass"):
+            e.adam_apply(np.zeros(int(e.lib.ffvd_train_exchange_count(e._h))), 0.01)
+
+
+TRAIN_WORKER = r"""
+import os, sys
+sys.path.insert(0, os.environ["FFVD_ROOT"])
+import numpy as np, torch.distributed as dist
+from ffvd_amd import synthetic, optim
+from ffvd_amd.distributed import ShardedElbo
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+mode = sys.argv[1]
+dist.init_process_group("gloo", rank=rank, world_size=world)       # two processes share the one GPU: gloo carries the block
+params, Y, c, meta = synthetic.make_named("small")
+sh = ShardedElbo(params, Y, c, meta, rank=rank, world=world, mode=mode, device=0, route="gram", grad=True, collective="torch")
+lr = optim.decayed_learning_rate()
+nlls = [sh.adam_step(lr)["nll"] for _ in range(4)]
+got = sh.engine.get_params()
+np.savez(sys.argv[2] + f".rank{rank}.npz", nll=np.array(nlls), s_begin=sh.plan["s_begin"], s_count=sh.plan["s_count"], **got)
+sh.close()
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("mode,port", [("chains", "29551"), ("dims", "29552")])
+def test_two_processes_sharded_adam_trajectory(tmp_path, mode, port):
+    """Two real ranks on the one GPU of the test box run ShardedElbo.adam_step 4 times (forward + backward + ONE exchange of
+    the gradient block + fused update per step; gloo carries the block because RCCL needs one GPU per rank): both ranks end
+    on the single-engine ffvd_adam_step trajectory to 1e-9."""
+    import os
+    import subprocess
+    import sys
+    script = tmp_path / "train_worker.py"
+    script.write_text(TRAIN_WORKER)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FFVD_ROOT=root, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), mode, str(tmp_path / "out")], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    params, Y, c, meta = synthetic.make_named("small")
+    ref_nll, ref = _single_engine_trajectory(params, Y, c, meta, 4, optim.decayed_learning_rate())
+    for r in range(2):
+        z = np.load(str(tmp_path / "out") + f".rank{r}.npz")
+        np.testing.assert_allclose(z["nll"], ref_nll, rtol=1e-9)
+        b, n = int(z["s_begin"]), int(z["s_count"])
+        for k in ref:
+            want = ref[k][b: b + n] if k == "X" else ref[k]
+            np.testing.assert_allclose(z[k], want, rtol=0, atol=1e-9 * max(1.0, float(np.max(np.abs(want)))), err_msg=f"rank {r} {k}")

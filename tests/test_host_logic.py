@@ -284,3 +284,76 @@ def test_file_rendezvous_ignores_stale_ids_and_forwards_failures(tmp_path):
     g0 = dist_mod._RENDEZVOUS_GENERATION[0]
     dist_mod.exchange_unique_id(lambda: good, 0, 2, rendezvous_dir=d)
     assert os.path.exists(os.path.join(d, f"rccl_unique_id.{g0}")) and dist_mod._RENDEZVOUS_GENERATION[0] == g0 + 1
+
+
+ADAM_WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["FFVD_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+from ffvd_amd import synthetic, distributed as dm, optim
+from oracle import ffvd_grad_oracle as gorc, ffvd_optim_oracle as oo
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+params, Y, c, meta = synthetic.make_named("tiny")
+S = meta["S"]
+pl = dm.plan(meta, world, rank, "chains")
+lr = optim.decayed_learning_rate()
+keys = list(dm.GRAD_KEYS)
+def chain_grad(p, s_X):
+    q = dict(p); q["X"] = s_X
+    return gorc.nll_grad(q, Y, c)
+# ---- this rank: its chains only; the closed-form ORACLE stands in for the GPU backward pass ---------------------------
+th = {k: np.array(params[k], dtype=np.float64) for k in keys}
+thX = np.array(params["X"][pl["s_begin"]: pl["s_begin"] + pl["s_count"]], dtype=np.float64)
+m = {k: np.zeros_like(th[k]) for k in keys}; v = {k: np.zeros_like(th[k]) for k in keys}
+mX, vX = np.zeros_like(thX), np.zeros_like(thX)
+for t in range(1, 5):
+    # the exchange block of ffvd_adam_step_allreduce: shared-parameter gradients of this rank's chains, divisor S (whole job)
+    local = {k: np.zeros_like(th[k]) for k in keys}
+    gX = np.zeros_like(thX)
+    for i in range(pl["s_count"]):
+        g = chain_grad(dict(params, **th), thX[i])
+        gX[i] = g["X"] / S
+        for k in keys:
+            local[k] += g[k] / S
+    block = torch.from_numpy(np.concatenate([local[k].ravel() for k in keys]))
+    dm.all_reduce_sums(block)                                       # ONE all-reduce; dX stays on the rank (chain shards)
+    off = 0
+    for k in keys:
+        n = th[k].size
+        th[k], m[k], v[k] = oo.adam_step(th[k], block.numpy()[off: off + n].reshape(th[k].shape), m[k], v[k], t, lr)
+        off += n
+    thX, mX, vX = oo.adam_step(thX, gX, mX, vX, t, lr)
+# ---- the single-process trajectory -----------------------------------------------------------------------------------
+ref = {k: np.array(params[k], dtype=np.float64) for k in keys + ["X"]}
+rm = {k: np.zeros_like(ref[k]) for k in ref}; rv = {k: np.zeros_like(ref[k]) for k in ref}
+for t in range(1, 5):
+    tot = {k: np.zeros_like(ref[k]) for k in ref}
+    for s in range(S):
+        g = chain_grad({k: ref[k] for k in keys}, ref["X"][s])
+        tot["X"][s] = g["X"] / S
+        for k in keys:
+            tot[k] += g[k] / S
+    for k in ref:
+        ref[k], rm[k], rv[k] = oo.adam_step(ref[k], tot[k], rm[k], rv[k], t, lr)
+for k in keys:
+    assert np.allclose(th[k], ref[k], rtol=0, atol=1e-9 * max(1.0, np.max(np.abs(ref[k])))), k
+assert np.allclose(thX, ref["X"][pl["s_begin"]: pl["s_begin"] + pl["s_count"]], rtol=0, atol=1e-9)
+print("OK")
+dist.destroy_process_group()
+'''
+
+
+def test_gloo_world2_sharded_adam_trajectory(tmp_path):
+    """world_size-2 rehearsal of the device-resident sharded training step (ffvd_adam_step_allreduce): per step ONE all-reduce
+    of the shared-parameter gradient block, chain shards update their own rows of X, and after 4 steps every rank sits on the
+    single-process Adam trajectory (1e-9)."""
+    import subprocess
+    script = tmp_path / "aworker.py"
+    script.write_text(ADAM_WORKER)
+    env = dict(os.environ, FFVD_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29538", WORLD_SIZE="2", OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "OK" in outs[0] and "OK" in outs[1]
