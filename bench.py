@@ -150,22 +150,18 @@ def run_rank(args):
     rehearsal = bool(os.environ.get("FFVD_BENCH_REHEARSAL"))
     if rehearsal:
         local_rank = 0
+    # stdout of this program is ONE JSON line.  Libraries write there from their C++ side -- gloo announces its connections,
+    # RCCL prints a version banner when a communicator forms (seen on the GPU box: "RCCL version : 2.27.7 ...") -- so file
+    # descriptor 1 points at stderr for the whole run and the line goes to the saved descriptor at the very end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     dist = None
     if world > 1:
         import torch.distributed as dist       # host-side plumbing: rendezvous id, barriers, max over ranks (gloo, CPU)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # gloo announces its connections on the C++ side's stdout; stdout of this program is ONE JSON line, so the
-        # file descriptor points at stderr while the group forms
-        sys.stdout.flush()
-        saved = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-            dist.barrier()
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved, 1)
-            os.close(saved)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
 
     params, Y, c, meta = synthetic.make_named(args.workload)
     mode = "dims" if meta["S"] < world or args.workload == "c5" else "chains"
@@ -325,7 +321,9 @@ def run_rank(args):
                 out["cpu_baseline"] = cpu_baseline_c4(params, Y, c, meta)
             else:
                 out["cpu_baseline"] = cpu_baseline(params, Y, c, meta, n, args.workload)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    os.close(json_fd)
     sh.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -54,6 +54,10 @@ void launch_kernel_diag(hipStream_t stream, int kind, const double *X, int N, in
 // for the one-launch dataflow variant, its progress words).  hint = CHOL_FLOW asks for the dataflow variant whatever the batch
 // (the factorisation is on the caller's critical path); CHOL_AUTO picks by batch size.
 enum { CHOL_AUTO = 0, CHOL_FLOW = 3 };
+// force a variant for the launches this THREAD enqueues from now on: 0 = back to the normal choice, 1 = left-looking launches per
+// block column, 2 = right-looking launches (neither has inter-workgroup waits); used to re-run a batch whose dataflow launch gave up
+enum { CHOL_FORCE_NONE = 0, CHOL_FORCE_LEFT = 1, CHOL_FORCE_RIGHT = 2 };
+void potrf_override_variant(int variant);
 size_t potrf_scratch_doubles(int n, int batch);
 // linv_t (optional, honoured by the dataflow variant only -- ask potrf_flow_selected): the identity-structured extra rows
 // are ALSO written transposed, L^-1 as an n x n lower-triangular matrix (ld n) per slab of linv_t_stride doubles; the blocks

@@ -1601,11 +1601,15 @@ static int chol_mode() {                    // 0 = auto, 1 = left-looking launch
     }();
     return v;
 }
+// Per-thread override (0 = none): the caller re-runs a batch whose dataflow launch gave up (a bounded wait fired) with one of
+// the launch-per-step variants, which have no inter-workgroup waits and therefore cannot stall (abi.hip, stall recovery).
+static thread_local int g_chol_override = 0;
+void potrf_override_variant(int variant) { g_chol_override = variant; }
 static int chol_variant(int batch, int nb, int hint);
 bool potrf_flow_selected(int n, int batch, int hint) { return chol_variant(batch, n / NB, hint) == 3; }
 bool potrf_flow_forms_inverse(int n, int batch, int hint) { return potrf_flow_selected(n, batch, hint) && 2 * (n / NB) <= DF_PS; }
 static int chol_variant(int batch, int nb, int hint) {
-    int m = chol_mode();
+    int m = g_chol_override ? g_chol_override : chol_mode();
     if (m == 0) m = (hint == CHOL_FLOW || batch >= 32) ? 3 : 2;
     if (m == 3 && nb > DF_PS) m = 1;
     return m;

@@ -119,6 +119,11 @@ int  ffvd_destroy(ffvd_handle *h);
 /* message of the most recent failure on `h` (or of the last failed ffvd_create / handle-less op when h == NULL) */
 const char *ffvd_last_error(const ffvd_handle *h);
 int  ffvd_sync(ffvd_handle *h);
+/* How often a synchronous call on this handle (ffvd_elbo, ffvd_elbo_grad, ffvd_adam_step, ffvd_sghmc_step) re-ran its iteration
+ * because the one-launch Cholesky gave up on a bounded wait (info = -1): the iteration is then enqueued once more, in process,
+ * with the launch-per-column Cholesky, the call returns FFVD_OK and ffvd_last_error holds a warning; only a second failure is
+ * FFVD_EDEVICE.  Collective calls do not retry (the other ranks have moved on). */
+int  ffvd_stall_recoveries(const ffvd_handle *h);
 /* bytes of device workspace owned by the handle */
 int64_t ffvd_workspace_bytes(const ffvd_handle *h);
 
