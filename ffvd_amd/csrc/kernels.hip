@@ -374,6 +374,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 #ifdef FFVD_DF_TRACE
 __device__ long long df_trace_buf[64 * 64];
+__device__ long long gram_trace_buf[128 * 10 * 4];      // start, end, HW_ID, blockIdx of every Gram tile (<= 128 units of 10 tiles)
 #define DF_STAMP0(slot) do { if (blockIdx.x == 0 && threadIdx.x == 0) df_trace_buf[63 * 64 + (slot)] = wall_clock64(); } while (0)
 #else
 #define DF_STAMP0(slot) do { } while (0)
@@ -1099,6 +1100,9 @@ struct DfArgs {
 #define DF_STAMP(row, slot) do { if ((row) >= 0 && threadIdx.x == 0) df_trace_buf[(row) * 64 + (slot)] = wall_clock64(); } while (0)
 extern "C" int ffvd_debug_df_trace(long long *out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(df_trace_buf), sizeof(long long) * 64 * 64);
+}
+extern "C" int ffvd_debug_gram_trace(long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gram_trace_buf), sizeof(long long) * 128 * 10 * 4);
 }
 #else
 #define DF_STAMP(row, slot) do { } while (0)
@@ -2116,6 +2120,12 @@ __global__ __launch_bounds__(512, 4) void gram_kernel(GramArgs a) {
     if (threadIdx.x == 0 && bz < 16 && ksplit == 1 && a.ntiles <= 10 && MODE == GRAM_KFU) {
         df_trace_buf[2048 + (bz * 10 + tile) * 2] = tw0;
         df_trace_buf[2048 + (bz * 10 + tile) * 2 + 1] = wall_clock64();
+    }
+    if (threadIdx.x == 0 && bz < 128 && ksplit == 1 && a.ntiles <= 10 && MODE == GRAM_KFU) {     // every tile of the launch (tools/gram_rounds.py)
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        long long *g = gram_trace_buf + (size_t)(bz * 10 + tile) * 4;
+        g[0] = tw0; g[1] = wall_clock64(); g[2] = (long long)hw; g[3] = (long long)blockIdx.x;
     }
 #endif
 }
