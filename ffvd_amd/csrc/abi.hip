@@ -46,6 +46,7 @@ struct ffvd_handle {
     struct Switches {
         bool fused_project = false, grad_explicit = false, no_defer_trace = false, no_late_join = false;
         bool no_main_first = false, no_kfu_first = false, atb128 = false, grad_serial = false, kuu_flow = true, kinv_gram = false, chain_rl = false;
+        bool debug_sync = false;    // FFVD_DEBUG_SYNC: name every launch group on stderr and wait for it (locates a faulting kernel)
     } sw;
     // resident parameters / data (handle-owned copies)
     double *X = nullptr, *Z = nullptr, *U = nullptr, *logvar = nullptr, *loglen = nullptr, *logQ = nullptr;
@@ -82,6 +83,8 @@ struct ffvd_handle {
         double *T1 = nullptr, *wv = nullptr, *bw = nullptr, *Ident = nullptr, *P2 = nullptr, *P3 = nullptr;
         bool whitened = false;
         double *E = nullptr, *rp = nullptr, *rsum = nullptr, *ez = nullptr, *kfu = nullptr;
+        float *Gam32 = nullptr;         // fp32-contraction backward: Gamma rounded to fp32, the right operand of R = K_fu Gamma
+        double *fsq = nullptr;          // reference route, fp64: sum_t |F_t|^2 per unit (the fp32 path has sqsum)
         double *cs_part = nullptr, *etx_part = nullptr, *rx2_part = nullptr, *dz_unit = nullptr, *dll_unit = nullptr, *dls_unit = nullptr;
         double *Asum = nullptr, *GamSum = nullptr, *Gs = nullptr, *gsum = nullptr, *P1 = nullptr, *KGK = nullptr, *Epsi = nullptr;
         double *rsum2 = nullptr, *ez2 = nullptr, *cs2 = nullptr, *etx2 = nullptr, *rx22 = nullptr, *dz_kuu = nullptr, *dll_kuu = nullptr, *dls_kuu = nullptr;
@@ -182,6 +185,7 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
         w.no_main_first = on("FFVD_NO_MAIN_FIRST");   w.no_kfu_first = on("FFVD_NO_KFU_FIRST");
         w.kuu_flow = !on("FFVD_NO_KUU_FLOW");   w.kinv_gram = on("FFVD_KINV_GRAM");   w.chain_rl = on("FFVD_CHAIN_RL");
         w.atb128 = on("FFVD_ATB128");                 w.grad_serial = on("FFVD_GRAD_SERIAL");
+        w.debug_sync = on("FFVD_DEBUG_SYNC");
     }
     h->P = c.D + c.C;
     h->Dl = c.d_count > 0 ? c.d_count : c.D;
@@ -235,8 +239,9 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
     // (explicit-U branch: only from 64 units of the headline size on -- below that the single fused kernel is quicker:
     //  1.10 vs 1.21 ms on config 5's 16 units -- or when the backward pass needs K_fu anyway)
     const bool big_a = (size_t)h->nbatch * Tp * Mp >= (size_t)64 * 4096 * 512 || c.grad;
+    const bool grad_ref = c.grad && c.branch == FFVD_BRANCH_B && c.route == FFVD_ROUTE_REFERENCE;    // backward pass in the reference's op order
     const bool proj_gemm = ((c.branch == FFVD_BRANCH_A && big_a) || (c.branch == FFVD_BRANCH_B && c.route == FFVD_ROUTE_REFERENCE)) &&
-                           !h->sw.fused_project;
+                           (!h->sw.fused_project || grad_ref);
     h->ngr = (proj_gemm && c.dtype != FFVD_F32C) ? (int)((Mp + 127) / 128) : 0;
     HIP_TRY(dev_alloc(h, &h->rowsq, (size_t)h->nbatch * (h->ngr > h->ng ? h->ngr : h->ng) * Tp));
     HIP_TRY(dev_alloc(h, &h->fmean, (size_t)h->nbatch * (h->ngr > h->ng ? h->ngr : h->ng) * Tp));
@@ -266,7 +271,7 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
         HIP_TRY(dev_alloc(h, &h->F, (size_t)(grad_a ? h->nbatch : h->cpp * Dl) * Tp * Mp));
         HIP_TRY(dev_alloc(h, &h->ucolA, Dl * Mp));
     }
-    if ((c.branch == FFVD_BRANCH_B && c.route == FFVD_ROUTE_GRAM) || grad_a) {
+    if ((c.branch == FFVD_BRANCH_B && c.route == FFVD_ROUTE_GRAM) || grad_a || grad_ref) {
         HIP_TRY(dev_alloc(h, &h->Kcopy, Dl * Mp * Mp));
         HIP_TRY(dev_alloc(h, &h->Linv, Dl * Mp * Mp));
         HIP_TRY(hipMemsetAsync(h->Linv, 0, Dl * Mp * Mp * sizeof(double), h->stream));     // blocks above the diagonal stay zero
@@ -282,8 +287,10 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
         HIP_TRY(dev_alloc(h, &g.Acopy, nbt * msq));      HIP_TRY(dev_alloc(h, &g.u, nbt * Mp));
         HIP_TRY(dev_alloc(h, &g.LAinv, nbt * msq));      HIP_TRY(dev_alloc(h, &g.Gamma, nbt * msq));
         HIP_TRY(dev_alloc(h, &g.gam_part, nbt * g.ngam)); HIP_TRY(dev_alloc(h, &g.uku, nbt));
-        if (P <= 6) HIP_TRY(dev_alloc(h, &g.rp, bwd_fused_rp_doubles((int)Mp, (int)Tp, (int)nbt)));   // fused E reductions
+        if (c.dtype == FFVD_F32C) HIP_TRY(dev_alloc(h, &g.Gam32, nbt * msq));                          // E formed on the fly from fp32 operands
+        else if (P <= 6) HIP_TRY(dev_alloc(h, &g.rp, bwd_fused_rp_doubles((int)Mp, (int)Tp, (int)nbt)));   // fused E reductions
         else HIP_TRY(dev_alloc(h, &g.E, nbt * Tp * Mp));
+        if (grad_ref && c.dtype != FFVD_F32C) HIP_TRY(dev_alloc(h, &g.fsq, nbt));
         HIP_TRY(dev_alloc(h, &g.rsum, nbt * Tp));        HIP_TRY(dev_alloc(h, &g.ez, nbt * Tp * P));
         HIP_TRY(dev_alloc(h, &g.kfu, nbt * Tp));
         HIP_TRY(dev_alloc(h, &g.cs_part, nbt * nblk * Mp)); HIP_TRY(dev_alloc(h, &g.etx_part, nbt * nblk * Mp * P));
@@ -293,7 +300,8 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
         HIP_TRY(dev_alloc(h, &g.Asum, Dl * msq));  HIP_TRY(dev_alloc(h, &g.GamSum, Dl * msq)); HIP_TRY(dev_alloc(h, &g.Gs, Dl * msq));
         HIP_TRY(dev_alloc(h, &g.gsum, Dl * msq));  HIP_TRY(dev_alloc(h, &g.P1, Dl * msq));     HIP_TRY(dev_alloc(h, &g.KGK, Dl * msq));
         HIP_TRY(dev_alloc(h, &g.Epsi, Dl * msq));
-        g.whitened = c.branch == FFVD_BRANCH_B && !h->sw.grad_explicit;
+        // (the reference route factorises H = I + F^T F / Q itself: its backward pass is the whitened one by construction)
+        g.whitened = c.branch == FFVD_BRANCH_B && (!h->sw.grad_explicit || grad_ref);
         if (g.whitened) {
             HIP_TRY(dev_alloc(h, &g.T1, nbt * msq));
             HIP_TRY(dev_alloc(h, &g.wv, nbt * Mp));    HIP_TRY(dev_alloc(h, &g.bw, nbt * Mp));
@@ -387,9 +395,8 @@ extern "C" int ffvd_create(const ffvd_config *cfg, ffvd_handle **out) {
         return set_error(nullptr, FFVD_EINVAL, msg);
     }
     if (cfg->dtype != FFVD_F64 && cfg->dtype != FFVD_F32C) return set_error(nullptr, FFVD_EINVAL, "ffvd_create: unknown dtype");
-    if (cfg->dtype == FFVD_F32C && (cfg->branch != FFVD_BRANCH_B || cfg->route != FFVD_ROUTE_REFERENCE || cfg->grad))
-        return set_error(nullptr, FFVD_EINVAL,
-                         "ffvd_create: FFVD_F32C is the collapsed-U branch on FFVD_ROUTE_REFERENCE without gradient");
+    if (cfg->dtype == FFVD_F32C && (cfg->branch != FFVD_BRANCH_B || cfg->route != FFVD_ROUTE_REFERENCE))
+        return set_error(nullptr, FFVD_EINVAL, "ffvd_create: FFVD_F32C is the collapsed-U branch on FFVD_ROUTE_REFERENCE");
     if (cfg->kernel_kind != FFVD_KERNEL_SE && cfg->kernel_kind != FFVD_KERNEL_LINEAR)
         return set_error(nullptr, FFVD_EINVAL, "ffvd_create: unknown kernel_kind");
     if (cfg->branch != FFVD_BRANCH_A && cfg->branch != FFVD_BRANCH_B)
@@ -402,9 +409,8 @@ extern "C" int ffvd_create(const ffvd_config *cfg, ffvd_handle **out) {
     if (!(cfg->jitter >= 0.0)) return set_error(nullptr, FFVD_EINVAL, "ffvd_create: jitter must be >= 0");
     if (cfg->route != FFVD_ROUTE_REFERENCE && cfg->route != FFVD_ROUTE_GRAM)
         return set_error(nullptr, FFVD_EINVAL, "ffvd_create: unknown route");
-    if (cfg->grad && cfg->branch == FFVD_BRANCH_B && (cfg->kernel_kind != FFVD_KERNEL_SE || cfg->route != FFVD_ROUTE_GRAM))
-        return set_error(nullptr, FFVD_EINVAL,
-                         "ffvd_create: grad = 1 in the collapsed-U branch needs the SE kernel and FFVD_ROUTE_GRAM");
+    if (cfg->grad && cfg->branch == FFVD_BRANCH_B && cfg->kernel_kind != FFVD_KERNEL_SE)
+        return set_error(nullptr, FFVD_EINVAL, "ffvd_create: grad = 1 in the collapsed-U branch needs the SE kernel");
     if (cfg->route == FFVD_ROUTE_GRAM && cfg->branch != FFVD_BRANCH_B)
         return set_error(nullptr, FFVD_EINVAL, "ffvd_create: FFVD_ROUTE_GRAM only applies to the collapsed-U branch");
     if (cfg->T_total < 0 || cfg->t_begin < 0 || (cfg->T_total > 0 && cfg->t_begin + cfg->T > cfg->T_total))
@@ -506,6 +512,17 @@ extern "C" int ffvd_set_params(ffvd_handle *h, const ffvd_params *p, int on_devi
 // ---- the per-iteration launch sequence -------------------------------------------------------
 // Stage timing: an event is recorded after each stage's launches; the interval ending at an event is
 // attributed to that stage (stage -1 = origin of an iteration).  Events come from a pool owned by the handle.
+// FFVD_DEBUG_SYNC=1: print the name of the launch group just enqueued and wait for both streams, so that a faulting kernel is the
+// one named last (diagnostic only; read once per handle)
+#define DBG_SYNC(h, name)                                                                              \
+    do {                                                                                               \
+        if ((h)->sw.debug_sync) {                                                                      \
+            fprintf(stderr, "[ffvd debug] %s ...", name); fflush(stderr);                             \
+            hipError_t e1_ = hipStreamSynchronize((h)->stream), e2_ = hipStreamSynchronize((h)->aux);  \
+            fprintf(stderr, " %s\n", (e1_ == hipSuccess && e2_ == hipSuccess) ? "ok" : hipGetErrorString(e1_ != hipSuccess ? e1_ : e2_)); \
+        }                                                                                              \
+    } while (0)
+
 struct StageTimer {
     ffvd_handle *h;
     void mark(int stage_id) {
@@ -550,6 +567,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
     const size_t kstride = (size_t)2 * Mp * Mp;
     const size_t msq = (size_t)Mp * Mp;
     const bool grad_a = c.grad && c.branch == FFVD_BRANCH_A;
+    const bool grad_ref = c.grad && c.branch == FFVD_BRANCH_B && !gram_route;     // training in the reference's op order (fp64 or fp32 contractions)
     auto project_args = [&](int s0, int ns) {
         ProjectArgs pa{};
         pa.kind = c.kernel_kind;
@@ -658,16 +676,16 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
         }
     }
     if (!kuu_on_main) {
-        launch_kuu_build(sk, c.kernel_kind, hv, c.M, Mp, P, Dl, c.jitter, h->Kuu, (gram_route || grad_a) ? h->Kcopy : nullptr);
+        launch_kuu_build(sk, c.kernel_kind, hv, c.M, Mp, P, Dl, c.jitter, h->Kuu, (gram_route || grad_a || grad_ref) ? h->Kcopy : nullptr);
         if (defer_trace || (defer_full && sk != s)) HIP_TRY(hipEventRecord(h->ev_kuu, sk));
         // chain on the main stream = on the critical path with nothing beside it: the dataflow launch; on the side stream
         // (beside the K_fu build / tile pass of a small batch) the right-looking launches, whose workgroups come and go
         const bool chain_flow = (sk == s) && potrf_flow_selected((int)Mp, (int)Dl, CHOL_FLOW) && !h->sw.chain_rl;
-        if (chain_flow && (gram_route || grad_a)) linv_done = true;
+        if (chain_flow && (gram_route || grad_a || grad_ref)) linv_done = true;
         launch_potrf_ext(sk, h->Kuu, Mp, Mp, Mp, Dl, kstride, h->info, h->dinvK, chain_flow ? CHOL_FLOW : CHOL_AUTO,
                          linv_done ? h->Linv : nullptr, msq);
     }
-    if (gram_route || grad_a) {
+    if (gram_route || grad_a || grad_ref) {
         // K^-1 = L^-T L^-1 (shared by all chains) and log|K|
         if (!linv_done) launch_transpose(sk, h->Kuu + msq, kstride, h->Linv, msq, Mp, Dl);
         GramArgs gk{};
@@ -689,6 +707,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
         launch_h_finish(sk, h->Kuu, Mp, kstride, Dl, h->kterms);
         if (sk != s) HIP_TRY(hipEventRecord(h->ev_join, sk));
     }
+    DBG_SYNC(h, "forward: K_uu chain");
     const ReduceArgs ra = reduce_args();
     // the per-chain likelihood / transition reductions depend on the inputs only (Gram route: no row sums of F), so
     // they ride on the side stream behind the K_uu chain and are back long before finalize needs them (kuu_on_main: they
@@ -739,6 +758,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
             launch_project(s, pa);
         }
         if (st && !(kfu_first && s0 == 0)) st->mark(1);
+        DBG_SYNC(h, "forward: K_fu / projection");
         if (c.branch == FFVD_BRANCH_B) {
             GramArgs ga = gram_args(s0, ns);
             bool trace_pending = false, acopy_done = false;      // acopy_done: the Gram kernel stored the copy of A itself
@@ -763,7 +783,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
                 trace_pending = true;
             } else if (c.dtype == FFVD_F32C) {
                 GramF32Args gf{};
-                gf.F = h->F32; gf.f_stride = (size_t)Tp * Mp; gf.rows = Tp; gf.with_row = 1; gf.brow = Mp;
+                gf.F = h->F32; gf.f_stride = (size_t)Tp * Mp; gf.rows = Tp; gf.with_row = 1; gf.brow = c.grad ? 2 * Mp : Mp;
                 gf.X = p.X; gf.log_Q = p.log_Q; gf.T = c.T; gf.D = c.D; gf.Mp = Mp; gf.Dl = Dl; gf.d_begin = c.d_begin;
                 gf.b0 = s0 * Dl; gf.nb = ns * Dl; gf.yn_over_batch = 1.0; gf.H = h->H; gf.h_stride = ga.h_stride;
                 gf.flush = h->gram_flush;
@@ -774,6 +794,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
                 launch_gram(s, ga);
             }
             if (st) st->mark(2);
+            DBG_SYNC(h, "forward: Gram");
             if (trace_pending) {
                 // trace partials from the raw tiles, on the side stream (K^-1 precedes in its order).  Enqueued AHEAD of the
                 // factorisation: that is one launch whose row workgroups hold every slot of the chip for most of its length,
@@ -787,7 +808,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
                 if (!acopy_done)
                     HIP_TRY(hipMemcpy2DAsync(h->gw.Acopy, msq * sizeof(double), h->H, ga.h_stride * sizeof(double),
                                              msq * sizeof(double), (size_t)ns * Dl, hipMemcpyDeviceToDevice, s));
-                if (h->gw.whitened) {
+                if (h->gw.whitened && gram_route) {
                     // H = W^T A W (W = L^-T of K_uu) replaces A in the slab, b = W^T c replaces c: the factorisation, the
                     // explicit inverse and everything the backward pass derives from them then live in the whitened
                     // variables, where cond(H) is about 1e4 instead of the 1e7 of A
@@ -819,6 +840,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
                 launch_h_finish(s, h->H, Mp, ga.h_stride, ns * Dl, h->hterms + (size_t)2 * s0 * Dl);
             }
             if (st) st->mark(3);
+            DBG_SYNC(h, "forward: Cholesky(H) + solves");
         }
     }
     if (!reduce_early) launch_chain_reduce(s, ra, h->chain_partial);
@@ -834,10 +856,12 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
     if (c.dtype == FFVD_F32C) {           // sum_t |F_t|^2 per unit from the projection's fp64 tile sums
         launch_sum_partials(s, h->sqpart, h->nsq, h->nbatch, h->sqsum);
         fa.trpart = h->sqsum; fa.ntiles = 1; fa.fsq_from_trpart = 1;
-    }
+    } else if (grad_ref)                  // the backward pass wants the same per-unit sum (dl/dalpha): all row sums of F^2 of a unit
+        launch_sum_partials(s, h->rowsq, h->ngr * Tp, h->nbatch, h->gw.fsq);
     fa.out_terms = out_dev ? out_dev : h->out_terms;
     launch_finalize(s, fa);
     if (st) st->mark(4);
+    DBG_SYNC(h, "forward: reductions + finalize");
     HIP_TRY(hipGetLastError());
     return FFVD_OK;
 }
@@ -1124,6 +1148,12 @@ static int enqueue_grad_b(ffvd_handle *h, int S_total) {
     const ffvd_params &p = h->cur;
     const size_t kstride = (size_t)2 * Mp * Mp;
     const bool wh = g.whitened;
+    // Reference route (F = K_fu L^-T, H = F^T F / Q + I factorised by the forward pass; fp64 or fp32 contractions): the slab already
+    // holds the factor of the whitened H, so the M x M side below is the whitened one as it stands; what differs is where K_fu
+    // lives (Kf2, or the fp32 copy), that sum_s H_s is read instead of W^T (sum_s A_s) W, and where sum_t |F_t|^2 comes from.
+    const bool ref = c.route == FFVD_ROUTE_REFERENCE;
+    const bool f32c = c.dtype == FFVD_F32C;
+    const double *Kf64 = ref ? h->Kf2 : h->F;
     // explicit form: u = A^-1 c = L_A^-T (L_A^-1 c), Gamma = alpha/2 (K^-1 - A^-1 - u u^T) with A^-1 from the factor of A.
     // whitened form (default): the slab holds the factor of H = W^T A W and y = L_H^-1 b.  Then w = H^-1 b, u = W w, and
     // A^-1 = B^T B with B = L_H^-1 L^-1 (a product of two accurate triangular factors; K^-1 = (L^-1)^T L^-1 is formed
@@ -1150,6 +1180,7 @@ static int enqueue_grad_b(ffvd_handle *h, int S_total) {
         ag.A = g.LAinv; ag.B = g.LAinv;
     }
     launch_atb(s, ag);
+    DBG_SYNC(h, "backward: w, u, B, Gamma");
     // K_uu side: Psi_d = sum_s Gamma_s / alpha_d - 1/2 K^-1 (sum_s A_s - S K) K^-1.  It needs Gamma and the saved
     // A-matrices only, so its dozen small launches go to the side stream and run beside the E product
     // (enqueued after it: the main stream must not wait for their launch overhead).
@@ -1159,15 +1190,27 @@ static int enqueue_grad_b(ffvd_handle *h, int S_total) {
         HIP_TRY(hipStreamWaitEvent(sk, h->ev_fork, 0));
     }
     EReduceArgs er{};
-    er.E = g.E; er.e_stride = fstride; er.Kf = h->F; er.u = g.u; er.u_stride = Mp; er.x_is_z = 0;
+    er.E = g.E; er.e_stride = fstride; er.Kf = Kf64; er.u = g.u; er.u_stride = Mp; er.x_is_z = 0;
     er.x = p.X; er.x_chain_stride = (size_t)(c.T + 1) * c.D; er.x_ld = c.D; er.x_cols = c.D; er.ctrl = h->ctrl; er.C = c.C;
     er.Z = p.Z; er.len = h->len; er.T = c.T; er.Tp = Tp; er.M = c.M; er.Mp = Mp; er.P = P; er.Dl = Dl; er.b0 = 0; er.nb = nb;
     er.nblk = Tp / 64; er.rsum = g.rsum; er.ez = g.ez; er.kfu = g.kfu; er.cs_part = g.cs_part; er.etx_part = g.etx_part;
     er.rx2_part = g.rx2_part;
-    if (g.rp) {
+    if (f32c) {
+        // fp32 contractions (BASELINE configs[3]): Gamma rounded once, R = K_fu Gamma on v_mfma_f32_32x32x2_f32 into the buffer F
+        // occupied in the forward pass, then E_tm = (2 R_tm + alpha delta_t u_m) K_tm formed on the fly inside the reduction
+        // kernel with every sum in fp64 (E itself is never stored)
+        launch_to_f32(s, g.Gamma, g.Gam32, (size_t)nb * msq);
+        ProjF32Args pg{};
+        pg.Kf = h->Kf32; pg.kf_stride = fstride; pg.Bunit = g.Gam32; pg.bunit_stride = msq; pg.F = h->F32; pg.f_stride = fstride;
+        pg.sqpart = nullptr; pg.Tp = Tp; pg.Mp = Mp; pg.Dl = Dl; pg.b0 = 0; pg.nb = nb;
+        launch_proj_gemm_f32(s, pg);
+        er.E = nullptr; er.Kf = nullptr; er.R32 = h->F32; er.Kf32 = h->Kf32; er.Xd = p.X; er.log_Q = p.log_Q; er.D = c.D;
+        er.d_begin = c.d_begin;
+        launch_e_reduce(s, er);
+    } else if (g.rp) {
         // E = (2 Kf Gamma + alpha delta u^T) o Kf formed and reduced tile by tile: it never reaches HBM
         BwdFusedArgs bf{};
-        bf.Kf = h->F; bf.kf_stride = fstride; bf.Gamma = g.Gamma; bf.g_stride = msq; bf.u = g.u; bf.u_stride = Mp;
+        bf.Kf = Kf64; bf.kf_stride = fstride; bf.Gamma = g.Gamma; bf.g_stride = msq; bf.u = g.u; bf.u_stride = Mp;
         bf.X = p.X; bf.ctrl = h->ctrl; bf.Z = p.Z; bf.log_Q = p.log_Q; bf.T = c.T; bf.Tp = Tp; bf.D = c.D; bf.C = c.C;
         bf.M = c.M; bf.Mp = Mp; bf.P = P; bf.Dl = Dl; bf.d_begin = c.d_begin; bf.b0 = 0; bf.nb = nb; bf.rp = g.rp;
         bf.cs_part = g.cs_part; bf.etx_part = g.etx_part; bf.rsum = g.rsum; bf.ez = g.ez; bf.kfu = g.kfu;
@@ -1176,15 +1219,17 @@ static int enqueue_grad_b(ffvd_handle *h, int S_total) {
     } else {
         // P > 6: materialise E and reduce it in a second kernel
         AtbArgs ae{};
-        ae.mode = ATB_BWD_E; ae.A = h->F; ae.a_stride = fstride; ae.lda = Mp; ae.nA = Tp; ae.a_rowmajor = 1;   // K_fu itself
+        ae.mode = ATB_BWD_E; ae.A = Kf64; ae.a_stride = fstride; ae.lda = Mp; ae.nA = Tp; ae.a_rowmajor = 1;   // K_fu itself
         ae.B = g.Gamma; ae.b_stride = msq; ae.ldb = Mp; ae.nB = Mp; ae.rows = Mp;
         ae.C = g.E; ae.c_stride = fstride; ae.ldc = Mp; ae.nb = nb; ae.b0 = 0; ae.Dl = Dl; ae.d_begin = c.d_begin;
         ae.log_Q = p.log_Q; ae.u = g.u; ae.u_stride = Mp; ae.X = p.X; ae.T = c.T; ae.D = c.D;
-        ae.Kf = h->F; ae.kf_stride = fstride; ae.ldkf = Mp;
+        ae.Kf = Kf64; ae.kf_stride = fstride; ae.ldkf = Mp;
         launch_atb(s, ae);
         launch_e_reduce(s, er);
     }
+    DBG_SYNC(h, "backward: E product + reductions");
     launch_e_finish(s, er, g.dz_unit, g.dll_unit, g.dls_unit);
+    DBG_SYNC(h, "backward: e_finish");
     // latent trajectories (after the E product) and the per-chain partials of the shared parameters (inputs only: side)
     DxArgs dx{};
     dx.X = p.X; dx.Y = h->Y; dx.CC = p.CC; dx.DD = p.DD; dx.log_Rchols = p.log_Rchols; dx.log_Q = p.log_Q; dx.len = h->len;
@@ -1193,19 +1238,23 @@ static int enqueue_grad_b(ffvd_handle *h, int S_total) {
     if (wh) launch_uku(sk, g.wv, Mp, g.Ident, 0, Mp, Dl, nb, g.uku);       // u^T K u = w^T w
     else launch_uku(sk, g.u, Mp, h->Kcopy, msq, Mp, Dl, nb, g.uku);   // u^T K u per unit: only grad_finalize reads it
     launch_shared_partials(sk, dx, g.shared_part, g.sp_stride);
-    launch_chain_sum(sk, g.Acopy, msq, S, Dl, msq, g.Asum, msq);
+    launch_chain_sum(sk, g.Acopy, msq, S, Dl, msq, g.Asum, msq);      // (reference route: the saved matrices are the H_s)
     launch_symmetrize(sk, g.Asum, Mp, Dl);
     launch_chain_sum(sk, g.Gamma, msq, S, Dl, msq, g.GamSum, msq);
-    launch_axpby(sk, g.Asum, h->Kcopy, 1.0, -(double)S, p.log_Q, c.d_begin, 0, msq, Dl, g.Gs);
+    if (!ref) launch_axpby(sk, g.Asum, h->Kcopy, 1.0, -(double)S, p.log_Q, c.d_begin, 0, msq, Dl, g.Gs);
     launch_axpby(sk, g.GamSum, nullptr, 1.0, 0.0, p.log_Q, c.d_begin, 1, msq, Dl, g.gsum);
     AtbArgs ap{};
     ap.mode = ATB_PLAIN; ap.a_stride = msq; ap.lda = Mp; ap.nA = Mp; ap.b_stride = msq;
     ap.ldb = Mp; ap.nB = Mp; ap.rows = Mp; ap.c_stride = msq; ap.ldc = Mp; ap.nb = Dl; ap.Dl = Dl;
     if (wh) {       // K^-1 Gs K^-1 = W (W^T Gs W) W^T, conjugated step by step (Gs and W^T Gs W are symmetric)
+        if (ref) launch_sub_identity(sk, g.Asum, (double)S, Mp, Dl, g.P2);     // W^T Gs W = sum_s (H_s - I): no products needed
+        else {
         ap.A = g.Gs; ap.B = h->Kuu + msq; ap.b_stride = kstride; ap.C = g.P1; ap.krange = 8;
         launch_atb(sk, ap);                             // P1 = Gs W
         ap.A = h->Kuu + msq; ap.a_stride = kstride; ap.B = g.P1; ap.b_stride = msq; ap.C = g.P2; ap.krange = 4;
         launch_atb(sk, ap);                             // P2 = W^T Gs W
+        }
+        ap.a_stride = msq; ap.b_stride = msq;
         ap.A = g.P2; ap.a_stride = msq; ap.B = h->Linv; ap.C = g.P3; ap.krange = 2;
         launch_atb(sk, ap);                             // P3 = P2 W^T
         ap.A = h->Linv; ap.B = g.P3; ap.C = g.KGK; ap.krange = 1;
@@ -1225,6 +1274,7 @@ static int enqueue_grad_b(ffvd_handle *h, int S_total) {
     launch_e_finish(sk, ek, g.dz_kuu, g.dll_kuu, g.dls_kuu);
     if (sk != s) HIP_TRY(hipEventRecord(h->ev_join, sk));
     if (sk != s) HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));
+    DBG_SYNC(h, "backward: K_uu side");
     launch_dx(s, dx);
     GradFinalArgs gf{};
     gf.T = c.T; gf.D = c.D; gf.P = P; gf.M = c.M; gf.Mp = Mp; gf.Ydim = c.Ydim; gf.Dl = Dl; gf.d_begin = c.d_begin; gf.S = S;
@@ -1232,12 +1282,15 @@ static int enqueue_grad_b(ffvd_handle *h, int S_total) {
     gf.Z = p.Z; gf.logvar = p.logvariance; gf.loglen = p.loglengthscales; gf.log_Q = p.log_Q; gf.CC = p.CC; gf.DD = p.DD;
     gf.log_Rchols = p.log_Rchols; gf.dz_unit = g.dz_unit; gf.dll_unit = g.dll_unit; gf.dls_unit = g.dls_unit;
     gf.dz_kuu = g.dz_kuu; gf.dll_kuu = g.dll_kuu; gf.dls_kuu = g.dls_kuu; gf.gam_part = g.gam_part; gf.ngam = g.ngam;
-    gf.trpart = h->trpart; gf.ntr = h->ntiles; gf.hterms = h->hterms; gf.uku = g.uku; gf.shared_part = g.shared_part;
+    gf.trpart = h->trpart; gf.ntr = h->ntiles; gf.hterms = h->hterms;
+    gf.uku = g.uku; gf.shared_part = g.shared_part;
+    if (ref) { gf.trpart = f32c ? h->sqsum : g.fsq; gf.ntr = 1; }       // sum_t |F_t|^2 per unit (Gram route: tr(K^-1 K_uf K_fu) by tiles)
     gf.sp_stride = g.sp_stride; gf.dZ = g.dZ; gf.dlogvar = g.dlogvar; gf.dloglen = g.dloglen; gf.dlogQ = g.dlogQ;
     gf.dCC = g.dCC; gf.dDD = g.dDD; gf.dlogR = g.dlogR;
     // entries this handle does not own (other ranks' dims; the shared terms off rank 0) stay zero for the all-reduce
     launch_fill(s, g.dlogvar, g.small_count, 0.0);        // dlogvar | dloglen | dlogQ | dCC | dDD | dlogR
     launch_grad_finalize(s, gf);
+    DBG_SYNC(h, "backward: dx + finalize");
     HIP_TRY(hipGetLastError());
     return FFVD_OK;
 }

@@ -49,6 +49,7 @@ void launch_chain_sum(hipStream_t stream, const double *in, size_t in_stride, in
 void launch_psi_e(hipStream_t stream, const double *gsum, const double *kgk, const double *Kcopy, int M, int Mp, int Dl,
                   double jitter, double *Eout);
 void launch_symmetrize(hipStream_t stream, double *A, int Mp, int batch);
+void launch_sub_identity(hipStream_t stream, const double *x, double sc, int Mp, int Dl, double *out);
 void launch_axpby(hipStream_t stream, const double *x, const double *z, double a, double bcoef, const double *log_Q,
                   int d_begin, int scale_mode, size_t n, int Dl, double *out);
 
@@ -67,6 +68,12 @@ struct EReduceArgs {
     int T, Tp, M, Mp, P, Dl, b0, nb, nblk;  // nblk = Tp / 64
     double *rsum, *ez, *kfu;                // [nb][Tp], [nb][Tp][P], [nb][Tp]
     double *cs_part, *etx_part, *rx2_part;  // [nb][nblk][Mp], [nb][nblk][Mp][P], [nb][nblk][P]
+    // fp32-contraction backward (dtype FFVD_F32C): E is not materialised in fp64; it is formed on the fly from the fp32 product
+    // R = K_fu Gamma and the fp32 K_fu,  E_tm = (2 R_tm + alpha delta_t u_m) K_tm,  every sum accumulated in fp64
+    const float *R32, *Kf32;                // [nb] slabs of Tp x Mp (same stride e_stride); R32 != NULL selects this form
+    const double *Xd;                       // [S][T+1][D] latent trajectories (delta_t = x_{t+1,d} - x_{t,d})
+    const double *log_Q;                    // [D]
+    int D, d_begin;
 };
 void launch_e_reduce(hipStream_t stream, const EReduceArgs &a);
 void launch_e_finish(hipStream_t stream, const EReduceArgs &a, double *dz_unit, double *dll_unit, double *dls_unit);

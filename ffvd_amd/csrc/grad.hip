@@ -806,6 +806,18 @@ void launch_axpby(hipStream_t stream, const double *x, const double *z, double a
                        d_begin, scale_mode, n, out);
 }
 
+// out = x - s I on Dl matrices (reference-route backward: sum_s H_s - S I = W^T (alpha sum_s G_s) W)
+__global__ void sub_identity_kernel(const double *x, double sc, int Mp, double *out) {
+    const size_t n = (size_t)Mp * Mp, e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const size_t o = (size_t)blockIdx.y * n + e;
+    out[o] = x[o] - ((e / Mp == e % Mp) ? sc : 0.0);
+}
+void launch_sub_identity(hipStream_t stream, const double *x, double sc, int Mp, int Dl, double *out) {
+    const size_t n = (size_t)Mp * Mp;
+    hipLaunchKernelGGL(sub_identity_kernel, dim3((unsigned)((n + 255) / 256), Dl), dim3(256), 0, stream, x, sc, Mp, out);
+}
+
 // ---------------------------------------------------------------------------------------------
 // E-reduction, stage 1: one workgroup per (64-row block, unit); accumulators stay in registers, the inducing
 // inputs of the current column slice and the x rows of the block sit in LDS.  For its rows t it produces
@@ -813,7 +825,7 @@ void launch_axpby(hipStream_t stream, const double *x, const double *z, double a
 // and the block partials over its rows:  cs[m] = sum_t E_tm,  etx[m][p] = sum_t E_tm x_tp,  rx2[p] = sum_t r_t x_tp^2.
 // x rows: [ x[t][0:x_cols] | ctrl[t][0:C] ] or, for the K_uu side, the inducing inputs themselves.
 // ---------------------------------------------------------------------------------------------
-template <int PM>      // PM: compile-time bound on P (8 or MAXP) so that the per-thread accumulators live in registers
+template <int PM, bool F32>      // PM: compile-time bound on P (8 or MAXP) so that the per-thread accumulators live in registers
 __global__ __launch_bounds__(512) void e_reduce_kernel(EReduceArgs a) {
     constexpr int NT = 512, RW = 8;           // threads, rows per wavefront (8 wavefronts x 8 rows = 64 rows)
     __shared__ double xs[64][PM + 1];
@@ -823,9 +835,19 @@ __global__ __launch_bounds__(512) void e_reduce_kernel(EReduceArgs a) {
     const int blk = blockIdx.x, bz = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = a.b0 + bz, s = b / a.Dl;
     const int t0 = blk * 64, P = a.P, Mp = a.Mp;
-    const double *E = a.E + (size_t)bz * a.e_stride;
-    const double *Kf = a.Kf ? a.Kf + (size_t)bz * a.e_stride : nullptr;
+    const double *E = F32 ? nullptr : a.E + (size_t)bz * a.e_stride;
+    const double *Kf = (!F32 && a.Kf) ? a.Kf + (size_t)bz * a.e_stride : nullptr;
     const double *ub = a.u ? a.u + (size_t)(a.u_per_dim ? b % a.Dl : bz) * a.u_stride : nullptr;
+    // fp32 form: E_tm = (2 R_tm + alpha delta_t u_m) K_tm from the fp32 product and the fp32 K_fu (never stored)
+    const float *R32 = F32 ? a.R32 + (size_t)bz * a.e_stride : nullptr;
+    const float *K32 = F32 ? a.Kf32 + (size_t)bz * a.e_stride : nullptr;
+    const int dgf = F32 ? a.d_begin + b % a.Dl : 0;
+    const double alphaf = F32 ? 1.0 / exp(a.log_Q[dgf]) : 0.0;
+    const double *Xdf = F32 ? a.Xd + (size_t)s * (a.T + 1) * a.D : nullptr;
+    auto adelta = [&](int t) { return alphaf * (Xdf[(size_t)(t + 1) * a.D + dgf] - Xdf[(size_t)t * a.D + dgf]); };
+    auto e32 = [&](int t, int m, double ad) {
+        return (2.0 * (double)R32[(size_t)t * Mp + m] + ad * ub[m]) * (double)K32[(size_t)t * Mp + m];
+    };
     const double *Zd = a.Z;                                          // unscaled inducing inputs M x P
     for (int idx = tid; idx < 64 * P; idx += NT) {                   // x rows of this block
         const int r = idx / P, p = idx % P, t = t0 + r;
@@ -857,13 +879,15 @@ __global__ __launch_bounds__(512) void e_reduce_kernel(EReduceArgs a) {
         for (int rr = 0; rr < RW; ++rr) {
             const int t = t0 + wave * RW + rr;
             if (t < a.T) {
+                const double adt = F32 ? adelta(t) : 0.0;
 #pragma unroll
                 for (int q = 0; q < NT / 64; ++q) {
                     const int mm = lane + 64 * q, m = m0 + mm;
                     if (m < a.M) {
-                        const double e = E[(size_t)t * Mp + m];
+                        const double e = F32 ? e32(t, m, adt) : E[(size_t)t * Mp + m];
                         rs[rr] += e;
-                        if (Kf) kf[rr] += Kf[(size_t)t * Mp + m] * ub[m];
+                        if (F32) kf[rr] += (double)K32[(size_t)t * Mp + m] * ub[m];
+                        else if (Kf) kf[rr] += Kf[(size_t)t * Mp + m] * ub[m];
 #pragma unroll
                         for (int p = 0; p < PM; ++p)
                             if (p < P) ez[rr][p] += e * zsm[mm][p];
@@ -882,8 +906,8 @@ __global__ __launch_bounds__(512) void e_reduce_kernel(EReduceArgs a) {
                     double e8[8];
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
-                        const int t = t0 + r0 + k;
-                        e8[k] = E[(size_t)(t < a.T ? t : t0) * Mp + m];
+                        const int t = t0 + r0 + k, tc = t < a.T ? t : t0;
+                        e8[k] = F32 ? e32(tc, m, adelta(tc)) : E[(size_t)tc * Mp + m];
                     }
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
@@ -932,8 +956,11 @@ __global__ __launch_bounds__(512) void e_reduce_kernel(EReduceArgs a) {
     }
 }
 void launch_e_reduce(hipStream_t stream, const EReduceArgs &a) {
-    if (a.P <= 8) hipLaunchKernelGGL(e_reduce_kernel<8>, dim3(a.nblk, a.nb), dim3(512), 0, stream, a);
-    else hipLaunchKernelGGL(e_reduce_kernel<MAXP>, dim3(a.nblk, a.nb), dim3(512), 0, stream, a);
+    if (a.R32) {
+        if (a.P <= 8) hipLaunchKernelGGL((e_reduce_kernel<8, true>), dim3(a.nblk, a.nb), dim3(512), 0, stream, a);
+        else hipLaunchKernelGGL((e_reduce_kernel<MAXP, true>), dim3(a.nblk, a.nb), dim3(512), 0, stream, a);
+    } else if (a.P <= 8) hipLaunchKernelGGL((e_reduce_kernel<8, false>), dim3(a.nblk, a.nb), dim3(512), 0, stream, a);
+    else hipLaunchKernelGGL((e_reduce_kernel<MAXP, false>), dim3(a.nblk, a.nb), dim3(512), 0, stream, a);
 }
 
 // E-reduction, stage 2: one workgroup per unit.  Sums the block partials in fixed order and forms

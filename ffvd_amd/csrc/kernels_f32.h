@@ -15,9 +15,15 @@ struct ProjF32Args {
     const float *LinvT;     // [Dl][Mp][Mp] L^-1 (row j = column j of L^-T)
     float *F;               // [nb][Tp][Mp] F = K_fu L^-T
     size_t f_stride;
-    double *sqpart;         // [nbatch_total][proj_f32_ntiles] per-tile sums of F^2 (fp64)
+    double *sqpart;         // [nbatch_total][proj_f32_ntiles] per-tile sums of F^2 (fp64); NULL = not wanted
     int Tp, Mp, Dl, b0, nb;
+    // backward pass: the right operand is a FULL symmetric Mp x Mp matrix per UNIT (Gamma, rounded to fp32) instead of the
+    // per-dim triangular L^-1:  F = K_fu Gamma  (the fp32 half of dl/dK_fu = 2 K_fu Gamma + delta (alpha u)^T)
+    const float *Bunit;     // [nb][Mp][Mp] or NULL
+    size_t bunit_stride;
 };
+// out[i] = (float)in[i]
+void launch_to_f32(hipStream_t stream, const double *in, float *out, size_t n);
 int proj_f32_ntiles(int Tp, int Mp);
 void launch_proj_gemm_f32(hipStream_t stream, const ProjF32Args &a);
 void launch_sum_partials(hipStream_t stream, const double *part, int n, int nb, double *out);

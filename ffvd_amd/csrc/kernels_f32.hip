@@ -173,11 +173,12 @@ __global__ __launch_bounds__(256, FFVD_F32_OCC) void proj_gemm_f32_kernel(ProjF3
     const int Mp = a.Mp, Tp = a.Tp;
     const int b = a.b0 + bz, dl = b % a.Dl;
     const float *Kfb = a.Kf + (size_t)bz * a.kf_stride;
-    const float *Wb = a.LinvT + (size_t)dl * Mp * Mp;
-    const int kend = ((tj + 1) * 128 < Mp) ? (tj + 1) * 128 : Mp;
+    const bool full = a.Bunit != nullptr;                   // full symmetric right operand per unit (backward pass)
+    const float *Wb = full ? a.Bunit + (size_t)bz * a.bunit_stride : a.LinvT + (size_t)dl * Mp * Mp;
+    const int kend = (!full && (tj + 1) * 128 < Mp) ? (tj + 1) * 128 : Mp;
     const int nchunk = kend / PK;
     // inside the diagonal k-block a wavefront stops at its own last column (W[k][j] = 0 for k > j)
-    const int my_chunks = ((tj * 128 + wc * 64 + 64 < kend) ? tj * 128 + wc * 64 + 64 : kend) / PK;
+    const int my_chunks = full ? nchunk : ((tj * 128 + wc * 64 + 64 < kend) ? tj * 128 + wc * 64 + 64 : kend) / PK;
 
     // staging: a row of the k-tile is PK / 4 lanes x 16 bytes; thread moves rows sr + SROWS i, columns sc of each operand
     constexpr int LPR = PK / 4, SROWS = 256 / LPR, NPASS = 128 / SROWS;
@@ -254,7 +255,15 @@ __global__ __launch_bounds__(256, FFVD_F32_OCC) void proj_gemm_f32_kernel(ProjF3
     for (int m = 32; m > 0; m >>= 1) ssq += __shfl_xor(ssq, m);
     if (lane == 0) red[wave] = ssq;
     __syncthreads();
-    if (tid == 0) a.sqpart[(size_t)b * (nti * ntj) + (size_t)tj * nti + ti] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (tid == 0 && a.sqpart) a.sqpart[(size_t)b * (nti * ntj) + (size_t)tj * nti + ti] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void to_f32_kernel(const double *in, float *out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = (float)in[i];
+}
+void launch_to_f32(hipStream_t stream, const double *in, float *out, size_t n) {
+    const size_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(to_f32_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, stream, in, out, n);
 }
 int proj_f32_ntiles(int Tp, int Mp) { return ((Tp + 127) / 128) * ((Mp + 127) / 128); }
 void launch_proj_gemm_f32(hipStream_t stream, const ProjF32Args &a) {
