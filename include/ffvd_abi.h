@@ -39,9 +39,12 @@ extern "C" {
  * T x M x M products F = K_fu L^-T (:242), F^T F (:246) in fp32 on v_mfma_f32_32x32x2_f32; K_uu, every M x M
  * factorisation and solve (:159-166, :253-254), H from the moment it leaves the matrix cores, delta^T F (:247-248) and
  * the sum of F^2 in the trace term (:255) in fp64.  All inputs and outputs of the ABI stay fp64.  Collapsed branch,
- * FFVD_ROUTE_REFERENCE, no gradient (the Gram route's error is eps * cond(K_uu): unusable in fp32).
+ * FFVD_ROUTE_REFERENCE (the Gram route's error is eps * cond(K_uu): unusable in fp32).
  * Measured against the fp64 oracle: every term and the nll within 1e-5 absolute (worst case 5.5e-6 with M = 1100 inducing
- * points for T = 1400; 2e-7 relative on the nll at T=16384, M=2048) -- tests/test_gpu_f32c.py. */
+ * points for T = 1400; 2e-7 relative on the nll at T=16384, M=2048) -- tests/test_gpu_f32c.py.
+ * With grad = 1 the backward pass forms its T x M x M product K_fu Gamma in fp32 as well (Gamma rounded once; dl/dK_fu is never
+ * stored, the reductions run in fp64): gradients within 1e-3 (X) / 1e-2 (Z, kernel hyper-parameters) of the largest entry of each
+ * array, measured 9e-5 / 3.5e-3 -- what one fp32 product of K_fu with Gamma ~ alpha |L^-T|^2 gives; config 4 trains with it. */
 #define FFVD_F32C 1
 
 #define FFVD_KERNEL_SE      0   /* kernels_multi_output.py:140-247 SquaredExponential (ARD) */
@@ -147,7 +150,7 @@ int  ffvd_elbo(ffvd_handle *h, const ffvd_params *p, uint32_t flags, double out_
 int  ffvd_elbo_async(ffvd_handle *h, double *out_terms_dev);
 /* Gradient of the mean-over-chains nll w.r.t. every parameter (what the reference gets from tf.gradients(nll, vars),
  * base_model.py:148, and AdamOptimizer.minimize(nll), dgp_model.py:303-305).  Needs a handle created with
- * grad = 1: the collapsed branch with the SE kernel and FFVD_ROUTE_GRAM, or the explicit-U branch with either kernel
+ * grad = 1: the collapsed branch with the SE kernel (either route; FFVD_F32C too), or the explicit-U branch with either kernel
  * (LinearK: the loglengthscales gradient is identically zero -- the kernel has none).  Host output pointers with
  * the shapes of ffvd_params; any of them may be NULL.  S_total = number of chains of the whole job (the divisor of
  * the mean).  Sharded jobs: every output is this handle's ADDITIVE share of the whole-job gradient -- entries of
