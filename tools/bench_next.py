@@ -23,6 +23,33 @@ with ElboEngine(T, D, C, M, S, route="gram", grad=True) as e:
     for _ in range(20): last = e.adam_step(lr)["nll"]
     out["adam_step_ms"] = (time.perf_counter() - t0) / 20 * 1e3
     out["nll_first"], out["nll_after_21_steps"] = first, last
+# round 3: training in the reference's op order (fp64 and fp32 contractions), and the sharded step of a 16-chain rank
+for name, kw in (("reference_route", dict(route="reference")), ("f32c", dict(dtype="f32c"))):
+    with ElboEngine(T, D, C, M, S, grad=True, **kw) as e:
+        e.set_data(Y, c); e.set_params(params)
+        first = e.adam_step(lr)["nll"]
+        t0 = time.perf_counter()
+        for _ in range(10): last = e.adam_step(lr)["nll"]
+        out[f"adam_step_{name}_ms"] = (time.perf_counter() - t0) / 10 * 1e3
+        out[f"nll_{name}_first_and_after_11_steps"] = [first, last]
+from ffvd_amd.distributed import ShardedElbo
+p16, Y16, c16, m16 = synthetic.make_named("c2", S=16)
+sh = ShardedElbo(p16, Y16, c16, m16, rank=0, world=1, mode="chains", device=0, always_reduce=True, route="gram", grad=True)
+try:
+    sh.adam_step(lr)
+    t0 = time.perf_counter()
+    for _ in range(20): sh.adam_step(lr)
+    out["sharded_adam_step_16_chain_rank_ms"] = (time.perf_counter() - t0) / 20 * 1e3
+    out["sharded_adam_step_note"] = ("one rank's share of an 8-rank... here a 2-rank job's 16 chains: forward + backward + ONE ncclAllReduce of the "
+                                     "gradient block in HBM (1-rank communicator) + fused Adam; ffvd_adam_step_allreduce")
+    with ElboEngine(T, D, C, M, 16, route="gram", grad=True) as e:
+        e.set_data(Y16, c16); e.set_params(p16)
+        e.adam_step(lr)
+        t0 = time.perf_counter()
+        for _ in range(20): e.adam_step(lr)
+        out["plain_adam_step_16_chains_ms"] = (time.perf_counter() - t0) / 20 * 1e3
+finally:
+    sh.close()
 kern = [SquaredExponential(D + C, variance=np.exp(params["logvariance"][d]), lengthscales=np.exp(params["loglengthscales"][d]))
         for d in range(D)]
 X = params["X"][0]

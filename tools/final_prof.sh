@@ -1,6 +1,6 @@
 set -e
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/r3z
+OUT=$R/gpurun_out/${TAG:-r3final}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $OUT/bench_c2.json 2> $OUT/bench_c2.err
