@@ -130,6 +130,10 @@ VARIANTS = {
     "dfstall": ["-DFFVD_DF_TEST_STALL"],
     # wall-clock stamps inside the dataflow Cholesky (tools/df_trace.py)
     "dftrace": ["-DFFVD_DF_TRACE"],
+    # A/B builds (tools/ab.sh) of the round-3 Gram schedule: without the tail split / without combos and tail split (= round 2)
+    "notail": ["-DGRAM_TAIL_SPLIT=0"],
+    "r2gram": ["-DGRAM_COMBO=0", "-DGRAM_TAIL_SPLIT=0"],
+    "dftrace_notail": ["-DFFVD_DF_TRACE", "-DGRAM_TAIL_SPLIT=0"],
 }
 
 

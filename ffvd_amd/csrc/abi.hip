@@ -37,6 +37,9 @@ struct ffvd_handle {
     double *gpart = nullptr;                     // split-K partial tiles of the Gram kernel (few units per pass)
     int gsplit = 1;
     double *graw = nullptr;                      // unsplit first pass: raw Gram tiles for the deferred trace pass
+    double *gtail = nullptr;                     // unsplit passes: blocks + counters of the tail split (kernels.h GramArgs)
+    int gtail_wg = 0;
+    double *growpart = nullptr;                  // Gram route: per-64-row-block partial sums of delta^T K_fu from the K_fu build
     hipStream_t aux = nullptr;          // side stream: the K_uu chain runs beside the K_fu build (Gram route)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_kuu = nullptr, ev_tiles = nullptr, ev_go = nullptr;
     std::string err;
@@ -364,6 +367,13 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
     if (c.branch == FFVD_BRANCH_B && c.dtype != FFVD_F32C) {
         const int upass = h->cpp * (int)Dl;
         h->gsplit = gram_ksplit((int)Mp, upass, (int)Tp);
+        const bool ext_row = c.route == FFVD_ROUTE_GRAM && c.T_total == 0;      // the K_fu build forms delta^T K_fu: the Gram kernel has no row
+        if (ext_row) HIP_TRY(dev_alloc(h, &h->growpart, (size_t)upass * (Tp / 64) * Mp));
+        h->gtail_wg = gram_tail_wg((int)Mp, upass, h->gsplit, ext_row ? 0 : 1);
+        if (h->gtail_wg > 0) {
+            HIP_TRY(dev_alloc(h, &h->gtail, gram_tail_doubles(h->gtail_wg)));
+            HIP_TRY(hipMemsetAsync(h->gtail, 0, gram_tail_doubles(h->gtail_wg) * sizeof(double), h->stream));   // counters start at 0
+        }
         if (h->gsplit > 1) HIP_TRY(dev_alloc(h, &h->gpart, gram_part_doubles((int)Mp, upass, h->gsplit)));
         else if (c.route == FFVD_ROUTE_GRAM && h->sw.kuu_flow && (size_t)upass * Tp * Mp >= (size_t)128 * 4096 * 512)
             // a K_fu build of 0.4 ms or more: the K_uu chain as ONE dataflow launch finishes beside it, the main stream
@@ -579,19 +589,28 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
         pa.rowsq = h->rowsq;
         pa.fmean = (c.branch == FFVD_BRANCH_A) ? h->fmean : nullptr;
         pa.ng = h->ng;
+        pa.gpart = gram_route ? h->growpart : nullptr;      // Gram route: delta^T K_fu is summed where K_fu is made
         return pa;
     };
     auto gram_args = [&](int s0, int ns) {
         GramArgs ga{};
         ga.mode = gram_route ? GRAM_KFU : GRAM_F;
-        ga.A = h->F; ga.a_stride = (size_t)Tp * Mp; ga.rows = Tp; ga.with_row = 1;
+        ga.A = h->F; ga.a_stride = (size_t)Tp * Mp; ga.rows = Tp; ga.with_row = (gram_route && h->growpart) ? 0 : 1;
         ga.X = p.X; ga.log_Q = p.log_Q; ga.T = c.T; ga.D = c.D; ga.Mp = Mp; ga.Dl = Dl;
         ga.d_begin = c.d_begin; ga.b0 = s0 * Dl; ga.nb = ns * Dl; ga.yn_over_batch = 1.0;
         ga.H = h->H; ga.h_stride = (size_t)(c.grad ? 2 * Mp + NB : Mp + NB) * Mp;
         if (c.grad) ga.brow = 2 * Mp;   // rows [Mp, 2Mp) hold I (they become L_A^-T), the b row moves to 2 Mp
         ga.Kadd = h->Kcopy; ga.kadd_stride = msq; ga.Kinv = h->Kinv; ga.kinv_stride = msq; ga.trpart = h->trpart;
         if (h->gpart) { ga.ksplit = h->gsplit; ga.part = h->gpart; }     // same row ranges in every pass of this handle
+        // tail split of the last partial round (full passes only: launch_gram drops it when the unit count differs)
+        if (h->gtail) { ga.tail_wg = h->gtail_wg; ga.tail_part = h->gtail; }
         return ga;
+    };
+    // Gram route: the row b = delta^T K_fu / Q of a pass, from the partial sums its K_fu build left behind (kernels.h ProjectArgs::gpart)
+    auto brow_finish = [&](int s0, int ns) {
+        if (!h->growpart) return;
+        launch_brow_finish(s, h->growpart, Tp / 64, Mp, Dl, c.d_begin, s0 * Dl, ns * Dl, p.log_Q, 1.0, h->H,
+                           (size_t)(c.grad ? 2 * Mp + NB : Mp + NB) * Mp, c.grad ? 2 * Mp : Mp);
     };
     auto reduce_args = [&]() {
         ReduceArgs ra{};
@@ -660,6 +679,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
         if (kfu_first) {
             if (st) st->mark(0);
             launch_kfu_build(s, project_args(0, ns_first));
+            brow_finish(0, ns_first);
             if (st) st->mark(1);
         }
         if (main_first) {
@@ -722,7 +742,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
         const int ns = (s0 + h->cpp <= c.S_local) ? h->cpp : c.S_local - s0;
         ProjectArgs pa = project_args(s0, ns);
         if (gram_route) {
-            if (!(kfu_first && s0 == 0)) launch_kfu_build(s, pa);
+            if (!(kfu_first && s0 == 0)) { launch_kfu_build(s, pa); brow_finish(s0, ns); }
             if (s0 == 0 && sk != s && !late_join) HIP_TRY(hipStreamWaitEvent(s, defer_full ? h->ev_kuu : h->ev_join, 0));
         } else if (c.dtype == FFVD_F32C) {
             if (s0 == 0) launch_linv_f32(s, h->Kuu + msq, kstride, h->Linv32, Mp, Dl);     // L^-1 as the fp32 B operand

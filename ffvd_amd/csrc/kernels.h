@@ -99,7 +99,15 @@ struct ProjectArgs {
     double *rowsq;          // [nbatch_total][ng][Tp] or null   (sum_j F[t][j]^2 per column group)
     double *fmean;          // [nbatch_total][ng][Tp] or null   (sum_j F[t][j] * U[j][d])
     int ng;                 // column groups = ceil(Mp / 512)
+    // kfu_build only, optional: per 64-row block the partial sums of delta^T K_fu (delta_t = x_{t+1,d} - x_{t,d} of the unit's own
+    // latent dim; conditionals_multi_output.py:247-248), [nb][Tp / 64][Mp]; launch_brow_finish adds the blocks in fixed order.
+    // (Round 3: the Gram kernel used to form this row beside its matrix work -- in idle wavefronts of the diagonal tiles; with
+    // the diagonal tiles dealt to fully loaded workgroups there are none, and the vector FMAs cost it 0.47 ms.)
+    double *gpart;
 };
+// H[bz] row `brow` (ld Mp) = (yn_over_batch / Q_d) * sum over the 64-row blocks of gpart (fixed order)
+void launch_brow_finish(hipStream_t stream, const double *gpart, int nblk, int Mp, int Dl, int d_begin, int b0, int nb,
+                        const double *log_Q, double yn_over_batch, double *H, size_t h_stride, int brow);
 // F = K_fu * L^{-T} with K_fu generated on the fly (never stored).
 void launch_project(hipStream_t stream, const ProjectArgs &a);
 // a.F[bz][t][m] = K_fu itself (route K_uu + K_uf K_fu / Q); uses x, ctrl, hv, T, Tp, M, Mp, b0, nb of `a`.
@@ -139,6 +147,18 @@ struct GramArgs {
     // combine pass only: 0 = epilogue + trace partials, 1 = epilogue without the trace (K^-1 not read), 2 = trace partials
     // only (H not written) -- lets the combine run before K^-1 exists and the trace follow on another stream
     int trace_mode;
+    // Round 3, unsplit launches with Mp a multiple of 512: (1) the four diagonal tiles of every group of four column panels are
+    // dealt to THREE workgroups of eight full 64 x 32 sub-blocks each ("combos", gram_combo_body) instead of four workgroups
+    // that each leave two wavefronts without matrix work -- wg_per_unit = workgroups per unit (filled by launch_gram);
+    // (2) the workgroups of the LAST, partial round of the launch are cut into two row halves that run side by side on the
+    // CUs that free up first; the half that finishes second adds the other's accumulators (two addends: the sum does not
+    // depend on which one that is) and runs the epilogue.  tail_wg = workgroups cut (multiple of 8, 0 = off), tail_part =
+    // [tail_wg][2] blocks of GRAM_TAIL_DOUBLES followed by [tail_wg] arrival counters (zero between launches: the second
+    // arrival re-arms its counter).
+    int combo, wg_per_unit;
+    int tail_wg;
+    double *tail_part;
+    int *tail_cnt;
 };
 int gram_ntiles(int Mp);
 // how many row ranges launch_gram should use for `nb` units (1 = no split), and the doubles `part` then needs
@@ -146,6 +166,11 @@ int gram_ksplit(int Mp, int nb, int rows);
 size_t gram_part_doubles(int Mp, int nb, int ksplit);
 // phase 0: everything; 1: tile pass only; 2: combine pass only; 3: trace-only combine pass (split-K launches);
 // 4: combine pass (epilogue + trace) over `part` whatever ksplit is (T-shards: the all-reduced raw tiles, ksplit = 1)
+constexpr int GRAM_TAIL_DOUBLES = 34 * 512;       // per thread: 32 accumulator values + two partial sums of the delta^T A row
+// workgroups of the last partial round of an unsplit launch over nb units that gram_kernel cuts in two (0 = none), and the
+// scratch a handle needs for them (doubles, counters included)
+int gram_tail_wg(int Mp, int nb, int ksplit, int with_row);
+size_t gram_tail_doubles(int tail_wg);
 void launch_gram(hipStream_t stream, GramArgs a, int phase = 0);
 
 // hterms[b] = { logdet(H) = 2 sum log diag(L_H),  b^T H^{-1} b = |row Mp|^2 } after launch_potrf_ext on H.

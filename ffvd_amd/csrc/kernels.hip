@@ -225,9 +225,16 @@ __global__ __launch_bounds__(256) void kfu_build_kernel(ProjectArgs a) {
     __shared__ __attribute__((aligned(16))) double xr8[SMALLP ? 64 : 1][8];
     __shared__ double xx[64];
     __shared__ double zs[64][(SMALLP ? 8 : MAXP) + 1];
+    __shared__ double dlt[64];                  // delta_t of this block's rows (gpart != null)
+    __shared__ double gsum[4][64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int t0 = blockIdx.x * 64, m0 = blockIdx.y * 64, bz = blockIdx.z;
     const int b = a.b0 + bz, s = b / a.Dl, dl = b % a.Dl;
+    if (a.gpart && tid < 64) {
+        const int t = t0 + tid, dg = a.d_begin + dl;
+        const double *xc = a.x + (size_t)s * a.x_chain_stride;
+        dlt[tid] = (t < a.T) ? xc[(size_t)(t + 1) * a.x_ld + dg] - xc[(size_t)t * a.x_ld + dg] : 0.0;     // :247
+    }
     const int P = a.P, Mp = a.Mp;
     const double var = a.hv.variance[dl];
     for (int p = tid >> 6; p < (SMALLP ? 8 : P); p += 4) {
@@ -260,6 +267,8 @@ __global__ __launch_bounds__(256) void kfu_build_kernel(ProjectArgs a) {
 #pragma unroll
     for (int p = 0; p < 8; ++p) zr[p] = (SMALLP || p < P) ? zs[lane][p] : 0.0;
     const int rbase = (tid >> 6) * 16;
+    const bool want_g = a.gpart != nullptr;
+    double gacc = 0.0;
     auto rows = [&](auto edge_tag) {             // interior tiles skip the per-element range selects
         constexpr bool EDGE = decltype(edge_tag)::value;
 #pragma unroll 4
@@ -282,10 +291,39 @@ __global__ __launch_bounds__(256) void kfu_build_kernel(ProjectArgs a) {
             double v = kernel_value<KIND>(dot, xx[r], zzv, var);
             if (EDGE && (!mok || t0 + r >= a.T)) v = 0.0;
             out[(size_t)r * Mp] = v;
+            if (want_g) gacc = fma(dlt[r], v, gacc);
         }
     };
     if (t0 + 64 > a.T || m0 + 64 > a.M) rows(std::true_type{});
     else rows(std::false_type{});
+    if (want_g) {                               // the four row groups of a column, added in fixed order
+        gsum[tid >> 6][lane] = gacc;
+        __syncthreads();
+        if (tid < 64)
+            a.gpart[((size_t)bz * (a.Tp / 64) + blockIdx.x) * Mp + m0 + tid] = (gsum[0][tid] + gsum[1][tid]) + (gsum[2][tid] + gsum[3][tid]);
+    }
+}
+
+__global__ __launch_bounds__(256) void brow_finish_kernel(const double *gpart, int nblk, int Mp, int Dl, int d_begin, int b0,
+                                                          const double *log_Q, double yn_over_batch, double *H, size_t h_stride, int brow) {
+    const int m = blockIdx.x * 256 + threadIdx.x, bz = blockIdx.y;
+    if (m >= Mp) return;
+    const double *g = gpart + (size_t)bz * nblk * Mp + m;
+    double acc = 0.0;
+    for (int k0 = 0; k0 < nblk; k0 += 8) {      // eight independent loads in flight, one fixed summation order
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (k0 + k < nblk) ? g[(size_t)(k0 + k) * Mp] : 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc += v[k];
+    }
+    const int dg = d_begin + (b0 + bz) % Dl;
+    H[(size_t)bz * h_stride + (size_t)brow * Mp + m] = acc * (yn_over_batch / exp(log_Q[dg]));
+}
+void launch_brow_finish(hipStream_t stream, const double *gpart, int nblk, int Mp, int Dl, int d_begin, int b0, int nb,
+                        const double *log_Q, double yn_over_batch, double *H, size_t h_stride, int brow) {
+    hipLaunchKernelGGL(brow_finish_kernel, dim3((Mp + 255) / 256, nb), dim3(256), 0, stream, gpart, nblk, Mp, Dl, d_begin, b0, log_Q,
+                       yn_over_batch, H, h_stride, brow);
 }
 void launch_kfu_build(hipStream_t stream, const ProjectArgs &a) {
     dim3 grid(a.Tp / 64, a.Mp / 64, a.nb);
@@ -1909,10 +1947,14 @@ constexpr int G_LD = 128 + 16;      // LDS row stride (doubles): lanes l and l+1
 __device__ __constant__ unsigned char GRAM_DIAG_WR[8] = {1, 1, 1, 1, 0, 0, 0, 0};
 __device__ __constant__ unsigned char GRAM_DIAG_WC[8] = {0, 1, 2, 3, 0, 1, 2, 3};
 
+__device__ __forceinline__ bool gram_tail_exchange(const GramArgs &a, const int tail_id, const int half, const bool active,
+                                                   d4 (&acc)[4][2], double &bs0, double &bs1, int *tail_slot);
+
 template <int MODE, bool DIAG>
 __device__ __forceinline__ void gram_body(const GramArgs a, const int bz, const int ti, const int tj, const int tile,
                                           const int kpart, const int ksplit, double (*As)[GT][G_LD],
-                                          double (*Bs)[GT][G_LD], double (*dls)[GT], double *red) {
+                                          double (*Bs)[GT][G_LD], double (*dls)[GT], double *red, const int tail_id = -1,
+                                          int *tail_slot = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = DIAG ? GRAM_DIAG_WR[wave] : (wave >> 2), wc = DIAG ? GRAM_DIAG_WC[wave] : (wave & 3);
@@ -1983,7 +2025,8 @@ __device__ __forceinline__ void gram_body(const GramArgs a, const int bz, const 
     double bsum = 0.0;
 
     const int nchunk_all = a.rows / GT;
-    const int per = (nchunk_all + ksplit - 1) / ksplit;
+    const int nrange = (tail_id >= 0) ? 2 : ksplit;                   // a tail workgroup is one of two row halves (kpart = the half)
+    const int per = (nchunk_all + nrange - 1) / nrange;
     const int cbeg = kpart * per;
     const int nchunk = (cbeg + per <= nchunk_all) ? cbeg + per : nchunk_all;      // this range: chunks [cbeg, nchunk)
     gload(cbeg);
@@ -2025,6 +2068,10 @@ __device__ __forceinline__ void gram_body(const GramArgs a, const int bz, const 
         __syncthreads();
     }
 
+    if (tail_id >= 0) {
+        double unused = 0.0;
+        if (!gram_tail_exchange(a, tail_id, kpart, active, acc, bsum, unused, tail_slot)) return;
+    }
     if (ksplit > 1) {            // raw partial sums of this row range; gram_combine finishes the job
         double *Pb = a.part + ((size_t)kpart * a.nb + bz) * ((size_t)(Mp + 1) * Mp);
         if (active) {
@@ -2094,6 +2141,249 @@ __device__ __forceinline__ void gram_body(const GramArgs a, const int bz, const 
     }
 }
 
+// Row half of a tail workgroup (GramArgs::tail_wg): leave the accumulators in memory, count in, and -- if the other half has
+// counted in before -- add its values and carry on (returns true); else done (returns false).  Nobody waits.  The blocks are
+// stored WRITE-THROUGH (sc1, relaxed agent-scope atomic stores) so that no release fence is needed -- an agent-scope release
+// writes back the XCD L2's dirty lines, which with 135 KB per half and the chip streaming K_fu made a half last twice its time;
+// the reader's ONE acquire invalidates its CU's L1 and then loads plainly (MI355X guide, inter-workgroup visibility: sc1 payload
+// stores, every storing wavefront's vmcnt(0), the workgroup's barrier, one lane's relaxed agent-scope add).
+__device__ __forceinline__ bool gram_tail_exchange(const GramArgs &a, const int tail_id, const int half, const bool active,
+                                                   d4 (&acc)[4][2], double &bs0, double &bs1, int *tail_slot) {
+    typedef __attribute__((address_space(1))) double gdouble;
+    const int tid = threadIdx.x;
+    gdouble *Pm = (gdouble *)(a.tail_part + ((size_t)tail_id * 2 + half) * GRAM_TAIL_DOUBLES);
+    const double *Po = a.tail_part + ((size_t)tail_id * 2 + (half ^ 1)) * GRAM_TAIL_DOUBLES;
+    if (active) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    __hip_atomic_store(Pm + (size_t)((x * 2 + y) * 4 + q) * 512 + tid, acc[x][y][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __hip_atomic_store(Pm + (size_t)32 * 512 + tid, bs0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(Pm + (size_t)33 * 512 + tid, bs1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wavefront's block has left it
+    __syncthreads();
+    if (tid == 0) {
+        const int seen = __hip_atomic_fetch_add(a.tail_cnt + tail_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (seen == 1) {                                         // the other half is complete and in memory
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(a.tail_cnt + tail_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the next launch
+        }
+        *tail_slot = seen;
+    }
+    __syncthreads();
+    if (*tail_slot != 1) return false;
+    // (a + b is the same number whichever half is `a`: the result does not depend on the order of arrival)
+    if (active) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[x][y][q] += Po[(size_t)((x * 2 + y) * 4 + q) * 512 + tid];
+    }
+    bs0 += Po[(size_t)32 * 512 + tid];
+    bs1 += Po[(size_t)33 * 512 + tid];
+    return true;
+}
+
+// "Combo" workgroups: the 24 sub-blocks (64 x 32) of the four diagonal tiles of a group of four column panels b .. b + 3, dealt
+// to three workgroups of eight -- every wavefront a full sub-block, every SIMD two matrix wavefronts, as in an off-diagonal tile:
+//   type 0 (panels b, b+1 in LDS):     tile (b,b) complete (6)                + rows 0-63 of tile (b+1,b+1) (2)
+//   type 1 (panels b+1, b+2):          rows 64-127 of tile (b+1,b+1) (4)      + rows 64-127 of tile (b+2,b+2) (4)
+//   type 2 (panels b+2, b+3):          rows 0-63 of tile (b+2,b+2) (2)        + tile (b+3,b+3) complete (6)
+// (gram_body<.., true> gives a diagonal tile's six sub-blocks to six wavefronts: SIMDs 0 and 1 carry two matrix wavefronts, SIMDs
+// 2 and 3 one, the tile lasts as long as an off-diagonal one -- 1085 vs 1091 us, tools/gram_rounds.py -- and what SIMDs 2 and 3
+// have to spare nobody can use.)  The row delta^T A of a panel is formed by the vector units of the workgroup that has the
+// panel in LDS anyway: type 0 panel b, type 1 panels b+1 and b+2, type 2 panel b+3.
+// entry = buffer (0 = first panel, 1 = second) << 3 | row half << 2 | column quarter
+__device__ __constant__ unsigned char GRAM_COMBO_ROLE[3][8] = {
+    {0 << 3 | 1 << 2 | 0, 0 << 3 | 1 << 2 | 1, 0 << 3 | 1 << 2 | 2, 0 << 3 | 1 << 2 | 3, 0 << 3 | 0 << 2 | 0, 0 << 3 | 0 << 2 | 1, 1 << 3 | 0 << 2 | 0, 1 << 3 | 0 << 2 | 1},
+    {0 << 3 | 1 << 2 | 0, 0 << 3 | 1 << 2 | 1, 0 << 3 | 1 << 2 | 2, 0 << 3 | 1 << 2 | 3, 1 << 3 | 1 << 2 | 0, 1 << 3 | 1 << 2 | 1, 1 << 3 | 1 << 2 | 2, 1 << 3 | 1 << 2 | 3},
+    {0 << 3 | 0 << 2 | 0, 0 << 3 | 0 << 2 | 1, 1 << 3 | 1 << 2 | 0, 1 << 3 | 1 << 2 | 1, 1 << 3 | 1 << 2 | 2, 1 << 3 | 1 << 2 | 3, 1 << 3 | 0 << 2 | 0, 1 << 3 | 0 << 2 | 1}};
+
+template <int MODE>
+__device__ __forceinline__ void gram_combo_body(const GramArgs a, const int bz, const int pbase, const int type, const int tail_id,
+                                                const int half, double (*As)[GT][G_LD], double (*Bs)[GT][G_LD],
+                                                double (*dls)[GT], double *red, int *tail_slot) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lk = lane >> 4;
+    const int Mp = a.Mp;
+    const int b = a.b0 + bz, s = b / a.Dl, dl = b % a.Dl, dg = a.d_begin + dl;
+    const int pa = pbase + type, pb = pbase + type + 1;                  // the two panels this workgroup stages
+    const int role = __builtin_amdgcn_readfirstlane((int)GRAM_COMBO_ROLE[type][wave]);
+    const int rbuf = role >> 3, rh = (role >> 2) & 1, rq = role & 3;
+    const int panel = rbuf ? pb : pa;
+    const int I0 = panel * 128 + rh * 64, J0 = panel * 128 + rq * 32;   // Mp % 512 == 0: every sub-block is real
+    const int r0 = rh * 64, c0 = rq * 32;                               // offsets inside the staged panel
+
+    const double *Ab = a.A + (size_t)bz * a.a_stride;
+    const double *Xs = (a.with_row && !(MODE == GRAM_PLAIN && a.rvec)) ? a.X + (size_t)s * (a.T + 1) * a.D : nullptr;
+    const int colA = pa * 128 + 2 * lane, colB = pb * 128 + 2 * lane;
+    const int rowl = tid >> 6;   // 0..7
+    double2 ra0, ra1, rb0, rb1;
+    double d1 = 0.0, d0 = 0.0;
+    bool dok = false;
+    auto gload = [&](int c) {
+        const double *row0 = Ab + ((size_t)c * GT + rowl) * Mp, *row1 = row0 + (size_t)8 * Mp;
+        ra0 = *reinterpret_cast<const double2 *>(row0 + colA);
+        rb0 = *reinterpret_cast<const double2 *>(row0 + colB);
+        ra1 = *reinterpret_cast<const double2 *>(row1 + colA);
+        rb1 = *reinterpret_cast<const double2 *>(row1 + colB);
+        if (a.with_row) {
+            const int tt = c * GT + (tid & (GT - 1));
+            if (MODE == GRAM_PLAIN && a.rvec) {                // a caller-supplied vector (residuals, backward pass)
+                d1 = a.rvec[(size_t)bz * a.rows + tt];
+                d0 = 0.0;
+                dok = true;
+            } else {
+                const int tc = tt < a.T ? tt : a.T - 1;
+                d1 = Xs[(size_t)(tc + 1) * a.D + dg];
+                d0 = Xs[(size_t)tc * a.D + dg];
+                dok = tt < a.T;
+            }
+        }
+    };
+    auto lstore = [&](int buf) {
+        *reinterpret_cast<double2 *>(&As[buf][rowl][2 * lane]) = ra0;
+        *reinterpret_cast<double2 *>(&Bs[buf][rowl][2 * lane]) = rb0;
+        *reinterpret_cast<double2 *>(&As[buf][rowl + 8][2 * lane]) = ra1;
+        *reinterpret_cast<double2 *>(&Bs[buf][rowl + 8][2 * lane]) = rb1;
+        if (a.with_row && tid < GT) dls[buf][tid] = dok ? d1 - d0 : 0.0;     // :247
+    };
+
+    d4 acc[4][2];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
+    // delta^T A by the vector units: thread (column gcol, slot gs) of the panel gpan adds rows [grow0, grow0 + gn) of every chunk
+    // into ITS word of `red` (a read-modify-write of a private LDS word: held in a register across the matrix phase the partial
+    // sums pushed the staging registers into scratch, which exposed the global loads of every chunk).  One panel (types 0, 2):
+    // four slots of 4 rows; two panels (type 1): two slots of 8 rows each.
+    const int gcol = tid & 127, gs = tid >> 7;
+    const int gpan = (type == 1) ? (gs >> 1) : (type == 0 ? 0 : 1);         // 0 = first panel (As), 1 = second (Bs)
+    const int gn = (type == 1) ? 8 : 4, grow0 = (type == 1) ? 8 * (gs & 1) : 4 * gs;
+    if (a.with_row) red[tid] = 0.0;
+
+    const int nchunk_all = a.rows / GT;
+    const int nrange = (tail_id >= 0) ? 2 : 1;
+    const int per = (nchunk_all + nrange - 1) / nrange;
+    const int cbeg = half * per;
+    const int nchunk = (cbeg + per <= nchunk_all) ? cbeg + per : nchunk_all;
+    gload(cbeg);
+    lstore(cbeg & 1);
+    __syncthreads();
+    for (int c = cbeg; c < nchunk; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunk) gload(c + 1);
+        {
+            const double(*Sp)[G_LD] = rbuf ? Bs[buf] : As[buf];          // this wavefront's panel holds both of its operands
+            double af[4], bf[2], afn[4], bfn[2];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) af[x] = Sp[lk][r0 + 16 * x + lr];
+#pragma unroll
+            for (int y = 0; y < 2; ++y) bf[y] = Sp[lk][c0 + 16 * y + lr];
+#pragma unroll
+            for (int ks = 0; ks < GT / 4; ++ks) {
+                if (ks + 1 < GT / 4) {       // fragments of the next k-step are requested before this step's MFMAs
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) afn[x] = Sp[4 * (ks + 1) + lk][r0 + 16 * x + lr];
+#pragma unroll
+                    for (int y = 0; y < 2; ++y) bfn[y] = Sp[4 * (ks + 1) + lk][c0 + 16 * y + lr];
+                }
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+#pragma unroll
+                    for (int y = 0; y < 2; ++y) acc[x][y] = mfma_f64(af[x], bf[y], acc[x][y]);
+#pragma unroll
+                for (int x = 0; x < 4; ++x) af[x] = afn[x];
+#pragma unroll
+                for (int y = 0; y < 2; ++y) bf[y] = bfn[y];
+            }
+        }
+        if (a.with_row) {
+            const double(*Gp)[G_LD] = gpan ? Bs[buf] : As[buf];
+            double v = red[tid];
+            for (int r = 0; r < gn; ++r) v += Gp[grow0 + r][gcol] * dls[buf][grow0 + r];
+            red[tid] = v;
+        }
+        if (c + 1 < nchunk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    double bs0 = a.with_row ? red[tid] : 0.0, bs1 = 0.0;
+    if (tail_id >= 0 && !gram_tail_exchange(a, tail_id, half, true, acc, bs0, bs1, tail_slot)) return;
+
+    const double scale = (MODE == GRAM_PLAIN) ? 1.0 : a.yn_over_batch / exp(a.log_Q[dg]);
+    double *Hb = a.H + (size_t)bz * a.h_stride;
+    const double *Kadd = (MODE == GRAM_KFU || MODE == GRAM_KFU_RAW) ? a.Kadd + (size_t)dl * a.kadd_stride : nullptr;
+    const double *Kinv = (MODE == GRAM_KFU) ? a.Kinv + (size_t)dl * a.kinv_stride : nullptr;
+    double *Rb = (MODE == GRAM_KFU_RAW) ? a.part + (size_t)bz * ((size_t)(Mp + 1) * Mp) : nullptr;
+    double *Cb2 = ((MODE == GRAM_KFU_RAW || MODE == GRAM_KFU) && a.Hcopy) ? a.Hcopy + (size_t)bz * a.hcopy_stride : nullptr;
+    double trp = 0.0;
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = I0 + 16 * x + lk + 4 * q, j = J0 + 16 * y + lr;
+                const double g = acc[x][y][q];
+                double v;
+                if (MODE == GRAM_F) v = g * scale + ((i == j) ? 1.0 : 0.0);
+                else if (MODE == GRAM_KFU_RAW) {
+                    v = g * scale + Kadd[(size_t)i * Mp + j];
+                    Rb[(size_t)i * Mp + j] = g;
+                    if (Cb2 && j <= i) {                    // the copy is made fully symmetric here (lower triangle + mirror)
+                        Cb2[(size_t)i * Mp + j] = v;
+                        if (j < i) Cb2[(size_t)j * Mp + i] = v;
+                    }
+                } else if (MODE == GRAM_KFU) {
+                    v = g * scale + Kadd[(size_t)i * Mp + j];
+                    if (Cb2 && j <= i) {
+                        Cb2[(size_t)i * Mp + j] = v;
+                        if (j < i) Cb2[(size_t)j * Mp + i] = v;
+                    }
+                    const double w = (i > j) ? 2.0 : ((i == j) ? 1.0 : 0.0);
+                    trp += w * (Kinv[(size_t)i * Mp + j] * g);
+                } else v = g;
+                Hb[(size_t)i * Mp + j] = v;
+            }
+    // delta^T A: the slots of a column are added in fixed order through LDS
+    if (a.with_row) {
+        __syncthreads();
+        red[tid] = bs0;
+        __syncthreads();
+        if (tid < 128) {
+            if (type == 1) {
+                Hb[(size_t)a.brow * Mp + pa * 128 + tid] = (red[tid] + red[128 + tid]) * scale;
+                Hb[(size_t)a.brow * Mp + pb * 128 + tid] = (red[256 + tid] + red[384 + tid]) * scale;
+            } else {
+                const double v = (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]);
+                Hb[(size_t)a.brow * Mp + (type == 0 ? pa : pb) * 128 + tid] = v * scale;
+            }
+        }
+        __syncthreads();
+    }
+    if (MODE == GRAM_KFU) {      // deterministic workgroup reduction of the trace partial; slot of the first panel's diagonal tile
+        red[tid] = trp;
+        __syncthreads();
+        for (int st = 256; st > 0; st >>= 1) {
+            if (tid < st) red[tid] += red[tid + st];
+            __syncthreads();
+        }
+        if (tid == 0) {
+            a.trpart[(size_t)b * a.ntiles + pa * (pa + 1) / 2 + pa] = red[0];
+            if (type == 2) a.trpart[(size_t)b * a.ntiles + pb * (pb + 1) / 2 + pb] = 0.0;     // (three workgroups, four slots)
+        }
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(512, 4) void gram_kernel(GramArgs a) {
     __shared__ double As[2][GT][G_LD];
@@ -2101,31 +2391,66 @@ __global__ __launch_bounds__(512, 4) void gram_kernel(GramArgs a) {
     __shared__ double dls[2][GT];
     __shared__ double red[512];
     // XCD-aware mapping: all tiles of one (chain, dim) share blockIdx % 8, i.e. one XCD's L2 (speed only)
+    __shared__ int tail_slot;
     const int id = blockIdx.x;
-    const int xcd = id & 7, loc = id >> 3;
+    const int xcd = id & 7;
+    int loc = id >> 3;
     const int ksplit = (a.ksplit > 1 && a.part) ? a.ksplit : 1;
-    const int per_unit = a.ntiles * ksplit;
+    const int per_unit = a.wg_per_unit;                  // ntiles * ksplit, or (combos) off-diagonal tiles + 3 per group of 4 panels
+    // tail split: the last tail_wg / 8 workgroup slots of every XCD's list appear twice, first all their first row halves, then
+    // all their second ones (workgroups that run together then read the same rows of K_fu)
+    int tail_id = -1, tail_half = 0;
+    if (a.tail_wg > 0) {
+        const int ntl = a.tail_wg / 8, lfull = ((a.nb + 7) / 8) * per_unit - ntl;
+        if (loc >= lfull) {
+            const int q = loc - lfull;
+            tail_id = (q % ntl) * 8 + xcd;
+            tail_half = q / ntl;
+            loc = lfull + q % ntl;
+        }
+    }
     const int bz = (loc / per_unit) * 8 + xcd;
     if (bz >= a.nb) return;
-    const int tile = (loc % per_unit) / ksplit, kpart = loc % ksplit;
+    int tile, kpart;
+    if (a.combo) {
+        const int n128 = a.Mp / 128, noff = n128 * (n128 - 1) / 2, w = loc % per_unit;
+        if (w >= noff) {                                 // one of the three combo workgroups of panel group (w - noff) / 3
+#ifdef FFVD_DF_TRACE
+            const long long tc0 = wall_clock64();
+#endif
+            gram_combo_body<MODE>(a, bz, 4 * ((w - noff) / 3), (w - noff) % 3, tail_id, tail_half, As, Bs, dls, red, &tail_slot);
+#ifdef FFVD_DF_TRACE
+            if (threadIdx.x == 0 && bz < 128 && per_unit <= 10 && MODE == GRAM_KFU) {
+                long long *g = gram_trace_buf + (size_t)(bz * 10 + w) * 4;
+                g[0] = tc0; g[1] = wall_clock64(); g[2] = 1; g[3] = (long long)blockIdx.x;
+            }
+#endif
+            return;
+        }
+        int ti = 1;                                      // off-diagonal tile w = ti (ti - 1) / 2 + tj,  tj < ti
+        while (ti * (ti + 1) / 2 <= w) ++ti;
+        tile = ti * (ti + 1) / 2 + (w - ti * (ti - 1) / 2);
+        kpart = tail_half;
+    } else {
+        tile = (loc % per_unit) / ksplit;
+        kpart = (tail_id >= 0) ? tail_half : loc % ksplit;
+    }
     int ti = 0;                       // tile = ti (ti + 1) / 2 + tj,  tj <= ti
     while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
     const int tj = tile - ti * (ti + 1) / 2;
 #ifdef FFVD_DF_TRACE
     const long long tw0 = wall_clock64();     // debug build (tools/gram_trace.py): start and end of the tiles of the first 16 units
 #endif
-    if (ti == tj) gram_body<MODE, true>(a, bz, ti, tj, tile, kpart, ksplit, As, Bs, dls, red);
-    else gram_body<MODE, false>(a, bz, ti, tj, tile, kpart, ksplit, As, Bs, dls, red);
+    if (ti == tj) gram_body<MODE, true>(a, bz, ti, tj, tile, kpart, ksplit, As, Bs, dls, red, tail_id, &tail_slot);
+    else gram_body<MODE, false>(a, bz, ti, tj, tile, kpart, ksplit, As, Bs, dls, red, tail_id, &tail_slot);
 #ifdef FFVD_DF_TRACE
     if (threadIdx.x == 0 && bz < 16 && ksplit == 1 && a.ntiles <= 10 && MODE == GRAM_KFU) {
         df_trace_buf[2048 + (bz * 10 + tile) * 2] = tw0;
         df_trace_buf[2048 + (bz * 10 + tile) * 2 + 1] = wall_clock64();
     }
-    if (threadIdx.x == 0 && bz < 128 && ksplit == 1 && a.ntiles <= 10 && MODE == GRAM_KFU) {     // every tile of the launch (tools/gram_rounds.py)
-        unsigned hw;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        long long *g = gram_trace_buf + (size_t)(bz * 10 + tile) * 4;
-        g[0] = tw0; g[1] = wall_clock64(); g[2] = (long long)hw; g[3] = (long long)blockIdx.x;
+    if (threadIdx.x == 0 && bz < 128 && ksplit == 1 && a.ntiles <= 10 && MODE == GRAM_KFU) {     // every workgroup of the launch (tools/gram_rounds.py)
+        long long *g = gram_trace_buf + (size_t)(bz * 10 + (a.combo ? loc % per_unit : tile)) * 4;   // (a tail workgroup: the half that ends last)
+        g[0] = tw0; g[1] = wall_clock64(); g[2] = (ti == tj) ? 1 : 0; g[3] = (long long)blockIdx.x;
     }
 #endif
 }
@@ -2231,6 +2556,43 @@ size_t gram_part_doubles(int Mp, int nb, int ksplit) {
     return ksplit > 1 ? (size_t)ksplit * nb * (size_t)(Mp + 1) * Mp : 0;
 }
 
+#ifndef GRAM_COMBO
+#define GRAM_COMBO 1
+#endif
+#ifndef GRAM_TAIL_SPLIT
+#define GRAM_TAIL_SPLIT 1
+#endif
+// workgroups per unit of an unsplit launch: with Mp a multiple of 512 the diagonal tiles of every four panels become three combos
+// (and only when the kernel has no delta^T A row to form: the combos have no idle wavefront for it)
+static bool gram_uses_combos(int Mp, int ksplit, int with_row) { return GRAM_COMBO && ksplit <= 1 && Mp % 512 == 0 && !with_row; }
+static int gram_wg_per_unit(int Mp, int ksplit, int with_row) {
+    const int n128 = (Mp / NB + 1) / 2;
+    if (gram_uses_combos(Mp, ksplit, with_row)) return n128 * (n128 - 1) / 2 + 3 * (n128 / 4);
+    return gram_ntiles(Mp) * (ksplit > 1 ? ksplit : 1);
+}
+// Which workgroups of an unsplit launch are cut in two row halves: those of the last, partial round, when their halves still fit
+// into half of the chip's slots (two per CU) -- then the halves take the slots that free up FIRST at the end of the last full
+// round and run beside its stragglers.  tools/gram_rounds.py (128 units): a round's tiles end 0.5-0.7 ms apart (the workgroup
+// that arrived first on a CU keeps the matrix pipe), a workgroup alone on its CU reaches 57-65 % of what two reach together,
+// and a 2-way split of a whole half round (256 tiles -> 512 halves) ended LATER than no split because the last halves start
+// when the last slot frees up; with combos the remainder is 128 workgroups -> 256 halves -> the 256 slots that free up first.
+int gram_tail_wg(int Mp, int nb, int ksplit, int with_row) {
+    if (!GRAM_TAIL_SPLIT || ksplit > 1) return 0;
+    static const int slots = [] {
+        int dev = 0, cus = 256;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) cus = p.multiProcessorCount;
+        return 2 * cus;
+    }();
+    const int n = ((nb + 7) / 8) * 8 * gram_wg_per_unit(Mp, ksplit, with_row);
+    if (n < 2 * slots) return 0;                                 // small launches have their own split-K path
+    const int r = n % slots;
+    return (r > 0 && 4 * r <= slots && r % 8 == 0) ? r : 0;
+}
+size_t gram_tail_doubles(int tail_wg) {
+    return tail_wg > 0 ? (size_t)tail_wg * 2 * GRAM_TAIL_DOUBLES + ((size_t)tail_wg + 1) / 2 : 0;
+}
+
 // phase: 0 = everything, 1 = the tile pass only, 2 = the combine pass only (split-K launches: the tile pass writes
 // raw partials and needs neither K_uu nor K^-1, so the caller may run it before those exist and combine afterwards)
 void launch_gram(hipStream_t stream, GramArgs a, int phase) {
@@ -2238,7 +2600,11 @@ void launch_gram(hipStream_t stream, GramArgs a, int phase) {
     if (a.brow <= 0) a.brow = a.Mp;
     if (!a.part || a.ksplit < 1) a.ksplit = 1;
     const int groups = (a.nb + 7) / 8;
-    const dim3 grid(groups * 8 * a.ntiles * a.ksplit);
+    a.combo = gram_uses_combos(a.Mp, a.ksplit, a.with_row) ? 1 : 0;
+    a.wg_per_unit = gram_wg_per_unit(a.Mp, a.ksplit, a.with_row);
+    if (a.ksplit > 1 || !a.tail_part || a.tail_wg != gram_tail_wg(a.Mp, a.nb, a.ksplit, a.with_row)) a.tail_wg = 0;
+    if (a.tail_wg > 0) a.tail_cnt = reinterpret_cast<int *>(a.tail_part + (size_t)a.tail_wg * 2 * GRAM_TAIL_DOUBLES);
+    const dim3 grid(groups * 8 * a.wg_per_unit + a.tail_wg);
     if (phase != 2 && phase != 3 && phase != 4) {
         if (a.mode == GRAM_F) hipLaunchKernelGGL(gram_kernel<GRAM_F>, grid, dim3(512), 0, stream, a);
         else if (a.mode == GRAM_KFU) hipLaunchKernelGGL(gram_kernel<GRAM_KFU>, grid, dim3(512), 0, stream, a);
