@@ -225,16 +225,13 @@ __global__ __launch_bounds__(256) void kfu_build_kernel(ProjectArgs a) {
     __shared__ __attribute__((aligned(16))) double xr8[SMALLP ? 64 : 1][8];
     __shared__ double xx[64];
     __shared__ double zs[64][(SMALLP ? 8 : MAXP) + 1];
-    __shared__ double dlt[64];                  // delta_t of this block's rows (gpart != null)
     __shared__ double gsum[4][64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int t0 = blockIdx.x * 64, m0 = blockIdx.y * 64, bz = blockIdx.z;
     const int b = a.b0 + bz, s = b / a.Dl, dl = b % a.Dl;
-    if (a.gpart && tid < 64) {
-        const int t = t0 + tid, dg = a.d_begin + dl;
-        const double *xc = a.x + (size_t)s * a.x_chain_stride;
-        dlt[tid] = (t < a.T) ? xc[(size_t)(t + 1) * a.x_ld + dg] - xc[(size_t)t * a.x_ld + dg] : 0.0;     // :247
-    }
+    // delta_t = x_{t+1,d} - x_{t,d} (:247) of a row is the same for the whole wavefront (a wavefront = 16 rows x 64 columns): every
+    // wavefront loads its 16 values once, one per lane, and hands them out by v_readlane
+    const double *xdl = a.x + (size_t)s * a.x_chain_stride + (a.d_begin + dl);
     const int P = a.P, Mp = a.Mp;
     const double var = a.hv.variance[dl];
     for (int p = tid >> 6; p < (SMALLP ? 8 : P); p += 4) {
@@ -266,9 +263,13 @@ __global__ __launch_bounds__(256) void kfu_build_kernel(ProjectArgs a) {
     double zr[8];                               // this thread's inducing input (first 8 components) in registers
 #pragma unroll
     for (int p = 0; p < 8; ++p) zr[p] = (SMALLP || p < P) ? zs[lane][p] : 0.0;
-    const int rbase = (tid >> 6) * 16;
+    const int rbase = __builtin_amdgcn_readfirstlane(tid >> 6) * 16;
     const bool want_g = a.gpart != nullptr;
-    double gacc = 0.0;
+    double gacc = 0.0, dlane = 0.0;             // lane i < 16 of every wavefront: delta of row rbase + i
+    if (want_g) {
+        const int t = t0 + rbase + (lane & 15);
+        if (t < a.T) dlane = xdl[(size_t)(t + 1) * a.x_ld] - xdl[(size_t)t * a.x_ld];
+    }
     auto rows = [&](auto edge_tag) {             // interior tiles skip the per-element range selects
         constexpr bool EDGE = decltype(edge_tag)::value;
 #pragma unroll 4
@@ -291,7 +292,11 @@ __global__ __launch_bounds__(256) void kfu_build_kernel(ProjectArgs a) {
             double v = kernel_value<KIND>(dot, xx[r], zzv, var);
             if (EDGE && (!mok || t0 + r >= a.T)) v = 0.0;
             out[(size_t)r * Mp] = v;
-            if (want_g) gacc = fma(dlt[r], v, gacc);
+            if (want_g) {                       // delta of this row out of lane i: two v_readlane, then ONE vector FMA
+                const double dr = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(dlane), i),
+                                                   __builtin_amdgcn_readlane(__double2loint(dlane), i));
+                gacc = fma(dr, v, gacc);
+            }
         }
     };
     if (t0 + 64 > a.T || m0 + 64 > a.M) rows(std::true_type{});
