@@ -850,3 +850,35 @@ def test_explicit_inverse_backward_switch(monkeypatch):
     assert np.max(np.abs(z_w - want)) < 1e-7 * scale
     assert np.max(np.abs(z_e - want)) < 1e-5 * scale
     assert not np.array_equal(z_w, z_e)              # the switch really selects another code path
+
+
+def test_combo_workgroups_and_tail_split_at_m1024():
+    """Round 3 Gram schedule away from the headline shape: M = 1024 (two groups of four panels: 28 off-diagonal tiles + 6 combo
+    workgroups per unit) with 32 units in one unsplit launch = 1088 workgroups, of which the last 64 are cut into row halves (32 chunks
+    each at T = 1024; T >= M because the synthetic inducing inputs are drawn from the trajectory).  Every chain must equal what a one-chain engine (2 units: the split-K schedule with the legacy diagonal tiles)
+    computes for it, two chains are checked against the oracle, forward and gradient are bit-reproducible."""
+    params, Y, c, meta = synthetic.make_workload(T=1024, D=2, C=1, M=1024, S=16)
+    with ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], 16, route="gram") as e:
+        e.set_data(Y, c)
+        full = e.nll_terms(params)
+        again = e.nll_terms(params)
+    np.testing.assert_array_equal(full["nll_per_chain"], again["nll_per_chain"])
+    for s in (0, 7, 15):
+        with ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], 1, route="gram") as e:
+            e.set_data(Y, c)
+            one = e.nll_terms(dict(params, X=params["X"][s:s + 1]))
+        # as many inducing points as transitions: cond(K_uu) ~ 1e7 and an nll of -0.03; the two schedules sum the Gram matrices in
+        # different orders, which moves the Gram route by eps * cond (measured 1.3e-9 absolute)
+        assert full["nll_per_chain"][s] == pytest.approx(one["nll"], rel=1e-8, abs=2e-8)
+    for s in (0, 15):
+        ref = orc.nll_terms(dict(params, X=params["X"][s]), Y, c, U_collapse=True)
+        assert full["nll_per_chain"][s] == pytest.approx(ref["nll"], rel=1e-7, abs=2e-8)
+    # training forward + backward through the same launch shape (the Gram kernel also stores the symmetric copy of A)
+    with ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], 16, route="gram", grad=True) as e:
+        e.set_data(Y, c)
+        t1, g1 = e.nll_and_grad(params)
+        t2, g2 = e.nll_and_grad(params)
+    assert t1["nll"] == pytest.approx(full["nll"], rel=1e-8, abs=2e-8)
+    for k in GRAD_KEYS:
+        np.testing.assert_array_equal(g1[k], g2[k])
+        assert np.all(np.isfinite(g1[k]))
