@@ -2203,8 +2203,9 @@ __device__ __forceinline__ bool gram_tail_exchange(const GramArgs &a, const int 
 //   type 2 (panels b+2, b+3):          rows 0-63 of tile (b+2,b+2) (2)        + tile (b+3,b+3) complete (6)
 // (gram_body<.., true> gives a diagonal tile's six sub-blocks to six wavefronts: SIMDs 0 and 1 carry two matrix wavefronts, SIMDs
 // 2 and 3 one, the tile lasts as long as an off-diagonal one -- 1085 vs 1091 us, tools/gram_rounds.py -- and what SIMDs 2 and 3
-// have to spare nobody can use.)  The row delta^T A of a panel is formed by the vector units of the workgroup that has the
-// panel in LDS anyway: type 0 panel b, type 1 panels b+1 and b+2, type 2 panel b+3.
+// have to spare nobody can use.)  Combos form no delta^T A row -- there is no idle wavefront for it, and vector FMAs beside the
+// matrix work cost 0.47 ms at config 2: launch_gram uses them only for launches with with_row = 0 (the Gram route sums
+// delta^T K_fu in the K_fu build, kfu_build_kernel / brow_finish_kernel).
 // entry = buffer (0 = first panel, 1 = second) << 3 | row half << 2 | column quarter
 __device__ __constant__ unsigned char GRAM_COMBO_ROLE[3][8] = {
     {0 << 3 | 1 << 2 | 0, 0 << 3 | 1 << 2 | 1, 0 << 3 | 1 << 2 | 2, 0 << 3 | 1 << 2 | 3, 0 << 3 | 0 << 2 | 0, 0 << 3 | 0 << 2 | 1, 1 << 3 | 0 << 2 | 0, 1 << 3 | 0 << 2 | 1},
@@ -2214,7 +2215,7 @@ __device__ __constant__ unsigned char GRAM_COMBO_ROLE[3][8] = {
 template <int MODE>
 __device__ __forceinline__ void gram_combo_body(const GramArgs a, const int bz, const int pbase, const int type, const int tail_id,
                                                 const int half, double (*As)[GT][G_LD], double (*Bs)[GT][G_LD],
-                                                double (*dls)[GT], double *red, int *tail_slot) {
+                                                double *red, int *tail_slot) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lk = lane >> 4;
@@ -2228,38 +2229,21 @@ __device__ __forceinline__ void gram_combo_body(const GramArgs a, const int bz, 
     const int r0 = rh * 64, c0 = rq * 32;                               // offsets inside the staged panel
 
     const double *Ab = a.A + (size_t)bz * a.a_stride;
-    const double *Xs = (a.with_row && !(MODE == GRAM_PLAIN && a.rvec)) ? a.X + (size_t)s * (a.T + 1) * a.D : nullptr;
     const int colA = pa * 128 + 2 * lane, colB = pb * 128 + 2 * lane;
     const int rowl = tid >> 6;   // 0..7
     double2 ra0, ra1, rb0, rb1;
-    double d1 = 0.0, d0 = 0.0;
-    bool dok = false;
     auto gload = [&](int c) {
         const double *row0 = Ab + ((size_t)c * GT + rowl) * Mp, *row1 = row0 + (size_t)8 * Mp;
         ra0 = *reinterpret_cast<const double2 *>(row0 + colA);
         rb0 = *reinterpret_cast<const double2 *>(row0 + colB);
         ra1 = *reinterpret_cast<const double2 *>(row1 + colA);
         rb1 = *reinterpret_cast<const double2 *>(row1 + colB);
-        if (a.with_row) {
-            const int tt = c * GT + (tid & (GT - 1));
-            if (MODE == GRAM_PLAIN && a.rvec) {                // a caller-supplied vector (residuals, backward pass)
-                d1 = a.rvec[(size_t)bz * a.rows + tt];
-                d0 = 0.0;
-                dok = true;
-            } else {
-                const int tc = tt < a.T ? tt : a.T - 1;
-                d1 = Xs[(size_t)(tc + 1) * a.D + dg];
-                d0 = Xs[(size_t)tc * a.D + dg];
-                dok = tt < a.T;
-            }
-        }
     };
     auto lstore = [&](int buf) {
         *reinterpret_cast<double2 *>(&As[buf][rowl][2 * lane]) = ra0;
         *reinterpret_cast<double2 *>(&Bs[buf][rowl][2 * lane]) = rb0;
         *reinterpret_cast<double2 *>(&As[buf][rowl + 8][2 * lane]) = ra1;
         *reinterpret_cast<double2 *>(&Bs[buf][rowl + 8][2 * lane]) = rb1;
-        if (a.with_row && tid < GT) dls[buf][tid] = dok ? d1 - d0 : 0.0;     // :247
     };
 
     d4 acc[4][2];
@@ -2267,15 +2251,6 @@ __device__ __forceinline__ void gram_combo_body(const GramArgs a, const int bz, 
     for (int x = 0; x < 4; ++x)
 #pragma unroll
         for (int y = 0; y < 2; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
-    // delta^T A by the vector units: thread (column gcol, slot gs) of the panel gpan adds rows [grow0, grow0 + gn) of every chunk
-    // into ITS word of `red` (a read-modify-write of a private LDS word: held in a register across the matrix phase the partial
-    // sums pushed the staging registers into scratch, which exposed the global loads of every chunk).  One panel (types 0, 2):
-    // four slots of 4 rows; two panels (type 1): two slots of 8 rows each.
-    const int gcol = tid & 127, gs = tid >> 7;
-    const int gpan = (type == 1) ? (gs >> 1) : (type == 0 ? 0 : 1);         // 0 = first panel (As), 1 = second (Bs)
-    const int gn = (type == 1) ? 8 : 4, grow0 = (type == 1) ? 8 * (gs & 1) : 4 * gs;
-    if (a.with_row) red[tid] = 0.0;
-
     const int nchunk_all = a.rows / GT;
     const int nrange = (tail_id >= 0) ? 2 : 1;
     const int per = (nchunk_all + nrange - 1) / nrange;
@@ -2312,16 +2287,10 @@ __device__ __forceinline__ void gram_combo_body(const GramArgs a, const int bz, 
                 for (int y = 0; y < 2; ++y) bf[y] = bfn[y];
             }
         }
-        if (a.with_row) {
-            const double(*Gp)[G_LD] = gpan ? Bs[buf] : As[buf];
-            double v = red[tid];
-            for (int r = 0; r < gn; ++r) v += Gp[grow0 + r][gcol] * dls[buf][grow0 + r];
-            red[tid] = v;
-        }
         if (c + 1 < nchunk) lstore(buf ^ 1);
         __syncthreads();
     }
-    double bs0 = a.with_row ? red[tid] : 0.0, bs1 = 0.0;
+    double bs0 = 0.0, bs1 = 0.0;           // (no delta^T A row here: launch_gram gives combos only to launches without one)
     if (tail_id >= 0 && !gram_tail_exchange(a, tail_id, half, true, acc, bs0, bs1, tail_slot)) return;
 
     const double scale = (MODE == GRAM_PLAIN) ? 1.0 : a.yn_over_batch / exp(a.log_Q[dg]);
@@ -2359,22 +2328,6 @@ __device__ __forceinline__ void gram_combo_body(const GramArgs a, const int bz, 
                 } else v = g;
                 Hb[(size_t)i * Mp + j] = v;
             }
-    // delta^T A: the slots of a column are added in fixed order through LDS
-    if (a.with_row) {
-        __syncthreads();
-        red[tid] = bs0;
-        __syncthreads();
-        if (tid < 128) {
-            if (type == 1) {
-                Hb[(size_t)a.brow * Mp + pa * 128 + tid] = (red[tid] + red[128 + tid]) * scale;
-                Hb[(size_t)a.brow * Mp + pb * 128 + tid] = (red[256 + tid] + red[384 + tid]) * scale;
-            } else {
-                const double v = (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]);
-                Hb[(size_t)a.brow * Mp + (type == 0 ? pa : pb) * 128 + tid] = v * scale;
-            }
-        }
-        __syncthreads();
-    }
     if (MODE == GRAM_KFU) {      // deterministic workgroup reduction of the trace partial; slot of the first panel's diagonal tile
         red[tid] = trp;
         __syncthreads();
@@ -2423,7 +2376,7 @@ __global__ __launch_bounds__(512, 4) void gram_kernel(GramArgs a) {
 #ifdef FFVD_DF_TRACE
             const long long tc0 = wall_clock64();
 #endif
-            gram_combo_body<MODE>(a, bz, 4 * ((w - noff) / 3), (w - noff) % 3, tail_id, tail_half, As, Bs, dls, red, &tail_slot);
+            gram_combo_body<MODE>(a, bz, 4 * ((w - noff) / 3), (w - noff) % 3, tail_id, tail_half, As, Bs, red, &tail_slot);
 #ifdef FFVD_DF_TRACE
             if (threadIdx.x == 0 && bz < 128 && per_unit <= 10 && MODE == GRAM_KFU) {
                 long long *g = gram_trace_buf + (size_t)(bz * 10 + w) * 4;
