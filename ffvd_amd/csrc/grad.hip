@@ -49,6 +49,30 @@ __device__ __forceinline__ void wave_sync_lds() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// The same when only the compiler needs telling: LDS serves the accesses of one wavefront in order (the fences above also wait
+// for the wavefront's outstanding global stores)
+__device__ __forceinline__ void wave_lds_order() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Sum over the 16 lanes of a DPP row (every lane ends up with it): quad_perm [1,0,3,2], [2,3,0,1], then the half-row and row
+// mirrors (after the first two steps all lanes of a quad agree, so a mirror exchanges quads / halves).  __shfl_xor compiles to
+// ds_bpermute, i.e. an LDS round trip per step.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row16_sum(double v) {
+    v += dpp_move_f64<0xB1>(v);
+    v += dpp_move_f64<0x4E>(v);
+    v += dpp_move_f64<0x141>(v);
+    v += dpp_move_f64<0x140>(v);
+    return v;
+}
+
 constexpr int AT = 16;
 constexpr int A_LD = 128 + 16;
 
@@ -376,11 +400,15 @@ int atb_ntiles_sym64(int n) { const int nt = (n + 63) / 64; return nt * (nt + 1)
 // acc (128 x 128 tile, 8 wavefronts of 64 x 32) = sum_{k < kend} Arows[i][k] * B[k][j], the 128 x 16 chunk of A
 // transposed on its way into LDS, both operands register-staged one chunk ahead.  `last_chunk` lets a wavefront stop
 // early when B is upper triangular.  Ends with the workgroup synchronised (LDS free for the caller's epilogue).
+// Row stride of the TRANSPOSED A chunk in LDS: a thread stores the four k-values it loaded for output row il at [k..k+3][il], the
+// 16 lanes that share an LDS cycle hold 4 different k-groups (rows 0, 4, 8, 12) of 4 consecutive il -- with an odd stride = 1 mod 4
+// they hit 32 different banks (stride 144: every k-group on the same ones, 4-way conflicts on every store)
+constexpr int A_LDT = 128 + 17;
 struct RowMajorTile {
     int ti, tj, tid, lane, wr, wc, lr, lk;
 };
 struct TileAcc { d4 v[4][2]; };
-__device__ __forceinline__ TileAcc gemm_rowmajor_a(double (*As)[AT][A_LD], double (*Bs)[AT][A_LD], const RowMajorTile t,
+__device__ __forceinline__ TileAcc gemm_rowmajor_a(double (*As)[AT][A_LDT], double (*Bs)[AT][A_LD], const RowMajorTile t,
                                                 const double *A, int nrowsA, const double *B, int ld,
                                                 int kend, int last_chunk) {
     d4 acc[4][2];
@@ -466,7 +494,7 @@ __device__ __forceinline__ TileAcc gemm_rowmajor_a(double (*As)[AT][A_LD], doubl
 // ---------------------------------------------------------------------------------------------
 constexpr int XW_LD = 128 + 4;
 __global__ __launch_bounds__(512, 4) void bwd_fused_kernel(BwdFusedArgs a) {
-    __shared__ double As[2][AT][A_LD];
+    __shared__ double As[2][AT][A_LDT];
     __shared__ double Bs[2][AT][A_LD];
     const int bz = blockIdx.y;
     const int ntj = (a.Mp + 127) / 128;
@@ -483,6 +511,14 @@ __global__ __launch_bounds__(512, 4) void bwd_fused_kernel(BwdFusedArgs a) {
     const RowMajorTile rt{ti, tj, tid, lane, wr, wc, lr, lk};
     TileAcc res = gemm_rowmajor_a(As, Bs, rt, Kfb, Tp, Gb, Mp, Mp, 1 << 30);
     d4 (&acc)[4][2] = res.v;
+#if defined(BWD_DIAG) && BWD_DIAG == 1      // diagnostic build (tools/build_grad_variant.sh): main loop only
+    {
+        double v = 0.0;
+        for (int x = 0; x < 4; ++x) for (int y = 0; y < 2; ++y) for (int q = 0; q < 4; ++q) v += acc[x][y][q];
+        a.rp[(((size_t)tj * a.nb + bz) * a.Tp + ti * 128 + (tid & 127)) * 8 + (tid >> 7)] = v;
+        return;
+    }
+#endif
 
     // ---------------- epilogue ----------------
     const int b = a.b0 + bz, s = b / a.Dl, dl = b % a.Dl, dg = a.d_begin + dl;
@@ -490,9 +526,29 @@ __global__ __launch_bounds__(512, 4) void bwd_fused_kernel(BwdFusedArgs a) {
     const double *ub = a.u + (size_t)unit_or_dim * a.u_stride;
     const double *Xs = a.X + (size_t)s * (a.T + 1) * a.D;
     const double *rv = a.rvec ? a.rvec + (size_t)bz * Tp : nullptr;
-    double *sm = &As[0][0][0];                 // 4608 doubles: XW [8][XW_LD] | Vs [8][XW_LD] | kfu_s [4][128]
-    double *sb = &Bs[0][0][0];                 // 4608 doubles: per-wavefront transpose patches, then the row partials
-    double *XW = sm, *Vs = sm + 8 * XW_LD, *kfu_s = sm + 16 * XW_LD;
+    // LDS map (doubles; both operand buffers are free once the main loop has synchronised):
+    //   As region: XW [8][XW_LD] | Vs [8][XW_LD] | dl_s [128] | row partials of the column quarters 2, 3  [2][128][8]
+    //   Bs region: per-wavefront transpose patches [8][16][17]  | row partials of the column quarters 0, 1  [2][128][8]
+    // row partial slots: 0 rsum, 1..P ez, 7 kfu.  Nothing aliases, so the epilogue needs two workgroup barriers: one after the
+    // staging, one before the final sum over the column quarters.
+    double *sm = &As[0][0][0], *sb = &Bs[0][0][0];
+    double *XW = sm, *Vs = sm + 8 * XW_LD, *dl_s = sm + 16 * XW_LD, *RPhi = dl_s + 128, *RPlo = sb + 8 * (16 * 17);
+    static_assert(16 * XW_LD + 128 + 2 * 128 * 8 <= 2 * AT * A_LD && 8 * 16 * 17 + 2 * 128 * 8 <= 2 * AT * A_LD, "epilogue LDS map");
+    double *RPw = ((wc & 2) ? RPhi : RPlo) + (size_t)(wc & 1) * (128 * 8);      // this wavefront's column quarter
+    // K_fu values of the accumulator positions: unconditional loads from clamped addresses, one 64 x 32 strip row (x) ahead of its use
+    const int jc[2] = {(J0 + lr < Mp) ? J0 + lr : Mp - 1, (J0 + 16 + lr < Mp) ? J0 + 16 + lr : Mp - 1};
+    const bool jok[2] = {J0 + lr < Mp, J0 + 16 + lr < Mp};
+    double kf[2][4];
+    auto kload = [&](int x) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = I0 + 16 * x + lk + 4 * q;
+            const double *row = Kfb + (size_t)((i < Tp) ? i : Tp - 1) * Mp;
+#pragma unroll
+            for (int y = 0; y < 2; ++y) kf[y][q] = row[jc[y]];
+        }
+    };
+    kload(0);
     for (int idx = tid; idx < 8 * 128; idx += 512) {
         const int p = idx >> 7, r = idx & 127;
         const int t = ti * 128 + r, j = tj * 128 + r;
@@ -506,101 +562,90 @@ __global__ __launch_bounds__(512, 4) void bwd_fused_kernel(BwdFusedArgs a) {
         XW[p * XW_LD + r] = xv;
         Vs[p * XW_LD + r] = zv;
     }
-    // e in place of g; kfu partial over this wavefront's 32 columns
-    {
-        double uj[2];
+    if (tid < 128) {
+        const int t = ti * 128 + tid;
+        dl_s[tid] = (t < a.T) ? alpha * (rv ? rv[t] : Xs[(size_t)(t + 1) * a.D + dg] - Xs[(size_t)t * a.D + dg]) : 0.0;
+    }
+    double uj[2];
+#pragma unroll
+    for (int y = 0; y < 2; ++y) uj[y] = jok[y] ? ub[jc[y]] : 0.0;
+    __syncthreads();
+    // One 16-row strip (x) of the wavefront's 64 x 32 block at a time, so that its accumulators die as the loop advances:
+    //   e in place of g, the kfu partial over the wavefront's 32 columns (16-lane DPP sum);
+    //   columns: [cs; etx] += [1; x^T] e -- the accumulator layout of e IS the B-operand layout with k = rows;
+    //   rows: [rsum, ez] = e [1, z] -- needs e as an A operand, i.e. transposed: each 16 x 16 block goes through a private LDS
+    //   patch.  LDS serves one wavefront's accesses in order, so only the compiler needs a fence (a workgroup-scope fence would
+    //   also wait for outstanding global accesses).
+    // The K_fu values of strip x + 1 are requested before the matrix work of strip x.
+    d4 ac[2] = {(d4){0.0, 0.0, 0.0, 0.0}, (d4){0.0, 0.0, 0.0, 0.0}};
+    double *Tw = sb + wave * (16 * 17);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int il = wr * 64 + 16 * x + lk + 4 * q;
+            const bool iok = ti * 128 + il < Tp;
+            const double rowv = dl_s[il];
+            double v = 0.0;
+#pragma unroll
+            for (int y = 0; y < 2; ++y) {
+                const bool ok = iok && jok[y];
+                const double k = ok ? kf[y][q] : 0.0;
+                acc[x][y][q] = (2.0 * acc[x][y][q] + rowv * uj[y]) * (a.linear ? (ok ? 1.0 : 0.0) : k);
+                v += k * uj[y];
+            }
+            v = row16_sum(v);
+            if (lr == 0) RPw[il * 8 + 7] = v;
+        }
+        if (x + 1 < 4) kload(x + 1);
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const double af = (lr < 8) ? XW[lr * XW_LD + wr * 64 + 16 * x + 4 * ks + lk] : 0.0;
+                ac[y] = mfma_f64(af, acc[x][y][ks], ac[y]);
+            }
+        d4 r4 = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int y = 0; y < 2; ++y) {
-            const int j = J0 + 16 * y + lr;
-            uj[y] = (j < Mp) ? ub[j] : 0.0;
-        }
 #pragma unroll
-        for (int x = 0; x < 4; ++x)
+            for (int q = 0; q < 4; ++q) Tw[(lk + 4 * q) * 17 + lr] = acc[x][y][q];
+            wave_lds_order();
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int i = I0 + 16 * x + lk + 4 * q;
-                const bool iok = i < Tp;
-                const double rowv = (i < a.T) ? alpha * (rv ? rv[i] : Xs[(size_t)(i + 1) * a.D + dg] - Xs[(size_t)i * a.D + dg]) : 0.0;
-                double v = 0.0;
-#pragma unroll
-                for (int y = 0; y < 2; ++y) {
-                    const int j = J0 + 16 * y + lr;
-                    const bool ok = iok && j < Mp;
-                    const double kf = ok ? Kfb[(size_t)i * Mp + j] : 0.0;
-                    acc[x][y][q] = (2.0 * acc[x][y][q] + rowv * uj[y]) * (a.linear ? (ok ? 1.0 : 0.0) : kf);
-                    v += kf * uj[y];
-                }
-                // reduced and parked right away: sixteen partial sums held across the loop cost 32 VGPRs this epilogue
-                // does not have
-                v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-                if (lr == 0) kfu_s[wc * 128 + wr * 64 + 16 * x + lk + 4 * q] = v;
+            for (int ks = 0; ks < 4; ++ks) {
+                const double af = Tw[lr * 17 + 4 * ks + lk];
+                const double bf = (lr < 8) ? Vs[lr * XW_LD + wc * 32 + 16 * y + 4 * ks + lk] : 0.0;
+                r4 = mfma_f64(af, bf, r4);
             }
+            wave_lds_order();
+        }
+        if (lr < 7) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) RPw[(wr * 64 + 16 * x + lk + 4 * q) * 8 + lr] = r4[q];
+        }
     }
-    __syncthreads();
-    // columns: [cs; etx] for the 64-row block (ti, wr), this wavefront's 32 columns
-    {
+    {       // column partials of the 64-row block (ti, wr)
         const int nblk = Tp / 64, blk = ti * 2 + wr;
 #pragma unroll
         for (int y = 0; y < 2; ++y) {
-            d4 ac = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int x = 0; x < 4; ++x)
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const double af = (lr < 8) ? XW[lr * XW_LD + wr * 64 + 16 * x + 4 * ks + lk] : 0.0;
-                    ac = mfma_f64(af, acc[x][y][ks], ac);
-                }
             const int j = J0 + 16 * y + lr;
             if (j < Mp && blk < nblk) {
                 const size_t pb = ((size_t)bz * nblk + blk) * Mp + j;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int p = lk + 4 * q;
-                    if (p == 0) a.cs_part[pb] = ac[q];
-                    else if (p <= P) a.etx_part[pb * P + (p - 1)] = ac[q];
+                    if (p == 0) a.cs_part[pb] = ac[y][q];
+                    else if (p <= P) a.etx_part[pb * P + (p - 1)] = ac[y][q];
                 }
             }
         }
-    }
-    // rows: [rsum, ez] over this wavefront's 32 columns, strip by strip through a private LDS patch
-    d4 ar[4];
-    {
-        double *Tw = sb + wave * (16 * 33);
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-#pragma unroll
-            for (int y = 0; y < 2; ++y)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) Tw[(lk + 4 * q) * 33 + 16 * y + lr] = acc[x][y][q];
-            wave_sync_lds();
-            d4 r4 = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int y = 0; y < 2; ++y)
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const double af = Tw[lr * 33 + 16 * y + 4 * ks + lk];
-                    const double bf = (lr < 8) ? Vs[lr * XW_LD + wc * 32 + 16 * y + 4 * ks + lk] : 0.0;
-                    r4 = mfma_f64(af, bf, r4);
-                }
-            ar[x] = r4;
-            wave_sync_lds();
-        }
-    }
-    __syncthreads();
-    if (lr < 8) {
-#pragma unroll
-        for (int x = 0; x < 4; ++x)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) sb[((size_t)wc * 128 + wr * 64 + 16 * x + lk + 4 * q) * 8 + lr] = ar[x][q];
     }
     __syncthreads();
     for (int idx = tid; idx < 128 * 8; idx += 512) {
         const int row = idx >> 3, c = idx & 7;
         const int t = ti * 128 + row;
         if (t >= Tp) continue;
-        double v = 0.0;
-        if (c == 7) { for (int w = 0; w < 4; ++w) v += kfu_s[w * 128 + row]; }
-        else { for (int w = 0; w < 4; ++w) v += sb[((size_t)w * 128 + row) * 8 + c]; }
+        const double v = (RPlo[row * 8 + c] + RPlo[128 * 8 + row * 8 + c]) + (RPhi[row * 8 + c] + RPhi[128 * 8 + row * 8 + c]);
         a.rp[(((size_t)tj * a.nb + bz) * Tp + t) * 8 + c] = v;
     }
 }
@@ -650,7 +695,7 @@ void launch_bwd_fused(hipStream_t stream, const BwdFusedArgs &a) {
 // triangular; inside that last block a wavefront stops at its own last column.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512, 4) void proj_gemm_kernel(ProjGemmArgs a) {
-    __shared__ double As[2][AT][A_LD];
+    __shared__ double As[2][AT][A_LDT];
     __shared__ double Bs[2][AT][A_LD];
     const int bz = blockIdx.y;
     const int ntj = (a.Mp + 127) / 128;
