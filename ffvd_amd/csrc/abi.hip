@@ -49,6 +49,8 @@ struct ffvd_handle {
     struct Switches {
         bool fused_project = false, grad_explicit = false, no_defer_trace = false, no_late_join = false;
         bool no_main_first = false, no_kfu_first = false, atb128 = false, grad_serial = false, kuu_flow = true, kinv_gram = false, chain_rl = false;
+        bool lt_armed = false;            // FFVD_GRAD_LT_ARMED=1: write the L^T rows to memory (launch_set_lt_rows) even where the dataflow kernel could read L itself
+        bool whiten_products = false;     // FFVD_GRAD_WHITEN_PRODUCTS=1: training forward forms H = W^T A W with two products (round 1/2) instead of arming L^T rows
         bool debug_sync = false;    // FFVD_DEBUG_SYNC: name every launch group on stderr and wait for it (locates a faulting kernel)
     } sw;
     // resident parameters / data (handle-owned copies)
@@ -186,6 +188,7 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
         w.fused_project = on("FFVD_FUSED_PROJECT");   w.grad_explicit = on("FFVD_GRAD_EXPLICIT");
         w.no_defer_trace = on("FFVD_NO_DEFER_TRACE"); w.no_late_join = on("FFVD_NO_LATE_JOIN");
         w.no_main_first = on("FFVD_NO_MAIN_FIRST");   w.no_kfu_first = on("FFVD_NO_KFU_FIRST");
+        w.whiten_products = on("FFVD_GRAD_WHITEN_PRODUCTS");   w.lt_armed = on("FFVD_GRAD_LT_ARMED");
         w.kuu_flow = !on("FFVD_NO_KUU_FLOW");   w.kinv_gram = on("FFVD_KINV_GRAM");   w.chain_rl = on("FFVD_CHAIN_RL");
         w.atb128 = on("FFVD_ATB128");                 w.grad_serial = on("FFVD_GRAD_SERIAL");
         w.debug_sync = on("FFVD_DEBUG_SYNC");
@@ -578,6 +581,15 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
     const size_t msq = (size_t)Mp * Mp;
     const bool grad_a = c.grad && c.branch == FFVD_BRANCH_A;
     const bool grad_ref = c.grad && c.branch == FFVD_BRANCH_B && !gram_route;     // training in the reference's op order (fp64 or fp32 contractions)
+    // Gram-route training, whitened backward pass (the default): the extension rows of every A-slab are armed with L^T instead of
+    // I, so that the factorisation of A leaves L^T L_A^-T = L_H^-T there (L_H = L^-1 L_A is the factor of H = L^-1 A L^-T) and
+    // y = L_A^-1 c = L_H^-1 W^T c in the b row: everything the whitened backward pass reads, without the two M^3 products per
+    // unit that formed H (0.8 ms at config 2).  DESIGN.md section 7.
+    const bool lt_rows = c.grad && gram_route && h->gw.whitened && !h->sw.whiten_products;
+    // ... and the dataflow factorisation reads L^T straight from the factor L (kernels.h, launch_potrf_ext lt_rows): nothing to arm,
+    // 2 x 268 MB less traffic at config 2.  The launch-per-column variants (forced by FFVD_CHOL or by the stall recovery) read the
+    // rows from memory: launch_set_lt_rows in front of them.
+    const bool lt_virtual = lt_rows && !h->sw.lt_armed && potrf_flow_selected((int)Mp, h->nbatch, CHOL_FLOW);
     auto project_args = [&](int s0, int ns) {
         ProjectArgs pa{};
         pa.kind = c.kernel_kind;
@@ -661,7 +673,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
             if (linv_done) {
                 launch_chain_reduce(s, reduce_args(), h->chain_partial);      // inputs only; fills the wait below
                 reduce_done = true;
-                if (c.grad && c.branch == FFVD_BRANCH_B) {
+                if (c.grad && c.branch == FFVD_BRANCH_B && !lt_rows) {
                     // training: the identity rows that become L_A^-T are re-armed here too (rows the K_fu build and the Gram
                     // kernel do not touch) instead of between the K_fu build and the Gram kernel
                     const GramArgs gi = gram_args(0, ns_first);
@@ -689,7 +701,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
         }
         // training: the identity rows that become L_A^-T are re-armed on the side stream, ahead of the K_uu build whose
         // event the main stream waits for anyway (0.05 ms off the critical path at the full batch)
-        ident_on_side = c.grad && (defer_full || defer_trace);
+        ident_on_side = c.grad && (defer_full || defer_trace) && !lt_rows;
         if (ident_on_side) {
             const GramArgs ga = gram_args(0, ns_first);
             launch_set_identity(sk, h->H, ga.h_stride, Mp, Mp, ns_first * Dl);
@@ -782,7 +794,9 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
         if (c.branch == FFVD_BRANCH_B) {
             GramArgs ga = gram_args(s0, ns);
             bool trace_pending = false, acopy_done = false;      // acopy_done: the Gram kernel stored the copy of A itself
-            if (c.grad && !((ident_on_side || ident_early) && s0 == 0)) launch_set_identity(s, h->H, ga.h_stride, Mp, Mp, ns * Dl);
+            if (lt_rows) {
+                // (armed right in front of the factorisation, when at all: L comes from the K_uu chain)
+            } else if (c.grad && !((ident_on_side || ident_early) && s0 == 0)) launch_set_identity(s, h->H, ga.h_stride, Mp, Mp, ns * Dl);
             if (s0 == 0 && late_join) {
                 if (!main_first) launch_gram(s, ga, 1);
                 if (defer_trace) {
@@ -828,7 +842,10 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
                 if (!acopy_done)
                     HIP_TRY(hipMemcpy2DAsync(h->gw.Acopy, msq * sizeof(double), h->H, ga.h_stride * sizeof(double),
                                              msq * sizeof(double), (size_t)ns * Dl, hipMemcpyDeviceToDevice, s));
-                if (h->gw.whitened && gram_route) {
+                if (lt_rows) {
+                    if (sk != s && s0 == 0) HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));       // L (and W, L^-1 for the backward pass) come from the K_uu chain
+                    if (!lt_virtual) launch_set_lt_rows(s, h->Kuu, kstride, Dl, h->H, ga.h_stride, Mp, Mp, ns * Dl);
+                } else if (h->gw.whitened && gram_route) {
                     // H = W^T A W (W = L^-T of K_uu) replaces A in the slab, b = W^T c replaces c: the factorisation, the
                     // explicit inverse and everything the backward pass derives from them then live in the whitened
                     // variables, where cond(H) is about 1e4 instead of the 1e7 of A
@@ -852,7 +869,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
                                              (size_t)Mp * sizeof(double), (size_t)nbp, hipMemcpyDeviceToDevice, s));
                 }
                 launch_potrf_ext(s, h->H, Mp, Mp + NB, Mp, ns * Dl, ga.h_stride, h->info + Dl + s0 * Dl, h->dinvH, CHOL_FLOW, nullptr, 0,
-                                 hwords_zeroed && s0 == 0, true);
+                                 hwords_zeroed && s0 == 0, true, nullptr, 0, lt_virtual ? h->Kuu : nullptr, kstride, Dl);
                 launch_h_finish(s, h->H, Mp, ga.h_stride, ns * Dl, h->hterms + (size_t)2 * s0 * Dl, 2 * Mp);
             } else {
                 launch_potrf_ext(s, h->H, Mp, NB, 0, ns * Dl, ga.h_stride, h->info + Dl + s0 * Dl, h->dinvH, CHOL_FLOW, nullptr, 0,
@@ -872,7 +889,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
     fa.log_Q = p.log_Q; fa.CC = p.CC; fa.DD = p.DD; fa.log_Rchols = p.log_Rchols;
     fa.chain_terms = h->chain_terms; fa.hterms = h->hterms; fa.chain_nll = h->chain_nll;
     fa.route = gram_route ? 1 : 0; fa.kterms = h->kterms; fa.trpart = h->trpart; fa.ntiles = h->ntiles;
-    fa.whitened = (c.grad && h->gw.whitened && gram_route) ? 1 : 0;
+    fa.whitened = (c.grad && h->gw.whitened && gram_route && !lt_rows) ? 1 : 0;      // L^T rows: the slab holds the factor of A itself
     if (c.dtype == FFVD_F32C) {           // sum_t |F_t|^2 per unit from the projection's fp64 tile sums
         launch_sum_partials(s, h->sqpart, h->nsq, h->nbatch, h->sqsum);
         fa.trpart = h->sqsum; fa.ntiles = 1; fa.fsq_from_trpart = 1;

@@ -66,7 +66,11 @@ bool potrf_flow_selected(int n, int batch, int hint);
 void launch_potrf_ext(hipStream_t stream, double *A, int n, int extra_rows, int identity_rows, int batch,
                       size_t slab_stride, int32_t *info, double *dinv, int hint = CHOL_AUTO, double *linv_t = nullptr,
                       size_t linv_t_stride = 0, bool words_zeroed = false, bool tail_is_vector = false, double *kinv = nullptr,
-                      size_t kinv_stride = 0);
+                      size_t kinv_stride = 0, const double *lt_rows = nullptr, size_t lt_stride = 0, int lt_dl = 1);
+// lt_rows (dataflow variant only -- ask potrf_flow_selected; the others read the rows from memory, arm them with
+// launch_set_lt_rows): the identity-structured extra rows of slab b START as L_d^T, d = b % lt_dl, read straight from the
+// lower-triangular factor L_d (n x n, ld n, slabs of lt_stride doubles) -- the rows in memory are not read, only written (and
+// their blocks left of the diagonal not at all: keep them zero).
 // kinv (dataflow variant with identity_rows == n, i.e. all of L^-T, and n <= 2048 -- ask potrf_flow_forms_inverse): the launch also
 // leaves A^-1 = L^-T L^-1 (n x n, ld n, both triangles) in every slab of kinv.
 bool potrf_flow_forms_inverse(int n, int batch, int hint);
@@ -77,6 +81,9 @@ bool potrf_flow_forms_inverse(int n, int batch, int hint);
 // stream whose order reaches the launch, and says so (words_zeroed).
 void potrf_flow_clear(hipStream_t stream, double *dinv, int batch);
 void launch_set_identity(hipStream_t stream, double *A, size_t slab_stride, int row0, int n, int batch);
+// rows [row0, row0 + n) of slab b <- L_d^T, d = b % Dl (upper triangular; L_d = lower-triangular n x n factor, ld n, n % 64 == 0)
+void launch_set_lt_rows(hipStream_t stream, const double *L, size_t l_stride, int Dl, double *A, size_t slab_stride, int row0,
+                        int n, int batch);
 // R <- R L^-T for `extra_rows` rows (multiple of NB) stored below a GIVEN lower-triangular factor L (n x n, ld n) in
 // every slab: the wavefront-level blocked substitution of the Cholesky panel step on its own.
 void launch_trsm_ext(hipStream_t stream, double *A, int n, int extra_rows, int batch, size_t slab_stride, double *dinv);

@@ -1136,6 +1136,10 @@ struct DfArgs {
     int vec_tail;      // the extra-row blocks behind the identity rows carry ONE live row each (their first): df_vector_row
     double *kinv;      // optional (identity rows = all of L^-T): (A)^-1 = L^-T L^-1, full symmetric n x n per slab (ld n), formed by
     size_t kinv_stride;//   the identity-row workgroups once their rows are complete (df_inverse_tiles)
+    int defer_ext;     // block order: identity-structured rows of all groups behind the main rows of all groups (potrf_df_kernel)
+    const double *lt;  // optional: the identity-structured extra rows of slab b start as L_d^T (d = b % lt_dl) instead of what
+    size_t lt_stride;  //   memory holds: block (e, j) = L_d(j, e)^T, read from the lower-triangular n x n factor L_d (ld n)
+    int lt_dl;
 };
 
 // Debug build only (-DFFVD_DF_TRACE, tools/df_trace.py): wall-clock stamps of matrix 0's block rows, in a buffer of their own.
@@ -1192,7 +1196,7 @@ template <bool LAST>
 __device__ __forceinline__ bool df_column(const DfArgs &a, double *S, int *pg, const double *dvb, const int row0, const int j,
                                           const int k0, double (*Xs)[LL_LD], double (*Ls)[LL_LD], double (*Dv)[16][DV_LD],
                                           int *wslot, int &wc, d4 (&cold_d)[2][2], d4 (&acc_d)[2][2], const int trow,
-                                          double *xt_row = nullptr) {
+                                          double *xt_row = nullptr, const double *lt_src = nullptr, const int lt_e = 0) {
     const int n = a.n;
     DF_STAMP(trow, 5 * (j & 7) + 0);
     const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
@@ -1210,7 +1214,11 @@ __device__ __forceinline__ bool df_column(const DfArgs &a, double *S, int *pg, c
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const size_t rr = (size_t)(row0 + qr * 32 + 16 * x + lk + 4 * q), cc = (size_t)(qc * 32 + 16 * y + lr);
-                cold_t[x][y][q] = S[rr * n + j0 + cc];
+                if (!LAST && lt_src) {       // block (e, j) of L^T: element [il][cl] = L[j0 + cl][e NB + il], zero below its diagonal
+                    const int il = qr * 32 + 16 * x + lk + 4 * q, cl = (int)cc;
+                    const double v = lt_src[(size_t)(j0 + cl) * n + lt_e * NB + il];
+                    cold_t[x][y][q] = (j > lt_e || cl >= il) ? v : 0.0;
+                } else cold_t[x][y][q] = S[rr * n + j0 + cc];
                 if (LAST) cold_d[x][y][q] = S[rr * n + row0 + cc];
             }
             acc_t[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
@@ -1486,9 +1494,27 @@ __global__ __launch_bounds__(256, 2) void potrf_df_kernel(DfArgs a) {
     __shared__ double Dv[4][16][DV_LD];
     __shared__ int wslot[2];
     const int n = a.n, nb = a.nb;
-    const int per_group = (nb + a.next) * a.G;
-    const int grp = blockIdx.x / per_group, rem = blockIdx.x % per_group;
-    const int ri = rem / a.G, b = grp * a.G + rem % a.G;
+    int grp, rem, ri;
+    if (a.defer_ext) {
+        // several groups with identity-structured rows: the main rows (and the tail rows) of EVERY group first, then the
+        // identity-structured rows of every group -- those wait for diagonal blocks only, and behind the main rows of all matrices
+        // they find them finished and hold their slot for a few microseconds per column instead of for the length of the chain
+        const int rows_a = nb + a.next - a.nid, per_a = rows_a * a.G, n_a = ((a.batch + a.G - 1) / a.G) * per_a;
+        if ((int)blockIdx.x < n_a) {
+            grp = blockIdx.x / per_a; rem = blockIdx.x % per_a;
+            const int rr = rem / a.G;
+            ri = (rr < nb) ? rr : rr + a.nid;
+        } else {
+            const int id2 = blockIdx.x - n_a, per_b = a.nid * a.G;
+            grp = id2 / per_b; rem = id2 % per_b;
+            ri = nb + rem / a.G;
+        }
+    } else {
+        const int per_group = (nb + a.next) * a.G;
+        grp = blockIdx.x / per_group; rem = blockIdx.x % per_group;
+        ri = rem / a.G;
+    }
+    const int b = grp * a.G + rem % a.G;
     if (b >= a.batch) return;
     const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1516,9 +1542,11 @@ __global__ __launch_bounds__(256, 2) void potrf_df_kernel(DfArgs a) {
     {
         const int nplain = main_row ? ncols - 1 : ncols;
         double *xt_row = (a.xt && !main_row && ri - nb < a.nid) ? a.xt + (size_t)b * a.xt_stride + (size_t)(ri - nb) * NB : nullptr;
+        const double *lt_src = (a.lt && !main_row && ri - nb < a.nid) ? a.lt + (size_t)(b % a.lt_dl) * a.lt_stride : nullptr;
         for (int j = k0; j < nplain; ++j) {
             d4 unused_c[2][2], unused_a[2][2];
-            if (!df_column<false>(a, S, pg, dvb, row0, j, k0, Xs, Ls, Dv, wslot, wc, unused_c, unused_a, trow, xt_row)) {
+            if (!df_column<false>(a, S, pg, dvb, row0, j, k0, Xs, Ls, Dv, wslot, wc, unused_c, unused_a, trow, xt_row, lt_src,
+                                  ri - nb)) {
                 if (tid == 0 && a.info) a.info[b] = -1;
                 return;
             }
@@ -1609,8 +1637,10 @@ void potrf_flow_clear(hipStream_t stream, double *scratch, int batch) {
 
 static void launch_potrf_flow(hipStream_t stream, double *A, int n, int extra_rows, int identity_rows, int batch,
                               size_t slab_stride, int32_t *info, double *scratch, double *linv_t, size_t linv_t_stride,
-                              bool words_zeroed, bool tail_is_vector, double *kinv, size_t kinv_stride) {
+                              bool words_zeroed, bool tail_is_vector, double *kinv, size_t kinv_stride, const double *lt_rows,
+                              size_t lt_stride, int lt_dl) {
     DfArgs a{};
+    a.lt = lt_rows; a.lt_stride = lt_stride; a.lt_dl = lt_dl > 0 ? lt_dl : 1;
     a.xt = linv_t; a.xt_stride = linv_t_stride;
     a.vec_tail = tail_is_vector ? 1 : 0;
     if (kinv && identity_rows == n && 2 * (n / NB) <= DF_PS) { a.kinv = kinv; a.kinv_stride = kinv_stride; }
@@ -1628,6 +1658,8 @@ static void launch_potrf_flow(hipStream_t stream, double *A, int n, int extra_ro
     a.G = ((size_t)bp * R <= 2048) ? bp : ((1024 / R + 7) / 8 * 8 < 8 ? 8 : (1024 / R + 7) / 8 * 8);
     if (a.G > bp) a.G = bp;
     const int groups = (batch + a.G - 1) / a.G;
+    static const int defer_mode = [] { const char *e = getenv("FFVD_DF_DEFER"); return e ? atoi(e) : -1; }();
+    a.defer_ext = (a.nid > 0 && groups > 1 && !a.xt && !a.kinv && defer_mode != 0) ? 1 : 0;
     // Few matrices (every block row finds a CU of its own): 16 KB of unused dynamic LDS keep a second workgroup off the CU --
     // a pivot chain that shares its SIMD with another row's MFMA loop takes up to twice as long (tools/df_trace.py)
     static const int pad_mode = [] { const char *e = getenv("FFVD_DF_PAD"); return e ? atoi(e) : -1; }();
@@ -1664,13 +1696,14 @@ static int chol_variant(int batch, int nb, int hint) {
 
 void launch_potrf_ext(hipStream_t stream, double *A, int n, int extra_rows, int identity_rows, int batch,
                       size_t slab_stride, int32_t *info, double *dinv, int hint, double *linv_t, size_t linv_t_stride,
-                      bool words_zeroed, bool tail_is_vector, double *kinv, size_t kinv_stride) {
+                      bool words_zeroed, bool tail_is_vector, double *kinv, size_t kinv_stride, const double *lt_rows,
+                      size_t lt_stride, int lt_dl) {
     const int nb = n / NB;
     const int nid = identity_rows / NB, ntail = extra_rows / NB - nid;
     const int variant = chol_variant(batch, nb, hint);
     if (variant == 3) {
         launch_potrf_flow(stream, A, n, extra_rows, identity_rows, batch, slab_stride, info, dinv, linv_t, linv_t_stride, words_zeroed,
-                          tail_is_vector, kinv, kinv_stride);
+                          tail_is_vector, kinv, kinv_stride, lt_rows, lt_stride, lt_dl);
         return;
     }
     if (variant == 1) {
@@ -1726,6 +1759,32 @@ __global__ void set_identity_kernel(double *A, size_t slab_stride, int row0, int
 void launch_set_identity(hipStream_t stream, double *A, size_t slab_stride, int row0, int n, int batch) {
     hipLaunchKernelGGL(set_identity_kernel, dim3((unsigned)(((size_t)n * n + 255) / 256), batch), dim3(256), 0, stream, A,
                        slab_stride, row0, n);
+}
+
+// rows [row0, row0 + n) of slab b <- L_d^T (upper triangular, zeros left of the diagonal), d = b % Dl, from the lower-triangular
+// n x n factor L_d (ld n).  Training forward of the Gram route: with L^T instead of I in the extension rows, the factorisation of
+// A = K + K_uf K_fu / Q leaves  L^T L_A^-T = L_H^-T  there, L_H = L^-1 L_A being the Cholesky factor of H = L^-1 A L^-T -- the
+// whitened quantities of the backward pass without forming H.  64 x 64 tiles through LDS.
+__global__ __launch_bounds__(256) void set_lt_rows_kernel(const double *L, size_t l_stride, int Dl, double *A, size_t slab_stride,
+                                                          int row0, int n) {
+    __shared__ double tile[64][65];
+    const int nt = n / 64, tr = blockIdx.x / nt, tc = blockIdx.x % nt, b = blockIdx.y;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    double *Ab = A + (size_t)b * slab_stride + (size_t)(row0 + tr * 64) * n + tc * 64;
+    if (tc < tr) {
+        for (int r = ty; r < 64; r += 4) Ab[(size_t)r * n + tx] = 0.0;
+        return;
+    }
+    // out[r][c] = L[tc * 64 + c][tr * 64 + r]
+    const double *Lb = L + (size_t)(b % Dl) * l_stride + (size_t)(tc * 64) * n + tr * 64;
+    for (int c = ty; c < 64; c += 4) tile[c][tx] = Lb[(size_t)c * n + tx];
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) Ab[(size_t)r * n + tx] = (tc > tr || tx >= r) ? tile[tx][r] : 0.0;
+}
+void launch_set_lt_rows(hipStream_t stream, const double *L, size_t l_stride, int Dl, double *A, size_t slab_stride, int row0,
+                        int n, int batch) {
+    const int nt = n / 64;
+    hipLaunchKernelGGL(set_lt_rows_kernel, dim3(nt * nt, batch), dim3(256), 0, stream, L, l_stride, Dl, A, slab_stride, row0, n);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -483,6 +483,35 @@ def test_full_batch_gradient_config2(monkeypatch):
     assert ts["nll"] == pytest.approx(tw["nll"], rel=1e-9)
 
 
+def test_training_forward_variants_agree(monkeypatch):
+    """The Gram-route training forward factorises A with L^T in the extension rows (L_H^-T = L^T L_A^-T comes out, DESIGN.md
+    section 7) and the dataflow kernel reads those rows straight from L.  Two longer ways to the same numbers stay selectable and
+    must agree: the rows written to memory first (what the launch-per-column Cholesky variants need), and H = W^T A W formed by
+    two products and factorised with identity rows (rounds 1-2).  Odd M (padding), two passes' worth of shapes."""
+    for name, kw in (("small", {}), ("ragged", {}), ("c2", dict(S=2, T=512, M=200))):
+        params, Y, c, meta = synthetic.make_named(name, **kw)
+
+        def grads():
+            with ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], meta["S"], route="gram", grad=True) as e:
+                e.set_data(Y, c)
+                return e.nll_and_grad(params)
+
+        t0, g0 = grads()
+        monkeypatch.setenv("FFVD_GRAD_LT_ARMED", "1")
+        t1, g1 = grads()
+        monkeypatch.delenv("FFVD_GRAD_LT_ARMED")
+        monkeypatch.setenv("FFVD_GRAD_WHITEN_PRODUCTS", "1")
+        t2, g2 = grads()
+        monkeypatch.delenv("FFVD_GRAD_WHITEN_PRODUCTS")
+        assert t1["nll"] == t0["nll"]
+        assert t2["nll"] == pytest.approx(t0["nll"], rel=1e-9, abs=1e-10)
+        for k in GRAD_KEYS:
+            np.testing.assert_array_equal(g1[k], g0[k], err_msg=name + " " + k)         # same arithmetic, rows via memory
+            scale = np.max(np.abs(g0[k])) + 1e-300
+            tol = 1e-6 if k in ("Z", "loglengthscales", "logvariance") else 1e-8
+            np.testing.assert_allclose(g2[k], g0[k], rtol=0, atol=tol * scale, err_msg=name + " " + k)
+
+
 @pytest.mark.parametrize("branch", ["B", "A"])
 def test_no_control_inputs(branch):
     """C = 0: the reference concatenates control inputs only when they exist (dgp_model.py:268-271, base_model.py:243-246);

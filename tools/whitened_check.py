@@ -131,3 +131,38 @@ def dz_alt(X):
     return -out / T
 v = sum(dz_alt(params["X"][s]) for s in range(S)) / S + Z / T
 print("K^-1 - B^T B ", " ".join("%+.2e" % (v[i] - f) for i, f in fd.items()))
+
+# Round 3: the same whitened quantities WITHOUT forming H.  L_H = L^-1 L_A (both lower triangular, so the product is H's Cholesky
+# factor), hence L_H^-T = L^T L_A^-T: the factorisation of A with L^T in the extension rows (instead of I) leaves L_H^-T there, and
+# y = L_A^-1 c equals L_H^-1 W^T c.  No W^T A W products.
+def dz_lt(X):
+    xc = np.concatenate((X[:-1], c[:T]), axis=1)
+    delta = X[1:] - X[:-1]
+    out = np.zeros_like(Z)
+    for d in range(D):
+        ell = np.exp(params["loglengthscales"][d])
+        kern = orc.SquaredExponential(params["logvariance"][d], params["loglengthscales"][d])
+        alpha = 1.0 / Q[d]
+        Kuu = kern.K(Z); K = Kuu + jitter * np.eye(M); Kf = kern.K(xc, Z)
+        G = Kf.T @ Kf; gv = Kf.T @ delta[:, d]
+        L = np.linalg.cholesky(K)
+        Linv = solve_triangular(L, np.eye(M), lower=True)
+        W = Linv.T
+        A = K + alpha * G
+        LA = np.linalg.cholesky(A)
+        LHinvT = solve_triangular(LA, L, lower=True).T      # rows: L^T L_A^-T (what the extension rows hold)
+        y = solve_triangular(LA, alpha * gv, lower=True)
+        B = LHinvT.T @ Linv
+        w = LHinvT @ y
+        u = W @ w
+        Kinv_w = W @ W.T
+        Ainv_w = B.T @ B
+        Gam = 0.5 * alpha * (Kinv_w - Ainv_w - np.outer(u, u))
+        Psi = 0.5 * (Kinv_w - Ainv_w - np.outer(u, u)) - 0.5 * alpha * (W @ (W.T @ G @ W) @ W.T)
+        dKf = 2.0 * Kf @ Gam + np.outer(delta[:, d], alpha * u)
+        _, dZ1, _, _ = _se_chain(dKf * Kf, xc, Z, ell, same=False)
+        dZ2, _, _, _ = _se_chain(Psi * Kuu, Z, Z, ell, same=True)
+        out += dZ1 + dZ2
+    return -out / T
+v = sum(dz_lt(params["X"][s]) for s in range(S)) / S + Z / T
+print("L^T rows     ", " ".join("%+.2e" % (v[i] - f) for i, f in fd.items()))
