@@ -49,6 +49,8 @@ struct ffvd_handle {
     struct Switches {
         bool fused_project = false, grad_explicit = false, no_defer_trace = false, no_late_join = false;
         bool no_main_first = false, no_kfu_first = false, atb128 = false, grad_serial = false, kuu_flow = true, kinv_gram = false, chain_rl = false;
+        bool no_host_main_first = false;  // FFVD_NO_HOST_MAIN_FIRST=1: one-pass split-K iteration with the chain's launches enqueued ahead of the combine pass (round 2)
+        bool no_small_side = false;       // FFVD_NO_SMALL_SIDE=1: tiny iterations keep the launch-per-step K_uu chain (round 2)
         bool lt_armed = false;            // FFVD_GRAD_LT_ARMED=1: write the L^T rows to memory (launch_set_lt_rows) even where the dataflow kernel could read L itself
         bool whiten_products = false;     // FFVD_GRAD_WHITEN_PRODUCTS=1: training forward forms H = W^T A W with two products (round 1/2) instead of arming L^T rows
         bool debug_sync = false;    // FFVD_DEBUG_SYNC: name every launch group on stderr and wait for it (locates a faulting kernel)
@@ -188,7 +190,7 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
         w.fused_project = on("FFVD_FUSED_PROJECT");   w.grad_explicit = on("FFVD_GRAD_EXPLICIT");
         w.no_defer_trace = on("FFVD_NO_DEFER_TRACE"); w.no_late_join = on("FFVD_NO_LATE_JOIN");
         w.no_main_first = on("FFVD_NO_MAIN_FIRST");   w.no_kfu_first = on("FFVD_NO_KFU_FIRST");
-        w.whiten_products = on("FFVD_GRAD_WHITEN_PRODUCTS");   w.lt_armed = on("FFVD_GRAD_LT_ARMED");
+        w.whiten_products = on("FFVD_GRAD_WHITEN_PRODUCTS");   w.lt_armed = on("FFVD_GRAD_LT_ARMED");   w.no_host_main_first = on("FFVD_NO_HOST_MAIN_FIRST");   w.no_small_side = on("FFVD_NO_SMALL_SIDE");
         w.kuu_flow = !on("FFVD_NO_KUU_FLOW");   w.kinv_gram = on("FFVD_KINV_GRAM");   w.chain_rl = on("FFVD_CHAIN_RL");
         w.atb128 = on("FFVD_ATB128");                 w.grad_serial = on("FFVD_GRAD_SERIAL");
         w.debug_sync = on("FFVD_DEBUG_SYNC");
@@ -707,48 +709,68 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
             launch_set_identity(sk, h->H, ga.h_stride, Mp, Mp, ns_first * Dl);
         }
     }
+    const ReduceArgs ra = reduce_args();
+    const bool reduce_early = gram_route && sk != s;
+    // One split-K pass with the main stream enqueued first: the HOST order matters too.  The combine pass, Cholesky(A) and its
+    // finish are enqueued right behind the K_uu build (the only thing of the chain they need), and the dozen launches of the rest
+    // of the chain after them -- with the chain's launches in front, the combine pass reached the queue 50-60 us after the tile
+    // pass had ended (tools/prof_timeline.sh SYNC_S=1 / 4, tools/prof_actuator_timeline.sh: the GPU was waiting for the host).
+    // ... unless the whole iteration is a handful of workgroups (the reference's own experiment size, FFVD_Main.py:356-369: M = 100,
+    // T <= 512): then nothing competes for slots and the side chain IS the critical path -- it is enqueued first, as ONE dataflow
+    // launch that also leaves L^-1 and K^-1 instead of six dependent launches, and the per-chain reductions move to the main stream
+    const bool small_side = defer_trace && main_first && !c.grad && !kuu_on_main && sk != s && !h->sw.chain_rl && !h->sw.no_small_side &&
+                            (size_t)first_units * h->ntiles * (h->gsplit > 1 ? h->gsplit : 1) <= 128;
+    const bool host_main_first = defer_trace && main_first && !c.grad && !kuu_on_main && sk != s && !small_side && !h->sw.no_host_main_first;
+    int chain_rc = FFVD_OK;
+    bool reduce_on_main = small_side;     // the per-chain reductions ride on the main stream, which has the slack there
+    bool reduce_launched = false;
+    auto chain_rest = [&]() -> int {
+        if (!kuu_on_main) {
+            // chain on the main stream = on the critical path with nothing beside it: the dataflow launch; on the side stream
+            // (beside the K_fu build / tile pass of a small batch) the right-looking launches, whose workgroups come and go
+            const bool chain_flow = ((sk == s) || small_side) && potrf_flow_selected((int)Mp, (int)Dl, CHOL_FLOW) && !h->sw.chain_rl;
+            if (chain_flow && (gram_route || grad_a || grad_ref)) linv_done = true;
+            if (chain_flow && small_side && gram_route && potrf_flow_forms_inverse((int)Mp, (int)Dl, CHOL_FLOW)) kinv_done = true;
+            launch_potrf_ext(sk, h->Kuu, Mp, Mp, Mp, Dl, kstride, h->info, h->dinvK, chain_flow ? CHOL_FLOW : CHOL_AUTO,
+                             linv_done ? h->Linv : nullptr, msq, false, false, kinv_done ? h->Kinv : nullptr, msq);
+        }
+        if (gram_route || grad_a || grad_ref) {
+            // K^-1 = L^-T L^-1 (shared by all chains) and log|K|
+            if (!linv_done) launch_transpose(sk, h->Kuu + msq, kstride, h->Linv, msq, Mp, Dl);
+            GramArgs gk{};
+            gk.mode = GRAM_PLAIN; gk.A = h->Linv; gk.a_stride = msq; gk.rows = Mp; gk.with_row = 0; gk.Mp = Mp; gk.Dl = Dl;
+            gk.d_begin = c.d_begin; gk.b0 = 0; gk.nb = Dl; gk.yn_over_batch = 1.0; gk.H = h->Kinv; gk.h_stride = msq;
+            if (kinv_done) {
+                // (the identity-row workgroups of the chain's launch have formed it: kernels.hip, df_inverse_tiles)
+            } else if (c.grad || (kuu_on_main && !h->sw.kinv_gram)) {
+                // the backward pass reads K^-1 everywhere, the Gram kernel only writes lower tiles; and beside the K_fu build
+                // (kuu_on_main: the main stream waits for this product) 256-thread workgroups find a slot where the Gram
+                // kernel's 1024-thread ones wait for the build to drain (0.19 against 0.05 ms)
+                AtbArgs ak{};
+                ak.mode = ATB_PLAIN; ak.A = h->Linv; ak.a_stride = msq; ak.lda = Mp; ak.nA = Mp; ak.B = h->Linv; ak.b_stride = msq;
+                ak.ldb = Mp; ak.nB = Mp; ak.rows = Mp; ak.C = h->Kinv; ak.c_stride = msq; ak.ldc = Mp; ak.nb = Dl; ak.Dl = Dl;
+                ak.k_lower = 1;                                  // L^-1 is lower triangular
+                ak.small_tiles = kuu_on_main ? 1 : 0;
+                launch_atb(sk, ak);
+            } else launch_gram(sk, gk);     // (split-K here was measured slower: 0.42 vs 0.37 ms for the K_uu stage)
+            launch_h_finish(sk, h->Kuu, Mp, kstride, Dl, h->kterms);
+            if (sk != s) HIP_TRY(hipEventRecord(h->ev_join, sk));
+        }
+        // the per-chain likelihood / transition reductions depend on the inputs only (Gram route: no row sums of F), so
+        // they ride on the side stream behind the K_uu chain and are back long before finalize needs them (kuu_on_main: they
+        // already ran on the main stream while it waited for the chain's kernel to be dispatched)
+        if (reduce_early && !reduce_done && !reduce_on_main) {
+            launch_chain_reduce(sk, ra, h->chain_partial);
+            HIP_TRY(hipEventRecord(h->ev_join2, sk));
+        }
+        return FFVD_OK;
+    };
     if (!kuu_on_main) {
         launch_kuu_build(sk, c.kernel_kind, hv, c.M, Mp, P, Dl, c.jitter, h->Kuu, (gram_route || grad_a || grad_ref) ? h->Kcopy : nullptr);
         if (defer_trace || (defer_full && sk != s)) HIP_TRY(hipEventRecord(h->ev_kuu, sk));
-        // chain on the main stream = on the critical path with nothing beside it: the dataflow launch; on the side stream
-        // (beside the K_fu build / tile pass of a small batch) the right-looking launches, whose workgroups come and go
-        const bool chain_flow = (sk == s) && potrf_flow_selected((int)Mp, (int)Dl, CHOL_FLOW) && !h->sw.chain_rl;
-        if (chain_flow && (gram_route || grad_a || grad_ref)) linv_done = true;
-        launch_potrf_ext(sk, h->Kuu, Mp, Mp, Mp, Dl, kstride, h->info, h->dinvK, chain_flow ? CHOL_FLOW : CHOL_AUTO,
-                         linv_done ? h->Linv : nullptr, msq);
     }
-    if (gram_route || grad_a || grad_ref) {
-        // K^-1 = L^-T L^-1 (shared by all chains) and log|K|
-        if (!linv_done) launch_transpose(sk, h->Kuu + msq, kstride, h->Linv, msq, Mp, Dl);
-        GramArgs gk{};
-        gk.mode = GRAM_PLAIN; gk.A = h->Linv; gk.a_stride = msq; gk.rows = Mp; gk.with_row = 0; gk.Mp = Mp; gk.Dl = Dl;
-        gk.d_begin = c.d_begin; gk.b0 = 0; gk.nb = Dl; gk.yn_over_batch = 1.0; gk.H = h->Kinv; gk.h_stride = msq;
-        if (kinv_done) {
-            // (the identity-row workgroups of the chain's launch have formed it: kernels.hip, df_inverse_tiles)
-        } else if (c.grad || (kuu_on_main && !h->sw.kinv_gram)) {
-            // the backward pass reads K^-1 everywhere, the Gram kernel only writes lower tiles; and beside the K_fu build
-            // (kuu_on_main: the main stream waits for this product) 256-thread workgroups find a slot where the Gram
-            // kernel's 1024-thread ones wait for the build to drain (0.19 against 0.05 ms)
-            AtbArgs ak{};
-            ak.mode = ATB_PLAIN; ak.A = h->Linv; ak.a_stride = msq; ak.lda = Mp; ak.nA = Mp; ak.B = h->Linv; ak.b_stride = msq;
-            ak.ldb = Mp; ak.nB = Mp; ak.rows = Mp; ak.C = h->Kinv; ak.c_stride = msq; ak.ldc = Mp; ak.nb = Dl; ak.Dl = Dl;
-            ak.k_lower = 1;                                  // L^-1 is lower triangular
-            ak.small_tiles = kuu_on_main ? 1 : 0;
-            launch_atb(sk, ak);
-        } else launch_gram(sk, gk);     // (split-K here was measured slower: 0.42 vs 0.37 ms for the K_uu stage)
-        launch_h_finish(sk, h->Kuu, Mp, kstride, Dl, h->kterms);
-        if (sk != s) HIP_TRY(hipEventRecord(h->ev_join, sk));
-    }
+    if (!host_main_first && (chain_rc = chain_rest()) != FFVD_OK) return chain_rc;
     DBG_SYNC(h, "forward: K_uu chain");
-    const ReduceArgs ra = reduce_args();
-    // the per-chain likelihood / transition reductions depend on the inputs only (Gram route: no row sums of F), so
-    // they ride on the side stream behind the K_uu chain and are back long before finalize needs them (kuu_on_main: they
-    // already ran on the main stream while it waited for the chain's kernel to be dispatched)
-    const bool reduce_early = gram_route && sk != s;
-    if (reduce_early && !reduce_done) {
-        launch_chain_reduce(sk, ra, h->chain_partial);
-        HIP_TRY(hipEventRecord(h->ev_join2, sk));
-    }
     if (st && !kfu_first) st->mark(0);
     for (int s0 = 0; s0 < c.S_local; s0 += h->cpp) {
         const int ns = (s0 + h->cpp <= c.S_local) ? h->cpp : c.S_local - s0;
@@ -829,7 +851,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
             }
             if (st) st->mark(2);
             DBG_SYNC(h, "forward: Gram");
-            if (trace_pending) {
+            if (trace_pending && !host_main_first) {
                 // trace partials from the raw tiles, on the side stream (K^-1 precedes in its order).  Enqueued AHEAD of the
                 // factorisation: that is one launch whose row workgroups hold every slot of the chip for most of its length,
                 // and a kernel that arrives behind it only starts when they leave (finalize then waited 0.26 ms for this pass)
@@ -875,6 +897,16 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
                 launch_potrf_ext(s, h->H, Mp, NB, 0, ns * Dl, ga.h_stride, h->info + Dl + s0 * Dl, h->dinvH, CHOL_FLOW, nullptr, 0,
                                  hwords_zeroed && s0 == 0, true);
                 launch_h_finish(s, h->H, Mp, ga.h_stride, ns * Dl, h->hterms + (size_t)2 * s0 * Dl);
+            }
+            if (reduce_on_main && !reduce_launched) { launch_chain_reduce(s, ra, h->chain_partial); reduce_launched = true; }
+            if (trace_pending) {        // host_main_first: the rest of the K_uu chain and the trace partials reach their queue now
+                launch_chain_reduce(s, ra, h->chain_partial);
+                reduce_on_main = reduce_launched = true;
+                if ((chain_rc = chain_rest()) != FFVD_OK) return chain_rc;
+                HIP_TRY(hipStreamWaitEvent(sk, h->ev_tiles, 0));
+                launch_gram(sk, ga, 3);
+                HIP_TRY(hipEventRecord(h->ev_join2, sk));
+                trace_pending = false;
             }
             if (st) st->mark(3);
             DBG_SYNC(h, "forward: Cholesky(H) + solves");

@@ -633,7 +633,9 @@ def test_time_shard_through_native_rccl_one_rank():
         assert finish(sh.step()) == t
     finally:
         sh.close()
-    assert t["nll"] == pytest.approx(whole["nll"], rel=1e-12)
+    # not the same arithmetic since round 3: at this size the plain handle's K_uu chain is one dataflow launch that forms K^-1
+    # itself, the T-shard handle multiplies L^-T L^-1 in a launch of its own -- eps * cond(K_uu) on the trace term
+    assert t["nll"] == pytest.approx(whole["nll"], rel=1e-9)
     with pytest.raises(ValueError):
         ElboEngine(64, 2, 1, 16, 1, route="reference", t_shard=(0, 128))      # the Gram form is what makes T additive
     with pytest.raises(ValueError):

@@ -11,7 +11,8 @@ Y, c = z["Y"], z["control_inputs"]
 T, D = params["X"].shape[0]-1, params["X"].shape[1]
 M, C = params["Z"].shape[0], c.shape[1]
 params["X"] = params["X"][None]
-for grad in (False, True):
+modes = {'forward': (False,), 'train': (True,)}.get(sys.argv[1] if len(sys.argv) > 1 else '', (False, True))
+for grad in modes:
     e = ElboEngine(T, D, C, M, 1, route="gram", grad=grad)
     e.set_data(Y, c); e.set_params(params)
     f = (lambda: e.adam_step(1e-9)) if grad else (lambda: e.nll_terms())

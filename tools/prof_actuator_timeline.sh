@@ -1,8 +1,8 @@
 set -e
 cd /tmp && export TMPDIR=/tmp
-OUT=$GRAFT_REPO_ROOT/gpurun_out/r10a
+OUT=$GRAFT_REPO_ROOT/gpurun_out/actuator_tl_${1:-both}
 mkdir -p $OUT
-rocprofv3 --kernel-trace --output-format csv -d $OUT/tl -- python3 $GRAFT_REPO_ROOT/tools/actuator_step.py > $OUT/out.txt 2> $OUT/err.txt
+rocprofv3 --kernel-trace --output-format csv -d $OUT/tl -- python3 $GRAFT_REPO_ROOT/tools/actuator_step.py $1 > $OUT/out.txt 2> $OUT/err.txt
 python3 - <<PY
 import csv, glob
 f = glob.glob("$OUT/tl/**/*kernel_trace.csv", recursive=True)[0]
