@@ -49,7 +49,6 @@ struct ffvd_handle {
     struct Switches {
         bool fused_project = false, grad_explicit = false, no_defer_trace = false, no_late_join = false;
         bool no_main_first = false, no_kfu_first = false, atb128 = false, grad_serial = false, kuu_flow = true, kinv_gram = false, chain_rl = false;
-        bool no_host_main_first = false;  // FFVD_NO_HOST_MAIN_FIRST=1: one-pass split-K iteration with the chain's launches enqueued ahead of the combine pass (round 2)
         bool no_small_side = false;       // FFVD_NO_SMALL_SIDE=1: tiny iterations keep the launch-per-step K_uu chain (round 2)
         bool lt_armed = false;            // FFVD_GRAD_LT_ARMED=1: write the L^T rows to memory (launch_set_lt_rows) even where the dataflow kernel could read L itself
         bool whiten_products = false;     // FFVD_GRAD_WHITEN_PRODUCTS=1: training forward forms H = W^T A W with two products (round 1/2) instead of arming L^T rows
@@ -190,7 +189,7 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
         w.fused_project = on("FFVD_FUSED_PROJECT");   w.grad_explicit = on("FFVD_GRAD_EXPLICIT");
         w.no_defer_trace = on("FFVD_NO_DEFER_TRACE"); w.no_late_join = on("FFVD_NO_LATE_JOIN");
         w.no_main_first = on("FFVD_NO_MAIN_FIRST");   w.no_kfu_first = on("FFVD_NO_KFU_FIRST");
-        w.whiten_products = on("FFVD_GRAD_WHITEN_PRODUCTS");   w.lt_armed = on("FFVD_GRAD_LT_ARMED");   w.no_host_main_first = on("FFVD_NO_HOST_MAIN_FIRST");   w.no_small_side = on("FFVD_NO_SMALL_SIDE");
+        w.whiten_products = on("FFVD_GRAD_WHITEN_PRODUCTS");   w.lt_armed = on("FFVD_GRAD_LT_ARMED");   w.no_small_side = on("FFVD_NO_SMALL_SIDE");
         w.kuu_flow = !on("FFVD_NO_KUU_FLOW");   w.kinv_gram = on("FFVD_KINV_GRAM");   w.chain_rl = on("FFVD_CHAIN_RL");
         w.atb128 = on("FFVD_ATB128");                 w.grad_serial = on("FFVD_GRAD_SERIAL");
         w.debug_sync = on("FFVD_DEBUG_SYNC");
@@ -711,18 +710,13 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
     }
     const ReduceArgs ra = reduce_args();
     const bool reduce_early = gram_route && sk != s;
-    // One split-K pass with the main stream enqueued first: the HOST order matters too.  The combine pass, Cholesky(A) and its
-    // finish are enqueued right behind the K_uu build (the only thing of the chain they need), and the dozen launches of the rest
-    // of the chain after them -- with the chain's launches in front, the combine pass reached the queue 50-60 us after the tile
-    // pass had ended (tools/prof_timeline.sh SYNC_S=1 / 4, tools/prof_actuator_timeline.sh: the GPU was waiting for the host).
-    // ... unless the whole iteration is a handful of workgroups (the reference's own experiment size, FFVD_Main.py:356-369: M = 100,
-    // T <= 512): then nothing competes for slots and the side chain IS the critical path -- it is enqueued first, as ONE dataflow
-    // launch that also leaves L^-1 and K^-1 instead of six dependent launches, and the per-chain reductions move to the main stream
+    // The whole iteration is a handful of workgroups (the reference's own experiment size, FFVD_Main.py:356-369: M = 100, T <= 512):
+    // nothing competes for slots and the side chain IS the critical path -- ONE dataflow launch that also leaves L^-1 and K^-1
+    // instead of six dependent launches, and the per-chain reductions move to the main stream, which has the slack there
     const bool small_side = defer_trace && main_first && !c.grad && !kuu_on_main && sk != s && !h->sw.chain_rl && !h->sw.no_small_side &&
                             (size_t)first_units * h->ntiles * (h->gsplit > 1 ? h->gsplit : 1) <= 128;
-    const bool host_main_first = defer_trace && main_first && !c.grad && !kuu_on_main && sk != s && !small_side && !h->sw.no_host_main_first;
     int chain_rc = FFVD_OK;
-    bool reduce_on_main = small_side;     // the per-chain reductions ride on the main stream, which has the slack there
+    const bool reduce_on_main = small_side;
     bool reduce_launched = false;
     auto chain_rest = [&]() -> int {
         if (!kuu_on_main) {
@@ -769,7 +763,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
         launch_kuu_build(sk, c.kernel_kind, hv, c.M, Mp, P, Dl, c.jitter, h->Kuu, (gram_route || grad_a || grad_ref) ? h->Kcopy : nullptr);
         if (defer_trace || (defer_full && sk != s)) HIP_TRY(hipEventRecord(h->ev_kuu, sk));
     }
-    if (!host_main_first && (chain_rc = chain_rest()) != FFVD_OK) return chain_rc;
+    if ((chain_rc = chain_rest()) != FFVD_OK) return chain_rc;
     DBG_SYNC(h, "forward: K_uu chain");
     if (st && !kfu_first) st->mark(0);
     for (int s0 = 0; s0 < c.S_local; s0 += h->cpp) {
@@ -851,7 +845,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
             }
             if (st) st->mark(2);
             DBG_SYNC(h, "forward: Gram");
-            if (trace_pending && !host_main_first) {
+            if (trace_pending) {
                 // trace partials from the raw tiles, on the side stream (K^-1 precedes in its order).  Enqueued AHEAD of the
                 // factorisation: that is one launch whose row workgroups hold every slot of the chip for most of its length,
                 // and a kernel that arrives behind it only starts when they leave (finalize then waited 0.26 ms for this pass)
@@ -899,15 +893,6 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
                 launch_h_finish(s, h->H, Mp, ga.h_stride, ns * Dl, h->hterms + (size_t)2 * s0 * Dl);
             }
             if (reduce_on_main && !reduce_launched) { launch_chain_reduce(s, ra, h->chain_partial); reduce_launched = true; }
-            if (trace_pending) {        // host_main_first: the rest of the K_uu chain and the trace partials reach their queue now
-                launch_chain_reduce(s, ra, h->chain_partial);
-                reduce_on_main = reduce_launched = true;
-                if ((chain_rc = chain_rest()) != FFVD_OK) return chain_rc;
-                HIP_TRY(hipStreamWaitEvent(sk, h->ev_tiles, 0));
-                launch_gram(sk, ga, 3);
-                HIP_TRY(hipEventRecord(h->ev_join2, sk));
-                trace_pending = false;
-            }
             if (st) st->mark(3);
             DBG_SYNC(h, "forward: Cholesky(H) + solves");
         }
