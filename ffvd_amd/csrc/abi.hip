@@ -717,7 +717,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
                             (size_t)first_units * h->ntiles * (h->gsplit > 1 ? h->gsplit : 1) <= 128;
     int chain_rc = FFVD_OK;
     const bool reduce_on_main = small_side;
-    bool reduce_launched = false;
+    bool reduce_launched = false, trace_on_main = false;
     auto chain_rest = [&]() -> int {
         if (!kuu_on_main) {
             // chain on the main stream = on the critical path with nothing beside it: the dataflow launch; on the side stream
@@ -845,7 +845,11 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
             }
             if (st) st->mark(2);
             DBG_SYNC(h, "forward: Gram");
-            if (trace_pending) {
+            if (trace_pending && small_side) {
+                // tiny iteration: the trace partials wait for the chain on the MAIN stream, behind Cholesky(A) -- one cross-stream
+                // hop (chain -> here) instead of two (tile pass -> side stream, side stream -> finalize)
+                trace_on_main = true;
+            } else if (trace_pending) {
                 // trace partials from the raw tiles, on the side stream (K^-1 precedes in its order).  Enqueued AHEAD of the
                 // factorisation: that is one launch whose row workgroups hold every slot of the chip for most of its length,
                 // and a kernel that arrives behind it only starts when they leave (finalize then waited 0.26 ms for this pass)
@@ -893,12 +897,17 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
                 launch_h_finish(s, h->H, Mp, ga.h_stride, ns * Dl, h->hterms + (size_t)2 * s0 * Dl);
             }
             if (reduce_on_main && !reduce_launched) { launch_chain_reduce(s, ra, h->chain_partial); reduce_launched = true; }
+            if (trace_pending && trace_on_main) {
+                HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));
+                launch_gram(s, ga, 3);
+                trace_pending = false;
+            }
             if (st) st->mark(3);
             DBG_SYNC(h, "forward: Cholesky(H) + solves");
         }
     }
     if (!reduce_early) launch_chain_reduce(s, ra, h->chain_partial);
-    else if (!reduce_done) HIP_TRY(hipStreamWaitEvent(s, h->ev_join2, 0));
+    else if (!reduce_done && !trace_on_main) HIP_TRY(hipStreamWaitEvent(s, h->ev_join2, 0));
     FinalizeArgs fa{};
     fa.kind = c.kernel_kind; fa.branch = c.branch; fa.prior_type = c.prior_type; fa.shared_terms = c.shared_terms;
     fa.T = c.T; fa.D = c.D; fa.P = P; fa.M = c.M; fa.Ydim = c.Ydim; fa.Dl = Dl; fa.d_begin = c.d_begin;
