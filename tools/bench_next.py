@@ -1,6 +1,9 @@
 """Timings of the SURVEY 8f rows built on top of the ELBO hot path, at the headline shape (config 2):
 backward pass, device-resident Adam step, batched posterior rollouts.  Prints one JSON object."""
 import json, os, sys, time
+# RCCL prints a banner on stdout when a communicator forms: keep descriptor 1 for the JSON object alone (as bench.py does)
+_json_fd = os.dup(1)
+os.dup2(2, 1)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from ffvd_amd import synthetic, conditionals_multi_output as cmo
@@ -77,4 +80,4 @@ dt = time.perf_counter() - t0
 out["pg_sweep_N100_ms"] = dt * 1e3
 out["pg_sweep_N100_us_per_step"] = dt / T * 1e6
 out["pg_reference_share"] = float((idx == N - 1).mean())
-print(json.dumps(out))
+os.write(_json_fd, (json.dumps(out) + "\n").encode())
