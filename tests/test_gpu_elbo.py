@@ -1,5 +1,7 @@
 """GPU parity, model level: the full ELBO (`nll` + component terms) through the C ABI against the committed
 golden vectors, the oracle on the same seeded inputs, and size-independent properties at BASELINE's full size."""
+import os
+
 import numpy as np
 import pytest
 
@@ -510,6 +512,39 @@ def test_training_forward_variants_agree(monkeypatch):
             scale = np.max(np.abs(g0[k])) + 1e-300
             tol = 1e-6 if k in ("Z", "loglengthscales", "logvariance") else 1e-8
             np.testing.assert_allclose(g2[k], g0[k], rtol=0, atol=tol * scale, err_msg=name + " " + k)
+
+
+_DEFER_SCRIPT = r"""
+import sys
+import numpy as np
+from ffvd_amd import synthetic
+from ffvd_amd.engine import ElboEngine
+params, Y, c, meta = synthetic.make_named("c2", S=57, T=512, M=256)
+with ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], meta["S"], route="gram", grad=True) as e:
+    e.set_data(Y, c)
+    t, g = e.nll_and_grad(params)
+np.savez(sys.argv[1], nll=t["nll"], **g)
+"""
+
+
+def test_identity_structured_rows_behind_all_main_rows(tmp_path):
+    """228 matrices x (4 main + 4 identity-structured + 1 vector) block rows: the dataflow Cholesky runs them in two groups (120 and
+    108 matrices, the second one ragged) and dispatches the identity-structured rows of both groups behind the main rows of both
+    (DfArgs::defer_ext).  Which workgroup runs when must not change a bit: the same training forward + backward with the
+    round-2 block order (FFVD_DF_DEFER=0, read once per process, hence the child process) gives identical numbers."""
+    import subprocess
+    import sys
+    outs = []
+    for mode in ("1", "0"):
+        path = str(tmp_path / ("g%s.npz" % mode))
+        env = dict(os.environ, FFVD_DF_DEFER=mode, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        r = subprocess.run([sys.executable, "-c", _DEFER_SCRIPT, path], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(path))
+    assert np.isfinite(float(outs[0]["nll"])) and float(outs[0]["nll"]) == float(outs[1]["nll"])
+    for k in GRAD_KEYS:
+        assert np.all(np.isfinite(outs[0][k])), k
+        np.testing.assert_array_equal(outs[0][k], outs[1][k], err_msg=k)
 
 
 @pytest.mark.parametrize("branch", ["B", "A"])
