@@ -50,6 +50,7 @@ struct ffvd_handle {
         bool fused_project = false, grad_explicit = false, no_defer_trace = false, no_late_join = false;
         bool no_main_first = false, no_kfu_first = false, atb128 = false, grad_serial = false, kuu_flow = true, kinv_gram = false, chain_rl = false;
         bool no_small_side = false;       // FFVD_NO_SMALL_SIDE=1: tiny iterations keep the launch-per-step K_uu chain (round 2)
+        bool ref_row_in_gram = false;     // FFVD_REF_ROW_IN_GRAM=1: reference route, delta^T F formed by the Gram kernel's diagonal tiles (rounds 1-2)
         bool lt_armed = false;            // FFVD_GRAD_LT_ARMED=1: write the L^T rows to memory (launch_set_lt_rows) even where the dataflow kernel could read L itself
         bool whiten_products = false;     // FFVD_GRAD_WHITEN_PRODUCTS=1: training forward forms H = W^T A W with two products (round 1/2) instead of arming L^T rows
         bool debug_sync = false;    // FFVD_DEBUG_SYNC: name every launch group on stderr and wait for it (locates a faulting kernel)
@@ -189,7 +190,7 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
         w.fused_project = on("FFVD_FUSED_PROJECT");   w.grad_explicit = on("FFVD_GRAD_EXPLICIT");
         w.no_defer_trace = on("FFVD_NO_DEFER_TRACE"); w.no_late_join = on("FFVD_NO_LATE_JOIN");
         w.no_main_first = on("FFVD_NO_MAIN_FIRST");   w.no_kfu_first = on("FFVD_NO_KFU_FIRST");
-        w.whiten_products = on("FFVD_GRAD_WHITEN_PRODUCTS");   w.lt_armed = on("FFVD_GRAD_LT_ARMED");   w.no_small_side = on("FFVD_NO_SMALL_SIDE");
+        w.whiten_products = on("FFVD_GRAD_WHITEN_PRODUCTS");   w.lt_armed = on("FFVD_GRAD_LT_ARMED");   w.no_small_side = on("FFVD_NO_SMALL_SIDE");   w.ref_row_in_gram = on("FFVD_REF_ROW_IN_GRAM");
         w.kuu_flow = !on("FFVD_NO_KUU_FLOW");   w.kinv_gram = on("FFVD_KINV_GRAM");   w.chain_rl = on("FFVD_CHAIN_RL");
         w.atb128 = on("FFVD_ATB128");                 w.grad_serial = on("FFVD_GRAD_SERIAL");
         w.debug_sync = on("FFVD_DEBUG_SYNC");
@@ -371,7 +372,8 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
     if (c.branch == FFVD_BRANCH_B && c.dtype != FFVD_F32C) {
         const int upass = h->cpp * (int)Dl;
         h->gsplit = gram_ksplit((int)Mp, upass, (int)Tp);
-        const bool ext_row = c.route == FFVD_ROUTE_GRAM && c.T_total == 0;      // the K_fu build forms delta^T K_fu: the Gram kernel has no row
+        // the K_fu build forms delta^T K_fu (Gram route) / the projection GEMM forms delta^T F (reference route): the Gram kernel has no row
+        const bool ext_row = (c.route == FFVD_ROUTE_GRAM && c.T_total == 0) || (c.route == FFVD_ROUTE_REFERENCE && h->ngr > 0 && !h->sw.ref_row_in_gram);
         if (ext_row) HIP_TRY(dev_alloc(h, &h->growpart, (size_t)upass * (Tp / 64) * Mp));
         h->gtail_wg = gram_tail_wg((int)Mp, upass, h->gsplit, ext_row ? 0 : 1);
         if (h->gtail_wg > 0) {
@@ -608,7 +610,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
     auto gram_args = [&](int s0, int ns) {
         GramArgs ga{};
         ga.mode = gram_route ? GRAM_KFU : GRAM_F;
-        ga.A = h->F; ga.a_stride = (size_t)Tp * Mp; ga.rows = Tp; ga.with_row = (gram_route && h->growpart) ? 0 : 1;
+        ga.A = h->F; ga.a_stride = (size_t)Tp * Mp; ga.rows = Tp; ga.with_row = h->growpart ? 0 : 1;
         ga.X = p.X; ga.log_Q = p.log_Q; ga.T = c.T; ga.D = c.D; ga.Mp = Mp; ga.Dl = Dl;
         ga.d_begin = c.d_begin; ga.b0 = s0 * Dl; ga.nb = ns * Dl; ga.yn_over_batch = 1.0;
         ga.H = h->H; ga.h_stride = (size_t)(c.grad ? 2 * Mp + NB : Mp + NB) * Mp;
@@ -786,7 +788,11 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
             pg.Kf = h->Kf2; pg.kf_stride = (size_t)Tp * Mp; pg.W = h->Kuu + msq; pg.w_stride = kstride;
             pg.F = h->F; pg.f_stride = (size_t)Tp * Mp; pg.rowsq = h->rowsq; pg.Tp = Tp; pg.Mp = Mp; pg.Dl = Dl;
             pg.b0 = s0 * Dl; pg.nb = ns * Dl;
+            pg.gpart = h->growpart; pg.X = p.X; pg.T = c.T; pg.D = c.D; pg.d_begin = c.d_begin;      // delta^T F by 128-row tiles (:247-248)
             launch_proj_gemm(s, pg);                                  // tilde_F = Knm Lm^-T, sum F^2  (:242,:255)
+            if (h->growpart)
+                launch_brow_finish(s, h->growpart, (int)((Tp + 127) / 128), Mp, Dl, c.d_begin, s0 * Dl, ns * Dl, p.log_Q, 1.0, h->H,
+                                   (size_t)(c.grad ? 2 * Mp + NB : Mp + NB) * Mp, c.grad ? 2 * Mp : Mp);
         } else if (c.branch == FFVD_BRANCH_A && h->ngr) {
             // explicit-U branch: K_fu once, then the triangular GEMM with fvar / fmean folded into its epilogue (F unstored)
             pa.F = h->F + (grad_a ? (size_t)s0 * Dl * Tp * Mp : 0);

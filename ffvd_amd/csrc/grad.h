@@ -110,6 +110,11 @@ struct ProjGemmArgs {
     // explicit-U branch: F itself is not needed (F == nullptr), but its product with the inducing outputs is:
     const double *u; size_t u_stride;          // [Dl] Mp, u_d = U[:, d] (zero padded) or nullptr
     double *fmean;                             // [nb][ntj][Tp] partials of F u (conditionals_multi_output.py:48)
+    // collapsed branch, reference route: delta^T F summed where F is made (per 128-row tile), so that the Gram kernel forms no row
+    // and may use its fully loaded diagonal workgroups (kernels.h, launch_brow_finish adds the tiles' partials)
+    double *gpart;                             // [nb][ceil(Tp / 128)][Mp] or nullptr
+    const double *X;                           // chains S x (T+1) x D (delta_t = x_{t+1,d} - x_{t,d}), needed with gpart
+    int T, D, d_begin;
 };
 void launch_proj_gemm(hipStream_t stream, const ProjGemmArgs &a);
 

@@ -724,8 +724,29 @@ __global__ __launch_bounds__(512, 4) void proj_gemm_kernel(ProjGemmArgs a) {
     // epilogue: F (if wanted), the row sums of F^2 and (explicit-U branch) of F u over this tile's columns
     double *Fb = a.F ? a.F + (size_t)bz * a.f_stride : nullptr;
     const double *ub = a.u ? a.u + (size_t)dl * a.u_stride : nullptr;
+    const bool tile_inside = (ti + 1) * 128 <= Tp && (tj + 1) * 128 <= Mp;       // uniform: the stores of F need no per-element test
     double *rs_s = &As[0][0][0];                     // [4 wc][128 rows]
     double *fm_s = &Bs[0][0][0];
+    double *dl_s = rs_s + 512, *cp_s = rs_s + 640;   // delta of the tile's 128 rows; [8 wavefronts][4 lk][32 columns] partials
+    if (a.gpart) {
+        if (tid < 128) {
+            const int t = ti * 128 + tid, s = b / a.Dl, dg = a.d_begin + dl;
+            const double *Xs = a.X + (size_t)s * (a.T + 1) * a.D;
+            dl_s[tid] = (t < a.T) ? Xs[(size_t)(t + 1) * a.D + dg] - Xs[(size_t)t * a.D + dg] : 0.0;
+        }
+        __syncthreads();
+        double cp[2] = {0.0, 0.0};
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double dv = dl_s[wr * 64 + 16 * x + lk + 4 * q];
+#pragma unroll
+                for (int y = 0; y < 2; ++y) cp[y] = fma(dv, acc[x][y][q], cp[y]);
+            }
+#pragma unroll
+        for (int y = 0; y < 2; ++y) cp_s[(wave * 4 + lk) * 32 + 16 * y + lr] = cp[y];
+    }
     double uj[2];
 #pragma unroll
     for (int y = 0; y < 2; ++y) {
@@ -742,12 +763,12 @@ __global__ __launch_bounds__(512, 4) void proj_gemm_kernel(ProjGemmArgs a) {
             for (int y = 0; y < 2; ++y) {
                 const int j = J0 + 16 * y + lr;
                 const double f = acc[x][y][q];
-                if (Fb && i < Tp && j < Mp) Fb[(size_t)i * Mp + j] = f;
+                if (Fb && (tile_inside || (i < Tp && j < Mp))) Fb[(size_t)i * Mp + j] = f;
                 v += f * f;
                 w += f * uj[y];
             }
-            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-            if (ub) { w += __shfl_xor(w, 1); w += __shfl_xor(w, 2); w += __shfl_xor(w, 4); w += __shfl_xor(w, 8); }
+            v = row16_sum(v);               // DPP (__shfl_xor is an LDS round trip per step)
+            if (ub) w = row16_sum(w);
             if (lr == 0) {
                 rs_s[wc * 128 + wr * 64 + 16 * x + lk + 4 * q] = v;
                 fm_s[wc * 128 + wr * 64 + 16 * x + lk + 4 * q] = w;
@@ -760,6 +781,16 @@ __global__ __launch_bounds__(512, 4) void proj_gemm_kernel(ProjGemmArgs a) {
             const size_t o = ((size_t)b * ntj + tj) * Tp + t;
             a.rowsq[o] = (rs_s[tid] + rs_s[128 + tid]) + (rs_s[256 + tid] + rs_s[384 + tid]);
             if (a.fmean) a.fmean[o] = (fm_s[tid] + fm_s[128 + tid]) + (fm_s[256 + tid] + fm_s[384 + tid]);
+        }
+    } else if (a.gpart && tid < 256) {       // column c of the tile: wavefronts (wr, wc = c / 32), four lk partials each, fixed order
+        const int c = tid - 128, wq = c >> 5, cc = c & 31, j = tj * 128 + c;
+        if (j < Mp) {
+            double v = 0.0;
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v += cp_s[((r * 4 + wq) * 4 + k) * 32 + cc];
+            a.gpart[((size_t)bz * ((Tp + 127) / 128) + ti) * Mp + j] = v;
         }
     }
 }
