@@ -51,6 +51,7 @@ struct ffvd_handle {
         bool no_main_first = false, no_kfu_first = false, atb128 = false, grad_serial = false, kuu_flow = true, kinv_gram = false, chain_rl = false;
         bool no_small_side = false;       // FFVD_NO_SMALL_SIDE=1: tiny iterations keep the launch-per-step K_uu chain (round 2)
         bool ref_row_in_gram = false;     // FFVD_REF_ROW_IN_GRAM=1: reference route, delta^T F formed by the Gram kernel's diagonal tiles (rounds 1-2)
+        bool no_ref_side = false;         // FFVD_NO_REF_SIDE=1: reference route / explicit-U branch with the K_uu chain on the main stream in front of the K_fu build
         bool lt_armed = false;            // FFVD_GRAD_LT_ARMED=1: write the L^T rows to memory (launch_set_lt_rows) even where the dataflow kernel could read L itself
         bool whiten_products = false;     // FFVD_GRAD_WHITEN_PRODUCTS=1: training forward forms H = W^T A W with two products (round 1/2) instead of arming L^T rows
         bool debug_sync = false;    // FFVD_DEBUG_SYNC: name every launch group on stderr and wait for it (locates a faulting kernel)
@@ -190,7 +191,7 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
         w.fused_project = on("FFVD_FUSED_PROJECT");   w.grad_explicit = on("FFVD_GRAD_EXPLICIT");
         w.no_defer_trace = on("FFVD_NO_DEFER_TRACE"); w.no_late_join = on("FFVD_NO_LATE_JOIN");
         w.no_main_first = on("FFVD_NO_MAIN_FIRST");   w.no_kfu_first = on("FFVD_NO_KFU_FIRST");
-        w.whiten_products = on("FFVD_GRAD_WHITEN_PRODUCTS");   w.lt_armed = on("FFVD_GRAD_LT_ARMED");   w.no_small_side = on("FFVD_NO_SMALL_SIDE");   w.ref_row_in_gram = on("FFVD_REF_ROW_IN_GRAM");
+        w.whiten_products = on("FFVD_GRAD_WHITEN_PRODUCTS");   w.lt_armed = on("FFVD_GRAD_LT_ARMED");   w.no_small_side = on("FFVD_NO_SMALL_SIDE");   w.ref_row_in_gram = on("FFVD_REF_ROW_IN_GRAM");   w.no_ref_side = on("FFVD_NO_REF_SIDE");
         w.kuu_flow = !on("FFVD_NO_KUU_FLOW");   w.kinv_gram = on("FFVD_KINV_GRAM");   w.chain_rl = on("FFVD_CHAIN_RL");
         w.atb128 = on("FFVD_ATB128");                 w.grad_serial = on("FFVD_GRAD_SERIAL");
         w.debug_sync = on("FFVD_DEBUG_SYNC");
@@ -653,6 +654,24 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
     bool kfu_first = false;     // the first pass's K_fu build goes to the main stream before the chain is enqueued
     bool ident_on_side = false, kuu_on_main = false, linv_done = false, hwords_zeroed = false, ident_early = false;
     bool kinv_done = false;     // K^-1 came out of the chain's dataflow launch (no product launch)
+    // Reference route / explicit-U branch on the projection GEMM (fp64): only the GEMM needs the chain's W = L^-T, the K_fu build
+    // does not -- the chain's dataflow launch goes to the side stream (resident before the build floods the chip, as in the Gram
+    // route's schedule below) and the main stream waits for it in front of the first projection GEMM: config 2 in the reference's
+    // op order 6.31 -> 6.05 ms.  (Config 5 generates K_fu inside its projection kernel: nothing to overlap there.)
+    const bool ref_side = !gram_route && h->ngr > 0 && c.dtype != FFVD_F32C && h->aux && !h->sw.no_ref_side &&
+                          !h->sw.chain_rl && potrf_flow_selected((int)Mp, (int)Dl, CHOL_FLOW);
+    if (ref_side) {
+        sk = h->aux;
+        launch_kuu_build(s, c.kernel_kind, hv, c.M, Mp, P, Dl, c.jitter, h->Kuu, (grad_a || grad_ref) ? h->Kcopy : nullptr);
+        HIP_TRY(hipEventRecord(h->ev_fork, s));
+        HIP_TRY(hipStreamWaitEvent(sk, h->ev_fork, 0));
+        potrf_flow_clear(sk, h->dinvK, (int)Dl);
+        HIP_TRY(hipEventRecord(h->ev_go, sk));
+        linv_done = grad_a || grad_ref;
+        launch_potrf_ext(sk, h->Kuu, Mp, Mp, Mp, Dl, kstride, h->info, h->dinvK, CHOL_FLOW, linv_done ? h->Linv : nullptr, msq, true);
+        HIP_TRY(hipStreamWaitEvent(s, h->ev_go, 0));
+        kuu_on_main = true;          // (built and factorised: chain_rest below adds K^-1 / log|K| where a backward pass wants them)
+    }
     if (gram_route && (late_join || (size_t)first_units * Tp * Mp >= (size_t)64 * 4096 * 512)) {
         sk = h->aux;
         kuu_on_main = h->kuu_flow_sched && !late_join;
@@ -751,7 +770,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
             } else launch_gram(sk, gk);     // (split-K here was measured slower: 0.42 vs 0.37 ms for the K_uu stage)
             launch_h_finish(sk, h->Kuu, Mp, kstride, Dl, h->kterms);
             if (sk != s) HIP_TRY(hipEventRecord(h->ev_join, sk));
-        }
+        } else if (ref_side) HIP_TRY(hipEventRecord(h->ev_join, sk));
         // the per-chain likelihood / transition reductions depend on the inputs only (Gram route: no row sums of F), so
         // they ride on the side stream behind the K_uu chain and are back long before finalize needs them (kuu_on_main: they
         // already ran on the main stream while it waited for the chain's kernel to be dispatched)
@@ -789,6 +808,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
             pg.F = h->F; pg.f_stride = (size_t)Tp * Mp; pg.rowsq = h->rowsq; pg.Tp = Tp; pg.Mp = Mp; pg.Dl = Dl;
             pg.b0 = s0 * Dl; pg.nb = ns * Dl;
             pg.gpart = h->growpart; pg.X = p.X; pg.T = c.T; pg.D = c.D; pg.d_begin = c.d_begin;      // delta^T F by 128-row tiles (:247-248)
+            if (ref_side && s0 == 0) HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));                  // W = L^-T from the side stream's chain
             launch_proj_gemm(s, pg);                                  // tilde_F = Knm Lm^-T, sum F^2  (:242,:255)
             if (h->growpart)
                 launch_brow_finish(s, h->growpart, (int)((Tp + 127) / 128), Mp, Dl, c.d_begin, s0 * Dl, ns * Dl, p.log_Q, 1.0, h->H,
@@ -797,6 +817,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
             // explicit-U branch: K_fu once, then the triangular GEMM with fvar / fmean folded into its epilogue (F unstored)
             pa.F = h->F + (grad_a ? (size_t)s0 * Dl * Tp * Mp : 0);
             launch_kfu_build(s, pa);
+            if (ref_side && s0 == 0) HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));                  // W = L^-T from the side stream's chain
             if (s0 == 0) launch_ucols(s, p.U, c.M, Mp, c.D, c.d_begin, Dl, h->ucolA);
             ProjGemmArgs pg{};
             pg.Kf = pa.F; pg.kf_stride = (size_t)Tp * Mp; pg.W = h->Kuu + msq; pg.w_stride = kstride;
