@@ -39,6 +39,7 @@ struct ffvd_handle {
     double *graw = nullptr;                      // unsplit first pass: raw Gram tiles for the deferred trace pass
     double *gtail = nullptr;                     // unsplit passes: blocks + counters of the tail split (kernels.h GramArgs)
     int gtail_wg = 0;
+    double *lrpart = nullptr;                    // LinearK explicit-U forward: partial sums of G = C C^T and v = C u per column block (kernels.h)
     double *growpart = nullptr;                  // Gram route: per-64-row-block partial sums of delta^T K_fu from the K_fu build
     hipStream_t aux = nullptr;          // side stream: the K_uu chain runs beside the K_fu build (Gram route)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_kuu = nullptr, ev_tiles = nullptr, ev_go = nullptr;
@@ -52,6 +53,7 @@ struct ffvd_handle {
         bool no_small_side = false;       // FFVD_NO_SMALL_SIDE=1: tiny iterations keep the launch-per-step K_uu chain (round 2)
         bool ref_row_in_gram = false;     // FFVD_REF_ROW_IN_GRAM=1: reference route, delta^T F formed by the Gram kernel's diagonal tiles (rounds 1-2)
         bool no_ref_side = false;         // FFVD_NO_REF_SIDE=1: reference route / explicit-U branch with the K_uu chain on the main stream in front of the K_fu build
+        bool no_linear_lowrank = false;   // FFVD_NO_LINEAR_LOWRANK=1: LinearK explicit-U forward through the M-wide projection (rounds 1-2)
         bool lt_armed = false;            // FFVD_GRAD_LT_ARMED=1: write the L^T rows to memory (launch_set_lt_rows) even where the dataflow kernel could read L itself
         bool whiten_products = false;     // FFVD_GRAD_WHITEN_PRODUCTS=1: training forward forms H = W^T A W with two products (round 1/2) instead of arming L^T rows
         bool debug_sync = false;    // FFVD_DEBUG_SYNC: name every launch group on stderr and wait for it (locates a faulting kernel)
@@ -191,7 +193,7 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
         w.fused_project = on("FFVD_FUSED_PROJECT");   w.grad_explicit = on("FFVD_GRAD_EXPLICIT");
         w.no_defer_trace = on("FFVD_NO_DEFER_TRACE"); w.no_late_join = on("FFVD_NO_LATE_JOIN");
         w.no_main_first = on("FFVD_NO_MAIN_FIRST");   w.no_kfu_first = on("FFVD_NO_KFU_FIRST");
-        w.whiten_products = on("FFVD_GRAD_WHITEN_PRODUCTS");   w.lt_armed = on("FFVD_GRAD_LT_ARMED");   w.no_small_side = on("FFVD_NO_SMALL_SIDE");   w.ref_row_in_gram = on("FFVD_REF_ROW_IN_GRAM");   w.no_ref_side = on("FFVD_NO_REF_SIDE");
+        w.whiten_products = on("FFVD_GRAD_WHITEN_PRODUCTS");   w.lt_armed = on("FFVD_GRAD_LT_ARMED");   w.no_small_side = on("FFVD_NO_SMALL_SIDE");   w.ref_row_in_gram = on("FFVD_REF_ROW_IN_GRAM");   w.no_ref_side = on("FFVD_NO_REF_SIDE");   w.no_linear_lowrank = on("FFVD_NO_LINEAR_LOWRANK");
         w.kuu_flow = !on("FFVD_NO_KUU_FLOW");   w.kinv_gram = on("FFVD_KINV_GRAM");   w.chain_rl = on("FFVD_CHAIN_RL");
         w.atb128 = on("FFVD_ATB128");                 w.grad_serial = on("FFVD_GRAD_SERIAL");
         w.debug_sync = on("FFVD_DEBUG_SYNC");
@@ -389,6 +391,8 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
         else if (c.route == FFVD_ROUTE_GRAM && (size_t)upass * Tp * Mp >= (size_t)64 * 4096 * 512 && !h->sw.no_defer_trace)
             HIP_TRY(dev_alloc(h, &h->graw, (size_t)upass * (Mp + 1) * Mp));   // raw tiles + trace pass beside Cholesky(A)
     }
+    if (c.branch == FFVD_BRANCH_A && !c.grad && !h->sw.no_linear_lowrank && linear_lowrank_supported(c.kernel_kind, P))
+        HIP_TRY(dev_alloc(h, &h->lrpart, linear_lowrank_doubles((int)Mp, (int)Dl, P)));
     HIP_TRY(dev_alloc(h, &h->dinvK, potrf_scratch_doubles((int)Mp, (int)Dl)));
     HIP_TRY(dev_alloc(h, &h->dinvH, potrf_scratch_doubles((int)Mp, h->nbatch ? h->nbatch : 1)));
     HIP_TRY(hipMemsetAsync(h->U, 0, (size_t)(c.M * c.D ? c.M * c.D : 1) * sizeof(double), h->stream));
@@ -637,6 +641,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
         ra.xk = p.X; ra.xk_chain_stride = (size_t)(c.T + 1) * c.D; ra.xk_ld = c.D; ra.xk_cols = c.D;
         ra.rowsq = (gram_route || c.dtype == FFVD_F32C) ? nullptr : h->rowsq; ra.fmean = h->fmean; ra.chain_terms = h->chain_terms;
         if (h->ngr) ra.ng = h->ngr;
+        if (h->lrpart) ra.ng = 1;            // LinearK through its rank: one value per (unit, row)
         return ra;
     };
     bool reduce_done = false;
@@ -813,6 +818,10 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
             if (h->growpart)
                 launch_brow_finish(s, h->growpart, (int)((Tp + 127) / 128), Mp, Dl, c.d_begin, s0 * Dl, ns * Dl, p.log_Q, 1.0, h->H,
                                    (size_t)(c.grad ? 2 * Mp + NB : Mp + NB) * Mp, c.grad ? 2 * Mp : Mp);
+        } else if (h->lrpart) {
+            // explicit-U branch, LinearK, forward only: fmean and sum_j F^2 through the kernel's rank P (no K_fu, no F)
+            if (sk != s && s0 == 0) HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));
+            launch_linear_lowrank(s, pa, h->lrpart);
         } else if (c.branch == FFVD_BRANCH_A && h->ngr) {
             // explicit-U branch: K_fu once, then the triangular GEMM with fvar / fmean folded into its epilogue (F unstored)
             pa.F = h->F + (grad_a ? (size_t)s0 * Dl * Tp * Mp : 0);

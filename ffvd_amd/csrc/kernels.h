@@ -117,6 +117,11 @@ void launch_brow_finish(hipStream_t stream, const double *gpart, int nblk, int M
                         const double *log_Q, double yn_over_batch, double *H, size_t h_stride, int brow);
 // F = K_fu * L^{-T} with K_fu generated on the fly (never stored).
 void launch_project(hipStream_t stream, const ProjectArgs &a);
+// LinearK, explicit-U branch, forward only (kernels.hip, "the projection through the kernel's rank"): fills a.rowsq / a.fmean with ONE
+// column group per unit ([nbatch][Tp]) from x, ctrl, hv, W, U -- no F, no K_fu.  `part`: linear_lowrank_doubles(Mp, Dl, P) doubles.
+bool linear_lowrank_supported(int kind, int P);
+size_t linear_lowrank_doubles(int Mp, int Dl, int P);
+void launch_linear_lowrank(hipStream_t stream, const ProjectArgs &a, double *part);
 // a.F[bz][t][m] = K_fu itself (route K_uu + K_uf K_fu / Q); uses x, ctrl, hv, T, Tp, M, Mp, b0, nb of `a`.
 void launch_kfu_build(hipStream_t stream, const ProjectArgs &a);
 

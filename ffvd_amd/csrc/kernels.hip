@@ -1990,6 +1990,123 @@ void launch_project(hipStream_t stream, const ProjectArgs &a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// LinearK, explicit-U branch, forward only: the projection through the kernel's rank.  K_fu = sigma^2 X Z^T (kernels.py:276) has
+// rank P = D + C, so F = K_fu L^-T = sigma^2 X C with C = Z^T L^-T (P x Mp), and what the branch reads of F
+// (conditionals_multi_output.py:44-52, dgp_model.py:346-351) are two forms per row:
+//     fmean_t = F_t u = sigma^2 x_t . v,   v = C u (P);       sum_j F_tj^2 = sigma^4 x_t^T G x_t,   G = C C^T (P x P).
+// T M^2 -> T P^2 flops per unit (BASELINE configs[4]: 0.50 ms of projection -> two launches of a few microseconds).  Same values as
+// the M-wide route up to summation order; C, v, G are bounded by construction (C C^T <= I / sigma^2-ish: Z^T K^-1 Z), so nothing cancels.
+// linear_cmat: one workgroup per (dim, block of 64 columns j): C[:, j] for its columns (W = L^-T upper triangular: m <= j; the rows
+// of Z staged through LDS 64 at a time, each wavefront a quarter of them), then the block's partial sums of G and v.  linear_rows: one thread per row t; every workgroup first adds the column blocks' partials.
+// ---------------------------------------------------------------------------------------------
+constexpr int LRP = 20;             // bound on P for this path (register arrays, 61 KB of LDS); larger P takes project_kernel
+__global__ __launch_bounds__(256) void linear_cmat_kernel(HyperView hv, const double *W, size_t w_stride, const double *U, int u_ld,
+                                                          int d_begin, int M, int Mp, int P, double *part /*[Dl][nblk][P*P + P]*/) {
+    __shared__ double zs[64][LRP];                       // 64 rows of Z, columns >= P zero: the sums below run over LRP unconditionally
+    __shared__ double cq[4][LRP][64];                    // per-wavefront partial C
+    __shared__ double cs[LRP][64];                       // C[:, block]
+    const int jb = blockIdx.x, dl = blockIdx.y, tid = threadIdx.x, nblk = gridDim.x;
+    const int jl = tid & 63, g = tid >> 6, j = jb * 64 + jl;
+    const double *Wd = W + (size_t)dl * w_stride;
+    const double *Zd = hv.Zs + (size_t)dl * Mp * P;      // LINEAR: Zs = Z, rows >= M are zero
+    double acc[LRP];
+#pragma unroll
+    for (int p = 0; p < LRP; ++p) acc[p] = 0.0;
+    for (int c = 0; c <= jb; ++c) {                      // W = L^-T is upper triangular: rows m <= j only
+        double w[16];                                    // this wavefront's 16 rows of the chunk, requested before the staging barrier
+#pragma unroll
+        for (int r = 0; r < 16; ++r) w[r] = Wd[(size_t)(c * 64 + g * 16 + r) * Mp + j];
+        if (c > 0) __syncthreads();
+        for (int e = tid; e < 64 * LRP; e += 256) {
+            const int m = e / LRP, pp = e % LRP;
+            zs[m][pp] = (pp < P) ? Zd[((size_t)c * 64 + m) * P + pp] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+#pragma unroll
+            for (int p = 0; p < LRP; ++p) acc[p] = fma(zs[g * 16 + r][p], w[r], acc[p]);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < LRP; ++p) cq[g][p][jl] = acc[p];
+    __syncthreads();
+    for (int e = tid; e < LRP * 64; e += 256) {
+        const int p = e >> 6, c = e & 63;
+        cs[p][c] = (cq[0][p][c] + cq[1][p][c]) + (cq[2][p][c] + cq[3][p][c]);
+    }
+    __syncthreads();
+    double *o = part + ((size_t)dl * nblk + jb) * ((size_t)P * P + P);
+    for (int e = tid; e < P * P + P; e += 256) {
+        double v = 0.0;
+        if (e < P * P) {
+            const double *a = cs[e / P], *b = cs[e % P];
+            for (int c = 0; c < 64; ++c) v = fma(a[c], b[c], v);
+        } else {
+            const double *a = cs[e - P * P];
+            for (int c = 0; c < 64; ++c) {
+                const int jj = jb * 64 + c;
+                const double u = (jj < M) ? U[(size_t)jj * u_ld + d_begin + dl] : 0.0;
+                v = fma(a[c], u, v);
+            }
+        }
+        o[e] = v;
+    }
+}
+__global__ __launch_bounds__(256) void linear_rows_kernel(ProjectArgs a, const double *part, int nblk) {
+    extern __shared__ double gv[];                       // G [P][P] | v [P]
+    const int bz = blockIdx.y, b = a.b0 + bz, s = b / a.Dl, dl = b % a.Dl, tid = threadIdx.x, P = a.P;
+    const int ne = P * P + P;
+    for (int e = tid; e < ne; e += 256) {
+        double v = 0.0;
+        for (int k = 0; k < nblk; ++k) v += part[((size_t)dl * nblk + k) * ne + e];
+        gv[e] = v;
+    }
+    __syncthreads();
+    const int t = blockIdx.x * 256 + tid;
+    if (t >= a.Tp) return;
+    double rs = 0.0, fm = 0.0;
+    if (t < a.T) {
+        double x[LRP];
+        const double *xr = a.x + (size_t)s * a.x_chain_stride + (size_t)t * a.x_ld;
+#pragma unroll
+        for (int p = 0; p < LRP; ++p) {
+            x[p] = 0.0;
+            if (p < a.x_cols) x[p] = xr[p];
+            else if (p < P) x[p] = a.ctrl[(size_t)t * a.C + (p - a.x_cols)];
+        }
+        double q = 0.0, m = 0.0;
+#pragma unroll
+        for (int p = 0; p < LRP; ++p) {
+            if (p < P) {
+                double y = 0.0;
+#pragma unroll
+                for (int r = 0; r < LRP; ++r)
+                    if (r < P) y = fma(gv[p * P + r], x[r], y);
+                q = fma(x[p], y, q);
+                m = fma(x[p], gv[P * P + p], m);
+            }
+        }
+        const double var = a.hv.variance[dl];
+        rs = var * var * q;
+        fm = var * m;
+    }
+    const size_t o = (size_t)b * a.Tp + t;              // one column group (ng = 1 for this path)
+    if (a.rowsq) a.rowsq[o] = rs;
+    if (a.fmean) a.fmean[o] = fm;
+}
+bool linear_lowrank_supported(int kind, int P) { return kind == 1 && P <= LRP; }
+size_t linear_lowrank_doubles(int Mp, int Dl, int P) { return (size_t)Dl * (Mp / 64) * ((size_t)P * P + P); }
+void launch_linear_lowrank(hipStream_t stream, const ProjectArgs &a, double *part) {
+    const int nblk = a.Mp / 64;
+    if (a.b0 == 0)          // C, G, v depend on the dim only: once per iteration (the first pass)
+        hipLaunchKernelGGL(linear_cmat_kernel, dim3(nblk, a.Dl), dim3(256), 0, stream, a.hv, a.W,
+                           a.w_stride, a.U, a.u_ld, a.d_begin, a.M, a.Mp, a.P, part);
+    hipLaunchKernelGGL(linear_rows_kernel, dim3((a.Tp + 255) / 256, a.nb), dim3(256), ((size_t)a.P * a.P + a.P) * sizeof(double), stream, a,
+                       part, nblk);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Gram:  C = A^T A over the rows of A (T x Mp), lower-triangular tiles only, batched.
 //   mode GRAM_F   : H = F^T F * (Y_N / (batch Q_d)) + I            (conditionals_multi_output.py:246)
 //   mode GRAM_KFU : A_d = K_uf K_fu * (Y_N / (batch Q_d)) + (K_uu + jitter I)     (collapsed bound in the
