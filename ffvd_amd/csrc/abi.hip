@@ -663,17 +663,20 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
     // does not -- the chain's dataflow launch goes to the side stream (resident before the build floods the chip, as in the Gram
     // route's schedule below) and the main stream waits for it in front of the first projection GEMM: config 2 in the reference's
     // op order 6.31 -> 6.05 ms.  (Config 5 generates K_fu inside its projection kernel: nothing to overlap there.)
+    // LinearK through its rank (h->lrpart, forward of the explicit-U branch): the chain carries Z^T instead of the identity rows
+    const bool zt_rows = h->lrpart != nullptr;
     const bool ref_side = !gram_route && h->ngr > 0 && c.dtype != FFVD_F32C && h->aux && !h->sw.no_ref_side &&
                           !h->sw.chain_rl && potrf_flow_selected((int)Mp, (int)Dl, CHOL_FLOW);
     if (ref_side) {
         sk = h->aux;
-        launch_kuu_build(s, c.kernel_kind, hv, c.M, Mp, P, Dl, c.jitter, h->Kuu, (grad_a || grad_ref) ? h->Kcopy : nullptr);
+        launch_kuu_build(s, c.kernel_kind, hv, c.M, Mp, P, Dl, c.jitter, h->Kuu, (grad_a || grad_ref) ? h->Kcopy : nullptr, zt_rows);
         HIP_TRY(hipEventRecord(h->ev_fork, s));
         HIP_TRY(hipStreamWaitEvent(sk, h->ev_fork, 0));
         potrf_flow_clear(sk, h->dinvK, (int)Dl);
         HIP_TRY(hipEventRecord(h->ev_go, sk));
         linv_done = grad_a || grad_ref;
-        launch_potrf_ext(sk, h->Kuu, Mp, Mp, Mp, Dl, kstride, h->info, h->dinvK, CHOL_FLOW, linv_done ? h->Linv : nullptr, msq, true);
+        launch_potrf_ext(sk, h->Kuu, Mp, zt_rows ? NB : Mp, zt_rows ? 0 : Mp, Dl, kstride, h->info, h->dinvK, CHOL_FLOW,
+                         linv_done ? h->Linv : nullptr, msq, true);
         HIP_TRY(hipStreamWaitEvent(s, h->ev_go, 0));
         kuu_on_main = true;          // (built and factorised: chain_rest below adds K^-1 / log|K| where a backward pass wants them)
     }
@@ -751,8 +754,9 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
             const bool chain_flow = ((sk == s) || small_side) && potrf_flow_selected((int)Mp, (int)Dl, CHOL_FLOW) && !h->sw.chain_rl;
             if (chain_flow && (gram_route || grad_a || grad_ref)) linv_done = true;
             if (chain_flow && small_side && gram_route && potrf_flow_forms_inverse((int)Mp, (int)Dl, CHOL_FLOW)) kinv_done = true;
-            launch_potrf_ext(sk, h->Kuu, Mp, Mp, Mp, Dl, kstride, h->info, h->dinvK, chain_flow ? CHOL_FLOW : CHOL_AUTO,
-                             linv_done ? h->Linv : nullptr, msq, false, false, kinv_done ? h->Kinv : nullptr, msq);
+            launch_potrf_ext(sk, h->Kuu, Mp, zt_rows ? NB : Mp, zt_rows ? 0 : Mp, Dl, kstride, h->info, h->dinvK,
+                             chain_flow ? CHOL_FLOW : CHOL_AUTO, linv_done ? h->Linv : nullptr, msq, false, false,
+                             kinv_done ? h->Kinv : nullptr, msq);
         }
         if (gram_route || grad_a || grad_ref) {
             // K^-1 = L^-T L^-1 (shared by all chains) and log|K|
@@ -786,7 +790,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
         return FFVD_OK;
     };
     if (!kuu_on_main) {
-        launch_kuu_build(sk, c.kernel_kind, hv, c.M, Mp, P, Dl, c.jitter, h->Kuu, (gram_route || grad_a || grad_ref) ? h->Kcopy : nullptr);
+        launch_kuu_build(sk, c.kernel_kind, hv, c.M, Mp, P, Dl, c.jitter, h->Kuu, (gram_route || grad_a || grad_ref) ? h->Kcopy : nullptr, zt_rows);
         if (defer_trace || (defer_full && sk != s)) HIP_TRY(hipEventRecord(h->ev_kuu, sk));
     }
     if ((chain_rc = chain_rest()) != FFVD_OK) return chain_rc;

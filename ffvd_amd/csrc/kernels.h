@@ -35,7 +35,9 @@ void launch_prep_hypers(hipStream_t stream, int kind, const double *Z, int M, in
 // A[dl] (ld = Mp, rows 0..Mp-1) = K_dl(Z, Z) + jitter*I with identity padding; rows Mp..2Mp-1 = I (the
 // "extra rows" that the extended Cholesky turns into L^{-T}).  A has Dl slabs of 2*Mp*Mp doubles.
 void launch_kuu_build(hipStream_t stream, int kind, HyperView hv, int M, int Mp, int P, int Dl, double jitter, double *A,
-                      double *Kcopy /* optional [Dl][Mp*Mp] copy that survives the factorisation */);
+                      double *Kcopy /* optional [Dl][Mp*Mp] copy that survives the factorisation */,
+                      bool zt_rows = false /* LINEAR, P <= 64: rows Mp..Mp+63 = Z^T (rows >= P zero) instead of the identity: they
+                                              become C = Z^T L^-T (launch_potrf_ext with 64 extra rows, none identity-structured) */);
 void launch_transpose(hipStream_t stream, const double *in, size_t in_stride, double *out, size_t out_stride, int Mp,
                       int Dl);
 
@@ -118,7 +120,8 @@ void launch_brow_finish(hipStream_t stream, const double *gpart, int nblk, int M
 // F = K_fu * L^{-T} with K_fu generated on the fly (never stored).
 void launch_project(hipStream_t stream, const ProjectArgs &a);
 // LinearK, explicit-U branch, forward only (kernels.hip, "the projection through the kernel's rank"): fills a.rowsq / a.fmean with ONE
-// column group per unit ([nbatch][Tp]) from x, ctrl, hv, W, U -- no F, no K_fu.  `part`: linear_lowrank_doubles(Mp, Dl, P) doubles.
+// column group per unit ([nbatch][Tp]) from x, ctrl, hv, U and a.W = the C rows the K_uu chain left behind (launch_kuu_build zt_rows;
+// slab stride a.w_stride) -- no F, no K_fu.  `part`: linear_lowrank_doubles(Mp, Dl, P) doubles.
 bool linear_lowrank_supported(int kind, int P);
 size_t linear_lowrank_doubles(int Mp, int Dl, int P);
 void launch_linear_lowrank(hipStream_t stream, const ProjectArgs &a, double *part);

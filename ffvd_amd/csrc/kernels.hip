@@ -135,7 +135,7 @@ __device__ __forceinline__ double kernel_value(double dot, double xx, double zz,
 // workgroups: 147 us for the 16 matrices of config 5 (32768 workgroups), 12 us for the 4 of config 2.
 constexpr int KUU_ROWS = 16;
 __global__ __launch_bounds__(256) void kuu_build_kernel(int kind, HyperView hv, int M, int Mp, int P, double jitter,
-                                                        double *A, double *Kcopy) {
+                                                        double *A, double *Kcopy, int zt_rows) {
     extern __shared__ double zs_lds[];                    // [256][P | 1]
     const int dl = blockIdx.z, tid = threadIdx.x;
     const int ncc = (Mp + 255) / 256;                     // column chunks per row
@@ -143,6 +143,14 @@ __global__ __launch_bounds__(256) void kuu_build_kernel(int kind, HyperView hv, 
     const int j = j0 + tid;
     double *slab = A + (size_t)dl * 2 * Mp * Mp;
     if (blockIdx.y == 1) {   // extra rows: identity, becomes L^{-T}
+        if (zt_rows) {       // ... or (LinearK through its rank) ONE 64-row block holding Z^T, which becomes C = Z^T L^-T: rows >= P zero
+            if (j < Mp && i0 < NB)
+                for (int r = 0; r < KUU_ROWS; ++r) {
+                    const int i = i0 + r;
+                    slab[(size_t)Mp * Mp + (size_t)i * Mp + j] = (i < P) ? hv.Zs[((size_t)dl * Mp + j) * P + i] : 0.0;
+                }
+            return;
+        }
         if (j < Mp)
             for (int r = 0; r < KUU_ROWS && i0 + r < Mp; ++r) slab[(size_t)Mp * Mp + (size_t)(i0 + r) * Mp + j] = (i0 + r == j) ? 1.0 : 0.0;
         return;
@@ -187,11 +195,11 @@ __global__ __launch_bounds__(256) void kuu_build_kernel(int kind, HyperView hv, 
     }
 }
 void launch_kuu_build(hipStream_t stream, int kind, HyperView hv, int M, int Mp, int P, int Dl, double jitter, double *A,
-                      double *Kcopy) {
+                      double *Kcopy, bool zt_rows) {
     const int ncc = (Mp + 255) / 256, nrg = (Mp + KUU_ROWS - 1) / KUU_ROWS;
     dim3 grid((unsigned)(ncc * nrg), 2, Dl);
     hipLaunchKernelGGL(kuu_build_kernel, grid, dim3(256), (size_t)256 * (P | 1) * sizeof(double), stream, kind, hv, M, Mp, P,
-                       jitter, A, Kcopy);
+                       jitter, A, Kcopy, zt_rows ? 1 : 0);
 }
 
 // out[dl][i][j] = in[dl][j][i] for Dl square Mp x Mp matrices (L^-T -> L^-1)
@@ -1995,52 +2003,25 @@ void launch_project(hipStream_t stream, const ProjectArgs &a) {
 // (conditionals_multi_output.py:44-52, dgp_model.py:346-351) are two forms per row:
 //     fmean_t = F_t u = sigma^2 x_t . v,   v = C u (P);       sum_j F_tj^2 = sigma^4 x_t^T G x_t,   G = C C^T (P x P).
 // T M^2 -> T P^2 flops per unit (BASELINE configs[4]: 0.50 ms of projection -> two launches of a few microseconds).  Same values as
-// the M-wide route up to summation order; C, v, G are bounded by construction (C C^T <= I / sigma^2-ish: Z^T K^-1 Z), so nothing cancels.
-// linear_cmat: one workgroup per (dim, block of 64 columns j): C[:, j] for its columns (W = L^-T upper triangular: m <= j; the rows
-// of Z staged through LDS 64 at a time, each wavefront a quarter of them), then the block's partial sums of G and v.  linear_rows: one thread per row t; every workgroup first adds the column blocks' partials.
+// the M-wide route up to summation order; C, v, G are bounded by construction (C C^T = Z^T K^-1 Z), so nothing cancels.
+// C comes out of the K_uu chain itself: its launch carries ONE 64-row extension block holding Z^T (kuu_build_kernel, zt_rows) instead
+// of the M identity rows that become L^-T -- extension rows X end as X L^-T.  linear_gv: partial sums of G and v per (dim, 64 columns);
+// linear_rows: one thread per row t, every workgroup first adds the partials.
 // ---------------------------------------------------------------------------------------------
-constexpr int LRP = 20;             // bound on P for this path (register arrays, 61 KB of LDS); larger P takes project_kernel
-__global__ __launch_bounds__(256) void linear_cmat_kernel(HyperView hv, const double *W, size_t w_stride, const double *U, int u_ld,
-                                                          int d_begin, int M, int Mp, int P, double *part /*[Dl][nblk][P*P + P]*/) {
-    __shared__ double zs[64][LRP];                       // 64 rows of Z, columns >= P zero: the sums below run over LRP unconditionally
-    __shared__ double cq[4][LRP][64];                    // per-wavefront partial C
-    __shared__ double cs[LRP][64];                       // C[:, block]
+constexpr int LRP = 32;             // bound on P for this path (register arrays; <= 64 rows of one extra block); larger P takes project_kernel
+__global__ __launch_bounds__(256) void linear_gv_kernel(const double *Crows, size_t c_stride, const double *U, int u_ld, int d_begin,
+                                                        int M, int Mp, int P, double *part /*[Dl][nblk][P*P + P]*/) {
+    __shared__ double cs[LRP][64];                       // C[:, this block of 64 columns]
     const int jb = blockIdx.x, dl = blockIdx.y, tid = threadIdx.x, nblk = gridDim.x;
-    const int jl = tid & 63, g = tid >> 6, j = jb * 64 + jl;
-    const double *Wd = W + (size_t)dl * w_stride;
-    const double *Zd = hv.Zs + (size_t)dl * Mp * P;      // LINEAR: Zs = Z, rows >= M are zero
-    double acc[LRP];
-#pragma unroll
-    for (int p = 0; p < LRP; ++p) acc[p] = 0.0;
-    for (int c = 0; c <= jb; ++c) {                      // W = L^-T is upper triangular: rows m <= j only
-        double w[16];                                    // this wavefront's 16 rows of the chunk, requested before the staging barrier
-#pragma unroll
-        for (int r = 0; r < 16; ++r) w[r] = Wd[(size_t)(c * 64 + g * 16 + r) * Mp + j];
-        if (c > 0) __syncthreads();
-        for (int e = tid; e < 64 * LRP; e += 256) {
-            const int m = e / LRP, pp = e % LRP;
-            zs[m][pp] = (pp < P) ? Zd[((size_t)c * 64 + m) * P + pp] : 0.0;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-#pragma unroll
-            for (int p = 0; p < LRP; ++p) acc[p] = fma(zs[g * 16 + r][p], w[r], acc[p]);
-        }
-    }
-#pragma unroll
-    for (int p = 0; p < LRP; ++p) cq[g][p][jl] = acc[p];
-    __syncthreads();
-    for (int e = tid; e < LRP * 64; e += 256) {
-        const int p = e >> 6, c = e & 63;
-        cs[p][c] = (cq[0][p][c] + cq[1][p][c]) + (cq[2][p][c] + cq[3][p][c]);
-    }
+    const double *C = Crows + (size_t)dl * c_stride;     // row p at C + p * Mp: C = Z^T L^-T out of the K_uu chain's launch
+    for (int e = tid; e < P * 64; e += 256) cs[e >> 6][e & 63] = C[(size_t)(e >> 6) * Mp + jb * 64 + (e & 63)];
     __syncthreads();
     double *o = part + ((size_t)dl * nblk + jb) * ((size_t)P * P + P);
     for (int e = tid; e < P * P + P; e += 256) {
         double v = 0.0;
         if (e < P * P) {
             const double *a = cs[e / P], *b = cs[e % P];
+#pragma unroll 8
             for (int c = 0; c < 64; ++c) v = fma(a[c], b[c], v);
         } else {
             const double *a = cs[e - P * P];
@@ -2099,9 +2080,9 @@ bool linear_lowrank_supported(int kind, int P) { return kind == 1 && P <= LRP; }
 size_t linear_lowrank_doubles(int Mp, int Dl, int P) { return (size_t)Dl * (Mp / 64) * ((size_t)P * P + P); }
 void launch_linear_lowrank(hipStream_t stream, const ProjectArgs &a, double *part) {
     const int nblk = a.Mp / 64;
-    if (a.b0 == 0)          // C, G, v depend on the dim only: once per iteration (the first pass)
-        hipLaunchKernelGGL(linear_cmat_kernel, dim3(nblk, a.Dl), dim3(256), 0, stream, a.hv, a.W,
-                           a.w_stride, a.U, a.u_ld, a.d_begin, a.M, a.Mp, a.P, part);
+    if (a.b0 == 0)          // G, v depend on the dim only: once per iteration (the first pass)
+        hipLaunchKernelGGL(linear_gv_kernel, dim3(nblk, a.Dl), dim3(256), 0, stream, a.W, a.w_stride, a.U, a.u_ld, a.d_begin, a.M, a.Mp,
+                           a.P, part);
     hipLaunchKernelGGL(linear_rows_kernel, dim3((a.Tp + 255) / 256, a.nb), dim3(256), ((size_t)a.P * a.P + a.P) * sizeof(double), stream, a,
                        part, nblk);
 }
