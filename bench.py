@@ -267,9 +267,22 @@ def run_rank(args):
         dom = max(("project_F", "gram_H"), key=lambda k: stage[k][0])
         ms_tot, launches = stage[dom]
         units_per_launch = s_local * d_local * args.steps / max(launches, 1)     # (s,d) units per launch
+        lowrank = (not collapsed and meta["kernel_type"] == "LinearK" and P <= 32
+                   and os.environ.get("FFVD_NO_LINEAR_LOWRANK", "") not in ("1", "true", "yes"))
+        if lowrank:
+            # LinearK through its rank: the projection is T*P^2 work, the dominant launch is the K_uu chain --
+            # one dataflow Cholesky of d_local matrices with one 64-row extension block (Z^T -> C), latency-bound by construction
+            alg["project_F"] = T * (2 * P * P + 4 * P)
+            alg["kuu_chol_inverse"] = M ** 3 / 3 + 64 * M * M
+            dom = max(("project_F", "kuu_chol_inverse"), key=lambda k: stage[k][0])
+            ms_tot, launches = stage[dom]
+            if dom == "kuu_chol_inverse":
+                units_per_launch = d_local * args.steps / max(launches, 1)
         dur_s = ms_tot / 1e3 / max(launches, 1)
         achieved = alg[dom] * units_per_launch / dur_s / 1e12 if dur_s > 0 else 0.0
         w_alg = synthetic.algorithmic_flops(**meta)                 # SURVEY 8(d) W_alg (reference formulation)
+        if lowrank:     # the formulation actually executed: per d one Cholesky with the Z^T block, per (s,d) the two P x P forms per row
+            w_alg = D * (M ** 3 / 3 + 64 * M * M) + S * D * T * (2 * P * P + 4 * P)
         if args.route == "gram":
             # structure-aware count of the formulation actually executed (SURVEY 8d requires a Gram-route build to
             # say so): per (s,d) T*M^2 syrk + M^3/3 Cholesky of K_uu + K_uf K_fu/Q + K_fu generation; per d
@@ -301,7 +314,10 @@ def run_rank(args):
                                       "K_fu and the two T x M x M products in fp32 (v_mfma_f32_32x32x2_f32); every M x M "
                                       "factorisation, the accumulation of H and the trace term in fp64"),
                        "route": ("gram: log|K_uu + K_uf K_fu/Q| - log|K_uu| (SURVEY Appendix A), flops counted as W_gram-style"
-                                 if args.route == "gram" else "reference: F = K_fu L^-T, H = F^T F/Q + I")},
+                                 if args.route == "gram" else
+                                 ("explicit-U with LinearK through the kernel's rank: F = sigma^2 X (Z^T L^-T), fmean and sum F^2 as "
+                                  "P x P forms per row (DESIGN.md section 5); FFVD_NO_LINEAR_LOWRANK=1 runs the M-wide projection"
+                                  if lowrank else "reference: F = K_fu L^-T, H = F^T F/Q + I"))},
             "nll": terms["nll"],
             "ms_per_step_without_collective": plain_ms,
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": peak,
