@@ -514,6 +514,23 @@ def test_training_forward_variants_agree(monkeypatch):
             np.testing.assert_allclose(g2[k], g0[k], rtol=0, atol=tol * scale, err_msg=name + " " + k)
 
 
+def test_linear_kernel_through_its_rank(monkeypatch):
+    """Explicit-U branch with LinearK, forward only: K_fu = sigma^2 X Z^T has rank P, so fmean and sum_j F^2 are P x P forms per row
+    of C = Z^T L^-T, which the K_uu chain leaves in ONE extension block.  Against the oracle, against
+    the M-wide projection (FFVD_NO_LINEAR_LOWRANK=1), with several chains in several passes, ragged M and no control inputs."""
+    for name, kw, cpp in (("small_lin", dict(S=3), 1), ("small_lin", dict(S=2, M=45, T=200), 0), ("small_lin", dict(C=0, S=1), 0)):
+        params, Y, c, meta = synthetic.make_named(name, **kw)
+        ref = orc.nll_terms_chains(params, Y, c, U_collapse=False, kernel_type="LinearK")
+        got = run_engine(params, Y, c, meta, collapse=False, chains_per_pass=cpp)
+        assert_terms(got, ref, TERMS_A)
+        monkeypatch.setenv("FFVD_NO_LINEAR_LOWRANK", "1")
+        wide = run_engine(params, Y, c, meta, collapse=False, chains_per_pass=cpp)
+        monkeypatch.delenv("FFVD_NO_LINEAR_LOWRANK")
+        assert_terms(wide, ref, TERMS_A)
+        for n in TERMS_A:
+            assert got[n] == pytest.approx(wide[n], rel=1e-10, abs=1e-11), n
+
+
 _DEFER_SCRIPT = r"""
 import sys
 import numpy as np
