@@ -2345,6 +2345,7 @@ extern "C" int ffvd_op_rollout(int kind, const double *Lm_inverse_seq, const dou
     }
     double *dW = sc.upload(Wp.data(), Wp.size());
     double *dxc = sc.upload(xc0.data(), xc0.size()), *dZ = sc.upload(Z, (size_t)M * P), *dU = sc.upload(f, (size_t)M * D);
+    double *dxc2 = sc.alloc<double>(xc0.size());          // the rows of step t + 1 (the step kernel reads one buffer and writes the other)
     double *dlv = sc.upload(logvariance, D), *dll = sc.alloc<double>((size_t)D * P), *dlq = sc.upload(log_Q, D);
     double *deps = sc.upload(eps, (size_t)steps * R * D);
     double *dctrl = C ? sc.upload(ctrl, (size_t)steps * C) : nullptr;
@@ -2363,8 +2364,11 @@ extern "C" int ffvd_op_rollout(int kind, const double *Lm_inverse_seq, const dou
     if (q_sqrt && skinny) Qp = pad_stack(q_sqrt, 1, M, Mp);                // (F is zero in the padded columns)
     double *dQs = q_sqrt ? (skinny ? sc.upload(Qp.data(), Qp.size()) : sc.upload(q_sqrt, (size_t)M * M)) : nullptr;   // slice d = 0 only
     double *extra = q_sqrt ? sc.alloc<double>((size_t)D * (skinny ? ngs : 1) * Tp) : nullptr;
-    if (!dW || !dxc || !dZ || !dU || !dlv || !dll || !dlq || !deps || (C && !dctrl) || !variance || !len || !Zs || !zz ||
-        !rowsq || !fmean || !dmean || !dvar || !dpx || !dpv || !Kf || !ucol || (q_sqrt && (!dQs || !extra || !F)))
+    // skinny path: W q_sqrt once per call (D products of M^3), so that the inflation term is a second right-hand side of the
+    // step's one product instead of a dependent product on F
+    double *dWQ = (q_sqrt && skinny) ? sc.alloc<double>((size_t)D * Mp * Mp) : nullptr;
+    if (!dW || !dxc || !dxc2 || !dZ || !dU || !dlv || !dll || !dlq || !deps || (C && !dctrl) || !variance || !len || !Zs || !zz ||
+        !rowsq || !fmean || !dmean || !dvar || !dpx || !dpv || !Kf || !ucol || (q_sqrt && (!dQs || !extra || !F)) || (q_sqrt && skinny && !dWQ))
         return set_error(nullptr, FFVD_ENOMEM, "ffvd_op_rollout: device allocation or upload failed");
     if (loglengthscales)
         HIP_TRY(hipMemcpyAsync(dll, loglengthscales, (size_t)D * P * sizeof(double), hipMemcpyHostToDevice, sc.stream));
@@ -2380,21 +2384,25 @@ extern "C" int ffvd_op_rollout(int kind, const double *Lm_inverse_seq, const dou
     pg.Kf = Kf; pg.kf_stride = (size_t)Tp * Mp; pg.W = dW; pg.w_stride = (size_t)Mp * Mp; pg.F = F; pg.f_stride = (size_t)Tp * Mp;
     pg.rowsq = rowsq; pg.fmean = fmean; pg.u = ucol; pg.u_stride = Mp; pg.Tp = Tp; pg.Mp = Mp; pg.Dl = D; pg.b0 = 0; pg.nb = D;
     // the whole loop is enqueued at once: steps x (K_fu rows, projection, [q_sqrt inflation], conditional, update)
+    if (dWQ)
+        launch_skinny_gemm(sc.stream, dW, (size_t)Mp * Mp, Mp, dQs, 0, Mp, 0, Mp, Mp, Mp, D, Mp, dWQ, (size_t)Mp * Mp, Mp, nullptr, 0,
+                           nullptr, nullptr);
+    double *xbuf[2] = {dxc, dxc2};                                           // input rows of step t in xbuf[t & 1]
     for (int t = 0; t < steps; ++t) {
+        pa.x = xbuf[t & 1];
         launch_kfu_build(sc.stream, pa);                                     // K(x_t, Z) per dim
         if (skinny) {
+            // conditional_after_kernel_precalculation (:300) and, in the same launch, sum_j (F q_sqrt)_j^2 = |K (W q_sqrt)|^2 (:371-380)
             launch_skinny_gemm(sc.stream, Kf, (size_t)Tp * Mp, Mp, dW, (size_t)Mp * Mp, Mp, 1, R, Mp, Mp, D, Tp,
-                               F, (size_t)Tp * Mp, Mp, ucol, Mp, rowsq, fmean);   // conditional_after_kernel_precalculation (:300)
-            if (q_sqrt) launch_skinny_gemm(sc.stream, F, (size_t)Tp * Mp, Mp, dQs, 0, Mp, 0, R, Mp, Mp, D, Tp,
-                                           nullptr, 0, 0, nullptr, 0, extra, nullptr);        // sum_j (F q_sqrt)_j^2  (:371-380)
-            launch_conditional_finish(sc.stream, kind, dxc, R, P, variance, rowsq, fmean, ngs, Tp, D, dmean, dvar, extra, ngs);
+                               nullptr, 0, 0, ucol, Mp, rowsq, fmean, q_sqrt ? dWQ : nullptr, (size_t)Mp * Mp, Mp, Mp, extra);
         } else {
             launch_proj_gemm(sc.stream, pg);
             if (q_sqrt) launch_qsqrt_inflation(sc.stream, F, (size_t)Tp * Mp, Tp, Mp, M, dQs, extra, R, D);
-            launch_conditional_finish(sc.stream, kind, dxc, R, P, variance, rowsq, fmean, ng, Tp, D, dmean, dvar, extra);
         }
-        launch_rollout_update(sc.stream, dmean, dvar, dlq, deps + (size_t)t * R * D,
-                              (C && t + 1 < steps) ? dctrl + (size_t)(t + 1) * C : nullptr, R, D, C, t, steps, dxc, dpx, dpv);
+        // conditional epilogue + x <- x + f_mu + eps sqrt(f_var + Q) in one launch (three dependent launches per step instead of five)
+        launch_rollout_finish_update(sc.stream, kind, variance, rowsq, fmean, skinny ? ngs : ng, Tp, extra, skinny ? ngs : 1, dlq,
+                                     deps + (size_t)t * R * D, (C && t + 1 < steps) ? dctrl + (size_t)(t + 1) * C : nullptr, R, D, C, t,
+                                     steps, xbuf[t & 1], xbuf[(t + 1) & 1], dpx, dpv);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(predict_x, dpx, (size_t)R * steps * D * sizeof(double), hipMemcpyDeviceToHost, sc.stream));

@@ -235,7 +235,9 @@ void launch_conditional_finish(hipStream_t stream, int kind, const double *x, in
 // sq / dot [nb][N / 16][Tp] (feed launch_conditional_finish with ng = N / 16).  kernels.hip has the details.
 void launch_skinny_gemm(hipStream_t stream, const double *A, size_t a_stride, int lda, const double *B, size_t b_stride, int ldb,
                         int upper, int rows, int K, int N, int nb, int Tp, double *C, size_t c_stride, int ldc,
-                        const double *u, size_t u_stride, double *sq, double *dot);
+                        const double *u, size_t u_stride, double *sq, double *dot,
+                        // optional second right-hand side B2 (K x N2, dense) in the same launch: only sq2[nb][N2 / 16][Tp] is formed
+                        const double *B2 = nullptr, size_t b2_stride = 0, int ldb2 = 0, int N2 = 0, double *sq2 = nullptr);
 // out[i * out_ld + b * out_bs] = sum_j W[b][i][j] y[b][j]
 void launch_matvec(hipStream_t stream, const double *W, size_t w_stride, const double *y, size_t y_stride, int Mp,
                    double *out, int out_ld, int out_bs, int M, int batch, int w_mod = 0);   // w_mod > 0: W slab index = batch index % w_mod
@@ -265,6 +267,11 @@ void launch_pg_step(hipStream_t stream, const double *mean, const double *var, c
                     const double *unif_t, const double *y_t, const double *x_ref_next, const double *CC, const double *DD,
                     const double *Rch, const double *ctrl_next, int R, int D, int C, int Ydim, double *xc, double *cand,
                     double *parts_next, int32_t *idx_out);
+// rollout step with the conditional epilogue folded in (same arithmetic as launch_conditional_finish + launch_rollout_update)
+void launch_rollout_finish_update(hipStream_t stream, int kind, const double *variance, const double *rowsq, const double *fmean,
+                                  int ng, int Tp, const double *extra, int extra_ng, const double *log_Q, const double *eps_t,
+                                  const double *ctrl_next, int R, int D, int C, int t, int steps, const double *x_in, double *x_out,
+                                  double *predict_x, double *predict_var);     // x_in != x_out: the caller alternates two R x (D + C) buffers
 
 // N sums over a 256-thread workgroup at once: wavefront shuffles, then the four wavefront partials in fixed order.
 // Every thread returns with the totals in v[].

@@ -2883,28 +2883,36 @@ struct SkinnyArgs {
     double *C; size_t c_stride; int ldc;            // or null
     const double *u; size_t u_stride;               // or null
     double *sq, *dot;                               // [nb][N / 16][Tp], or null
+    // optional SECOND right-hand side in the same launch (its slabs behind the first one's): C2 = A B2 is not stored, only
+    // sq2[nb][N2 / 16][Tp] = sum over the slab of C2^2.  The rollouts' q_sqrt inflation |F q_sqrt|^2 = |K (W q_sqrt)|^2 rides beside
+    // F = K W this way: both products read the same K rows and the step loses a dependent launch.
+    const double *B2; size_t b2_stride; int ldb2, N2;
+    double *sq2;
 };
 __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
     __shared__ double red[3][2][4][64];
-    const int n0 = blockIdx.x * 16, r0 = blockIdx.y * 32, b = blockIdx.z;
+    const int nslab1 = a.N / 16;
+    const bool second = (int)blockIdx.x >= nslab1;
+    const int n0 = (second ? (int)blockIdx.x - nslab1 : (int)blockIdx.x) * 16, r0 = blockIdx.y * 32, b = blockIdx.z;
     if (r0 >= a.rows) return;
     const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const double *Ab = a.A + (size_t)b * a.a_stride, *Bb = a.B + (size_t)b * a.b_stride;
-    const int kend = (a.upper && n0 + 16 < a.K) ? n0 + 16 : a.K;
+    const double *Ab = a.A + (size_t)b * a.a_stride, *Bb = second ? a.B2 + (size_t)b * a.b2_stride : a.B + (size_t)b * a.b_stride;
+    const int ldb = second ? a.ldb2 : a.ldb;
+    const int kend = (!second && a.upper && n0 + 16 < a.K) ? n0 + 16 : a.K;
     const int nkb = kend / 16, per = (nkb + 3) / 4;                 // 16-wide k blocks, a quarter of them per wavefront
     const int kb0 = w * per, kb1 = (kb0 + per < nkb) ? kb0 + per : nkb;
     d4 acc[2] = {(d4){0.0, 0.0, 0.0, 0.0}, (d4){0.0, 0.0, 0.0, 0.0}};
     // Inside a k block the four lane groups take k = 4 lk + s in MFMA s (a sum does not care about its order), so a lane reads
     // four CONSECUTIVE doubles of its A row (two 16-byte loads feed four MFMAs, 128-byte runs per row) instead of four 8-byte ones
     const double *ap0 = Ab + (size_t)(r0 + lr) * a.lda + 4 * lk, *ap1 = ap0 + (size_t)16 * a.lda;
-    const double *bp = Bb + (size_t)(4 * lk) * a.ldb + n0 + lr;
+    const double *bp = Bb + (size_t)(4 * lk) * ldb + n0 + lr;
     for (int kb = kb0; kb < kb1; ++kb) {       // (the compiler does not unroll this loop; two blocks in flight by hand were no faster)
         const int k0 = 16 * kb;
         const d2 a0l = *reinterpret_cast<const d2 *>(ap0 + k0), a0h = *reinterpret_cast<const d2 *>(ap0 + k0 + 2);
         const d2 a1l = *reinterpret_cast<const d2 *>(ap1 + k0), a1h = *reinterpret_cast<const d2 *>(ap1 + k0 + 2);
-        const double *bq = bp + (size_t)k0 * a.ldb;
-        const double b0 = bq[0], b1 = bq[a.ldb], b2 = bq[2 * (size_t)a.ldb], b3 = bq[3 * (size_t)a.ldb];
+        const double *bq = bp + (size_t)k0 * ldb;
+        const double b0 = bq[0], b1 = bq[ldb], b2 = bq[2 * (size_t)ldb], b3 = bq[3 * (size_t)ldb];
         acc[0] = mfma_f64(a0l.x, b0, acc[0]); acc[1] = mfma_f64(a1l.x, b0, acc[1]);
         acc[0] = mfma_f64(a0l.y, b1, acc[0]); acc[1] = mfma_f64(a1l.y, b1, acc[1]);
         acc[0] = mfma_f64(a0h.x, b2, acc[0]); acc[1] = mfma_f64(a1h.x, b2, acc[1]);
@@ -2918,32 +2926,35 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
     }
     __syncthreads();
     if (w > 0) return;
-    const int slab = blockIdx.x, nslab = a.N / 16;
-    const double un = a.u ? a.u[(size_t)b * a.u_stride + n0 + lr] : 0.0;
+    const int slab = n0 / 16, nslab = second ? a.N2 / 16 : nslab1;
+    const double un = (a.u && !second) ? a.u[(size_t)b * a.u_stride + n0 + lr] : 0.0;
+    double *sqp = second ? a.sq2 : a.sq, *dotp = second ? nullptr : a.dot, *Cp = second ? nullptr : a.C;
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const double c = ((acc[x][q] + red[0][x][q][lane]) + red[1][x][q][lane]) + red[2][x][q][lane];
             const int row = r0 + 16 * x + lk + 4 * q;
-            if (a.C) a.C[(size_t)b * a.c_stride + (size_t)row * a.ldc + n0 + lr] = c;
+            if (Cp) Cp[(size_t)b * a.c_stride + (size_t)row * a.ldc + n0 + lr] = c;
             double s2 = c * c, du = c * un;
             s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2); s2 += __shfl_xor(s2, 4); s2 += __shfl_xor(s2, 8);
             du += __shfl_xor(du, 1); du += __shfl_xor(du, 2); du += __shfl_xor(du, 4); du += __shfl_xor(du, 8);
             if (lr == 0) {
                 const size_t o = ((size_t)b * nslab + slab) * a.Tp + row;
-                if (a.sq) a.sq[o] = s2;
-                if (a.dot) a.dot[o] = du;
+                if (sqp) sqp[o] = s2;
+                if (dotp) dotp[o] = du;
             }
         }
 }
 // rows <= Tp (a multiple of 32) rows of A exist; N, K multiples of 16.
 void launch_skinny_gemm(hipStream_t stream, const double *A, size_t a_stride, int lda, const double *B, size_t b_stride, int ldb,
                         int upper, int rows, int K, int N, int nb, int Tp, double *C, size_t c_stride, int ldc,
-                        const double *u, size_t u_stride, double *sq, double *dot) {
+                        const double *u, size_t u_stride, double *sq, double *dot, const double *B2, size_t b2_stride, int ldb2,
+                        int N2, double *sq2) {
     if (rows <= 0 || nb <= 0) return;
-    SkinnyArgs a{A, a_stride, lda, B, b_stride, ldb, upper, rows, K, N, nb, Tp, C, c_stride, ldc, u, u_stride, sq, dot};
-    hipLaunchKernelGGL(skinny_gemm_kernel, dim3(N / 16, (rows + 31) / 32, nb), dim3(256), 0, stream, a);
+    SkinnyArgs a{A, a_stride, lda, B, b_stride, ldb, upper, rows, K, N, nb, Tp, C, c_stride, ldc, u, u_stride, sq, dot,
+                 B2, b2_stride, ldb2, B2 ? N2 : 0, sq2};
+    hipLaunchKernelGGL(skinny_gemm_kernel, dim3(N / 16 + (B2 ? N2 / 16 : 0), (rows + 31) / 32, nb), dim3(256), 0, stream, a);
 }
 
 // out[b][i] = sum_j W[b][i][j] * y[b][j]   (posterior mean of the whitened inducing outputs: L_H^-T (L_H^-1 b))
@@ -3138,6 +3149,70 @@ void launch_finalize(hipStream_t stream, const FinalizeArgs &a) {
 // One step of the posterior rollout (collect_samples_formal, base_model.py:304-314) for R rollouts side by side:
 //   x_next = x + f_mu + eps * sqrt(f_var + Q);  predict_x[r][t] = x_next;  predict_var[r][t] = f_var + Q;
 // and the GP input row of the next step, xc[r] = [x_next, control_inputs[t + 1]].
+// The conditional() epilogue inside a step-loop kernel, bit for bit what conditional_finish_kernel computes: 16 lanes per (row n,
+// dim d) sum the partials strided, an xor-butterfly combines them; every lane returns the sums (call with ALL lanes of the 16 active).
+struct FinishIn {
+    int kind, P, ng, Tp, D, extra_ng;
+    const double *variance, *rowsq, *fmean, *extra;     // extra: optional [D][extra_ng][Tp]
+};
+__device__ __forceinline__ void finish_mean_var16(const FinishIn &f, const double *xrow /* P inputs of row n */, const bool live, const int n,
+                                                  const int d, const int l, double &mean, double &var) {
+    double rs = 0.0, fm = 0.0, ex = 0.0;
+    if (live) {
+        for (int g = l; g < f.ng; g += 16) {
+            rs += f.rowsq[((size_t)d * f.ng + g) * f.Tp + n];
+            fm += f.fmean[((size_t)d * f.ng + g) * f.Tp + n];
+        }
+        if (f.extra)
+            for (int g = l; g < f.extra_ng; g += 16) ex += f.extra[((size_t)d * f.extra_ng + g) * f.Tp + n];
+    }
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) { rs += __shfl_xor(rs, m); fm += __shfl_xor(fm, m); ex += __shfl_xor(ex, m); }
+    double kd = live ? f.variance[d] : 0.0;
+    if (live && f.kind == 1) {
+        double s = 0.0;
+        for (int p = 0; p < f.P; ++p) { const double v = xrow[p]; s += (v * v) * f.variance[d]; }
+        kd = s;
+    }
+    mean = fm;
+    var = kd - rs;
+    if (f.extra) var = var + ex;
+}
+
+// Rollout step with the conditional epilogue folded in.  The input rows are read from x_in and the advanced rows written to x_out
+// (the caller alternates two buffers): LinearK's Kdiag reads a whole row, which another lane group of the same row advances.
+__global__ __launch_bounds__(256) void rollout_finish_update_kernel(FinishIn f, const double *log_Q, const double *eps_t,
+                                                                    const double *ctrl_next, int R, int C, int t, int steps,
+                                                                    const double *x_in, double *x_out, double *predict_x,
+                                                                    double *predict_var) {
+    const int idx = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, l = threadIdx.x & 15;
+    const int D = f.D, P = f.P;
+    const bool live = idx < R * D;
+    const int r = live ? idx / D : 0, d = live ? idx % D : 0;
+    double m, vv;
+    finish_mean_var16(f, x_in + (size_t)r * P, live, r, d, l, m, vv);
+    if (!live) return;
+    if (l == 0) {
+        const double v = vv + exp(log_Q[d]);
+        const double xn = (m + x_in[(size_t)r * P + d]) + eps_t[r * D + d] * sqrt(v);
+        const size_t o = ((size_t)r * steps + t) * D + d;
+        predict_x[o] = xn;
+        predict_var[o] = v;
+        x_out[(size_t)r * P + d] = xn;
+    } else if (d == 0) {        // the control columns of row r: the next step's, or carried over
+        for (int c = l - 1; c < C; c += 15) x_out[(size_t)r * P + D + c] = ctrl_next ? ctrl_next[c] : x_in[(size_t)r * P + D + c];
+    }
+}
+void launch_rollout_finish_update(hipStream_t stream, int kind, const double *variance, const double *rowsq, const double *fmean,
+                                  int ng, int Tp, const double *extra, int extra_ng, const double *log_Q, const double *eps_t,
+                                  const double *ctrl_next, int R, int D, int C, int t, int steps, const double *x_in, double *x_out,
+                                  double *predict_x, double *predict_var) {
+    if (R * D == 0) return;
+    FinishIn f{kind, D + C, ng, Tp, D, extra_ng, variance, rowsq, fmean, extra};
+    hipLaunchKernelGGL(rollout_finish_update_kernel, dim3((R * D * 16 + 255) / 256), dim3(256), 0, stream, f, log_Q, eps_t, ctrl_next, R,
+                       C, t, steps, x_in, x_out, predict_x, predict_var);
+}
+
 __global__ void rollout_update_kernel(const double *mean, const double *var, const double *log_Q, const double *eps_t,
                                       const double *ctrl_next, int R, int D, int C, int t, int steps, double *xc,
                                       double *predict_x, double *predict_var) {
