@@ -36,3 +36,41 @@ for it in range(10):
         w2 = max(w2, err)
         assert err < 2e-7, (ov, collapse, route, got["nll"], ref["nll"])
 print("elbo worst rel err", w2)
+# 3. (round 3) gradient of the collapsed branch on random shapes, Gram route (L^T rows, training forward) and reference route,
+#    against the closed-form oracle; LinearK explicit-U forward through its rank against the oracle
+from oracle import ffvd_grad_oracle as gorc
+KEYS = ("X", "Z", "logvariance", "loglengthscales", "log_Q", "CC", "DD", "log_Rchols")
+w3 = 0.0
+for it in range(6):
+    T_ = int(rng.integers(60, 300))
+    ov = dict(T=T_, M=int(rng.integers(10, min(200, T_))), D=int(rng.integers(1, 5)), C=int(rng.integers(0, 3)), S=int(rng.integers(1, 4)))
+    params, Y, c, meta = synthetic.make_named("tiny", **ov)
+    S = meta["S"]
+    ref = {k: np.zeros_like(np.asarray(params[k], dtype=np.float64)) for k in KEYS}
+    for s in range(S):
+        p = dict(params); p["X"] = params["X"][s]
+        ga = gorc.nll_grad(p, Y, c)
+        ref["X"][s] = ga["X"] / S
+        for k in KEYS[1:]: ref[k] += ga[k] / S
+    for route in ("gram", "reference"):
+        with ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], S, route=route, grad=True) as e:
+            e.set_data(Y, c)
+            _, g = e.nll_and_grad(params)
+        for k in KEYS:
+            err = np.max(np.abs(g[k] - ref[k])) / (np.max(np.abs(ref[k])) + 1e-300)
+            w3 = max(w3, err)
+            assert err < 2e-6, (ov, route, k, err)
+print("gradient worst rel err", w3)
+w4 = 0.0
+for it in range(6):
+    T_ = int(rng.integers(60, 300))
+    ov = dict(T=T_, M=int(rng.integers(10, min(200, T_))), D=int(rng.integers(1, 7)), C=int(rng.integers(0, 3)), S=int(rng.integers(1, 4)))
+    params, Y, c, meta = synthetic.make_named("small_lin", **ov)
+    with ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], meta["S"], U_collapse=False, kernel_type="LinearK") as e:
+        e.set_data(Y, c)
+        got = e.nll_terms(params)
+    ref = orc.nll_terms_chains(params, Y, c, U_collapse=False, kernel_type="LinearK")
+    err = abs(got["nll"] - ref["nll"]) / max(1.0, abs(ref["nll"]))
+    w4 = max(w4, err)
+    assert err < 1e-7, (ov, got["nll"], ref["nll"])
+print("LinearK through its rank, worst rel err", w4)
