@@ -50,6 +50,7 @@ struct ffvd_handle {
     struct Switches {
         bool fused_project = false, grad_explicit = false, no_defer_trace = false, no_late_join = false;
         bool no_main_first = false, no_kfu_first = false, atb128 = false, grad_serial = false, kuu_flow = true, kinv_gram = false, chain_rl = false;
+        int small_side_wgs = 512;         // FFVD_SMALL_SIDE_WGS: tile-pass workgroups (one round of the chip) up to which an iteration counts as tiny (see small_side)
         bool no_small_side = false;       // FFVD_NO_SMALL_SIDE=1: tiny iterations keep the launch-per-step K_uu chain (round 2)
         bool ref_row_in_gram = false;     // FFVD_REF_ROW_IN_GRAM=1: reference route, delta^T F formed by the Gram kernel's diagonal tiles (rounds 1-2)
         bool no_ref_side = false;         // FFVD_NO_REF_SIDE=1: reference route / explicit-U branch with the K_uu chain on the main stream in front of the K_fu build
@@ -193,7 +194,7 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
         w.fused_project = on("FFVD_FUSED_PROJECT");   w.grad_explicit = on("FFVD_GRAD_EXPLICIT");
         w.no_defer_trace = on("FFVD_NO_DEFER_TRACE"); w.no_late_join = on("FFVD_NO_LATE_JOIN");
         w.no_main_first = on("FFVD_NO_MAIN_FIRST");   w.no_kfu_first = on("FFVD_NO_KFU_FIRST");
-        w.whiten_products = on("FFVD_GRAD_WHITEN_PRODUCTS");   w.lt_armed = on("FFVD_GRAD_LT_ARMED");   w.no_small_side = on("FFVD_NO_SMALL_SIDE");   w.ref_row_in_gram = on("FFVD_REF_ROW_IN_GRAM");   w.no_ref_side = on("FFVD_NO_REF_SIDE");   w.no_linear_lowrank = on("FFVD_NO_LINEAR_LOWRANK");
+        w.whiten_products = on("FFVD_GRAD_WHITEN_PRODUCTS");   w.lt_armed = on("FFVD_GRAD_LT_ARMED");   w.no_small_side = on("FFVD_NO_SMALL_SIDE");   if (const char *e = getenv("FFVD_SMALL_SIDE_WGS")) w.small_side_wgs = atoi(e);   w.ref_row_in_gram = on("FFVD_REF_ROW_IN_GRAM");   w.no_ref_side = on("FFVD_NO_REF_SIDE");   w.no_linear_lowrank = on("FFVD_NO_LINEAR_LOWRANK");
         w.kuu_flow = !on("FFVD_NO_KUU_FLOW");   w.kinv_gram = on("FFVD_KINV_GRAM");   w.chain_rl = on("FFVD_CHAIN_RL");
         w.atb128 = on("FFVD_ATB128");                 w.grad_serial = on("FFVD_GRAD_SERIAL");
         w.debug_sync = on("FFVD_DEBUG_SYNC");
@@ -743,7 +744,9 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
     // nothing competes for slots and the side chain IS the critical path -- ONE dataflow launch that also leaves L^-1 and K^-1
     // instead of six dependent launches, and the per-chain reductions move to the main stream, which has the slack there
     const bool small_side = defer_trace && main_first && !c.grad && !kuu_on_main && sk != s && !h->sw.chain_rl && !h->sw.no_small_side &&
-                            (size_t)first_units * h->ntiles * (h->gsplit > 1 ? h->gsplit : 1) <= 128;
+                            (size_t)first_units * h->ntiles * (h->gsplit > 1 ? h->gsplit : 1) <= (size_t)h->sw.small_side_wgs &&
+                            (size_t)Dl * 2 * (Mp / NB) <= 32;       // (the chain's block rows: at M = 512 they are 64 and the tile pass feels them:
+                                                                     //  0.66 / 0.95 against 0.60 / 0.76 ms at 1 / 4 chains)
     int chain_rc = FFVD_OK;
     const bool reduce_on_main = small_side;
     bool reduce_launched = false, trace_on_main = false;

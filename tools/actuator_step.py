@@ -10,13 +10,14 @@ params = {k: z[k] for k in ("X","Z","U","logvariance","loglengthscales","log_Q",
 Y, c = z["Y"], z["control_inputs"]
 T, D = params["X"].shape[0]-1, params["X"].shape[1]
 M, C = params["Z"].shape[0], c.shape[1]
-params["X"] = params["X"][None]
+S = int(os.environ.get("ACT_S", "1"))
+params["X"] = np.repeat(params["X"][None], S, axis=0) + 1e-3 * np.random.default_rng(0).standard_normal((S,) + params["X"].shape)
 modes = {'forward': (False,), 'train': (True,)}.get(sys.argv[1] if len(sys.argv) > 1 else '', (False, True))
 for grad in modes:
-    e = ElboEngine(T, D, C, M, 1, route="gram", grad=grad)
+    e = ElboEngine(T, D, C, M, S, route="gram", grad=grad)
     e.set_data(Y, c); e.set_params(params)
     f = (lambda: e.adam_step(1e-9)) if grad else (lambda: e.nll_terms())
     for _ in range(10): f()
     n = 300; t0 = time.perf_counter()
     for _ in range(n): f()
-    print("actuator T=%d M=%d D=%d %s: %.3f ms per call" % (T, M, D, "adam_step" if grad else "forward", (time.perf_counter()-t0)/n*1e3))
+    print("actuator T=%d M=%d D=%d S=%d %s: %.3f ms per call" % (T, M, D, S, "adam_step" if grad else "forward", (time.perf_counter()-t0)/n*1e3))
