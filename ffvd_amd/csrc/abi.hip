@@ -1341,9 +1341,13 @@ static int enqueue_grad_b(ffvd_handle *h, int S_total) {
     dx.X = p.X; dx.Y = h->Y; dx.CC = p.CC; dx.DD = p.DD; dx.log_Rchols = p.log_Rchols; dx.log_Q = p.log_Q; dx.len = h->len;
     dx.rsum = g.rsum; dx.ez = g.ez; dx.kfu = g.kfu; dx.S = S; dx.S_total = S_total; dx.T = c.T; dx.Tp = Tp; dx.D = c.D;
     dx.P = P; dx.Ydim = c.Ydim; dx.Dl = Dl; dx.d_begin = c.d_begin; dx.shared_terms = c.shared_terms; dx.dX = g.dX;
-    if (wh) launch_uku(sk, g.wv, Mp, g.Ident, 0, Mp, Dl, nb, g.uku);       // u^T K u = w^T w
-    else launch_uku(sk, g.u, Mp, h->Kcopy, msq, Mp, Dl, nb, g.uku);   // u^T K u per unit: only grad_finalize reads it
-    launch_shared_partials(sk, dx, g.shared_part, g.sp_stride);
+    // u^T K u and the per-chain partials of the shared parameters feed grad_finalize only.  Beside a long E product they ride on
+    // the side stream; when that product is a few dozen microseconds (the reference's own experiment sizes) the side stream's
+    // dozen launches ARE the backward pass's critical path and these two go to the main stream, which has the slack there
+    hipStream_t su = ((size_t)nb * Tp * Mp <= (size_t)64 * 1024 * 128 && !h->sw.grad_serial) ? s : sk;
+    if (wh) launch_uku(su, g.wv, Mp, g.Ident, 0, Mp, Dl, nb, g.uku);       // u^T K u = w^T w
+    else launch_uku(su, g.u, Mp, h->Kcopy, msq, Mp, Dl, nb, g.uku);   // u^T K u per unit: only grad_finalize reads it
+    launch_shared_partials(su, dx, g.shared_part, g.sp_stride);
     launch_chain_sum(sk, g.Acopy, msq, S, Dl, msq, g.Asum, msq);      // (reference route: the saved matrices are the H_s)
     launch_symmetrize(sk, g.Asum, Mp, Dl);
     launch_chain_sum(sk, g.Gamma, msq, S, Dl, msq, g.GamSum, msq);
