@@ -1271,6 +1271,44 @@ static int enqueue_grad_b(ffvd_handle *h, int S_total) {
     ag.C = g.Gamma; ag.c_stride = msq; ag.ldc = Mp; ag.nb = nb; ag.b0 = 0; ag.Dl = Dl; ag.d_begin = c.d_begin;
     ag.log_Q = p.log_Q; ag.u = g.u; ag.u_stride = Mp; ag.Kinv = h->Kinv; ag.Kcopy = h->Kcopy; ag.k_stride = msq; ag.ldk = Mp;
     ag.part = g.gam_part; ag.k_lower = 1; ag.sym = 1; ag.small_tiles = 1;   // inverse factor lower triangular, its Gram symmetric
+    // K_uu side, first half: K^-1 (sum_s A_s - S K) K^-1 needs the saved A-matrices and the K_uu chain only, not Gamma.  When the E
+    // product is short (tiny problems: the side stream's launches are the critical path of the backward pass) it starts here,
+    // ahead of w / u / B / Gamma; Gamma's sum joins it through ev_go.
+    hipStream_t sk = h->sw.grad_serial ? s : h->aux;
+    const bool tiny = (size_t)nb * Tp * Mp <= (size_t)64 * 1024 * 128 && sk != s;
+    auto kgk_chain = [&]() -> int {
+        launch_chain_sum(sk, g.Acopy, msq, S, Dl, msq, g.Asum, msq);      // (reference route: the saved matrices are the H_s)
+        launch_symmetrize(sk, g.Asum, Mp, Dl);
+        if (!ref) launch_axpby(sk, g.Asum, h->Kcopy, 1.0, -(double)S, p.log_Q, c.d_begin, 0, msq, Dl, g.Gs);
+        AtbArgs ap{};
+        ap.mode = ATB_PLAIN; ap.a_stride = msq; ap.lda = Mp; ap.nA = Mp; ap.b_stride = msq;
+        ap.ldb = Mp; ap.nB = Mp; ap.rows = Mp; ap.c_stride = msq; ap.ldc = Mp; ap.nb = Dl; ap.Dl = Dl;
+        if (wh) {       // K^-1 Gs K^-1 = W (W^T Gs W) W^T, conjugated step by step (Gs and W^T Gs W are symmetric)
+            if (ref) launch_sub_identity(sk, g.Asum, (double)S, Mp, Dl, g.P2);     // W^T Gs W = sum_s (H_s - I): no products needed
+            else {
+                ap.A = g.Gs; ap.B = h->Kuu + msq; ap.b_stride = kstride; ap.C = g.P1; ap.krange = 8;
+                launch_atb(sk, ap);                             // P1 = Gs W
+                ap.A = h->Kuu + msq; ap.a_stride = kstride; ap.B = g.P1; ap.b_stride = msq; ap.C = g.P2; ap.krange = 4;
+                launch_atb(sk, ap);                             // P2 = W^T Gs W
+            }
+            ap.a_stride = msq; ap.b_stride = msq;
+            ap.A = g.P2; ap.a_stride = msq; ap.B = h->Linv; ap.C = g.P3; ap.krange = 2;
+            launch_atb(sk, ap);                             // P3 = P2 W^T
+            ap.A = h->Linv; ap.B = g.P3; ap.C = g.KGK; ap.krange = 1;
+            launch_atb(sk, ap);                             // KGK = W P3
+        } else {
+            ap.A = g.Gs; ap.B = h->Kinv; ap.C = g.P1;
+            launch_atb(sk, ap);                             // P1 = Gs^T K^-1 = Gs K^-1
+            ap.A = g.P1; ap.C = g.KGK;
+            launch_atb(sk, ap);                             // P1^T K^-1 = K^-1 Gs K^-1
+        }
+        return FFVD_OK;
+    };
+    if (tiny) {
+        HIP_TRY(hipEventRecord(h->ev_fork, s));
+        HIP_TRY(hipStreamWaitEvent(sk, h->ev_fork, 0));
+        kgk_chain();
+    }
     if (wh) {
         launch_matvec(s, h->H + msq, hstride, h->H + 2 * msq, hstride, Mp, g.wv, 1, Mp, Mp, nb);          // w = L_H^-T y
         launch_matvec(s, h->Kuu + msq, kstride, g.wv, Mp, Mp, g.u, 1, Mp, Mp, nb, Dl);                     // u = W w
@@ -1290,10 +1328,9 @@ static int enqueue_grad_b(ffvd_handle *h, int S_total) {
     // K_uu side: Psi_d = sum_s Gamma_s / alpha_d - 1/2 K^-1 (sum_s A_s - S K) K^-1.  It needs Gamma and the saved
     // A-matrices only, so its dozen small launches go to the side stream and run beside the E product
     // (enqueued after it: the main stream must not wait for their launch overhead).
-    hipStream_t sk = h->sw.grad_serial ? s : h->aux;
     if (sk != s) {
-        HIP_TRY(hipEventRecord(h->ev_fork, s));
-        HIP_TRY(hipStreamWaitEvent(sk, h->ev_fork, 0));
+        HIP_TRY(hipEventRecord(tiny ? h->ev_go : h->ev_fork, s));          // Gamma is there
+        HIP_TRY(hipStreamWaitEvent(sk, tiny ? h->ev_go : h->ev_fork, 0));
     }
     EReduceArgs er{};
     er.E = g.E; er.e_stride = fstride; er.Kf = Kf64; er.u = g.u; er.u_stride = Mp; er.x_is_z = 0;
@@ -1348,33 +1385,9 @@ static int enqueue_grad_b(ffvd_handle *h, int S_total) {
     if (wh) launch_uku(su, g.wv, Mp, g.Ident, 0, Mp, Dl, nb, g.uku);       // u^T K u = w^T w
     else launch_uku(su, g.u, Mp, h->Kcopy, msq, Mp, Dl, nb, g.uku);   // u^T K u per unit: only grad_finalize reads it
     launch_shared_partials(su, dx, g.shared_part, g.sp_stride);
-    launch_chain_sum(sk, g.Acopy, msq, S, Dl, msq, g.Asum, msq);      // (reference route: the saved matrices are the H_s)
-    launch_symmetrize(sk, g.Asum, Mp, Dl);
+    if (!tiny) kgk_chain();
     launch_chain_sum(sk, g.Gamma, msq, S, Dl, msq, g.GamSum, msq);
-    if (!ref) launch_axpby(sk, g.Asum, h->Kcopy, 1.0, -(double)S, p.log_Q, c.d_begin, 0, msq, Dl, g.Gs);
     launch_axpby(sk, g.GamSum, nullptr, 1.0, 0.0, p.log_Q, c.d_begin, 1, msq, Dl, g.gsum);
-    AtbArgs ap{};
-    ap.mode = ATB_PLAIN; ap.a_stride = msq; ap.lda = Mp; ap.nA = Mp; ap.b_stride = msq;
-    ap.ldb = Mp; ap.nB = Mp; ap.rows = Mp; ap.c_stride = msq; ap.ldc = Mp; ap.nb = Dl; ap.Dl = Dl;
-    if (wh) {       // K^-1 Gs K^-1 = W (W^T Gs W) W^T, conjugated step by step (Gs and W^T Gs W are symmetric)
-        if (ref) launch_sub_identity(sk, g.Asum, (double)S, Mp, Dl, g.P2);     // W^T Gs W = sum_s (H_s - I): no products needed
-        else {
-        ap.A = g.Gs; ap.B = h->Kuu + msq; ap.b_stride = kstride; ap.C = g.P1; ap.krange = 8;
-        launch_atb(sk, ap);                             // P1 = Gs W
-        ap.A = h->Kuu + msq; ap.a_stride = kstride; ap.B = g.P1; ap.b_stride = msq; ap.C = g.P2; ap.krange = 4;
-        launch_atb(sk, ap);                             // P2 = W^T Gs W
-        }
-        ap.a_stride = msq; ap.b_stride = msq;
-        ap.A = g.P2; ap.a_stride = msq; ap.B = h->Linv; ap.C = g.P3; ap.krange = 2;
-        launch_atb(sk, ap);                             // P3 = P2 W^T
-        ap.A = h->Linv; ap.B = g.P3; ap.C = g.KGK; ap.krange = 1;
-        launch_atb(sk, ap);                             // KGK = W P3
-    } else {
-        ap.A = g.Gs; ap.B = h->Kinv; ap.C = g.P1;
-        launch_atb(sk, ap);                             // P1 = Gs^T K^-1 = Gs K^-1
-        ap.A = g.P1; ap.C = g.KGK;
-        launch_atb(sk, ap);                             // P1^T K^-1 = K^-1 Gs K^-1
-    }
     launch_psi_e(sk, g.gsum, g.KGK, h->Kcopy, c.M, Mp, Dl, c.jitter, g.Epsi);
     EReduceArgs ek{};
     ek.E = g.Epsi; ek.e_stride = msq; ek.Kf = nullptr; ek.u = nullptr; ek.x_is_z = 1; ek.Z = p.Z; ek.len = h->len;
