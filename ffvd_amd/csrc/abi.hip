@@ -358,7 +358,7 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
         h->chain_terms = h->tsbuf + raw;
     } else
         HIP_TRY(dev_alloc(h, &h->chain_terms, (size_t)c.S_local * 8));
-    HIP_TRY(dev_alloc(h, &h->chain_partial, (size_t)c.S_local * 32));
+    HIP_TRY(dev_alloc(h, &h->chain_partial, (size_t)c.S_local * 128));        // [S][<= 32 row ranges][4] (launch_chain_reduce)
     {
         const size_t nS = (size_t)(c.S_local ? c.S_local : 1), ninfo = (size_t)(Dl + h->nbatch);
         const size_t ndbl = 8 + nS + (ninfo + 1) / 2;
@@ -2075,7 +2075,7 @@ extern "C" int ffvd_op_collapse(int kind, const double *Lm_inverse_seq, const do
     ra.C = 0; ra.Ydim = 0; ra.Dl = D; ra.d_begin = 0; ra.S = 1; ra.ng = ng; ra.shared_terms = 0;
     ra.xk = dXc; ra.xk_chain_stride = 0; ra.xk_ld = P; ra.xk_cols = P; ra.rowsq = rowsq; ra.fmean = nullptr;
     ra.chain_terms = cterms;
-    double *cpart = sc.alloc<double>(32);
+    double *cpart = sc.alloc<double>(128);
     if (!cpart) return set_error(nullptr, FFVD_ENOMEM, "ffvd_op_collapse: device allocation failed");
     launch_chain_reduce(sc.stream, ra, cpart);
     std::vector<double> ht((size_t)D * 2), ct(8);

@@ -133,10 +133,15 @@ __device__ __forceinline__ double kernel_value(double dot, double xx, double zz,
 // (row stride P | 1 doubles: conflict-free reads whatever P) and reused for every row i, whose z_i is a scalar operand.  The
 // first version (one output per thread, 256 per workgroup, operands from global) was bound by the dispatch of its tiny
 // workgroups: 147 us for the 16 matrices of config 5 (32768 workgroups), 12 us for the 4 of config 2.
+// The row operands z_i (and |z_i|^2) go through LDS too and the inner product runs over a compile-time PM >= P with zero padding
+// (same terms in the same order, then zeros): with a run-time P the p loop was not unrolled and read z_i[p] from global memory
+// with a wait per iteration -- 19 us for the 4 matrices of config 2, 37-46 us for the 16 of config 5 (P = 17), for a few
+// microseconds of arithmetic.
 constexpr int KUU_ROWS = 16;
+template <int PM>
 __global__ __launch_bounds__(256) void kuu_build_kernel(int kind, HyperView hv, int M, int Mp, int P, double jitter,
                                                         double *A, double *Kcopy, int zt_rows) {
-    extern __shared__ double zs_lds[];                    // [256][P | 1]
+    extern __shared__ double zs_lds[];                    // [256][P | 1] | zi [KUU_ROWS][PM] | zzi [KUU_ROWS]
     const int dl = blockIdx.z, tid = threadIdx.x;
     const int ncc = (Mp + 255) / 256;                     // column chunks per row
     const int i0 = (int)(blockIdx.x / ncc) * KUU_ROWS, j0 = (int)(blockIdx.x % ncc) * 256;
@@ -166,10 +171,18 @@ __global__ __launch_bounds__(256) void kuu_build_kernel(int kind, HyperView hv, 
             r += dr; c += dc;
             if (c >= P) { c -= P; ++r; }
         }
-        __syncthreads();
     }
+    double *zi_lds = zs_lds + (size_t)256 * ld, *zzi_lds = zi_lds + KUU_ROWS * PM;
+    for (int e = tid; e < KUU_ROWS * PM; e += 256) {
+        const int rr = e / PM, pp = e % PM, i = i0 + rr;
+        zi_lds[e] = (pp < P && i < Mp) ? hv.Zs[((size_t)dl * Mp + i) * P + pp] : 0.0;
+    }
+    if (tid < KUU_ROWS) zzi_lds[tid] = (kind == 0 && i0 + tid < Mp) ? hv.zz[(size_t)dl * Mp + i0 + tid] : 0.0;
+    __syncthreads();
     if (j >= Mp) return;
-    const double *zl = zs_lds + (size_t)tid * ld;
+    double zl[PM];
+#pragma unroll
+    for (int p = 0; p < PM; ++p) zl[p] = (p < P) ? zs_lds[(size_t)tid * ld + p] : 0.0;
     const double var = hv.variance[dl];
     const double zzj = (kind == 0 && j < M) ? hv.zz[(size_t)dl * Mp + j] : 0.0;
     for (int r = 0; r < KUU_ROWS && i0 + r < Mp; ++r) {
@@ -178,13 +191,15 @@ __global__ __launch_bounds__(256) void kuu_build_kernel(int kind, HyperView hv, 
         if (i >= M || j >= M) {
             v = (i == j) ? 1.0 : 0.0;
         } else {
-            const double *zi = hv.Zs + ((size_t)dl * Mp + i) * P;
+            const double *zi = zi_lds + r * PM;
             double dot = 0.0;
             if (kind == 0) {
-                for (int p = 0; p < P; ++p) dot += zi[p] * zl[p];
-                v = kernel_value<0>(dot, hv.zz[(size_t)dl * Mp + i], zzj, var);
+#pragma unroll
+                for (int p = 0; p < PM; ++p) dot += zi[p] * zl[p];
+                v = kernel_value<0>(dot, zzi_lds[r], zzj, var);
             } else {
-                for (int p = 0; p < P; ++p) dot += (zi[p] * var) * zl[p];
+#pragma unroll
+                for (int p = 0; p < PM; ++p) dot += (zi[p] * var) * zl[p];
                 v = dot;
             }
             if (i == j) v += jitter;   // conditionals_multi_output.py:108,159
@@ -198,8 +213,12 @@ void launch_kuu_build(hipStream_t stream, int kind, HyperView hv, int M, int Mp,
                       double *Kcopy, bool zt_rows) {
     const int ncc = (Mp + 255) / 256, nrg = (Mp + KUU_ROWS - 1) / KUU_ROWS;
     dim3 grid((unsigned)(ncc * nrg), 2, Dl);
-    hipLaunchKernelGGL(kuu_build_kernel, grid, dim3(256), (size_t)256 * (P | 1) * sizeof(double), stream, kind, hv, M, Mp, P,
-                       jitter, A, Kcopy, zt_rows ? 1 : 0);
+    if (P <= 8)
+        hipLaunchKernelGGL(kuu_build_kernel<8>, grid, dim3(256), ((size_t)256 * (P | 1) + KUU_ROWS * 9) * sizeof(double), stream, kind, hv, M,
+                           Mp, P, jitter, A, Kcopy, zt_rows ? 1 : 0);
+    else
+        hipLaunchKernelGGL(kuu_build_kernel<MAXP>, grid, dim3(256), ((size_t)256 * (P | 1) + KUU_ROWS * (MAXP + 1)) * sizeof(double), stream,
+                           kind, hv, M, Mp, P, jitter, A, Kcopy, zt_rows ? 1 : 0);
 }
 
 // out[dl][i][j] = in[dl][j][i] for Dl square Mp x Mp matrices (L^-T -> L^-1)
@@ -2761,14 +2780,15 @@ void launch_h_finish(hipStream_t stream, const double *H, int Mp, size_t h_strid
 // Per-chain streaming reductions (likelihoods.py:76-111; dgp_model.py:250-252,283-284,346-351)
 // chain_terms[s] = { lik quadratic sum, transition quadratic sum, trace sum, prior_x_0 }
 // ---------------------------------------------------------------------------------------------
-constexpr int CR_SPLIT = 8;     // workgroups per chain
-__global__ __launch_bounds__(256) void chain_reduce_kernel(ReduceArgs a, double *partial /*[S][CR_SPLIT][4]*/) {
+constexpr int CR_SPLIT = 8;     // workgroups per chain (four times as many from 8 latent dims on: a row's terms are a loop over the dims)
+static int chain_reduce_split(int Dl) { return Dl >= 8 ? 4 * CR_SPLIT : CR_SPLIT; }
+__global__ __launch_bounds__(256) void chain_reduce_kernel(ReduceArgs a, double *partial /*[S][nsplit][4]*/, const int nsplit) {
     __shared__ double scratch[256];
     const int s = blockIdx.x, part = blockIdx.y, tid = threadIdx.x;
     const int T = a.T, D = a.D;
     const double *Xs = a.X + (size_t)s * (T + 1) * D;
     double lik = 0.0, xq = 0.0, tr = 0.0;
-    for (int t = part * 256 + tid; t < T; t += 256 * CR_SPLIT) {
+    for (int t = part * 256 + tid; t < T; t += 256 * nsplit) {
         if (a.shared_terms) {
             for (int j = 0; j < a.Ydim; ++j) {
                 double ym = 0.0;
@@ -2808,16 +2828,16 @@ __global__ __launch_bounds__(256) void chain_reduce_kernel(ReduceArgs a, double 
     xq = block_sum_256(xq, scratch);
     tr = block_sum_256(tr, scratch);
     if (tid == 0) {
-        double *o = partial + ((size_t)s * CR_SPLIT + part) * 4;
+        double *o = partial + ((size_t)s * nsplit + part) * 4;
         o[0] = lik; o[1] = xq; o[2] = tr;
     }
 }
-__global__ void chain_combine_kernel(ReduceArgs a, const double *partial) {
+__global__ void chain_combine_kernel(ReduceArgs a, const double *partial, const int nsplit) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= a.S) return;
     double lik = 0.0, xq = 0.0, tr = 0.0;
-    for (int p = 0; p < CR_SPLIT; ++p) {
-        const double *o = partial + ((size_t)s * CR_SPLIT + p) * 4;
+    for (int p = 0; p < nsplit; ++p) {
+        const double *o = partial + ((size_t)s * nsplit + p) * 4;
         lik += o[0]; xq += o[1]; tr += o[2];
     }
     const double *Xs = a.X + (size_t)s * (a.T + 1) * a.D;
@@ -2827,8 +2847,9 @@ __global__ void chain_combine_kernel(ReduceArgs a, const double *partial) {
     o[0] = lik; o[1] = xq; o[2] = tr; o[3] = a.skip_x0 ? 0.0 : -px0 / 2.0;     // prior_x_0 dgp_model.py:252
 }
 void launch_chain_reduce(hipStream_t stream, const ReduceArgs &a, double *partial) {
-    hipLaunchKernelGGL(chain_reduce_kernel, dim3(a.S, CR_SPLIT), dim3(256), 0, stream, a, partial);
-    hipLaunchKernelGGL(chain_combine_kernel, dim3((a.S + 63) / 64), dim3(64), 0, stream, a, partial);
+    const int nsplit = chain_reduce_split(a.Dl);
+    hipLaunchKernelGGL(chain_reduce_kernel, dim3(a.S, nsplit), dim3(256), 0, stream, a, partial, nsplit);
+    hipLaunchKernelGGL(chain_combine_kernel, dim3((a.S + 63) / 64), dim3(64), 0, stream, a, partial, nsplit);
 }
 
 // conditional() outputs (conditionals_multi_output.py:41,48,120): mean N x D, var N x D
