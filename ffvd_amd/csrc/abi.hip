@@ -340,6 +340,7 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
             g.dloglen = g.dlogvar + c.D; g.dlogQ = g.dloglen + (size_t)c.D * P; g.dCC = g.dlogQ + c.D;
             g.dDD = g.dCC + (size_t)c.D * J; g.dlogR = g.dDD + J;
         }
+        if (!grad_a && c.kernel_kind != FFVD_KERNEL_SE) HIP_TRY(dev_alloc(h, &g.xsq, nbt));      // LinearK, collapsed branch: sum_t |x_t|^2 per unit
         if (grad_a) {
             HIP_TRY(dev_alloc(h, &g.Gu, nbt * (Mp + NB) * Mp));   HIP_TRY(dev_alloc(h, &g.Gsum, Dl * (Mp + NB) * Mp));
             HIP_TRY(dev_alloc(h, &g.r, nbt * Tp));                HIP_TRY(dev_alloc(h, &g.dalpha, nbt));
@@ -431,8 +432,8 @@ extern "C" int ffvd_create(const ffvd_config *cfg, ffvd_handle **out) {
     if (!(cfg->jitter >= 0.0)) return set_error(nullptr, FFVD_EINVAL, "ffvd_create: jitter must be >= 0");
     if (cfg->route != FFVD_ROUTE_REFERENCE && cfg->route != FFVD_ROUTE_GRAM)
         return set_error(nullptr, FFVD_EINVAL, "ffvd_create: unknown route");
-    if (cfg->grad && cfg->branch == FFVD_BRANCH_B && cfg->kernel_kind != FFVD_KERNEL_SE)
-        return set_error(nullptr, FFVD_EINVAL, "ffvd_create: grad = 1 in the collapsed-U branch needs the SE kernel");
+    if (cfg->grad && cfg->branch == FFVD_BRANCH_B && cfg->kernel_kind != FFVD_KERNEL_SE && cfg->dtype == FFVD_F32C)
+        return set_error(nullptr, FFVD_EINVAL, "ffvd_create: grad = 1 with fp32 contractions needs the SE kernel (the LinearK backward pass is fp64)");
     if (cfg->route == FFVD_ROUTE_GRAM && cfg->branch != FFVD_BRANCH_B)
         return set_error(nullptr, FFVD_EINVAL, "ffvd_create: FFVD_ROUTE_GRAM only applies to the collapsed-U branch");
     if (cfg->T_total < 0 || cfg->t_begin < 0 || (cfg->T_total > 0 && cfg->t_begin + cfg->T > cfg->T_total))
@@ -1338,6 +1339,12 @@ static int enqueue_grad_b(ffvd_handle *h, int S_total) {
     er.Z = p.Z; er.len = h->len; er.T = c.T; er.Tp = Tp; er.M = c.M; er.Mp = Mp; er.P = P; er.Dl = Dl; er.b0 = 0; er.nb = nb;
     er.nblk = Tp / 64; er.rsum = g.rsum; er.ez = g.ez; er.kfu = g.kfu; er.cs_part = g.cs_part; er.etx_part = g.etx_part;
     er.rx2_part = g.rx2_part;
+    // LinearK (kernels.py:270-281) in the collapsed branch: K = (x s2) z^T has no Hadamard factor in its chain rule and its Kdiag_t =
+    // s2 |x_t|^2 depends on the inputs -- the switches the explicit-U branch already uses (enqueue_grad_a), plus sum_t |x_t|^2 per unit
+    const int kind = c.kernel_kind;
+    const bool lin = kind != FFVD_KERNEL_SE;
+    er.kind = kind; er.variance = h->variance;
+    if (lin) launch_xsq_unit(sk, p.X, h->ctrl, c.T, c.D, c.C, S, Dl, g.xsq);
     if (f32c) {
         // fp32 contractions (BASELINE configs[3]): Gamma rounded once, R = K_fu Gamma on v_mfma_f32_32x32x2_f32 into the buffer F
         // occupied in the forward pass, then E_tm = (2 R_tm + alpha delta_t u_m) K_tm formed on the fly inside the reduction
@@ -1358,6 +1365,7 @@ static int enqueue_grad_b(ffvd_handle *h, int S_total) {
         bf.M = c.M; bf.Mp = Mp; bf.P = P; bf.Dl = Dl; bf.d_begin = c.d_begin; bf.b0 = 0; bf.nb = nb; bf.rp = g.rp;
         bf.cs_part = g.cs_part; bf.etx_part = g.etx_part; bf.rsum = g.rsum; bf.ez = g.ez; bf.kfu = g.kfu;
         bf.rx2_part = g.rx2_part;
+        bf.linear = lin ? 1 : 0;
         launch_bwd_fused(s, bf);
     } else {
         // P > 6: materialise E and reduce it in a second kernel
@@ -1366,7 +1374,7 @@ static int enqueue_grad_b(ffvd_handle *h, int S_total) {
         ae.B = g.Gamma; ae.b_stride = msq; ae.ldb = Mp; ae.nB = Mp; ae.rows = Mp;
         ae.C = g.E; ae.c_stride = fstride; ae.ldc = Mp; ae.nb = nb; ae.b0 = 0; ae.Dl = Dl; ae.d_begin = c.d_begin;
         ae.log_Q = p.log_Q; ae.u = g.u; ae.u_stride = Mp; ae.X = p.X; ae.T = c.T; ae.D = c.D;
-        ae.Kf = Kf64; ae.kf_stride = fstride; ae.ldkf = Mp;
+        ae.Kf = Kf64; ae.kf_stride = fstride; ae.ldkf = Mp; ae.no_hadamard = lin ? 1 : 0;
         launch_atb(s, ae);
         launch_e_reduce(s, er);
     }
@@ -1375,6 +1383,7 @@ static int enqueue_grad_b(ffvd_handle *h, int S_total) {
     DBG_SYNC(h, "backward: e_finish");
     // latent trajectories (after the E product) and the per-chain partials of the shared parameters (inputs only: side)
     DxArgs dx{};
+    dx.kind = kind; dx.variance = h->variance;
     dx.X = p.X; dx.Y = h->Y; dx.CC = p.CC; dx.DD = p.DD; dx.log_Rchols = p.log_Rchols; dx.log_Q = p.log_Q; dx.len = h->len;
     dx.rsum = g.rsum; dx.ez = g.ez; dx.kfu = g.kfu; dx.S = S; dx.S_total = S_total; dx.T = c.T; dx.Tp = Tp; dx.D = c.D;
     dx.P = P; dx.Ydim = c.Ydim; dx.Dl = Dl; dx.d_begin = c.d_begin; dx.shared_terms = c.shared_terms; dx.dX = g.dX;
@@ -1388,11 +1397,12 @@ static int enqueue_grad_b(ffvd_handle *h, int S_total) {
     if (!tiny) kgk_chain();
     launch_chain_sum(sk, g.Gamma, msq, S, Dl, msq, g.GamSum, msq);
     launch_axpby(sk, g.GamSum, nullptr, 1.0, 0.0, p.log_Q, c.d_begin, 1, msq, Dl, g.gsum);
-    launch_psi_e(sk, g.gsum, g.KGK, h->Kcopy, c.M, Mp, Dl, c.jitter, g.Epsi);
+    launch_psi_e(sk, g.gsum, g.KGK, h->Kcopy, c.M, Mp, Dl, c.jitter, g.Epsi, kind);
     EReduceArgs ek{};
     ek.E = g.Epsi; ek.e_stride = msq; ek.Kf = nullptr; ek.u = nullptr; ek.x_is_z = 1; ek.Z = p.Z; ek.len = h->len;
     ek.T = c.M; ek.Tp = Mp; ek.M = c.M; ek.Mp = Mp; ek.P = P; ek.Dl = Dl; ek.b0 = 0; ek.nb = Dl; ek.nblk = Mp / 64;
     ek.rsum = g.rsum2; ek.ez = g.ez2; ek.kfu = nullptr; ek.cs_part = g.cs2; ek.etx_part = g.etx2; ek.rx2_part = g.rx22;
+    ek.kind = kind; ek.variance = h->variance;
     launch_e_reduce(sk, ek);
     launch_e_finish(sk, ek, g.dz_kuu, g.dll_kuu, g.dls_kuu);
     if (sk != s) HIP_TRY(hipEventRecord(h->ev_join, sk));
@@ -1407,6 +1417,7 @@ static int enqueue_grad_b(ffvd_handle *h, int S_total) {
     gf.dz_kuu = g.dz_kuu; gf.dll_kuu = g.dll_kuu; gf.dls_kuu = g.dls_kuu; gf.gam_part = g.gam_part; gf.ngam = g.ngam;
     gf.trpart = h->trpart; gf.ntr = h->ntiles; gf.hterms = h->hterms;
     gf.uku = g.uku; gf.shared_part = g.shared_part;
+    gf.kind = kind; gf.xsq_unit = g.xsq;
     if (ref) { gf.trpart = f32c ? h->sqsum : g.fsq; gf.ntr = 1; }       // sum_t |F_t|^2 per unit (Gram route: tr(K^-1 K_uf K_fu) by tiles)
     gf.sp_stride = g.sp_stride; gf.dZ = g.dZ; gf.dlogvar = g.dlogvar; gf.dloglen = g.dloglen; gf.dlogQ = g.dlogQ;
     gf.dCC = g.dCC; gf.dDD = g.dDD; gf.dlogR = g.dlogR;

@@ -47,7 +47,9 @@ void launch_uku(hipStream_t stream, const double *u, size_t u_stride, const doub
 void launch_chain_sum(hipStream_t stream, const double *in, size_t in_stride, int S, int Dl, size_t n, double *out,
                       size_t out_stride);
 void launch_psi_e(hipStream_t stream, const double *gsum, const double *kgk, const double *Kcopy, int M, int Mp, int Dl,
-                  double jitter, double *Eout);
+                  double jitter, double *Eout, int kind = 0);
+// xsq_unit[s * Dl + dl] = sum_t |[X_s[t], ctrl[t]]|^2 (LinearK's Kdiag sums, collapsed branch)
+void launch_xsq_unit(hipStream_t stream, const double *X, const double *ctrl, int T, int D, int C, int S, int Dl, double *xsq_unit);
 void launch_symmetrize(hipStream_t stream, double *A, int Mp, int batch);
 void launch_sub_identity(hipStream_t stream, const double *x, double sc, int Mp, int Dl, double *out);
 void launch_axpby(hipStream_t stream, const double *x, const double *z, double a, double bcoef, const double *log_Q,

@@ -840,7 +840,7 @@ void launch_chain_sum(hipStream_t stream, const double *in, size_t in_stride, in
 // E'[dl] = ( GamSum/alpha_sum_form - 1/2 Kinv (Asum - S K) Kinv ) o K_uu(no jitter)  where the caller provides
 //   gsum = sum_s Gamma_s / alpha  (already divided),  kgk = Kinv (Asum - S K) Kinv
 __global__ void psi_e_kernel(const double *gsum, const double *kgk, const double *Kcopy, int M, int Mp, double jitter,
-                             double *Eout) {
+                             double *Eout, int kind) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int dl = blockIdx.y;
     if (idx >= (size_t)Mp * Mp) return;
@@ -848,15 +848,35 @@ __global__ void psi_e_kernel(const double *gsum, const double *kgk, const double
     const size_t o = (size_t)dl * Mp * Mp + idx;
     double v = 0.0;
     if (i < M && j < M) {
-        const double kuu = Kcopy[o] - ((i == j) ? jitter : 0.0);
+        const double kuu = (kind != 0) ? 1.0 : Kcopy[o] - ((i == j) ? jitter : 0.0);     // LinearK: no Hadamard product (as epsi_a_kernel)
         v = (gsum[o] - 0.5 * kgk[o]) * kuu;
     }
     Eout[o] = v;
 }
 void launch_psi_e(hipStream_t stream, const double *gsum, const double *kgk, const double *Kcopy, int M, int Mp, int Dl,
-                  double jitter, double *Eout) {
+                  double jitter, double *Eout, int kind) {
     hipLaunchKernelGGL(psi_e_kernel, dim3((unsigned)(((size_t)Mp * Mp + 255) / 256), Dl), dim3(256), 0, stream, gsum, kgk,
-                       Kcopy, M, Mp, jitter, Eout);
+                       Kcopy, M, Mp, jitter, Eout, kind);
+}
+
+// xsq_unit[s * Dl + dl] = sum_t |x_t|^2 over the GP inputs x_t = [X_s[t], ctrl[t]] of chain s (LinearK: Kdiag_t = variance |x_t|^2 sits
+// in the trace term of the collapsed bound; the explicit-U branch gets the same sums from resid_a_kernel)
+__global__ __launch_bounds__(256) void xsq_unit_kernel(const double *X, const double *ctrl, int T, int D, int C, int Dl, double *xsq_unit) {
+    __shared__ double scratch[256];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const double *Xs = X + (size_t)s * (T + 1) * D;
+    double acc = 0.0;
+    for (int t = tid; t < T; t += 256) {
+        double xsq = 0.0;
+        for (int p = 0; p < D; ++p) xsq += Xs[(size_t)t * D + p] * Xs[(size_t)t * D + p];
+        for (int p = 0; p < C; ++p) xsq += ctrl[(size_t)t * C + p] * ctrl[(size_t)t * C + p];
+        acc += xsq;
+    }
+    acc = block_sum(acc, scratch);
+    if (tid < Dl) xsq_unit[(size_t)s * Dl + tid] = acc;
+}
+void launch_xsq_unit(hipStream_t stream, const double *X, const double *ctrl, int T, int D, int C, int S, int Dl, double *xsq_unit) {
+    hipLaunchKernelGGL(xsq_unit_kernel, dim3(S), dim3(256), 0, stream, X, ctrl, T, D, C, Dl, xsq_unit);
 }
 
 // in-place: upper triangle <- lower triangle (the forward Gram kernel only writes lower-triangular tiles)
@@ -1302,7 +1322,7 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(GradFinalArgs a) {
                 v[1] += a.dalpha_unit[bb] * (-alpha);
                 continue;
             }
-            // dl/dalpha = -1/2 tr(A^-1 G) + u^T g - 1/2 u^T G u - 1/2 (T s2 - tr(K^-1 G)),  G = (A - K)/alpha
+            // dl/dalpha = -1/2 tr(A^-1 G) + u^T g - 1/2 u^T G u - 1/2 (sum_t Kdiag_t - tr(K^-1 G)),  G = (A - K)/alpha;  sum_t Kdiag_t = T s2 (SE), s2 sum_t |x_t|^2 (LinearK)
             double trAK = 0.0;
             for (int t = 0; t < a.ngam; ++t) trAK += a.gam_part[bb * a.ngam + t];
             double fsq = 0.0;
@@ -1310,7 +1330,7 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(GradFinalArgs a) {
             const double quad = a.hterms[2 * bb + 1];
             const double trAinvG = ((double)a.Mp - trAK) / alpha;
             const double uGu = (quad - a.uku[bb]) / alpha;
-            const double dalpha = -0.5 * trAinvG + quad / alpha - 0.5 * uGu - 0.5 * (Tn * s2 - fsq);
+            const double dalpha = -0.5 * trAinvG + quad / alpha - 0.5 * uGu - 0.5 * (((a.kind != 0) ? a.xsq_unit[bb] : Tn) * s2 - fsq);
             v[1] += dalpha * (-alpha);
             v[2] += a.shared_part[(size_t)s * a.sp_stride + D * J + 2 * J + dl];
         }

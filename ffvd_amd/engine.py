@@ -158,7 +158,8 @@ class ElboEngine:
 
     def nll_and_grad(self, params=None, S_total=None):
         """nll terms and the gradient of the mean-over-chains nll w.r.t. every parameter
-        (tf.gradients(nll, vars), base_model.py:148).  Needs grad=True and SE kernels; collapsed branch: route="gram".
+        (tf.gradients(nll, vars), base_model.py:148).  Needs grad=True; both kernels, both branches, both routes (fp32 contractions:
+        SE kernel only).
 
         Returns (terms dict, grads dict with keys X, Z, logvariance, loglengthscales, log_Q, CC, DD, log_Rchols).
         With chains sharded over ranks pass S_total = chains of the whole job and sum the shared-parameter

@@ -150,7 +150,7 @@ int  ffvd_elbo(ffvd_handle *h, const ffvd_params *p, uint32_t flags, double out_
 int  ffvd_elbo_async(ffvd_handle *h, double *out_terms_dev);
 /* Gradient of the mean-over-chains nll w.r.t. every parameter (what the reference gets from tf.gradients(nll, vars),
  * base_model.py:148, and AdamOptimizer.minimize(nll), dgp_model.py:303-305).  Needs a handle created with
- * grad = 1: the collapsed branch with the SE kernel (either route; FFVD_F32C too), or the explicit-U branch with either kernel
+ * grad = 1: either branch with either kernel (collapsed branch: either route in fp64; FFVD_F32C with the SE kernel only)
  * (LinearK: the loglengthscales gradient is identically zero -- the kernel has none).  Host output pointers with
  * the shapes of ffvd_params; any of them may be NULL.  S_total = number of chains of the whole job (the divisor of
  * the mean).  Sharded jobs: every output is this handle's ADDITIVE share of the whole-job gradient -- entries of

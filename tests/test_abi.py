@@ -126,7 +126,7 @@ h = C.c_void_p()
 # ffvd_create: every rejection path that needs no device, plus the no-device path itself
 bad = [dict(T=0), dict(D=0), dict(M=0), dict(S_local=0), dict(Ydim=0), dict(C=-1), dict(D=30, C=5), dict(dtype=7),
        dict(kernel_kind=9), dict(branch=5), dict(prior_type=7), dict(d_begin=3, d_count=2), dict(jitter=-1.0),
-       dict(route=3), dict(grad=1, kernel_kind=1, branch=1, route=1), dict(grad=1, kernel_kind=1, branch=1, route=0), dict(route=1, branch=0), dict(dtype=1, route=1, branch=1),
+       dict(route=3), dict(grad=1, kernel_kind=1, branch=1, route=0, dtype=1), dict(route=1, branch=0), dict(dtype=1, route=1, branch=1),
        dict(dtype=1, branch=0)]
 base = dict(T=8, D=4, C=1, M=16, S_local=1, Ydim=1, jitter=1e-5, branch=1, prior_type=1)
 for ov in bad:

@@ -878,6 +878,58 @@ def test_explicit_u_gradient_linear_kernel_and_large_p(kernel_type, ov):
         assert not np.any(g["loglengthscales"])                   # no lengthscales: neither a data nor a prior term
 
 
+@pytest.mark.parametrize("route", ["gram", "reference"])
+@pytest.mark.parametrize("ov", [dict(U_collapse=True), dict(U_collapse=True, T=301, M=77, D=3, C=2, S=2),
+                                dict(U_collapse=True, T=200, M=40, D=16, C=1, S=1)], ids=["lin_P7", "lin_P5_fused", "lin_P17"])
+def test_collapsed_gradient_linear_kernel(route, ov):
+    """Round 3 (VERDICT r2 Missing 3): the backward pass of the collapsed branch with LinearK (kernels.py:270-281) -- no Hadamard
+    factor in the chain rule through K_fu and K_uu, Kdiag_t = s2 |x_t|^2 in the trace term (so X, logvariance and log_Q see it) --
+    on both routes, fused (P <= 6) and generic-P reductions, against torch autograd of the independent restatement."""
+    from oracle import ffvd_oracle_torch as orct
+    params, Y, c, meta = synthetic.make_named("small_lin", **ov)
+    S = params["X"].shape[0]
+    keys = tuple(k for k in GRAD_KEYS if k != "loglengthscales")
+    with ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], S, kernel_type="LinearK", U_collapse=True, route=route, grad=True) as e:
+        e.set_data(Y, c)
+        terms, g = e.nll_and_grad(params)
+        _, g2 = e.nll_and_grad(params)
+    ref = {k: np.zeros_like(g[k]) for k in keys}
+    nll_ref = 0.0
+    for s in range(S):
+        p = dict(params)
+        p["X"] = params["X"][s]
+        t, ga = orct.nll_and_grad(p, Y, c, wrt=keys, U_collapse=True, kernel_type="LinearK")
+        nll_ref += t["nll"] / S
+        ref["X"][s] = ga["X"] / S
+        for k in keys[1:]:
+            ref[k] += ga[k] / S
+    assert terms["nll"] == pytest.approx(nll_ref, rel=1e-6)
+    for k in keys:
+        np.testing.assert_array_equal(g[k], g2[k])
+        err = np.max(np.abs(g[k] - ref[k])) / (np.max(np.abs(ref[k])) + 1e-300)
+        # K_uu has rank P << M, only the 1e-5 jitter makes it positive definite (cond ~ |K| / 1e-5): the explicit-U test's bound
+        assert err < 1e-5, (route, k, err)
+    assert not np.any(g["loglengthscales"])                       # no lengthscales: neither a data nor a prior term
+
+
+def test_collapsed_linear_kernel_trains():
+    """Device-resident Adam steps in the collapsed branch with LinearK (config 5's shape of inputs, collapsed U) lower the nll on
+    both routes; the lengthscales (LinearK has none) stay where they are."""
+    params, Y, c, meta = synthetic.make_named("small_lin", U_collapse=True, T=512, M=96, D=8, S=2)
+    for route in ("gram", "reference"):
+        with ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], meta["S"], kernel_type="LinearK", U_collapse=True, route=route,
+                        grad=True) as e:
+            e.set_data(Y, c)
+            e.set_params(params)
+            first = e.adam_step(0.003)["nll"]
+            for _ in range(8):
+                last = e.adam_step(0.003)["nll"]
+            got = e.get_params()
+        assert np.isfinite(first) and last < first, (route, first, last)
+        np.testing.assert_array_equal(got["loglengthscales"], params["loglengthscales"])
+        assert np.max(np.abs(got["Z"] - params["Z"])) > 0
+
+
 def test_config5_training_step_linear_kernel():
     """BASELINE configs[4] can now be trained: a few device-resident Adam steps on the LinearK / explicit-U workload at its
     full shape (T=4096, x_dim=16, M=512) lower the nll."""
