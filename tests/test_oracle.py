@@ -97,6 +97,56 @@ def test_gram_route_identity():
         np.testing.assert_allclose(np.sum(A * A), np.sum(F * F), rtol=1e-12)
 
 
+def test_whitened_factor_without_forming_h():
+    """The identities behind the round-3 training forward: with K = L L^T and A = K + K_uf K_fu / Q = L_A L_A^T,
+    the Cholesky factor of the whitened H = L^-1 A L^-T is L^-1 L_A (lower x lower, positive diagonal: the factor is unique), so
+    L_H^-T = L^T L_A^-T -- what an extended factorisation of A leaves in extension rows that start as L^T -- and the solved row
+    L_A^-1 c equals L_H^-1 (L^-1 c).  log|H| = log|A| - log|K|."""
+    from scipy.linalg import solve_triangular
+    params, Y, c, meta = synthetic.make_named("small")
+    kern = orc.make_kernels(params)
+    X = params["X"][0]
+    xc = np.concatenate((X[:-1], c[: meta["T"]]), axis=1)
+    Z, M = params["Z"], meta["M"]
+    for d, k in enumerate(kern):
+        K = k.K(Z) + 1e-5 * np.eye(M)
+        Kfu = k.K(xc, Z)
+        alpha = 1.0 / np.exp(params["log_Q"][d])
+        A = K + alpha * (Kfu.T @ Kfu)
+        cvec = alpha * (Kfu.T @ (X[1:, d] - X[:-1, d]))
+        L, LA = np.linalg.cholesky(K), np.linalg.cholesky(A)
+        Linv = solve_triangular(L, np.eye(M), lower=True)
+        H = Linv @ A @ Linv.T
+        LH = np.linalg.cholesky(0.5 * (H + H.T))
+        np.testing.assert_allclose(Linv @ LA, LH, rtol=1e-7, atol=1e-9)
+        rows = solve_triangular(LA, L, lower=True).T                       # L^T L_A^-T
+        np.testing.assert_allclose(rows, np.linalg.inv(LH).T, rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(solve_triangular(LA, cvec, lower=True), solve_triangular(LH, Linv @ cvec, lower=True), rtol=1e-7, atol=1e-10)
+        assert 2 * np.sum(np.log(np.diag(LH))) == pytest.approx(2 * np.sum(np.log(np.diag(LA))) - 2 * np.sum(np.log(np.diag(L))), rel=1e-9)
+
+
+def test_linear_kernel_projection_through_its_rank():
+    """The identities behind config 5's forward: LinearK's K_fu = s2 X Z^T (kernels.py:276) has rank P, so
+    F = K_fu L^-T = s2 X C with C = Z^T L^-T, F u = s2 X (C u) and sum_j F_tj^2 = s2^2 x_t^T (C C^T) x_t -- the two quantities the
+    explicit-U branch reads of F (conditionals_multi_output.py:44-52)."""
+    from scipy.linalg import solve_triangular
+    params, Y, c, meta = synthetic.make_named("small_lin")
+    kern = orc.make_kernels(params, kernel_type="LinearK")
+    X = params["X"][0]
+    xc = np.concatenate((X[:-1], c[: meta["T"]]), axis=1)
+    Z, M = params["Z"], meta["M"]
+    for d, k in enumerate(kern):
+        s2 = np.exp(params["logvariance"][d])
+        K = k.K(Z) + 1e-5 * np.eye(M)
+        L = np.linalg.cholesky(K)
+        F = solve_triangular(L, k.K(xc, Z).T, lower=True).T                # K_fu L^-T
+        C = solve_triangular(L, Z, lower=True).T                           # Z^T L^-T  (P x M)
+        u = params["U"][:, d]
+        np.testing.assert_allclose(F, s2 * (xc @ C), rtol=1e-7, atol=1e-10)
+        np.testing.assert_allclose(F @ u, s2 * (xc @ (C @ u)), rtol=1e-7, atol=1e-10)
+        np.testing.assert_allclose(np.sum(F * F, axis=1), s2 * s2 * np.einsum("tp,pq,tq->t", xc, C @ C.T, xc), rtol=1e-7, atol=1e-12)
+
+
 def test_conditional_routes_agree():
     """Branch-A conditional via trsm (:6-70) == via the pre-computed inverse (:324-387)."""
     params, Y, c, meta = synthetic.make_named("tiny")
