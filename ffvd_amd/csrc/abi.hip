@@ -748,6 +748,8 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
                             (size_t)first_units * h->ntiles * (h->gsplit > 1 ? h->gsplit : 1) <= (size_t)h->sw.small_side_wgs &&
                             (size_t)Dl * 2 * (Mp / NB) <= 32;       // (the chain's block rows: at M = 512 they are 64 and the tile pass feels them:
                                                                      //  0.66 / 0.95 against 0.60 / 0.76 ms at 1 / 4 chains)
+    // (chain as the dataflow launch on the stream that builds K_uu: the build zeroes its progress words, one launch less)
+    const bool chain_flow_here = !kuu_on_main && ((sk == s) || small_side) && potrf_flow_selected((int)Mp, (int)Dl, CHOL_FLOW) && !h->sw.chain_rl;
     int chain_rc = FFVD_OK;
     const bool reduce_on_main = small_side;
     bool reduce_launched = false, trace_on_main = false;
@@ -755,12 +757,12 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
         if (!kuu_on_main) {
             // chain on the main stream = on the critical path with nothing beside it: the dataflow launch; on the side stream
             // (beside the K_fu build / tile pass of a small batch) the right-looking launches, whose workgroups come and go
-            const bool chain_flow = ((sk == s) || small_side) && potrf_flow_selected((int)Mp, (int)Dl, CHOL_FLOW) && !h->sw.chain_rl;
+            const bool chain_flow = chain_flow_here;
             if (chain_flow && (gram_route || grad_a || grad_ref)) linv_done = true;
             if (chain_flow && small_side && gram_route && potrf_flow_forms_inverse((int)Mp, (int)Dl, CHOL_FLOW)) kinv_done = true;
             launch_potrf_ext(sk, h->Kuu, Mp, zt_rows ? NB : Mp, zt_rows ? 0 : Mp, Dl, kstride, h->info, h->dinvK,
-                             chain_flow ? CHOL_FLOW : CHOL_AUTO, linv_done ? h->Linv : nullptr, msq, false, false,
-                             kinv_done ? h->Kinv : nullptr, msq);
+                             chain_flow ? CHOL_FLOW : CHOL_AUTO, linv_done ? h->Linv : nullptr, msq, chain_flow /* words zeroed by the build */,
+                             false, kinv_done ? h->Kinv : nullptr, msq);
         }
         if (gram_route || grad_a || grad_ref) {
             // K^-1 = L^-T L^-1 (shared by all chains) and log|K|
@@ -794,7 +796,8 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
         return FFVD_OK;
     };
     if (!kuu_on_main) {
-        launch_kuu_build(sk, c.kernel_kind, hv, c.M, Mp, P, Dl, c.jitter, h->Kuu, (gram_route || grad_a || grad_ref) ? h->Kcopy : nullptr, zt_rows);
+        launch_kuu_build(sk, c.kernel_kind, hv, c.M, Mp, P, Dl, c.jitter, h->Kuu, (gram_route || grad_a || grad_ref) ? h->Kcopy : nullptr, zt_rows,
+                         chain_flow_here ? h->dinvK : nullptr);
         if (defer_trace || (defer_full && sk != s)) HIP_TRY(hipEventRecord(h->ev_kuu, sk));
     }
     if ((chain_rc = chain_rest()) != FFVD_OK) return chain_rc;

@@ -37,7 +37,9 @@ void launch_prep_hypers(hipStream_t stream, int kind, const double *Z, int M, in
 void launch_kuu_build(hipStream_t stream, int kind, HyperView hv, int M, int Mp, int P, int Dl, double jitter, double *A,
                       double *Kcopy /* optional [Dl][Mp*Mp] copy that survives the factorisation */,
                       bool zt_rows = false /* LINEAR, P <= 64: rows Mp..Mp+63 = Z^T (rows >= P zero) instead of the identity: they
-                                              become C = Z^T L^-T (launch_potrf_ext with 64 extra rows, none identity-structured) */);
+                                              become C = Z^T L^-T (launch_potrf_ext with 64 extra rows, none identity-structured) */,
+                      double *flow_words = nullptr /* the scratch block of the dataflow Cholesky that follows on the SAME stream for
+                                              these Dl matrices: its progress words are zeroed here (then: words_zeroed = true) */);
 void launch_transpose(hipStream_t stream, const double *in, size_t in_stride, double *out, size_t out_stride, int Mp,
                       int Dl);
 

@@ -140,9 +140,12 @@ __device__ __forceinline__ double kernel_value(double dot, double xx, double zz,
 constexpr int KUU_ROWS = 16;
 template <int PM>
 __global__ __launch_bounds__(256) void kuu_build_kernel(int kind, HyperView hv, int M, int Mp, int P, double jitter,
-                                                        double *A, double *Kcopy, int zt_rows) {
+                                                        double *A, double *Kcopy, int zt_rows, double *zero, int nzero) {
     extern __shared__ double zs_lds[];                    // [256][P | 1] | zi [KUU_ROWS][PM] | zzi [KUU_ROWS]
     const int dl = blockIdx.z, tid = threadIdx.x;
+    // the progress words of the dataflow Cholesky that follows on the same stream (launch_kuu_build, flow_words): one launch less
+    if (zero && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+        for (int i = tid; i < nzero; i += 256) zero[i] = 0.0;
     const int ncc = (Mp + 255) / 256;                     // column chunks per row
     const int i0 = (int)(blockIdx.x / ncc) * KUU_ROWS, j0 = (int)(blockIdx.x % ncc) * 256;
     const int j = j0 + tid;
@@ -210,15 +213,17 @@ __global__ __launch_bounds__(256) void kuu_build_kernel(int kind, HyperView hv, 
     }
 }
 void launch_kuu_build(hipStream_t stream, int kind, HyperView hv, int M, int Mp, int P, int Dl, double jitter, double *A,
-                      double *Kcopy, bool zt_rows) {
+                      double *Kcopy, bool zt_rows, double *flow_words) {
+    // (what potrf_flow_clear zeroes for Dl matrices)
+    const int nzero = flow_words ? (int)((((size_t)Dl * 64 + 4 + 3) / 4 * 4) / 2) : 0;
     const int ncc = (Mp + 255) / 256, nrg = (Mp + KUU_ROWS - 1) / KUU_ROWS;
     dim3 grid((unsigned)(ncc * nrg), 2, Dl);
     if (P <= 8)
         hipLaunchKernelGGL(kuu_build_kernel<8>, grid, dim3(256), ((size_t)256 * (P | 1) + KUU_ROWS * 9) * sizeof(double), stream, kind, hv, M,
-                           Mp, P, jitter, A, Kcopy, zt_rows ? 1 : 0);
+                           Mp, P, jitter, A, Kcopy, zt_rows ? 1 : 0, flow_words, nzero);
     else
         hipLaunchKernelGGL(kuu_build_kernel<MAXP>, grid, dim3(256), ((size_t)256 * (P | 1) + KUU_ROWS * (MAXP + 1)) * sizeof(double), stream,
-                           kind, hv, M, Mp, P, jitter, A, Kcopy, zt_rows ? 1 : 0);
+                           kind, hv, M, Mp, P, jitter, A, Kcopy, zt_rows ? 1 : 0, flow_words, nzero);
 }
 
 // out[dl][i][j] = in[dl][j][i] for Dl square Mp x Mp matrices (L^-T -> L^-1)
@@ -1147,6 +1152,7 @@ void launch_trsm_ext(hipStream_t stream, double *A, int n, int extra_rows, int b
 #define DF_MFMA_FACTOR 1
 #endif
 constexpr int DF_PS = 64;                         // progress words per matrix (main block rows: n <= 4096)
+static_assert(DF_PS == 64, "launch_kuu_build zeroes 64 progress words per matrix");
 constexpr int DF_DINV = 4 * 16 * 16;              // doubles of inverted diagonal sub-blocks per (matrix, block column)
 constexpr long long DF_SPIN_TICKS = 100000000LL;  // bound of one wait: 1 s of the 100 MHz wall clock
 
