@@ -178,7 +178,8 @@ def run_rank(args):
         sh = ShardedElbo(params, Y, c, meta, rank=rank, world=world, mode=mode, device=local_rank, collective=collective,
                          always_reduce=always, **eng_kw)
     except Exception as exc:               # noqa: BLE001 -- reported below, never swallowed
-        err = exc
+        # (only the text: the exception's traceback would pin the half-built shard; ShardedElbo closes its engine itself)
+        err = RuntimeError(f"{type(exc).__name__}: {exc}")
     exchange = None                        # what the timed step did with the 8 partial sums (config.parallelism)
     if dist is not None and not rehearsal:
         # The benchmark must say which exchange it timed.  If the library's own RCCL communicator cannot be formed on

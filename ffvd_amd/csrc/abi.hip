@@ -969,6 +969,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
     } else if (grad_ref)                  // the backward pass wants the same per-unit sum (dl/dalpha): all row sums of F^2 of a unit
         launch_sum_partials(s, h->rowsq, h->ngr * Tp, h->nbatch, h->gw.fsq);
     fa.out_terms = out_dev ? out_dev : h->out_terms;
+    fa.info = h->info; fa.ninfo = Dl + h->nbatch;       // any failed / abandoned factorisation of this rank -> NaN sums on every rank
     launch_finalize(s, fa);
     if (st) st->mark(4);
     DBG_SYNC(h, "forward: reductions + finalize");
@@ -1010,13 +1011,23 @@ static int check_info(ffvd_handle *h) {
 // inter-workgroup waits (every launch re-zeroes what it needs; the dataflow launches of later iterations clear their own words).
 // A second failure is reported as FFVD_EDEVICE.  The first recovery leaves a note for ffvd_last_error.  Collective entry points
 // (ffvd_elbo_allreduce, ffvd_*_step_allreduce, T-shards) do NOT retry: the other ranks have already moved on.
+// The override is thread-local state: it is reset on EVERY exit path of the scope that set it (an error return between
+// set and reset left the launch-per-column variant selected for every later factorisation of the thread).
+struct CholOverrideGuard {
+    bool armed = false;
+    void force_left() { potrf_override_variant(CHOL_FORCE_LEFT); armed = true; }
+    ~CholOverrideGuard() { if (armed) potrf_override_variant(CHOL_FORCE_NONE); }
+};
+
 template <class Enqueue>
 static int fetch_with_stall_recovery(ffvd_handle *h, Enqueue enqueue) {
     int rc;
     for (int attempt = 0;; ++attempt) {
-        if (attempt == 1) potrf_override_variant(CHOL_FORCE_LEFT);
-        rc = enqueue();
-        if (attempt == 1) potrf_override_variant(CHOL_FORCE_NONE);
+        {
+            CholOverrideGuard guard;
+            if (attempt == 1) guard.force_left();
+            rc = enqueue();
+        }
         if (rc) return rc;
         hipError_t e1 = hipMemcpyAsync(h->h_res, h->resblk, h->res_bytes, hipMemcpyDeviceToHost, h->stream);      // terms, chain nll, info flags
         hipError_t e2 = (e1 == hipSuccess) ? hipStreamSynchronize(h->stream) : e1;
@@ -1639,7 +1650,7 @@ static int train_fetch(ffvd_handle *h, const char *who) {
     if ((rc = check_info(h))) return rc;
     for (int i = 0; i < 8; ++i)
         if (!std::isfinite(h->h_sums[i]))
-            return set_error(h, FFVD_ENOTPD, std::string(who) + ": non-finite sums after the exchange (a factorisation failed on another rank); parameters untouched");
+            return set_error(h, FFVD_ENOTPD, std::string(who) + ": non-finite sums after the exchange (a factorisation failed or was abandoned on another rank); parameters untouched");
     return FFVD_OK;
 }
 
@@ -1894,14 +1905,16 @@ extern "C" int ffvd_op_cholesky(const double *A, int n, int batch, double *L, in
     for (int attempt = 0;; ++attempt) {
         // attempt 1 (only after the dataflow launch gave up on a bounded wait): the same batch again with the launch-per-column
         // Cholesky, which has no inter-workgroup waits (stall recovery, see fetch_with_stall_recovery)
-        if (attempt == 1) {
-            fill_pad();
-            HIP_TRY(hipMemcpyAsync(dA, pad.data(), pad.size() * sizeof(double), hipMemcpyHostToDevice, sc.stream));
-            potrf_override_variant(CHOL_FORCE_LEFT);
+        {
+            CholOverrideGuard guard;            // reset on the error returns below as well
+            if (attempt == 1) {
+                fill_pad();
+                HIP_TRY(hipMemcpyAsync(dA, pad.data(), pad.size() * sizeof(double), hipMemcpyHostToDevice, sc.stream));
+                guard.force_left();
+            }
+            HIP_TRY(hipMemsetAsync(dinfo, 0, batch * sizeof(int32_t), sc.stream));
+            launch_potrf_ext(sc.stream, dA, np, 0, 0, batch, slab, dinfo, dinv);
         }
-        HIP_TRY(hipMemsetAsync(dinfo, 0, batch * sizeof(int32_t), sc.stream));
-        launch_potrf_ext(sc.stream, dA, np, 0, 0, batch, slab, dinfo, dinv);
-        if (attempt == 1) potrf_override_variant(CHOL_FORCE_NONE);
         HIP_TRY(hipMemcpyAsync(pad.data(), dA, pad.size() * sizeof(double), hipMemcpyDeviceToHost, sc.stream));
         HIP_TRY(hipMemcpyAsync(hinfo.data(), dinfo, batch * sizeof(int32_t), hipMemcpyDeviceToHost, sc.stream));
         HIP_TRY(hipStreamSynchronize(sc.stream));
@@ -2564,6 +2577,7 @@ static int enqueue_tshard_local(ffvd_handle *h) {
     ra.xk = p.X; ra.xk_chain_stride = (size_t)(c.T + 1) * c.D; ra.xk_ld = c.D; ra.xk_cols = c.D;
     ra.rowsq = nullptr; ra.fmean = h->fmean; ra.chain_terms = h->chain_terms;
     ra.skip_x0 = c.t_begin > 0;
+    ra.info = h->info; ra.ninfo = Dl;       // a failed / abandoned K_uu chain of THIS shard turns its chain sums into NaN: they are part of the exchange
     launch_chain_reduce(s, ra, h->chain_partial);
     HIP_TRY(hipGetLastError());
     return FFVD_OK;
@@ -2594,6 +2608,7 @@ static int enqueue_tshard_finish(ffvd_handle *h) {
     fa.chain_terms = h->chain_terms; fa.hterms = h->hterms; fa.chain_nll = h->chain_nll;
     fa.route = 1; fa.kterms = h->kterms; fa.trpart = h->trpart; fa.ntiles = h->ntiles;
     fa.out_terms = h->out_terms;
+    fa.info = h->info; fa.ninfo = Dl + h->nbatch;
     launch_finalize(s, fa);
     HIP_TRY(hipGetLastError());
     return FFVD_OK;
@@ -2632,10 +2647,37 @@ extern "C" int ffvd_tshard_finish(ffvd_handle *h, double out_terms[8], double *o
     int rc;
     if ((rc = tshard_ready(h, "ffvd_tshard_finish"))) return rc;
     HIP_TRY(hipSetDevice(h->cfg.device_id));
-    if ((rc = enqueue_tshard_finish(h))) return rc;
-    HIP_TRY(hipMemcpyAsync(h->h_res, h->resblk, h->res_bytes, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    if ((rc = check_info(h))) return rc;
+    // The finish is a pure function of the exchanged buffer (read-only here) and of this rank's K_uu chain, and no collective
+    // follows inside the call: a dataflow Cholesky(A) that gave up on a bounded wait is re-run ONCE with the launch-per-column
+    // variant, like the single-rank entry points (fetch_with_stall_recovery).  A failure of the K_uu chain itself (local phase,
+    // BEFORE the exchange) has already turned the exchanged chain sums into NaN on every rank.
+    for (int attempt = 0;; ++attempt) {
+        {
+            CholOverrideGuard guard;
+            if (attempt == 1) {
+                guard.force_left();
+                HIP_TRY(hipMemsetAsync(h->info + h->Dl, 0, (size_t)h->nbatch * sizeof(int32_t), h->stream));
+            }
+            if ((rc = enqueue_tshard_finish(h))) return rc;
+        }
+        HIP_TRY(hipMemcpyAsync(h->h_res, h->resblk, h->res_bytes, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        rc = check_info(h);
+        bool kuu_ok = true;
+        for (int i = 0; i < h->Dl; ++i) kuu_ok = kuu_ok && h->h_info[i] == 0;
+        if (rc == FFVD_EDEVICE && h->stalled && kuu_ok && attempt == 0) continue;
+        if (rc == FFVD_OK && attempt == 1) {
+            if (h->stall_recoveries++ == 0)
+                h->warning = "warning: the one-launch (dataflow) Cholesky gave up on a bounded wait; the T-shard finish was re-run with "
+                             "the launch-per-column Cholesky and completed";
+            h->err = h->warning;
+        }
+        break;
+    }
+    if (rc) return rc;
+    for (int i = 0; i < 7; ++i)
+        if (!std::isfinite(h->h_out[i]))
+            return set_error(h, FFVD_ENOTPD, "ffvd_tshard_finish: non-finite sums after the exchange (a factorisation failed or was abandoned on another rank)");
     if (out_terms) memcpy(out_terms, h->h_out, 8 * sizeof(double));
     if (out_nll) *out_nll = h->h_out[FFVD_TERM_NLL] / (double)h->cfg.S_local;
     return FFVD_OK;
@@ -2807,7 +2849,7 @@ extern "C" int ffvd_elbo_allreduce(ffvd_handle *h, void *rccl_comm, double out_t
     bool finite = true;
     for (int i = 0; i < 8; ++i) finite = finite && std::isfinite(h->h_out[i]);
     if (!finite)                                      // a failed factorisation on ANOTHER rank poisons the sums with NaN
-        return set_error(h, FFVD_ENOTPD, "ffvd_elbo_allreduce: non-finite partial sums after the all-reduce (a factorisation failed on another rank)");
+        return set_error(h, FFVD_ENOTPD, "ffvd_elbo_allreduce: non-finite partial sums after the all-reduce (a factorisation failed or was abandoned on another rank)");
     if (out_terms) memcpy(out_terms, h->h_out, 8 * sizeof(double));
     if (out_nll) *out_nll = h->h_out[FFVD_TERM_NLL] / h->h_out[FFVD_TERM_COUNT];
     return FFVD_OK;

@@ -206,6 +206,8 @@ struct ReduceArgs {
     const double *rowsq, *fmean;   // [S*Dl][ng][Tp]
     double *chain_terms;           // [S][8] partial sums per chain
     int skip_x0;                   // T-shards other than the first: X[0] is not the job's x_0, leave prior_x_0 out
+    const int32_t *info;           // optional (T-shard local phase, where the chain sums are part of the exchange buffer): factorisation flags
+    int ninfo;                     //   already final on this stream; any non-zero one turns the chain sums into NaN
 };
 // partial: scratch of S * 8 * 4 doubles
 void launch_chain_reduce(hipStream_t stream, const ReduceArgs &a, double *partial);
@@ -225,6 +227,9 @@ struct FinalizeArgs {
     int fsq_from_trpart;           // route 0, fp32-contraction path: trpart[S*Dl][ntiles] = sum_t |F_t|^2 (no row sums)
     double *chain_nll;             // [S]
     double *out_terms;             // [8]
+    const int32_t *info;           // optional: the iteration's factorisation flags ([ninfo]: K_uu per local dim, then one per unit).  Any
+    int ninfo;                     //   non-zero flag (bad pivot, or -1: a dataflow launch gave up on a bounded wait and left finite garbage)
+                                   //   turns the seven sums into NaN, so that an all-reduce carries the failure to EVERY rank
 };
 void launch_finalize(hipStream_t stream, const FinalizeArgs &a);
 

@@ -2334,6 +2334,14 @@ __device__ __forceinline__ void gram_body(const GramArgs a, const int bz, const 
 // writes back the XCD L2's dirty lines, which with 135 KB per half and the chip streaming K_fu made a half last twice its time;
 // the reader's ONE acquire invalidates its CU's L1 and then loads plainly (MI355X guide, inter-workgroup visibility: sc1 payload
 // stores, every storing wavefront's vmcnt(0), the workgroup's barrier, one lane's relaxed agent-scope add).
+// TARGET-SPECIFIC hand-off: the partial block is published with relaxed agent-scope stores + s_waitcnt vmcnt(0) + barrier +
+// a relaxed fetch_add, with NO release fence (an agent-scope release writes back the XCD L2's dirty lines and doubled the time of
+// a half).  That is sound on gfx942 / gfx950 only: stores are counted in vmcnt, the atomic stores are emitted
+// with sc1 (write-through to memory-side coherence) and a CU's L1 is not shared across workgroups' hand-off.  Targets that track
+// stores in vscnt (gfx10+) or another compiler lowering of the atomic stores would break it silently -- so the build refuses them.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "gram_tail_exchange relies on gfx942/gfx950 store semantics (vmcnt-counted sc1 write-through stores); build for gfx950"
+#endif
 __device__ __forceinline__ bool gram_tail_exchange(const GramArgs &a, const int tail_id, const int half, const bool active,
                                                    d4 (&acc)[4][2], double &bs0, double &bs1, int *tail_slot) {
     typedef __attribute__((address_space(1))) double gdouble;
@@ -2851,6 +2859,9 @@ __global__ void chain_combine_kernel(ReduceArgs a, const double *partial, const 
     for (int d = 0; d < a.D; ++d) px0 += Xs[d] * Xs[d];
     double *o = a.chain_terms + (size_t)s * 8;
     o[0] = lik; o[1] = xq; o[2] = tr; o[3] = a.skip_x0 ? 0.0 : -px0 / 2.0;     // prior_x_0 dgp_model.py:252
+    bool bad = false;
+    for (int i = 0; i < a.ninfo; ++i) bad = bad || a.info[i] != 0;
+    if (bad) o[0] = o[1] = o[2] = __longlong_as_double(0x7ff8000000000000LL);
 }
 void launch_chain_reduce(hipStream_t stream, const ReduceArgs &a, double *partial) {
     const int nsplit = chain_reduce_split(a.Dl);
@@ -3164,6 +3175,14 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
         for (int i = 0; i < 7; ++i) part[i] += terms[i];
     }
     block_sum_multi_256<7>(part, reinterpret_cast<double(*)[7]>(&scratch[0][0]));
+    // A failed or abandoned factorisation of THIS rank must be visible in the sums every rank receives (ffvd_elbo_allreduce,
+    // ffvd_*_step_allreduce test them for finiteness): a bad pivot usually produces NaN by itself, an abandoned dataflow launch
+    // (info = -1) leaves finite garbage.  The reference's counterpart is the error session.run raises (dgp_model.py:320-324).
+    int bad = 0;
+    for (int i = tid; i < a.ninfo; i += 256) bad |= (a.info[i] != 0);
+    if (__syncthreads_or(bad))
+#pragma unroll
+        for (int i = 0; i < 7; ++i) part[i] = __longlong_as_double(0x7ff8000000000000LL);
 #pragma unroll
     for (int i = 0; i < 7; ++i)
         if (tid == i) a.out_terms[i] = part[i];

@@ -101,7 +101,7 @@ def all_reduce_grads(grads, mode="chains", device=None, group=None):
 _RENDEZVOUS_GENERATION = [0]      # communicators this process has formed through a rendezvous directory
 
 
-def exchange_unique_id(make_id, rank, world, rendezvous_dir=None, timeout_s=120.0, tag=None):
+def exchange_unique_id(make_id, rank, world, rendezvous_dir=None, timeout_s=120.0, tag=None, cleanup_s=None):
     """Hand rank 0's 128-byte RCCL id (ffvd_comm_unique_id) to every rank.  Host-side plumbing only:
     with `rendezvous_dir` through a file (written atomically by rank 0, polled by the others), otherwise through the
     initialised torch.distributed group (any backend; gloo in the launchers of this repo).
@@ -126,7 +126,9 @@ def exchange_unique_id(make_id, rank, world, rendezvous_dir=None, timeout_s=120.
         if tag is None:
             tag = _RENDEZVOUS_GENERATION[0]
             _RENDEZVOUS_GENERATION[0] += 1
-        path = os.path.join(rendezvous_dir, f"rccl_unique_id.{tag}")
+        nonce = os.environ.get("FFVD_RENDEZVOUS_NONCE") or os.environ.get("TORCHELASTIC_RUN_ID") or os.environ.get("MASTER_PORT") or ""
+        nonce = "".join(ch for ch in nonce if ch.isalnum() or ch in "-_")[:48]
+        path = os.path.join(rendezvous_dir, f"rccl_unique_id.{nonce + '.' if nonce else ''}{tag}")
         if rank == 0:
             blob, err = guarded()
             try:
@@ -136,6 +138,17 @@ def exchange_unique_id(make_id, rank, world, rendezvous_dir=None, timeout_s=120.
             with open(path + ".tmp", "wb") as f:
                 f.write(b"OK" + blob if err is None else b"ER" + err.encode())
             os.replace(path + ".tmp", path)
+            if cleanup_s is not None:
+                import threading
+
+                def _remove():
+                    try:
+                        os.unlink(path)
+                    except OSError:
+                        pass
+                timer = threading.Timer(float(cleanup_s), _remove)
+                timer.daemon = True
+                timer.start()
             if err is not None:
                 raise RuntimeError(f"RCCL unique id could not be created on rank 0: {err}")
             return blob
@@ -203,14 +216,18 @@ class ShardedElbo:
             self.engine.set_params(local)
         self.reduces = world > 1 or self.always_reduce or self.time_shard
         self.engine.shard_of = world          # plain ElboEngine.adam_step would train on this rank's share only
-        if self.reduces and collective == "rccl":
-            blob = exchange_unique_id(self.engine.comm_unique_id, rank, world, rendezvous_dir, tag=rendezvous_tag)
-            self.engine.comm_init(world, rank, blob)
-        elif self.reduces and not self.time_shard:
-            import torch
-            self.torch = torch
-            self.sums = torch.zeros(8, dtype=torch.float64, device=f"cuda:{device}")
-            self.ext_stream = torch.cuda.ExternalStream(self.engine.stream_handle(), device=f"cuda:{device}")
+        try:
+            if self.reduces and collective == "rccl":
+                blob = exchange_unique_id(self.engine.comm_unique_id, rank, world, rendezvous_dir, tag=rendezvous_tag)
+                self.engine.comm_init(world, rank, blob)
+            elif self.reduces and not self.time_shard:
+                import torch
+                self.torch = torch
+                self.sums = torch.zeros(8, dtype=torch.float64, device=f"cuda:{device}")
+                self.ext_stream = torch.cuda.ExternalStream(self.engine.stream_handle(), device=f"cuda:{device}")
+        except BaseException:
+            self.engine.close()           # a half-built shard must not keep its (multi-GB) workspaces alive through a traceback
+            raise
 
     def close(self):
         self.engine.close()
@@ -305,7 +322,11 @@ class ShardedElbo:
             raise ValueError("T-shard handles have no backward pass")
         S = self.meta["S"]
         if not self.reduces:
-            return self.engine.sghmc_step(noise, epsilon, mdecay, burn_in)
+            self.engine.shard_of = 1
+            try:
+                return self.engine.sghmc_step(noise, epsilon, mdecay, burn_in)
+            finally:
+                self.engine.shard_of = self.world
         if self.collective == "rccl":
             return finish(self.engine.sghmc_step_allreduce(S, noise, epsilon, mdecay, burn_in))
         block = self._host_reduce(self.engine.train_local(S))

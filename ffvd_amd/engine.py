@@ -207,6 +207,8 @@ class ElboEngine:
     def sghmc_step(self, noise, epsilon=0.01, mdecay=0.05, burn_in=True):
         """One burn_in_op / sample_op (base_model.py:143-179) on the device for the arrays that are keys of `noise`
         (name -> standard-normal array of the parameter's shape).  Returns the nll terms before the update."""
+        if getattr(self, "shard_of", 1) > 1:
+            raise ValueError("sghmc_step: this engine holds one shard of a multi-rank job; use ShardedElbo.sghmc_step")
         if not self.grad:
             raise ValueError("engine was created without grad=True")
         shapes = {"Z": (self.M, self.P), "logvariance": (self.D,), "loglengthscales": (self.D, self.P),

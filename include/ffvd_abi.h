@@ -125,7 +125,10 @@ int  ffvd_sync(ffvd_handle *h);
 /* How often a synchronous call on this handle (ffvd_elbo, ffvd_elbo_grad, ffvd_adam_step, ffvd_sghmc_step) re-ran its iteration
  * because the one-launch Cholesky gave up on a bounded wait (info = -1): the iteration is then enqueued once more, in process,
  * with the launch-per-column Cholesky, the call returns FFVD_OK and ffvd_last_error holds a warning; only a second failure is
- * FFVD_EDEVICE.  Collective calls do not retry (the other ranks have moved on). */
+ * FFVD_EDEVICE.  Collective calls do not retry (the other ranks have moved on); instead the failure is made COLLECTIVE: the
+ * finalize kernel turns the rank's seven partial sums into NaN whenever one of its factorisation flags is non-zero (bad pivot or
+ * abandoned launch), so after the all-reduce EVERY rank sees non-finite sums, returns an error (FFVD_EDEVICE on the rank that
+ * stalled, FFVD_ENOTPD elsewhere) and leaves its parameters untouched.  ffvd_tshard_finish (no collective after it) retries. */
 int  ffvd_stall_recoveries(const ffvd_handle *h);
 /* bytes of device workspace owned by the handle */
 int64_t ffvd_workspace_bytes(const ffvd_handle *h);

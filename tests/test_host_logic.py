@@ -260,9 +260,14 @@ def test_gloo_world2_failed_unique_id_reaches_every_rank(tmp_path):
     assert "OK" in outs[0] and "OK" in outs[1]
 
 
-def test_file_rendezvous_ignores_stale_ids_and_forwards_failures(tmp_path):
+def test_file_rendezvous_ignores_stale_ids_and_forwards_failures(tmp_path, monkeypatch):
     """File rendezvous of the RCCL id: the file name carries a tag (generation), a stale file of another tag is never read,
-    and a failure on rank 0 is written into the file so that the polling ranks raise instead of timing out."""
+    and a failure on rank 0 is written into the file so that the polling ranks raise instead of timing out.  With a per-job
+    nonce in the environment (launcher run id / MASTER_PORT) the id an EARLIER job left under the same tag is never read
+    either, and rank 0 can remove its file once the ranks have had time to read it."""
+    import time
+    for k in ("FFVD_RENDEZVOUS_NONCE", "TORCHELASTIC_RUN_ID", "MASTER_PORT"):
+        monkeypatch.delenv(k, raising=False)
     d = str(tmp_path)
     with open(os.path.join(d, "rccl_unique_id"), "wb") as f:        # left behind by an older run / the old file name
         f.write(b"stale")
@@ -284,6 +289,16 @@ def test_file_rendezvous_ignores_stale_ids_and_forwards_failures(tmp_path):
     g0 = dist_mod._RENDEZVOUS_GENERATION[0]
     dist_mod.exchange_unique_id(lambda: good, 0, 2, rendezvous_dir=d)
     assert os.path.exists(os.path.join(d, f"rccl_unique_id.{g0}")) and dist_mod._RENDEZVOUS_GENERATION[0] == g0 + 1
+    # a second job in the same directory, same tag: its nonce keeps it away from the first job's file
+    monkeypatch.setenv("MASTER_PORT", "29777")
+    other = bytes(reversed(range(128)))
+    with pytest.raises(TimeoutError):
+        dist_mod.exchange_unique_id(None, 1, 2, rendezvous_dir=d, tag="run7", timeout_s=0.05)      # job 1's "run7" is not job 2's
+    assert dist_mod.exchange_unique_id(lambda: other, 0, 2, rendezvous_dir=d, tag="run7", cleanup_s=0.2) == other
+    assert dist_mod.exchange_unique_id(None, 1, 2, rendezvous_dir=d, tag="run7") == other
+    assert os.path.exists(os.path.join(d, "rccl_unique_id.29777.run7"))
+    time.sleep(0.6)
+    assert not os.path.exists(os.path.join(d, "rccl_unique_id.29777.run7"))                          # removed by rank 0's timer
 
 
 ADAM_WORKER = r'''
