@@ -1067,7 +1067,7 @@ for what in ("step", "adam"):
             sh.adam_step(1e-2)
         out.append("OK")
     except Exception as exc:                     # noqa: BLE001 -- the test asserts on the type and text
-        out.append(type(exc).__name__ + ":" + str(exc).replace(" ", "_")[:120])
+        out.append(type(exc).__name__ + ":" + str(exc).replace(" ", "_")[:240])
 after = sh.engine.get_params()
 same = all(np.array_equal(before[k], after[k]) for k in before)
 digest = float(sum(np.abs(after[k]).sum() for k in ("Z", "logvariance", "loglengthscales", "log_Q")))
