@@ -86,6 +86,7 @@ _SIGNATURES = {
     "ffvd_sghmc_apply": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_uint32, C.c_int, C.c_void_p, _dp,
                                    C.POINTER(C.c_double)]),
     "ffvd_stall_recoveries": (C.c_int, [C.c_void_p]),
+    "ffvd_single_launch": (C.c_int, [C.c_void_p]),
     "ffvd_get_stream": (C.c_void_p, [C.c_void_p]),
     "ffvd_optimizer_reset": (C.c_int, [C.c_void_p]),
     "ffvd_update_params": (C.c_int, [C.c_void_p, C.c_void_p]),

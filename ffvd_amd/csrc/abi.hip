@@ -5,6 +5,7 @@
 #include "kernels_f32.h"
 #include "grad.h"
 #include "optim.h"
+#include "tiny.h"
 
 #include <algorithm>
 #include <cmath>
@@ -58,6 +59,7 @@ struct ffvd_handle {
         bool lt_armed = false;            // FFVD_GRAD_LT_ARMED=1: write the L^T rows to memory (launch_set_lt_rows) even where the dataflow kernel could read L itself
         bool whiten_products = false;     // FFVD_GRAD_WHITEN_PRODUCTS=1: training forward forms H = W^T A W with two products (round 1/2) instead of arming L^T rows
         bool debug_sync = false;    // FFVD_DEBUG_SYNC: name every launch group on stderr and wait for it (locates a faulting kernel)
+        bool no_tiny = false;       // FFVD_NO_TINY=1: the multi-kernel schedule also at the reference's own experiment size (rounds 1-3)
     } sw;
     // resident parameters / data (handle-owned copies)
     double *X = nullptr, *Z = nullptr, *U = nullptr, *logvar = nullptr, *loglen = nullptr, *logQ = nullptr;
@@ -71,6 +73,11 @@ struct ffvd_handle {
     double *stage = nullptr;    // staging buffer of ffvd_allreduce_sum
     int64_t stage_count = 0;
     bool kuu_flow_sched = false;   // schedule of the big unsplit Gram pass, decided in ffvd_create (see there)
+    // one-launch iteration of the reference's own experiment size (tiny.hip): decided once in ffvd_create
+    TinyPlan tiny{};
+    double *tiny_scratch = nullptr;
+    int *tiny_flags = nullptr;
+    bool tiny_dirty = false;       // a launch was abandoned on a bounded wait: its hand-off words are re-zeroed before the next one
     bool info_pending = false;  // an ffvd_elbo_async was enqueued whose Cholesky info flags nobody has looked at yet
     // workspace
     double *variance = nullptr, *len = nullptr, *Zs = nullptr, *zz = nullptr;
@@ -198,6 +205,7 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
         w.kuu_flow = !on("FFVD_NO_KUU_FLOW");   w.kinv_gram = on("FFVD_KINV_GRAM");   w.chain_rl = on("FFVD_CHAIN_RL");
         w.atb128 = on("FFVD_ATB128");                 w.grad_serial = on("FFVD_GRAD_SERIAL");
         w.debug_sync = on("FFVD_DEBUG_SYNC");
+        w.no_tiny = on("FFVD_NO_TINY");
     }
     h->P = c.D + c.C;
     h->Dl = c.d_count > 0 ? c.d_count : c.D;
@@ -395,6 +403,19 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
     }
     if (c.branch == FFVD_BRANCH_A && !c.grad && !h->sw.no_linear_lowrank && linear_lowrank_supported(c.kernel_kind, P))
         HIP_TRY(dev_alloc(h, &h->lrpart, linear_lowrank_doubles((int)Mp, (int)Dl, P)));
+    if (c.branch == FFVD_BRANCH_B && c.dtype == FFVD_F64 && c.T_total == 0 && !h->sw.no_tiny) {
+        // The whole iteration as ONE launch when every role's workgroup fits on the chip at once (tiny.hip).  The multi-kernel
+        // workspaces above stay: a launch abandoned on a bounded wait is re-run on them (fetch_with_stall_recovery).
+        int cus = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, c.device_id) == hipSuccess) cus = prop.multiProcessorCount;
+        h->tiny = tiny_plan(c.kernel_kind, c.T, c.D, c.C, c.M, c.S_local, (int)Dl, c.grad, cus);
+        if (h->tiny.ok) {
+            HIP_TRY(dev_alloc(h, &h->tiny_scratch, tiny_scratch_doubles(h->tiny, c.T, (int)P, c.M, c.S_local, (int)Dl, c.D, c.Ydim, c.grad)));
+            HIP_TRY(dev_alloc(h, &h->tiny_flags, tiny_flag_ints(h->tiny, c.S_local)));
+            HIP_TRY(hipMemsetAsync(h->tiny_flags, 0, tiny_flag_ints(h->tiny, c.S_local) * sizeof(int), h->stream));
+        }
+    }
     HIP_TRY(dev_alloc(h, &h->dinvK, potrf_scratch_doubles((int)Mp, (int)Dl)));
     HIP_TRY(dev_alloc(h, &h->dinvH, potrf_scratch_doubles((int)Mp, h->nbatch ? h->nbatch : 1)));
     HIP_TRY(hipMemsetAsync(h->U, 0, (size_t)(c.M * c.D ? c.M * c.D : 1) * sizeof(double), h->stream));
@@ -561,7 +582,40 @@ struct StageTimer {
     }
 };
 
+// The iteration (with_grad: and its backward pass, gradients scaled by 1 / S_total into the arrays of gw) as ONE launch: tiny.hip.
+static bool tiny_selected(const ffvd_handle *h) { return h->tiny.ok && potrf_override_current() == CHOL_FORCE_NONE; }
+static int enqueue_tiny(ffvd_handle *h, double *out_dev, StageTimer *st, bool with_grad, int S_total) {
+    StageTimer live{h};
+    if (!st && h->timing_on) st = &live;
+    const ffvd_config &c = h->cfg;
+    const ffvd_params &p = h->cur;
+    hipStream_t s = h->stream;
+    if (st) st->mark(-1);
+    if (h->tiny_dirty) {
+        HIP_TRY(hipMemsetAsync(h->tiny_flags, 0, tiny_flag_ints(h->tiny, c.S_local) * sizeof(int), s));
+        h->tiny_dirty = false;
+    }
+    TinyArgs a{};
+    a.kind = c.kernel_kind; a.T = c.T; a.D = c.D; a.C = c.C; a.P = h->P; a.M = c.M; a.Dl = h->Dl; a.d_begin = c.d_begin;
+    a.S = c.S_local; a.Ydim = c.Ydim; a.prior_type = c.prior_type; a.shared_terms = c.shared_terms;
+    a.grad = with_grad ? 1 : 0; a.S_total = S_total; a.jitter = c.jitter;
+    a.X = p.X; a.Z = p.Z; a.logvar = p.logvariance; a.loglen = p.loglengthscales; a.log_Q = p.log_Q; a.CC = p.CC; a.DD = p.DD;
+    a.logR = p.log_Rchols; a.Y = h->Y; a.ctrl = h->ctrl;
+    tiny_bind_scratch(a, h->tiny, h->tiny_scratch, h->tiny_flags);
+    a.info = h->info; a.chain_nll = h->chain_nll; a.out_terms = out_dev ? out_dev : h->out_terms;
+    if (with_grad) {
+        const ffvd_handle::GradWs &g = h->gw;
+        a.dX = g.dX; a.dZ = g.dZ; a.dlogvar = g.dlogvar; a.dloglen = g.dloglen; a.dlogQ = g.dlogQ; a.dCC = g.dCC; a.dDD = g.dDD;
+        a.dlogR = g.dlogR;
+    }
+    HIP_TRY(launch_tiny(s, a, h->tiny));
+    if (st) { st->mark(2); st->mark(4); }
+    DBG_SYNC(h, with_grad ? "one-launch iteration + backward pass" : "one-launch iteration");
+    return FFVD_OK;
+}
+
 static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
+    if (tiny_selected(h)) return enqueue_tiny(h, out_dev, st, false, h->cfg.S_local);
     StageTimer live{h};
     if (!st && h->timing_on) st = &live;
     const ffvd_config &c = h->cfg;
@@ -987,8 +1041,9 @@ static int check_info(ffvd_handle *h) {
     const int Dl = h->Dl;
     h->stalled = false;
     for (int i = 0; i < Dl + h->nbatch; ++i) {
-        if (h->h_info[i] < 0) {        // the dataflow Cholesky bounds every wait (kernels.hip, potrf_df_kernel)
+        if (h->h_info[i] < 0) {        // the dataflow Cholesky bounds every wait (kernels.hip, potrf_df_kernel); so does tiny.hip
             h->stalled = true;
+            h->tiny_dirty = true;
             return set_error(h, FFVD_EDEVICE, "blocked Cholesky abandoned: a block row waited more than 1 s for the row above it");
         }
         if (h->h_info[i] != 0) {
@@ -1044,6 +1099,8 @@ static int fetch_with_stall_recovery(ffvd_handle *h, Enqueue enqueue) {
 }
 
 extern "C" int ffvd_stall_recoveries(const ffvd_handle *h) { return h ? h->stall_recoveries : 0; }
+
+extern "C" int ffvd_single_launch(const ffvd_handle *h) { return (h && h->tiny.ok) ? h->tiny.nw : 0; }
 
 extern "C" int ffvd_elbo(ffvd_handle *h, const ffvd_params *p, uint32_t flags, double out_terms[8], double *out_nll) {
     if (!h) return set_error(nullptr, FFVD_EINVAL, "ffvd_elbo: null handle");
@@ -1446,6 +1503,12 @@ static int enqueue_grad_b(ffvd_handle *h, int S_total) {
 static int enqueue_grad(ffvd_handle *h, int S_total) {
     return h->cfg.branch == FFVD_BRANCH_A ? enqueue_grad_a(h, S_total) : enqueue_grad_b(h, S_total);
 }
+// forward + backward pass of one training iteration: ONE launch where the handle has the small-problem plan (tiny.hip)
+static int enqueue_forward_backward(ffvd_handle *h, int S_total) {
+    if (h->cfg.grad && tiny_selected(h)) return enqueue_tiny(h, nullptr, nullptr, true, S_total);
+    const int r = enqueue_elbo(h, nullptr, nullptr);
+    return r ? r : enqueue_grad(h, S_total);
+}
 
 extern "C" int ffvd_elbo_grad(ffvd_handle *h, const ffvd_params *p, uint32_t flags, int S_total, double out_terms[8],
                               double *out_nll, const ffvd_grads *gout) {
@@ -1465,7 +1528,7 @@ extern "C" int ffvd_elbo_grad(ffvd_handle *h, const ffvd_params *p, uint32_t fla
         } else if ((rc = ffvd_set_params(h, p, 0))) return rc;
     }
     if ((rc = ready(h, "ffvd_elbo_grad"))) return rc;
-    if ((rc = fetch_with_stall_recovery(h, [&] { int r = enqueue_elbo(h, nullptr, nullptr); return r ? r : enqueue_grad(h, S_total); })))
+    if ((rc = fetch_with_stall_recovery(h, [&] { return enqueue_forward_backward(h, S_total); })))
         return rc;
     const ffvd_config &c = h->cfg;
     ffvd_handle::GradWs &g = h->gw;
@@ -1542,7 +1605,7 @@ extern "C" int ffvd_adam_step(ffvd_handle *h, double lr, double beta1, double be
     if ((rc = ready(h, "ffvd_adam_step"))) return rc;
     if (!h->adam_ready && (rc = ffvd_optimizer_reset(h))) return rc;
     // (a failed factorisation leaves the parameters untouched)
-    if ((rc = fetch_with_stall_recovery(h, [&] { int r = enqueue_elbo(h, nullptr, nullptr); return r ? r : enqueue_grad(h, h->cfg.S_local); })))
+    if ((rc = fetch_with_stall_recovery(h, [&] { return enqueue_forward_backward(h, h->cfg.S_local); })))
         return rc;
     if ((rc = adam_update(h, lr, beta1, beta2, eps, train_mask))) return rc;
     if (out_terms) memcpy(out_terms, h->h_out, 8 * sizeof(double));
@@ -1606,7 +1669,7 @@ extern "C" int ffvd_sghmc_step(ffvd_handle *h, double epsilon, double mdecay, ui
     int rc;
     if ((rc = ready(h, "ffvd_sghmc_step"))) return rc;
     if ((rc = sghmc_prepare(h, sample_mask, noise, "ffvd_sghmc_step"))) return rc;
-    if ((rc = fetch_with_stall_recovery(h, [&] { int r = enqueue_elbo(h, nullptr, nullptr); return r ? r : enqueue_grad(h, h->cfg.S_local); })))
+    if ((rc = fetch_with_stall_recovery(h, [&] { return enqueue_forward_backward(h, h->cfg.S_local); })))
         return rc;
     if ((rc = sghmc_update(h, epsilon, mdecay, sample_mask, burn_in))) return rc;
     if (out_terms) memcpy(out_terms, h->h_out, 8 * sizeof(double));
@@ -1626,8 +1689,7 @@ static int train_local(ffvd_handle *h, int S_total, const char *who) {
     int rc;
     if ((rc = ready(h, who))) return rc;
     h->train_S_total = 0;
-    if ((rc = enqueue_elbo(h, nullptr, nullptr))) return rc;
-    if ((rc = enqueue_grad(h, S_total))) return rc;
+    if ((rc = enqueue_forward_backward(h, S_total))) return rc;
     HIP_TRY(hipMemcpyAsync(h->gw.pack, h->out_terms, 8 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     h->train_S_total = S_total;
     return FFVD_OK;

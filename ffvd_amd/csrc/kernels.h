@@ -62,6 +62,7 @@ enum { CHOL_AUTO = 0, CHOL_FLOW = 3 };
 // block column, 2 = right-looking launches (neither has inter-workgroup waits); used to re-run a batch whose dataflow launch gave up
 enum { CHOL_FORCE_NONE = 0, CHOL_FORCE_LEFT = 1, CHOL_FORCE_RIGHT = 2 };
 void potrf_override_variant(int variant);
+int potrf_override_current();
 size_t potrf_scratch_doubles(int n, int batch);
 // linv_t (optional, honoured by the dataflow variant only -- ask potrf_flow_selected): the identity-structured extra rows
 // are ALSO written transposed, L^-1 as an n x n lower-triangular matrix (ld n) per slab of linv_t_stride doubles; the blocks

@@ -1,0 +1,55 @@
+// The whole ELBO iteration of the reference's own experiment size -- and its backward pass -- as ONE launch
+// (FFVD_Main.py:356-369: T <= 512, M = 100, D = 4; 4000 outer iterations of models.py:142-182, each 1 or 22 evaluations of
+// nll and its gradient, base_model.py:915-950).  See tiny.hip for the design; abi.hip decides per handle (tiny_plan).
+#pragma once
+#include "kernels.h"
+
+namespace ffvd {
+
+constexpr int TINY_MPMAX = 128;     // inducing points, padded to 16 (not 64: this path has no 64-blocked kernel)
+constexpr int TINY_PMAX = 8;        // GP input dimension D + C (all six reference datasets: 5)
+constexpr int TINY_TMAX = 2048;     // transitions
+
+struct TinyArgs {
+    int kind, T, D, C, P, M, Mp, NT, Dl, d_begin, S, Ydim;
+    int SR, nstrips, nunits;        // rows per strip workgroup (16 per wavefront), strips per unit, units = S * Dl
+    int prior_type, shared_terms, grad, S_total;
+    double jitter;
+    const double *X, *Z, *logvar, *loglen, *log_Q, *CC, *DD, *logR, *Y, *ctrl;
+    // scratch (tiny_scratch_doubles; all of it is rewritten by every launch)
+    double *Wg, *Wt;                // [nunits][Mp*Mp]  W = L^-T (upper block triangle) and its transpose L^-1
+    double *Pp;                     // [nunits][nstrips][pstride]  per-strip F^T F tiles, F^T delta, chain-term partials
+    double *Hs, *Nw, *Nm2;          // [nunits][Mp*Mp]  backward: H - I, N = I - H^-1 - w w^T, N - (H - I)
+    double *wv;                     // [nunits][Mp]     backward: w = H^-1 b
+    double *hterms;                 // [nunits][2]      log|H|, b^T H^-1 b   (FinalizeArgs::hterms)
+    double *uterms;                 // [nunits][8]      backward scalars of a unit: 0 dl/dalpha
+    double *Qp;                     // [nunits][nstrips][qstride]  backward: per-strip column sums / E^T x / r x^2 partials
+    double *dxc;                    // [nunits][Tp][P + 1]  backward: rows of dl/dx_comb (p < P) and dl/ddelta (slot P)
+    double *dz2;                    // [nunits][Mp][TINY_PMAX] K_uu side: rows of dl/dZ;  kuu_part [nunits][NT][TINY_PMAX + 1]
+    double *kuu_part;
+    double *unit_out;               // [nunits][M*P + P + 2]  per-unit totals: dl/dZ, dl/dloglen, dl/dlogvar-part
+    double *chain_terms;            // [S][8]
+    double *chain_part;             // [S][sp_stride]  backward: dCC, dDD, dlog_Rchols row 0, transition part of dlog_Q per local dim
+    int sp_stride;
+    int *flags;                     // [nunits*4 + S + 8] hand-off words, all zero between launches (the last workgroup re-arms them)
+    int32_t *info;                  // [Dl + nunits]
+    double *chain_nll, *out_terms;
+    double *dX, *dZ, *dlogvar, *dloglen, *dlogQ, *dCC, *dDD, *dlogR;   // backward outputs (layout of ffvd_grads)
+};
+
+struct TinyPlan {
+    bool ok;
+    int nw;             // wavefronts per workgroup: 4 (64-row strips) or 8 (128-row strips)
+    int Mp, NT, SR, nstrips, nunits;
+    size_t lds_bytes;
+};
+// Can this shape run as one launch on a chip with `cus` compute units?  (Every workgroup must be resident at once: the roles wait
+// for each other.)
+TinyPlan tiny_plan(int kind, int T, int D, int C, int M, int S, int Dl, int grad, int cus);
+size_t tiny_scratch_doubles(const TinyPlan &pl, int T, int P, int M, int S, int Dl, int D, int Ydim, int grad);
+size_t tiny_flag_ints(const TinyPlan &pl, int S);
+// carve `scratch` / `flags` into the pointers of `a` (shapes already filled in)
+void tiny_bind_scratch(TinyArgs &a, const TinyPlan &pl, double *scratch, int *flags);
+hipError_t launch_tiny(hipStream_t stream, const TinyArgs &a, const TinyPlan &pl);
+
+}  // namespace ffvd

@@ -1,0 +1,1114 @@
+// ONE launch for the whole ELBO iteration -- and, with grad, its backward pass -- at the reference's own experiment size
+// (FFVD_Main.py:356-369: T <= 512, M = 100, D = 4 latent dims, 1-10 chains; models.py:142-182 runs 4000 outer iterations,
+// each 1 or 22 evaluations of nll and its gradient).  At that size the multi-kernel schedule of abi.hip is a chain of 17 (53
+// with the backward pass) dependent launches of 4-20 us each on two streams; nothing in it is bound by the hardware.
+//
+// Arithmetic: the reference's own op order for the collapsed branch (conditionals_multi_output.py:124-169, :230-257):
+//   L = chol(K(Z,Z) + jitter I),  W = L^-T,  F = K(x_comb, Z) W,  H = I + F^T F / Q,  b = delta^T F / Q,
+//   -1/2 log|H|,  1/2 b H^-1 b^T,  -1/2 sum_t (sigma^2 - |F_t|^2) / Q        (H has condition ~1e4; nothing is formed in the
+//   K_uu + K_uf K_fu / Q variables of the big-batch Gram route), likelihood / transition / prior terms as in dgp_model.py:248-288.
+// Backward pass: the closed form of oracle/ffvd_grad_oracle.py (whitened variables), arranged as in tools/tiny_proto.py.
+//
+// Roles (one workgroup each, ALL resident at once -- tiny_plan checks that they fit; hand-offs through agent-scope flags exactly as
+// in the dataflow Cholesky of kernels.hip: plain stores -> every wavefront's s_waitcnt vmcnt(0) -> barrier -> one lane's release +
+// flag store; one lane polls -> acquire -> barrier -> plain loads; every wait is bounded by the wall clock):
+//   head(u), one per (chain, latent dim) unit, blockIdx < nunits (dispatched first; a head never waits before it has published W):
+//     K_uu in LDS -> blocked Cholesky (16 x 16 tiles: the 16-pivot chains on ONE wavefront, everything else on the matrix cores
+//     of the others, L^-T riding along as identity-structured extension tiles) -> W, W^T to L2 -> flag W
+//     ... waits for its strips ... H = I + alpha sum_strips F^T F -> the same factorisation -> log|H|, |L_H^-1 b|^2
+//     (grad: H^-1, w = H^-1 b, N = I - H^-1 - w w^T, N - (H - I) -> L2 -> flag N).
+//   strip(u, i), 16 rows per wavefront: K_fu rows generated into registers (MFMA accumulator layout) and LDS while the head
+//     factorises -> wait W -> F = K W on the matrix cores -> row sums of F^2, F^T F tiles, F^T delta, chain-term partials -> count
+//     (grad: wait N -> R = F N + delta w^T -> dl/dK_fu = alpha R W^T -> E = dl/dK_fu o K_fu in registers -> row sums, E Z, column
+//     sums, E^T x as MFMA products against [1 | Z] and [1 | x] -> rows of dl/dX, partials of dl/dZ, dl/dloglen, dl/dlogvar; and one
+//     16-row block of the K_uu side, Psi = 1/2 W (N - (H - I)) W^T o K_uu, per strip -> count).
+//   closers: the workgroup that completes a unit adds its strips' partials; the one that completes a chain forms the chain's
+//     terms (and dl/dX, the likelihood gradients); the one that completes the launch runs the nll assembly (finalize_body, the
+//     code of finalize_kernel), the shared-parameter gradients, and re-arms the flags.  Fixed summation orders: results do not
+//     depend on which workgroup closes.
+#include "tiny.h"
+#include "dev_common.h"
+
+namespace ffvd {
+
+constexpr int TNT = TINY_MPMAX / 16;            // tile columns at most
+constexpr int TPP = TINY_PMAX;                  // GP input dimension at most
+constexpr long long TINY_SPIN_TICKS = 100000000LL;   // 1 s of the 100 MHz wall clock
+
+// ---- LDS layout (doubles), shared by host and device ----------------------------------------------------------------------
+struct TinyLds {
+    int ctl, red, vec, mat, dinv, sc, xo, zo, misc, total;
+};
+// ctl / red / vec / mat are common to both roles; behind them the head keeps (dinv, sc) and a strip (xo, zo, misc) in the SAME
+// space: a workgroup is one or the other (and a closer uses the common part only).
+__host__ __device__ inline TinyLds tiny_lds(int Mp, int SR) {
+    TinyLds l;
+    const int LD = Mp + 1, NT = Mp / 16;
+    int o = 0;
+    l.ctl = o;  o += 8;                         // ints: wait slot, arrive slot
+    l.red = o;  o += 8 * 24;                    // reduction scratch [<= 8 wavefronts][<= 24 values]
+    l.vec = o;  o += 4 * Mp;                    // head: b, y, w;  strip: w;  closer: column sums
+    l.mat = o;                                  // head: the matrix being factorised [Mp][LD];  strip: K_fu / F / R / E rows [SR][LD]
+    int oh = o + Mp * LD;
+    l.dinv = oh; oh += (NT * 16 * 17 > Mp * 9) ? NT * 16 * 17 : Mp * 9;     // head: inverted diagonal tiles W(s,s); (K_uu build: Z / l and |.|^2)
+    l.sc = oh;   oh += 16 * 17;                 // head: the diagonal tile handed to the pivot chain
+    int os = o + SR * LD;
+    l.xo = os;   os += SR * 16;                 // strip: x / l rows + |.|^2 (K build), later [1 | x_comb] rows
+    l.zo = os;   os += Mp * 16;                 // strip: Z / l rows + |.|^2 (K build), later [1 | Z] rows
+    l.misc = os; os += 4 * SR + 64;             // strip: delta, per-row values
+    l.total = oh > os ? oh : os;
+    return l;
+}
+
+__host__ __device__ inline int tiny_ntl(int NT) { return NT * (NT + 1) / 2; }
+__host__ __device__ inline int tiny_pstride(int Mp) { return tiny_ntl(Mp / 16) * 256 + Mp + 8; }
+__host__ __device__ inline int tiny_qstride(int Mp) { return 16 * Mp + 16; }
+
+// ---- hand-offs --------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int tiny_wait(int *flag, int need, int *abort_w, int *slot) {
+    if (threadIdx.x == 0) {
+        int v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v < need) {
+            const long long t0 = wall_clock64();
+            for (;;) {
+                __builtin_amdgcn_s_sleep(1);
+                v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v >= need) break;
+                if (__hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { v = -1; break; }
+                if (wall_clock64() - t0 > TINY_SPIN_TICKS) {
+                    __hip_atomic_store(abort_w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    v = -1;
+                    break;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        *slot = v;
+    }
+    __syncthreads();
+    const int v = *slot;
+    __syncthreads();
+    return v;
+}
+// every thread's stores are in memory; then ONE lane releases and sets the flag
+__device__ __forceinline__ void tiny_publish(int *flag, int value) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// ... or counts in; returns how many had arrived before (the same value in every thread).  The arrival that completes a count
+// has acquired everything the others released.
+__device__ __forceinline__ int tiny_arrive(int *cnt, int *slot) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int seen = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        *slot = seen;
+    }
+    __syncthreads();
+    const int v = *slot;
+    __syncthreads();
+    return v;
+}
+
+// fixed-order sums of N values over the workgroup (NW wavefronts)
+template <int N, int NW>
+__device__ __forceinline__ void tiny_sum(double (&v)[N], double *red) {
+    block_sum_multi<N, NW>(v, reinterpret_cast<double(*)[N]>(red));
+    __syncthreads();
+}
+
+// ---- blocked Cholesky of an n x n matrix in LDS (n = 16 NT), with L^-T -----------------------------------------------------
+// 16-pivot chain on the tile in Sc (lower triangle valid): lanes 0-15 carry its rows, lanes 16-31 the rows of the identity through
+// the same column operations -- they come out as L_ss^-T (kernels.hip, chol64_mfma_1w).  Writes L_ss (zeros above the diagonal)
+// into the diagonal tile of Am and L_ss^-T into Dv.  Returns 0 or 1 + the first non-positive pivot of the tile.
+__device__ __forceinline__ int tiny_chain16(const double (*Sc)[17], double *Am, const int LD, const int s0, double (*Dv)[17], const int lane) {
+    const int lr = lane & 15;
+    int bad = 0;
+    double a[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) a[c] = (lane < 16) ? Sc[lr][c] : ((lane < 32 && lr == c) ? 1.0 : 0.0);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const double ajj = readlane_f64(a[j], j);
+        if (!(ajj > 0.0) && bad == 0) bad = j + 1;
+        double piv, y;
+        pivot_sqrt(ajj, piv, y);
+        a[j] *= y;
+#pragma unroll
+        for (int c = j + 1; c < 16; ++c) a[c] = fma(-a[j], readlane_f64(a[j], c), a[c]);
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) Am[(size_t)(s0 + lr) * LD + s0 + c] = (c <= lr) ? a[c] : 0.0;
+    } else if (lane < 32) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) Dv[lr][c] = a[c];
+    }
+    return bad;
+}
+
+// S = A(s,s) - sum_{k<s} L(s,k) L(s,k)^T into Sc (one wavefront)
+__device__ __forceinline__ void tiny_diag_gather(const double *Am, const int LD, const int s, double (*Sc)[17], const int lane) {
+    const int lr = lane & 15, lk = lane >> 4, s0 = 16 * s;
+    d4 a0 = (d4){0.0, 0.0, 0.0, 0.0}, a1 = a0;
+    for (int k = 0; k < s; ++k) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const double v = Am[(size_t)(s0 + lr) * LD + 16 * k + 4 * t + lk];
+            if (t & 1) a1 = mfma_f64(v, v, a1);
+            else a0 = mfma_f64(v, v, a0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Sc[lk + 4 * r][lr] = Am[(size_t)(s0 + lk + 4 * r) * LD + s0 + lr] - (a0[r] + a1[r]);
+}
+
+// One 16 x 16 tile of block column s (one wavefront): X = (T - sum_{k0<=k<s} Xrow(k) L(s,k)^T) L_ss^-T, in place.
+//   main row block rb > s:  T = A(rb,s), k from 0;      extension row block e = rb < s (identity-structured: it becomes
+//   W(e,s) = (L^-T)(e,s)):  T = 0, k from e, and the k = e term reads W(e,e) = Dinv[e].
+// The products run transposed in the accumulator layout, which is the B-operand layout of the next product (potrf_panel_kernel);
+// one residual refinement step against L_ss restores substitution accuracy.
+__device__ __forceinline__ void tiny_tile_solve(double *Am, const int LD, double (*Dinv)[16][17], const int s, const int rb, const bool ext,
+                                                const int lane) {
+    const int lr = lane & 15, lk = lane >> 4, s0 = 16 * s, r0 = 16 * rb;
+    d4 a0 = (d4){0.0, 0.0, 0.0, 0.0}, a1 = a0;
+    for (int k = ext ? rb : 0; k < s; ++k) {
+        const bool dk = ext && k == rb;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const double av = Am[(size_t)(s0 + lr) * LD + 16 * k + 4 * t + lk];
+            const double bv = dk ? Dinv[rb][lr][4 * t + lk] : Am[(size_t)(r0 + lr) * LD + 16 * k + 4 * t + lk];
+            if (t & 1) a1 = mfma_f64(av, bv, a1);
+            else a0 = mfma_f64(av, bv, a0);
+        }
+    }
+    d4 Rt;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Rt[r] = (ext ? 0.0 : Am[(size_t)(r0 + lr) * LD + s0 + lk + 4 * r]) - (a0[r] + a1[r]);
+    d4 x = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) x = mfma_f64(Dinv[s][lk + 4 * t][lr], Rt[t], x);
+    d4 res = Rt;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) res = mfma_f64(-Am[(size_t)(s0 + lr) * LD + s0 + 4 * t + lk], x[t], res);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) x = mfma_f64(Dinv[s][lk + 4 * t][lr], res[t], x);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Am[(size_t)(r0 + lr) * LD + s0 + lk + 4 * r] = x[r];
+}
+
+// In: lower triangle of Am.  Out: lower triangle = L (diagonal tiles with zeros above the diagonal), tiles above the diagonal =
+// W = L^-T, Dinv[s] = W(s,s).  Left-looking by tile column; wavefront 0 owns the critical path (tile (s+1,s), then the gather and
+// the 16-pivot chain of diagonal tile s+1), the others solve the remaining tiles of column s beside it; one barrier per column.
+template <int NW>
+__device__ __forceinline__ void tiny_chol_inv(double *Am, const int LD, const int NT, double (*Dinv)[16][17], double (*Sc)[17],
+                                              int32_t *info_word) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bad = 0;
+    if (wave == 0) {
+        tiny_diag_gather(Am, LD, 0, Sc, lane);
+        wave_lds_order();
+        bad = tiny_chain16(Sc, Am, LD, 0, Dinv[0], lane);
+    }
+    __syncthreads();
+    for (int s = 0; s < NT; ++s) {
+        if (wave == 0) {
+            if (s + 1 < NT) {
+                __builtin_amdgcn_s_setprio(3);
+                tiny_tile_solve(Am, LD, Dinv, s, s + 1, false, lane);
+                wave_lds_order();
+                tiny_diag_gather(Am, LD, s + 1, Sc, lane);
+                wave_lds_order();
+                const int b2 = tiny_chain16(Sc, Am, LD, 16 * (s + 1), Dinv[s + 1], lane);
+                if (b2 && !bad) bad = 16 * (s + 1) + b2;
+                __builtin_amdgcn_s_setprio(0);
+            }
+        } else {
+            int idx = 0;
+            for (int i = s + 2; i < NT; ++i, ++idx)
+                if (idx % (NW - 1) == wave - 1) tiny_tile_solve(Am, LD, Dinv, s, i, false, lane);
+            for (int e = 0; e < s; ++e, ++idx)
+                if (idx % (NW - 1) == wave - 1) tiny_tile_solve(Am, LD, Dinv, s, e, true, lane);
+        }
+        __syncthreads();
+    }
+    if (wave == 0 && lane == 0 && bad && *info_word == 0) *info_word = bad;
+}
+
+// element (i, j) of W = L^-T as tiny_chol_inv leaves it (i <= j by tiles; zero below the block diagonal)
+__device__ __forceinline__ double tiny_w_elem(const double *Am, const int LD, double (*Dinv)[16][17], const int i, const int j) {
+    const int ti = i >> 4, tj = j >> 4;
+    if (ti < tj) return Am[(size_t)i * LD + j];
+    if (ti == tj) return Dinv[ti][i & 15][j & 15];
+    return 0.0;
+}
+
+__device__ __forceinline__ void tiny_tile_ij(int tau, int &i, int &j) {      // lower-triangular tile index -> (i, j), j <= i
+    int ii = 0;
+    while ((ii + 1) * (ii + 2) / 2 <= tau) ++ii;
+    i = ii;
+    j = tau - ii * (ii + 1) / 2;
+}
+
+// ---- closers ------------------------------------------------------------------------------------------------------------------
+struct TinyCtx {
+    int *fW, *cP, *fN, *c2, *cchain, *call, *abort_w;
+};
+__device__ __forceinline__ TinyCtx tiny_ctx(const TinyArgs &a, int u, int s) {
+    TinyCtx c;
+    c.fW = a.flags + 4 * u; c.cP = c.fW + 1; c.fN = c.fW + 2; c.c2 = c.fW + 3;
+    c.cchain = a.flags + 4 * a.nunits + s;
+    c.call = a.flags + 4 * a.nunits + a.S;
+    c.abort_w = c.call + 1;
+    return c;
+}
+
+// Everything of unit u is in memory.  The workgroup that completes a chain forms that chain's sums; the one that completes the
+// launch assembles the result.
+template <int NW>
+__device__ void tiny_unit_done(const TinyArgs &a, const int u, double *lds, const TinyLds &L) {
+    constexpr int NTHR = 64 * NW;
+    const int tid = threadIdx.x;
+    const int s = u / a.Dl;
+    int *slot = reinterpret_cast<int *>(lds + L.ctl);
+    double *red = lds + L.red;
+    const TinyCtx cx = tiny_ctx(a, u, s);
+    const int T = a.T, D = a.D, P = a.P, M = a.M, Mp = a.Mp, Dl = a.Dl, J = a.Ydim, nst = a.nstrips;
+    const int Tp = nst * a.SR;
+    const int pstride = tiny_pstride(Mp), qstride = tiny_qstride(Mp), ntl = tiny_ntl(a.NT);
+    if (a.grad) {
+        // ---- unit totals of the backward pass: dl/dZ (K_fu side + K_uu side), dl/dloglengthscales, dl/dlogvariance part --------
+        const int dl = u % Dl, dg = a.d_begin + dl;
+        const double *Qu = a.Qp + (size_t)u * nst * qstride;
+        double *uo = a.unit_out + (size_t)u * (M * P + P + 2);
+        double *cs = lds + L.vec;                    // [Mp] column sums of E
+        double *etx = lds + L.mat;                   // [P][Mp]
+        for (int idx = tid; idx < (P + 1) * Mp; idx += NTHR) {
+            double v = 0.0;
+            for (int st = 0; st < nst; ++st) v += Qu[(size_t)st * qstride + idx];
+            if (idx < Mp) cs[idx] = v;
+            else etx[idx - Mp] = v;
+        }
+        __syncthreads();
+        double acc[TPP + 1];
+#pragma unroll
+        for (int p = 0; p <= TPP; ++p) acc[p] = 0.0;
+        for (int m = tid; m < M; m += NTHR) {
+#pragma unroll
+            for (int p = 0; p < TPP; ++p)
+                if (p < P) {
+                    const double len = exp(a.loglen[(size_t)dg * P + p]), inv2 = 1.0 / (len * len);
+                    const double z = a.Z[(size_t)m * P + p], e = etx[p * Mp + m];
+                    uo[m * P + p] = (e - z * cs[m]) * inv2 + a.dz2[((size_t)u * Mp + m) * TPP + p];
+                    acc[p] += (-2.0 * e * z + cs[m] * z * z) * inv2;
+                }
+        }
+        if (tid < P) {
+            const double len = exp(a.loglen[(size_t)dg * P + tid]), inv2 = 1.0 / (len * len);
+            double v = 0.0;
+            for (int st = 0; st < nst; ++st) v += Qu[(size_t)st * qstride + 16 * Mp + tid];      // sum_t r_t x_tp^2
+            double k2 = 0.0;
+            for (int rb = 0; rb < a.NT; ++rb) k2 += a.kuu_part[((size_t)u * a.NT + rb) * (TPP + 1) + tid];
+            acc[tid] += v * inv2 + k2;
+        }
+        if (tid == 0) {
+            double v = 0.0;
+            for (int st = 0; st < nst; ++st) v += Qu[(size_t)st * qstride + 16 * Mp + 8];         // sum E
+            for (int rb = 0; rb < a.NT; ++rb) v += a.kuu_part[((size_t)u * a.NT + rb) * (TPP + 1) + TPP];
+            acc[TPP] = v;
+        }
+        tiny_sum<TPP + 1, NW>(acc, red);
+        if (tid < P) uo[M * P + tid] = acc[tid];
+        if (tid == 0) uo[M * P + P] = acc[TPP];
+    }
+    if (tiny_arrive(cx.cchain, slot) != Dl - 1) return;
+    // ---- chain s is complete: its likelihood / transition / trace sums (chain_reduce_kernel), prior_x_0 ------------------------
+    {
+        double v[3] = {0.0, 0.0, 0.0};
+        if (tid == 0)
+            for (int dl = 0; dl < Dl; ++dl)
+                for (int st = 0; st < nst; ++st) {
+                    const double *sc = a.Pp + ((size_t)(s * Dl + dl) * nst + st) * pstride + ntl * 256 + Mp;
+                    v[0] += sc[2]; v[1] += sc[0]; v[2] += sc[1];
+                }
+        if (tid == 0) {
+            const double *Xs = a.X + (size_t)s * (T + 1) * D;
+            double px0 = 0.0;
+            for (int d = 0; d < D; ++d) px0 += Xs[d] * Xs[d];
+            double *o = a.chain_terms + (size_t)s * 8;
+            o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = -px0 / 2.0;
+        }
+    }
+    if (a.grad) {
+        // ---- dl/dX of the chain (dx_kernel) and the likelihood gradients (shared_partials_kernel) ------------------------------
+        const double *Xs = a.X + (size_t)s * (T + 1) * D;
+        double *gX = a.dX + (size_t)s * (T + 1) * D;
+        const double Tn = (double)T, Sn = (double)a.S_total;
+        const int row = P + 1;
+        for (int idx = tid; idx < (T + 1) * D; idx += NTHR) {
+            const int t = idx / D, d = idx % D;
+            double g = 0.0;
+            for (int dl = 0; dl < Dl; ++dl) {
+                const double *du = a.dxc + (size_t)(s * Dl + dl) * Tp * row;
+                if (t < T) g += -du[(size_t)t * row + d] / Tn;                          // -dl/dx_comb through every local kernel
+                if (a.d_begin + dl == d) {
+                    const double Q = exp(a.log_Q[d]);
+                    if (t < T) {
+                        const double dlt = Xs[(size_t)(t + 1) * D + d] - Xs[(size_t)t * D + d];
+                        g += du[(size_t)t * row + P] / Tn - dlt / Q / Tn;               // delta_t = x_{t+1} - x_t
+                    }
+                    if (t > 0) {
+                        const double dlt = Xs[(size_t)t * D + d] - Xs[(size_t)(t - 1) * D + d];
+                        g += -du[(size_t)(t - 1) * row + P] / Tn + dlt / Q / Tn;
+                    }
+                }
+            }
+            if (a.shared_terms) {
+                if (t > 0)
+                    for (int j = 0; j < J; ++j) {
+                        double ym = a.DD[j];
+                        for (int dd = 0; dd < D; ++dd) ym += Xs[(size_t)t * D + dd] * a.CC[(size_t)dd * J + j];
+                        const double R = exp(a.logR[j]);
+                        const double r = (a.Y[(size_t)(t - 1) * J + j] - ym) / R;
+                        g += -(r / R) * a.CC[(size_t)d * J + j] / Tn;
+                    }
+                if (t == 0) g += Xs[d] / Tn;
+            }
+            gX[idx] = g / Sn;
+        }
+        double *cp = a.chain_part + (size_t)s * a.sp_stride;
+        for (int item = 0; item < D * J + 2 * J + Dl; ++item) {
+            double v[1] = {0.0};
+            if (item < D * J + 2 * J) {
+                if (a.shared_terms) {
+                    const int j = (item < D * J) ? item % J : (item - D * J) % J;
+                    const int kind = (item < D * J) ? 0 : ((item < D * J + J) ? 1 : 2), d = item / J;
+                    const double R = exp(a.logR[j]);
+                    for (int t = tid; t < T; t += NTHR) {
+                        double ym = a.DD[j];
+                        for (int dd = 0; dd < D; ++dd) ym += Xs[(size_t)(t + 1) * D + dd] * a.CC[(size_t)dd * J + j];
+                        const double r = (a.Y[(size_t)t * J + j] - ym) / R;
+                        if (kind == 0) v[0] += Xs[(size_t)(t + 1) * D + d] * (r / R);
+                        else if (kind == 1) v[0] += r / R;
+                        else v[0] += r * r - 1.0;
+                    }
+                }
+            } else {
+                const int d = a.d_begin + (item - D * J - 2 * J);
+                const double Q = exp(a.log_Q[d]);
+                for (int t = tid; t < T; t += NTHR) {
+                    const double dlt = Xs[(size_t)(t + 1) * D + d] - Xs[(size_t)t * D + d];
+                    v[0] += 0.5 - 0.5 * dlt * dlt / Q;
+                }
+            }
+            tiny_sum<1, NW>(v, red);
+            if (tid == 0) cp[item] = (item < D * J + 2 * J) ? -v[0] / Tn : v[0] / Tn;
+        }
+    }
+    if (tiny_arrive(cx.call, slot) != a.S - 1) return;
+    // ---- the launch is complete: nll assembly, shared-parameter gradients, flags re-armed ----------------------------------------
+    {
+        FinalizeArgs fa{};
+        fa.kind = a.kind; fa.branch = 1; fa.prior_type = a.prior_type; fa.shared_terms = a.shared_terms;
+        fa.T = T; fa.D = D; fa.P = P; fa.M = M; fa.Ydim = J; fa.Dl = Dl; fa.d_begin = a.d_begin; fa.S = a.S;
+        fa.Z = a.Z; fa.U = nullptr; fa.logvar = a.logvar; fa.loglen = a.loglen; fa.log_Q = a.log_Q; fa.CC = a.CC; fa.DD = a.DD;
+        fa.log_Rchols = a.logR; fa.chain_terms = a.chain_terms; fa.hterms = a.hterms; fa.route = 0; fa.kterms = nullptr;
+        fa.whitened = 0; fa.trpart = nullptr; fa.ntiles = 0; fa.fsq_from_trpart = 0; fa.chain_nll = a.chain_nll;
+        fa.out_terms = a.out_terms; fa.info = a.info; fa.ninfo = Dl + a.nunits;
+        finalize_body<NTHR>(fa, reinterpret_cast<double(*)[10]>(red));
+        __syncthreads();
+    }
+    if (a.grad) {
+        const double Tn = (double)T, Sn = (double)a.S_total, wgt = (double)a.S / Sn;
+        const int S = a.S, ustride = M * P + P + 2;
+        for (int idx = tid; idx < M * P; idx += NTHR) {                       // grad_dz_kernel
+            double acc = 0.0;
+            for (int uu = 0; uu < a.nunits; ++uu) acc += a.unit_out[(size_t)uu * ustride + idx];
+            double g = -acc / Tn / Sn;
+            if (a.shared_terms && a.prior_type == 1) g += wgt * a.Z[idx] / Tn;
+            a.dZ[idx] = g;
+        }
+        for (int idx = tid; idx < D * P; idx += NTHR) {                       // grad_finalize_kernel
+            const int d = idx / P, p = idx % P, dl = d - a.d_begin;
+            double g = 0.0;
+            if (dl >= 0 && dl < Dl) {
+                double acc = 0.0;
+                for (int ss = 0; ss < S; ++ss) acc += a.unit_out[(size_t)(ss * Dl + dl) * ustride + M * P + p];
+                g = (a.kind != 0) ? 0.0 : -acc / Tn / Sn + wgt * a.loglen[idx] / Tn;
+            }
+            a.dloglen[idx] = g;
+        }
+        for (int d = tid; d < D; d += NTHR) {
+            const int dl = d - a.d_begin;
+            double gv = 0.0, gq = 0.0;
+            if (dl >= 0 && dl < Dl) {
+                const double alpha = 1.0 / exp(a.log_Q[d]), s2 = exp(a.logvar[d]);
+                double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+                for (int ss = 0; ss < S; ++ss) {
+                    const size_t bb = (size_t)ss * Dl + dl;
+                    v0 += a.unit_out[bb * ustride + M * P + P] - 0.5 * alpha * s2 * Tn;
+                    v1 += a.uterms[bb * 8] * (-alpha);
+                    v2 += a.chain_part[(size_t)ss * a.sp_stride + D * J + 2 * J + dl];
+                }
+                gv = -v0 / Tn / Sn + wgt * (a.logvar[d] - (a.kind == 0 ? LOG_PRIOR_VARIANCE_SE : LOG_PRIOR_VARIANCE_LIN)) / Tn;
+                gq = -v1 / Tn / Sn + v2 / Sn + wgt * a.log_Q[d] / Tn;
+            }
+            a.dlogvar[d] = gv;
+            a.dlogQ[d] = gq;
+        }
+        for (int idx = tid; idx < D * J + J + J * J; idx += NTHR) {
+            double g = 0.0;
+            if (a.shared_terms) {
+                if (idx < D * J + 2 * J) {
+                    double acc = 0.0;
+                    for (int ss = 0; ss < S; ++ss) acc += a.chain_part[(size_t)ss * a.sp_stride + idx];
+                    acc /= Sn;
+                    if (idx < D * J) g = acc + wgt * a.CC[idx] / Tn;
+                    else if (idx < D * J + J) g = acc + wgt * a.DD[idx - D * J] / Tn;
+                    else g = acc + wgt * a.logR[idx - D * J - J] / Tn;
+                } else g = wgt * a.logR[idx - D * J - J] / Tn;                 // only row 0 of log_Rchols enters the likelihood
+            }
+            if (idx < D * J) a.dCC[idx] = g;
+            else if (idx < D * J + J) a.dDD[idx - D * J] = g;
+            else a.dlogR[idx - D * J - J] = g;
+        }
+    }
+    for (int i = tid; i < 4 * a.nunits + a.S + 1; i += NTHR) a.flags[i] = 0;      // the abort word stays as it is (0 on this path)
+}
+
+// ---- the kernel ---------------------------------------------------------------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 1) void tiny_kernel(const TinyArgs a) {
+    constexpr int NTHR = 64 * NW, SR = 16 * NW;
+    extern __shared__ double lds[];
+    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T = a.T, D = a.D, P = a.P, M = a.M, Mp = a.Mp, NT = a.NT, Dl = a.Dl, nst = a.nstrips;
+    const int LD = Mp + 1, ntl = tiny_ntl(NT), pstride = tiny_pstride(Mp);
+    const TinyLds L = tiny_lds(Mp, SR);
+    int *slot = reinterpret_cast<int *>(lds + L.ctl);
+    double *red = lds + L.red;
+    double *Am = lds + L.mat;
+    const bool head = (int)blockIdx.x < a.nunits;
+    const int u = head ? (int)blockIdx.x : ((int)blockIdx.x - a.nunits) / nst;
+    const int strip = head ? 0 : ((int)blockIdx.x - a.nunits) % nst;
+    const int s = u / Dl, dl = u % Dl, dg = a.d_begin + dl;
+    const TinyCtx cx = tiny_ctx(a, u, s);
+    const double var = exp(a.logvar[dg]);                                   // kernels_multi_output.py:157
+    const double Qd = exp(a.log_Q[dg]), alpha = 1.0 / Qd;
+    const size_t msq = (size_t)Mp * Mp;
+    double *Wu = a.Wg + (size_t)u * msq, *Wtu = a.Wt + (size_t)u * msq;
+
+    if (head) {
+        // This iteration's factorisation flags start at zero (a head is the only writer of its words), and the result starts as NaN:
+        // a launch that is abandoned on a bounded wait never reaches the workgroup that writes the sums, and a collective caller
+        // (ffvd_elbo_allreduce, no retry) must not find the previous iteration's finite values there.
+        if (tid == 0) {
+            a.info[Dl + u] = 0;
+            if (s == 0) a.info[dl] = 0;
+        }
+        if (u == 0 && tid < 7) a.out_terms[tid] = __longlong_as_double(0x7ff8000000000000LL);
+        // ======================================================================================================================
+        // head, phase 0:  K = K(Z,Z) + jitter I  ->  L, W = L^-T                              (conditionals_multi_output.py:159-166)
+        // ======================================================================================================================
+        double (*Dinv)[16][17] = reinterpret_cast<double(*)[16][17]>(lds + L.dinv);
+        double (*Sc)[17] = reinterpret_cast<double(*)[17]>(lds + L.sc);
+        {
+            double *zs = lds + L.dinv, *zz = zs + (size_t)Mp * 8;           // aliases Dinv: dead before the factorisation starts
+            for (int e = tid; e < Mp * 8; e += NTHR) {
+                const int m = e >> 3, p = e & 7;
+                zs[e] = (m < M && p < P) ? a.Z[(size_t)m * P + p] / exp(a.loglen[(size_t)dg * P + p]) : 0.0;     // :161, :170
+            }
+            __syncthreads();
+            for (int m = tid; m < Mp; m += NTHR) {
+                double sacc = 0.0;
+#pragma unroll
+                for (int p = 0; p < 8; ++p) sacc += zs[m * 8 + p] * zs[m * 8 + p];
+                zz[m] = sacc;
+            }
+            __syncthreads();
+            for (int e = tid; e < Mp * Mp; e += NTHR) {
+                const int i = e / Mp, j = e - i * Mp;
+                if (j > i) continue;
+                double v;
+                if (i >= M || j >= M) v = (i == j) ? 1.0 : 0.0;
+                else {
+                    double dot = 0.0;
+#pragma unroll
+                    for (int p = 0; p < 8; ++p) dot += zs[i * 8 + p] * zs[j * 8 + p];
+                    v = kernel_value<0>(dot, zz[i], zz[j], var);
+                    if (i == j) v += a.jitter;                               // :159
+                }
+                Am[(size_t)i * LD + j] = v;
+            }
+            __syncthreads();
+        }
+        tiny_chol_inv<NW>(Am, LD, NT, Dinv, Sc, a.info + (s == 0 ? dl : Dl + u));      // (every chain's head factorises the same K_uu)
+        for (int e = tid; e < Mp * Mp; e += NTHR) {
+            const int i = e / Mp, j = e - i * Mp;
+            Wu[e] = tiny_w_elem(Am, LD, Dinv, i, j);                         // row-major W
+            Wtu[e] = tiny_w_elem(Am, LD, Dinv, j, i);                        // row-major W^T
+        }
+        tiny_publish(cx.fW, 1);
+        // ======================================================================================================================
+        // head, phase 1:  H = I + F^T F / Q, b = delta^T F / Q, log|H|, b H^-1 b^T                           (:246-254)
+        // ======================================================================================================================
+        if (tiny_wait(cx.cP, nst, cx.abort_w, slot) < 0) {
+            if (tid == 0) a.info[Dl + u] = -1;
+            return;
+        }
+        double *bv = lds + L.vec, *yv = bv + Mp, *wl = yv + Mp;
+        const double *Pu = a.Pp + (size_t)u * nst * pstride;
+        double *Hu = a.Hs + (size_t)u * msq;
+        for (int tau = 0; tau < ntl; ++tau) {
+            int ti, tj;
+            tiny_tile_ij(tau, ti, tj);
+            for (int e = tid; e < 256; e += NTHR) {
+                double v = 0.0;
+                for (int st = 0; st < nst; ++st) v += Pu[(size_t)st * pstride + tau * 256 + e];
+                const int m = e >> 4, n = e & 15, gi = 16 * ti + m, gj = 16 * tj + n;
+                const double hv = alpha * v;                                  // batch_size == Y_N: the factor Y_N / batch is 1 (:246)
+                Am[(size_t)gi * LD + gj] = hv + ((gi == gj) ? 1.0 : 0.0);
+                if (a.grad) { Hu[(size_t)gi * Mp + gj] = hv; Hu[(size_t)gj * Mp + gi] = hv; }
+            }
+        }
+        for (int m = tid; m < Mp; m += NTHR) {
+            double v = 0.0;
+            for (int st = 0; st < nst; ++st) v += Pu[(size_t)st * pstride + ntl * 256 + m];
+            bv[m] = alpha * v;                                                // :248
+        }
+        __syncthreads();
+        tiny_chol_inv<NW>(Am, LD, NT, Dinv, Sc, a.info + Dl + u);
+        for (int j = tid; j < Mp; j += NTHR) {                                // y = L_H^-1 b = W_H^T b
+            double acc = 0.0;
+            const int jend = (j | 15);
+            for (int i = 0; i <= jend && i < Mp; ++i) acc += tiny_w_elem(Am, LD, Dinv, i, j) * bv[i];
+            yv[j] = acc;
+        }
+        __syncthreads();
+        {
+            double v[2] = {0.0, 0.0};
+            for (int i = tid; i < Mp; i += NTHR) { v[0] += log(Am[(size_t)i * LD + i]); v[1] += yv[i] * yv[i]; }
+            tiny_sum<2, NW>(v, red);
+            if (tid == 0) { a.hterms[2 * u] = 2.0 * v[0]; a.hterms[2 * u + 1] = v[1]; }     // logdet (:253), b H^-1 b^T (:254)
+        }
+        if (!a.grad) {
+            tiny_unit_done<NW>(a, u, lds, L);
+            return;
+        }
+        // ---- backward: H^-1 = W_H W_H^T, w = W_H y, N = I - H^-1 - w w^T, N2 = N - (H - I), dl/dalpha ------------------------------
+        for (int i = tid; i < Mp; i += NTHR) {
+            double acc = 0.0;
+            for (int k = (i & ~15); k < Mp; ++k) acc += tiny_w_elem(Am, LD, Dinv, i, k) * yv[k];
+            wl[i] = acc;
+            a.wv[(size_t)u * Mp + i] = acc;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // H - I (written above) is read back below
+        __syncthreads();
+        double *Nu = a.Nw + (size_t)u * msq, *N2u = a.Nm2 + (size_t)u * msq;
+        double trhinv = 0.0;
+        for (int tau = wave; tau < ntl; tau += NW) {
+            int ti, tj;
+            tiny_tile_ij(tau, ti, tj);
+            d4 a0 = (d4){0.0, 0.0, 0.0, 0.0}, a1 = a0;
+            for (int k = ti; k < NT; ++k) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const double av = (k == ti) ? Dinv[ti][lr][4 * t + lk] : Am[(size_t)(16 * ti + lr) * LD + 16 * k + 4 * t + lk];
+                    const double bw = (k == tj) ? Dinv[tj][lr][4 * t + lk] : Am[(size_t)(16 * tj + lr) * LD + 16 * k + 4 * t + lk];
+                    if (t & 1) a1 = mfma_f64(av, bw, a1);
+                    else a0 = mfma_f64(av, bw, a0);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gi = 16 * ti + lk + 4 * r, gj = 16 * tj + lr;
+                const double hinv = a0[r] + a1[r];
+                const double nw = ((gi == gj) ? 1.0 : 0.0) - hinv - wl[gi] * wl[gj];
+                const double n2 = nw - Hu[(size_t)gi * Mp + gj];
+                Nu[(size_t)gi * Mp + gj] = nw; N2u[(size_t)gi * Mp + gj] = n2;
+                if (ti != tj) { Nu[(size_t)gj * Mp + gi] = nw; N2u[(size_t)gj * Mp + gi] = n2; }
+                if (gi == gj) trhinv += hinv;
+            }
+        }
+        {
+            double v[4] = {trhinv, 0.0, 0.0, 0.0};                            // tr H^-1, tr(H - I), w^T (H - I) w, w^T b
+            for (int i = tid; i < Mp; i += NTHR) {
+                double hw = 0.0;
+                for (int j = 0; j < Mp; ++j) hw += Hu[(size_t)i * Mp + j] * wl[j];
+                v[1] += Hu[(size_t)i * Mp + i];
+                v[2] += wl[i] * hw;
+                v[3] += wl[i] * bv[i];
+            }
+            tiny_sum<4, NW>(v, red);
+            if (tid == 0) {
+                // dl/dalpha = -1/2 tr(A^-1 G) + u^T g - 1/2 u^T G u - 1/2 (T sigma^2 - tr(K^-1 G)) in whitened variables (ffvd_grad_oracle.py)
+                const double trAinvG = ((double)Mp - v[0]) / alpha, trKinvG = v[1] / alpha;
+                a.uterms[(size_t)u * 8] = -0.5 * trAinvG + v[3] / alpha - 0.5 * v[2] / alpha - 0.5 * ((double)T * var - trKinvG);
+            }
+        }
+        tiny_publish(cx.fN, 1);
+        return;
+    }
+
+    // ==========================================================================================================================
+    // strip, phase 0:  rows [t0, t0 + SR) of K_fu = K(x_comb, Z) in registers (accumulator layout) and LDS                   (:240)
+    // ==========================================================================================================================
+    const int t0 = strip * SR;
+    double *Ks = lds + L.mat;
+    double *xs = lds + L.xo, *xx = xs + (size_t)SR * 8;
+    double *zs = lds + L.zo, *zz = zs + (size_t)Mp * 8;
+    double *dlt = lds + L.misc, *rowv = dlt + SR;
+    const double *Xs = a.X + (size_t)s * (T + 1) * D;
+    for (int e = tid; e < Mp * 8; e += NTHR) {
+        const int m = e >> 3, p = e & 7;
+        zs[e] = (m < M && p < P) ? a.Z[(size_t)m * P + p] / exp(a.loglen[(size_t)dg * P + p]) : 0.0;
+    }
+    for (int e = tid; e < SR * 8; e += NTHR) {
+        const int r = e >> 3, p = e & 7, t = t0 + r;
+        double v = 0.0;
+        if (t < T && p < P) {
+            v = (p < D) ? Xs[(size_t)t * D + p] : a.ctrl[(size_t)t * a.C + (p - D)];
+            v = v / exp(a.loglen[(size_t)dg * P + p]);
+        }
+        xs[e] = v;
+    }
+    for (int r = tid; r < SR; r += NTHR) {
+        const int t = t0 + r;
+        dlt[r] = (t < T) ? Xs[(size_t)(t + 1) * D + dg] - Xs[(size_t)t * D + dg] : 0.0;       // :247
+    }
+    __syncthreads();
+    for (int m = tid; m < Mp; m += NTHR) {
+        double sacc = 0.0;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) sacc += zs[m * 8 + p] * zs[m * 8 + p];
+        zz[m] = sacc;
+    }
+    for (int r = tid; r < SR; r += NTHR) {
+        double sacc = 0.0;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) sacc += xs[r * 8 + p] * xs[r * 8 + p];
+        xx[r] = sacc;
+    }
+    __syncthreads();
+    double kreg[TNT][4];
+#pragma unroll
+    for (int c = 0; c < TNT; ++c) {
+        if (c < NT) {
+            const int m = 16 * c + lr;
+            double zr[8];
+#pragma unroll
+            for (int p = 0; p < 8; ++p) zr[p] = zs[m * 8 + p];
+            const double zzm = zz[m];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * wave + lk + 4 * r;
+                double dot = 0.0;
+#pragma unroll
+                for (int p = 0; p < 8; ++p) dot += xs[row * 8 + p] * zr[p];
+                double v = kernel_value<0>(dot, xx[row], zzm, var);
+                if (m >= M || t0 + row >= T) v = 0.0;
+                kreg[c][r] = v;
+                Ks[(size_t)row * LD + m] = v;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) kreg[c][r] = 0.0;
+        }
+    }
+    wave_lds_order();
+    // ==========================================================================================================================
+    // strip, phase 1:  F = K_fu W (:242), F^T F, F^T delta, sum F^2 (:255), chain-term partials
+    // ==========================================================================================================================
+    if (tiny_wait(cx.fW, 1, cx.abort_w, slot) < 0) return;
+    d4 facc[TNT];
+#pragma unroll
+    for (int j = 0; j < TNT; ++j) facc[j] = (d4){0.0, 0.0, 0.0, 0.0};
+    for (int k = 0; k < NT; ++k) {
+        double av[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) av[t] = Ks[(size_t)(16 * wave + lr) * LD + 16 * k + 4 * t + lk];
+#pragma unroll
+        for (int j = 0; j < TNT; ++j)
+            if (j < NT && j >= k) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) facc[j] = mfma_f64(av[t], Wu[(size_t)(16 * k + 4 * t + lk) * Mp + 16 * j + lr], facc[j]);
+            }
+    }
+    wave_lds_order();
+    {
+        double rs[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int j = 0; j < TNT; ++j)
+            if (j < NT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    rs[r] += facc[j][r] * facc[j][r];
+                    Ks[(size_t)(16 * wave + lk + 4 * r) * LD + 16 * j + lr] = facc[j][r];      // F replaces K_fu in LDS (K_fu stays in registers)
+                }
+            }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int m = 8; m > 0; m >>= 1) rs[r] += __shfl_xor(rs[r], m);
+            if (lr == 0) rowv[16 * wave + lk + 4 * r] = rs[r];
+        }
+    }
+    __syncthreads();
+    double *Pu = a.Pp + ((size_t)u * nst + strip) * pstride;
+    for (int tau = wave; tau < ntl; tau += NW) {
+        int ti, tj;
+        tiny_tile_ij(tau, ti, tj);
+        d4 a0 = (d4){0.0, 0.0, 0.0, 0.0}, a1 = a0;
+#pragma unroll 4
+        for (int q = 0; q < SR / 4; ++q) {
+            const double av = Ks[(size_t)(4 * q + lk) * LD + 16 * ti + lr], bw = Ks[(size_t)(4 * q + lk) * LD + 16 * tj + lr];
+            if (q & 1) a1 = mfma_f64(av, bw, a1);
+            else a0 = mfma_f64(av, bw, a0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Pu[tau * 256 + (lk + 4 * r) * 16 + lr] = a0[r] + a1[r];
+    }
+    for (int m = tid; m < Mp; m += NTHR) {
+        double acc = 0.0;
+        for (int r = 0; r < SR; ++r) acc += Ks[(size_t)r * LD + m] * dlt[r];
+        Pu[ntl * 256 + m] = acc;
+    }
+    {
+        double v[3] = {0.0, 0.0, 0.0};          // transition, trace, likelihood partial sums of these rows (chain_reduce_kernel)
+        for (int r = tid; r < SR; r += NTHR) {
+            const int t = t0 + r;
+            if (t < T) {
+                const double q = dlt[r] / sqrt(Qd);                          // dgp_model.py:283-284
+                v[0] += -0.5 * (q * q);
+                v[1] += -0.5 * ((var - rowv[r]) / Qd);                       // conditionals_multi_output.py:255
+                if (dl == 0 && a.shared_terms)
+                    for (int j = 0; j < a.Ydim; ++j) {
+                        double ym = 0.0;
+                        for (int d = 0; d < D; ++d) ym += Xs[(size_t)(t + 1) * D + d] * a.CC[(size_t)d * a.Ydim + j];      // likelihoods.py:76-79
+                        ym += a.DD[j];
+                        const double R = exp(a.logR[j]);                     // Rchols[0] = first row (dgp_model.py:250)
+                        const double rr = (a.Y[(size_t)t * a.Ydim + j] - ym) / R;
+                        v[2] += -0.5 * (rr * rr);
+                    }
+            }
+        }
+        tiny_sum<3, NW>(v, red);
+        if (tid == 0) { double *sc = Pu + ntl * 256 + Mp; sc[0] = v[0]; sc[1] = v[1]; sc[2] = v[2]; }
+    }
+    const int before = tiny_arrive(cx.cP, slot);
+    (void)before;
+    if (!a.grad) return;
+    // ==========================================================================================================================
+    // strip, phase 2 (backward):  dl/dK_fu = alpha (F N + delta w^T) W^T,  E = dl/dK_fu o K_fu,  its reductions
+    // ==========================================================================================================================
+    if (tiny_wait(cx.fN, 1, cx.abort_w, slot) < 0) return;
+    double *wl = lds + L.vec;
+    double *XO = lds + L.xo, *ZO = lds + L.zo;
+    for (int m = tid; m < Mp; m += NTHR) wl[m] = a.wv[(size_t)u * Mp + m];
+    for (int e = tid; e < Mp * 16; e += NTHR) {
+        const int m = e >> 4, n = e & 15;
+        ZO[e] = (n == 0) ? 1.0 : ((m < M && n <= P) ? a.Z[(size_t)m * P + n - 1] : 0.0);
+    }
+    for (int e = tid; e < SR * 16; e += NTHR) {
+        const int r = e >> 4, n = e & 15, t = t0 + r;
+        double v = 0.0;
+        if (n == 0) v = 1.0;
+        else if (t < T && n <= P) v = (n - 1 < D) ? Xs[(size_t)t * D + n - 1] : a.ctrl[(size_t)t * a.C + (n - 1 - D)];
+        XO[e] = v;
+    }
+    __syncthreads();
+    const int Tp = nst * SR, drow = P + 1;
+    double *dxu = a.dxc + (size_t)u * Tp * drow;
+    for (int r = tid; r < SR; r += NTHR) {                                   // dl/ddelta_t = alpha (F w)_t
+        double acc = 0.0;
+        for (int j = 0; j < Mp; ++j) acc += Ks[(size_t)r * LD + j] * wl[j];
+        if (t0 + r < T) dxu[(size_t)(t0 + r) * drow + P] = alpha * acc;
+    }
+    const double *Nu = a.Nw + (size_t)u * msq;
+#pragma unroll
+    for (int j = 0; j < TNT; ++j) facc[j] = (d4){0.0, 0.0, 0.0, 0.0};
+    for (int k = 0; k < NT; ++k) {
+        double av[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) av[t] = Ks[(size_t)(16 * wave + lr) * LD + 16 * k + 4 * t + lk];
+#pragma unroll
+        for (int j = 0; j < TNT; ++j)
+            if (j < NT) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) facc[j] = mfma_f64(av[t], Nu[(size_t)(16 * k + 4 * t + lk) * Mp + 16 * j + lr], facc[j]);
+            }
+    }
+    __syncthreads();                                                          // every thread's reads of F (dl/ddelta above) are done
+#pragma unroll
+    for (int j = 0; j < TNT; ++j)
+        if (j < NT) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                Ks[(size_t)(16 * wave + lk + 4 * r) * LD + 16 * j + lr] = facc[j][r] + dlt[16 * wave + lk + 4 * r] * wl[16 * j + lr];   // R
+        }
+    wave_lds_order();
+#pragma unroll
+    for (int j = 0; j < TNT; ++j) facc[j] = (d4){0.0, 0.0, 0.0, 0.0};
+    for (int k = 0; k < NT; ++k) {
+        double av[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) av[t] = Ks[(size_t)(16 * wave + lr) * LD + 16 * k + 4 * t + lk];
+#pragma unroll
+        for (int j = 0; j < TNT; ++j)
+            if (j < NT && j <= k) {                                            // W^T is lower triangular by tiles
+#pragma unroll
+                for (int t = 0; t < 4; ++t) facc[j] = mfma_f64(av[t], Wtu[(size_t)(16 * k + 4 * t + lk) * Mp + 16 * j + lr], facc[j]);
+            }
+    }
+    wave_lds_order();
+#pragma unroll
+    for (int j = 0; j < TNT; ++j)
+        if (j < NT) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                facc[j][r] = alpha * facc[j][r] * kreg[j][r];                 // E, accumulator layout = B-operand layout with k = row
+                Ks[(size_t)(16 * wave + lk + 4 * r) * LD + 16 * j + lr] = facc[j][r];
+            }
+        }
+    wave_lds_order();
+    // row side: [r | E Z] = E [1 | Z]   (16 rows of this wavefront x 16 columns)
+    double *part = rowv;                                                      // [NW][16] per-wavefront partials of sum_t r_t x_tp^2 and sum E
+    {
+        d4 a0 = (d4){0.0, 0.0, 0.0, 0.0}, a1 = a0;
+        for (int k = 0; k < NT; ++k) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const double av = Ks[(size_t)(16 * wave + lr) * LD + 16 * k + 4 * t + lk], bw = ZO[(size_t)(16 * k + 4 * t + lk) * 16 + lr];
+                if (t & 1) a1 = mfma_f64(av, bw, a1);
+                else a0 = mfma_f64(av, bw, a0);
+            }
+        }
+        double rx2 = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double v = a0[r] + a1[r];
+            const double rt = __shfl(v, lane & 48);                           // lane lr = 0 of this row: the row sum r_t
+            const int row = 16 * wave + lk + 4 * r, t = t0 + row;
+            const double x = XO[(size_t)row * 16 + lr];
+            if (lr >= 1 && lr <= P) {
+                const double len = exp(a.loglen[(size_t)dg * P + lr - 1]);
+                if (t < T) dxu[(size_t)t * drow + lr - 1] = -(x * rt - v) / (len * len);      // dl/dx_comb_t,p (_se_chain)
+                rx2 += rt * x * x;
+            } else if (lr == 0) rx2 += v;                                     // sum of the row sums
+        }
+        rx2 += __shfl_xor(rx2, 16);
+        rx2 += __shfl_xor(rx2, 32);
+        __syncthreads();                                                      // rowv (phase 1) is dead; every wavefront is past its E rows
+        if (lk == 0) part[wave * 16 + lr] = rx2;
+    }
+    // column side: [cs ; E^T x] = [1 | x]^T E for this wavefront's rows, then the wavefronts' tiles added in fixed order
+    {
+        double *CB = Ks;                                                      // [NW][16][Mp]: E is dead in LDS (it stays in registers)
+#pragma unroll
+        for (int j = 0; j < TNT; ++j)
+            if (j < NT) {
+                d4 c0 = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) c0 = mfma_f64(XO[(size_t)(16 * wave + 4 * q + lk) * 16 + lr], facc[j][q], c0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) CB[((size_t)wave * 16 + lk + 4 * r) * Mp + 16 * j + lr] = c0[r];
+            }
+        __syncthreads();
+        double *Qu = a.Qp + ((size_t)u * nst + strip) * tiny_qstride(Mp);
+        for (int idx = tid; idx < (P + 1) * Mp; idx += NTHR) {
+            double v = 0.0;
+            for (int w = 0; w < NW; ++w) v += CB[(size_t)w * 16 * Mp + idx];
+            Qu[idx] = v;
+        }
+        if (tid <= P) {
+            double v = 0.0;
+            for (int w = 0; w < NW; ++w) v += part[w * 16 + tid];
+            if (tid == 0) Qu[16 * Mp + 8] = v;                                // sum E
+            else Qu[16 * Mp + tid - 1] = v;                                   // sum_t r_t x_tp^2
+        }
+        __syncthreads();
+    }
+    // K_uu side, one 16-row block per strip:  Psi = 1/2 W N2 W^T (dl/dK_uu),  E_u = Psi o K(Z,Z),  row sums and E_u Z
+    for (int rb = strip; rb < NT; rb += nst) {
+        double *T1 = Ks;                                                      // [16][LD]
+        double *Eu = Ks + (size_t)16 * LD;                                    // [16][LD]
+        const double *N2u = a.Nm2 + (size_t)u * msq;
+        for (int j = wave; j < NT; j += NW) {                                 // T1 = W(rb, :) N2
+            d4 a0 = (d4){0.0, 0.0, 0.0, 0.0}, a1 = a0;
+            for (int k = rb; k < NT; ++k) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const double av = Wu[(size_t)(16 * rb + lr) * Mp + 16 * k + 4 * t + lk], bw = N2u[(size_t)(16 * k + 4 * t + lk) * Mp + 16 * j + lr];
+                    if (t & 1) a1 = mfma_f64(av, bw, a1);
+                    else a0 = mfma_f64(av, bw, a0);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) T1[(size_t)(lk + 4 * r) * LD + 16 * j + lr] = a0[r] + a1[r];
+        }
+        __syncthreads();
+        for (int j = wave; j < NT; j += NW) {                                 // Psi(rb, j) = 1/2 T1 W^T(:, j),  E_u = Psi o K_uu
+            d4 a0 = (d4){0.0, 0.0, 0.0, 0.0}, a1 = a0;
+            for (int k = j; k < NT; ++k) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const double av = T1[(size_t)lr * LD + 16 * k + 4 * t + lk], bw = Wtu[(size_t)(16 * k + 4 * t + lk) * Mp + 16 * j + lr];
+                    if (t & 1) a1 = mfma_f64(av, bw, a1);
+                    else a0 = mfma_f64(av, bw, a0);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gi = 16 * rb + lk + 4 * r, gj = 16 * j + lr;
+                double kv = 0.0;
+                if (gi < M && gj < M) {                                        // K(Z,Z) without the jitter (ffvd_grad_oracle.py: Psi * Kuu)
+                    double dot = 0.0, zi2 = 0.0, zj2 = 0.0;
+                    for (int p = 0; p < P; ++p) {
+                        const double len = exp(a.loglen[(size_t)dg * P + p]);
+                        const double zi = a.Z[(size_t)gi * P + p] / len, zj = a.Z[(size_t)gj * P + p] / len;
+                        dot += zi * zj; zi2 += zi * zi; zj2 += zj * zj;
+                    }
+                    kv = kernel_value<0>(dot, zi2, zj2, var);
+                }
+                Eu[(size_t)(lk + 4 * r) * LD + gj] = 0.5 * (a0[r] + a1[r]) * kv;
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            d4 a0 = (d4){0.0, 0.0, 0.0, 0.0}, a1 = a0;
+            for (int k = 0; k < NT; ++k) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const double av = Eu[(size_t)lr * LD + 16 * k + 4 * t + lk], bw = ZO[(size_t)(16 * k + 4 * t + lk) * 16 + lr];
+                    if (t & 1) a1 = mfma_f64(av, bw, a1);
+                    else a0 = mfma_f64(av, bw, a0);
+                }
+            }
+            double sll = 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double v = a0[r] + a1[r];
+                const double ru = __shfl(v, lane & 48);
+                const int gi = 16 * rb + lk + 4 * r;
+                if (lr >= 1 && lr <= P) {
+                    const double len = exp(a.loglen[(size_t)dg * P + lr - 1]), inv2 = 1.0 / (len * len);
+                    const double z = (gi < M) ? a.Z[(size_t)gi * P + lr - 1] : 0.0;
+                    a.dz2[((size_t)u * Mp + gi) * TPP + lr - 1] = -2.0 * (z * ru - v) * inv2;       // E_u symmetric: both roles of Z
+                    sll += 2.0 * (ru * z * z - z * v) * inv2;
+                } else if (lr == 0) sll += v;
+            }
+            sll += __shfl_xor(sll, 16);
+            sll += __shfl_xor(sll, 32);
+            if (lk == 0 && lr <= P) a.kuu_part[((size_t)u * NT + rb) * (TPP + 1) + (lr == 0 ? TPP : lr - 1)] = sll;
+        }
+        __syncthreads();
+    }
+    if (tiny_arrive(cx.c2, slot) != nst - 1) return;
+    tiny_unit_done<NW>(a, u, lds, L);
+}
+
+// ---- host side --------------------------------------------------------------------------------------------------------------------
+TinyPlan tiny_plan(int kind, int T, int D, int C, int M, int S, int Dl, int grad, int cus) {
+    TinyPlan pl{};
+    pl.ok = false;
+    const int P = D + C;
+    if (kind != 0 || P > TINY_PMAX || M < 1 || T < 1 || T > TINY_TMAX || S < 1 || Dl < 1) return pl;
+    pl.Mp = round_up(M, 16);
+    if (pl.Mp > TINY_MPMAX) return pl;
+    pl.NT = pl.Mp / 16;
+    pl.nunits = S * Dl;
+    (void)grad;
+    for (int nw = 4; nw <= 8; nw += 4) {
+        const int SR = 16 * nw, nst = (T + SR - 1) / SR;
+        const TinyLds l = tiny_lds(pl.Mp, SR);
+        const size_t bytes = (size_t)l.total * sizeof(double);
+        if (bytes + 1024 > 160 * 1024) continue;           // (the kernel also has a few hundred bytes of static LDS)
+        if (nst > 32) continue;
+        if (pl.NT > nst * 8) continue;                     // (the K_uu side deals its NT row blocks over the strips)
+        if ((long long)pl.nunits * (1 + nst) > (long long)cus) continue;      // every workgroup resident at once, one per CU
+        pl.ok = true; pl.nw = nw; pl.SR = SR; pl.nstrips = nst; pl.lds_bytes = bytes;
+        return pl;
+    }
+    return pl;
+}
+
+namespace {
+struct TinyCarve {
+    size_t Wg, Wt, Pp, Hs, Nw, Nm2, wv, hterms, uterms, Qp, dxc, dz2, kuu, uout, cterms, cpart, total;
+};
+TinyCarve tiny_carve(const TinyPlan &pl, int T, int P, int M, int S, int Dl, int D, int Ydim, int grad) {
+    (void)T;
+    TinyCarve c{};
+    const size_t nu = pl.nunits, msq = (size_t)pl.Mp * pl.Mp, nst = pl.nstrips;
+    auto al = [](size_t n) { return (n + 31) / 32 * 32; };
+    size_t o = 0;
+    c.Wg = o; o += al(nu * msq);
+    c.Wt = o; o += al(nu * msq);
+    c.Pp = o; o += al(nu * nst * tiny_pstride(pl.Mp));
+    c.hterms = o; o += al(nu * 2);
+    c.cterms = o; o += al((size_t)S * 8);
+    c.Hs = o; o += al(nu * msq);                    // (written in forward-only launches too: cheap, keeps the kernel uniform)
+    if (grad) {
+        c.Nw = o; o += al(nu * msq);
+        c.Nm2 = o; o += al(nu * msq);
+        c.wv = o; o += al(nu * pl.Mp);
+        c.uterms = o; o += al(nu * 8);
+        c.Qp = o; o += al(nu * nst * tiny_qstride(pl.Mp));
+        c.dxc = o; o += al(nu * nst * pl.SR * (P + 1));
+        c.dz2 = o; o += al(nu * pl.Mp * TINY_PMAX);
+        c.kuu = o; o += al(nu * pl.NT * (TINY_PMAX + 1));
+        c.uout = o; o += al(nu * ((size_t)M * P + P + 2));
+        c.cpart = o; o += al((size_t)S * (D * Ydim + 2 * Ydim + Dl));
+    }
+    c.total = o;
+    return c;
+}
+}  // namespace
+
+size_t tiny_scratch_doubles(const TinyPlan &pl, int T, int P, int M, int S, int Dl, int D, int Ydim, int grad) {
+    return tiny_carve(pl, T, P, M, S, Dl, D, Ydim, grad).total;
+}
+size_t tiny_flag_ints(const TinyPlan &pl, int S) { return (size_t)4 * pl.nunits + S + 8; }
+
+void tiny_bind_scratch(TinyArgs &a, const TinyPlan &pl, double *scratch, int *flags) {
+    const TinyCarve c = tiny_carve(pl, a.T, a.P, a.M, a.S, a.Dl, a.D, a.Ydim, a.grad);
+    a.Mp = pl.Mp; a.NT = pl.NT; a.SR = pl.SR; a.nstrips = pl.nstrips; a.nunits = pl.nunits;
+    a.Wg = scratch + c.Wg; a.Wt = scratch + c.Wt; a.Pp = scratch + c.Pp; a.hterms = scratch + c.hterms;
+    a.chain_terms = scratch + c.cterms; a.Hs = scratch + c.Hs;
+    a.sp_stride = a.D * a.Ydim + 2 * a.Ydim + a.Dl;
+    if (a.grad) {
+        a.Nw = scratch + c.Nw; a.Nm2 = scratch + c.Nm2; a.wv = scratch + c.wv; a.uterms = scratch + c.uterms;
+        a.Qp = scratch + c.Qp; a.dxc = scratch + c.dxc; a.dz2 = scratch + c.dz2; a.kuu_part = scratch + c.kuu;
+        a.unit_out = scratch + c.uout; a.chain_part = scratch + c.cpart;
+    }
+    a.flags = flags;
+}
+
+hipError_t launch_tiny(hipStream_t stream, const TinyArgs &a, const TinyPlan &pl) {
+    static size_t attr_bytes[2] = {0, 0};              // dynamic LDS each instantiation has been allowed so far
+    const int grid = pl.nunits * (1 + pl.nstrips);
+    const int which = pl.nw == 4 ? 0 : 1;
+    const void *fn = which == 0 ? reinterpret_cast<const void *>(&tiny_kernel<4>) : reinterpret_cast<const void *>(&tiny_kernel<8>);
+    if (pl.lds_bytes > attr_bytes[which] && pl.lds_bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes);
+        if (e != hipSuccess) return e;
+        attr_bytes[which] = pl.lds_bytes;
+    }
+    if (which == 0) hipLaunchKernelGGL(tiny_kernel<4>, dim3(grid), dim3(256), pl.lds_bytes, stream, a);
+    else hipLaunchKernelGGL(tiny_kernel<8>, dim3(grid), dim3(512), pl.lds_bytes, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace ffvd

@@ -130,6 +130,12 @@ int  ffvd_sync(ffvd_handle *h);
  * abandoned launch), so after the all-reduce EVERY rank sees non-finite sums, returns an error (FFVD_EDEVICE on the rank that
  * stalled, FFVD_ENOTPD elsewhere) and leaves its parameters untouched.  ffvd_tshard_finish (no collective after it) retries. */
 int  ffvd_stall_recoveries(const ffvd_handle *h);
+/* Non-zero when the handle evaluates its iteration (and, with grad = 1, the backward pass) as ONE kernel launch: the collapsed-U
+ * branch with SquaredExponential kernels in fp64 at the reference's own experiment size (FFVD_Main.py:356-369: M <= 128,
+ * P = D + C <= 8, every role's workgroup resident at once; ffvd_amd/csrc/tiny.hip).  The value is the wavefronts per workgroup
+ * (4 or 8).  The arithmetic is the reference's op order (F = K_fu L^-T, H = I + F^T F / Q, conditionals_multi_output.py:230-257)
+ * whatever cfg.route says.  FFVD_NO_TINY=1 in the environment keeps the multi-kernel schedule. */
+int  ffvd_single_launch(const ffvd_handle *h);
 /* bytes of device workspace owned by the handle */
 int64_t ffvd_workspace_bytes(const ffvd_handle *h);
 

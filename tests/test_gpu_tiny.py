@@ -1,0 +1,196 @@
+"""GPU parity of the one-launch iteration (ffvd_amd/csrc/tiny.hip): the whole ELBO evaluation -- and its backward pass -- of the
+reference's own experiment size (FFVD_Main.py:356-369: T <= 512, M = 100, D = 4; models.py:142-182) as ONE kernel launch, against
+the CPU oracle (nll + the six named terms of dgp_model.py:264-297, the closed-form gradient of oracle/ffvd_grad_oracle.py), the
+committed goldens, and the multi-kernel schedule of the same library (FFVD_NO_TINY=1)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from ffvd_amd import synthetic
+from ffvd_amd.engine import ElboEngine
+from oracle import ffvd_oracle as orc
+from oracle import ffvd_grad_oracle as gorc
+
+pytestmark = pytest.mark.gpu
+
+TERMS = ("nll_part_prior", "nll_log_likelihood", "x_t_prior_Q", "nll_reg_trace_inverse_Q_B", "later_term1", "later_term2", "nll")
+GRAD_KEYS = ("X", "Z", "logvariance", "loglengthscales", "log_Q", "CC", "DD", "log_Rchols")
+
+
+def engine(meta, S=None, **kw):
+    return ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], S if S is not None else meta["S"], Ydim=meta["Ydim"], **kw)
+
+
+def single_launch(e):
+    return int(e.lib.ffvd_single_launch(e._h))
+
+
+def oracle_grad(params, Y, c, **kw):
+    S = params["X"].shape[0]
+    want = None
+    for s in range(S):
+        g = gorc.nll_grad(dict(params, X=params["X"][s]), Y, c, **kw)
+        if want is None:
+            want = {k: np.zeros_like(v) for k, v in g.items() if k != "X"}
+            want["X"] = np.zeros_like(params["X"])
+        for k in g:
+            if k == "X":
+                want["X"][s] = g["X"] / S
+            else:
+                want[k] += g[k] / S
+    return want
+
+
+def actuator(S):
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "actuator_slim.npz"), allow_pickle=False)
+    params = {k: z[k] for k in ("X", "Z", "U", "logvariance", "loglengthscales", "log_Q", "CC", "DD", "log_Rchols")}
+    Y, c = z["Y"], z["control_inputs"]
+    T, D = params["X"].shape[0] - 1, params["X"].shape[1]
+    meta = dict(T=T, D=D, C=c.shape[1], M=params["Z"].shape[0], S=S, Ydim=Y.shape[1])
+    X = np.repeat(params["X"][None], S, axis=0)
+    if S > 1:
+        X = X + 1e-3 * np.random.default_rng(0).standard_normal(X.shape)
+        X[0] = params["X"]
+    params["X"] = np.ascontiguousarray(X)
+    return params, Y, c, meta, z
+
+
+@pytest.mark.parametrize("name", ["tiny", "small", "ragged"])
+def test_forward_matches_golden_and_oracle(name):
+    """The seeded synthetic shapes of tests/golden (M = 24, 96, 77: padded to 32, 96, 80 -- multiples of 16, not of 64; T = 96, 384,
+    301: ragged last strip) through ONE launch: every named term against the golden vector and the oracle to 1e-10."""
+    params, Y, c, meta = synthetic.make_named(name)
+    g = load_golden(name)
+    with engine(meta) as e:
+        assert single_launch(e) in (4, 8)
+        e.set_data(Y, c)
+        got = e.nll_terms(params)
+        again = e.nll_terms(params)
+    ref = orc.nll_terms_chains(params, Y, c, U_collapse=True)
+    for n in TERMS:
+        assert got[n] == pytest.approx(float(g["B_" + n]), rel=1e-10, abs=1e-11), n
+        assert got[n] == pytest.approx(ref[n], rel=1e-10, abs=1e-11), n
+        assert got[n] == again[n], n                    # bit-reproducible: fixed summation orders whoever closes
+    np.testing.assert_allclose(got["nll_per_chain"], ref["nll_per_chain"], rtol=1e-10)
+
+
+@pytest.mark.parametrize("S", [1, 10])
+def test_actuator_config1(S):
+    """BASELINE configs[0] (actuator, x_dim = 4, M = 100, S = 10): the fixture's nll and terms, one launch.  Chain 0 carries the
+    fixture's own X: its nll is the golden value (SURVEY 8a anchor -2.369303046...)."""
+    params, Y, c, meta, z = actuator(S)
+    with engine(meta) as e:
+        assert single_launch(e) in (4, 8)
+        e.set_data(Y, c)
+        got = e.nll_terms(params)
+    assert got["nll_per_chain"][0] == pytest.approx(float(load_golden("actuator")["B_nll"]), rel=1e-10)
+    ref = orc.nll_terms_chains(params, Y, c, U_collapse=True)
+    for n in TERMS:
+        assert got[n] == pytest.approx(ref[n], rel=1e-10, abs=1e-11), n
+
+
+@pytest.mark.parametrize("shape", [dict(T=64, D=1, C=1, M=16, S=1), dict(T=17, D=2, C=0, M=5, S=3), dict(T=512, D=4, C=1, M=128, S=2),
+                                   dict(T=1000, D=3, C=2, M=113, S=2), dict(T=200, D=6, C=2, M=40, S=5), dict(T=130, D=2, C=1, M=97, S=7)])
+def test_shapes_forward_and_gradient(shape):
+    """Edge shapes: one tile, no control input, M = 128 (the largest), M = 113 (padded to 128), P = 8 (the largest), T just over a
+    strip boundary.  Forward against the oracle, gradient against the closed form, both also against the multi-kernel schedule."""
+    params, Y, c, meta = synthetic.make_workload(**shape)
+    with engine(meta, grad=True, route="gram") as e:
+        assert single_launch(e) in (4, 8), shape
+        e.set_data(Y, c)
+        t, g = e.nll_and_grad(params)
+        f = e.nll_terms(params)
+    ref = orc.nll_terms_chains(params, Y, c, U_collapse=True)
+    for n in TERMS:
+        assert t[n] == pytest.approx(ref[n], rel=1e-9, abs=1e-10), n
+        assert f[n] == t[n], n
+    want = oracle_grad(params, Y, c)
+    for k in GRAD_KEYS:
+        scale = float(np.max(np.abs(want[k]))) or 1.0
+        tol = 2e-6 if k == "Z" else 1e-7           # dZ: eps * cond(K_uu) in BOTH closed forms
+        assert np.max(np.abs(g[k] - want[k])) < tol * scale, (k, np.max(np.abs(g[k] - want[k])) / scale)
+
+
+def test_equals_the_multi_kernel_schedule(monkeypatch):
+    """The same library with FFVD_NO_TINY=1 (rounds 1-3: 17 / 53 dependent launches on two streams) and the one-launch path give the
+    same nll and the same gradient; four device-resident Adam steps from either path end at the same parameters."""
+    params, Y, c, meta = synthetic.make_named("small")
+    out = {}
+    for mode in ("one", "multi"):
+        if mode == "multi":
+            monkeypatch.setenv("FFVD_NO_TINY", "1")
+        with engine(meta, grad=True, route="gram") as e:
+            assert (single_launch(e) != 0) == (mode == "one")
+            e.set_data(Y, c)
+            t, g = e.nll_and_grad(params)
+            e.set_params(params)
+            for _ in range(4):
+                e.adam_step(0.003)
+            out[mode] = (t, g, e.get_params())
+    monkeypatch.delenv("FFVD_NO_TINY")
+    assert out["one"][0]["nll"] == pytest.approx(out["multi"][0]["nll"], rel=1e-10)
+    for k in GRAD_KEYS:
+        a, b = out["one"][1][k], out["multi"][1][k]
+        assert np.max(np.abs(a - b)) < (5e-6 if k == "Z" else 1e-7) * np.max(np.abs(b)), k
+    for k in GRAD_KEYS:
+        a, b = out["one"][2][k], out["multi"][2][k]
+        assert np.max(np.abs(a - b)) < 1e-6 * max(1.0, np.max(np.abs(b))), k
+
+
+def test_dim_shards_and_uniform_prior():
+    """Latent-dim shards (d_begin / d_count, shared_terms on one shard only) and the chain-count divisor S_total through the one-launch
+    path: the shards' sums and gradient shares add up to the single handle's; prior_type 'uniform' drops prior_Z."""
+    params, Y, c, meta = synthetic.make_workload(T=150, D=4, C=1, M=50, S=3)
+    with engine(meta, grad=True) as e:
+        e.set_data(Y, c)
+        whole_t, whole_g = e.nll_and_grad(params)
+    sums = np.zeros(8)
+    gsum = {k: 0.0 for k in GRAD_KEYS}
+    for d0, dc, shared in ((0, 1, True), (1, 3, False)):
+        with engine(meta, grad=True, d_begin=d0, d_count=dc, shared_terms=shared) as e:
+            assert single_launch(e)
+            e.set_data(Y, c)
+            t, g = e.nll_and_grad(params)
+            sums += t["sums8"]
+            for k in GRAD_KEYS:
+                gsum[k] = gsum[k] + g[k]
+    assert sums[6] / sums[7] == pytest.approx(whole_t["nll"], rel=1e-11)
+    for k in GRAD_KEYS:
+        assert np.max(np.abs(gsum[k] - whole_g[k])) < 1e-9 * max(1e-30, np.max(np.abs(whole_g[k]))), k
+    with engine(meta, grad=True, prior_type="uniform") as e:
+        e.set_data(Y, c)
+        t, g = e.nll_and_grad(params)
+    ref = orc.nll_terms_chains(params, Y, c, U_collapse=True, prior_type="uniform")
+    assert t["nll"] == pytest.approx(ref["nll"], rel=1e-10)
+    want = oracle_grad(params, Y, c, prior_type="uniform")
+    assert np.max(np.abs(g["Z"] - want["Z"])) < 2e-6 * np.max(np.abs(want["Z"]))
+
+
+def test_non_positive_definite_is_reported():
+    """A failed pivot inside the launch surfaces as LinAlgError with the factorisation named (dgp_model.py:320-324 is the reference's
+    counterpart: an error at session.run), and the handle stays usable."""
+    params, Y, c, meta = synthetic.make_named("tiny")
+    bad = dict(params, Z=np.repeat(params["Z"][:1], meta["M"], axis=0))       # identical inducing points ...
+    with engine(meta, jitter=0.0) as e:                                       # ... and no jitter: K_uu is singular
+        e.set_data(Y, c)
+        with pytest.raises(np.linalg.LinAlgError):
+            e.nll_terms(bad)
+    with engine(meta) as e:
+        e.set_data(Y, c)
+        assert np.isfinite(e.nll_terms(params)["nll"])
+
+
+def test_model_loop_runs_on_one_launch_per_step():
+    """RegressionModel.fit -- the loop of models.py:142-182 -- on the actuator fixture lowers the nll; every train_hypers step is one
+    launch + the fused Adam update."""
+    params, Y, c, meta, z = actuator(1)
+    with engine(meta, grad=True) as e:
+        assert single_launch(e)
+        e.set_data(Y, c)
+        e.set_params(params)
+        first = e.adam_step(0.003)["nll"]
+        for _ in range(30):
+            last = e.adam_step(0.003)["nll"]
+    assert last < first
