@@ -134,6 +134,10 @@ VARIANTS = {
     "notail": ["-DGRAM_TAIL_SPLIT=0"],
     "r2gram": ["-DGRAM_COMBO=0", "-DGRAM_TAIL_SPLIT=0"],
     "dftrace_notail": ["-DFFVD_DF_TRACE", "-DGRAM_TAIL_SPLIT=0"],
+    # tiny.hip (the one-launch iteration): wall-clock stamps of every workgroup's phases (tools/tiny_trace.py); a build whose
+    # unit-0 head never publishes W, so that every bounded wait of that launch must give up (tests/test_gpu_tiny.py)
+    "tinytrace": ("tiny.hip", ["-DFFVD_TINY_TRACE"]),
+    "tinystall": ("tiny.hip", ["-DFFVD_TINY_TEST_STALL"]),
 }
 
 
@@ -143,18 +147,20 @@ def build_variant(name, verbose=False):
     build(force=False, verbose=verbose)
     out = variant_path(name)
     stamp = out + ".hash"
-    want = source_hash() + " " + " ".join(VARIANTS[name])
+    spec = VARIANTS[name]
+    source, defines = spec if isinstance(spec, tuple) else ("kernels.hip", spec)
+    want = source_hash() + " " + source + " " + " ".join(defines)
     if os.path.exists(out) and os.path.exists(stamp) and open(stamp).read().strip() == want:
         return out
     cc = hipcc_path()
-    obj = os.path.join(OBJDIR, f"kernels.hip.{name}.o")
-    cmd = [cc] + FLAGS + VARIANTS[name] + ["-c", os.path.join(CSRC, "kernels.hip"), "-o", obj]
+    obj = os.path.join(OBJDIR, f"{source}.{name}.o")
+    cmd = [cc] + FLAGS + defines + ["-c", os.path.join(CSRC, source), "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     proc = subprocess.run(cmd, capture_output=True, text=True)
     if proc.returncode != 0:
-        raise RuntimeError(f"hipcc failed on kernels.hip ({name}):\n" + proc.stdout + proc.stderr)
-    objs = [obj] + [os.path.join(OBJDIR, src + ".o") for src in SOURCES if src != "kernels.hip"]
+        raise RuntimeError(f"hipcc failed on {source} ({name}):\n" + proc.stdout + proc.stderr)
+    objs = [obj] + [os.path.join(OBJDIR, src + ".o") for src in SOURCES if src != source]
     proc = subprocess.run([cc] + objs + LINK + ["-o", out], capture_output=True, text=True)
     if proc.returncode != 0:
         raise RuntimeError(f"hipcc link failed ({name}):\n" + proc.stdout + proc.stderr)

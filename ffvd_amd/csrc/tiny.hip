@@ -35,6 +35,17 @@ constexpr int TNT = TINY_MPMAX / 16;            // tile columns at most
 constexpr int TPP = TINY_PMAX;                  // GP input dimension at most
 constexpr long long TINY_SPIN_TICKS = 100000000LL;   // 1 s of the 100 MHz wall clock
 
+// Debug build only (-DFFVD_TINY_TRACE, tools/tiny_trace.py): wall-clock stamps of every workgroup's phases.
+#ifdef FFVD_TINY_TRACE
+__device__ long long tiny_trace_buf[1024 * 16];
+#define TSTAMP(slot) do { if (threadIdx.x == 0 && blockIdx.x < 1024) tiny_trace_buf[blockIdx.x * 16 + (slot)] = wall_clock64(); } while (0)
+extern "C" int ffvd_debug_tiny_trace(long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tiny_trace_buf), sizeof(long long) * 1024 * 16);
+}
+#else
+#define TSTAMP(slot) do { } while (0)
+#endif
+
 // ---- LDS layout (doubles), shared by host and device ----------------------------------------------------------------------
 struct TinyLds {
     int ctl, red, vec, mat, dinv, sc, xo, zo, misc, total;
@@ -510,6 +521,7 @@ __global__ __launch_bounds__(64 * NW, 1) void tiny_kernel(const TinyArgs a) {
     const size_t msq = (size_t)Mp * Mp;
     double *Wu = a.Wg + (size_t)u * msq, *Wtu = a.Wt + (size_t)u * msq;
 
+    TSTAMP(0);
     if (head) {
         // This iteration's factorisation flags start at zero (a head is the only writer of its words), and the result starts as NaN:
         // a launch that is abandoned on a bounded wait never reaches the workgroup that writes the sums, and a collective caller
@@ -554,13 +566,19 @@ __global__ __launch_bounds__(64 * NW, 1) void tiny_kernel(const TinyArgs a) {
             }
             __syncthreads();
         }
+        TSTAMP(1);
         tiny_chol_inv<NW>(Am, LD, NT, Dinv, Sc, a.info + (s == 0 ? dl : Dl + u));      // (every chain's head factorises the same K_uu)
+        TSTAMP(2);
         for (int e = tid; e < Mp * Mp; e += NTHR) {
             const int i = e / Mp, j = e - i * Mp;
             Wu[e] = tiny_w_elem(Am, LD, Dinv, i, j);                         // row-major W
             Wtu[e] = tiny_w_elem(Am, LD, Dinv, j, i);                        // row-major W^T
         }
+#ifdef FFVD_TINY_TEST_STALL
+        if (u != 0)
+#endif
         tiny_publish(cx.fW, 1);
+        TSTAMP(3);
         // ======================================================================================================================
         // head, phase 1:  H = I + F^T F / Q, b = delta^T F / Q, log|H|, b H^-1 b^T                           (:246-254)
         // ======================================================================================================================
@@ -568,6 +586,7 @@ __global__ __launch_bounds__(64 * NW, 1) void tiny_kernel(const TinyArgs a) {
             if (tid == 0) a.info[Dl + u] = -1;
             return;
         }
+        TSTAMP(4);
         double *bv = lds + L.vec, *yv = bv + Mp, *wl = yv + Mp;
         const double *Pu = a.Pp + (size_t)u * nst * pstride;
         double *Hu = a.Hs + (size_t)u * msq;
@@ -589,7 +608,9 @@ __global__ __launch_bounds__(64 * NW, 1) void tiny_kernel(const TinyArgs a) {
             bv[m] = alpha * v;                                                // :248
         }
         __syncthreads();
+        TSTAMP(5);
         tiny_chol_inv<NW>(Am, LD, NT, Dinv, Sc, a.info + Dl + u);
+        TSTAMP(6);
         for (int j = tid; j < Mp; j += NTHR) {                                // y = L_H^-1 b = W_H^T b
             double acc = 0.0;
             const int jend = (j | 15);
@@ -603,8 +624,10 @@ __global__ __launch_bounds__(64 * NW, 1) void tiny_kernel(const TinyArgs a) {
             tiny_sum<2, NW>(v, red);
             if (tid == 0) { a.hterms[2 * u] = 2.0 * v[0]; a.hterms[2 * u + 1] = v[1]; }     // logdet (:253), b H^-1 b^T (:254)
         }
+        TSTAMP(7);
         if (!a.grad) {
             tiny_unit_done<NW>(a, u, lds, L);
+            TSTAMP(8);
             return;
         }
         // ---- backward: H^-1 = W_H W_H^T, w = W_H y, N = I - H^-1 - w w^T, N2 = N - (H - I), dl/dalpha ------------------------------
@@ -659,6 +682,7 @@ __global__ __launch_bounds__(64 * NW, 1) void tiny_kernel(const TinyArgs a) {
             }
         }
         tiny_publish(cx.fN, 1);
+        TSTAMP(8);
         return;
     }
 
@@ -728,10 +752,12 @@ __global__ __launch_bounds__(64 * NW, 1) void tiny_kernel(const TinyArgs a) {
         }
     }
     wave_lds_order();
+    TSTAMP(1);
     // ==========================================================================================================================
     // strip, phase 1:  F = K_fu W (:242), F^T F, F^T delta, sum F^2 (:255), chain-term partials
     // ==========================================================================================================================
     if (tiny_wait(cx.fW, 1, cx.abort_w, slot) < 0) return;
+    TSTAMP(2);
     d4 facc[TNT];
 #pragma unroll
     for (int j = 0; j < TNT; ++j) facc[j] = (d4){0.0, 0.0, 0.0, 0.0};
@@ -766,6 +792,7 @@ __global__ __launch_bounds__(64 * NW, 1) void tiny_kernel(const TinyArgs a) {
         }
     }
     __syncthreads();
+    TSTAMP(3);
     double *Pu = a.Pp + ((size_t)u * nst + strip) * pstride;
     for (int tau = wave; tau < ntl; tau += NW) {
         int ti, tj;
@@ -807,13 +834,16 @@ __global__ __launch_bounds__(64 * NW, 1) void tiny_kernel(const TinyArgs a) {
         tiny_sum<3, NW>(v, red);
         if (tid == 0) { double *sc = Pu + ntl * 256 + Mp; sc[0] = v[0]; sc[1] = v[1]; sc[2] = v[2]; }
     }
+    TSTAMP(4);
     const int before = tiny_arrive(cx.cP, slot);
     (void)before;
+    TSTAMP(5);
     if (!a.grad) return;
     // ==========================================================================================================================
     // strip, phase 2 (backward):  dl/dK_fu = alpha (F N + delta w^T) W^T,  E = dl/dK_fu o K_fu,  its reductions
     // ==========================================================================================================================
     if (tiny_wait(cx.fN, 1, cx.abort_w, slot) < 0) return;
+    TSTAMP(6);
     double *wl = lds + L.vec;
     double *XO = lds + L.xo, *ZO = lds + L.zo;
     for (int m = tid; m < Mp; m += NTHR) wl[m] = a.wv[(size_t)u * Mp + m];
@@ -883,6 +913,7 @@ __global__ __launch_bounds__(64 * NW, 1) void tiny_kernel(const TinyArgs a) {
             }
         }
     wave_lds_order();
+    TSTAMP(7);
     // row side: [r | E Z] = E [1 | Z]   (16 rows of this wavefront x 16 columns)
     double *part = rowv;                                                      // [NW][16] per-wavefront partials of sum_t r_t x_tp^2 and sum E
     {
@@ -940,6 +971,7 @@ __global__ __launch_bounds__(64 * NW, 1) void tiny_kernel(const TinyArgs a) {
         }
         __syncthreads();
     }
+    TSTAMP(8);
     // K_uu side, one 16-row block per strip:  Psi = 1/2 W N2 W^T (dl/dK_uu),  E_u = Psi o K(Z,Z),  row sums and E_u Z
     for (int rb = strip; rb < NT; rb += nst) {
         double *T1 = Ks;                                                      // [16][LD]
@@ -1015,8 +1047,11 @@ __global__ __launch_bounds__(64 * NW, 1) void tiny_kernel(const TinyArgs a) {
         }
         __syncthreads();
     }
+    TSTAMP(9);
     if (tiny_arrive(cx.c2, slot) != nst - 1) return;
+    TSTAMP(10);
     tiny_unit_done<NW>(a, u, lds, L);
+    TSTAMP(11);
 }
 
 // ---- host side --------------------------------------------------------------------------------------------------------------------

@@ -127,7 +127,8 @@ def test_dataflow_cholesky_gives_up_instead_of_hanging(tmp_path):
     # kernels.hip; a no-op when its recorded source hash is current) and a box without hipcc FAILS the test
     lib_path = fb.build_variant("dfstall")
     assert os.path.exists(lib_path)
-    env = dict(os.environ, FFVD_LIB=lib_path, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, FFVD_LIB=lib_path, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+               FFVD_NO_TINY="1")           # the handle part exercises the dataflow Cholesky of the multi-kernel schedule
     env.pop("FFVD_CHOL", None)
     t0 = time.perf_counter()
     zpath = str(tmp_path / "dz.npy")

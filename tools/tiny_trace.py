@@ -1,0 +1,42 @@
+"""Wall-clock stamps of every workgroup of the one-launch iteration (tiny.hip, debug build `python -m ffvd_amd.build --tinytrace`):
+head / strip phases in microseconds since the earliest stamp of the launch.  GPU box.  usage: tiny_trace.py [forward|train] [S]"""
+import ctypes as ct, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from ffvd_amd import build as fb
+os.environ["FFVD_LIB"] = fb.build_variant("tinytrace")
+import numpy as np
+from ffvd_amd.engine import ElboEngine
+z = np.load(os.path.join(ROOT, "tests", "golden", "actuator_slim.npz"), allow_pickle=False)
+params = {k: z[k] for k in ("X", "Z", "U", "logvariance", "loglengthscales", "log_Q", "CC", "DD", "log_Rchols")}
+Y, c = z["Y"], z["control_inputs"]
+T, D = params["X"].shape[0] - 1, params["X"].shape[1]
+M, C = params["Z"].shape[0], c.shape[1]
+grad = len(sys.argv) > 1 and sys.argv[1] == "train"
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+params["X"] = np.repeat(params["X"][None], S, axis=0) + 1e-3 * np.random.default_rng(0).standard_normal((S,) + params["X"].shape)
+e = ElboEngine(T, D, C, M, S, grad=grad)
+e.set_data(Y, c); e.set_params(params)
+f = (lambda: e.adam_step(1e-9)) if grad else (lambda: e.nll_terms())
+for _ in range(5): f()
+buf = (ct.c_longlong * (1024 * 16))()
+e.lib.ffvd_debug_tiny_trace.argtypes = [ct.c_void_p]
+assert e.lib.ffvd_debug_tiny_trace(buf) == 0
+a = np.array(buf[:]).reshape(1024, 16)
+nunits = S * D
+nst = (T + 63) // 64 if int(e.lib.ffvd_single_launch(e._h)) == 4 else (T + 127) // 128
+nwg = nunits * (1 + nst)
+a = a[:nwg].astype(np.float64)
+t0 = a[a > 0].min()
+us = np.where(a > 0, (a - t0) / 100.0, np.nan)
+names_h = ["start", "K built", "chol(K) done", "W published", "strips in", "H summed", "chol(H) done", "terms", "done"]
+names_s = ["start", "K_fu built", "W seen", "F in LDS", "partials out", "counted", "N seen", "E ready", "reduced", "K_uu rows", "last strip", "closed"]
+print("mode", "train" if grad else "forward", "S", S, "workgroups", nwg, "wavefronts/wg", int(e.lib.ffvd_single_launch(e._h)))
+print("heads (us):")
+for u in range(min(nunits, 8)):
+    print("  u%-3d" % u, " ".join("%s=%.1f" % (n, us[u, i]) for i, n in enumerate(names_h) if not np.isnan(us[u, i])))
+print("strips of unit 0 (us):")
+for i in range(nst):
+    r = us[nunits + i]
+    print("  s%-3d" % i, " ".join("%s=%.1f" % (n, r[k]) for k, n in enumerate(names_s) if not np.isnan(r[k])))
+print("span of the launch: %.1f us" % np.nanmax(us))
