@@ -111,14 +111,15 @@ __device__ __forceinline__ void block_sum_multi(double (&v)[N], double (*scratch
     }
 }
 
+// Two halves: the ten parameter-only sums (finalize_priors: every thread returns with the totals), and the per-chain assembly on
+// them (finalize_assemble).  finalize_kernel runs one after the other; the small-problem kernel forms the sums early, in a
+// workgroup that is waiting anyway.
 template <int NTHR>
-__device__ __forceinline__ void finalize_body(const FinalizeArgs &a, double (*scratch)[10] /*[NTHR / 64][10]*/) {
+__device__ __forceinline__ void finalize_priors(const FinalizeArgs &a, double (*scratch)[10] /*[NTHR / 64][10]*/, double (&sm)[10]) {
     const int tid = threadIdx.x;
-    const double Tn = (double)a.T;      // batch_size == Y_N == T for the full batch (dgp_model.py:261-262)
     // shared priors and constants: ten small sums, every thread takes a strided share, one reduction for all
     // 0 |Z|^2  1 |U|^2  2 sum loglen^2  3 sum (logvar - log 0.05)^2  4 |log_Q|^2  5 |C|^2  6 |d|^2  7 |log_Rchols|^2
     // 8 sum_j log R_j  9 sum_d log sqrt(Q_d)
-    double sm[10];
 #pragma unroll
     for (int i = 0; i < 10; ++i) sm[i] = 0.0;
     if (a.shared_terms && a.prior_type == 1)
@@ -147,6 +148,12 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs &a, double (*sc
     }
     for (int j = tid; j < a.Ydim; j += NTHR) sm[8] += log(exp(a.log_Rchols[j]));    // -reduce_sum(log(Rchols)) likelihoods.py:101
     block_sum_multi<10, NTHR / 64>(sm, scratch);
+}
+
+template <int NTHR>
+__device__ __forceinline__ void finalize_assemble(const FinalizeArgs &a, double (*scratch)[10] /*[NTHR / 64][10]*/, const double (&sm)[10]) {
+    const int tid = threadIdx.x;
+    const double Tn = (double)a.T;      // batch_size == Y_N == T for the full batch (dgp_model.py:261-262)
     const double prior_hyper = -sm[2] / 2.0 - sm[3] / 2.0;
     const double hyp = a.shared_terms ? (-sm[4] / 2.0 - sm[5] / 2.0 - sm[6] / 2.0 - sm[7] / 2.0) : 0.0;
     const double prior_z = (a.shared_terms && a.prior_type == 1) ? -sm[0] / 2.0 : 0.0;     // prior_Z dgp_model.py:108-109
@@ -202,6 +209,13 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs &a, double (*sc
     for (int i = 0; i < 7; ++i)
         if (tid == i) a.out_terms[i] = part[i];
     if (tid == 7) a.out_terms[7] = a.shared_terms ? (double)a.S : 0.0;
+}
+
+template <int NTHR>
+__device__ __forceinline__ void finalize_body(const FinalizeArgs &a, double (*scratch)[10] /*[NTHR / 64][10]*/) {
+    double sm[10];
+    finalize_priors<NTHR>(a, scratch, sm);
+    finalize_assemble<NTHR>(a, scratch, sm);
 }
 
 }  // namespace ffvd

@@ -24,11 +24,13 @@ struct TinyArgs {
     double *hterms;                 // [nunits][2]      log|H|, b^T H^-1 b   (FinalizeArgs::hterms)
     double *uterms;                 // [nunits][8]      backward scalars of a unit: 0 dl/dalpha
     double *Qp;                     // [nunits][nstrips][qstride]  backward: per-strip column sums / E^T x / r x^2 partials
+    double *Kst;                    // [nunits][nstrips][threads][32]  backward: each lane's K_fu elements (accumulator layout) parked in L2
     double *dxc;                    // [nunits][Tp][P + 1]  backward: rows of dl/dx_comb (p < P) and dl/ddelta (slot P)
     double *dz2;                    // [nunits][Mp][TINY_PMAX] K_uu side: rows of dl/dZ;  kuu_part [nunits][NT][TINY_PMAX + 1]
     double *kuu_part;
     double *unit_out;               // [nunits][M*P + P + 2]  per-unit totals: dl/dZ, dl/dloglen, dl/dlogvar-part
     double *chain_terms;            // [S][8]
+    double *prior_sums;             // [16] the ten parameter-only sums of the nll assembly (finalize_priors), formed early by head 0
     double *chain_part;             // [S][sp_stride]  backward: dCC, dDD, dlog_Rchols row 0, transition part of dlog_Q per local dim
     int sp_stride;
     int *flags;                     // [nunits*4 + S + 8] hand-off words, all zero between launches (the last workgroup re-arms them)

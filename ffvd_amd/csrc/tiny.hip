@@ -37,10 +37,10 @@ constexpr long long TINY_SPIN_TICKS = 100000000LL;   // 1 s of the 100 MHz wall 
 
 // Debug build only (-DFFVD_TINY_TRACE, tools/tiny_trace.py): wall-clock stamps of every workgroup's phases.
 #ifdef FFVD_TINY_TRACE
-__device__ long long tiny_trace_buf[1024 * 16];
-#define TSTAMP(slot) do { if (threadIdx.x == 0 && blockIdx.x < 1024) tiny_trace_buf[blockIdx.x * 16 + (slot)] = wall_clock64(); } while (0)
+__device__ long long tiny_trace_buf[1024 * 32];
+#define TSTAMP(slot) do { if (threadIdx.x == 0 && blockIdx.x < 1024) tiny_trace_buf[blockIdx.x * 32 + (slot)] = wall_clock64(); } while (0)
 extern "C" int ffvd_debug_tiny_trace(long long *out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tiny_trace_buf), sizeof(long long) * 1024 * 16);
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tiny_trace_buf), sizeof(long long) * 1024 * 32);
 }
 #else
 #define TSTAMP(slot) do { } while (0)
@@ -48,7 +48,7 @@ extern "C" int ffvd_debug_tiny_trace(long long *out) {
 
 // ---- LDS layout (doubles), shared by host and device ----------------------------------------------------------------------
 struct TinyLds {
-    int ctl, red, vec, mat, dinv, sc, xo, zo, misc, total;
+    int ctl, tab, red, vec, mat, dinv, sc, xo, zo, misc, total;
 };
 // ctl / red / vec / mat are common to both roles; behind them the head keeps (dinv, sc) and a strip (xo, zo, misc) in the SAME
 // space: a workgroup is one or the other (and a closer uses the common part only).
@@ -57,6 +57,7 @@ __host__ __device__ inline TinyLds tiny_lds(int Mp, int SR) {
     const int LD = Mp + 1, NT = Mp / 16;
     int o = 0;
     l.ctl = o;  o += 8;                         // ints: wait slot, arrive slot
+    l.tab = o;  o += 32;                        // ints: (i, j) of the lower-triangular tiles (<= 36 ints = 18 doubles), the lengthscales [8] behind them
     l.red = o;  o += 8 * 24;                    // reduction scratch [<= 8 wavefronts][<= 24 values]
     l.vec = o;  o += 4 * Mp;                    // head: b, y, w;  strip: w;  closer: column sums
     l.mat = o;                                  // head: the matrix being factorised [Mp][LD];  strip: K_fu / F / R / E rows [SR][LD]
@@ -253,6 +254,7 @@ __device__ __forceinline__ void tiny_chol_inv(double *Am, const int LD, const in
                 if (idx % (NW - 1) == wave - 1) tiny_tile_solve(Am, LD, Dinv, s, e, true, lane);
         }
         __syncthreads();
+        TSTAMP(18 + (s < 8 ? s : 7));
     }
     if (wave == 0 && lane == 0 && bad && *info_word == 0) *info_word = bad;
 }
@@ -283,6 +285,17 @@ __device__ __forceinline__ TinyCtx tiny_ctx(const TinyArgs &a, int u, int s) {
     c.call = a.flags + 4 * a.nunits + a.S;
     c.abort_w = c.call + 1;
     return c;
+}
+
+__device__ __forceinline__ FinalizeArgs tiny_finalize_args(const TinyArgs &a) {
+    FinalizeArgs fa{};
+    fa.kind = a.kind; fa.branch = 1; fa.prior_type = a.prior_type; fa.shared_terms = a.shared_terms;
+    fa.T = a.T; fa.D = a.D; fa.P = a.P; fa.M = a.M; fa.Ydim = a.Ydim; fa.Dl = a.Dl; fa.d_begin = a.d_begin; fa.S = a.S;
+    fa.Z = a.Z; fa.U = nullptr; fa.logvar = a.logvar; fa.loglen = a.loglen; fa.log_Q = a.log_Q; fa.CC = a.CC; fa.DD = a.DD;
+    fa.log_Rchols = a.logR; fa.chain_terms = a.chain_terms; fa.hterms = a.hterms; fa.route = 0; fa.kterms = nullptr;
+    fa.whitened = 0; fa.trpart = nullptr; fa.ntiles = 0; fa.fsq_from_trpart = 0; fa.chain_nll = a.chain_nll;
+    fa.out_terms = a.out_terms; fa.info = a.info; fa.ninfo = a.Dl + a.nunits;
+    return fa;
 }
 
 // Everything of unit u is in memory.  The workgroup that completes a chain forms that chain's sums; the one that completes the
@@ -331,7 +344,9 @@ __device__ void tiny_unit_done(const TinyArgs &a, const int u, double *lds, cons
             for (int st = 0; st < nst; ++st) v += Qu[(size_t)st * qstride + 16 * Mp + tid];      // sum_t r_t x_tp^2
             double k2 = 0.0;
             for (int rb = 0; rb < a.NT; ++rb) k2 += a.kuu_part[((size_t)u * a.NT + rb) * (TPP + 1) + tid];
-            acc[tid] += v * inv2 + k2;
+#pragma unroll
+            for (int p = 0; p < TPP; ++p)
+                if (tid == p) acc[p] += v * inv2 + k2;                       // (compile-time indices: the array stays in registers)
         }
         if (tid == 0) {
             double v = 0.0;
@@ -340,19 +355,20 @@ __device__ void tiny_unit_done(const TinyArgs &a, const int u, double *lds, cons
             acc[TPP] = v;
         }
         tiny_sum<TPP + 1, NW>(acc, red);
-        if (tid < P) uo[M * P + tid] = acc[tid];
+#pragma unroll
+        for (int p = 0; p < TPP; ++p)
+            if (tid == p && p < P) uo[M * P + p] = acc[p];
         if (tid == 0) uo[M * P + P] = acc[TPP];
     }
     if (tiny_arrive(cx.cchain, slot) != Dl - 1) return;
     // ---- chain s is complete: its likelihood / transition / trace sums (chain_reduce_kernel), prior_x_0 ------------------------
     {
         double v[3] = {0.0, 0.0, 0.0};
-        if (tid == 0)
-            for (int dl = 0; dl < Dl; ++dl)
-                for (int st = 0; st < nst; ++st) {
-                    const double *sc = a.Pp + ((size_t)(s * Dl + dl) * nst + st) * pstride + ntl * 256 + Mp;
-                    v[0] += sc[2]; v[1] += sc[0]; v[2] += sc[1];
-                }
+        for (int i = tid; i < Dl * nst; i += NTHR) {
+            const double *sc = a.Pp + ((size_t)s * Dl * nst + i) * pstride + ntl * 256 + Mp;
+            v[0] += sc[2]; v[1] += sc[0]; v[2] += sc[1];
+        }
+        tiny_sum<3, NW>(v, red);
         if (tid == 0) {
             const double *Xs = a.X + (size_t)s * (T + 1) * D;
             double px0 = 0.0;
@@ -430,14 +446,11 @@ __device__ void tiny_unit_done(const TinyArgs &a, const int u, double *lds, cons
     if (tiny_arrive(cx.call, slot) != a.S - 1) return;
     // ---- the launch is complete: nll assembly, shared-parameter gradients, flags re-armed ----------------------------------------
     {
-        FinalizeArgs fa{};
-        fa.kind = a.kind; fa.branch = 1; fa.prior_type = a.prior_type; fa.shared_terms = a.shared_terms;
-        fa.T = T; fa.D = D; fa.P = P; fa.M = M; fa.Ydim = J; fa.Dl = Dl; fa.d_begin = a.d_begin; fa.S = a.S;
-        fa.Z = a.Z; fa.U = nullptr; fa.logvar = a.logvar; fa.loglen = a.loglen; fa.log_Q = a.log_Q; fa.CC = a.CC; fa.DD = a.DD;
-        fa.log_Rchols = a.logR; fa.chain_terms = a.chain_terms; fa.hterms = a.hterms; fa.route = 0; fa.kterms = nullptr;
-        fa.whitened = 0; fa.trpart = nullptr; fa.ntiles = 0; fa.fsq_from_trpart = 0; fa.chain_nll = a.chain_nll;
-        fa.out_terms = a.out_terms; fa.info = a.info; fa.ninfo = Dl + a.nunits;
-        finalize_body<NTHR>(fa, reinterpret_cast<double(*)[10]>(red));
+        const FinalizeArgs fa = tiny_finalize_args(a);
+        double sm[10];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) sm[i] = a.prior_sums[i];                 // formed by head 0 while it waited for its strips
+        finalize_assemble<NTHR>(fa, reinterpret_cast<double(*)[10]>(red), sm);
         __syncthreads();
     }
     if (a.grad) {
@@ -499,8 +512,50 @@ __device__ void tiny_unit_done(const TinyArgs &a, const int u, double *lds, cons
 }
 
 // ---- the kernel ---------------------------------------------------------------------------------------------------------------
+// B fragments of one k step of a row-panel product C(16 rows x Mp) += A(16 x 16 k-block) B(k-block, :), straight from L2 into
+// registers one step ahead of their use: b[j][t] = B[(16 k + 4 t + lk)][16 j + lr] for the column tiles j in [jlo, jhi).
+__device__ __forceinline__ void tiny_load_b(double (&b)[TNT][4], const double *B, const int Mp, const int k, const int jlo, const int jhi,
+                                            const int lr, const int lk) {
+#pragma unroll
+    for (int j = 0; j < TNT; ++j)
+        if (j >= jlo && j < jhi) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) b[j][t] = B[(size_t)(16 * k + 4 * t + lk) * Mp + 16 * j + lr];
+        }
+}
+__device__ __forceinline__ void tiny_mma_row(d4 (&acc)[TNT], const double *Arow /* &A[16w + lr][0] in LDS */, const double (&b)[TNT][4],
+                                             const int k, const int jlo, const int jhi, const int lk) {
+    double av[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) av[t] = Arow[16 * k + 4 * t + lk];
+#pragma unroll
+    for (int j = 0; j < TNT; ++j)
+        if (j >= jlo && j < jhi) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[j] = mfma_f64(av[t], b[j][t], acc[j]);
+        }
+}
+// acc(16 x Mp) = A(16 x Mp, LDS rows) B(Mp x Mp, L2), B's tile (k, j) taken for j in [jlo(k), jhi(k)):
+//   MODE 0: all j;  MODE 1: j >= k (B upper triangular by tiles);  MODE 2: j <= k (lower).
+template <int MODE>
+__device__ __forceinline__ void tiny_row_gemm(d4 (&acc)[TNT], const double *Arow, const double *B, const int Mp, const int NT,
+                                              const int lr, const int lk) {
+    double b0[TNT][4], b1[TNT][4];
+    auto lo = [&](int k) { return MODE == 1 ? k : 0; };
+    auto hi = [&](int k) { return MODE == 2 ? k + 1 : NT; };
+    tiny_load_b(b0, B, Mp, 0, lo(0), hi(0), lr, lk);
+    for (int k = 0; k < NT; k += 2) {
+        if (k + 1 < NT) tiny_load_b(b1, B, Mp, k + 1, lo(k + 1), hi(k + 1), lr, lk);
+        tiny_mma_row(acc, Arow, b0, k, lo(k), hi(k), lk);
+        if (k + 1 < NT) {
+            if (k + 2 < NT) tiny_load_b(b0, B, Mp, k + 2, lo(k + 2), hi(k + 2), lr, lk);
+            tiny_mma_row(acc, Arow, b1, k + 1, lo(k + 1), hi(k + 1), lk);
+        }
+    }
+}
+
 template <int NW>
-__global__ __launch_bounds__(64 * NW, 1) void tiny_kernel(const TinyArgs a) {
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void tiny_kernel(const TinyArgs a) {      // (<= 256 registers: the MFMAs take VGPR accumulators, no AGPR copies)
     constexpr int NTHR = 64 * NW, SR = 16 * NW;
     extern __shared__ double lds[];
     const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
@@ -509,6 +564,8 @@ __global__ __launch_bounds__(64 * NW, 1) void tiny_kernel(const TinyArgs a) {
     const int LD = Mp + 1, ntl = tiny_ntl(NT), pstride = tiny_pstride(Mp);
     const TinyLds L = tiny_lds(Mp, SR);
     int *slot = reinterpret_cast<int *>(lds + L.ctl);
+    int *tab = reinterpret_cast<int *>(lds + L.tab);
+    double *ilen = lds + L.tab + 18;                                         // [8] lengthscales (1 where p >= P)
     double *red = lds + L.red;
     double *Am = lds + L.mat;
     const bool head = (int)blockIdx.x < a.nunits;
@@ -520,8 +577,14 @@ __global__ __launch_bounds__(64 * NW, 1) void tiny_kernel(const TinyArgs a) {
     const double Qd = exp(a.log_Q[dg]), alpha = 1.0 / Qd;
     const size_t msq = (size_t)Mp * Mp;
     double *Wu = a.Wg + (size_t)u * msq, *Wtu = a.Wt + (size_t)u * msq;
-
     TSTAMP(0);
+    for (int tau = tid; tau < ntl; tau += NTHR) {
+        int ti, tj;
+        tiny_tile_ij(tau, ti, tj);
+        tab[tau] = ti | (tj << 8);
+    }
+    if (tid < 8) ilen[tid] = (tid < P) ? exp(a.loglen[(size_t)dg * P + tid]) : 1.0;      // :161
+
     if (head) {
         // This iteration's factorisation flags start at zero (a head is the only writer of its words), and the result starts as NaN:
         // a launch that is abandoned on a bounded wait never reaches the workgroup that writes the sums, and a collective caller
@@ -537,28 +600,37 @@ __global__ __launch_bounds__(64 * NW, 1) void tiny_kernel(const TinyArgs a) {
         double (*Dinv)[16][17] = reinterpret_cast<double(*)[16][17]>(lds + L.dinv);
         double (*Sc)[17] = reinterpret_cast<double(*)[17]>(lds + L.sc);
         {
-            double *zs = lds + L.dinv, *zz = zs + (size_t)Mp * 8;           // aliases Dinv: dead before the factorisation starts
-            for (int e = tid; e < Mp * 8; e += NTHR) {
-                const int m = e >> 3, p = e & 7;
-                zs[e] = (m < M && p < P) ? a.Z[(size_t)m * P + p] / exp(a.loglen[(size_t)dg * P + p]) : 0.0;     // :161, :170
+            double *zs = lds + L.dinv, *zz = zs + (size_t)Mp * 9;           // aliases Dinv: dead before the factorisation starts.  Row stride 9:
+                                                                             // 16 lanes reading 16 consecutive rows hit 16 different banks
+            __syncthreads();
+            TSTAMP(16);
+            {
+                const int p = tid & 7;                                       // (NTHR is a multiple of 8: a thread keeps its component)
+                const double len = ilen[p];
+                for (int e = tid; e < Mp * 8; e += NTHR) {
+                    const int m = e >> 3;
+                    zs[m * 9 + p] = (m < M && p < P) ? a.Z[(size_t)m * P + p] / len : 0.0;   // :170
+                }
             }
             __syncthreads();
             for (int m = tid; m < Mp; m += NTHR) {
                 double sacc = 0.0;
 #pragma unroll
-                for (int p = 0; p < 8; ++p) sacc += zs[m * 8 + p] * zs[m * 8 + p];
+                for (int p = 0; p < 8; ++p) sacc += zs[m * 9 + p] * zs[m * 9 + p];
                 zz[m] = sacc;
             }
             __syncthreads();
-            for (int e = tid; e < Mp * Mp; e += NTHR) {
-                const int i = e / Mp, j = e - i * Mp;
-                if (j > i) continue;
+            TSTAMP(17);
+#pragma unroll 4
+            for (int idx = tid; idx < ntl * 256; idx += NTHR) {              // lower-triangular tiles only (one wavefront per SIMD: independent elements interleaved)
+                const int tt = tab[idx >> 8], e = idx & 255;
+                const int i = 16 * (tt & 255) + (e >> 4), j = 16 * (tt >> 8) + (e & 15);
                 double v;
                 if (i >= M || j >= M) v = (i == j) ? 1.0 : 0.0;
                 else {
                     double dot = 0.0;
 #pragma unroll
-                    for (int p = 0; p < 8; ++p) dot += zs[i * 8 + p] * zs[j * 8 + p];
+                    for (int p = 0; p < 8; ++p) dot += zs[i * 9 + p] * zs[j * 9 + p];
                     v = kernel_value<0>(dot, zz[i], zz[j], var);
                     if (i == j) v += a.jitter;                               // :159
                 }
@@ -569,16 +641,34 @@ __global__ __launch_bounds__(64 * NW, 1) void tiny_kernel(const TinyArgs a) {
         TSTAMP(1);
         tiny_chol_inv<NW>(Am, LD, NT, Dinv, Sc, a.info + (s == 0 ? dl : Dl + u));      // (every chain's head factorises the same K_uu)
         TSTAMP(2);
-        for (int e = tid; e < Mp * Mp; e += NTHR) {
-            const int i = e / Mp, j = e - i * Mp;
-            Wu[e] = tiny_w_elem(Am, LD, Dinv, i, j);                         // row-major W
-            Wtu[e] = tiny_w_elem(Am, LD, Dinv, j, i);                        // row-major W^T
+        // W (tiles on and above the block diagonal) and W^T (on and below) to L2: the strips read nothing else of them
+        for (int j = lane; j < Mp; j += 64) {
+            const int tj = j >> 4;
+#pragma unroll 4
+            for (int i = wave; i < 16 * tj; i += NW) Wu[(size_t)i * Mp + j] = Am[(size_t)i * LD + j];                 // W(i, j), tile row above the diagonal
+#pragma unroll 4
+            for (int i = 16 * tj + wave; i < 16 * tj + 16; i += NW) {
+                Wu[(size_t)i * Mp + j] = Dinv[tj][i & 15][j & 15];
+                Wtu[(size_t)i * Mp + j] = Dinv[tj][j & 15][i & 15];
+            }
+#pragma unroll 4
+            for (int i = 16 * (tj + 1) + wave; i < Mp; i += NW) Wtu[(size_t)i * Mp + j] = Am[(size_t)j * LD + i];     // W^T(i, j) = W(j, i)
         }
+        TSTAMP(26);
 #ifdef FFVD_TINY_TEST_STALL
         if (u != 0)
 #endif
         tiny_publish(cx.fW, 1);
         TSTAMP(3);
+        if (u == 0) {                                                         // the ten parameter-only sums of the nll assembly, while the strips work
+            const FinalizeArgs fa = tiny_finalize_args(a);
+            double sm[10];
+            finalize_priors<NTHR>(fa, reinterpret_cast<double(*)[10]>(red), sm);
+#pragma unroll
+            for (int i = 0; i < 10; ++i)
+                if (tid == i) a.prior_sums[i] = sm[i];
+            __syncthreads();
+        }
         // ======================================================================================================================
         // head, phase 1:  H = I + F^T F / Q, b = delta^T F / Q, log|H|, b H^-1 b^T                           (:246-254)
         // ======================================================================================================================
@@ -590,38 +680,68 @@ __global__ __launch_bounds__(64 * NW, 1) void tiny_kernel(const TinyArgs a) {
         double *bv = lds + L.vec, *yv = bv + Mp, *wl = yv + Mp;
         const double *Pu = a.Pp + (size_t)u * nst * pstride;
         double *Hu = a.Hs + (size_t)u * msq;
-        for (int tau = 0; tau < ntl; ++tau) {
-            int ti, tj;
-            tiny_tile_ij(tau, ti, tj);
-            for (int e = tid; e < 256; e += NTHR) {
-                double v = 0.0;
-                for (int st = 0; st < nst; ++st) v += Pu[(size_t)st * pstride + tau * 256 + e];
-                const int m = e >> 4, n = e & 15, gi = 16 * ti + m, gj = 16 * tj + n;
-                const double hv = alpha * v;                                  // batch_size == Y_N: the factor Y_N / batch is 1 (:246)
-                Am[(size_t)gi * LD + gj] = hv + ((gi == gj) ? 1.0 : 0.0);
-                if (a.grad) { Hu[(size_t)gi * Mp + gj] = hv; Hu[(size_t)gj * Mp + gi] = hv; }
+        double trHm = 0.0;                                                    // tr(H - I), this thread's share
+        {
+            // the strips' partial blocks are contiguous vectors: [ntl tiles of 256 | Mp]; two elements per load, four loads
+            // per strip in flight ahead of the adds
+            const int total2 = (ntl * 256 + Mp) / 2;
+            for (int base = 0; base < total2; base += 4 * NTHR) {
+                double2 acc[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = make_double2(0.0, 0.0);
+                for (int st0 = 0; st0 < nst; st0 += 8) {                      // 32 loads in flight, then their adds in fixed order
+                    double2 v[8][4];
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) {
+                        const double2 *src = reinterpret_cast<const double2 *>(Pu + (size_t)(st0 + g) * pstride);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int i2 = base + q * NTHR + tid;
+                            v[g][q] = (st0 + g < nst && i2 < total2) ? src[i2] : make_double2(0.0, 0.0);
+                        }
+                    }
+#pragma unroll
+                    for (int g = 0; g < 8; ++g)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { acc[q].x += v[g][q].x; acc[q].y += v[g][q].y; }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i2 = base + q * NTHR + tid;
+                    if (i2 >= total2) continue;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int idx = 2 * i2 + h;
+                        const double v = alpha * (h ? acc[q].y : acc[q].x);   // batch_size == Y_N: the factor Y_N / batch is 1 (:246)
+                        if (idx >= ntl * 256) { bv[idx - ntl * 256] = v; continue; }          // :248
+                        const int tt = tab[idx >> 8], e = idx & 255;
+                        const int gi = 16 * (tt & 255) + (e >> 4), gj = 16 * (tt >> 8) + (e & 15);
+                        Am[(size_t)gi * LD + gj] = v + ((gi == gj) ? 1.0 : 0.0);
+                        if (gi == gj) trHm += v;
+                        if (a.grad) { Hu[(size_t)gi * Mp + gj] = v; Hu[(size_t)gj * Mp + gi] = v; }
+                    }
+                }
             }
-        }
-        for (int m = tid; m < Mp; m += NTHR) {
-            double v = 0.0;
-            for (int st = 0; st < nst; ++st) v += Pu[(size_t)st * pstride + ntl * 256 + m];
-            bv[m] = alpha * v;                                                // :248
         }
         __syncthreads();
         TSTAMP(5);
         tiny_chol_inv<NW>(Am, LD, NT, Dinv, Sc, a.info + Dl + u);
         TSTAMP(6);
         for (int j = tid; j < Mp; j += NTHR) {                                // y = L_H^-1 b = W_H^T b
-            double acc = 0.0;
-            const int jend = (j | 15);
-            for (int i = 0; i <= jend && i < Mp; ++i) acc += tiny_w_elem(Am, LD, Dinv, i, j) * bv[i];
-            yv[j] = acc;
+            const int tj = j >> 4;
+            double acc0 = 0.0, acc1 = 0.0;
+            for (int i = 0; i + 1 < 16 * tj; i += 2) { acc0 += Am[(size_t)i * LD + j] * bv[i]; acc1 += Am[(size_t)(i + 1) * LD + j] * bv[i + 1]; }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc0 += Dinv[tj][i][j & 15] * bv[16 * tj + i];
+            yv[j] = acc0 + acc1;
         }
         __syncthreads();
+        double quad;
         {
             double v[2] = {0.0, 0.0};
             for (int i = tid; i < Mp; i += NTHR) { v[0] += log(Am[(size_t)i * LD + i]); v[1] += yv[i] * yv[i]; }
             tiny_sum<2, NW>(v, red);
+            quad = v[1];
             if (tid == 0) { a.hterms[2 * u] = 2.0 * v[0]; a.hterms[2 * u + 1] = v[1]; }     // logdet (:253), b H^-1 b^T (:254)
         }
         TSTAMP(7);
@@ -630,20 +750,21 @@ __global__ __launch_bounds__(64 * NW, 1) void tiny_kernel(const TinyArgs a) {
             TSTAMP(8);
             return;
         }
-        // ---- backward: H^-1 = W_H W_H^T, w = W_H y, N = I - H^-1 - w w^T, N2 = N - (H - I), dl/dalpha ------------------------------
+        // ---- backward: H^-1 = W_H W_H^T, w = W_H y, N = I - H^-1 - w w^T, dl/dalpha ------------------------------------------------
         for (int i = tid; i < Mp; i += NTHR) {
-            double acc = 0.0;
-            for (int k = (i & ~15); k < Mp; ++k) acc += tiny_w_elem(Am, LD, Dinv, i, k) * yv[k];
-            wl[i] = acc;
-            a.wv[(size_t)u * Mp + i] = acc;
+            const int ti = i >> 4;
+            double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc0 += Dinv[ti][i & 15][k] * yv[16 * ti + k];
+            for (int k = 16 * (ti + 1); k + 1 < Mp; k += 2) { acc0 += Am[(size_t)i * LD + k] * yv[k]; acc1 += Am[(size_t)i * LD + k + 1] * yv[k + 1]; }
+            wl[i] = acc0 + acc1;
+            a.wv[(size_t)u * Mp + i] = acc0 + acc1;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // H - I (written above) is read back below
         __syncthreads();
-        double *Nu = a.Nw + (size_t)u * msq, *N2u = a.Nm2 + (size_t)u * msq;
+        double *Nu = a.Nw + (size_t)u * msq;
         double trhinv = 0.0;
         for (int tau = wave; tau < ntl; tau += NW) {
-            int ti, tj;
-            tiny_tile_ij(tau, ti, tj);
+            const int ti = tab[tau] & 255, tj = tab[tau] >> 8;
             d4 a0 = (d4){0.0, 0.0, 0.0, 0.0}, a1 = a0;
             for (int k = ti; k < NT; ++k) {
 #pragma unroll
@@ -659,27 +780,22 @@ __global__ __launch_bounds__(64 * NW, 1) void tiny_kernel(const TinyArgs a) {
                 const int gi = 16 * ti + lk + 4 * r, gj = 16 * tj + lr;
                 const double hinv = a0[r] + a1[r];
                 const double nw = ((gi == gj) ? 1.0 : 0.0) - hinv - wl[gi] * wl[gj];
-                const double n2 = nw - Hu[(size_t)gi * Mp + gj];
-                Nu[(size_t)gi * Mp + gj] = nw; N2u[(size_t)gi * Mp + gj] = n2;
-                if (ti != tj) { Nu[(size_t)gj * Mp + gi] = nw; N2u[(size_t)gj * Mp + gi] = n2; }
+                Nu[(size_t)gi * Mp + gj] = nw;
+                if (ti != tj) Nu[(size_t)gj * Mp + gi] = nw;
                 if (gi == gj) trhinv += hinv;
             }
         }
         {
-            double v[4] = {trhinv, 0.0, 0.0, 0.0};                            // tr H^-1, tr(H - I), w^T (H - I) w, w^T b
-            for (int i = tid; i < Mp; i += NTHR) {
-                double hw = 0.0;
-                for (int j = 0; j < Mp; ++j) hw += Hu[(size_t)i * Mp + j] * wl[j];
-                v[1] += Hu[(size_t)i * Mp + i];
-                v[2] += wl[i] * hw;
-                v[3] += wl[i] * bv[i];
-            }
+            double v[4] = {trhinv, trHm, 0.0, 0.0};                          // tr H^-1, tr(H - I), w^T w, w^T b
+            for (int i = tid; i < Mp; i += NTHR) { v[2] += wl[i] * wl[i]; v[3] += wl[i] * bv[i]; }
             tiny_sum<4, NW>(v, red);
             if (tid == 0) {
-                // dl/dalpha = -1/2 tr(A^-1 G) + u^T g - 1/2 u^T G u - 1/2 (T sigma^2 - tr(K^-1 G)) in whitened variables (ffvd_grad_oracle.py)
+                // dl/dalpha = -1/2 tr(A^-1 G) + u^T g - 1/2 u^T G u - 1/2 (T sigma^2 - tr(K^-1 G)) in whitened variables
+                // (ffvd_grad_oracle.py);  w^T (H - I) w = w^T b - w^T w because H w = b
                 const double trAinvG = ((double)Mp - v[0]) / alpha, trKinvG = v[1] / alpha;
-                a.uterms[(size_t)u * 8] = -0.5 * trAinvG + v[3] / alpha - 0.5 * v[2] / alpha - 0.5 * ((double)T * var - trKinvG);
+                a.uterms[(size_t)u * 8] = -0.5 * trAinvG + v[3] / alpha - 0.5 * (v[3] - v[2]) / alpha - 0.5 * ((double)T * var - trKinvG);
             }
+            (void)quad;
         }
         tiny_publish(cx.fN, 1);
         TSTAMP(8);
@@ -691,64 +807,89 @@ __global__ __launch_bounds__(64 * NW, 1) void tiny_kernel(const TinyArgs a) {
     // ==========================================================================================================================
     const int t0 = strip * SR;
     double *Ks = lds + L.mat;
-    double *xs = lds + L.xo, *xx = xs + (size_t)SR * 8;
-    double *zs = lds + L.zo, *zz = zs + (size_t)Mp * 8;
-    double *dlt = lds + L.misc, *rowv = dlt + SR;
+    double *xs = lds + L.xo, *xx = xs + (size_t)SR * 9;                      // (row stride 9: no bank conflicts between rows)
+    double *zs = lds + L.zo, *zz = zs + (size_t)Mp * 9;
+    double *dlt = lds + L.misc, *rowv = dlt + SR, *chn = rowv + SR;          // chn: [2][SR] per-row transition / likelihood terms
     const double *Xs = a.X + (size_t)s * (T + 1) * D;
-    for (int e = tid; e < Mp * 8; e += NTHR) {
-        const int m = e >> 3, p = e & 7;
-        zs[e] = (m < M && p < P) ? a.Z[(size_t)m * P + p] / exp(a.loglen[(size_t)dg * P + p]) : 0.0;
-    }
-    for (int e = tid; e < SR * 8; e += NTHR) {
-        const int r = e >> 3, p = e & 7, t = t0 + r;
-        double v = 0.0;
-        if (t < T && p < P) {
-            v = (p < D) ? Xs[(size_t)t * D + p] : a.ctrl[(size_t)t * a.C + (p - D)];
-            v = v / exp(a.loglen[(size_t)dg * P + p]);
+    __syncthreads();
+    {
+        const int p = tid & 7;
+        const double len = ilen[p];
+        for (int e = tid; e < Mp * 8; e += NTHR) {
+            const int m = e >> 3;
+            zs[m * 9 + p] = (m < M && p < P) ? a.Z[(size_t)m * P + p] / len : 0.0;
         }
-        xs[e] = v;
+        for (int e = tid; e < SR * 8; e += NTHR) {
+            const int r = e >> 3, t = t0 + r;
+            double v = 0.0;
+            if (t < T && p < P) v = ((p < D) ? Xs[(size_t)t * D + p] : a.ctrl[(size_t)t * a.C + (p - D)]) / len;
+            xs[r * 9 + p] = v;
+        }
     }
     for (int r = tid; r < SR; r += NTHR) {
         const int t = t0 + r;
-        dlt[r] = (t < T) ? Xs[(size_t)(t + 1) * D + dg] - Xs[(size_t)t * D + dg] : 0.0;       // :247
+        double dv = 0.0, tq = 0.0, tl = 0.0;
+        if (t < T) {
+            dv = Xs[(size_t)(t + 1) * D + dg] - Xs[(size_t)t * D + dg];     // :247
+            const double q = dv / sqrt(Qd);                                  // dgp_model.py:283-284
+            tq = -0.5 * (q * q);
+            if (dl == 0 && a.shared_terms)
+                for (int j = 0; j < a.Ydim; ++j) {
+                    double ym = 0.0;
+                    for (int d = 0; d < D; ++d) ym += Xs[(size_t)(t + 1) * D + d] * a.CC[(size_t)d * a.Ydim + j];      // likelihoods.py:76-79
+                    ym += a.DD[j];
+                    const double R = exp(a.logR[j]);                         // Rchols[0] = first row (dgp_model.py:250)
+                    const double rr = (a.Y[(size_t)t * a.Ydim + j] - ym) / R;
+                    tl += -0.5 * (rr * rr);
+                }
+        }
+        dlt[r] = dv; chn[r] = tq; chn[SR + r] = tl;
     }
     __syncthreads();
     for (int m = tid; m < Mp; m += NTHR) {
         double sacc = 0.0;
 #pragma unroll
-        for (int p = 0; p < 8; ++p) sacc += zs[m * 8 + p] * zs[m * 8 + p];
+        for (int p = 0; p < 8; ++p) sacc += zs[m * 9 + p] * zs[m * 9 + p];
         zz[m] = sacc;
     }
     for (int r = tid; r < SR; r += NTHR) {
         double sacc = 0.0;
 #pragma unroll
-        for (int p = 0; p < 8; ++p) sacc += xs[r * 8 + p] * xs[r * 8 + p];
+        for (int p = 0; p < 8; ++p) sacc += xs[r * 9 + p] * xs[r * 9 + p];
         xx[r] = sacc;
     }
     __syncthreads();
-    double kreg[TNT][4];
+    // (backward: each lane parks its K_fu elements in L2 until E = dl/dK_fu o K_fu needs them: 64 registers less in both phases)
+    double *kst = a.grad ? a.Kst + (((size_t)u * nst + strip) * NTHR + tid) * 32 : nullptr;
+    {
+        double xr[4][8], xxr[4];
 #pragma unroll
-    for (int c = 0; c < TNT; ++c) {
-        if (c < NT) {
-            const int m = 16 * c + lr;
-            double zr[8];
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * wave + lk + 4 * r;
 #pragma unroll
-            for (int p = 0; p < 8; ++p) zr[p] = zs[m * 8 + p];
-            const double zzm = zz[m];
+            for (int p = 0; p < 8; ++p) xr[r][p] = xs[row * 9 + p];
+            xxr[r] = xx[row];
+        }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 16 * wave + lk + 4 * r;
-                double dot = 0.0;
+        for (int c = 0; c < TNT; ++c) {
+            if (c < NT) {
+                const int m = 16 * c + lr;
+                double zr[8];
 #pragma unroll
-                for (int p = 0; p < 8; ++p) dot += xs[row * 8 + p] * zr[p];
-                double v = kernel_value<0>(dot, xx[row], zzm, var);
-                if (m >= M || t0 + row >= T) v = 0.0;
-                kreg[c][r] = v;
-                Ks[(size_t)row * LD + m] = v;
+                for (int p = 0; p < 8; ++p) zr[p] = zs[m * 9 + p];
+                const double zzm = zz[m];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * wave + lk + 4 * r;
+                    double dot = 0.0;
+#pragma unroll
+                    for (int p = 0; p < 8; ++p) dot += xr[r][p] * zr[p];
+                    double v = kernel_value<0>(dot, xxr[r], zzm, var);
+                    if (m >= M || t0 + row >= T) v = 0.0;
+                    if (kst) kst[c * 4 + r] = v;
+                    Ks[(size_t)row * LD + m] = v;
+                }
             }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) kreg[c][r] = 0.0;
         }
     }
     wave_lds_order();
@@ -758,20 +899,11 @@ __global__ __launch_bounds__(64 * NW, 1) void tiny_kernel(const TinyArgs a) {
     // ==========================================================================================================================
     if (tiny_wait(cx.fW, 1, cx.abort_w, slot) < 0) return;
     TSTAMP(2);
+    const double *Arow = Ks + (size_t)(16 * wave + lr) * LD;                  // this lane's A-operand row of the wavefront's 16 rows
     d4 facc[TNT];
 #pragma unroll
     for (int j = 0; j < TNT; ++j) facc[j] = (d4){0.0, 0.0, 0.0, 0.0};
-    for (int k = 0; k < NT; ++k) {
-        double av[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) av[t] = Ks[(size_t)(16 * wave + lr) * LD + 16 * k + 4 * t + lk];
-#pragma unroll
-        for (int j = 0; j < TNT; ++j)
-            if (j < NT && j >= k) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) facc[j] = mfma_f64(av[t], Wu[(size_t)(16 * k + 4 * t + lk) * Mp + 16 * j + lr], facc[j]);
-            }
-    }
+    tiny_row_gemm<1>(facc, Arow, Wu, Mp, NT, lr, lk);
     wave_lds_order();
     {
         double rs[4] = {0.0, 0.0, 0.0, 0.0};
@@ -795,8 +927,7 @@ __global__ __launch_bounds__(64 * NW, 1) void tiny_kernel(const TinyArgs a) {
     TSTAMP(3);
     double *Pu = a.Pp + ((size_t)u * nst + strip) * pstride;
     for (int tau = wave; tau < ntl; tau += NW) {
-        int ti, tj;
-        tiny_tile_ij(tau, ti, tj);
+        const int ti = tab[tau] & 255, tj = tab[tau] >> 8;
         d4 a0 = (d4){0.0, 0.0, 0.0, 0.0}, a1 = a0;
 #pragma unroll 4
         for (int q = 0; q < SR / 4; ++q) {
@@ -807,46 +938,34 @@ __global__ __launch_bounds__(64 * NW, 1) void tiny_kernel(const TinyArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) Pu[tau * 256 + (lk + 4 * r) * 16 + lr] = a0[r] + a1[r];
     }
+    TSTAMP(16);
     for (int m = tid; m < Mp; m += NTHR) {
-        double acc = 0.0;
-        for (int r = 0; r < SR; ++r) acc += Ks[(size_t)r * LD + m] * dlt[r];
-        Pu[ntl * 256 + m] = acc;
+        double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll 4
+        for (int r = 0; r < SR; r += 2) { acc0 += Ks[(size_t)r * LD + m] * dlt[r]; acc1 += Ks[(size_t)(r + 1) * LD + m] * dlt[r + 1]; }
+        Pu[ntl * 256 + m] = acc0 + acc1;
     }
+    TSTAMP(17);
     {
         double v[3] = {0.0, 0.0, 0.0};          // transition, trace, likelihood partial sums of these rows (chain_reduce_kernel)
         for (int r = tid; r < SR; r += NTHR) {
-            const int t = t0 + r;
-            if (t < T) {
-                const double q = dlt[r] / sqrt(Qd);                          // dgp_model.py:283-284
-                v[0] += -0.5 * (q * q);
-                v[1] += -0.5 * ((var - rowv[r]) / Qd);                       // conditionals_multi_output.py:255
-                if (dl == 0 && a.shared_terms)
-                    for (int j = 0; j < a.Ydim; ++j) {
-                        double ym = 0.0;
-                        for (int d = 0; d < D; ++d) ym += Xs[(size_t)(t + 1) * D + d] * a.CC[(size_t)d * a.Ydim + j];      // likelihoods.py:76-79
-                        ym += a.DD[j];
-                        const double R = exp(a.logR[j]);                     // Rchols[0] = first row (dgp_model.py:250)
-                        const double rr = (a.Y[(size_t)t * a.Ydim + j] - ym) / R;
-                        v[2] += -0.5 * (rr * rr);
-                    }
-            }
+            v[0] += chn[r];
+            if (t0 + r < T) v[1] += -0.5 * ((var - rowv[r]) / Qd);           // conditionals_multi_output.py:255
+            v[2] += chn[SR + r];
         }
         tiny_sum<3, NW>(v, red);
         if (tid == 0) { double *sc = Pu + ntl * 256 + Mp; sc[0] = v[0]; sc[1] = v[1]; sc[2] = v[2]; }
     }
     TSTAMP(4);
-    const int before = tiny_arrive(cx.cP, slot);
-    (void)before;
+    tiny_arrive(cx.cP, slot);
     TSTAMP(5);
     if (!a.grad) return;
     // ==========================================================================================================================
     // strip, phase 2 (backward):  dl/dK_fu = alpha (F N + delta w^T) W^T,  E = dl/dK_fu o K_fu,  its reductions
     // ==========================================================================================================================
-    if (tiny_wait(cx.fN, 1, cx.abort_w, slot) < 0) return;
-    TSTAMP(6);
     double *wl = lds + L.vec;
     double *XO = lds + L.xo, *ZO = lds + L.zo;
-    for (int m = tid; m < Mp; m += NTHR) wl[m] = a.wv[(size_t)u * Mp + m];
+    // (the operands [1 | Z] and [1 | x_comb] of the reductions, while the head factorises H: the K-build copies are dead)
     for (int e = tid; e < Mp * 16; e += NTHR) {
         const int m = e >> 4, n = e & 15;
         ZO[e] = (n == 0) ? 1.0 : ((m < M && n <= P) ? a.Z[(size_t)m * P + n - 1] : 0.0);
@@ -858,28 +977,21 @@ __global__ __launch_bounds__(64 * NW, 1) void tiny_kernel(const TinyArgs a) {
         else if (t < T && n <= P) v = (n - 1 < D) ? Xs[(size_t)t * D + n - 1] : a.ctrl[(size_t)t * a.C + (n - 1 - D)];
         XO[e] = v;
     }
+    if (tiny_wait(cx.fN, 1, cx.abort_w, slot) < 0) return;
+    TSTAMP(6);
+    for (int m = tid; m < Mp; m += NTHR) wl[m] = a.wv[(size_t)u * Mp + m];
     __syncthreads();
     const int Tp = nst * SR, drow = P + 1;
     double *dxu = a.dxc + (size_t)u * Tp * drow;
     for (int r = tid; r < SR; r += NTHR) {                                   // dl/ddelta_t = alpha (F w)_t
-        double acc = 0.0;
-        for (int j = 0; j < Mp; ++j) acc += Ks[(size_t)r * LD + j] * wl[j];
-        if (t0 + r < T) dxu[(size_t)(t0 + r) * drow + P] = alpha * acc;
+        double acc0 = 0.0, acc1 = 0.0;
+        for (int j = 0; j + 1 < Mp; j += 2) { acc0 += Ks[(size_t)r * LD + j] * wl[j]; acc1 += Ks[(size_t)r * LD + j + 1] * wl[j + 1]; }
+        if (t0 + r < T) dxu[(size_t)(t0 + r) * drow + P] = alpha * (acc0 + acc1);
     }
     const double *Nu = a.Nw + (size_t)u * msq;
 #pragma unroll
     for (int j = 0; j < TNT; ++j) facc[j] = (d4){0.0, 0.0, 0.0, 0.0};
-    for (int k = 0; k < NT; ++k) {
-        double av[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) av[t] = Ks[(size_t)(16 * wave + lr) * LD + 16 * k + 4 * t + lk];
-#pragma unroll
-        for (int j = 0; j < TNT; ++j)
-            if (j < NT) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) facc[j] = mfma_f64(av[t], Nu[(size_t)(16 * k + 4 * t + lk) * Mp + 16 * j + lr], facc[j]);
-            }
-    }
+    tiny_row_gemm<0>(facc, Arow, Nu, Mp, NT, lr, lk);
     __syncthreads();                                                          // every thread's reads of F (dl/ddelta above) are done
 #pragma unroll
     for (int j = 0; j < TNT; ++j)
@@ -891,24 +1003,14 @@ __global__ __launch_bounds__(64 * NW, 1) void tiny_kernel(const TinyArgs a) {
     wave_lds_order();
 #pragma unroll
     for (int j = 0; j < TNT; ++j) facc[j] = (d4){0.0, 0.0, 0.0, 0.0};
-    for (int k = 0; k < NT; ++k) {
-        double av[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) av[t] = Ks[(size_t)(16 * wave + lr) * LD + 16 * k + 4 * t + lk];
-#pragma unroll
-        for (int j = 0; j < TNT; ++j)
-            if (j < NT && j <= k) {                                            // W^T is lower triangular by tiles
-#pragma unroll
-                for (int t = 0; t < 4; ++t) facc[j] = mfma_f64(av[t], Wtu[(size_t)(16 * k + 4 * t + lk) * Mp + 16 * j + lr], facc[j]);
-            }
-    }
+    tiny_row_gemm<2>(facc, Arow, Wtu, Mp, NT, lr, lk);                        // W^T is lower triangular by tiles
     wave_lds_order();
 #pragma unroll
     for (int j = 0; j < TNT; ++j)
         if (j < NT) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                facc[j][r] = alpha * facc[j][r] * kreg[j][r];                 // E, accumulator layout = B-operand layout with k = row
+                facc[j][r] = alpha * facc[j][r] * kst[j * 4 + r];             // E, accumulator layout = B-operand layout with k = row
                 Ks[(size_t)(16 * wave + lk + 4 * r) * LD + 16 * j + lr] = facc[j][r];
             }
         }
@@ -921,12 +1023,13 @@ __global__ __launch_bounds__(64 * NW, 1) void tiny_kernel(const TinyArgs a) {
         for (int k = 0; k < NT; ++k) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const double av = Ks[(size_t)(16 * wave + lr) * LD + 16 * k + 4 * t + lk], bw = ZO[(size_t)(16 * k + 4 * t + lk) * 16 + lr];
+                const double av = Arow[16 * k + 4 * t + lk], bw = ZO[(size_t)(16 * k + 4 * t + lk) * 16 + lr];
                 if (t & 1) a1 = mfma_f64(av, bw, a1);
                 else a0 = mfma_f64(av, bw, a0);
             }
         }
         double rx2 = 0.0;
+        const double len = (lr >= 1 && lr <= P) ? ilen[lr - 1] : 1.0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const double v = a0[r] + a1[r];
@@ -934,7 +1037,6 @@ __global__ __launch_bounds__(64 * NW, 1) void tiny_kernel(const TinyArgs a) {
             const int row = 16 * wave + lk + 4 * r, t = t0 + row;
             const double x = XO[(size_t)row * 16 + lr];
             if (lr >= 1 && lr <= P) {
-                const double len = exp(a.loglen[(size_t)dg * P + lr - 1]);
                 if (t < T) dxu[(size_t)t * drow + lr - 1] = -(x * rt - v) / (len * len);      // dl/dx_comb_t,p (_se_chain)
                 rx2 += rt * x * x;
             } else if (lr == 0) rx2 += v;                                     // sum of the row sums
@@ -972,19 +1074,42 @@ __global__ __launch_bounds__(64 * NW, 1) void tiny_kernel(const TinyArgs a) {
         __syncthreads();
     }
     TSTAMP(8);
-    // K_uu side, one 16-row block per strip:  Psi = 1/2 W N2 W^T (dl/dK_uu),  E_u = Psi o K(Z,Z),  row sums and E_u Z
+    // K_uu side, one 16-row block per strip:  Psi = 1/2 W N2 W^T (dl/dK_uu),  N2 = N - (H - I),  E_u = Psi o K(Z,Z),  row sums and E_u Z
     for (int rb = strip; rb < NT; rb += nst) {
         double *T1 = Ks;                                                      // [16][LD]
         double *Eu = Ks + (size_t)16 * LD;                                    // [16][LD]
-        const double *N2u = a.Nm2 + (size_t)u * msq;
+        double *Wr = Ks + (size_t)32 * LD;                                    // [16][LD] rows rb of W
+        const double *Hu = a.Hs + (size_t)u * msq;
+        for (int e = tid; e < 16 * Mp; e += NTHR) {
+            const int m = e / Mp, j = e - m * Mp;
+            Wr[(size_t)m * LD + j] = (j >= 16 * rb) ? Wu[(size_t)(16 * rb + m) * Mp + j] : 0.0;
+        }
+        __syncthreads();
         for (int j = wave; j < NT; j += NW) {                                 // T1 = W(rb, :) N2
             d4 a0 = (d4){0.0, 0.0, 0.0, 0.0}, a1 = a0;
-            for (int k = rb; k < NT; ++k) {
+            double nb[2][4];
+            auto ldn = [&](int k, double (&o)[4]) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    const double av = Wu[(size_t)(16 * rb + lr) * Mp + 16 * k + 4 * t + lk], bw = N2u[(size_t)(16 * k + 4 * t + lk) * Mp + 16 * j + lr];
-                    if (t & 1) a1 = mfma_f64(av, bw, a1);
-                    else a0 = mfma_f64(av, bw, a0);
+                    const size_t idx = (size_t)(16 * k + 4 * t + lk) * Mp + 16 * j + lr;
+                    o[t] = Nu[idx] - Hu[idx];
+                }
+            };
+            auto mm = [&](int k, const double (&bfr)[4]) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const double av = Wr[(size_t)lr * LD + 16 * k + 4 * t + lk];
+                    if (t & 1) a1 = mfma_f64(av, bfr[t], a1);
+                    else a0 = mfma_f64(av, bfr[t], a0);
+                }
+            };
+            ldn(rb, nb[0]);
+            for (int k = rb; k < NT; k += 2) {                                // (two k steps per trip: the buffers keep compile-time indices)
+                if (k + 1 < NT) ldn(k + 1, nb[1]);
+                mm(k, nb[0]);
+                if (k + 1 < NT) {
+                    if (k + 2 < NT) ldn(k + 2, nb[0]);
+                    mm(k + 1, nb[1]);
                 }
             }
 #pragma unroll
@@ -993,24 +1118,42 @@ __global__ __launch_bounds__(64 * NW, 1) void tiny_kernel(const TinyArgs a) {
         __syncthreads();
         for (int j = wave; j < NT; j += NW) {                                 // Psi(rb, j) = 1/2 T1 W^T(:, j),  E_u = Psi o K_uu
             d4 a0 = (d4){0.0, 0.0, 0.0, 0.0}, a1 = a0;
-            for (int k = j; k < NT; ++k) {
+            double wb[2][4];
+            auto ldw = [&](int k, double (&o)[4]) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) o[t] = Wtu[(size_t)(16 * k + 4 * t + lk) * Mp + 16 * j + lr];
+            };
+            auto mm = [&](int k, const double (&bfr)[4]) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    const double av = T1[(size_t)lr * LD + 16 * k + 4 * t + lk], bw = Wtu[(size_t)(16 * k + 4 * t + lk) * Mp + 16 * j + lr];
-                    if (t & 1) a1 = mfma_f64(av, bw, a1);
-                    else a0 = mfma_f64(av, bw, a0);
+                    const double av = T1[(size_t)lr * LD + 16 * k + 4 * t + lk];
+                    if (t & 1) a1 = mfma_f64(av, bfr[t], a1);
+                    else a0 = mfma_f64(av, bfr[t], a0);
+                }
+            };
+            ldw(j, wb[0]);
+            for (int k = j; k < NT; k += 2) {
+                if (k + 1 < NT) ldw(k + 1, wb[1]);
+                mm(k, wb[0]);
+                if (k + 1 < NT) {
+                    if (k + 2 < NT) ldw(k + 2, wb[0]);
+                    mm(k + 1, wb[1]);
                 }
             }
+            const int gj = 16 * j + lr;
+            double zj[8], zj2 = 0.0;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) { zj[p] = (p < P) ? ZO[(size_t)gj * 16 + 1 + p] / ilen[p] : 0.0; zj2 += zj[p] * zj[p]; }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int gi = 16 * rb + lk + 4 * r, gj = 16 * j + lr;
+                const int gi = 16 * rb + lk + 4 * r;
                 double kv = 0.0;
                 if (gi < M && gj < M) {                                        // K(Z,Z) without the jitter (ffvd_grad_oracle.py: Psi * Kuu)
-                    double dot = 0.0, zi2 = 0.0, zj2 = 0.0;
-                    for (int p = 0; p < P; ++p) {
-                        const double len = exp(a.loglen[(size_t)dg * P + p]);
-                        const double zi = a.Z[(size_t)gi * P + p] / len, zj = a.Z[(size_t)gj * P + p] / len;
-                        dot += zi * zj; zi2 += zi * zi; zj2 += zj * zj;
+                    double dot = 0.0, zi2 = 0.0;
+#pragma unroll
+                    for (int p = 0; p < 8; ++p) {
+                        const double zi = (p < P) ? ZO[(size_t)gi * 16 + 1 + p] / ilen[p] : 0.0;
+                        dot += zi * zj[p]; zi2 += zi * zi;
                     }
                     kv = kernel_value<0>(dot, zi2, zj2, var);
                 }
@@ -1029,14 +1172,14 @@ __global__ __launch_bounds__(64 * NW, 1) void tiny_kernel(const TinyArgs a) {
                 }
             }
             double sll = 0.0;
+            const double len = (lr >= 1 && lr <= P) ? ilen[lr - 1] : 1.0, inv2 = 1.0 / (len * len);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const double v = a0[r] + a1[r];
                 const double ru = __shfl(v, lane & 48);
                 const int gi = 16 * rb + lk + 4 * r;
                 if (lr >= 1 && lr <= P) {
-                    const double len = exp(a.loglen[(size_t)dg * P + lr - 1]), inv2 = 1.0 / (len * len);
-                    const double z = (gi < M) ? a.Z[(size_t)gi * P + lr - 1] : 0.0;
+                    const double z = ZO[(size_t)gi * 16 + lr];
                     a.dz2[((size_t)u * Mp + gi) * TPP + lr - 1] = -2.0 * (z * ru - v) * inv2;       // E_u symmetric: both roles of Z
                     sll += 2.0 * (ru * z * z - z * v) * inv2;
                 } else if (lr == 0) sll += v;
@@ -1081,7 +1224,7 @@ TinyPlan tiny_plan(int kind, int T, int D, int C, int M, int S, int Dl, int grad
 
 namespace {
 struct TinyCarve {
-    size_t Wg, Wt, Pp, Hs, Nw, Nm2, wv, hterms, uterms, Qp, dxc, dz2, kuu, uout, cterms, cpart, total;
+    size_t Wg, Wt, Pp, Hs, Nw, Nm2, wv, hterms, uterms, Qp, dxc, dz2, kuu, uout, cterms, cpart, psums, kst, total;
 };
 TinyCarve tiny_carve(const TinyPlan &pl, int T, int P, int M, int S, int Dl, int D, int Ydim, int grad) {
     (void)T;
@@ -1094,6 +1237,7 @@ TinyCarve tiny_carve(const TinyPlan &pl, int T, int P, int M, int S, int Dl, int
     c.Pp = o; o += al(nu * nst * tiny_pstride(pl.Mp));
     c.hterms = o; o += al(nu * 2);
     c.cterms = o; o += al((size_t)S * 8);
+    c.psums = o; o += 32;
     c.Hs = o; o += al(nu * msq);                    // (written in forward-only launches too: cheap, keeps the kernel uniform)
     if (grad) {
         c.Nw = o; o += al(nu * msq);
@@ -1102,6 +1246,7 @@ TinyCarve tiny_carve(const TinyPlan &pl, int T, int P, int M, int S, int Dl, int
         c.uterms = o; o += al(nu * 8);
         c.Qp = o; o += al(nu * nst * tiny_qstride(pl.Mp));
         c.dxc = o; o += al(nu * nst * pl.SR * (P + 1));
+        c.kst = o; o += al(nu * nst * (size_t)pl.nw * 64 * 32);
         c.dz2 = o; o += al(nu * pl.Mp * TINY_PMAX);
         c.kuu = o; o += al(nu * pl.NT * (TINY_PMAX + 1));
         c.uout = o; o += al(nu * ((size_t)M * P + P + 2));
@@ -1121,11 +1266,11 @@ void tiny_bind_scratch(TinyArgs &a, const TinyPlan &pl, double *scratch, int *fl
     const TinyCarve c = tiny_carve(pl, a.T, a.P, a.M, a.S, a.Dl, a.D, a.Ydim, a.grad);
     a.Mp = pl.Mp; a.NT = pl.NT; a.SR = pl.SR; a.nstrips = pl.nstrips; a.nunits = pl.nunits;
     a.Wg = scratch + c.Wg; a.Wt = scratch + c.Wt; a.Pp = scratch + c.Pp; a.hterms = scratch + c.hterms;
-    a.chain_terms = scratch + c.cterms; a.Hs = scratch + c.Hs;
+    a.chain_terms = scratch + c.cterms; a.Hs = scratch + c.Hs; a.prior_sums = scratch + c.psums;
     a.sp_stride = a.D * a.Ydim + 2 * a.Ydim + a.Dl;
     if (a.grad) {
         a.Nw = scratch + c.Nw; a.Nm2 = scratch + c.Nm2; a.wv = scratch + c.wv; a.uterms = scratch + c.uterms;
-        a.Qp = scratch + c.Qp; a.dxc = scratch + c.dxc; a.dz2 = scratch + c.dz2; a.kuu_part = scratch + c.kuu;
+        a.Qp = scratch + c.Qp; a.dxc = scratch + c.dxc; a.Kst = scratch + c.kst; a.dz2 = scratch + c.dz2; a.kuu_part = scratch + c.kuu;
         a.unit_out = scratch + c.uout; a.chain_part = scratch + c.cpart;
     }
     a.flags = flags;

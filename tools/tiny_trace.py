@@ -19,10 +19,10 @@ e = ElboEngine(T, D, C, M, S, grad=grad)
 e.set_data(Y, c); e.set_params(params)
 f = (lambda: e.adam_step(1e-9)) if grad else (lambda: e.nll_terms())
 for _ in range(5): f()
-buf = (ct.c_longlong * (1024 * 16))()
+buf = (ct.c_longlong * (1024 * 32))()
 e.lib.ffvd_debug_tiny_trace.argtypes = [ct.c_void_p]
 assert e.lib.ffvd_debug_tiny_trace(buf) == 0
-a = np.array(buf[:]).reshape(1024, 16)
+a = np.array(buf[:]).reshape(1024, 32)
 nunits = S * D
 nst = (T + 63) // 64 if int(e.lib.ffvd_single_launch(e._h)) == 4 else (T + 127) // 128
 nwg = nunits * (1 + nst)
@@ -35,6 +35,8 @@ print("mode", "train" if grad else "forward", "S", S, "workgroups", nwg, "wavefr
 print("heads (us):")
 for u in range(min(nunits, 8)):
     print("  u%-3d" % u, " ".join("%s=%.1f" % (n, us[u, i]) for i, n in enumerate(names_h) if not np.isnan(us[u, i])))
+print("head 0 detail (us): prologue %s | chol(H) columns %s | W stored %.1f" % (" ".join("%.1f" % us[0, i] for i in (16, 17)), " ".join("%.1f" % us[0, i] for i in range(18, 26) if not np.isnan(us[0, i])), us[0, 26]))
+print("strip 0 detail (us): F^T F tiles out %.1f, F^T delta out %.1f" % (us[nunits, 16], us[nunits, 17]))
 print("strips of unit 0 (us):")
 for i in range(nst):
     r = us[nunits + i]
