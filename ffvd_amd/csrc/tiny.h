@@ -13,6 +13,7 @@ constexpr int TINY_TMAX = 2048;     // transitions
 struct TinyArgs {
     int kind, T, D, C, P, M, Mp, NT, Dl, d_begin, S, Ydim;
     int SR, nstrips, nunits;        // rows per strip workgroup (16 per wavefront), strips per unit, units = S * Dl
+    int side;                       // backward: NT more workgroups per unit take the row blocks of the K_uu side (else the strips do)
     int prior_type, shared_terms, grad, S_total;
     double jitter;
     const double *X, *Z, *logvar, *loglen, *log_Q, *CC, *DD, *logR, *Y, *ctrl;
@@ -43,6 +44,7 @@ struct TinyPlan {
     bool ok;
     int nw;             // wavefronts per workgroup: 4 (64-row strips) or 8 (128-row strips)
     int Mp, NT, SR, nstrips, nunits;
+    int side;           // grad: workgroups of their own for the K_uu side of the backward pass (they fit beside heads and strips)
     size_t lds_bytes;
 };
 // Can this shape run as one launch on a chip with `cus` compute units?  (Every workgroup must be resident at once: the roles wait

@@ -169,11 +169,11 @@ __device__ __forceinline__ int tiny_chain16(const double (*Sc)[17], double *Am, 
     return bad;
 }
 
-// S = A(s,s) - sum_{k<s} L(s,k) L(s,k)^T into Sc (one wavefront)
-__device__ __forceinline__ void tiny_diag_gather(const double *Am, const int LD, const int s, double (*Sc)[17], const int lane) {
+// S = A(s,s) - sum_{kbeg<=k<s} L(s,k) L(s,k)^T into Sc (one wavefront)
+__device__ __forceinline__ void tiny_diag_gather(const double *Am, const int LD, const int s, const int kbeg, double (*Sc)[17], const int lane) {
     const int lr = lane & 15, lk = lane >> 4, s0 = 16 * s;
     d4 a0 = (d4){0.0, 0.0, 0.0, 0.0}, a1 = a0;
-    for (int k = 0; k < s; ++k) {
+    for (int k = kbeg; k < s; ++k) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const double v = Am[(size_t)(s0 + lr) * LD + 16 * k + 4 * t + lk];
@@ -191,10 +191,10 @@ __device__ __forceinline__ void tiny_diag_gather(const double *Am, const int LD,
 // The products run transposed in the accumulator layout, which is the B-operand layout of the next product (potrf_panel_kernel);
 // one residual refinement step against L_ss restores substitution accuracy.
 __device__ __forceinline__ void tiny_tile_solve(double *Am, const int LD, double (*Dinv)[16][17], const int s, const int rb, const bool ext,
-                                                const int lane) {
+                                                const int lane, const int kmain = 0 /* main rows: first term still to subtract */) {
     const int lr = lane & 15, lk = lane >> 4, s0 = 16 * s, r0 = 16 * rb;
     d4 a0 = (d4){0.0, 0.0, 0.0, 0.0}, a1 = a0;
-    for (int k = ext ? rb : 0; k < s; ++k) {
+    for (int k = ext ? rb : kmain; k < s; ++k) {
         const bool dk = ext && k == rb;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -219,6 +219,29 @@ __device__ __forceinline__ void tiny_tile_solve(double *Am, const int LD, double
     for (int r = 0; r < 4; ++r) Am[(size_t)(r0 + lr) * LD + s0 + lk + 4 * r] = x[r];
 }
 
+// Row block r is factorised by wavefront 0 in column step r - 1.  One step earlier (column r - 2) every term k <= r - 3 of its two
+// tiles on the critical path is final: a helper subtracts them in place then,
+//   A(r, r-1) -= sum_{k<kend} L(r,k) L(r-1,k)^T,   A(r, r) -= sum_{k<kend} L(r,k) L(r,k)^T,   kend = r - 2,
+// and wavefront 0 is left with one term for the tile and two for the diagonal block whatever the column (the gathers were 40 % of
+// its step at column 5: tools/tiny_trace.py).
+__device__ __forceinline__ void tiny_pregather(double *Am, const int LD, const int r, const int kend, const int lane) {
+    const int lr = lane & 15, lk = lane >> 4, r0 = 16 * r, q0 = 16 * (r - 1);
+    d4 g0 = (d4){0.0, 0.0, 0.0, 0.0}, g1 = g0, h0 = g0, h1 = g0;
+    for (int k = 0; k < kend; ++k) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const double lq = Am[(size_t)(q0 + lr) * LD + 16 * k + 4 * t + lk], lrw = Am[(size_t)(r0 + lr) * LD + 16 * k + 4 * t + lk];
+            if (t & 1) { g1 = mfma_f64(lq, lrw, g1); h1 = mfma_f64(lrw, lrw, h1); }
+            else { g0 = mfma_f64(lq, lrw, g0); h0 = mfma_f64(lrw, lrw, h0); }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        Am[(size_t)(r0 + lr) * LD + q0 + lk + 4 * q] -= g0[q] + g1[q];        // (transposed in the accumulator layout, as in tiny_tile_solve)
+        Am[(size_t)(r0 + lk + 4 * q) * LD + r0 + lr] -= h0[q] + h1[q];
+    }
+}
+
 // In: lower triangle of Am.  Out: lower triangle = L (diagonal tiles with zeros above the diagonal), tiles above the diagonal =
 // W = L^-T, Dinv[s] = W(s,s).  Left-looking by tile column; wavefront 0 owns the critical path (tile (s+1,s), then the gather and
 // the 16-pivot chain of diagonal tile s+1), the others solve the remaining tiles of column s beside it; one barrier per column.
@@ -229,7 +252,7 @@ __device__ __forceinline__ void tiny_chol_inv(double *Am, const int LD, const in
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int bad = 0;
     if (wave == 0) {
-        tiny_diag_gather(Am, LD, 0, Sc, lane);
+        tiny_diag_gather(Am, LD, 0, 0, Sc, lane);
         wave_lds_order();
         bad = tiny_chain16(Sc, Am, LD, 0, Dinv[0], lane);
     }
@@ -237,10 +260,11 @@ __device__ __forceinline__ void tiny_chol_inv(double *Am, const int LD, const in
     for (int s = 0; s < NT; ++s) {
         if (wave == 0) {
             if (s + 1 < NT) {
+                const int kb = s >= 1 ? s - 1 : 0;                            // terms k < s - 1 of row s + 1 were subtracted in step s - 1
                 __builtin_amdgcn_s_setprio(3);
-                tiny_tile_solve(Am, LD, Dinv, s, s + 1, false, lane);
+                tiny_tile_solve(Am, LD, Dinv, s, s + 1, false, lane, kb);
                 wave_lds_order();
-                tiny_diag_gather(Am, LD, s + 1, Sc, lane);
+                tiny_diag_gather(Am, LD, s + 1, kb, Sc, lane);
                 wave_lds_order();
                 const int b2 = tiny_chain16(Sc, Am, LD, 16 * (s + 1), Dinv[s + 1], lane);
                 if (b2 && !bad) bad = 16 * (s + 1) + b2;
@@ -248,6 +272,12 @@ __device__ __forceinline__ void tiny_chol_inv(double *Am, const int LD, const in
             }
         } else {
             int idx = 0;
+            if (s >= 1 && s + 2 < NT) {                                       // row s + 2: its terms k <= s - 1, one step ahead of wavefront 0
+                if (idx % (NW - 1) == wave - 1) tiny_pregather(Am, LD, s + 2, s, lane);
+                ++idx;
+            }
+            // (the helper that pre-gathered row s + 2 must not ALSO solve tile (s + 2, s) before it: that tile's gather reads what the
+            //  pre-gather leaves alone -- columns < s of row s + 2 -- and writes column s; the pre-gather writes columns s + 1, s + 2)
             for (int i = s + 2; i < NT; ++i, ++idx)
                 if (idx % (NW - 1) == wave - 1) tiny_tile_solve(Am, LD, Dinv, s, i, false, lane);
             for (int e = 0; e < s; ++e, ++idx)
@@ -296,6 +326,45 @@ __device__ __forceinline__ FinalizeArgs tiny_finalize_args(const TinyArgs &a) {
     fa.whitened = 0; fa.trpart = nullptr; fa.ntiles = 0; fa.fsq_from_trpart = 0; fa.chain_nll = a.chain_nll;
     fa.out_terms = a.out_terms; fa.info = a.info; fa.ninfo = a.Dl + a.nunits;
     return fa;
+}
+
+// The likelihood gradients of chain s and the transition-prior part of dlog_Q (shared_partials_kernel): functions of the inputs only,
+// formed by the chain's first head while it waits for its strips.
+template <int NW>
+__device__ void tiny_chain_part(const TinyArgs &a, const int s, double *red) {
+    constexpr int NTHR = 64 * NW;
+    const int tid = threadIdx.x;
+    const int T = a.T, D = a.D, Dl = a.Dl, J = a.Ydim;
+    const double *Xs = a.X + (size_t)s * (T + 1) * D;
+    const double Tn = (double)T;
+        double *cp = a.chain_part + (size_t)s * a.sp_stride;
+        for (int item = 0; item < D * J + 2 * J + Dl; ++item) {
+            double v[1] = {0.0};
+            if (item < D * J + 2 * J) {
+                if (a.shared_terms) {
+                    const int j = (item < D * J) ? item % J : (item - D * J) % J;
+                    const int kind = (item < D * J) ? 0 : ((item < D * J + J) ? 1 : 2), d = item / J;
+                    const double R = exp(a.logR[j]);
+                    for (int t = tid; t < T; t += NTHR) {
+                        double ym = a.DD[j];
+                        for (int dd = 0; dd < D; ++dd) ym += Xs[(size_t)(t + 1) * D + dd] * a.CC[(size_t)dd * J + j];
+                        const double r = (a.Y[(size_t)t * J + j] - ym) / R;
+                        if (kind == 0) v[0] += Xs[(size_t)(t + 1) * D + d] * (r / R);
+                        else if (kind == 1) v[0] += r / R;
+                        else v[0] += r * r - 1.0;
+                    }
+                }
+            } else {
+                const int d = a.d_begin + (item - D * J - 2 * J);
+                const double Q = exp(a.log_Q[d]);
+                for (int t = tid; t < T; t += NTHR) {
+                    const double dlt = Xs[(size_t)(t + 1) * D + d] - Xs[(size_t)t * D + d];
+                    v[0] += 0.5 - 0.5 * dlt * dlt / Q;
+                }
+            }
+            tiny_sum<1, NW>(v, red);
+            if (tid == 0) cp[item] = (item < D * J + 2 * J) ? -v[0] / Tn : v[0] / Tn;
+        }
 }
 
 // Everything of unit u is in memory.  The workgroup that completes a chain forms that chain's sums; the one that completes the
@@ -414,34 +483,6 @@ __device__ void tiny_unit_done(const TinyArgs &a, const int u, double *lds, cons
             }
             gX[idx] = g / Sn;
         }
-        double *cp = a.chain_part + (size_t)s * a.sp_stride;
-        for (int item = 0; item < D * J + 2 * J + Dl; ++item) {
-            double v[1] = {0.0};
-            if (item < D * J + 2 * J) {
-                if (a.shared_terms) {
-                    const int j = (item < D * J) ? item % J : (item - D * J) % J;
-                    const int kind = (item < D * J) ? 0 : ((item < D * J + J) ? 1 : 2), d = item / J;
-                    const double R = exp(a.logR[j]);
-                    for (int t = tid; t < T; t += NTHR) {
-                        double ym = a.DD[j];
-                        for (int dd = 0; dd < D; ++dd) ym += Xs[(size_t)(t + 1) * D + dd] * a.CC[(size_t)dd * J + j];
-                        const double r = (a.Y[(size_t)t * J + j] - ym) / R;
-                        if (kind == 0) v[0] += Xs[(size_t)(t + 1) * D + d] * (r / R);
-                        else if (kind == 1) v[0] += r / R;
-                        else v[0] += r * r - 1.0;
-                    }
-                }
-            } else {
-                const int d = a.d_begin + (item - D * J - 2 * J);
-                const double Q = exp(a.log_Q[d]);
-                for (int t = tid; t < T; t += NTHR) {
-                    const double dlt = Xs[(size_t)(t + 1) * D + d] - Xs[(size_t)t * D + d];
-                    v[0] += 0.5 - 0.5 * dlt * dlt / Q;
-                }
-            }
-            tiny_sum<1, NW>(v, red);
-            if (tid == 0) cp[item] = (item < D * J + 2 * J) ? -v[0] / Tn : v[0] / Tn;
-        }
     }
     if (tiny_arrive(cx.call, slot) != a.S - 1) return;
     // ---- the launch is complete: nll assembly, shared-parameter gradients, flags re-armed ----------------------------------------
@@ -511,6 +552,124 @@ __device__ void tiny_unit_done(const TinyArgs &a, const int u, double *lds, cons
     for (int i = tid; i < 4 * a.nunits + a.S + 1; i += NTHR) a.flags[i] = 0;      // the abort word stays as it is (0 on this path)
 }
 
+// K_uu side of the backward pass, one 16-row block rb of unit u (one workgroup, after the head's flag N):
+//   Psi = 1/2 W N2 W^T (dl/dK_uu),  N2 = N - (H - I),  E_u = Psi o K(Z,Z),  its row sums and E_u Z  ->  rows of dl/dZ, partials of
+//   dl/dloglengthscales, dl/dlogvariance.  ZO = [1 | Z] rows in LDS; three 16-row patches of the strip matrix area.
+template <int NW>
+__device__ __forceinline__ void tiny_kuu_rows(const TinyArgs &a, const int u, const int rb, double *Ks, const double *ZO, const double *ilen,
+                                              const double var) {
+    constexpr int NTHR = 64 * NW;
+    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int P = a.P, M = a.M, Mp = a.Mp, NT = a.NT, LD = Mp + 1;
+    const size_t msq = (size_t)Mp * Mp;
+    const double *Wu = a.Wg + (size_t)u * msq, *Wtu = a.Wt + (size_t)u * msq, *Nu = a.Nw + (size_t)u * msq;
+        double *T1 = Ks;                                                      // [16][LD]
+        double *Eu = Ks + (size_t)16 * LD;                                    // [16][LD]
+        double *Wr = Ks + (size_t)32 * LD;                                    // [16][LD] rows rb of W
+        const double *Hu = a.Hs + (size_t)u * msq;
+        for (int e = tid; e < 16 * Mp; e += NTHR) {
+            const int m = e / Mp, j = e - m * Mp;
+            Wr[(size_t)m * LD + j] = (j >= 16 * rb) ? Wu[(size_t)(16 * rb + m) * Mp + j] : 0.0;
+        }
+        __syncthreads();
+        for (int j = wave; j < NT; j += NW) {                                 // T1 = W(rb, :) N2
+            d4 a0 = (d4){0.0, 0.0, 0.0, 0.0}, a1 = a0;
+            // every B fragment of the tile's k range is requested before the first product: one L2 round trip per tile
+            double nn[TNT][4], nh[TNT][4];
+#pragma unroll
+            for (int kk = 0; kk < TNT; ++kk)
+                if (rb + kk < NT) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const size_t idx = (size_t)(16 * (rb + kk) + 4 * t + lk) * Mp + 16 * j + lr;
+                        nn[kk][t] = Nu[idx]; nh[kk][t] = Hu[idx];
+                    }
+                }
+#pragma unroll
+            for (int kk = 0; kk < TNT; ++kk)
+                if (rb + kk < NT) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const double av = Wr[(size_t)lr * LD + 16 * (rb + kk) + 4 * t + lk];
+                        if (t & 1) a1 = mfma_f64(av, nn[kk][t] - nh[kk][t], a1);
+                        else a0 = mfma_f64(av, nn[kk][t] - nh[kk][t], a0);
+                    }
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) T1[(size_t)(lk + 4 * r) * LD + 16 * j + lr] = a0[r] + a1[r];
+        }
+        __syncthreads();
+        for (int j = wave; j < NT; j += NW) {                                 // Psi(rb, j) = 1/2 T1 W^T(:, j),  E_u = Psi o K_uu
+            d4 a0 = (d4){0.0, 0.0, 0.0, 0.0}, a1 = a0;
+            double wb[TNT][4];
+#pragma unroll
+            for (int kk = 0; kk < TNT; ++kk)
+                if (j + kk < NT) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) wb[kk][t] = Wtu[(size_t)(16 * (j + kk) + 4 * t + lk) * Mp + 16 * j + lr];
+                }
+#pragma unroll
+            for (int kk = 0; kk < TNT; ++kk)
+                if (j + kk < NT) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const double av = T1[(size_t)lr * LD + 16 * (j + kk) + 4 * t + lk];
+                        if (t & 1) a1 = mfma_f64(av, wb[kk][t], a1);
+                        else a0 = mfma_f64(av, wb[kk][t], a0);
+                    }
+                }
+            const int gj = 16 * j + lr;
+            double zj[8], zj2 = 0.0;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) { zj[p] = (p < P) ? ZO[(size_t)gj * 16 + 1 + p] / ilen[p] : 0.0; zj2 += zj[p] * zj[p]; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gi = 16 * rb + lk + 4 * r;
+                double kv = 0.0;
+                if (gi < M && gj < M) {                                        // K(Z,Z) without the jitter (ffvd_grad_oracle.py: Psi * Kuu)
+                    double dot = 0.0, zi2 = 0.0;
+#pragma unroll
+                    for (int p = 0; p < 8; ++p) {
+                        const double zi = (p < P) ? ZO[(size_t)gi * 16 + 1 + p] / ilen[p] : 0.0;
+                        dot += zi * zj[p]; zi2 += zi * zi;
+                    }
+                    kv = kernel_value<0>(dot, zi2, zj2, var);
+                }
+                Eu[(size_t)(lk + 4 * r) * LD + gj] = 0.5 * (a0[r] + a1[r]) * kv;
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            d4 a0 = (d4){0.0, 0.0, 0.0, 0.0}, a1 = a0;
+            for (int k = 0; k < NT; ++k) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const double av = Eu[(size_t)lr * LD + 16 * k + 4 * t + lk], bw = ZO[(size_t)(16 * k + 4 * t + lk) * 16 + lr];
+                    if (t & 1) a1 = mfma_f64(av, bw, a1);
+                    else a0 = mfma_f64(av, bw, a0);
+                }
+            }
+            double sll = 0.0;
+            const double len = (lr >= 1 && lr <= P) ? ilen[lr - 1] : 1.0, inv2 = 1.0 / (len * len);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double v = a0[r] + a1[r];
+                const double ru = __shfl(v, lane & 48);
+                const int gi = 16 * rb + lk + 4 * r;
+                if (lr >= 1 && lr <= P) {
+                    const double z = ZO[(size_t)gi * 16 + lr];
+                    a.dz2[((size_t)u * Mp + gi) * TPP + lr - 1] = -2.0 * (z * ru - v) * inv2;       // E_u symmetric: both roles of Z
+                    sll += 2.0 * (ru * z * z - z * v) * inv2;
+                } else if (lr == 0) sll += v;
+            }
+            sll += __shfl_xor(sll, 16);
+            sll += __shfl_xor(sll, 32);
+            if (lk == 0 && lr <= P) a.kuu_part[((size_t)u * NT + rb) * (TPP + 1) + (lr == 0 ? TPP : lr - 1)] = sll;
+        }
+        __syncthreads();
+    }
+
 // ---- the kernel ---------------------------------------------------------------------------------------------------------------
 // B fragments of one k step of a row-panel product C(16 rows x Mp) += A(16 x 16 k-block) B(k-block, :), straight from L2 into
 // registers one step ahead of their use: b[j][t] = B[(16 k + 4 t + lk)][16 j + lr] for the column tiles j in [jlo, jhi).
@@ -569,8 +728,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void tiny_kernel(const Ti
     double *red = lds + L.red;
     double *Am = lds + L.mat;
     const bool head = (int)blockIdx.x < a.nunits;
-    const int u = head ? (int)blockIdx.x : ((int)blockIdx.x - a.nunits) / nst;
-    const int strip = head ? 0 : ((int)blockIdx.x - a.nunits) % nst;
+    const bool side = (int)blockIdx.x >= a.nunits * (1 + nst);              // (only launched with a.side)
+    const int u = head ? (int)blockIdx.x : (side ? ((int)blockIdx.x - a.nunits * (1 + nst)) / NT : ((int)blockIdx.x - a.nunits) / nst);
+    const int strip = head ? 0 : (side ? ((int)blockIdx.x - a.nunits * (1 + nst)) % NT : ((int)blockIdx.x - a.nunits) % nst);
     const int s = u / Dl, dl = u % Dl, dg = a.d_begin + dl;
     const TinyCtx cx = tiny_ctx(a, u, s);
     const double var = exp(a.logvar[dg]);                                   // kernels_multi_output.py:157
@@ -669,6 +829,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void tiny_kernel(const Ti
                 if (tid == i) a.prior_sums[i] = sm[i];
             __syncthreads();
         }
+        if (a.grad && dl == 0) tiny_chain_part<NW>(a, s, red);                  // likelihood gradients of the chain: inputs only
         // ======================================================================================================================
         // head, phase 1:  H = I + F^T F / Q, b = delta^T F / Q, log|H|, b H^-1 b^T                           (:246-254)
         // ======================================================================================================================
@@ -802,6 +963,26 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void tiny_kernel(const Ti
         return;
     }
 
+    const int narrive2 = nst + (a.side ? NT : 0);                            // arrivals that complete the backward pass of a unit
+    if (side) {
+        // ======================================================================================================================
+        // side(u, rb): one 16-row block of the K_uu side of the backward pass, beside the strips' phase 2
+        // ======================================================================================================================
+        double *ZO = lds + L.zo;
+        for (int e = tid; e < Mp * 16; e += NTHR) {
+            const int m = e >> 4, n = e & 15;
+            ZO[e] = (n == 0) ? 1.0 : ((m < M && n <= P) ? a.Z[(size_t)m * P + n - 1] : 0.0);
+        }
+        if (tiny_wait(cx.fN, 1, cx.abort_w, slot) < 0) return;
+        TSTAMP(6);
+        tiny_kuu_rows<NW>(a, u, strip, lds + L.mat, ZO, ilen, var);
+        TSTAMP(9);
+        if (tiny_arrive(cx.c2, slot) != narrive2 - 1) return;
+        TSTAMP(10);
+        tiny_unit_done<NW>(a, u, lds, L);
+        TSTAMP(11);
+        return;
+    }
     // ==========================================================================================================================
     // strip, phase 0:  rows [t0, t0 + SR) of K_fu = K(x_comb, Z) in registers (accumulator layout) and LDS                   (:240)
     // ==========================================================================================================================
@@ -1074,124 +1255,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void tiny_kernel(const Ti
         __syncthreads();
     }
     TSTAMP(8);
-    // K_uu side, one 16-row block per strip:  Psi = 1/2 W N2 W^T (dl/dK_uu),  N2 = N - (H - I),  E_u = Psi o K(Z,Z),  row sums and E_u Z
-    for (int rb = strip; rb < NT; rb += nst) {
-        double *T1 = Ks;                                                      // [16][LD]
-        double *Eu = Ks + (size_t)16 * LD;                                    // [16][LD]
-        double *Wr = Ks + (size_t)32 * LD;                                    // [16][LD] rows rb of W
-        const double *Hu = a.Hs + (size_t)u * msq;
-        for (int e = tid; e < 16 * Mp; e += NTHR) {
-            const int m = e / Mp, j = e - m * Mp;
-            Wr[(size_t)m * LD + j] = (j >= 16 * rb) ? Wu[(size_t)(16 * rb + m) * Mp + j] : 0.0;
-        }
-        __syncthreads();
-        for (int j = wave; j < NT; j += NW) {                                 // T1 = W(rb, :) N2
-            d4 a0 = (d4){0.0, 0.0, 0.0, 0.0}, a1 = a0;
-            double nb[2][4];
-            auto ldn = [&](int k, double (&o)[4]) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const size_t idx = (size_t)(16 * k + 4 * t + lk) * Mp + 16 * j + lr;
-                    o[t] = Nu[idx] - Hu[idx];
-                }
-            };
-            auto mm = [&](int k, const double (&bfr)[4]) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const double av = Wr[(size_t)lr * LD + 16 * k + 4 * t + lk];
-                    if (t & 1) a1 = mfma_f64(av, bfr[t], a1);
-                    else a0 = mfma_f64(av, bfr[t], a0);
-                }
-            };
-            ldn(rb, nb[0]);
-            for (int k = rb; k < NT; k += 2) {                                // (two k steps per trip: the buffers keep compile-time indices)
-                if (k + 1 < NT) ldn(k + 1, nb[1]);
-                mm(k, nb[0]);
-                if (k + 1 < NT) {
-                    if (k + 2 < NT) ldn(k + 2, nb[0]);
-                    mm(k + 1, nb[1]);
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) T1[(size_t)(lk + 4 * r) * LD + 16 * j + lr] = a0[r] + a1[r];
-        }
-        __syncthreads();
-        for (int j = wave; j < NT; j += NW) {                                 // Psi(rb, j) = 1/2 T1 W^T(:, j),  E_u = Psi o K_uu
-            d4 a0 = (d4){0.0, 0.0, 0.0, 0.0}, a1 = a0;
-            double wb[2][4];
-            auto ldw = [&](int k, double (&o)[4]) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) o[t] = Wtu[(size_t)(16 * k + 4 * t + lk) * Mp + 16 * j + lr];
-            };
-            auto mm = [&](int k, const double (&bfr)[4]) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const double av = T1[(size_t)lr * LD + 16 * k + 4 * t + lk];
-                    if (t & 1) a1 = mfma_f64(av, bfr[t], a1);
-                    else a0 = mfma_f64(av, bfr[t], a0);
-                }
-            };
-            ldw(j, wb[0]);
-            for (int k = j; k < NT; k += 2) {
-                if (k + 1 < NT) ldw(k + 1, wb[1]);
-                mm(k, wb[0]);
-                if (k + 1 < NT) {
-                    if (k + 2 < NT) ldw(k + 2, wb[0]);
-                    mm(k + 1, wb[1]);
-                }
-            }
-            const int gj = 16 * j + lr;
-            double zj[8], zj2 = 0.0;
-#pragma unroll
-            for (int p = 0; p < 8; ++p) { zj[p] = (p < P) ? ZO[(size_t)gj * 16 + 1 + p] / ilen[p] : 0.0; zj2 += zj[p] * zj[p]; }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int gi = 16 * rb + lk + 4 * r;
-                double kv = 0.0;
-                if (gi < M && gj < M) {                                        // K(Z,Z) without the jitter (ffvd_grad_oracle.py: Psi * Kuu)
-                    double dot = 0.0, zi2 = 0.0;
-#pragma unroll
-                    for (int p = 0; p < 8; ++p) {
-                        const double zi = (p < P) ? ZO[(size_t)gi * 16 + 1 + p] / ilen[p] : 0.0;
-                        dot += zi * zj[p]; zi2 += zi * zi;
-                    }
-                    kv = kernel_value<0>(dot, zi2, zj2, var);
-                }
-                Eu[(size_t)(lk + 4 * r) * LD + gj] = 0.5 * (a0[r] + a1[r]) * kv;
-            }
-        }
-        __syncthreads();
-        if (wave == 0) {
-            d4 a0 = (d4){0.0, 0.0, 0.0, 0.0}, a1 = a0;
-            for (int k = 0; k < NT; ++k) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const double av = Eu[(size_t)lr * LD + 16 * k + 4 * t + lk], bw = ZO[(size_t)(16 * k + 4 * t + lk) * 16 + lr];
-                    if (t & 1) a1 = mfma_f64(av, bw, a1);
-                    else a0 = mfma_f64(av, bw, a0);
-                }
-            }
-            double sll = 0.0;
-            const double len = (lr >= 1 && lr <= P) ? ilen[lr - 1] : 1.0, inv2 = 1.0 / (len * len);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const double v = a0[r] + a1[r];
-                const double ru = __shfl(v, lane & 48);
-                const int gi = 16 * rb + lk + 4 * r;
-                if (lr >= 1 && lr <= P) {
-                    const double z = ZO[(size_t)gi * 16 + lr];
-                    a.dz2[((size_t)u * Mp + gi) * TPP + lr - 1] = -2.0 * (z * ru - v) * inv2;       // E_u symmetric: both roles of Z
-                    sll += 2.0 * (ru * z * z - z * v) * inv2;
-                } else if (lr == 0) sll += v;
-            }
-            sll += __shfl_xor(sll, 16);
-            sll += __shfl_xor(sll, 32);
-            if (lk == 0 && lr <= P) a.kuu_part[((size_t)u * NT + rb) * (TPP + 1) + (lr == 0 ? TPP : lr - 1)] = sll;
-        }
-        __syncthreads();
-    }
+    // K_uu side, one 16-row block per strip (unless the launch has workgroups of its own for it: tiny_plan)
+    if (!a.side)
+        for (int rb = strip; rb < NT; rb += nst) tiny_kuu_rows<NW>(a, u, rb, Ks, ZO, ilen, var);
     TSTAMP(9);
-    if (tiny_arrive(cx.c2, slot) != nst - 1) return;
+    if (tiny_arrive(cx.c2, slot) != narrive2 - 1) return;
     TSTAMP(10);
     tiny_unit_done<NW>(a, u, lds, L);
     TSTAMP(11);
@@ -1207,7 +1275,6 @@ TinyPlan tiny_plan(int kind, int T, int D, int C, int M, int S, int Dl, int grad
     if (pl.Mp > TINY_MPMAX) return pl;
     pl.NT = pl.Mp / 16;
     pl.nunits = S * Dl;
-    (void)grad;
     for (int nw = 4; nw <= 8; nw += 4) {
         const int SR = 16 * nw, nst = (T + SR - 1) / SR;
         const TinyLds l = tiny_lds(pl.Mp, SR);
@@ -1217,6 +1284,7 @@ TinyPlan tiny_plan(int kind, int T, int D, int C, int M, int S, int Dl, int grad
         if (pl.NT > nst * 8) continue;                     // (the K_uu side deals its NT row blocks over the strips)
         if ((long long)pl.nunits * (1 + nst) > (long long)cus) continue;      // every workgroup resident at once, one per CU
         pl.ok = true; pl.nw = nw; pl.SR = SR; pl.nstrips = nst; pl.lds_bytes = bytes;
+        pl.side = (grad && (long long)pl.nunits * (1 + nst + pl.NT) <= (long long)cus) ? 1 : 0;
         return pl;
     }
     return pl;
@@ -1265,6 +1333,7 @@ size_t tiny_flag_ints(const TinyPlan &pl, int S) { return (size_t)4 * pl.nunits 
 void tiny_bind_scratch(TinyArgs &a, const TinyPlan &pl, double *scratch, int *flags) {
     const TinyCarve c = tiny_carve(pl, a.T, a.P, a.M, a.S, a.Dl, a.D, a.Ydim, a.grad);
     a.Mp = pl.Mp; a.NT = pl.NT; a.SR = pl.SR; a.nstrips = pl.nstrips; a.nunits = pl.nunits;
+    a.side = (a.grad && pl.side) ? 1 : 0;
     a.Wg = scratch + c.Wg; a.Wt = scratch + c.Wt; a.Pp = scratch + c.Pp; a.hterms = scratch + c.hterms;
     a.chain_terms = scratch + c.cterms; a.Hs = scratch + c.Hs; a.prior_sums = scratch + c.psums;
     a.sp_stride = a.D * a.Ydim + 2 * a.Ydim + a.Dl;
@@ -1278,7 +1347,7 @@ void tiny_bind_scratch(TinyArgs &a, const TinyPlan &pl, double *scratch, int *fl
 
 hipError_t launch_tiny(hipStream_t stream, const TinyArgs &a, const TinyPlan &pl) {
     static size_t attr_bytes[2] = {0, 0};              // dynamic LDS each instantiation has been allowed so far
-    const int grid = pl.nunits * (1 + pl.nstrips);
+    const int grid = pl.nunits * (1 + pl.nstrips + (a.side ? pl.NT : 0));
     const int which = pl.nw == 4 ? 0 : 1;
     const void *fn = which == 0 ? reinterpret_cast<const void *>(&tiny_kernel<4>) : reinterpret_cast<const void *>(&tiny_kernel<8>);
     if (pl.lds_bytes > attr_bytes[which] && pl.lds_bytes > 48 * 1024) {

@@ -25,7 +25,8 @@ assert e.lib.ffvd_debug_tiny_trace(buf) == 0
 a = np.array(buf[:]).reshape(1024, 32)
 nunits = S * D
 nst = (T + 63) // 64 if int(e.lib.ffvd_single_launch(e._h)) == 4 else (T + 127) // 128
-nwg = nunits * (1 + nst)
+NT = (M + 15) // 16
+nwg = nunits * (1 + nst + (NT if grad else 0))
 a = a[:nwg].astype(np.float64)
 t0 = a[a > 0].min()
 us = np.where(a > 0, (a - t0) / 100.0, np.nan)
@@ -41,4 +42,9 @@ print("strips of unit 0 (us):")
 for i in range(nst):
     r = us[nunits + i]
     print("  s%-3d" % i, " ".join("%s=%.1f" % (n, r[k]) for k, n in enumerate(names_s) if not np.isnan(r[k])))
+if grad and nwg > nunits * (1 + nst):
+    print("side workgroups of unit 0 (us):")
+    for rb in range(NT):
+        r = us[nunits * (1 + nst) + rb]
+        print("  k%-3d" % rb, " ".join("%s=%.1f" % (names_s[k], r[k]) for k in (0, 6, 9, 10, 11) if not np.isnan(r[k])))
 print("span of the launch: %.1f us" % np.nanmax(us))
