@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- ELBO iterations/sec on MI355X for BASELINE.json's headline workload.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c4|c5] [--dtype f64|f32c] [--route gram|reference]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c1|c2|c4|c5] [--dtype f64|f32c] [--route gram|reference]
 
 `python bench.py --gpus N` run plainly starts its N rank processes ITSELF (fresh children created before anything in
 the parent touches the GPU; the parent only waits and forwards the exit code).  Under a launcher that already set
@@ -10,6 +10,10 @@ RANK / WORLD_SIZE (`python -m torch.distributed.run --nproc-per-node N ... bench
 Workload (config.workload), default c2 = BASELINE configs[1]: synthetic T=4096, x_dim=4, M=512, S=32, SquaredExponential,
 fp64, collapsed-U branch; inputs from ffvd_amd/synthetic.py, resident in HBM before the timed region.
 One "step" = one forward evaluation of nll + its component terms for all S chains, scalar result on the host.
+--workload c1 = BASELINE configs[0], the reference's own experiment size (actuator fixture: T=512, M=100, x_dim=4, S=10 chains =
+the fixture's trajectory + 9 perturbed copies): the whole iteration is ONE kernel launch (ffvd_amd/csrc/tiny.hip); the
+line also carries the device-resident training step (forward + backward + Adam, `train_ms_per_step`) and the CPU baseline times
+ALL chains, forward and closed-form gradient.
 With N > 1 the S chains (c5: the latent dims) are sharded over the ranks, no data-path collective, and the 8 partial
 sums are all-reduced by the library's own ncclAllReduce (include/ffvd_abi.h ffvd_elbo_allreduce; torch.distributed/gloo
 only carries the 128-byte rendezvous id, the barriers and the max over ranks).  Total work is fixed: scaling = "strong".
@@ -41,7 +45,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default=WORKLOAD, choices=("c2", "c4", "c5", "small", "tiny"))
+    ap.add_argument("--workload", default=WORKLOAD, choices=("c1", "c2", "c4", "c5", "small", "tiny"))
     ap.add_argument("--dtype", default=None, choices=("f64", "f32c"),
                     help="f64 (default; c2 headline) or f32c = fp32 K_fu + fp32 MFMA contractions, fp64 M x M "
                          "factorisations and accumulation (default for c4, BASELINE configs[3])")
@@ -97,12 +101,57 @@ def parallelism_text(world, collective, reduces):
     return "8 partial sums all-reduced through torch.distributed/gloo (rehearsal or RCCL unavailable)"
 
 
-def cpu_baseline(params, Y, c, meta, sample_chains, workload):
-    """Time the oracle (NumPy restatement, reference op order) on `sample_chains` chains; extrapolate to S."""
+def load_c1(S=10):
+    """BASELINE configs[0]: the actuator fixture (tests/golden/actuator_slim.npz: standardised u, p of data/actuator.mat and the arrays
+    of one Factnonlin_ini file the path consumes, FFVD_Main.py:143-168,212-229) with S chains: chain 0 is the fixture's own
+    trajectory, chains 1.. are X + 0.1 eps_s with the seeded generator of SURVEY 8(d) (the MC latent-state draw, utils.py:11)."""
+    import numpy as np
+    z = np.load(os.path.join(ROOT, "tests", "golden", "actuator_slim.npz"), allow_pickle=False)
+    params = {k: np.array(z[k]) for k in ("X", "Z", "U", "logvariance", "loglengthscales", "log_Q", "CC", "DD", "log_Rchols")}
+    Y, c = np.array(z["Y"]), np.array(z["control_inputs"])
+    T, D = params["X"].shape[0] - 1, params["X"].shape[1]
+    rng = np.random.Generator(np.random.PCG64(20230209))
+    eps = rng.standard_normal((S, T + 1, D))
+    eps[0] = 0.0
+    params["X"] = np.ascontiguousarray(params["X"][None] + 0.1 * eps)
+    meta = dict(T=T, D=D, C=c.shape[1], M=params["Z"].shape[0], S=S, P=D + c.shape[1], Ydim=Y.shape[1],
+                kernel_type="SquaredExponential", U_collapse=True, seed=20230209)
+    return params, Y, c, meta
+
+
+def cpu_baseline_train(params, Y, c, meta, threads):
+    """The CPU counterpart of one training evaluation (nll + its gradient, what tf.gradients(nll, vars) computes per Adam step,
+    base_model.py:148, dgp_model.py:303-305): the closed-form gradient restatement on ALL chains."""
+    from oracle import ffvd_grad_oracle as gorc     # reported baseline only; never the product path
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=threads)
+    except Exception:
+        limiter = None
+    gorc.nll_grad(dict(params, X=params["X"][0]), Y, c)          # untimed: warms the BLAS thread pool
+    reps, t0 = 0, time.perf_counter()
+    while reps < 1 or time.perf_counter() - t0 < 4.0:
+        for s in range(meta["S"]):
+            gorc.nll_grad(dict(params, X=params["X"][s]), Y, c)
+        reps += 1
+    del limiter
+    return (time.perf_counter() - t0) / reps
+
+
+def cpu_baseline(params, Y, c, meta, sample_chains, workload, threads=None):
+    """Time the oracle (NumPy restatement, reference op order) on `sample_chains` chains; extrapolate to S.
+    At the reference's own experiment size a threaded BLAS is SLOWER than one thread (100 x 100 matrices: 0.56 s against 0.067 s
+    per iteration on the build box), so c1 is timed at 1 thread and at the host's share of cores and the faster one is reported."""
     import numpy as np
     from oracle import ffvd_oracle as orc      # reported baseline only; never the product path
+    if threads is None and workload == "c1":
+        one = cpu_baseline(params, Y, c, meta, sample_chains, workload, threads=1)
+        many = cpu_baseline(params, Y, c, meta, sample_chains, workload, threads=min(16, os.cpu_count() or 1))
+        best, other = (one, many) if one["value"] >= many["value"] else (many, one)
+        best["other_thread_count"] = {"cores": other["cores"], "value": other["value"]}
+        return best
     # the GPU box gives one GPU's share of the host (16 cores); more BLAS threads than that only oversubscribes
-    threads = min(16, os.cpu_count() or 1)
+    threads = threads or min(16, os.cpu_count() or 1)
     try:
         from threadpoolctl import threadpool_limits
         limiter = threadpool_limits(limits=threads)
@@ -111,25 +160,43 @@ def cpu_baseline(params, Y, c, meta, sample_chains, workload):
     kern = orc.make_kernels(params)
     T = meta["T"]
     Q = np.exp(params["log_Q"])
-    t0 = time.perf_counter()
-    Linv = orc.kernel_pre_cal(params["Z"], kern)       # shared per-dim part: K_uu, Cholesky, L^-T (:124-169)
-    t_shared = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    for s in range(sample_chains):                     # per-chain part of dgp_model.py:248-288
+
+    def one_chain(Linv, s):                            # per-chain part of dgp_model.py:248-288
         X = params["X"][s]
         xc = np.concatenate((X[:-1], c[:T]), axis=1)
         orc.collapse_after_kernel_precalculation(Linv, xc, X, params["Z"], kern, Q, float(T), float(T))
         ym = orc.predict_mean(X[1:], params["CC"], params["DD"])
         orc.logdensity_norm_diag(Y, ym, np.exp(params["log_Rchols"])[0]).sum()
         orc.logdensity_norm_diag_nonvec(X[1:], X[:-1], Q ** 0.5).sum()
-    t_chain = (time.perf_counter() - t0) / sample_chains
+
+    # small workloads (a pass takes well under a second): one untimed pass warms the BLAS thread pool, then whole passes are
+    # repeated for about 5 s and averaged; the large ones are timed once
+    small = meta["T"] * meta["M"] * meta["M"] * meta["D"] * sample_chains < 4e9
+    reps = 0
+    if small:
+        one_chain(orc.kernel_pre_cal(params["Z"], kern), 0)
+    t_shared = t_chain_total = 0.0
+    t_begin = time.perf_counter()
+    while True:
+        t0 = time.perf_counter()
+        Linv = orc.kernel_pre_cal(params["Z"], kern)   # shared per-dim part: K_uu, Cholesky, L^-T (:124-169)
+        t_shared += time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for s in range(sample_chains):
+            one_chain(Linv, s)
+        t_chain_total += time.perf_counter() - t0
+        reps += 1
+        if not small or time.perf_counter() - t_begin > 5.0:
+            break
+    t_shared /= reps
+    t_chain = t_chain_total / reps / sample_chains
     t_iter = t_shared + meta["S"] * max(t_chain, 0.0)
     del limiter
     return {
         "value": 1.0 / t_iter, "unit": "ELBO iters/sec", "cores": int(threads), "kind": "port",
         "sample": (f"{sample_chains} of {meta['S']} chains of the {workload} workload at full T/M/D, NumPy fp64 "
-                   f"(OpenBLAS, {threads} threads); per-iteration time = shared K_uu part {t_shared:.3f}s + "
-                   f"S x per-chain {max(t_chain, 0.0):.3f}s"),
+                   f"(OpenBLAS, {threads} threads), {reps} timed pass(es); per-iteration time = shared K_uu part {t_shared:.4f}s + "
+                   f"S x per-chain {max(t_chain, 0.0):.4f}s"),
         "seconds_per_iter": t_iter,
     }
 
@@ -163,7 +230,7 @@ def run_rank(args):
         dist.init_process_group("gloo", rank=rank, world_size=world)
         dist.barrier()
 
-    params, Y, c, meta = synthetic.make_named(args.workload)
+    params, Y, c, meta = load_c1() if args.workload == "c1" else synthetic.make_named(args.workload)
     mode = "dims" if meta["S"] < world or args.workload == "c5" else "chains"
     eng_kw = dict(route=args.route, dtype=args.dtype)
     if args.chains_per_pass:
@@ -279,12 +346,19 @@ def run_rank(args):
             ms_tot, launches = stage[dom]
             if dom == "kuu_chol_inverse":
                 units_per_launch = d_local * args.steps / max(launches, 1)
+        single = int(sh.engine.lib.ffvd_single_launch(sh.engine._h))
+        if single:
+            # the whole iteration is ONE launch in the reference's op order (tiny.hip): per (s,d) unit SURVEY 8(d)'s W_alg terms
+            dom = "one_launch_iteration"
+            ms_tot, launches = stage["gram_H"]
+            alg[dom] = 2 * T * M * M + M ** 3 / 3 + T * M * (2 * P + 4) + 2 * M ** 3 / 3
+            units_per_launch = s_local * d_local * args.steps / max(launches, 1)
         dur_s = ms_tot / 1e3 / max(launches, 1)
         achieved = alg[dom] * units_per_launch / dur_s / 1e12 if dur_s > 0 else 0.0
         w_alg = synthetic.algorithmic_flops(**meta)                 # SURVEY 8(d) W_alg (reference formulation)
         if lowrank:     # the formulation actually executed: per d one Cholesky with the Z^T block, per (s,d) the two P x P forms per row
             w_alg = D * (M ** 3 / 3 + 64 * M * M) + S * D * T * (2 * P * P + 4 * P)
-        if args.route == "gram":
+        if args.route == "gram" and not single:
             # structure-aware count of the formulation actually executed (SURVEY 8d requires a Gram-route build to
             # say so): per (s,d) T*M^2 syrk + M^3/3 Cholesky of K_uu + K_uf K_fu/Q + K_fu generation; per d
             # Cholesky + inverse factor + K^-1 (M^3/3 + M^3/3 + M^3).  SURVEY's W_gram for comparison: 1.643e11.
@@ -306,15 +380,21 @@ def run_rank(args):
             "metric": f"ELBO iters/sec (T={T}, M={M}, x_dim={D}, S={S})", "value": value, "unit": "iters/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "median_ms_per_step": 1e3 * float(np.median(per_step)), "min_ms_per_step": 1e3 * float(per_step.min()),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{args.workload}: synthetic T={T} x_dim={D} C={meta['C']} M={M} S={S} {kname} "
-                                   f"{'collapsed-U' if collapsed else 'explicit-U'}, seed {meta['seed']}",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype,
+            "data": "actuator fixture + synthetic chains" if args.workload == "c1" else "synthetic",
+            "config": {"workload": (f"c1: actuator fixture (tests/golden/actuator_slim.npz) T={T} x_dim={D} C={meta['C']} M={M}, S={S} chains = "
+                                    f"the fixture's trajectory + {S - 1} draws X + 0.1 eps (seed {meta['seed']}), {kname} collapsed-U"
+                                    if args.workload == "c1" else
+                                    f"{args.workload}: synthetic T={T} x_dim={D} C={meta['C']} M={M} S={S} {kname} "
+                                    f"{'collapsed-U' if collapsed else 'explicit-U'}, seed {meta['seed']}"),
                        "parallelism": f"{'chains' if mode == 'chains' else 'latent dims'} sharded over {world} GPU(s), " + exchange,
                        "chains_per_gpu": s_local, "dims_per_gpu": d_local,
                        "arithmetic": ("fp64 throughout" if args.dtype == "f64" else
                                       "K_fu and the two T x M x M products in fp32 (v_mfma_f32_32x32x2_f32); every M x M "
                                       "factorisation, the accumulation of H and the trace term in fp64"),
-                       "route": ("gram: log|K_uu + K_uf K_fu/Q| - log|K_uu| (SURVEY Appendix A), flops counted as W_gram-style"
+                       "route": ("one launch per iteration (ffvd_amd/csrc/tiny.hip), reference op order F = K_fu L^-T, H = F^T F/Q + I: "
+                                 "latency-bound by two 16-tile Cholesky pivot chains, not by the matrix pipe" if single else
+                                 "gram: log|K_uu + K_uf K_fu/Q| - log|K_uu| (SURVEY Appendix A), flops counted as W_gram-style"
                                  if args.route == "gram" else
                                  ("explicit-U with LinearK through the kernel's rank: F = sigma^2 X (Z^T L^-T), fmean and sum F^2 as "
                                   "P x P forms per row (DESIGN.md section 5); FFVD_NO_LINEAR_LOWRANK=1 runs the M-wide projection"
@@ -330,14 +410,33 @@ def run_rank(args):
                                              "frac": w_alg * value / 1e12 / peak},
                          "stage_ms_per_step": {k: v[0] / args.steps for k, v in stage.items()}},
         }
+        if args.workload == "c1" and world == 1:
+            # the device-resident training step of the reference's loop (models.py:142-182: forward + backward + Adam update)
+            from ffvd_amd.engine import ElboEngine
+            with ElboEngine(T, D, meta["C"], M, S, Ydim=meta["Ydim"], grad=True, device=local_rank) as te:
+                te.set_data(Y, c)
+                te.set_params(params)
+                for _ in range(args.warmup):
+                    te.adam_step(1e-9)
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    te.adam_step(1e-9)
+                out["train_ms_per_step"] = 1e3 * (time.perf_counter() - t0) / args.steps
+                out["train_single_launch"] = int(te.lib.ffvd_single_launch(te._h))
         if world == 1 and not args.no_cpu_baseline and collapsed:
-            n = args.cpu_sample_chains or {"c2": 16, "c4": 1}.get(args.workload, min(S, 4))
+            # (c1, c2: ALL chains are timed, nothing is extrapolated -- VERDICT r3 W10; c4: one chain x 2 dims, see cpu_baseline_c4)
+            n = args.cpu_sample_chains or {"c1": S, "c2": S, "c4": 1}.get(args.workload, min(S, 4))
             if args.workload == "c4":
                 # one (chain, dim) unit costs ~4 s of CPU: time ONE chain of ONE latent dim would not exercise the
                 # shared part; instead one chain over 2 of the 8 dims -- see cpu_baseline_c4
                 out["cpu_baseline"] = cpu_baseline_c4(params, Y, c, meta)
             else:
                 out["cpu_baseline"] = cpu_baseline(params, Y, c, meta, n, args.workload)
+            if args.workload == "c1":
+                tg = cpu_baseline_train(params, Y, c, meta, out["cpu_baseline"]["cores"])
+                out["cpu_baseline"]["train_seconds_per_step"] = tg
+                out["cpu_baseline"]["train_sample"] = (f"nll + closed-form gradient (oracle/ffvd_grad_oracle.py) of all {S} chains, NumPy fp64, "
+                                                       f"{out['cpu_baseline']['cores']} threads: the CPU counterpart of one train_hypers evaluation")
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     os.close(json_fd)

@@ -75,6 +75,42 @@ def test_one_json_line_with_the_agreed_keys():
         assert "no collective" in par
 
 
+def test_c1_workload_is_the_actuator_fixture():
+    """--workload c1 = BASELINE configs[0]: the actuator fixture with S = 10 chains, chain 0 the fixture's own trajectory (its nll is
+    the golden value), the others perturbed with the seeded generator of SURVEY 8(d)."""
+    import numpy as np
+    import bench
+    from oracle import ffvd_oracle as orc
+    assert bench.parse_args(["--workload", "c1"]).workload == "c1"
+    params, Y, c, meta = bench.load_c1()
+    assert (meta["T"], meta["M"], meta["D"], meta["C"], meta["S"], meta["P"]) == (512, 100, 4, 1, 10, 5)
+    assert params["X"].shape == (10, 513, 4) and Y.shape == (512, 1)
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "golden_actuator.npz"))
+    got = orc.nll_terms(dict(params, X=params["X"][0]), Y, c, U_collapse=True)["nll"]
+    assert got == pytest.approx(float(gold["B_nll"]), rel=1e-12)
+    assert np.max(np.abs(params["X"][1] - params["X"][0])) > 0.1       # the other chains are draws, not copies
+    p2 = bench.load_c1()[0]
+    np.testing.assert_array_equal(p2["X"], params["X"])                 # seeded
+
+
+@pytest.mark.gpu
+def test_c1_line_has_gpu_and_cpu_side_by_side():
+    """VERDICT r3 Missing 2: configs[0] -- the one configuration a CPU can run in milliseconds -- with the CPU baseline of ALL chains
+    beside it, forward and training step, the whole iteration in one launch."""
+    d = _run(["--workload", "c1", "--steps", "20", "--warmup", "5"])
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["metric"].startswith("ELBO iters/sec (T=512, M=100, x_dim=4, S=10)")
+    assert "actuator" in d["config"]["workload"] or "c1" in d["config"]["workload"]
+    assert "one launch" in d["config"]["route"]
+    assert d["train_ms_per_step"] > 0.0 and d["train_single_launch"] in (4, 8)
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0.0 and "10 of 10 chains" in cb["sample"]
+    assert cb["train_seconds_per_step"] > 0.0
+    assert 0.0 < d["roofline"]["frac"] < 1.0
+    assert d["nll"] == pytest.approx(d["nll"])          # finite
+
+
 @pytest.mark.gpu
 def test_plain_invocation_with_two_gpus_starts_its_own_ranks():
     """`python bench.py --gpus 2` without a launcher: the parent spawns the ranks itself.  On the one-GPU test box both ranks share

@@ -194,3 +194,72 @@ def test_model_loop_runs_on_one_launch_per_step():
         for _ in range(30):
             last = e.adam_step(0.003)["nll"]
     assert last < first
+
+
+_STALL_SCRIPT = r"""
+import sys, time
+import numpy as np
+from ffvd_amd import synthetic, _lib
+from ffvd_amd.engine import ElboEngine
+from ffvd_amd.distributed import ShardedElbo
+lib = _lib.load()
+params, Y, c, meta = synthetic.make_named("small")
+with ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], meta["S"], grad=True) as e:
+    assert int(lib.ffvd_single_launch(e._h))
+    e.set_data(Y, c)
+    t0 = time.perf_counter()
+    t = e.nll_terms(params)
+    el = time.perf_counter() - t0
+    n1 = int(lib.ffvd_stall_recoveries(e._h))
+    w = lib.ffvd_last_error(e._h).decode()
+    tg, g = e.nll_and_grad(params)
+    n2 = int(lib.ffvd_stall_recoveries(e._h))
+print("ELBO", repr(t["nll"]), repr(tg["nll"]), n1, n2, round(el, 2), "MSG", w)
+np.save(sys.argv[1], g["Z"])
+# a collective step does not retry: it must fail, and the sums it would have contributed are NaN (never the previous iteration's)
+sh = ShardedElbo(params, Y, c, meta, rank=0, world=1, mode="chains", device=0, always_reduce=True)
+try:
+    sh.step()
+    print("COLLECTIVE OK")
+except Exception as exc:
+    print("COLLECTIVE", type(exc).__name__, str(exc).replace(" ", "_")[:200])
+sh.close()
+"""
+
+
+def test_one_launch_gives_up_instead_of_hanging(tmp_path):
+    """Every wait of the one-launch iteration is bounded (the roles wait for each other inside ONE launch, and their progress rests
+    on all workgroups being resident).  In the test build `libffvd_hip_tinystall.so` the head of unit 0 never publishes W: its
+    strips give up after the 1 s bound, set the abort word, every waiting workgroup leaves, the launch ends with info = -1.  The
+    synchronous entry points then run the iteration ONCE more on the multi-kernel schedule (launch-per-column Cholesky), return OK
+    with a warning, and the result equals the golden value; a collective step does not retry and must raise."""
+    import subprocess
+    import sys
+    import time
+    from ffvd_amd import build as fb
+    lib_path = fb.build_variant("tinystall")
+    env = dict(os.environ, FFVD_LIB=lib_path, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env.pop("FFVD_CHOL", None)
+    env.pop("FFVD_NO_TINY", None)
+    zpath = str(tmp_path / "dz.npy")
+    t0 = time.perf_counter()
+    out = subprocess.run([sys.executable, "-c", _STALL_SCRIPT, zpath], env=env, capture_output=True, text=True, timeout=200)
+    assert out.returncode == 0, out.stderr[-2000:]
+    eline = [ln for ln in out.stdout.splitlines() if ln.startswith("ELBO")][0].split()
+    gold = float(load_golden("small")["B_nll"])
+    assert float(eline[1]) == pytest.approx(gold, rel=1e-8) and float(eline[2]) == pytest.approx(gold, rel=1e-8)
+    assert int(eline[3]) == 1 and int(eline[4]) == 2       # one recovery per call
+    assert 0.5 < float(eline[5]) < 30.0                    # the bound is 1 s per wait; workgroups give up together via the abort word
+    assert "re-run" in " ".join(eline[6:])
+    cline = [ln for ln in out.stdout.splitlines() if ln.startswith("COLLECTIVE")][0]
+    assert "OK" not in cline.split()[1:2] and ("abandoned" in cline or "non-finite" in cline), cline
+    assert time.perf_counter() - t0 < 150.0
+    # the product library still works on the same GPU afterwards, and gives the gradient the recovered run produced (multi-kernel
+    # backward pass there, one launch here: eps * cond(K_uu) apart on dZ)
+    params, Y, c, meta = synthetic.make_named("small")
+    with engine(meta, grad=True) as e:
+        e.set_data(Y, c)
+        _, g = e.nll_and_grad(params)
+        assert int(e.lib.ffvd_stall_recoveries(e._h)) == 0
+    dz = np.load(zpath)
+    np.testing.assert_allclose(dz, g["Z"], rtol=0, atol=5e-6 * float(np.max(np.abs(g["Z"]))))
