@@ -87,6 +87,7 @@ _SIGNATURES = {
                                    C.POINTER(C.c_double)]),
     "ffvd_stall_recoveries": (C.c_int, [C.c_void_p]),
     "ffvd_single_launch": (C.c_int, [C.c_void_p]),
+    "ffvd_schedule_name": (C.c_char_p, [C.c_void_p]),
     "ffvd_get_stream": (C.c_void_p, [C.c_void_p]),
     "ffvd_optimizer_reset": (C.c_int, [C.c_void_p]),
     "ffvd_update_params": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -44,6 +44,7 @@ struct ffvd_handle {
     double *growpart = nullptr;                  // Gram route: per-64-row-block partial sums of delta^T K_fu from the K_fu build
     hipStream_t aux = nullptr;          // side stream: the K_uu chain runs beside the K_fu build (Gram route)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_kuu = nullptr, ev_tiles = nullptr, ev_go = nullptr;
+    hipEvent_t ev_hwords = nullptr;     // recorded right behind a side-stream clear of Cholesky(A)'s progress words: the launch that trusts the clear waits for IT
     std::string err;
     std::vector<void *> allocs;
     int64_t ws_bytes = 0;
@@ -59,6 +60,8 @@ struct ffvd_handle {
         bool lt_armed = false;            // FFVD_GRAD_LT_ARMED=1: write the L^T rows to memory (launch_set_lt_rows) even where the dataflow kernel could read L itself
         bool whiten_products = false;     // FFVD_GRAD_WHITEN_PRODUCTS=1: training forward forms H = W^T A W with two products (round 1/2) instead of arming L^T rows
         bool debug_sync = false;    // FFVD_DEBUG_SYNC: name every launch group on stderr and wait for it (locates a faulting kernel)
+        int side_delay_us = 0;      // FFVD_DEBUG_SIDE_DELAY_US=n: a spin kernel of n us at the head of every side-stream fork (schedule tests: results
+        int main_delay_us = 0;      //   must not depend on which stream is late); FFVD_DEBUG_MAIN_DELAY_US=n: the same on the main stream behind a fork
         bool no_tiny = false;       // FFVD_NO_TINY=1: the multi-kernel schedule also at the reference's own experiment size (rounds 1-3)
     } sw;
     // resident parameters / data (handle-owned copies)
@@ -188,6 +191,7 @@ extern "C" int ffvd_destroy(ffvd_handle *h) {
     if (h->ev_kuu) hipEventDestroy(h->ev_kuu);
     if (h->ev_tiles) hipEventDestroy(h->ev_tiles);
     if (h->ev_go) hipEventDestroy(h->ev_go);
+    if (h->ev_hwords) hipEventDestroy(h->ev_hwords);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
     return FFVD_OK;
@@ -206,6 +210,8 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
         w.atb128 = on("FFVD_ATB128");                 w.grad_serial = on("FFVD_GRAD_SERIAL");
         w.debug_sync = on("FFVD_DEBUG_SYNC");
         w.no_tiny = on("FFVD_NO_TINY");
+        if (const char *e = getenv("FFVD_DEBUG_SIDE_DELAY_US")) w.side_delay_us = atoi(e);
+        if (const char *e = getenv("FFVD_DEBUG_MAIN_DELAY_US")) w.main_delay_us = atoi(e);
     }
     h->P = c.D + c.C;
     h->Dl = c.d_count > 0 ? c.d_count : c.D;
@@ -238,6 +244,7 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
     HIP_TRY(hipEventCreateWithFlags(&h->ev_kuu, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_tiles, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_go, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_hwords, hipEventDisableTiming));
     HIP_TRY(dev_alloc(h, &h->X, (size_t)c.S_local * (c.T + 1) * c.D));
     HIP_TRY(dev_alloc(h, &h->Z, (size_t)c.M * P));
     HIP_TRY(dev_alloc(h, &h->U, (size_t)c.M * c.D));
@@ -582,6 +589,87 @@ struct StageTimer {
     }
 };
 
+// ---- which schedule an iteration runs: EVERY flag in one place -------------------------------------------------------
+// enqueue_elbo consumes these and computes none of its own; what it still tracks by itself is launch PROGRESS (which buffers a
+// launch already produced: linv_done, kinv_done, hwords_zeroed, reduce_done ...).  The only run-time input besides the handle's
+// constants is the Cholesky variant forced for the calling thread (stall recovery / FFVD_CHOL), through potrf_flow_selected.
+struct ElboSchedule {
+    bool gram_route, grad_a, grad_ref;
+    bool lt_rows, lt_virtual;       // Gram-route training: L^T in the extension rows of A (read in place by the dataflow kernel)
+    int first_units, ns_first;
+    bool late_join;                 // split-K first pass: the K_uu chain only has to be back for the combine pass
+    bool defer_trace;               //   ... one pass: the combine pass waits for the K_uu COPY only, trace partials follow on the side stream
+    bool main_first;                //   ... and the main stream's K_fu build + tile pass are enqueued before the chain's launches
+    bool defer_full;                // unsplit first pass beside the chain: raw tiles kept, trace pass on the side stream
+    bool side_chain;                // Gram route: the K_uu chain runs on the side stream
+    bool kuu_flow;                  //   ... as ONE dataflow launch resident before the K_fu build, joined before the Gram kernel
+    bool kfu_first, ident_on_side;
+    bool zt_rows, ref_side;         // explicit-U / reference route: the chain's dataflow launch beside the K_fu build
+    bool small_side;                // tiny iteration on the multi-kernel path: the side chain as one dataflow launch, reductions on the main stream
+    bool chain_flow_here;           // the chain is the dataflow launch on the stream that builds K_uu (the build zeroes its words)
+    bool reduce_early;
+    const char *name;
+};
+static ElboSchedule plan_schedule(const ffvd_handle *h) {
+    const ffvd_config &c = h->cfg;
+    const int Mp = h->Mp, Tp = h->Tp, Dl = h->Dl;
+    ElboSchedule sc{};
+    sc.gram_route = (c.branch == FFVD_BRANCH_B && c.route == FFVD_ROUTE_GRAM);
+    sc.grad_a = c.grad && c.branch == FFVD_BRANCH_A;
+    sc.grad_ref = c.grad && c.branch == FFVD_BRANCH_B && !sc.gram_route;
+    sc.first_units = ((c.S_local < h->cpp) ? c.S_local : h->cpp) * Dl;
+    sc.ns_first = (h->cpp <= c.S_local) ? h->cpp : c.S_local;
+    sc.late_join = sc.gram_route && h->gpart && sc.first_units == h->cpp * Dl && !h->sw.no_late_join;
+    sc.lt_rows = c.grad && sc.gram_route && h->gw.whitened && !h->sw.whiten_products;
+    sc.lt_virtual = sc.lt_rows && !h->sw.lt_armed && potrf_flow_selected(Mp, h->nbatch, CHOL_FLOW);
+    sc.defer_trace = sc.late_join && c.S_local <= h->cpp && !h->sw.no_defer_trace;
+    sc.main_first = sc.defer_trace && !h->sw.no_main_first;
+    sc.defer_full = sc.gram_route && !sc.late_join && h->graw;
+    sc.zt_rows = h->lrpart != nullptr;
+    sc.ref_side = !sc.gram_route && h->ngr > 0 && c.dtype != FFVD_F32C && h->aux && !h->sw.no_ref_side && !h->sw.chain_rl &&
+                  potrf_flow_selected(Mp, Dl, CHOL_FLOW);
+    sc.side_chain = sc.gram_route && (sc.late_join || (size_t)sc.first_units * Tp * Mp >= (size_t)64 * 4096 * 512);
+    sc.kuu_flow = sc.side_chain && h->kuu_flow_sched && !sc.late_join;
+    sc.kfu_first = sc.side_chain && (sc.main_first || (sc.defer_full && !h->sw.no_kfu_first));
+    sc.ident_on_side = sc.side_chain && c.grad && (sc.defer_full || sc.defer_trace) && !sc.lt_rows;
+    const bool on_side = sc.ref_side || sc.side_chain;          // sk != s
+    const bool kuu_on_main = sc.ref_side || sc.kuu_flow;        // K_uu is built (and its chain launched) before the common chain code
+    sc.reduce_early = sc.gram_route && on_side;
+    sc.small_side = sc.defer_trace && sc.main_first && !c.grad && !kuu_on_main && on_side && !h->sw.chain_rl && !h->sw.no_small_side &&
+                    (size_t)sc.first_units * h->ntiles * (h->gsplit > 1 ? h->gsplit : 1) <= (size_t)h->sw.small_side_wgs &&
+                    (size_t)Dl * 2 * (Mp / NB) <= 32;
+    sc.chain_flow_here = !kuu_on_main && (!on_side || sc.small_side) && potrf_flow_selected(Mp, Dl, CHOL_FLOW) && !h->sw.chain_rl;
+    // invariants the launch code relies on (a violated one would be a silent wrong answer, not a crash)
+    if ((sc.defer_full && sc.late_join) || (sc.defer_trace && !sc.late_join) || (sc.kuu_flow && sc.defer_full) || (sc.small_side && sc.kuu_flow) ||
+        (sc.ref_side && sc.side_chain) || (sc.main_first && !sc.defer_trace) || (sc.kuu_flow && h->graw))
+        sc.name = nullptr;
+    else if (!sc.gram_route) sc.name = sc.ref_side ? "projection route, K_uu chain as one dataflow launch on the side stream beside the K_fu build"
+                                                   : "projection route, serial (K_uu chain on the main stream)";
+    else if (sc.kuu_flow) sc.name = "full unsplit: K_uu chain as one dataflow launch beside the K_fu build, joined before the Gram kernel";
+    else if (sc.defer_full && sc.side_chain) sc.name = "unsplit with raw tiles: K_uu chain beside K_fu build and Gram kernel, trace pass on the side stream, joined at finalize";
+    else if (sc.small_side) sc.name = "small side: split-K one pass, side chain as one dataflow launch, reductions and trace partials on the main stream";
+    else if (sc.defer_trace) sc.name = "split-K one pass, late join: combine waits for the K_uu copy, trace partials on the side stream";
+    else if (sc.late_join) sc.name = "split-K several passes: the first combine pass waits for the whole chain";
+    else sc.name = "serial: K_uu chain on the main stream in front of the K_fu build";
+    return sc;
+}
+extern "C" const char *ffvd_schedule_name(const ffvd_handle *h) {
+    if (!h) return "";
+    if (h->tiny.ok && potrf_override_current() == CHOL_FORCE_NONE) return "one launch (tiny.hip)";
+    const ElboSchedule sc = plan_schedule(h);
+    return sc.name ? sc.name : "INVALID";
+}
+
+// Fork the side stream off the main stream.  Diagnostic switches (schedule tests): a spin kernel at the head of the side stream
+// (FFVD_DEBUG_SIDE_DELAY_US) and / or of the main stream behind the fork (FFVD_DEBUG_MAIN_DELAY_US) -- results must not change.
+static int fork_side(ffvd_handle *h, hipEvent_t ev, hipStream_t from, hipStream_t to) {
+    HIP_TRY(hipEventRecord(ev, from));
+    HIP_TRY(hipStreamWaitEvent(to, ev, 0));
+    if (h->sw.side_delay_us > 0) launch_spin(to, h->sw.side_delay_us);
+    if (h->sw.main_delay_us > 0) launch_spin(from, h->sw.main_delay_us);
+    return FFVD_OK;
+}
+
 // The iteration (with_grad: and its backward pass, gradients scaled by 1 / S_total into the arrays of gw) as ONE launch: tiny.hip.
 static bool tiny_selected(const ffvd_handle *h) { return h->tiny.ok && potrf_override_current() == CHOL_FORCE_NONE; }
 static int enqueue_tiny(ffvd_handle *h, double *out_dev, StageTimer *st, bool with_grad, int S_total) {
@@ -626,7 +714,9 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
     launch_prep_hypers(s, c.kernel_kind, p.Z, c.M, Mp, P, Dl, c.d_begin, p.logvariance, p.loglengthscales,
                        h->variance, h->len, h->Zs, h->zz, h->info, Dl + h->nbatch);
     HyperView hv{h->variance, h->len, h->Zs, h->zz};
-    const bool gram_route = (c.branch == FFVD_BRANCH_B && c.route == FFVD_ROUTE_GRAM);
+    const ElboSchedule sc = plan_schedule(h);
+    if (!sc.name) return set_error(h, FFVD_EINVAL, "internal: inconsistent schedule flags (plan_schedule)");
+    const bool gram_route = sc.gram_route;
     // Gram route: nothing of the K_fu build depends on K_uu, so the latency-bound K_uu chain (build, Cholesky with
     // the L^-T rows, K^-1, log|K|: a handful of workgroups per launch) runs on the side stream.  Schedules, by what
     // the first pass looks like (DESIGN.md section 5 has the measurements):
@@ -637,23 +727,22 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
     //   split-K Gram, several passes (late_join only): the combine pass of the first pass waits for the whole chain.
     //   small unsplit pass without raw-tile buffer: the chain runs first on the main stream (sk == s).
     hipStream_t sk = s;
-    const int first_units = ((c.S_local < h->cpp) ? c.S_local : h->cpp) * Dl;
     // split-K first pass: its tile kernel writes raw partials and needs neither K_uu nor K^-1, so the chain may run
     // beside the K_fu build AND the tile pass and only has to be back for the combine pass
-    const bool late_join = gram_route && h->gpart && first_units == h->cpp * Dl && !h->sw.no_late_join;
+    const bool late_join = sc.late_join;
     const size_t kstride = (size_t)2 * Mp * Mp;
     const size_t msq = (size_t)Mp * Mp;
-    const bool grad_a = c.grad && c.branch == FFVD_BRANCH_A;
-    const bool grad_ref = c.grad && c.branch == FFVD_BRANCH_B && !gram_route;     // training in the reference's op order (fp64 or fp32 contractions)
+    const bool grad_a = sc.grad_a;
+    const bool grad_ref = sc.grad_ref;     // training in the reference's op order (fp64 or fp32 contractions)
     // Gram-route training, whitened backward pass (the default): the extension rows of every A-slab are armed with L^T instead of
     // I, so that the factorisation of A leaves L^T L_A^-T = L_H^-T there (L_H = L^-1 L_A is the factor of H = L^-1 A L^-T) and
     // y = L_A^-1 c = L_H^-1 W^T c in the b row: everything the whitened backward pass reads, without the two M^3 products per
     // unit that formed H (0.8 ms at config 2).  DESIGN.md section 7.
-    const bool lt_rows = c.grad && gram_route && h->gw.whitened && !h->sw.whiten_products;
+    const bool lt_rows = sc.lt_rows;
     // ... and the dataflow factorisation reads L^T straight from the factor L (kernels.h, launch_potrf_ext lt_rows): nothing to arm,
     // 2 x 268 MB less traffic at config 2.  The launch-per-column variants (forced by FFVD_CHOL or by the stall recovery) read the
     // rows from memory: launch_set_lt_rows in front of them.
-    const bool lt_virtual = lt_rows && !h->sw.lt_armed && potrf_flow_selected((int)Mp, h->nbatch, CHOL_FLOW);
+    const bool lt_virtual = sc.lt_virtual;
     auto project_args = [&](int s0, int ns) {
         ProjectArgs pa{};
         pa.kind = c.kernel_kind;
@@ -705,29 +794,28 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
     // K_fu build + tile pass at 4 chains), and the only thing the main stream needs from its tail is K^-1 for the trace
     // partials.  So the combine pass waits for the K_uu copy alone, Cholesky(A) starts at once, and the trace partials
     // are computed from the same raw partial tiles on the side stream once K^-1 is there.
-    const bool defer_trace = late_join && c.S_local <= h->cpp && !h->sw.no_defer_trace;
+    const bool defer_trace = sc.defer_trace;
     // ... and with the main stream now the critical one, its K_fu build and tile pass are enqueued BEFORE the ~25
     // launches of the chain (the caller reads the result back every iteration, so each iteration starts on idle streams)
-    const bool main_first = defer_trace && !h->sw.no_main_first;
+    const bool main_first = sc.main_first;
     // Unsplit first pass beside the chain: same idea with the raw tiles written by the Gram kernel itself
-    const bool defer_full = gram_route && !late_join && h->graw;
-    const int ns_first = (h->cpp <= c.S_local) ? h->cpp : c.S_local;
-    bool kfu_first = false;     // the first pass's K_fu build goes to the main stream before the chain is enqueued
-    bool ident_on_side = false, kuu_on_main = false, linv_done = false, hwords_zeroed = false, ident_early = false;
+    const bool defer_full = sc.defer_full;
+    const int ns_first = sc.ns_first;
+    const bool kfu_first = sc.kfu_first;     // the first pass's K_fu build goes to the main stream before the chain is enqueued
+    const bool ident_on_side = sc.ident_on_side;
+    bool kuu_on_main = false, linv_done = false, hwords_zeroed = false, ident_early = false;      // launch progress, not schedule
     bool kinv_done = false;     // K^-1 came out of the chain's dataflow launch (no product launch)
     // Reference route / explicit-U branch on the projection GEMM (fp64): only the GEMM needs the chain's W = L^-T, the K_fu build
     // does not -- the chain's dataflow launch goes to the side stream (resident before the build floods the chip, as in the Gram
     // route's schedule below) and the main stream waits for it in front of the first projection GEMM: config 2 in the reference's
     // op order 6.31 -> 6.05 ms.  (Config 5 generates K_fu inside its projection kernel: nothing to overlap there.)
     // LinearK through its rank (h->lrpart, forward of the explicit-U branch): the chain carries Z^T instead of the identity rows
-    const bool zt_rows = h->lrpart != nullptr;
-    const bool ref_side = !gram_route && h->ngr > 0 && c.dtype != FFVD_F32C && h->aux && !h->sw.no_ref_side &&
-                          !h->sw.chain_rl && potrf_flow_selected((int)Mp, (int)Dl, CHOL_FLOW);
+    const bool zt_rows = sc.zt_rows;
+    const bool ref_side = sc.ref_side;
     if (ref_side) {
         sk = h->aux;
         launch_kuu_build(s, c.kernel_kind, hv, c.M, Mp, P, Dl, c.jitter, h->Kuu, (grad_a || grad_ref) ? h->Kcopy : nullptr, zt_rows);
-        HIP_TRY(hipEventRecord(h->ev_fork, s));
-        HIP_TRY(hipStreamWaitEvent(sk, h->ev_fork, 0));
+        { int rcf = fork_side(h, h->ev_fork, s, sk); if (rcf) return rcf; }
         potrf_flow_clear(sk, h->dinvK, (int)Dl);
         HIP_TRY(hipEventRecord(h->ev_go, sk));
         linv_done = grad_a || grad_ref;
@@ -736,13 +824,12 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
         HIP_TRY(hipStreamWaitEvent(s, h->ev_go, 0));
         kuu_on_main = true;          // (built and factorised: chain_rest below adds K^-1 / log|K| where a backward pass wants them)
     }
-    if (gram_route && (late_join || (size_t)first_units * Tp * Mp >= (size_t)64 * 4096 * 512)) {
+    if (sc.side_chain) {
         sk = h->aux;
-        kuu_on_main = h->kuu_flow_sched && !late_join;
+        kuu_on_main = sc.kuu_flow;
         if (kuu_on_main)
             launch_kuu_build(s, c.kernel_kind, hv, c.M, Mp, P, Dl, c.jitter, h->Kuu, h->Kcopy);
-        HIP_TRY(hipEventRecord(h->ev_fork, s));
-        HIP_TRY(hipStreamWaitEvent(sk, h->ev_fork, 0));
+        { int rcf = fork_side(h, h->ev_fork, s, sk); if (rcf) return rcf; }
         if (kuu_on_main) {
             HIP_TRY(hipEventRecord(h->ev_kuu, s));
             linv_done = potrf_flow_selected((int)Mp, (int)Dl, CHOL_FLOW);      // L^-1 comes out of the factorisation itself
@@ -769,11 +856,11 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
                 HIP_TRY(hipStreamWaitEvent(s, h->ev_go, 0));
                 if (c.S_local <= h->cpp) {          // single pass: the words of Cholesky(A) are cleared here, off the main stream
                     potrf_flow_clear(sk, h->dinvH, h->nbatch);
+                    HIP_TRY(hipEventRecord(h->ev_hwords, sk));      // the factorisation that trusts this clear waits for THIS event
                     hwords_zeroed = true;
                 }
             }
         }
-        kfu_first = main_first || (defer_full && !h->sw.no_kfu_first);
         if (kfu_first) {
             if (st) st->mark(0);
             launch_kfu_build(s, project_args(0, ns_first));
@@ -787,23 +874,19 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
         }
         // training: the identity rows that become L_A^-T are re-armed on the side stream, ahead of the K_uu build whose
         // event the main stream waits for anyway (0.05 ms off the critical path at the full batch)
-        ident_on_side = c.grad && (defer_full || defer_trace) && !lt_rows;
         if (ident_on_side) {
             const GramArgs ga = gram_args(0, ns_first);
             launch_set_identity(sk, h->H, ga.h_stride, Mp, Mp, ns_first * Dl);
         }
     }
     const ReduceArgs ra = reduce_args();
-    const bool reduce_early = gram_route && sk != s;
+    const bool reduce_early = sc.reduce_early;
     // The whole iteration is a handful of workgroups (the reference's own experiment size, FFVD_Main.py:356-369: M = 100, T <= 512):
     // nothing competes for slots and the side chain IS the critical path -- ONE dataflow launch that also leaves L^-1 and K^-1
     // instead of six dependent launches, and the per-chain reductions move to the main stream, which has the slack there
-    const bool small_side = defer_trace && main_first && !c.grad && !kuu_on_main && sk != s && !h->sw.chain_rl && !h->sw.no_small_side &&
-                            (size_t)first_units * h->ntiles * (h->gsplit > 1 ? h->gsplit : 1) <= (size_t)h->sw.small_side_wgs &&
-                            (size_t)Dl * 2 * (Mp / NB) <= 32;       // (the chain's block rows: at M = 512 they are 64 and the tile pass feels them:
-                                                                     //  0.66 / 0.95 against 0.60 / 0.76 ms at 1 / 4 chains)
+    const bool small_side = sc.small_side;
     // (chain as the dataflow launch on the stream that builds K_uu: the build zeroes its progress words, one launch less)
-    const bool chain_flow_here = !kuu_on_main && ((sk == s) || small_side) && potrf_flow_selected((int)Mp, (int)Dl, CHOL_FLOW) && !h->sw.chain_rl;
+    const bool chain_flow_here = sc.chain_flow_here;
     int chain_rc = FFVD_OK;
     const bool reduce_on_main = small_side;
     bool reduce_launched = false, trace_on_main = false;
@@ -989,10 +1072,12 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
                     HIP_TRY(hipMemcpy2DAsync(h->H + 2 * msq, ga.h_stride * sizeof(double), g.bw, (size_t)Mp * sizeof(double),
                                              (size_t)Mp * sizeof(double), (size_t)nbp, hipMemcpyDeviceToDevice, s));
                 }
+                if (hwords_zeroed && s0 == 0) HIP_TRY(hipStreamWaitEvent(s, h->ev_hwords, 0));      // the side-stream clear of these words
                 launch_potrf_ext(s, h->H, Mp, Mp + NB, Mp, ns * Dl, ga.h_stride, h->info + Dl + s0 * Dl, h->dinvH, CHOL_FLOW, nullptr, 0,
                                  hwords_zeroed && s0 == 0, true, nullptr, 0, lt_virtual ? h->Kuu : nullptr, kstride, Dl);
                 launch_h_finish(s, h->H, Mp, ga.h_stride, ns * Dl, h->hterms + (size_t)2 * s0 * Dl, 2 * Mp);
             } else {
+                if (hwords_zeroed && s0 == 0) HIP_TRY(hipStreamWaitEvent(s, h->ev_hwords, 0));      // the side-stream clear of these words
                 launch_potrf_ext(s, h->H, Mp, NB, 0, ns * Dl, ga.h_stride, h->info + Dl + s0 * Dl, h->dinvH, CHOL_FLOW, nullptr, 0,
                                  hwords_zeroed && s0 == 0, true);
                 launch_h_finish(s, h->H, Mp, ga.h_stride, ns * Dl, h->hterms + (size_t)2 * s0 * Dl);
@@ -1377,8 +1462,7 @@ static int enqueue_grad_b(ffvd_handle *h, int S_total) {
         return FFVD_OK;
     };
     if (tiny) {
-        HIP_TRY(hipEventRecord(h->ev_fork, s));
-        HIP_TRY(hipStreamWaitEvent(sk, h->ev_fork, 0));
+        { int rcf = fork_side(h, h->ev_fork, s, sk); if (rcf) return rcf; }
         kgk_chain();
     }
     if (wh) {
@@ -1400,10 +1484,7 @@ static int enqueue_grad_b(ffvd_handle *h, int S_total) {
     // K_uu side: Psi_d = sum_s Gamma_s / alpha_d - 1/2 K^-1 (sum_s A_s - S K) K^-1.  It needs Gamma and the saved
     // A-matrices only, so its dozen small launches go to the side stream and run beside the E product
     // (enqueued after it: the main stream must not wait for their launch overhead).
-    if (sk != s) {
-        HIP_TRY(hipEventRecord(tiny ? h->ev_go : h->ev_fork, s));          // Gamma is there
-        HIP_TRY(hipStreamWaitEvent(sk, tiny ? h->ev_go : h->ev_fork, 0));
-    }
+    if (sk != s) { int rcf = fork_side(h, tiny ? h->ev_go : h->ev_fork, s, sk); if (rcf) return rcf; }          // Gamma is there
     EReduceArgs er{};
     er.E = g.E; er.e_stride = fstride; er.Kf = Kf64; er.u = g.u; er.u_stride = Mp; er.x_is_z = 0;
     er.x = p.X; er.x_chain_stride = (size_t)(c.T + 1) * c.D; er.x_ld = c.D; er.x_cols = c.D; er.ctrl = h->ctrl; er.C = c.C;

@@ -61,6 +61,7 @@ enum { CHOL_AUTO = 0, CHOL_FLOW = 3 };
 // force a variant for the launches this THREAD enqueues from now on: 0 = back to the normal choice, 1 = left-looking launches per
 // block column, 2 = right-looking launches (neither has inter-workgroup waits); used to re-run a batch whose dataflow launch gave up
 enum { CHOL_FORCE_NONE = 0, CHOL_FORCE_LEFT = 1, CHOL_FORCE_RIGHT = 2 };
+void launch_spin(hipStream_t stream, int us);
 void potrf_override_variant(int variant);
 int potrf_override_current();
 size_t potrf_scratch_doubles(int n, int batch);

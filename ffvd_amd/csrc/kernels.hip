@@ -45,6 +45,15 @@ __global__ void fill_kernel(double *p, size_t n, double v) {
     size_t stride = (size_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) p[i] = v;
 }
+// Diagnostic (schedule tests, FFVD_DEBUG_SIDE_DELAY_US / FFVD_DEBUG_MAIN_DELAY_US): one wavefront that occupies its stream for `us`
+// microseconds of the 100 MHz wall clock and touches no memory.
+__global__ void spin_kernel(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+void launch_spin(hipStream_t stream, int us) {
+    if (us > 0) hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, stream, (long long)us * 100);
+}
 void launch_fill(hipStream_t stream, double *p, size_t n, double v) {
     if (n == 0) return;
     int blocks = (int)((n + 255) / 256);

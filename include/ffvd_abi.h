@@ -136,6 +136,11 @@ int  ffvd_stall_recoveries(const ffvd_handle *h);
  * (4 or 8).  The arithmetic is the reference's op order (F = K_fu L^-T, H = I + F^T F / Q, conditionals_multi_output.py:230-257)
  * whatever cfg.route says.  FFVD_NO_TINY=1 in the environment keeps the multi-kernel schedule. */
 int  ffvd_single_launch(const ffvd_handle *h);
+/* One line naming the launch schedule the handle's iteration runs (decided from the configuration in ONE place, plan_schedule in
+ * abi.hip; "INVALID" if its consistency check ever fails -- the ELBO entry points then return FFVD_EINVAL instead of a wrong
+ * number).  Diagnostics: FFVD_DEBUG_SIDE_DELAY_US / FFVD_DEBUG_MAIN_DELAY_US = n (read at ffvd_create) put a spin kernel of n
+ * microseconds at the head of the side / main stream at every fork; results must be bit-identical with and without. */
+const char *ffvd_schedule_name(const ffvd_handle *h);
 /* bytes of device workspace owned by the handle */
 int64_t ffvd_workspace_bytes(const ffvd_handle *h);
 

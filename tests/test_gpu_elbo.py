@@ -1124,3 +1124,61 @@ def test_an_abandoned_factorisation_fails_on_every_rank(tmp_path):
     assert "abandoned" in lines[1][2] or "bounded" in lines[1][2] or "abandoned" in lines[1][3], lines[1]     # the stalled rank names its own failure
     assert "another_rank" in lines[0][2] and "another_rank" in lines[0][3], lines[0]
     assert lines[0][5] == lines[1][5]                               # replicas still equal
+
+
+def _schedule_case(case):
+    if case == "c2_full":
+        params, Y, c, meta = synthetic.make_named("c2")
+        return params, Y, c, meta, dict(route="gram"), "full unsplit"
+    if case == "c2_rank4":
+        params, Y, c, meta = synthetic.make_named("c2", S=4)
+        return params, Y, c, meta, dict(route="gram"), "split-K one pass"
+    if case == "c2_16":
+        params, Y, c, meta = synthetic.make_named("c2", S=16)
+        return params, Y, c, meta, dict(route="gram"), "unsplit with raw tiles"
+    if case == "c2_reference":
+        params, Y, c, meta = synthetic.make_named("c2", S=8)
+        return params, Y, c, meta, dict(route="reference"), "projection route, K_uu chain as one dataflow launch on the side stream"
+    if case == "actuator_multi_kernel":
+        params, Y, c, meta = synthetic.make_named("small", S=1)
+        return params, Y, c, meta, dict(route="gram"), "small side"
+    raise KeyError(case)
+
+
+@pytest.mark.parametrize("case", ["c2_full", "c2_rank4", "c2_16", "c2_reference", "actuator_multi_kernel"])
+@pytest.mark.parametrize("grad", [False, True])
+def test_results_do_not_depend_on_which_stream_is_late(case, grad, monkeypatch):
+    """the iteration runs on two streams tied by events, and a missing wait would not crash -- stale progress words or
+    a half-written K^-1 give a finite wrong nll.  `plan_schedule` (abi.hip) now decides every schedule flag in one place and names
+    the schedule; here each schedule of the multi-kernel path runs three times -- as it is, with a 300 us spin kernel at the head of
+    the side stream at every fork, and with one on the main stream -- and the three results must be BIT-identical (forward terms,
+    per-chain nll, and with grad the whole gradient)."""
+    monkeypatch.setenv("FFVD_NO_TINY", "1")
+    params, Y, c, meta, kw, name = _schedule_case(case)
+    if grad and case in ("c2_16", "c2_reference"):
+        pytest.skip("training uses the Gram route's full-batch / split-K schedules (covered by c2_full, c2_rank4, actuator)")
+    outs = []
+    for env in ({}, {"FFVD_DEBUG_SIDE_DELAY_US": "300"}, {"FFVD_DEBUG_MAIN_DELAY_US": "300"}):
+        for k in ("FFVD_DEBUG_SIDE_DELAY_US", "FFVD_DEBUG_MAIN_DELAY_US"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], meta["S"], grad=grad, **kw) as e:
+            sched = e.lib.ffvd_schedule_name(e._h).decode()
+            assert sched != "INVALID"
+            if not grad:
+                assert name in sched, (case, sched)
+            e.set_data(Y, c)
+            if grad:
+                t, g = e.nll_and_grad(params)
+            else:
+                t, g = e.nll_terms(params), {}
+            assert int(e.lib.ffvd_stall_recoveries(e._h)) == 0
+        outs.append((t, g))
+    t0, g0 = outs[0]
+    for t, g in outs[1:]:
+        for n in TERMS_B:
+            assert t[n] == t0[n], (case, n)
+        np.testing.assert_array_equal(t["nll_per_chain"], t0["nll_per_chain"])
+        for k in g0:
+            np.testing.assert_array_equal(g[k], g0[k])
