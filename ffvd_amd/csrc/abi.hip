@@ -1543,7 +1543,7 @@ static int enqueue_grad_b(ffvd_handle *h, int S_total) {
     // the side stream; when that product is a few dozen microseconds (the reference's own experiment sizes) the side stream's
     // dozen launches ARE the backward pass's critical path and these two go to the main stream, which has the slack there
     hipStream_t su = ((size_t)nb * Tp * Mp <= (size_t)64 * 1024 * 128 && !h->sw.grad_serial) ? s : sk;
-    if (wh) launch_uku(su, g.wv, Mp, g.Ident, 0, Mp, Dl, nb, g.uku);       // u^T K u = w^T w
+    if (wh) launch_utu(su, g.wv, Mp, Mp, nb, g.uku);                       // u^T K u = w^T w
     else launch_uku(su, g.u, Mp, h->Kcopy, msq, Mp, Dl, nb, g.uku);   // u^T K u per unit: only grad_finalize reads it
     launch_shared_partials(su, dx, g.shared_part, g.sp_stride);
     if (!tiny) kgk_chain();

@@ -44,6 +44,7 @@ int atb_ntiles_sym64(int n);    // ... with AtbArgs::small_tiles (64 x 64 tiles)
 
 void launch_uku(hipStream_t stream, const double *u, size_t u_stride, const double *K, size_t k_stride, int Mp, int Dl,
                 int nb, double *out);
+void launch_utu(hipStream_t stream, const double *u, size_t u_stride, int Mp, int nb, double *out);      // out[b] = |u_b|^2
 void launch_chain_sum(hipStream_t stream, const double *in, size_t in_stride, int S, int Dl, size_t n, double *out,
                       size_t out_stride);
 void launch_psi_e(hipStream_t stream, const double *gsum, const double *kgk, const double *Kcopy, int M, int Mp, int Dl,

@@ -821,6 +821,25 @@ void launch_uku(hipStream_t stream, const double *u, size_t u_stride, const doub
                 int nb, double *out) {
     hipLaunchKernelGGL(uku_kernel, dim3(nb), dim3(256), 0, stream, u, u_stride, K, k_stride, Mp, Dl, out);
 }
+// out[b] = u_b^T u_b: what uku_kernel computes against the identity (the whitened backward pass wants w^T w), with the same
+// partition of the sum over the threads -- bit-identical -- and without walking an M x M identity matrix row by row per thread
+// (0.93 ms for 128 units at M = 512, the head of the side chain of the training step: VERDICT r3 W11).
+__global__ __launch_bounds__(256) void utu_kernel(const double *u, size_t u_stride, int Mp, double *out) {
+    __shared__ double scratch[256];
+    const int bz = blockIdx.x, tid = threadIdx.x;
+    const double *ub = u + (size_t)bz * u_stride;
+    double acc = 0.0;
+    for (int i = tid; i < Mp; i += 256) {
+        double row = 0.0;
+        row += ub[i];                       // (the identity's row i: exact zeros elsewhere)
+        acc += ub[i] * row;
+    }
+    acc = block_sum(acc, scratch);
+    if (tid == 0) out[bz] = acc;
+}
+void launch_utu(hipStream_t stream, const double *u, size_t u_stride, int Mp, int nb, double *out) {
+    hipLaunchKernelGGL(utu_kernel, dim3(nb), dim3(256), 0, stream, u, u_stride, Mp, out);
+}
 
 // out[dl][e] = sum_s in[(s*Dl + dl)][e]  (fixed order over chains: deterministic)
 __global__ void chain_sum_kernel(const double *in, size_t in_stride, int S, int Dl, size_t n, double *out, size_t out_stride) {
