@@ -670,6 +670,15 @@ __device__ __forceinline__ void tiny_kuu_rows(const TinyArgs &a, const int u, co
         __syncthreads();
     }
 
+// Without side workgroups the NT row blocks of the K_uu side go to the nst strips (block rb to strip rb mod nst) -- except hn blocks
+// [h0, h0 + hn) that the head takes: it idles from the moment it has published N, while a strip still has its phase 2 ahead.
+__device__ __forceinline__ void tiny_kuu_split(const int NT, const int nst, int &hn, int &h0) {
+    hn = NT - nst;
+    if (hn > 3) hn = 3;
+    if (hn < 0 || NT < 3) hn = 0;               // (the head's matrix area must hold the three 16-row patches: Mp >= 48)
+    h0 = nst;
+}
+
 // ---- the kernel ---------------------------------------------------------------------------------------------------------------
 // B fragments of one k step of a row-panel product C(16 rows x Mp) += A(16 x 16 k-block) B(k-block, :), straight from L2 into
 // registers one step ahead of their use: b[j][t] = B[(16 k + 4 t + lk)][16 j + lr] for the column tiles j in [jlo, jhi).
@@ -960,10 +969,29 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void tiny_kernel(const Ti
         }
         tiny_publish(cx.fN, 1);
         TSTAMP(8);
+        if (a.side) return;
+        // No workgroups of their own for the K_uu side (they did not fit): the head is free from here on while its strips run their
+        // phase 2 -- it takes up to three of the row blocks (tiny_kuu_split), then counts in like a strip.
+        {
+            int hn, h0;
+            tiny_kuu_split(NT, nst, hn, h0);
+            if (hn > 0) {
+                double *ZO = lds + L.dinv;                                    // [Mp][16]: the inverted diagonal tiles are dead
+                __syncthreads();
+                for (int e = tid; e < Mp * 16; e += NTHR) {
+                    const int m = e >> 4, n = e & 15;
+                    ZO[e] = (n == 0) ? 1.0 : ((m < M && n <= P) ? a.Z[(size_t)m * P + n - 1] : 0.0);
+                }
+                __syncthreads();
+                for (int rb = h0; rb < h0 + hn; ++rb) tiny_kuu_rows<NW>(a, u, rb, Am, ZO, ilen, var);
+            }
+            if (tiny_arrive(cx.c2, slot) != nst) return;                      // nst strips + this head
+            tiny_unit_done<NW>(a, u, lds, L);
+        }
         return;
     }
 
-    const int narrive2 = nst + (a.side ? NT : 0);                            // arrivals that complete the backward pass of a unit
+    const int narrive2 = nst + (a.side ? NT : 1);                            // arrivals that complete the backward pass of a unit (side workgroups, or the head)
     if (side) {
         // ======================================================================================================================
         // side(u, rb): one 16-row block of the K_uu side of the backward pass, beside the strips' phase 2
@@ -1256,8 +1284,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void tiny_kernel(const Ti
     }
     TSTAMP(8);
     // K_uu side, one 16-row block per strip (unless the launch has workgroups of its own for it: tiny_plan)
-    if (!a.side)
-        for (int rb = strip; rb < NT; rb += nst) tiny_kuu_rows<NW>(a, u, rb, Ks, ZO, ilen, var);
+    if (!a.side) {
+        int hn, h0;
+        tiny_kuu_split(NT, nst, hn, h0);
+        for (int rb = strip; rb < NT; rb += nst) {
+            if (rb >= h0 && rb < h0 + hn) continue;                           // the head's blocks
+            tiny_kuu_rows<NW>(a, u, rb, Ks, ZO, ilen, var);
+        }
+    }
     TSTAMP(9);
     if (tiny_arrive(cx.c2, slot) != narrive2 - 1) return;
     TSTAMP(10);
