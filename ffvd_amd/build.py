@@ -138,6 +138,8 @@ VARIANTS = {
     # unit-0 head never publishes W, so that every bounded wait of that launch must give up (tests/test_gpu_tiny.py)
     "tinytrace": ("tiny.hip", ["-DFFVD_TINY_TRACE"]),
     "tinystall": ("tiny.hip", ["-DFFVD_TINY_TEST_STALL"]),
+    # A/B build: the head does not take row blocks of the K_uu side (tools/dbg_cmp.py diffs the scratch block of two builds)
+    "tinynohelp": ("tiny.hip", ["-DFFVD_TINY_NO_HEAD_HELP"]),
 }
 
 

@@ -80,6 +80,8 @@ struct ffvd_handle {
     TinyPlan tiny{};
     double *tiny_scratch = nullptr;
     int *tiny_flags = nullptr;
+    TinyArgs *tiny_dargs = nullptr;     // [2] device copies of the argument block (forward / forward + backward)
+    TinyArgs *tiny_hargs = nullptr;     // [2] pinned host shadows of what those copies hold
     bool tiny_dirty = false;       // a launch was abandoned on a bounded wait: its hand-off words are re-zeroed before the next one
     bool info_pending = false;  // an ffvd_elbo_async was enqueued whose Cholesky info flags nobody has looked at yet
     // workspace
@@ -184,6 +186,7 @@ extern "C" int ffvd_destroy(ffvd_handle *h) {
     for (void *p : h->allocs) hipFree(p);
     for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
     if (h->h_res) hipHostFree(h->h_res);
+    if (h->tiny_hargs) hipHostFree(h->tiny_hargs);
     if (h->aux) { hipStreamSynchronize(h->aux); hipStreamDestroy(h->aux); }
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_join) hipEventDestroy(h->ev_join);
@@ -421,6 +424,9 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
             HIP_TRY(dev_alloc(h, &h->tiny_scratch, tiny_scratch_doubles(h->tiny, c.T, (int)P, c.M, c.S_local, (int)Dl, c.D, c.Ydim, c.grad)));
             HIP_TRY(dev_alloc(h, &h->tiny_flags, tiny_flag_ints(h->tiny, c.S_local)));
             HIP_TRY(hipMemsetAsync(h->tiny_flags, 0, tiny_flag_ints(h->tiny, c.S_local) * sizeof(int), h->stream));
+            HIP_TRY(dev_alloc(h, &h->tiny_dargs, 2));
+            HIP_TRY(hipHostMalloc((void **)&h->tiny_hargs, 2 * sizeof(TinyArgs)));
+            memset(h->tiny_hargs, 0xff, 2 * sizeof(TinyArgs));          // (differs from any real block: the first launch uploads)
         }
     }
     HIP_TRY(dev_alloc(h, &h->dinvK, potrf_scratch_doubles((int)Mp, (int)Dl)));
@@ -696,7 +702,7 @@ static int enqueue_tiny(ffvd_handle *h, double *out_dev, StageTimer *st, bool wi
         a.dX = g.dX; a.dZ = g.dZ; a.dlogvar = g.dlogvar; a.dloglen = g.dloglen; a.dlogQ = g.dlogQ; a.dCC = g.dCC; a.dDD = g.dDD;
         a.dlogR = g.dlogR;
     }
-    HIP_TRY(launch_tiny(s, a, h->tiny));
+    HIP_TRY(launch_tiny(s, a, h->tiny, h->tiny_dargs + (with_grad ? 1 : 0), h->tiny_hargs + (with_grad ? 1 : 0)));
     if (st) { st->mark(2); st->mark(4); }
     DBG_SYNC(h, with_grad ? "one-launch iteration + backward pass" : "one-launch iteration");
     return FFVD_OK;
@@ -1186,6 +1192,17 @@ static int fetch_with_stall_recovery(ffvd_handle *h, Enqueue enqueue) {
 extern "C" int ffvd_stall_recoveries(const ffvd_handle *h) { return h ? h->stall_recoveries : 0; }
 
 extern "C" int ffvd_single_launch(const ffvd_handle *h) { return (h && h->tiny.ok) ? h->tiny.nw : 0; }
+
+// Debug: copy `count` doubles of the one-launch path's scratch block, starting at `offset`, to the host (tools only).
+extern "C" int64_t ffvd_debug_tiny_scratch(ffvd_handle *h, int64_t offset, int64_t count, double *out) {
+    if (!h || !h->tiny.ok) return -1;
+    const ffvd_config &c = h->cfg;
+    const int64_t total = (int64_t)tiny_scratch_doubles(h->tiny, c.T, h->P, c.M, c.S_local, h->Dl, c.D, c.Ydim, c.grad);
+    if (!out) return total;
+    if (offset < 0 || offset + count > total) return -1;
+    hipStreamSynchronize(h->stream);
+    return hipMemcpy(out, h->tiny_scratch + offset, (size_t)count * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess ? total : -1;
+}
 
 extern "C" int ffvd_elbo(ffvd_handle *h, const ffvd_params *p, uint32_t flags, double out_terms[8], double *out_nll) {
     if (!h) return set_error(nullptr, FFVD_EINVAL, "ffvd_elbo: null handle");

@@ -54,6 +54,8 @@ size_t tiny_scratch_doubles(const TinyPlan &pl, int T, int P, int M, int S, int 
 size_t tiny_flag_ints(const TinyPlan &pl, int S);
 // carve `scratch` / `flags` into the pointers of `a` (shapes already filled in)
 void tiny_bind_scratch(TinyArgs &a, const TinyPlan &pl, double *scratch, int *flags);
-hipError_t launch_tiny(hipStream_t stream, const TinyArgs &a, const TinyPlan &pl);
+// dev_args: a TinyArgs in device memory the kernel reads its arguments from; host_shadow: what that copy currently holds (pinned or
+// plain host memory that stays valid until the stream has passed the copy: the handle owns both, one pair per launch flavour)
+hipError_t launch_tiny(hipStream_t stream, const TinyArgs &a, const TinyPlan &pl, TinyArgs *dev_args, TinyArgs *host_shadow);
 
 }  // namespace ffvd

@@ -28,6 +28,7 @@
 //     depend on which workgroup closes.
 #include "tiny.h"
 #include "dev_common.h"
+#include <cstring>
 
 namespace ffvd {
 
@@ -331,7 +332,7 @@ __device__ __forceinline__ FinalizeArgs tiny_finalize_args(const TinyArgs &a) {
 // The likelihood gradients of chain s and the transition-prior part of dlog_Q (shared_partials_kernel): functions of the inputs only,
 // formed by the chain's first head while it waits for its strips.
 template <int NW>
-__device__ void tiny_chain_part(const TinyArgs &a, const int s, double *red) {
+__device__ __noinline__ void tiny_chain_part(const TinyArgs &a, const int s, double *red) {
     constexpr int NTHR = 64 * NW;
     const int tid = threadIdx.x;
     const int T = a.T, D = a.D, Dl = a.Dl, J = a.Ydim;
@@ -370,7 +371,7 @@ __device__ void tiny_chain_part(const TinyArgs &a, const int s, double *red) {
 // Everything of unit u is in memory.  The workgroup that completes a chain forms that chain's sums; the one that completes the
 // launch assembles the result.
 template <int NW>
-__device__ void tiny_unit_done(const TinyArgs &a, const int u, double *lds, const TinyLds &L) {
+__device__ __noinline__ void tiny_unit_done(const TinyArgs &a, const int u, double *lds, const TinyLds &L) {
     constexpr int NTHR = 64 * NW;
     const int tid = threadIdx.x;
     const int s = u / a.Dl;
@@ -556,8 +557,8 @@ __device__ void tiny_unit_done(const TinyArgs &a, const int u, double *lds, cons
 //   Psi = 1/2 W N2 W^T (dl/dK_uu),  N2 = N - (H - I),  E_u = Psi o K(Z,Z),  its row sums and E_u Z  ->  rows of dl/dZ, partials of
 //   dl/dloglengthscales, dl/dlogvariance.  ZO = [1 | Z] rows in LDS; three 16-row patches of the strip matrix area.
 template <int NW>
-__device__ __forceinline__ void tiny_kuu_rows(const TinyArgs &a, const int u, const int rb, double *Ks, const double *ZO, const double *ilen,
-                                              const double var) {
+__device__ __noinline__ void tiny_kuu_rows(const TinyArgs &a, const int u, const int rb, double *Ks, const double *ZO, const double *ilen,
+                                           const double var) {
     constexpr int NTHR = 64 * NW;
     const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -676,6 +677,10 @@ __device__ __forceinline__ void tiny_kuu_split(const int NT, const int nst, int 
     hn = NT - nst;
     if (hn > 3) hn = 3;
     if (hn < 0 || NT < 3) hn = 0;               // (the head's matrix area must hold the three 16-row patches: Mp >= 48)
+#ifdef FFVD_TINY_NO_HEAD_HELP
+    hn = 0;
+#endif
+
     h0 = nst;
 }
 
@@ -722,8 +727,13 @@ __device__ __forceinline__ void tiny_row_gemm(d4 (&acc)[TNT], const double *Arow
     }
 }
 
+// The argument block lives in DEVICE memory and every role reads its fields through one pointer (scalar loads): passed by value, the
+// 50-field block either sat in SGPRs for the whole kernel (400+ SGPR spills) or -- for a callee that is not inlined -- in a
+// private-memory copy that did not survive the spill traffic of the K_uu-side code (wrong chain sums, then memory faults, once a
+// head ran that code before closing its unit; found by diffing the scratch block of two builds, tools/dbg_cmp.py).
 template <int NW>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void tiny_kernel(const TinyArgs a) {      // (<= 256 registers: the MFMAs take VGPR accumulators, no AGPR copies)
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void tiny_kernel(const TinyArgs *__restrict__ ap) {      // (<= 256 registers: the MFMAs take VGPR accumulators, no AGPR copies)
+    const TinyArgs &a = *ap;
     constexpr int NTHR = 64 * NW, SR = 16 * NW;
     extern __shared__ double lds[];
     const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
@@ -1379,7 +1389,7 @@ void tiny_bind_scratch(TinyArgs &a, const TinyPlan &pl, double *scratch, int *fl
     a.flags = flags;
 }
 
-hipError_t launch_tiny(hipStream_t stream, const TinyArgs &a, const TinyPlan &pl) {
+hipError_t launch_tiny(hipStream_t stream, const TinyArgs &a, const TinyPlan &pl, TinyArgs *dev_args, TinyArgs *host_shadow) {
     static size_t attr_bytes[2] = {0, 0};              // dynamic LDS each instantiation has been allowed so far
     const int grid = pl.nunits * (1 + pl.nstrips + (a.side ? pl.NT : 0));
     const int which = pl.nw == 4 ? 0 : 1;
@@ -1389,8 +1399,14 @@ hipError_t launch_tiny(hipStream_t stream, const TinyArgs &a, const TinyPlan &pl
         if (e != hipSuccess) return e;
         attr_bytes[which] = pl.lds_bytes;
     }
-    if (which == 0) hipLaunchKernelGGL(tiny_kernel<4>, dim3(grid), dim3(256), pl.lds_bytes, stream, a);
-    else hipLaunchKernelGGL(tiny_kernel<8>, dim3(grid), dim3(512), pl.lds_bytes, stream, a);
+    // the argument block travels only when it differs from what the device copy holds (steady state: never)
+    if (memcmp(host_shadow, &a, sizeof(TinyArgs)) != 0) {
+        *host_shadow = a;
+        hipError_t e = hipMemcpyAsync(dev_args, host_shadow, sizeof(TinyArgs), hipMemcpyHostToDevice, stream);
+        if (e != hipSuccess) return e;
+    }
+    if (which == 0) hipLaunchKernelGGL(tiny_kernel<4>, dim3(grid), dim3(256), pl.lds_bytes, stream, (const TinyArgs *)dev_args);
+    else hipLaunchKernelGGL(tiny_kernel<8>, dim3(grid), dim3(512), pl.lds_bytes, stream, (const TinyArgs *)dev_args);
     return hipGetLastError();
 }
 

@@ -92,10 +92,13 @@ def test_actuator_config1(S):
 
 
 @pytest.mark.parametrize("shape", [dict(T=64, D=1, C=1, M=16, S=1), dict(T=17, D=2, C=0, M=5, S=3), dict(T=512, D=4, C=1, M=128, S=2),
-                                   dict(T=1000, D=3, C=2, M=113, S=2), dict(T=200, D=6, C=2, M=40, S=5), dict(T=130, D=2, C=1, M=97, S=7)])
+                                   dict(T=1000, D=3, C=2, M=113, S=2), dict(T=200, D=6, C=2, M=40, S=5), dict(T=130, D=2, C=1, M=97, S=7),
+                                   dict(T=512, D=4, C=1, M=100, S=10), dict(T=512, D=4, C=1, M=100, S=6), dict(T=700, D=4, C=1, M=128, S=5)])
 def test_shapes_forward_and_gradient(shape):
     """Edge shapes: one tile, no control input, M = 128 (the largest), M = 113 (padded to 128), P = 8 (the largest), T just over a
-    strip boundary.  Forward against the oracle, gradient against the closed form, both also against the multi-kernel schedule."""
+    strip boundary; the actuator shape at 10 chains (8 wavefronts per workgroup, 128-row strips, no workgroups of their own for the
+    K_uu side: the strips and the head share its row blocks) and at 6 chains (4 wavefronts, likewise no side workgroups); M = 128 without
+    side workgroups.  Forward against the oracle, gradient against the closed form."""
     params, Y, c, meta = synthetic.make_workload(**shape)
     with engine(meta, grad=True, route="gram") as e:
         assert single_launch(e) in (4, 8), shape
