@@ -17,8 +17,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libffvd_hip.so")
 HASH = LIB + ".hash"
 OBJDIR = os.path.join(HERE, "build")
-SOURCES = ["kernels.hip", "kernels_f32.hip", "grad.hip", "optim.hip", "tiny.hip", "abi.hip"]
-HEADERS = ["kernels.h", "dev_common.h", "tiny.h", "kernels_f32.h", "grad.h", "optim.h", os.path.join("..", "..", "include", "ffvd_abi.h")]
+SOURCES = ["kernels.hip", "kernels_f32.hip", "grad.hip", "optim.hip", "tiny.hip", "loops.hip", "abi.hip"]
+HEADERS = ["kernels.h", "dev_common.h", "step_bodies.h", "tiny.h", "kernels_f32.h", "grad.h", "optim.h", os.path.join("..", "..", "include", "ffvd_abi.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 LINK = ["-shared", "-fPIC", "--offload-arch=gfx950", "-ldl"]
 

@@ -6,6 +6,7 @@
 #include "grad.h"
 #include "optim.h"
 #include "tiny.h"
+#include "step_bodies.h"
 
 #include <algorithm>
 #include <cmath>
@@ -2595,22 +2596,52 @@ extern "C" int ffvd_op_rollout(int kind, const double *Lm_inverse_seq, const dou
         launch_skinny_gemm(sc.stream, dW, (size_t)Mp * Mp, Mp, dQs, 0, Mp, 0, Mp, Mp, Mp, D, Mp, dWQ, (size_t)Mp * Mp, Mp, nullptr, 0,
                            nullptr, nullptr);
     double *xbuf[2] = {dxc, dxc2};                                           // input rows of step t in xbuf[t & 1]
-    for (int t = 0; t < steps; ++t) {
-        pa.x = xbuf[t & 1];
-        launch_kfu_build(sc.stream, pa);                                     // K(x_t, Z) per dim
-        if (skinny) {
-            // conditional_after_kernel_precalculation (:300) and, in the same launch, sum_j (F q_sqrt)_j^2 = |K (W q_sqrt)|^2 (:371-380)
-            launch_skinny_gemm(sc.stream, Kf, (size_t)Tp * Mp, Mp, dW, (size_t)Mp * Mp, Mp, 1, R, Mp, Mp, D, Tp,
-                               nullptr, 0, 0, ucol, Mp, rowsq, fmean, q_sqrt ? dWQ : nullptr, (size_t)Mp * Mp, Mp, Mp, extra);
-        } else {
-            launch_proj_gemm(sc.stream, pg);
-            if (q_sqrt) launch_qsqrt_inflation(sc.stream, F, (size_t)Tp * Mp, Tp, Mp, M, dQs, extra, R, D);
+    auto step_launches = [&]() {                                              // three dependent launches per step
+        for (int t = 0; t < steps; ++t) {
+            pa.x = xbuf[t & 1];
+            launch_kfu_build(sc.stream, pa);                                     // K(x_t, Z) per dim
+            if (skinny) {
+                // conditional_after_kernel_precalculation (:300) and, in the same launch, sum_j (F q_sqrt)_j^2 = |K (W q_sqrt)|^2 (:371-380)
+                launch_skinny_gemm(sc.stream, Kf, (size_t)Tp * Mp, Mp, dW, (size_t)Mp * Mp, Mp, 1, R, Mp, Mp, D, Tp,
+                                   nullptr, 0, 0, ucol, Mp, rowsq, fmean, q_sqrt ? dWQ : nullptr, (size_t)Mp * Mp, Mp, Mp, extra);
+            } else {
+                launch_proj_gemm(sc.stream, pg);
+                if (q_sqrt) launch_qsqrt_inflation(sc.stream, F, (size_t)Tp * Mp, Tp, Mp, M, dQs, extra, R, D);
+            }
+            // conditional epilogue + x <- x + f_mu + eps sqrt(f_var + Q) in one launch (three dependent launches per step instead of five)
+            launch_rollout_finish_update(sc.stream, kind, variance, rowsq, fmean, skinny ? ngs : ng, Tp, extra, skinny ? ngs : 1, dlq,
+                                         deps + (size_t)t * R * D, (C && t + 1 < steps) ? dctrl + (size_t)(t + 1) * C : nullptr, R, D, C, t,
+                                         steps, xbuf[t & 1], xbuf[(t + 1) & 1], dpx, dpv);
         }
-        // conditional epilogue + x <- x + f_mu + eps sqrt(f_var + Q) in one launch (three dependent launches per step instead of five)
-        launch_rollout_finish_update(sc.stream, kind, variance, rowsq, fmean, skinny ? ngs : ng, Tp, extra, skinny ? ngs : 1, dlq,
-                                     deps + (size_t)t * R * D, (C && t + 1 < steps) ? dctrl + (size_t)(t + 1) * C : nullptr, R, D, C, t,
-                                     steps, xbuf[t & 1], xbuf[(t + 1) & 1], dpx, dpv);
-    }
+    };
+    // Round 4: the whole loop as ONE persistent launch whose workgroups walk the same three phases per step and meet
+    // at a grid-wide barrier in between (loops.hip; the same kernel bodies: bit-identical).  MEASURED SLOWER -- 64.7 against 32.7 us per
+    // step at 32 rollouts, 148 against 48 at 100: a grid-wide barrier of 256 workgroups costs ~15 us on this chip (every workgroup's
+    // agent-scope release writes back its XCD's L2), three times what the kernel boundary it replaces costs -- so it is opt-in:
+    // FFVD_STEP_LOOP=1.
+    const char *nsl = getenv("FFVD_STEP_LOOP");
+    const bool use_loop = skinny && nsl && *nsl && strcmp(nsl, "0") != 0;
+    if (use_loop) {
+        int32_t *words = sc.alloc<int32_t>(4);
+        OP_CHECK(words, "ffvd_op_rollout");
+        HIP_TRY(hipMemsetAsync(words, 0, 4 * sizeof(int32_t), sc.stream));
+        RolloutLoopArgs la{};
+        la.pa = pa;
+        la.sk = SkinnyArgs{Kf, (size_t)Tp * Mp, Mp, dW, (size_t)Mp * Mp, Mp, 1, R, Mp, Mp, D, Tp, nullptr, 0, 0, ucol, (size_t)Mp, rowsq, fmean,
+                           q_sqrt ? dWQ : nullptr, (size_t)Mp * Mp, Mp, q_sqrt ? Mp : 0, extra};
+        la.f = FinishIn{kind, D + C, ngs, Tp, D, ngs, variance, rowsq, fmean, extra};
+        la.log_Q = dlq; la.eps = deps; la.ctrl = dctrl; la.R = R; la.C = C; la.steps = steps;
+        la.xbuf0 = xbuf[0]; la.xbuf1 = xbuf[1]; la.predict_x = dpx; la.predict_var = dpv;
+        la.bar = reinterpret_cast<unsigned *>(words); la.abort_w = words + 1;
+        launch_rollout_loop(sc.stream, la);
+        int32_t hw[4] = {0, 0, 0, 0};
+        HIP_TRY(hipMemcpyAsync(hw, words, sizeof hw, hipMemcpyDeviceToHost, sc.stream));
+        HIP_TRY(hipStreamSynchronize(sc.stream));
+        if (hw[1] != 0) {           // a wait gave up (the grid was not resident at once): the per-step launches, from the initial rows
+            HIP_TRY(hipMemcpyAsync(dxc, xc0.data(), xc0.size() * sizeof(double), hipMemcpyHostToDevice, sc.stream));
+            step_launches();
+        }
+    } else step_launches();
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(predict_x, dpx, (size_t)R * steps * D * sizeof(double), hipMemcpyDeviceToHost, sc.stream));
     HIP_TRY(hipMemcpyAsync(predict_var, dpv, (size_t)R * steps * D * sizeof(double), hipMemcpyDeviceToHost, sc.stream));
@@ -2674,16 +2705,43 @@ extern "C" int ffvd_op_pg_sweep(int kind, const double *Lm_inverse_seq, const do
     pg.Kf = Kf; pg.kf_stride = (size_t)Tp * Mp; pg.W = dW; pg.w_stride = (size_t)Mp * Mp; pg.F = nullptr; pg.f_stride = 0;
     pg.rowsq = rowsq; pg.fmean = fmean; pg.u = ucol; pg.u_stride = Mp; pg.Tp = Tp; pg.Mp = Mp; pg.Dl = D; pg.b0 = 0; pg.nb = D;
     // the whole sweep is enqueued at once: steps x (K_fu rows, projection, conditional, propagate + weight + resample)
-    for (int t = 0; t < steps; ++t) {
-        launch_kfu_build(sc.stream, pa);
-        if (skinny) launch_skinny_gemm(sc.stream, Kf, (size_t)Tp * Mp, Mp, dW, (size_t)Mp * Mp, Mp, 1, R, Mp, Mp, D, Tp,
-                                       nullptr, 0, 0, ucol, Mp, rowsq, fmean);
-        else launch_proj_gemm(sc.stream, pg);                                // conditional_after_kernel_precalculation (:95-97)
-        launch_conditional_finish(sc.stream, kind, dxc, R, P, variance, rowsq, fmean, ngs, Tp, D, dmean, dvar, nullptr);
-        launch_pg_step(sc.stream, dmean, dvar, dlq, deps + (size_t)t * R * D, dun + (size_t)t * R, dY + (size_t)t * Ydim,
-                       dXr + (size_t)(t + 1) * D, dCC, dDD, dR, (C && t + 1 < steps) ? dctrl + (size_t)(t + 1) * C : nullptr,
-                       R, D, C, Ydim, dxc, cand, dparts + (size_t)t * R * D, didx + (size_t)t * R);
-    }
+    auto step_launches = [&]() {
+        for (int t = 0; t < steps; ++t) {
+            launch_kfu_build(sc.stream, pa);
+            if (skinny) launch_skinny_gemm(sc.stream, Kf, (size_t)Tp * Mp, Mp, dW, (size_t)Mp * Mp, Mp, 1, R, Mp, Mp, D, Tp,
+                                           nullptr, 0, 0, ucol, Mp, rowsq, fmean);
+            else launch_proj_gemm(sc.stream, pg);                                // conditional_after_kernel_precalculation (:95-97)
+            launch_conditional_finish(sc.stream, kind, dxc, R, P, variance, rowsq, fmean, ngs, Tp, D, dmean, dvar, nullptr);
+            launch_pg_step(sc.stream, dmean, dvar, dlq, deps + (size_t)t * R * D, dun + (size_t)t * R, dY + (size_t)t * Ydim,
+                           dXr + (size_t)(t + 1) * D, dCC, dDD, dR, (C && t + 1 < steps) ? dctrl + (size_t)(t + 1) * C : nullptr,
+                           R, D, C, Ydim, dxc, cand, dparts + (size_t)t * R * D, didx + (size_t)t * R);
+        }
+    };
+    // Round 4: ONE persistent launch for the sweep (loops.hip), three grid-wide barriers per step instead of four dependent launches:
+    // measured slower (151 against 37 us per step, see ffvd_op_rollout), opt-in with FFVD_STEP_LOOP=1
+    const char *nsl = getenv("FFVD_STEP_LOOP");
+    const bool use_loop = skinny && nsl && *nsl && strcmp(nsl, "0") != 0;
+    if (use_loop) {
+        int32_t *words = sc.alloc<int32_t>(4);
+        OP_CHECK(words, "ffvd_op_pg_sweep");
+        HIP_TRY(hipMemsetAsync(words, 0, 4 * sizeof(int32_t), sc.stream));
+        PgLoopArgs la{};
+        la.pa = pa;
+        la.sk = SkinnyArgs{Kf, (size_t)Tp * Mp, Mp, dW, (size_t)Mp * Mp, Mp, 1, R, Mp, Mp, D, Tp, nullptr, 0, 0, ucol, (size_t)Mp, rowsq, fmean,
+                           nullptr, 0, 0, 0, nullptr};
+        la.kind = kind; la.R = R; la.D = D; la.C = C; la.Ydim = Ydim; la.steps = steps; la.ngs = ngs;
+        la.variance = variance; la.rowsq = rowsq; la.fmean = fmean; la.mean = dmean; la.var = dvar; la.cand = cand; la.parts = dparts;
+        la.idx = didx; la.log_Q = dlq; la.eps = deps; la.unif = dun; la.Y = dY; la.X_ref = dXr; la.CC = dCC; la.DD = dDD; la.Rch = dR;
+        la.ctrl = dctrl; la.bar = reinterpret_cast<unsigned *>(words); la.abort_w = words + 1;
+        launch_pg_loop(sc.stream, la);
+        int32_t hw[4] = {0, 0, 0, 0};
+        HIP_TRY(hipMemcpyAsync(hw, words, sizeof hw, hipMemcpyDeviceToHost, sc.stream));
+        HIP_TRY(hipStreamSynchronize(sc.stream));
+        if (hw[1] != 0) {
+            HIP_TRY(hipMemcpyAsync(dxc, xc0.data(), xc0.size() * sizeof(double), hipMemcpyHostToDevice, sc.stream));
+            step_launches();
+        }
+    } else step_launches();
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(particles + (size_t)R * D, dparts, (size_t)steps * R * D * sizeof(double), hipMemcpyDeviceToHost, sc.stream));
     HIP_TRY(hipMemcpyAsync(idx, didx, (size_t)steps * R * sizeof(int32_t), hipMemcpyDeviceToHost, sc.stream));

@@ -19,6 +19,7 @@
 //     same panel/trailing kernels: identity rows become L^{-T}, the row delta^T F / Q becomes L_H^{-1} b.
 #include "kernels.h"
 #include "dev_common.h"
+#include "step_bodies.h"
 #include <type_traits>
 #include <cstdlib>
 
@@ -220,94 +221,9 @@ void launch_transpose(hipStream_t stream, const double *in, size_t in_stride, do
 // build is bound by its fp64 VALU work as much as by the write); NQ = 0: the general form.
 template <int KIND, int NQ>
 __global__ __launch_bounds__(256) void kfu_build_kernel(ProjectArgs a) {
-    constexpr bool SMALLP = NQ > 0;
-    __shared__ double xs[SMALLP ? 1 : MAXP][SMALLP ? 1 : 64];
-    __shared__ __attribute__((aligned(16))) double xr8[SMALLP ? 64 : 1][8];
-    __shared__ double xx[64];
-    __shared__ double zs[64][(SMALLP ? 8 : MAXP) + 1];
-    __shared__ double gsum[4][64];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int t0 = blockIdx.x * 64, m0 = blockIdx.y * 64, bz = blockIdx.z;
-    const int b = a.b0 + bz, s = b / a.Dl, dl = b % a.Dl;
-    // delta_t = x_{t+1,d} - x_{t,d} (:247) of a row is the same for the whole wavefront (a wavefront = 16 rows x 64 columns): every
-    // wavefront loads its 16 values once, one per lane, and hands them out by v_readlane
-    const double *xdl = a.x + (size_t)s * a.x_chain_stride + (a.d_begin + dl);
-    const int P = a.P, Mp = a.Mp;
-    const double var = a.hv.variance[dl];
-    for (int p = tid >> 6; p < (SMALLP ? 8 : P); p += 4) {
-        const int t = t0 + lane;
-        double v = 0.0;
-        if (t < a.T && p < P) {
-            v = (p < a.x_cols) ? a.x[(size_t)s * a.x_chain_stride + (size_t)t * a.x_ld + p]
-                               : a.ctrl[(size_t)t * a.C + (p - a.x_cols)];
-            if (KIND == 0) v = v / a.hv.len[(size_t)dl * P + p];
-            else v = v * var;
-        }
-        if (SMALLP) xr8[lane][p] = v;
-        else xs[p][lane] = v;
-        zs[lane][p] = (p < P) ? a.hv.Zs[((size_t)dl * Mp + m0 + lane) * P + p] : 0.0;
-    }
-    __syncthreads();
-    if (tid < 64) {
-        double acc = 0.0;
-        if (KIND == 0) {
-            if (SMALLP) for (int p = 0; p < 8; ++p) acc += xr8[tid][p] * xr8[tid][p];     // padding adds exact zeros
-            else for (int p = 0; p < P; ++p) acc += xs[p][tid] * xs[p][tid];
-        }
-        xx[tid] = acc;
-    }
-    __syncthreads();
-    const double zzv = a.hv.zz[(size_t)dl * Mp + m0 + lane];
-    double *out = a.F + ((size_t)bz * a.Tp + t0) * Mp + m0 + lane;
-    const bool mok = (m0 + lane) < a.M;
-    double zr[8];                               // this thread's inducing input (first 8 components) in registers
-#pragma unroll
-    for (int p = 0; p < 8; ++p) zr[p] = (SMALLP || p < P) ? zs[lane][p] : 0.0;
-    const int rbase = __builtin_amdgcn_readfirstlane(tid >> 6) * 16;
-    const bool want_g = a.gpart != nullptr;
-    double gacc = 0.0, dlane = 0.0;             // lane i < 16 of every wavefront: delta of row rbase + i
-    if (want_g) {
-        const int t = t0 + rbase + (lane & 15);
-        if (t < a.T) dlane = xdl[(size_t)(t + 1) * a.x_ld] - xdl[(size_t)t * a.x_ld];
-    }
-    auto rows = [&](auto edge_tag) {             // interior tiles skip the per-element range selects
-        constexpr bool EDGE = decltype(edge_tag)::value;
-#pragma unroll 4
-        for (int i = 0; i < 16; ++i) {
-            const int r = rbase + i;
-            double dot = 0.0;
-            if (SMALLP) {
-#pragma unroll
-                for (int q = 0; q < (NQ > 0 ? NQ : 1); ++q) {
-                    const double2 xv = *reinterpret_cast<const double2 *>(&xr8[r][2 * q]);
-                    dot += xv.x * zr[2 * q];
-                    dot += xv.y * zr[2 * q + 1];
-                }
-            } else {
-#pragma unroll
-                for (int p = 0; p < 8; ++p)
-                    if (p < P) dot += xs[p][r] * zr[p];
-                for (int p = 8; p < P; ++p) dot += xs[p][r] * zs[lane][p];
-            }
-            double v = kernel_value<KIND>(dot, xx[r], zzv, var);
-            if (EDGE && (!mok || t0 + r >= a.T)) v = 0.0;
-            out[(size_t)r * Mp] = v;
-            if (want_g) {                       // delta of this row out of lane i: two v_readlane, then ONE vector FMA
-                const double dr = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(dlane), i),
-                                                   __builtin_amdgcn_readlane(__double2loint(dlane), i));
-                gacc = fma(dr, v, gacc);
-            }
-        }
-    };
-    if (t0 + 64 > a.T || m0 + 64 > a.M) rows(std::true_type{});
-    else rows(std::false_type{});
-    if (want_g) {                               // the four row groups of a column, added in fixed order
-        gsum[tid >> 6][lane] = gacc;
-        __syncthreads();
-        if (tid < 64)
-            a.gpart[((size_t)bz * (a.Tp / 64) + blockIdx.x) * Mp + m0 + tid] = (gsum[0][tid] + gsum[1][tid]) + (gsum[2][tid] + gsum[3][tid]);
-    }
+    kfu_build_body<KIND, NQ>(a, blockIdx.x, blockIdx.y, blockIdx.z);
 }
+
 
 __global__ __launch_bounds__(256) void brow_finish_kernel(const double *gpart, int nblk, int Mp, int Dl, int d_begin, int b0,
                                                           const double *log_Q, double yn_over_batch, double *H, size_t h_stride, int brow) {
@@ -2812,28 +2728,7 @@ __global__ __launch_bounds__(256) void conditional_finish_kernel(int kind, const
                                           const double *rowsq, const double *fmean, int ng, int Tp, int D,
                                           double *mean, double *var, const double *extra /*[D][extra_ng][Tp] or null*/,
                                           int extra_ng) {
-    const int idx = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, l = threadIdx.x & 15;
-    const bool live = idx < N * D;
-    const int n = live ? idx / D : 0, d = live ? idx % D : 0;
-    double rs = 0.0, fm = 0.0, ex = 0.0;
-    for (int g = l; g < ng; g += 16) {
-        rs += rowsq[((size_t)d * ng + g) * Tp + n];
-        fm += fmean[((size_t)d * ng + g) * Tp + n];
-    }
-    if (extra)
-        for (int g = l; g < extra_ng; g += 16) ex += extra[((size_t)d * extra_ng + g) * Tp + n];
-#pragma unroll
-    for (int m = 1; m < 16; m <<= 1) { rs += __shfl_xor(rs, m); fm += __shfl_xor(fm, m); ex += __shfl_xor(ex, m); }
-    if (!live || l != 0) return;
-    double kd = variance[d];
-    if (kind == 1) {
-        double s = 0.0;
-        for (int p = 0; p < P; ++p) { double v = x[(size_t)n * P + p]; s += (v * v) * variance[d]; }
-        kd = s;
-    }
-    mean[idx] = fm;
-    var[idx] = kd - rs;
-    if (extra) var[idx] = var[idx] + ex;                            // fvar + reduce_sum(square(LTA), 1)  (:380)
+    conditional_finish_body(blockIdx.x, kind, x, N, P, variance, rowsq, fmean, ng, Tp, D, mean, var, extra, extra_ng);
 }
 void launch_conditional_finish(hipStream_t stream, int kind, const double *x, int N, int P, const double *variance,
                                const double *rowsq, const double *fmean, int ng, int Tp, int D, double *mean,
@@ -2850,75 +2745,8 @@ void launch_conditional_finish(hipStream_t stream, int kind, const double *x, in
 // LDS staging: 64 MFMAs per wavefront at K = 512), partial tiles added through LDS in fixed order.  N / 16 x rows / 32 x nb
 // workgroups instead of the handful of 128 x 128 tiles the projection GEMM cuts such a product into: 50 -> 7 us per step at 32 rows.
 // `upper`: B[k][n] = 0 for k > n (L^-T), the k range of a slab ends at its last column.
-struct SkinnyArgs {
-    const double *A; size_t a_stride; int lda;
-    const double *B; size_t b_stride; int ldb;      // b_stride = 0: one B for every unit
-    int upper, rows, K, N, nb, Tp;
-    double *C; size_t c_stride; int ldc;            // or null
-    const double *u; size_t u_stride;               // or null
-    double *sq, *dot;                               // [nb][N / 16][Tp], or null
-    // optional SECOND right-hand side in the same launch (its slabs behind the first one's): C2 = A B2 is not stored, only
-    // sq2[nb][N2 / 16][Tp] = sum over the slab of C2^2.  The rollouts' q_sqrt inflation |F q_sqrt|^2 = |K (W q_sqrt)|^2 rides beside
-    // F = K W this way: both products read the same K rows and the step loses a dependent launch.
-    const double *B2; size_t b2_stride; int ldb2, N2;
-    double *sq2;
-};
 __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
-    __shared__ double red[3][2][4][64];
-    const int nslab1 = a.N / 16;
-    const bool second = (int)blockIdx.x >= nslab1;
-    const int n0 = (second ? (int)blockIdx.x - nslab1 : (int)blockIdx.x) * 16, r0 = blockIdx.y * 32, b = blockIdx.z;
-    if (r0 >= a.rows) return;
-    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const double *Ab = a.A + (size_t)b * a.a_stride, *Bb = second ? a.B2 + (size_t)b * a.b2_stride : a.B + (size_t)b * a.b_stride;
-    const int ldb = second ? a.ldb2 : a.ldb;
-    const int kend = (!second && a.upper && n0 + 16 < a.K) ? n0 + 16 : a.K;
-    const int nkb = kend / 16, per = (nkb + 3) / 4;                 // 16-wide k blocks, a quarter of them per wavefront
-    const int kb0 = w * per, kb1 = (kb0 + per < nkb) ? kb0 + per : nkb;
-    d4 acc[2] = {(d4){0.0, 0.0, 0.0, 0.0}, (d4){0.0, 0.0, 0.0, 0.0}};
-    // Inside a k block the four lane groups take k = 4 lk + s in MFMA s (a sum does not care about its order), so a lane reads
-    // four CONSECUTIVE doubles of its A row (two 16-byte loads feed four MFMAs, 128-byte runs per row) instead of four 8-byte ones
-    const double *ap0 = Ab + (size_t)(r0 + lr) * a.lda + 4 * lk, *ap1 = ap0 + (size_t)16 * a.lda;
-    const double *bp = Bb + (size_t)(4 * lk) * ldb + n0 + lr;
-    for (int kb = kb0; kb < kb1; ++kb) {       // (the compiler does not unroll this loop; two blocks in flight by hand were no faster)
-        const int k0 = 16 * kb;
-        const d2 a0l = *reinterpret_cast<const d2 *>(ap0 + k0), a0h = *reinterpret_cast<const d2 *>(ap0 + k0 + 2);
-        const d2 a1l = *reinterpret_cast<const d2 *>(ap1 + k0), a1h = *reinterpret_cast<const d2 *>(ap1 + k0 + 2);
-        const double *bq = bp + (size_t)k0 * ldb;
-        const double b0 = bq[0], b1 = bq[ldb], b2 = bq[2 * (size_t)ldb], b3 = bq[3 * (size_t)ldb];
-        acc[0] = mfma_f64(a0l.x, b0, acc[0]); acc[1] = mfma_f64(a1l.x, b0, acc[1]);
-        acc[0] = mfma_f64(a0l.y, b1, acc[0]); acc[1] = mfma_f64(a1l.y, b1, acc[1]);
-        acc[0] = mfma_f64(a0h.x, b2, acc[0]); acc[1] = mfma_f64(a1h.x, b2, acc[1]);
-        acc[0] = mfma_f64(a0h.y, b3, acc[0]); acc[1] = mfma_f64(a1h.y, b3, acc[1]);
-    }
-    if (w > 0) {
-#pragma unroll
-        for (int x = 0; x < 2; ++x)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) red[w - 1][x][q][lane] = acc[x][q];
-    }
-    __syncthreads();
-    if (w > 0) return;
-    const int slab = n0 / 16, nslab = second ? a.N2 / 16 : nslab1;
-    const double un = (a.u && !second) ? a.u[(size_t)b * a.u_stride + n0 + lr] : 0.0;
-    double *sqp = second ? a.sq2 : a.sq, *dotp = second ? nullptr : a.dot, *Cp = second ? nullptr : a.C;
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const double c = ((acc[x][q] + red[0][x][q][lane]) + red[1][x][q][lane]) + red[2][x][q][lane];
-            const int row = r0 + 16 * x + lk + 4 * q;
-            if (Cp) Cp[(size_t)b * a.c_stride + (size_t)row * a.ldc + n0 + lr] = c;
-            double s2 = c * c, du = c * un;
-            s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2); s2 += __shfl_xor(s2, 4); s2 += __shfl_xor(s2, 8);
-            du += __shfl_xor(du, 1); du += __shfl_xor(du, 2); du += __shfl_xor(du, 4); du += __shfl_xor(du, 8);
-            if (lr == 0) {
-                const size_t o = ((size_t)b * nslab + slab) * a.Tp + row;
-                if (sqp) sqp[o] = s2;
-                if (dotp) dotp[o] = du;
-            }
-        }
+    skinny_body(a, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 // rows <= Tp (a multiple of 32) rows of A exist; N, K multiples of 16.
 void launch_skinny_gemm(hipStream_t stream, const double *A, size_t a_stride, int lda, const double *B, size_t b_stride, int ldb,
@@ -3045,57 +2873,11 @@ void launch_finalize(hipStream_t stream, const FinalizeArgs &a) {
 // and the GP input row of the next step, xc[r] = [x_next, control_inputs[t + 1]].
 // The conditional() epilogue inside a step-loop kernel, bit for bit what conditional_finish_kernel computes: 16 lanes per (row n,
 // dim d) sum the partials strided, an xor-butterfly combines them; every lane returns the sums (call with ALL lanes of the 16 active).
-struct FinishIn {
-    int kind, P, ng, Tp, D, extra_ng;
-    const double *variance, *rowsq, *fmean, *extra;     // extra: optional [D][extra_ng][Tp]
-};
-__device__ __forceinline__ void finish_mean_var16(const FinishIn &f, const double *xrow /* P inputs of row n */, const bool live, const int n,
-                                                  const int d, const int l, double &mean, double &var) {
-    double rs = 0.0, fm = 0.0, ex = 0.0;
-    if (live) {
-        for (int g = l; g < f.ng; g += 16) {
-            rs += f.rowsq[((size_t)d * f.ng + g) * f.Tp + n];
-            fm += f.fmean[((size_t)d * f.ng + g) * f.Tp + n];
-        }
-        if (f.extra)
-            for (int g = l; g < f.extra_ng; g += 16) ex += f.extra[((size_t)d * f.extra_ng + g) * f.Tp + n];
-    }
-#pragma unroll
-    for (int m = 1; m < 16; m <<= 1) { rs += __shfl_xor(rs, m); fm += __shfl_xor(fm, m); ex += __shfl_xor(ex, m); }
-    double kd = live ? f.variance[d] : 0.0;
-    if (live && f.kind == 1) {
-        double s = 0.0;
-        for (int p = 0; p < f.P; ++p) { const double v = xrow[p]; s += (v * v) * f.variance[d]; }
-        kd = s;
-    }
-    mean = fm;
-    var = kd - rs;
-    if (f.extra) var = var + ex;
-}
-
-// Rollout step with the conditional epilogue folded in.  The input rows are read from x_in and the advanced rows written to x_out
-// (the caller alternates two buffers): LinearK's Kdiag reads a whole row, which another lane group of the same row advances.
 __global__ __launch_bounds__(256) void rollout_finish_update_kernel(FinishIn f, const double *log_Q, const double *eps_t,
                                                                     const double *ctrl_next, int R, int C, int t, int steps,
                                                                     const double *x_in, double *x_out, double *predict_x,
                                                                     double *predict_var) {
-    const int idx = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, l = threadIdx.x & 15;
-    const int D = f.D, P = f.P;
-    const bool live = idx < R * D;
-    const int r = live ? idx / D : 0, d = live ? idx % D : 0;
-    double m, vv;
-    finish_mean_var16(f, x_in + (size_t)r * P, live, r, d, l, m, vv);
-    if (!live) return;
-    if (l == 0) {
-        const double v = vv + exp(log_Q[d]);
-        const double xn = (m + x_in[(size_t)r * P + d]) + eps_t[r * D + d] * sqrt(v);
-        const size_t o = ((size_t)r * steps + t) * D + d;
-        predict_x[o] = xn;
-        predict_var[o] = v;
-        x_out[(size_t)r * P + d] = xn;
-    } else if (d == 0) {        // the control columns of row r: the next step's, or carried over
-        for (int c = l - 1; c < C; c += 15) x_out[(size_t)r * P + D + c] = ctrl_next ? ctrl_next[c] : x_in[(size_t)r * P + D + c];
-    }
+    rollout_finish_update_body(blockIdx.x, f, log_Q, eps_t, ctrl_next, R, C, t, steps, x_in, x_out, predict_x, predict_var);
 }
 void launch_rollout_finish_update(hipStream_t stream, int kind, const double *variance, const double *rowsq, const double *fmean,
                                   int ng, int Tp, const double *extra, int extra_ng, const double *log_Q, const double *eps_t,
@@ -3137,70 +2919,13 @@ void launch_rollout_update(hipStream_t stream, const double *mean, const double 
 // One workgroup: thread i < R propagates particle i and forms its log weight, thread R the reference's; the softmax
 // CDF is summed sequentially in index order (as the oracle's cumsum) by one thread; then every thread i < R finds its
 // ancestor by binary search and gathers.
-constexpr int PG_MAXN = 1024, PG_MAXY = 8;
 __global__ __launch_bounds__(PG_MAXN) void pg_step_kernel(const double *mean, const double *var, const double *log_Q,
                                                           const double *eps_t, const double *unif_t, const double *y_t,
                                                           const double *x_ref_next, const double *CC, const double *DD,
                                                           const double *Rch, const double *ctrl_next, int R, int D, int C,
                                                           int Ydim, double *xc, double *cand, double *parts_next,
                                                           int32_t *idx_out) {
-    __shared__ double w[PG_MAXN], cdf[PG_MAXN];
-    __shared__ double wmax_s;
-    const int i = threadIdx.x, N = R + 1, P = D + C;
-    if (i < N) {
-        for (int p = 0; p < D; ++p) {
-            double xn;
-            if (i < R) {
-                const double v = var[i * D + p] + exp(log_Q[p]);
-                xn = (mean[i * D + p] + xc[i * P + p]) + eps_t[i * D + p] * sqrt(v);          // :99-101
-            } else xn = x_ref_next[p];                                                         // :111
-            cand[(size_t)i * D + p] = xn;
-        }
-        // logdensity_norm(Y[tt], predict_mean(x), Rchols), likelihoods.py:76-79,114-127
-        double a[PG_MAXY], q = 0.0, ld = 0.0;
-        for (int j = 0; j < Ydim; ++j) {
-            double ym = 0.0;
-            for (int d = 0; d < D; ++d) ym += cand[(size_t)i * D + d] * CC[d * Ydim + j];
-            ym += DD[j];
-            double r = y_t[j] - ym;
-            for (int k = 0; k < j; ++k) r -= Rch[j * Ydim + k] * a[k];
-            a[j] = r / Rch[j * Ydim + j];
-            q += a[j] * a[j];
-            ld += log(Rch[j * Ydim + j]);
-        }
-        w[i] = -0.5 * q + (-ld);
-    }
-    __syncthreads();
-    if (i == 0) {
-        double m = w[0];
-        for (int k = 1; k < N; ++k) m = (w[k] > m) ? w[k] : m;
-        wmax_s = m;
-    }
-    __syncthreads();
-    if (i < N) w[i] = exp(w[i] - wmax_s);
-    __syncthreads();
-    if (i == 0) {
-        double c = 0.0;
-        for (int k = 0; k < N; ++k) { c += w[k]; cdf[k] = c; }
-    }
-    __syncthreads();
-    if (i < R) {
-        const double target = unif_t[i] * cdf[N - 1];
-        int lo = 0, hi = N;                      // first k with cdf[k] > target
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (cdf[mid] > target) hi = mid; else lo = mid + 1;
-        }
-        const int k = (lo < N) ? lo : N - 1;
-        idx_out[i] = k;
-        for (int p = 0; p < D; ++p) {
-            const double x = cand[(size_t)k * D + p];
-            parts_next[(size_t)i * D + p] = x;
-            xc[i * P + p] = x;
-        }
-        if (ctrl_next)
-            for (int c = 0; c < C; ++c) xc[i * P + D + c] = ctrl_next[c];
-    }
+    pg_step_body<0>(mean, var, log_Q, eps_t, unif_t, y_t, x_ref_next, CC, DD, Rch, ctrl_next, R, D, C, Ydim, xc, cand, parts_next, idx_out);
 }
 void launch_pg_step(hipStream_t stream, const double *mean, const double *var, const double *log_Q, const double *eps_t,
                     const double *unif_t, const double *y_t, const double *x_ref_next, const double *CC, const double *DD,

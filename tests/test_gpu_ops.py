@@ -423,3 +423,45 @@ def test_pg_sweep_linear_kernel():
     pg, ig = pg_sweep(Lm, params["Z"], kern, params["U"], X, Y, c, params["CC"], params["DD"], R, Q, x0, eps, u)
     np.testing.assert_array_equal(ig, io)
     np.testing.assert_allclose(pg, po, rtol=1e-8, atol=1e-9)
+
+
+def test_step_loops_equal_the_per_step_launches(monkeypatch):
+    """Round 4: the step loops of the rollouts and of the particle-Gibbs sweep can run as ONE persistent launch whose
+    workgroups walk the phases of every step and meet at a grid-wide barrier (loops.hip, FFVD_STEP_LOOP=1 -- opt-in: measured 2-4 x
+    SLOWER than the three / four dependent launches per step, a 256-workgroup barrier costs more than a kernel boundary on this chip).
+    Both forms call the same kernel bodies (step_bodies.h): the results must be bit-identical, with and without the q_sqrt inflation,
+    at 7 and at 100 rollouts (one and several row blocks per slab), LinearK included."""
+    from ffvd_amd import conditionals_multi_output as cmo
+    from ffvd_amd.prediction import rollout, pg_sweep
+    from ffvd_amd.kernels import SquaredExponential, LinearK
+    rng = np.random.default_rng(3)
+    for name, R, steps in (("small", 7, 40), ("ragged", 100, 25), ("small_lin", 33, 30)):
+        params, Y, c, meta = synthetic.make_named(name)
+        D, C, T = meta["D"], meta["C"], meta["T"]
+        X = params["X"][0]
+        Q = np.exp(params["log_Q"])
+        if meta["kernel_type"] == "LinearK":
+            kern = [LinearK(D + C, variance=np.exp(params["logvariance"][d])) for d in range(D)]
+        else:
+            kern = [SquaredExponential(D + C, variance=np.exp(params["logvariance"][d]),
+                                       lengthscales=np.exp(params["loglengthscales"][d])) for d in range(D)]
+        ctrl = np.concatenate((c, rng.standard_normal((steps, C))))
+        eps = rng.standard_normal((steps, R, D))
+        xc = np.concatenate((X[:-1], c), axis=1)
+        L = cmo.kernel_pre_cal(params["Z"], kern)
+        U, H = cmo.collapse_u_mean_after_kernel_precalculation(L, xc, X, params["Z"], kern, Q)
+        x0, epg, u = rng.standard_normal((R, D)), rng.standard_normal((T, R, D)), rng.random((T, R))
+        Rch = np.exp(params["log_Rchols"])
+        out = {}
+        for mode in ("loop", "launches"):
+            if mode == "loop":
+                monkeypatch.setenv("FFVD_STEP_LOOP", "1")
+            else:
+                monkeypatch.delenv("FFVD_STEP_LOOP", raising=False)
+            out[mode] = (rollout(L, params["Z"], kern, U, H, X[-1], ctrl, T, steps, Q, eps),
+                         rollout(L, params["Z"], kern, U, None, X[-1], ctrl, T, steps, Q, eps),
+                         pg_sweep(L, params["Z"], kern, params["U"], X, Y, c, params["CC"], params["DD"], Rch, Q, x0, epg, u))
+        monkeypatch.delenv("FFVD_STEP_LOOP", raising=False)
+        for a, b in zip(out["loop"], out["launches"]):
+            np.testing.assert_array_equal(a[0], b[0])
+            np.testing.assert_array_equal(a[1], b[1])
