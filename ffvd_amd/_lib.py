@@ -116,6 +116,9 @@ _SIGNATURES = {
     "ffvd_tshard_get": (C.c_int, [C.c_void_p, _dp]),
     "ffvd_tshard_set": (C.c_int, [C.c_void_p, _dp]),
     "ffvd_tshard_finish": (C.c_int, [C.c_void_p, _dp, _dp]),
+    "ffvd_tshard_finish_grad": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp]),
+    "ffvd_tshard_grad_fetch": (C.c_int, [C.c_void_p, _dp, C.POINTER(FfvdGrads)]),
+    "ffvd_elbo_tshard_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _dp, _dp, C.POINTER(FfvdGrads)]),
     "ffvd_op_conditional": (C.c_int, [C.c_int, _dp, C.c_int, _dp, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp,
                                       C.c_double, _dp, _dp]),
 }

@@ -473,9 +473,10 @@ extern "C" int ffvd_create(const ffvd_config *cfg, ffvd_handle **out) {
         return set_error(nullptr, FFVD_EINVAL, "ffvd_create: FFVD_ROUTE_GRAM only applies to the collapsed-U branch");
     if (cfg->T_total < 0 || cfg->t_begin < 0 || (cfg->T_total > 0 && cfg->t_begin + cfg->T > cfg->T_total))
         return set_error(nullptr, FFVD_EINVAL, "ffvd_create: T-shard [t_begin, t_begin + T) outside [0, T_total)");
-    if (cfg->T_total > 0 && (cfg->branch != FFVD_BRANCH_B || cfg->route != FFVD_ROUTE_GRAM || cfg->dtype != FFVD_F64 || cfg->grad))
-        return set_error(nullptr, FFVD_EINVAL,
-                         "ffvd_create: a T-shard (T_total > 0) is the collapsed-U branch on FFVD_ROUTE_GRAM in fp64, without gradient");
+    if (cfg->T_total > 0 && (cfg->branch != FFVD_BRANCH_B || cfg->route != FFVD_ROUTE_GRAM || cfg->dtype != FFVD_F64))
+        return set_error(nullptr, FFVD_EINVAL, "ffvd_create: a T-shard (T_total > 0) is the collapsed-U branch on FFVD_ROUTE_GRAM in fp64");
+    if (cfg->T_total > 0 && cfg->grad && (cfg->d_begin != 0 || (cfg->d_count > 0 && cfg->d_count != cfg->D)))
+        return set_error(nullptr, FFVD_EINVAL, "ffvd_create: grad = 1 on a T-shard needs every latent dim on the handle (T-shards and dim shards do not combine in the backward pass)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || cfg->device_id < 0 || cfg->device_id >= ndev) {
         snprintf(msg, sizeof msg, "ffvd_create: device %d not available (%d HIP devices visible)", cfg->device_id, ndev);
@@ -1402,6 +1403,7 @@ static int enqueue_grad_a(ffvd_handle *h, int S_total) {
     dx.X = p.X; dx.Y = h->Y; dx.CC = p.CC; dx.DD = p.DD; dx.log_Rchols = p.log_Rchols; dx.log_Q = p.log_Q; dx.len = h->len;
     dx.rsum = g.rsum; dx.ez = g.ez; dx.kfu = g.kfu; dx.S = S; dx.S_total = S_total; dx.T = c.T; dx.Tp = Tp; dx.D = c.D;
     dx.P = P; dx.Ydim = c.Ydim; dx.Dl = Dl; dx.d_begin = c.d_begin; dx.shared_terms = c.shared_terms; dx.dX = g.dX;
+    dx.T_norm = c.T_total; dx.skip_x0 = (c.T_total > 0 && c.t_begin > 0) ? 1 : 0;      // T-shards: the job's 1 / T, x_0 on the first shard
     launch_dx(s, dx);
     launch_shared_partials(s, dx, g.shared_part, g.sp_stride);
     GradFinalArgs gf{};
@@ -1557,6 +1559,7 @@ static int enqueue_grad_b(ffvd_handle *h, int S_total) {
     dx.X = p.X; dx.Y = h->Y; dx.CC = p.CC; dx.DD = p.DD; dx.log_Rchols = p.log_Rchols; dx.log_Q = p.log_Q; dx.len = h->len;
     dx.rsum = g.rsum; dx.ez = g.ez; dx.kfu = g.kfu; dx.S = S; dx.S_total = S_total; dx.T = c.T; dx.Tp = Tp; dx.D = c.D;
     dx.P = P; dx.Ydim = c.Ydim; dx.Dl = Dl; dx.d_begin = c.d_begin; dx.shared_terms = c.shared_terms; dx.dX = g.dX;
+    dx.T_norm = c.T_total; dx.skip_x0 = (c.T_total > 0 && c.t_begin > 0) ? 1 : 0;      // T-shards: the job's 1 / T, x_0 on the first shard
     // u^T K u and the per-chain partials of the shared parameters feed grad_finalize only.  Beside a long E product they ride on
     // the side stream; when that product is a few dozen microseconds (the reference's own experiment sizes) the side stream's
     // dozen launches ARE the backward pass's critical path and these two go to the main stream, which has the slack there
@@ -1582,6 +1585,7 @@ static int enqueue_grad_b(ffvd_handle *h, int S_total) {
     GradFinalArgs gf{};
     gf.T = c.T; gf.D = c.D; gf.P = P; gf.M = c.M; gf.Mp = Mp; gf.Ydim = c.Ydim; gf.Dl = Dl; gf.d_begin = c.d_begin; gf.S = S;
     gf.S_total = S_total; gf.shared_terms = c.shared_terms; gf.prior_type = c.prior_type;
+    gf.T_norm = c.T_total; gf.replicated_skip = (c.T_total > 0 && c.t_begin > 0) ? 1 : 0;
     gf.Z = p.Z; gf.logvar = p.logvariance; gf.loglen = p.loglengthscales; gf.log_Q = p.log_Q; gf.CC = p.CC; gf.DD = p.DD;
     gf.log_Rchols = p.log_Rchols; gf.dz_unit = g.dz_unit; gf.dll_unit = g.dll_unit; gf.dls_unit = g.dls_unit;
     gf.dz_kuu = g.dz_kuu; gf.dll_kuu = g.dll_kuu; gf.dls_kuu = g.dls_kuu; gf.gam_part = g.gam_part; gf.ngam = g.ngam;
@@ -1609,6 +1613,27 @@ static int enqueue_forward_backward(ffvd_handle *h, int S_total) {
     return r ? r : enqueue_grad(h, S_total);
 }
 
+// the gradient arrays of the handle to the caller's host arrays (enqueued on the main stream; the caller synchronises)
+static int copy_grads_out(ffvd_handle *h, const ffvd_grads *gout) {
+    const ffvd_config &c = h->cfg;
+    ffvd_handle::GradWs &g = h->gw;
+    hipStream_t s = h->stream;
+    const size_t P = h->P, J = c.Ydim;
+    if (gout->X) HIP_TRY(hipMemcpyAsync(gout->X, g.dX, (size_t)c.S_local * (c.T + 1) * c.D * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (gout->Z) HIP_TRY(hipMemcpyAsync(gout->Z, g.dZ, (size_t)c.M * P * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (gout->logvariance) HIP_TRY(hipMemcpyAsync(gout->logvariance, g.dlogvar, (size_t)c.D * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (gout->loglengthscales) HIP_TRY(hipMemcpyAsync(gout->loglengthscales, g.dloglen, (size_t)c.D * P * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (gout->log_Q) HIP_TRY(hipMemcpyAsync(gout->log_Q, g.dlogQ, (size_t)c.D * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (gout->CC) HIP_TRY(hipMemcpyAsync(gout->CC, g.dCC, (size_t)c.D * J * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (gout->DD) HIP_TRY(hipMemcpyAsync(gout->DD, g.dDD, J * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (gout->log_Rchols) HIP_TRY(hipMemcpyAsync(gout->log_Rchols, g.dlogR, J * J * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (gout->U) {
+        if (g.dU) HIP_TRY(hipMemcpyAsync(gout->U, g.dU, (size_t)c.M * c.D * sizeof(double), hipMemcpyDeviceToHost, s));
+        else memset(gout->U, 0, (size_t)c.M * c.D * sizeof(double));        // collapsed branch: U is integrated out
+    }
+    return FFVD_OK;
+}
+
 extern "C" int ffvd_elbo_grad(ffvd_handle *h, const ffvd_params *p, uint32_t flags, int S_total, double out_terms[8],
                               double *out_nll, const ffvd_grads *gout) {
     if (!h) return set_error(nullptr, FFVD_EINVAL, "ffvd_elbo_grad: null handle");
@@ -1629,22 +1654,9 @@ extern "C" int ffvd_elbo_grad(ffvd_handle *h, const ffvd_params *p, uint32_t fla
     if ((rc = ready(h, "ffvd_elbo_grad"))) return rc;
     if ((rc = fetch_with_stall_recovery(h, [&] { return enqueue_forward_backward(h, S_total); })))
         return rc;
+    if ((rc = copy_grads_out(h, gout))) return rc;
     const ffvd_config &c = h->cfg;
-    ffvd_handle::GradWs &g = h->gw;
     hipStream_t s = h->stream;
-    const size_t P = h->P, J = c.Ydim;
-    if (gout->X) HIP_TRY(hipMemcpyAsync(gout->X, g.dX, (size_t)c.S_local * (c.T + 1) * c.D * sizeof(double), hipMemcpyDeviceToHost, s));
-    if (gout->Z) HIP_TRY(hipMemcpyAsync(gout->Z, g.dZ, (size_t)c.M * P * sizeof(double), hipMemcpyDeviceToHost, s));
-    if (gout->logvariance) HIP_TRY(hipMemcpyAsync(gout->logvariance, g.dlogvar, (size_t)c.D * sizeof(double), hipMemcpyDeviceToHost, s));
-    if (gout->loglengthscales) HIP_TRY(hipMemcpyAsync(gout->loglengthscales, g.dloglen, (size_t)c.D * P * sizeof(double), hipMemcpyDeviceToHost, s));
-    if (gout->log_Q) HIP_TRY(hipMemcpyAsync(gout->log_Q, g.dlogQ, (size_t)c.D * sizeof(double), hipMemcpyDeviceToHost, s));
-    if (gout->CC) HIP_TRY(hipMemcpyAsync(gout->CC, g.dCC, (size_t)c.D * J * sizeof(double), hipMemcpyDeviceToHost, s));
-    if (gout->DD) HIP_TRY(hipMemcpyAsync(gout->DD, g.dDD, J * sizeof(double), hipMemcpyDeviceToHost, s));
-    if (gout->log_Rchols) HIP_TRY(hipMemcpyAsync(gout->log_Rchols, g.dlogR, J * J * sizeof(double), hipMemcpyDeviceToHost, s));
-    if (gout->U) {
-        if (g.dU) HIP_TRY(hipMemcpyAsync(gout->U, g.dU, (size_t)c.M * c.D * sizeof(double), hipMemcpyDeviceToHost, s));
-        else memset(gout->U, 0, (size_t)c.M * c.D * sizeof(double));        // collapsed branch: U is integrated out
-    }
     HIP_TRY(hipStreamSynchronize(s));
     if (out_terms) memcpy(out_terms, h->h_out, 8 * sizeof(double));
     if (out_nll) *out_nll = h->h_out[FFVD_TERM_NLL] / (double)c.S_local;
@@ -2814,9 +2826,26 @@ static int enqueue_tshard_finish(ffvd_handle *h) {
     ga.nb = h->nbatch; ga.yn_over_batch = 1.0; ga.H = h->H; ga.h_stride = (size_t)(Mp + NB) * Mp;
     ga.Kadd = h->Kcopy; ga.kadd_stride = msq; ga.Kinv = h->Kinv; ga.kinv_stride = msq; ga.trpart = h->trpart;
     ga.part = h->tsbuf; ga.ksplit = 1;
-    launch_gram(s, ga, 4);
-    launch_potrf_ext(s, h->H, Mp, NB, 0, h->nbatch, ga.h_stride, h->info + Dl, h->dinvH, CHOL_FLOW, nullptr, 0, false, true);
-    launch_h_finish(s, h->H, Mp, ga.h_stride, h->nbatch, h->hterms);
+    if (c.grad) {
+        // training forward (round 4: T-shards have a backward pass): the slab keeps Mp extension rows in front of the b row -- L^T there,
+        // so that the factorisation of A leaves L_H^-T and y = L_A^-1 c, exactly what enqueue_grad_b reads -- and
+        // A itself is saved before it is overwritten
+        ga.brow = 2 * Mp; ga.h_stride = (size_t)(2 * Mp + NB) * Mp;
+        launch_gram(s, ga, 4);
+        HIP_TRY(hipMemcpy2DAsync(h->gw.Acopy, msq * sizeof(double), h->H, ga.h_stride * sizeof(double), msq * sizeof(double),
+                                 (size_t)h->nbatch, hipMemcpyDeviceToDevice, s));
+        // (FFVD_GRAD_EXPLICIT: identity rows instead, the factorisation then leaves L_A^-T -- the unwhitened form of the backward pass)
+        const bool lt_virtual = h->gw.whitened && !h->sw.lt_armed && potrf_flow_selected(Mp, h->nbatch, CHOL_FLOW);
+        if (!h->gw.whitened) launch_set_identity(s, h->H, ga.h_stride, Mp, Mp, h->nbatch);
+        else if (!lt_virtual) launch_set_lt_rows(s, h->Kuu, (size_t)2 * msq, Dl, h->H, ga.h_stride, Mp, Mp, h->nbatch);
+        launch_potrf_ext(s, h->H, Mp, Mp + NB, Mp, h->nbatch, ga.h_stride, h->info + Dl, h->dinvH, CHOL_FLOW, nullptr, 0, false, true,
+                         nullptr, 0, lt_virtual ? h->Kuu : nullptr, (size_t)2 * msq, Dl);
+        launch_h_finish(s, h->H, Mp, ga.h_stride, h->nbatch, h->hterms, 2 * Mp);
+    } else {
+        launch_gram(s, ga, 4);
+        launch_potrf_ext(s, h->H, Mp, NB, 0, h->nbatch, ga.h_stride, h->info + Dl, h->dinvH, CHOL_FLOW, nullptr, 0, false, true);
+        launch_h_finish(s, h->H, Mp, ga.h_stride, h->nbatch, h->hterms);
+    }
     FinalizeArgs fa{};
     fa.kind = c.kernel_kind; fa.branch = c.branch; fa.prior_type = c.prior_type; fa.shared_terms = c.shared_terms;
     fa.T = c.T_total;                                   // every /T of dgp_model.py:261-297 is the whole job's
@@ -2861,10 +2890,9 @@ extern "C" int ffvd_tshard_set(ffvd_handle *h, const double *host_in) {
     return FFVD_OK;
 }
 
-extern "C" int ffvd_tshard_finish(ffvd_handle *h, double out_terms[8], double *out_nll) {
+// The finish (S_total > 0: and the backward pass behind it) with the recovery of an abandoned dataflow Cholesky(A).
+static int tshard_finish_run(ffvd_handle *h, int S_total, const char *who, double out_terms[8], double *out_nll) {
     int rc;
-    if ((rc = tshard_ready(h, "ffvd_tshard_finish"))) return rc;
-    HIP_TRY(hipSetDevice(h->cfg.device_id));
     // The finish is a pure function of the exchanged buffer (read-only here) and of this rank's K_uu chain, and no collective
     // follows inside the call: a dataflow Cholesky(A) that gave up on a bounded wait is re-run ONCE with the launch-per-column
     // variant, like the single-rank entry points (fetch_with_stall_recovery).  A failure of the K_uu chain itself (local phase,
@@ -2877,6 +2905,16 @@ extern "C" int ffvd_tshard_finish(ffvd_handle *h, double out_terms[8], double *o
                 HIP_TRY(hipMemsetAsync(h->info + h->Dl, 0, (size_t)h->nbatch * sizeof(int32_t), h->stream));
             }
             if ((rc = enqueue_tshard_finish(h))) return rc;
+            if (S_total > 0) {
+                // backward pass on the job's factorisation: this shard's ADDITIVE share of every gradient (grad_finalize: the
+                // M x M-side terms and the priors count on the first shard only), dX for the shard's own rows.  The term sums
+                // head the block like in a sharded training step -- the job's on the first shard, zero elsewhere -- so that
+                // ONE all-reduce(sum) of ffvd_train_exchange_count doubles completes both.
+                if ((rc = enqueue_grad_b(h, S_total))) return rc;
+                if (h->cfg.t_begin == 0)
+                    HIP_TRY(hipMemcpyAsync(h->gw.pack, h->out_terms, 8 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+                else HIP_TRY(hipMemsetAsync(h->gw.pack, 0, 8 * sizeof(double), h->stream));
+            }
         }
         HIP_TRY(hipMemcpyAsync(h->h_res, h->resblk, h->res_bytes, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
@@ -2895,9 +2933,52 @@ extern "C" int ffvd_tshard_finish(ffvd_handle *h, double out_terms[8], double *o
     if (rc) return rc;
     for (int i = 0; i < 7; ++i)
         if (!std::isfinite(h->h_out[i]))
-            return set_error(h, FFVD_ENOTPD, "ffvd_tshard_finish: non-finite sums after the exchange (a factorisation failed or was abandoned on another rank)");
+            return set_error(h, FFVD_ENOTPD, std::string(who) + ": non-finite sums after the exchange (a factorisation failed or was abandoned on another rank)");
     if (out_terms) memcpy(out_terms, h->h_out, 8 * sizeof(double));
     if (out_nll) *out_nll = h->h_out[FFVD_TERM_NLL] / (double)h->cfg.S_local;
+    return FFVD_OK;
+}
+
+extern "C" int ffvd_tshard_finish(ffvd_handle *h, double out_terms[8], double *out_nll) {
+    int rc;
+    if ((rc = tshard_ready(h, "ffvd_tshard_finish"))) return rc;
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    return tshard_finish_run(h, 0, "ffvd_tshard_finish", out_terms, out_nll);
+}
+
+// ---- gradient of a T-sharded job -------------------------------------------------------------------------
+// After the exchange of the raw tiles every shard holds the job's A, its factor, u and Gamma; the K_fu side of the backward pass
+// (E = (2 K_fu Gamma + alpha delta u^T) o K_fu and its reductions) runs over the shard's own rows and is additive over shards,
+// like the likelihood / transition sums; the M x M side (K_uu chain rule, tr(A^-1 G), u^T G u, priors) is the same on every shard
+// and counted on the first.  dX covers the shard's own T + 1 rows: the row two neighbouring shards share (the last of one, the
+// first of the next) gets a part from each -- the caller adds them.
+static int tshard_grad_ready(ffvd_handle *h, const char *who, int S_total) {
+    int rc;
+    if ((rc = tshard_ready(h, who))) return rc;
+    if (!h->cfg.grad) return set_error(h, FFVD_EINVAL, std::string(who) + ": the handle was created without grad = 1");
+    if (S_total < h->cfg.S_local) return set_error(h, FFVD_EINVAL, std::string(who) + ": S_total < S_local");
+    return FFVD_OK;
+}
+
+extern "C" int ffvd_tshard_finish_grad(ffvd_handle *h, int S_total, double out_terms[8], double *out_nll) {
+    int rc;
+    if ((rc = tshard_grad_ready(h, "ffvd_tshard_finish_grad", S_total))) return rc;
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    return tshard_finish_run(h, S_total, "ffvd_tshard_finish_grad", out_terms, out_nll);
+}
+
+extern "C" int ffvd_tshard_grad_fetch(ffvd_handle *h, double out_terms[8], const ffvd_grads *gout) {
+    int rc;
+    if ((rc = tshard_grad_ready(h, "ffvd_tshard_grad_fetch", h ? h->cfg.S_local : 0))) return rc;
+    if (!gout) return set_error(h, FFVD_EINVAL, "ffvd_tshard_grad_fetch: null gradient struct");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    if ((rc = copy_grads_out(h, gout))) return rc;
+    HIP_TRY(hipMemcpyAsync(h->h_sums, h->gw.pack, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < 8; ++i)
+        if (!std::isfinite(h->h_sums[i]))
+            return set_error(h, FFVD_ENOTPD, "ffvd_tshard_grad_fetch: non-finite sums in the exchanged block (a factorisation failed on another rank)");
+    if (out_terms) memcpy(out_terms, h->h_sums, 8 * sizeof(double));
     return FFVD_OK;
 }
 
@@ -2909,6 +2990,30 @@ extern "C" int ffvd_elbo_tshard(ffvd_handle *h, void *rccl_comm, double out_term
     if ((rc = enqueue_tshard_local(h))) return rc;
     if ((rc = ffvd_allreduce_sum_async(h, rccl_comm, h->tsbuf, h->ts_count))) return rc;      // the ONE exchange step
     return ffvd_tshard_finish(h, out_terms, out_nll);
+}
+// nll + gradient of a T-sharded job: two exchange steps (raw tiles + chain sums; then the gradient block), both native RCCL
+extern "C" int ffvd_elbo_tshard_grad(ffvd_handle *h, void *rccl_comm, int S_total, double out_terms[8], double *out_nll,
+                                     const ffvd_grads *gout) {
+    int rc;
+    if ((rc = tshard_grad_ready(h, "ffvd_elbo_tshard_grad", S_total))) return rc;
+    if (!gout) return set_error(h, FFVD_EINVAL, "ffvd_elbo_tshard_grad: null gradient struct");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    if ((rc = enqueue_tshard_local(h))) return rc;
+    if ((rc = ffvd_allreduce_sum_async(h, rccl_comm, h->tsbuf, h->ts_count))) return rc;
+    // a failed finish still takes part in the second exchange (NaN sums at the head of its block): the ranks stay in step
+    const int rc_fin = tshard_finish_run(h, S_total, "ffvd_elbo_tshard_grad", nullptr, nullptr);
+    if (rc_fin) {
+        std::vector<double> nan8(8, std::nan(""));
+        HIP_TRY(hipMemcpy(h->gw.pack, nan8.data(), 8 * sizeof(double), hipMemcpyHostToDevice));
+    }
+    const std::string first_err = rc_fin ? h->err : std::string();
+    if ((rc = ffvd_allreduce_sum_async(h, rccl_comm, h->gw.pack, (int64_t)h->gw.pack_shared))) return rc;
+    if (rc_fin) { HIP_TRY(hipStreamSynchronize(h->stream)); return set_error(h, rc_fin, first_err); }
+    double sums[8];
+    if ((rc = ffvd_tshard_grad_fetch(h, sums, gout))) return rc;
+    if (out_terms) memcpy(out_terms, sums, 8 * sizeof(double));
+    if (out_nll) *out_nll = sums[FFVD_TERM_NLL] / sums[FFVD_TERM_COUNT];
+    return FFVD_OK;
 }
 
 // ---- native RCCL collectives (SURVEY 8b `ffvd_elbo_allreduce(h, rccl_comm)`, 8e) ---------------------------------

@@ -128,6 +128,9 @@ struct DxArgs {
     const double *rsum, *ez, *kfu;
     int S, S_total, T, Tp, D, P, Ydim, Dl, d_begin, shared_terms;
     double *dX;
+    // T-shard handles (cfg.T_total > 0): the handle holds rows [t_begin, t_begin + T) of a job with T_norm transitions -- every 1 / T
+    // of dgp_model.py:261-297 is the job's (0 = use T), and X[0] is the job's x_0 (prior_x_0) on the first shard only
+    int T_norm, skip_x0;
 };
 void launch_dx(hipStream_t stream, const DxArgs &a);
 void launch_shared_partials(hipStream_t stream, const DxArgs &a, double *out, int stride);
@@ -149,6 +152,10 @@ struct GradFinalArgs {
     double *dU;
     int kind;                                          // FFVD_KERNEL_*
     const double *xsq_unit;                            // LinearK: [nb] sum_t |x_comb_t|^2 (Kdiag = variance |x|^2 enters the trace term)
+    // T-shard handles: T_norm = the job's transitions (0 = T).  Every shard finishes the SAME all-reduced Gram matrices, so the terms
+    // that do not sum over this shard's own rows -- the K_uu side, the G-dependent part of dl/dalpha, the priors -- are identical on
+    // every shard: replicated_skip != 0 (all shards but the first) leaves them out, and the sum over shards counts them once.
+    int T_norm, replicated_skip;
 };
 void launch_grad_finalize(hipStream_t stream, const GradFinalArgs &a);
 

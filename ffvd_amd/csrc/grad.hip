@@ -1194,7 +1194,7 @@ __global__ __launch_bounds__(256) void dx_kernel(DxArgs a) {
     if (idx >= (size_t)a.S * per) return;
     const int s = (int)(idx / per), t = (int)((idx % per) / D), p = (int)(idx % D);
     const double *Xs = a.X + (size_t)s * per;
-    const double Tn = (double)T;
+    const double Tn = (double)(a.T_norm > 0 ? a.T_norm : T);
     double g = 0.0;
     if (a.shared_terms) {
         if (t >= 1) {                                   // likelihood: row t-1 of Y sees X[t]
@@ -1208,7 +1208,7 @@ __global__ __launch_bounds__(256) void dx_kernel(DxArgs a) {
             }
             g += -acc / Tn;
         }
-        if (t == 0) g += Xs[p] / Tn;                    // prior_x_0
+        if (t == 0 && !a.skip_x0) g += Xs[p] / Tn;      // prior_x_0
     }
     // terms tied to latent dim p itself (delta_{t,p}) -- only if p is one of this handle's dims
     const int dl_p = p - a.d_begin;
@@ -1257,6 +1257,7 @@ __global__ __launch_bounds__(256) void shared_partials_kernel(DxArgs a, double *
     __shared__ double scratch[256];
     const int s = blockIdx.x, tid = threadIdx.x;
     const int T = a.T, D = a.D, J = a.Ydim;
+    const double Tn = (double)(a.T_norm > 0 ? a.T_norm : T);
     const double *Xs = a.X + (size_t)s * (T + 1) * D;
     double *o = out + (size_t)s * stride;
     for (int j = 0; j < J; ++j) {
@@ -1272,11 +1273,11 @@ __global__ __launch_bounds__(256) void shared_partials_kernel(DxArgs a, double *
                 if (d == 0) { dd += r / R; dr += r * r - 1.0; }
             }
             dc = block_sum(dc, scratch);
-            if (tid == 0) o[d * J + j] = -dc / (double)T;
+            if (tid == 0) o[d * J + j] = -dc / Tn;
         }
         dd = block_sum(dd, scratch);
         dr = block_sum(dr, scratch);
-        if (tid == 0) { o[D * J + j] = -dd / (double)T; o[D * J + J + j] = -dr / (double)T; }
+        if (tid == 0) { o[D * J + j] = -dd / Tn; o[D * J + J + j] = -dr / Tn; }
     }
     for (int dl = 0; dl < a.Dl; ++dl) {
         const int d = a.d_begin + dl;
@@ -1287,7 +1288,7 @@ __global__ __launch_bounds__(256) void shared_partials_kernel(DxArgs a, double *
             acc += 0.5 - 0.5 * dlt * dlt / Q;
         }
         acc = block_sum(acc, scratch);
-        if (tid == 0) o[D * J + 2 * J + dl] = acc / (double)T;
+        if (tid == 0) o[D * J + 2 * J + dl] = acc / Tn;
     }
 }
 void launch_shared_partials(hipStream_t stream, const DxArgs &a, double *out, int stride) {
@@ -1303,10 +1304,11 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(GradFinalArgs a) {
     __shared__ double scratch[4][8];
     const int tid = threadIdx.x, dl = blockIdx.x, dg = a.d_begin + dl;
     const int D = a.D, P = a.P, J = a.Ydim, Dl = a.Dl, S = a.S;
-    const double Tn = (double)a.T, Sn = (double)a.S_total;
+    const double Tloc = (double)a.T, Tn = (double)(a.T_norm > 0 ? a.T_norm : a.T), Sn = (double)a.S_total;
+    const double rep = a.replicated_skip ? 0.0 : 1.0;      // T-shards: terms every shard computes identically count on the first only
     // prior gradients are weighted by this handle's share of the chains, so that the sum over chain shards
     // (and over dim shards, where S == S_total and every dim has one owner) is the whole-job gradient
-    const double w = (double)S / Sn;
+    const double w = rep * (double)S / Sn;
     // loglengthscales of this dim, eight components at a time
     for (int p0 = 0; p0 < P; p0 += 8) {
         double v[8];
@@ -1322,7 +1324,7 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(GradFinalArgs a) {
         for (int q = 0; q < 8; ++q)
             if (tid == q && p0 + q < P) {
                 const int p = p0 + q;
-                const double acc = v[q] + a.dll_kuu[(size_t)dl * P + p];
+                const double acc = v[q] + rep * a.dll_kuu[(size_t)dl * P + p];
                 // LinearK has no lengthscales: neither a data term nor the prior_hyper term (dgp_model.py:123-130)
                 a.dloglen[(size_t)dg * P + p] = (a.kind != 0) ? 0.0 : -acc / Tn / Sn + w * a.loglen[(size_t)dg * P + p] / Tn;
             }
@@ -1336,7 +1338,7 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(GradFinalArgs a) {
         for (int s = tid; s < S; s += 256) {
             const size_t bb = (size_t)s * Dl + dl;
             // K_fu side + direct Kdiag term (SE: Kdiag = s2; LinearK: Kdiag_t = s2 |x_t|^2)
-            v[0] += a.dls_unit[bb] - 0.5 * alpha * s2 * ((a.kind != 0) ? a.xsq_unit[bb] : Tn);
+            v[0] += a.dls_unit[bb] - 0.5 * alpha * s2 * ((a.kind != 0) ? a.xsq_unit[bb] : Tloc);
             if (a.branch_a) {                                        // explicit U: dl/dalpha comes per unit from resid_a
                 v[1] += a.dalpha_unit[bb] * (-alpha);
                 continue;
@@ -1349,13 +1351,17 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(GradFinalArgs a) {
             const double quad = a.hterms[2 * bb + 1];
             const double trAinvG = ((double)a.Mp - trAK) / alpha;
             const double uGu = (quad - a.uku[bb]) / alpha;
-            const double dalpha = -0.5 * trAinvG + quad / alpha - 0.5 * uGu - 0.5 * (((a.kind != 0) ? a.xsq_unit[bb] : Tn) * s2 - fsq);
+            const double kdsum = ((a.kind != 0) ? a.xsq_unit[bb] : Tloc) * s2;      // sum_t Kdiag_t over THIS handle's rows
+            // (T-shards: tr(A^-1 G), u^T g, u^T G u and tr(K^-1 G) are the job's -- the same on every shard, counted on the first;
+            //  sum_t Kdiag_t is this shard's share.  Otherwise the expression as it always was.)
+            const double dalpha = (a.T_norm > 0) ? rep * (-0.5 * trAinvG + quad / alpha - 0.5 * uGu + 0.5 * fsq) - 0.5 * kdsum
+                                                 : -0.5 * trAinvG + quad / alpha - 0.5 * uGu - 0.5 * (kdsum - fsq);
             v[1] += dalpha * (-alpha);
             v[2] += a.shared_part[(size_t)s * a.sp_stride + D * J + 2 * J + dl];
         }
         block_sum_multi_256<8>(v, scratch);
         if (tid == 0) {
-            const double ls = v[0] + a.dls_kuu[dl];
+            const double ls = v[0] + rep * a.dls_kuu[dl];
             a.dlogvar[dg] = -ls / Tn / Sn + w * (a.logvar[dg] - (a.kind == 0 ? LOG_PRIOR_VARIANCE_SE : LOG_PRIOR_VARIANCE_LIN)) / Tn;
             a.dlogQ[dg] = -v[1] / Tn / Sn + (a.branch_a ? 0.0 : v[2] / Sn) + w * a.log_Q[dg] / Tn;
         }
@@ -1405,14 +1411,15 @@ __global__ __launch_bounds__(256) void grad_dz_kernel(GradFinalArgs a) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int M = a.M, P = a.P, Dl = a.Dl, S = a.S;
     if (idx >= M * P) return;
-    const double Tn = (double)a.T, Sn = (double)a.S_total;
+    const double Tn = (double)(a.T_norm > 0 ? a.T_norm : a.T), Sn = (double)a.S_total;
+    const double rep = a.replicated_skip ? 0.0 : 1.0;
     double acc = 0.0;
     for (int s = 0; s < S; ++s)
         for (int dl = 0; dl < Dl; ++dl) acc += a.dz_unit[((size_t)(s * Dl + dl) * M * P) + idx];
     double kk = 0.0;
     for (int dl = 0; dl < Dl; ++dl) kk += a.dz_kuu[(size_t)dl * M * P + idx];
-    double g = -(acc + kk) / Tn / Sn;
-    if (a.shared_terms && a.prior_type == 1) g += ((double)S / Sn) * a.Z[idx] / Tn;
+    double g = -(acc + rep * kk) / Tn / Sn;
+    if (a.shared_terms && a.prior_type == 1) g += rep * ((double)S / Sn) * a.Z[idx] / Tn;
     a.dZ[idx] = g;
 }
 void launch_grad_finalize(hipStream_t stream, const GradFinalArgs &a) {

@@ -270,7 +270,22 @@ class ShardedElbo:
     def nll_and_grad(self):
         """Whole-job nll terms and gradient (the engine must have been built with grad=True, route="gram"):
         local backward pass scaled by 1/S_total, then one all-reduce of the 8 sums and one of the packed
-        shared-parameter gradients."""
+        shared-parameter gradients.  T-shards: two exchange steps (raw tiles + chain sums, then the gradient block); dX comes
+        back for the WHOLE trajectory -- every shard's rows placed at their global position and summed, which also adds the two
+        parts of the rows neighbouring shards share."""
+        if self.time_shard:
+            S, t0 = self.meta["S"], self.plan["t_begin"]
+            if self.collective == "rccl":
+                sums, g = self.engine.elbo_tshard_grad(S_total=S)
+                reduce_host = self.engine.allreduce_host
+            else:
+                t = self._host_reduce(self.engine.tshard_local())
+                sums, g = self.engine.tshard_grad_fetch(self._host_reduce(self.engine.tshard_finish_grad(t, S_total=S)))
+                reduce_host = lambda a: self._host_reduce(np.ascontiguousarray(a).ravel().copy())
+            full = np.zeros((S, self.meta["T"] + 1, self.meta["D"]))
+            full[:, t0: t0 + g["X"].shape[1]] = g["X"]
+            g["X"] = np.asarray(reduce_host(full)).reshape(full.shape)
+            return finish(sums), g
         terms, g = self.engine.nll_and_grad(S_total=self.meta["S"])
         if not self.reduces:
             return finish(terms["sums8"]), g
@@ -302,7 +317,7 @@ class ShardedElbo:
         collective nothing but the 8 sums reaches the host; groups RCCL cannot form (collective="torch": two test ranks on
         one GPU) carry the block through torch.distributed.  Returns the whole-job terms before the update."""
         if self.time_shard:
-            raise ValueError("T-shard handles have no backward pass")
+            raise ValueError("T-shard handles have no device-resident optimiser step (nll_and_grad returns the job's gradient)")
         S = self.meta["S"]
         if not self.reduces:
             self.engine.shard_of = 1
@@ -319,7 +334,7 @@ class ShardedElbo:
     def sghmc_step(self, noise, epsilon=0.01, mdecay=0.05, burn_in=True):
         """One burn_in_op / sample_op of the whole job; `noise` must be identical on every rank."""
         if self.time_shard:
-            raise ValueError("T-shard handles have no backward pass")
+            raise ValueError("T-shard handles have no device-resident sampler step (nll_and_grad returns the job's gradient)")
         S = self.meta["S"]
         if not self.reduces:
             self.engine.shard_of = 1

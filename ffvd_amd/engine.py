@@ -367,6 +367,47 @@ class ElboEngine:
         _lib.check(self.lib.ffvd_tshard_finish(self._h, _lib.dptr(out), ct.byref(nll)), self._h, "ffvd_tshard_finish")
         return out
 
+    # gradient of a T-sharded job (include/ffvd_abi.h "Gradient of a T-sharded job")
+    def _grad_arrays(self):
+        g = {
+            "X": np.zeros((self.S, self.T + 1, self.D)), "Z": np.zeros((self.M, self.P)),
+            "logvariance": np.zeros(self.D), "loglengthscales": np.zeros((self.D, self.P)),
+            "log_Q": np.zeros(self.D), "CC": np.zeros((self.D, self.Ydim)), "DD": np.zeros(self.Ydim),
+            "log_Rchols": np.zeros((self.Ydim, self.Ydim)), "U": np.zeros((self.M, self.D)),
+        }
+        return g, _lib.FfvdGrads(**{k: v.ctypes.data for k, v in g.items()})
+
+    def elbo_tshard_grad(self, S_total=None, comm=None):
+        """Local rows -> ncclAllReduce (tiles + chain sums) -> finish + backward pass -> ncclAllReduce (gradient block).
+        Returns (whole-job 8 sums, grads dict); grads["X"] holds this shard's own T + 1 rows (boundary rows: add the neighbour's)."""
+        g, gs = self._grad_arrays()
+        out = np.zeros(8)
+        nll = ct.c_double()
+        _lib.check(self.lib.ffvd_elbo_tshard_grad(self._h, comm, int(S_total or self.S), _lib.dptr(out), ct.byref(nll), ct.byref(gs)),
+                   self._h, "ffvd_elbo_tshard_grad")
+        return out, g
+
+    def tshard_finish_grad(self, reduced, S_total=None):
+        """Three-step form: upload the all-reduced exchange buffer, finish + backward pass; returns this shard's gradient block
+        (to be summed over the shards) as a host array."""
+        r = _lib.as_f64(reduced, (int(self.lib.ffvd_tshard_count(self._h)),), "reduced")
+        _lib.check(self.lib.ffvd_tshard_set(self._h, _lib.dptr(r)), self._h, "ffvd_tshard_set")
+        out = np.zeros(8)
+        nll = ct.c_double()
+        _lib.check(self.lib.ffvd_tshard_finish_grad(self._h, int(S_total or self.S), _lib.dptr(out), ct.byref(nll)), self._h,
+                   "ffvd_tshard_finish_grad")
+        buf = np.zeros(int(self.lib.ffvd_train_exchange_count(self._h)))
+        _lib.check(self.lib.ffvd_train_exchange_get(self._h, _lib.dptr(buf)), self._h, "ffvd_train_exchange_get")
+        return buf
+
+    def tshard_grad_fetch(self, reduced_block):
+        """... and the summed block back: returns (whole-job 8 sums, grads dict)."""
+        self._train_set(reduced_block)
+        g, gs = self._grad_arrays()
+        out = np.zeros(8)
+        _lib.check(self.lib.ffvd_tshard_grad_fetch(self._h, _lib.dptr(out), ct.byref(gs)), self._h, "ffvd_tshard_grad_fetch")
+        return out, g
+
     def allreduce_host(self, array, comm=None):
         """all-reduce(sum) of a small host fp64 array through the handle's device staging buffer on the engine's stream
         (8 sums + shared-parameter gradients of a sharded training step: a few KB).  Returns a new flat array."""

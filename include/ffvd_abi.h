@@ -282,7 +282,7 @@ int  ffvd_allreduce_sum(ffvd_handle *h, void *rccl_comm, double *buf_host, int64
 /* ---- T-shard fallback (SURVEY 8e last bullet, section 5 "long-context"): when chains x latent dims < ranks ---------
  * T is a pure reduction axis of the collapsed bound: the Gram matrices K_uf K_fu (M x M per unit) and the rows
  * delta^T K_fu, the likelihood and transition sums are all sums over t.  A T-shard handle (cfg.T = rows of the shard,
- * cfg.T_total, cfg.t_begin; FFVD_BRANCH_B, FFVD_ROUTE_GRAM, FFVD_F64, no gradient; X = rows t_begin .. t_begin + T of
+ * cfg.T_total, cfg.t_begin; FFVD_BRANCH_B, FFVD_ROUTE_GRAM, FFVD_F64; X = rows t_begin .. t_begin + T of
  * every chain, Y / control_inputs = the shard's rows) evaluates its rows' share; ONE all-reduce(sum) of the raw Gram
  * tiles + the per-chain partial sums (S_local * D * (M_p + 1) * M_p + 8 S_local doubles, M_p = M rounded up to 64)
  * follows, and EVERY rank finishes the same factorisations on the reduced sums, so every rank holds the whole-job
@@ -294,6 +294,21 @@ int64_t ffvd_tshard_count(const ffvd_handle *h);              /* doubles in the 
 int  ffvd_tshard_get(ffvd_handle *h, double *host_out);       /* copy the exchange buffer to the host (synchronises) */
 int  ffvd_tshard_set(ffvd_handle *h, const double *host_in);  /* ... and the reduced sums back                    */
 int  ffvd_tshard_finish(ffvd_handle *h, double out_terms[8], double *out_nll);
+/* Gradient of a T-sharded job (cfg.grad = 1, every latent dim on the handle).  After the exchange of the raw tiles every shard
+ * holds the job's A = K_uu + K_uf K_fu / Q, its factor, u and Gamma, so the backward pass needs no further operand from the other
+ * shards: its K_fu side (the T x M product and its reductions, dgp_model.py:261-288 differentiated) runs over the shard's own rows
+ * and is ADDITIVE over shards like the likelihood and transition sums; the M x M side (K_uu chain rule, tr(A^-1 G), u^T G u, the
+ * priors) is identical on every shard and counted on the first (t_begin == 0) only.  ffvd_tshard_finish_grad = finish + backward
+ * pass (divisor S_total, every 1 / T the job's T_total); it leaves the block [8 term sums (first shard; zero elsewhere) | dZ |
+ * dlogvariance | dloglengthscales | dlog_Q | dCC | dDD | dlog_Rchols] at ffvd_train_exchange_ptr, ffvd_train_exchange_count
+ * doubles: ONE all-reduce(sum) of it (ffvd_allreduce_sum_async, or ffvd_train_exchange_get / _set through the host) completes
+ * the gradient and the terms on every rank; ffvd_tshard_grad_fetch then copies it out.  dX covers the shard's OWN T + 1 rows and
+ * does not take part in the exchange: the row two neighbouring shards share (the last of one, the first of the next) receives a
+ * part from each, which the caller adds.  ffvd_elbo_tshard_grad = all of it with the two native RCCL all-reduces. */
+int  ffvd_tshard_finish_grad(ffvd_handle *h, int S_total, double out_terms[8], double *out_nll);
+int  ffvd_tshard_grad_fetch(ffvd_handle *h, double out_terms[8], const ffvd_grads *gout);
+int  ffvd_elbo_tshard_grad(ffvd_handle *h, void *rccl_comm, int S_total, double out_terms[8], double *out_nll,
+                           const ffvd_grads *gout);
 
 /* the handle's HIP stream (a hipStream_t), so that a collective library or another framework can order its work after
  * ffvd_elbo_async without a host synchronisation (e.g. torch.cuda.ExternalStream around the RCCL all-reduce). */

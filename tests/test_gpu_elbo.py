@@ -708,6 +708,80 @@ def test_time_shard_through_native_rccl_one_rank():
         ElboEngine(64, 2, 1, 16, 1, route="gram", t_shard=(100, 128))         # shard outside the job
 
 
+GRAD_NAMES = ("Z", "logvariance", "loglengthscales", "log_Q", "CC", "DD", "log_Rchols")
+
+
+@pytest.mark.parametrize("name,ov,nshard", [("small", dict(S=1, D=2), 3), ("ragged", dict(S=2, D=1), 4),
+                                             ("small_lin", dict(S=1, D=2, U_collapse=True), 2), ("small", dict(S=3, D=3), 2)])
+def test_time_shards_sum_to_the_single_engine_gradient(name, ov, nshard, monkeypatch):
+    """The backward pass of a T-sharded job: after the exchange of the raw tiles every shard differentiates
+    its own rows against the job's factorisation; the gradient blocks are added as the second all-reduce would, and the sum must
+    be the unsharded Gram-route gradient -- to 1e-7 of each array's largest entry (measured 2e-8 at worst: the tiles are summed in
+    another order than the unsharded pass, eps * cond(A) in the factor, and the gradient sees it amplified once more; the nll itself
+    agrees to 1e-10), dX row by row with the rows two shards share taking a part from each."""
+    from ffvd_amd.distributed import shard_range
+    params, Y, c, meta = synthetic.make_named(name, **ov)
+    T, S = meta["T"], meta["S"]
+    monkeypatch.setenv("FFVD_NO_TINY", "1")           # the unsharded GRAM-route engine
+    with ElboEngine(T, meta["D"], meta["C"], meta["M"], S, kernel_type=meta["kernel_type"], route="gram", grad=True) as e:
+        e.set_data(Y, c)
+        whole, gw = e.nll_and_grad(params)
+    monkeypatch.delenv("FFVD_NO_TINY")
+    engines, bufs = [], []
+    try:
+        for r in range(nshard):
+            t0, tc = shard_range(T, nshard, r)
+            e = ElboEngine(tc, meta["D"], meta["C"], meta["M"], S, kernel_type=meta["kernel_type"], route="gram",
+                           t_shard=(t0, T), grad=True)
+            e.set_data(Y[t0: t0 + tc], c[t0: t0 + tc])
+            e.set_params(dict(params, X=np.ascontiguousarray(params["X"][:, t0: t0 + tc + 1])))
+            engines.append(e)
+            bufs.append(e.tshard_local())
+        total = np.sum(bufs, axis=0)
+        blocks = [e.tshard_finish_grad(total) for e in engines]
+        assert [bool(np.any(b[:8])) for b in blocks] == [True] + [False] * (nshard - 1)      # the terms travel once
+        block = np.sum(blocks, axis=0)
+        dX = np.zeros_like(params["X"])
+        for r, e in enumerate(engines):
+            t0, tc = shard_range(T, nshard, r)
+            sums, g = e.tshard_grad_fetch(block)
+            assert sums[7] == S and sums[6] / S == pytest.approx(whole["nll"], rel=1e-10)
+            for n in GRAD_NAMES:
+                scale = max(np.abs(gw[n]).max(), 1e-12)
+                assert np.abs(g[n] - gw[n]).max() <= 1e-7 * scale, (n, r)
+            dX[:, t0: t0 + tc + 1] += g["X"]
+        assert np.abs(dX - gw["X"]).max() <= 1e-7 * np.abs(gw["X"]).max()
+    finally:
+        for e in engines:
+            e.close()
+
+
+def test_time_shard_gradient_through_native_rccl_one_rank(monkeypatch):
+    """ffvd_elbo_tshard_grad end to end on one rank (both collectives are the identity, everything else is the real path), and
+    what a T-shard handle refuses."""
+    from ffvd_amd.distributed import ShardedElbo
+    params, Y, c, meta = synthetic.make_named("small", S=2, D=2)
+    monkeypatch.setenv("FFVD_NO_TINY", "1")
+    with ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], meta["S"], route="gram", grad=True) as e:
+        e.set_data(Y, c)
+        whole, gw = e.nll_and_grad(params)
+    monkeypatch.delenv("FFVD_NO_TINY")
+    sh = ShardedElbo(params, Y, c, meta, rank=0, world=1, mode="time", device=0, grad=True)
+    try:
+        t, g = sh.nll_and_grad()
+        t2, g2 = sh.nll_and_grad()
+        assert t == t2 and all(np.array_equal(g[k], g2[k]) for k in g)
+        with pytest.raises(ValueError, match="optimiser step"):
+            sh.adam_step(1e-3)
+    finally:
+        sh.close()
+    assert t["nll"] == pytest.approx(whole["nll"], rel=1e-9)
+    for n in GRAD_NAMES + ("X",):
+        assert np.abs(g[n] - gw[n]).max() <= 1e-7 * max(np.abs(gw[n]).max(), 1e-12), n
+    with pytest.raises(ValueError, match="every latent dim"):
+        ElboEngine(64, 2, 1, 16, 1, route="gram", t_shard=(0, 128), grad=True, d_begin=1, d_count=1)
+
+
 SHARD_WORKER = r'''
 import os, sys
 sys.path.insert(0, os.environ["FFVD_ROOT"])
@@ -722,7 +796,11 @@ if mode == "time":                                                  # S * D = 1 
     sh = ShardedElbo(params, Y, c, meta, rank=rank, world=world, mode="auto", device=0, collective="torch")
     assert sh.time_shard
     t = finish(sh.step())
-    print("RESULT", rank, repr(t["nll"]), repr(finish(sh.step())["nll"]), flush=True)
+    t2 = finish(sh.step())
+    shg = ShardedElbo(params, Y, c, meta, rank=rank, world=world, mode="auto", device=0, collective="torch", grad=True)
+    tg, g = shg.nll_and_grad()
+    np.save(os.path.join(os.environ["FFVD_OUT"], "tgrad%d.npy" % rank), np.concatenate([g[k].ravel() for k in sorted(g) if k != "U"]))
+    print("RESULT", rank, repr(t["nll"]), repr(t2["nll"]), repr(tg["nll"]), flush=True)
     dist.destroy_process_group()
     sys.exit(0)
 params, Y, c, meta = synthetic.make_named("small")
@@ -774,7 +852,7 @@ def test_two_processes_share_the_gpu_and_reduce(tmp_path, mode):
         assert usum == pytest.approx(float(np.abs(ga["U"]).sum()), rel=1e-9)
 
 
-def test_two_processes_time_shard(tmp_path):
+def test_two_processes_time_shard(tmp_path, monkeypatch):
     """The T-shard fallback with two real ranks on the one GPU of the test box (S * D = 1): the exchange buffer travels
     over gloo, both ranks end up with the single-process nll."""
     import os
@@ -783,7 +861,7 @@ def test_two_processes_time_shard(tmp_path):
     script = tmp_path / "shard_worker.py"
     script.write_text(SHARD_WORKER)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, FFVD_ROOT=root, MASTER_ADDR="127.0.0.1", MASTER_PORT="29543", WORLD_SIZE="2")
+    env = dict(os.environ, FFVD_ROOT=root, MASTER_ADDR="127.0.0.1", MASTER_PORT="29543", WORLD_SIZE="2", FFVD_OUT=str(tmp_path))
     procs = [subprocess.Popen([sys.executable, str(script), "time"], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=300)[0] for p in procs]
@@ -795,6 +873,18 @@ def test_two_processes_time_shard(tmp_path):
         assert float(line[2]) == float(line[3])
         # two T-ranges summed, then factorised: a different summation order than the unsharded Gram pass (eps * cond(K_uu))
         assert float(line[2]) == pytest.approx(whole["nll"], rel=1e-9)
+        assert float(line[4]) == pytest.approx(whole["nll"], rel=1e-9)
+    # ... and with the job's gradient (second exchange: the gradient block; third: dX rows at their global position)
+    monkeypatch.setenv("FFVD_NO_TINY", "1")           # the unsharded GRAM-route engine
+    with ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], meta["S"], route="gram", grad=True) as e:
+        e.set_data(Y, c)
+        _, gw = e.nll_and_grad(params)
+    gw.pop("U", None)
+    want = np.concatenate([gw[k].ravel() for k in sorted(gw)])
+    for r in range(2):
+        got = np.load(tmp_path / ("tgrad%d.npy" % r))
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() <= 1e-7 * np.abs(want).max()
 
 
 def _random_shapes(n, seed):
