@@ -133,6 +133,8 @@ VARIANTS = {
     # A/B builds (tools/ab.sh) of the round-3 Gram schedule: without the tail split / without combos and tail split (= round 2)
     "notail": ["-DGRAM_TAIL_SPLIT=0"],
     "r2gram": ["-DGRAM_COMBO=0", "-DGRAM_TAIL_SPLIT=0"],
+    # ... and round 3's Gram schedule (three 64 x 32-sub-block combos per four diagonal tiles) against round 4's pair combos
+    "r3gram": ["-DGRAM_COMBO=1"],
     "dftrace_notail": ["-DFFVD_DF_TRACE", "-DGRAM_TAIL_SPLIT=0"],
     # tiny.hip (the one-launch iteration): wall-clock stamps of every workgroup's phases (tools/tiny_trace.py); a build whose
     # unit-0 head never publishes W, so that every bounded wait of that launch must give up (tests/test_gpu_tiny.py)

@@ -185,7 +185,7 @@ int gram_ksplit(int Mp, int nb, int rows);
 size_t gram_part_doubles(int Mp, int nb, int ksplit);
 // phase 0: everything; 1: tile pass only; 2: combine pass only; 3: trace-only combine pass (split-K launches);
 // 4: combine pass (epilogue + trace) over `part` whatever ksplit is (T-shards: the all-reduced raw tiles, ksplit = 1)
-constexpr int GRAM_TAIL_DOUBLES = 34 * 512;       // per thread: 32 accumulator values + two partial sums of the delta^T A row
+constexpr int GRAM_TAIL_DOUBLES = 38 * 512;       // per thread: up to 36 accumulator values (the pair combos' nine tiles) + two partial sums of the delta^T A row
 // workgroups of the last partial round of an unsplit launch over nb units that gram_kernel cuts in two (0 = none), and the
 // scratch a handle needs for them (doubles, counters included)
 int gram_tail_wg(int Mp, int nb, int ksplit, int with_row);

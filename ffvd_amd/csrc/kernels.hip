@@ -1978,6 +1978,9 @@ void launch_linear_lowrank(hipStream_t stream, const ProjectArgs &a, double *par
 // (Measured alternatives at M = 512, T = 4096, 128 units: 4 wavefronts of 64x64 3.45 ms; 16 wavefronts of 32x32,
 //  one workgroup per CU 3.36 ms; 128x64 tiles, 8 wavefronts of 32x32 3.27 ms; this layout 2.98 ms.)
 // ---------------------------------------------------------------------------------------------
+#ifndef GRAM_COMBO
+#define GRAM_COMBO 2                // 0: none, 1: three 64 x 32-sub-block workgroups per four diagonal tiles (round 3), 2: pair combos (round 4)
+#endif
 constexpr int GT = 16;              // rows of A per LDS chunk
 constexpr int G_LD = 128 + 16;      // LDS row stride (doubles): lanes l and l+16 land in different bank halves
 
@@ -1986,8 +1989,9 @@ constexpr int G_LD = 128 + 16;      // LDS row stride (doubles): lanes l and l+1
 __device__ __constant__ unsigned char GRAM_DIAG_WR[8] = {1, 1, 1, 1, 0, 0, 0, 0};
 __device__ __constant__ unsigned char GRAM_DIAG_WC[8] = {0, 1, 2, 3, 0, 1, 2, 3};
 
+template <int N>
 __device__ __forceinline__ bool gram_tail_exchange(const GramArgs &a, const int tail_id, const int half, const bool active,
-                                                   d4 (&acc)[4][2], double &bs0, double &bs1, int *tail_slot);
+                                                   d4 (&acc)[N], double &bs0, double &bs1, int *tail_slot);
 
 template <int MODE, bool DIAG>
 __device__ __forceinline__ void gram_body(const GramArgs a, const int bz, const int ti, const int tj, const int tile,
@@ -2109,7 +2113,7 @@ __device__ __forceinline__ void gram_body(const GramArgs a, const int bz, const 
 
     if (tail_id >= 0) {
         double unused = 0.0;
-        if (!gram_tail_exchange(a, tail_id, kpart, active, acc, bsum, unused, tail_slot)) return;
+        if (!gram_tail_exchange(a, tail_id, kpart, active, reinterpret_cast<d4(&)[8]>(acc), bsum, unused, tail_slot)) return;
     }
     if (ksplit > 1) {            // raw partial sums of this row range; gram_combine finishes the job
         double *Pb = a.part + ((size_t)kpart * a.nb + bz) * ((size_t)(Mp + 1) * Mp);
@@ -2194,23 +2198,23 @@ __device__ __forceinline__ void gram_body(const GramArgs a, const int bz, const 
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
 #error "gram_tail_exchange relies on gfx942/gfx950 store semantics (vmcnt-counted sc1 write-through stores); build for gfx950"
 #endif
+template <int N>
 __device__ __forceinline__ bool gram_tail_exchange(const GramArgs &a, const int tail_id, const int half, const bool active,
-                                                   d4 (&acc)[4][2], double &bs0, double &bs1, int *tail_slot) {
+                                                   d4 (&acc)[N], double &bs0, double &bs1, int *tail_slot) {
+    static_assert((N * 4 + 2) * 512 <= GRAM_TAIL_DOUBLES, "tail block too small");
     typedef __attribute__((address_space(1))) double gdouble;
     const int tid = threadIdx.x;
     gdouble *Pm = (gdouble *)(a.tail_part + ((size_t)tail_id * 2 + half) * GRAM_TAIL_DOUBLES);
     const double *Po = a.tail_part + ((size_t)tail_id * 2 + (half ^ 1)) * GRAM_TAIL_DOUBLES;
     if (active) {
 #pragma unroll
-        for (int x = 0; x < 4; ++x)
+        for (int x = 0; x < N; ++x)
 #pragma unroll
-            for (int y = 0; y < 2; ++y)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    __hip_atomic_store(Pm + (size_t)((x * 2 + y) * 4 + q) * 512 + tid, acc[x][y][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int q = 0; q < 4; ++q)
+                __hip_atomic_store(Pm + (size_t)(x * 4 + q) * 512 + tid, acc[x][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __hip_atomic_store(Pm + (size_t)32 * 512 + tid, bs0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(Pm + (size_t)33 * 512 + tid, bs1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(Pm + (size_t)(4 * N) * 512 + tid, bs0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(Pm + (size_t)(4 * N + 1) * 512 + tid, bs1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wavefront's block has left it
     __syncthreads();
     if (tid == 0) {
@@ -2227,14 +2231,12 @@ __device__ __forceinline__ bool gram_tail_exchange(const GramArgs &a, const int 
     // (a + b is the same number whichever half is `a`: the result does not depend on the order of arrival)
     if (active) {
 #pragma unroll
-        for (int x = 0; x < 4; ++x)
+        for (int x = 0; x < N; ++x)
 #pragma unroll
-            for (int y = 0; y < 2; ++y)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[x][y][q] += Po[(size_t)((x * 2 + y) * 4 + q) * 512 + tid];
+            for (int q = 0; q < 4; ++q) acc[x][q] += Po[(size_t)(x * 4 + q) * 512 + tid];
     }
-    bs0 += Po[(size_t)32 * 512 + tid];
-    bs1 += Po[(size_t)33 * 512 + tid];
+    bs0 += Po[(size_t)(4 * N) * 512 + tid];
+    bs1 += Po[(size_t)(4 * N + 1) * 512 + tid];
     return true;
 }
 
@@ -2333,7 +2335,7 @@ __device__ __forceinline__ void gram_combo_body(const GramArgs a, const int bz, 
         __syncthreads();
     }
     double bs0 = 0.0, bs1 = 0.0;           // (no delta^T A row here: launch_gram gives combos only to launches without one)
-    if (tail_id >= 0 && !gram_tail_exchange(a, tail_id, half, true, acc, bs0, bs1, tail_slot)) return;
+    if (tail_id >= 0 && !gram_tail_exchange(a, tail_id, half, true, reinterpret_cast<d4(&)[8]>(acc), bs0, bs1, tail_slot)) return;
 
     const double scale = (MODE == GRAM_PLAIN) ? 1.0 : a.yn_over_batch / exp(a.log_Q[dg]);
     double *Hb = a.H + (size_t)bz * a.h_stride;
@@ -2384,6 +2386,163 @@ __device__ __forceinline__ void gram_combo_body(const GramArgs a, const int bz, 
     }
 }
 
+
+// "Pair" combos (round 4): 16-granular triangle.  A diagonal 128-tile has 8 x 9 / 2 = 36 MFMA tiles on or below its diagonal; row
+// block i (16 rows) owns i + 1 of them, so the row blocks i and 7 - i together own NINE whatever i -- four wavefronts per diagonal
+// tile, each with nine MFMAs per k-step, and no MFMA tile above the diagonal is executed.  A workgroup takes the diagonal tiles of
+// two neighbouring panels (both staged as before); it lasts 9 / 8 of an off-diagonal tile, and the four panels of M = 512 cost
+// 2 x 1.125 workgroup-times instead of 3: executed flops 1.03 x the triangle's instead of 1.125 x.  Operands: on a diagonal tile
+// the A fragment of row block i IS the B fragment of column block i, so role R reads the 8 - R column fragments 0 .. 7 - R and
+// nothing else (8, 7, 6, 5 fragment reads for 9 MFMAs; the 64 x 32 sub-blocks read 6 for 8).  Earlier attempts at the triangle
+// (1 x 4 row roles with 5 reads per 4 MFMAs, evenly dealt tiles) lost to their read / MFMA ratio.
+// The unwritten above-diagonal MFMA tiles INSIDE the diagonal 64-blocks are mirrored from below in the epilogue (bit for bit what
+// the sub-blocks used to compute there: the same products in the same order), so the buffers look as they always did.
+template <int R>
+__device__ __forceinline__ void gram_pair_ksteps(const double (*Sp)[G_LD], const int lr, const int lk, d4 (&acc)[9]) {
+    // Registers: nine accumulator tiles are 72 of the 128 VGPRs, so the next k-step's fragments cannot have an array of their own
+    // (the 64 x 32 sub-blocks keep 6 + 6): column fragment c is re-loaded into its own register right after its last MFMA of this
+    // step, and only the two row operands -- f[R], f[7 - R], needed by every MFMA of the step -- are held in copies.
+    constexpr int NF = 8 - R;
+    double f[NF];
+#pragma unroll
+    for (int c = 0; c < NF; ++c) f[c] = Sp[lk][16 * c + lr];
+    double aR = f[R], aS = f[7 - R];
+#pragma unroll
+    for (int ks = 0; ks < GT / 4; ++ks) {
+#pragma unroll
+        for (int c = 0; c < NF; ++c) {
+            acc[R + 1 + c] = mfma_f64(aS, f[c], acc[R + 1 + c]);             // row block 7 - R, columns 0 .. 7 - R
+            if (c <= R) acc[c] = mfma_f64(aR, f[c], acc[c]);                 // row block R, columns 0 .. R
+            if (ks + 1 < GT / 4) f[c] = Sp[4 * (ks + 1) + lk][16 * c + lr];
+            __builtin_amdgcn_sched_barrier(0);          // (keep the re-load behind the MFMAs that free its register: hoisted loads need eight more)
+        }
+        if (ks + 1 < GT / 4) { aR = f[R]; aS = f[7 - R]; }
+    }
+}
+
+// (the whole body is instantiated per role: with the role switch inside the chunk loop the nine accumulator tiles crossed a four-way
+//  merge every chunk and the register allocator kept them in scratch)
+template <int MODE, int R>
+__device__ __forceinline__ void gram_pair_role(const GramArgs a, const int bz, const int pa, const int tail_id,
+                                               const int half, double (*As)[GT][G_LD], double (*Bs)[GT][G_LD],
+                                               double *red, int *tail_slot) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lk = lane >> 4;
+    const int Mp = a.Mp;
+    const int b = a.b0 + bz, dl = b % a.Dl, dg = a.d_begin + dl;
+    const int pb = pa + 1;                                               // the two panels this workgroup stages
+    const int rbuf = wave >> 2;                                          // wavefronts w and w + 4 share a SIMD: the same role R = w & 3 on both panels
+    const int P0 = (rbuf ? pb : pa) * 128;
+
+    const double *Ab = a.A + (size_t)bz * a.a_stride;
+    const int rowl = tid >> 6;   // 0..7
+    // Staging: LDS-DMA (global_load_lds_dwordx4: one wavefront-instruction = one 1 KiB row of a panel, lane l -> bytes 16 l of the
+    // row), no staging registers -- nine accumulator tiles + eight fragments leave no room for the sixteen the register-staged
+    // bodies hold across the MFMA phase.  Uniform 64-bit bases per chunk (SGPRs) + ONE 32-bit byte offset per thread.  Written as asm: hipcc waits vmcnt(0) in front of the first ds_read that follows a DMA it
+    // knows about (it cannot tell the two buffers apart), i.e. before the MFMA phase the DMA is meant to run behind; the loads
+    // it does not count are waited for by hand in front of the barrier.
+    const unsigned voff = (unsigned)((rowl * Mp + pa * 128 + 2 * lane) * (int)sizeof(double));
+    typedef __attribute__((address_space(3))) void lvoid;
+    auto glds = [&](const double *base, const void *lds_row) {
+        const unsigned dst = (unsigned)(uintptr_t)(lvoid *)lds_row;
+        unsigned keep;
+        // (no immediate offset: the instruction adds it to the LDS address as well as to the global one)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(dst), "s"(base) : "memory");
+    };
+    auto gload = [&](int c, int buf) {
+        const double *base0 = Ab + (size_t)c * GT * Mp, *base1 = base0 + (size_t)8 * Mp;
+        glds(base0, &As[buf][wave][0]);
+        glds(base0 + 128, &Bs[buf][wave][0]);
+        glds(base1, &As[buf][wave + 8][0]);
+        glds(base1 + 128, &Bs[buf][wave + 8][0]);
+    };
+
+    d4 acc[9];
+#pragma unroll
+    for (int x = 0; x < 9; ++x) acc[x] = (d4){0.0, 0.0, 0.0, 0.0};
+    const int nchunk_all = a.rows / GT;
+    const int nrange = (tail_id >= 0) ? 2 : 1;
+    const int per = (nchunk_all + nrange - 1) / nrange;
+    const int cbeg = half * per;
+    const int nchunk = (cbeg + per <= nchunk_all) ? cbeg + per : nchunk_all;
+    gload(cbeg, cbeg & 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int c = cbeg; c < nchunk; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunk) gload(c + 1, buf ^ 1);                       // the buffer nobody reads until the barrier below
+        {
+            const double(*Sp)[G_LD] = rbuf ? Bs[buf] : As[buf];          // this wavefront's panel holds both of its operands
+            gram_pair_ksteps<R>(Sp, lr, lk, acc);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the next chunk has landed (the DMAs are invisible to hipcc's counting)
+        __syncthreads();
+    }
+    double bs0 = 0.0, bs1 = 0.0;           // (no delta^T A row here: launch_gram gives combos only to launches without one)
+    if (tail_id >= 0 && !gram_tail_exchange(a, tail_id, half, true, acc, bs0, bs1, tail_slot)) return;
+
+    const double scale = (MODE == GRAM_PLAIN) ? 1.0 : a.yn_over_batch / exp(a.log_Q[dg]);
+    double *Hb = a.H + (size_t)bz * a.h_stride;
+    const double *Kadd = (MODE == GRAM_KFU || MODE == GRAM_KFU_RAW) ? a.Kadd + (size_t)dl * a.kadd_stride : nullptr;
+    const double *Kinv = (MODE == GRAM_KFU) ? a.Kinv + (size_t)dl * a.kinv_stride : nullptr;
+    double *Rb = (MODE == GRAM_KFU_RAW) ? a.part + (size_t)bz * ((size_t)(Mp + 1) * Mp) : nullptr;
+    double *Cb2 = ((MODE == GRAM_KFU_RAW || MODE == GRAM_KFU) && a.Hcopy) ? a.Hcopy + (size_t)bz * a.hcopy_stride : nullptr;
+    double trp = 0.0;
+#pragma unroll
+    for (int x = 0; x < 9; ++x) {
+        const int rb = (x <= R) ? R : 7 - R, cb = (x <= R) ? x : x - R - 1;        // (accumulator x: row block, column block)
+        const bool mirror = cb < rb && (rb >> 2) == (cb >> 2);                     // below the diagonal of a diagonal 64-block
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = P0 + 16 * rb + lk + 4 * q, j = P0 + 16 * cb + lr;
+            const double g = acc[x][q];
+            double v;
+            if (MODE == GRAM_F) v = g * scale + ((i == j) ? 1.0 : 0.0);
+            else if (MODE == GRAM_KFU_RAW || MODE == GRAM_KFU) {
+                v = g * scale + Kadd[(size_t)i * Mp + j];
+                if (MODE == GRAM_KFU_RAW) Rb[(size_t)i * Mp + j] = g;
+                if (Cb2 && j <= i) {                    // the copy is made fully symmetric here (lower triangle + mirror)
+                    Cb2[(size_t)i * Mp + j] = v;
+                    if (j < i) Cb2[(size_t)j * Mp + i] = v;
+                }
+                if (MODE == GRAM_KFU) {
+                    const double w = (i > j) ? 2.0 : ((i == j) ? 1.0 : 0.0);
+                    trp += w * (Kinv[(size_t)i * Mp + j] * g);
+                }
+            } else v = g;
+            Hb[(size_t)i * Mp + j] = v;
+            if (mirror) {
+                if (MODE == GRAM_KFU_RAW) Rb[(size_t)j * Mp + i] = g;
+                Hb[(size_t)j * Mp + i] = (MODE == GRAM_KFU_RAW || MODE == GRAM_KFU) ? g * scale + Kadd[(size_t)j * Mp + i] : v;
+            }
+        }
+    }
+    if (MODE == GRAM_KFU) {      // deterministic workgroup reduction of the trace partial; slot of the first panel's diagonal tile
+        red[tid] = trp;
+        __syncthreads();
+        for (int st = 256; st > 0; st >>= 1) {
+            if (tid < st) red[tid] += red[tid + st];
+            __syncthreads();
+        }
+        if (tid == 0) {
+            a.trpart[(size_t)b * a.ntiles + pa * (pa + 1) / 2 + pa] = red[0];
+            a.trpart[(size_t)b * a.ntiles + pb * (pb + 1) / 2 + pb] = 0.0;          // (one workgroup, two slots)
+        }
+    }
+}
+template <int MODE>
+__device__ __forceinline__ void gram_pair_body(const GramArgs a, const int bz, const int pa, const int tail_id,
+                                               const int half, double (*As)[GT][G_LD], double (*Bs)[GT][G_LD],
+                                               double *red, int *tail_slot) {
+    const int R = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) & 3;
+    if (R == 0) gram_pair_role<MODE, 0>(a, bz, pa, tail_id, half, As, Bs, red, tail_slot);
+    else if (R == 1) gram_pair_role<MODE, 1>(a, bz, pa, tail_id, half, As, Bs, red, tail_slot);
+    else if (R == 2) gram_pair_role<MODE, 2>(a, bz, pa, tail_id, half, As, Bs, red, tail_slot);
+    else gram_pair_role<MODE, 3>(a, bz, pa, tail_id, half, As, Bs, red, tail_slot);
+}
+
 template <int MODE>
 __global__ __launch_bounds__(512, 4) void gram_kernel(GramArgs a) {
     __shared__ double As[2][GT][G_LD];
@@ -2409,16 +2568,23 @@ __global__ __launch_bounds__(512, 4) void gram_kernel(GramArgs a) {
             loc = lfull + q % ntl;
         }
     }
-    const int bz = (loc / per_unit) * 8 + xcd;
+    // (pair combos last 9 / 8 of an off-diagonal tile; dealing them FIRST in the launch, one per CU while the chip fills, changed
+    //  nothing against this unit-major order: 3.12 vs 3.12 ms, profiles/r04_ab_gram_pair.txt)
+    const int unit_l = loc / per_unit, wsel = loc % per_unit;
+    const int bz = unit_l * 8 + xcd;
     if (bz >= a.nb) return;
     int tile, kpart;
     if (a.combo) {
-        const int n128 = a.Mp / 128, noff = n128 * (n128 - 1) / 2, w = loc % per_unit;
-        if (w >= noff) {                                 // one of the three combo workgroups of panel group (w - noff) / 3
+        const int n128 = a.Mp / 128, noff = n128 * (n128 - 1) / 2, w = wsel;
+        if (w >= noff) {                                 // a combo workgroup: pair combos take two panels, the older ones three per group of four
 #ifdef FFVD_DF_TRACE
             const long long tc0 = wall_clock64();
 #endif
+#if GRAM_COMBO == 2
+            gram_pair_body<MODE>(a, bz, 2 * (w - noff), tail_id, tail_half, As, Bs, red, &tail_slot);
+#else
             gram_combo_body<MODE>(a, bz, 4 * ((w - noff) / 3), (w - noff) % 3, tail_id, tail_half, As, Bs, red, &tail_slot);
+#endif
 #ifdef FFVD_DF_TRACE
             if (threadIdx.x == 0 && bz < 128 && per_unit <= 10 && MODE == GRAM_KFU) {
                 long long *g = gram_trace_buf + (size_t)(bz * 10 + w) * 4;
@@ -2449,7 +2615,7 @@ __global__ __launch_bounds__(512, 4) void gram_kernel(GramArgs a) {
         df_trace_buf[2048 + (bz * 10 + tile) * 2 + 1] = wall_clock64();
     }
     if (threadIdx.x == 0 && bz < 128 && ksplit == 1 && a.ntiles <= 10 && MODE == GRAM_KFU) {     // every workgroup of the launch (tools/gram_rounds.py)
-        long long *g = gram_trace_buf + (size_t)(bz * 10 + (a.combo ? loc % per_unit : tile)) * 4;   // (a tail workgroup: the half that ends last)
+        long long *g = gram_trace_buf + (size_t)(bz * 10 + (a.combo ? wsel : tile)) * 4;   // (a tail workgroup: the half that ends last)
         g[0] = tw0; g[1] = wall_clock64(); g[2] = (ti == tj) ? 1 : 0; g[3] = (long long)blockIdx.x;
     }
 #endif
@@ -2556,18 +2722,17 @@ size_t gram_part_doubles(int Mp, int nb, int ksplit) {
     return ksplit > 1 ? (size_t)ksplit * nb * (size_t)(Mp + 1) * Mp : 0;
 }
 
-#ifndef GRAM_COMBO
-#define GRAM_COMBO 1
-#endif
 #ifndef GRAM_TAIL_SPLIT
 #define GRAM_TAIL_SPLIT 1
 #endif
 // workgroups per unit of an unsplit launch: with Mp a multiple of 512 the diagonal tiles of every four panels become three combos
 // (and only when the kernel has no delta^T A row to form: the combos have no idle wavefront for it)
-static bool gram_uses_combos(int Mp, int ksplit, int with_row) { return GRAM_COMBO && ksplit <= 1 && Mp % 512 == 0 && !with_row; }
+static bool gram_uses_combos(int Mp, int ksplit, int with_row) {
+    return GRAM_COMBO && ksplit <= 1 && Mp % (GRAM_COMBO == 2 ? 256 : 512) == 0 && !with_row;
+}
 static int gram_wg_per_unit(int Mp, int ksplit, int with_row) {
     const int n128 = (Mp / NB + 1) / 2;
-    if (gram_uses_combos(Mp, ksplit, with_row)) return n128 * (n128 - 1) / 2 + 3 * (n128 / 4);
+    if (gram_uses_combos(Mp, ksplit, with_row)) return n128 * (n128 - 1) / 2 + (GRAM_COMBO == 2 ? n128 / 2 : 3 * (n128 / 4));
     return gram_ntiles(Mp) * (ksplit > 1 ? ksplit : 1);
 }
 // Which workgroups of an unsplit launch are cut in two row halves: those of the last, partial round, when their halves still fit

@@ -887,6 +887,42 @@ def test_two_processes_time_shard(tmp_path, monkeypatch):
         assert np.abs(got - want).max() <= 1e-7 * np.abs(want).max()
 
 
+@pytest.mark.parametrize("ov,env", [(dict(M=256, T=320, S=3, D=2), {"FFVD_GSPLIT": "1"}),       # one off-diagonal tile + one pair combo per unit
+                                    (dict(M=768, T=832, S=1, D=2), {"FFVD_GSPLIT": "1"}),       # 15 + 3
+                                    (dict(M=512, T=576, S=34, D=4), {})])                       # 1088 workgroups: 64 of them cut in row halves
+def test_gram_pair_combos_other_shapes(ov, env, monkeypatch):
+    """The 16-granular diagonal workgroups of the Gram kernel (two diagonal 128-tiles per workgroup, nine MFMA tiles per wavefront,
+    LDS-DMA staging) away from config 2: other panel counts, and a launch whose last workgroups -- pair combos among them -- run as
+    two row halves that meet through memory.  Gram route against the reference op order (which has no such kernel) and the oracle."""
+    params, Y, c, meta = synthetic.make_named("c2", **ov)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setenv("FFVD_NO_TINY", "1")
+    S = meta["S"]
+    with ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], S, route="gram") as e:
+        e.set_data(Y, c)
+        tg = e.nll_terms(params)
+        assert e.nll_terms(params)["nll"] == tg["nll"]
+    with ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], S) as e:
+        e.set_data(Y, c)
+        tr = e.nll_terms(params)
+    # (T = 576 leaves the nll of a chain at 0.04-0.11, the remainder of terms of order 1: the absolute floor is that of the terms)
+    np.testing.assert_allclose(tg["nll_per_chain"], tr["nll_per_chain"], rtol=1e-8, atol=2e-9)
+    p0 = dict(params, X=params["X"][S - 1])
+    ref = orc.nll_terms(p0, Y, c, U_collapse=True)
+    assert tg["nll_per_chain"][S - 1] == pytest.approx(ref["nll"], rel=1e-8, abs=2e-9)
+    if S >= 34:          # training forward + backward on the same launch shape: the Gram kernel also writes the symmetric copy of A
+        with ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], S, route="gram", grad=True) as e:
+            e.set_data(Y, c)
+            t1, g1 = e.nll_and_grad(params)
+        with ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], S, grad=True) as e:
+            e.set_data(Y, c)
+            t2, g2 = e.nll_and_grad(params)
+        assert t1["nll"] == pytest.approx(t2["nll"], rel=1e-8, abs=2e-9)
+        for n in ("Z", "loglengthscales", "log_Q"):
+            assert np.abs(g1[n] - g2[n]).max() <= 1e-6 * np.abs(g2[n]).max(), n
+
+
 def _random_shapes(n, seed):
     rng = np.random.default_rng(seed)
     out = []
