@@ -395,9 +395,9 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
     }
     if (c.branch == FFVD_BRANCH_B && c.dtype != FFVD_F32C) {
         const int upass = h->cpp * (int)Dl;
-        h->gsplit = gram_ksplit((int)Mp, upass, (int)Tp);
         // the K_fu build forms delta^T K_fu (Gram route) / the projection GEMM forms delta^T F (reference route): the Gram kernel has no row
         const bool ext_row = (c.route == FFVD_ROUTE_GRAM && c.T_total == 0) || (c.route == FFVD_ROUTE_REFERENCE && h->ngr > 0 && !h->sw.ref_row_in_gram);
+        h->gsplit = gram_ksplit((int)Mp, upass, (int)Tp, ext_row ? 0 : 1);
         if (ext_row) HIP_TRY(dev_alloc(h, &h->growpart, (size_t)upass * (Tp / 64) * Mp));
         h->gtail_wg = gram_tail_wg((int)Mp, upass, h->gsplit, ext_row ? 0 : 1);
         if (h->gtail_wg > 0) {

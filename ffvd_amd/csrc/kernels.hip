@@ -2424,8 +2424,8 @@ __device__ __forceinline__ void gram_pair_ksteps(const double (*Sp)[G_LD], const
 //  merge every chunk and the register allocator kept them in scratch)
 template <int MODE, int R>
 __device__ __forceinline__ void gram_pair_role(const GramArgs a, const int bz, const int pa, const int tail_id,
-                                               const int half, double (*As)[GT][G_LD], double (*Bs)[GT][G_LD],
-                                               double *red, int *tail_slot) {
+                                               const int half /* row range: tail half or split-K part */, const int ksplit,
+                                               double (*As)[GT][G_LD], double (*Bs)[GT][G_LD], double *red, int *tail_slot) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lk = lane >> 4;
@@ -2463,7 +2463,7 @@ __device__ __forceinline__ void gram_pair_role(const GramArgs a, const int bz, c
 #pragma unroll
     for (int x = 0; x < 9; ++x) acc[x] = (d4){0.0, 0.0, 0.0, 0.0};
     const int nchunk_all = a.rows / GT;
-    const int nrange = (tail_id >= 0) ? 2 : 1;
+    const int nrange = (tail_id >= 0) ? 2 : ksplit;
     const int per = (nchunk_all + nrange - 1) / nrange;
     const int cbeg = half * per;
     const int nchunk = (cbeg + per <= nchunk_all) ? cbeg + per : nchunk_all;
@@ -2482,6 +2482,22 @@ __device__ __forceinline__ void gram_pair_role(const GramArgs a, const int bz, c
     }
     double bs0 = 0.0, bs1 = 0.0;           // (no delta^T A row here: launch_gram gives combos only to launches without one)
     if (tail_id >= 0 && !gram_tail_exchange(a, tail_id, half, true, acc, bs0, bs1, tail_slot)) return;
+    if (ksplit > 1) {            // raw partial sums of this row range; gram_combine finishes the job (it reads whole 64 x 32 sub-blocks:
+                                 // the tiles above the diagonal inside the diagonal 64-blocks are mirrored here as well)
+        double *Pb = a.part + ((size_t)half * a.nb + bz) * ((size_t)(Mp + 1) * Mp);
+#pragma unroll
+        for (int x = 0; x < 9; ++x) {
+            const int rb = (x <= R) ? R : 7 - R, cb = (x <= R) ? x : x - R - 1;
+            const bool mirror = cb < rb && (rb >> 2) == (cb >> 2);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = P0 + 16 * rb + lk + 4 * q, j = P0 + 16 * cb + lr;
+                Pb[(size_t)i * Mp + j] = acc[x][q];
+                if (mirror) Pb[(size_t)j * Mp + i] = acc[x][q];
+            }
+        }
+        return;
+    }
 
     const double scale = (MODE == GRAM_PLAIN) ? 1.0 : a.yn_over_batch / exp(a.log_Q[dg]);
     double *Hb = a.H + (size_t)bz * a.h_stride;
@@ -2534,13 +2550,13 @@ __device__ __forceinline__ void gram_pair_role(const GramArgs a, const int bz, c
 }
 template <int MODE>
 __device__ __forceinline__ void gram_pair_body(const GramArgs a, const int bz, const int pa, const int tail_id,
-                                               const int half, double (*As)[GT][G_LD], double (*Bs)[GT][G_LD],
+                                               const int half, const int ksplit, double (*As)[GT][G_LD], double (*Bs)[GT][G_LD],
                                                double *red, int *tail_slot) {
     const int R = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) & 3;
-    if (R == 0) gram_pair_role<MODE, 0>(a, bz, pa, tail_id, half, As, Bs, red, tail_slot);
-    else if (R == 1) gram_pair_role<MODE, 1>(a, bz, pa, tail_id, half, As, Bs, red, tail_slot);
-    else if (R == 2) gram_pair_role<MODE, 2>(a, bz, pa, tail_id, half, As, Bs, red, tail_slot);
-    else gram_pair_role<MODE, 3>(a, bz, pa, tail_id, half, As, Bs, red, tail_slot);
+    if (R == 0) gram_pair_role<MODE, 0>(a, bz, pa, tail_id, half, ksplit, As, Bs, red, tail_slot);
+    else if (R == 1) gram_pair_role<MODE, 1>(a, bz, pa, tail_id, half, ksplit, As, Bs, red, tail_slot);
+    else if (R == 2) gram_pair_role<MODE, 2>(a, bz, pa, tail_id, half, ksplit, As, Bs, red, tail_slot);
+    else gram_pair_role<MODE, 3>(a, bz, pa, tail_id, half, ksplit, As, Bs, red, tail_slot);
 }
 
 template <int MODE>
@@ -2575,13 +2591,14 @@ __global__ __launch_bounds__(512, 4) void gram_kernel(GramArgs a) {
     if (bz >= a.nb) return;
     int tile, kpart;
     if (a.combo) {
-        const int n128 = a.Mp / 128, noff = n128 * (n128 - 1) / 2, w = wsel;
+        const int n128 = a.Mp / 128, noff = n128 * (n128 - 1) / 2, w = wsel / ksplit;      // (split-K: the row ranges of a workgroup are neighbours in the list)
+        const int cpart = (tail_id >= 0) ? tail_half : wsel % ksplit;
         if (w >= noff) {                                 // a combo workgroup: pair combos take two panels, the older ones three per group of four
 #ifdef FFVD_DF_TRACE
             const long long tc0 = wall_clock64();
 #endif
 #if GRAM_COMBO == 2
-            gram_pair_body<MODE>(a, bz, 2 * (w - noff), tail_id, tail_half, As, Bs, red, &tail_slot);
+            gram_pair_body<MODE>(a, bz, 2 * (w - noff), tail_id, cpart, ksplit, As, Bs, red, &tail_slot);
 #else
             gram_combo_body<MODE>(a, bz, 4 * ((w - noff) / 3), (w - noff) % 3, tail_id, tail_half, As, Bs, red, &tail_slot);
 #endif
@@ -2596,7 +2613,7 @@ __global__ __launch_bounds__(512, 4) void gram_kernel(GramArgs a) {
         int ti = 1;                                      // off-diagonal tile w = ti (ti - 1) / 2 + tj,  tj < ti
         while (ti * (ti + 1) / 2 <= w) ++ti;
         tile = ti * (ti + 1) / 2 + (w - ti * (ti - 1) / 2);
-        kpart = tail_half;
+        kpart = cpart;
     } else {
         tile = (loc % per_unit) / ksplit;
         kpart = (tail_id >= 0) ? tail_half : loc % ksplit;
@@ -2703,18 +2720,31 @@ int gram_ntiles(int Mp) {
     return n128 * (n128 + 1) / 2;
 }
 
+static bool gram_uses_combos(int Mp, int ksplit, int with_row);
+static int gram_wg_per_unit(int Mp, int ksplit, int with_row);
 // Few tiles cannot fill the 512 workgroup slots (256 CUs x 2), and 1-2 tiles per slot balance badly (640 tiles take
 // 1.56 x the time of 512).  Measured at M = 512, T = 4096: 160 tiles 0.60 ms unsplit / 0.48 ms in 3 row ranges (one
 // full round) / 0.55-0.62 ms in 2, 4, 6, 8; 320 tiles 1.10 -> 0.86 ms in 3-4 ranges; 640 tiles 1.67 -> 1.52 ms in 2.
-int gram_ksplit(int Mp, int nb, int rows) {
-    const int n = nb * gram_ntiles(Mp);
+int gram_ksplit(int Mp, int nb, int rows, int with_row) {
     if (const char *e = getenv("FFVD_GSPLIT")) return atoi(e) > 0 ? atoi(e) : 1;       // tuning override
+    const int nchunk = rows / GT;
+    if (gram_uses_combos(Mp, 1, with_row) && GRAM_COMBO == 2) {
+        // pair combos: 8 workgroups per unit at M = 512.  Measured per-rank iteration times at config 2's shape, 1 .. 24 chains and
+        // 1, 2, 3, 4, 6, 8 row ranges (tools/gram_split_sweep.sh, profiles/r04_gram_split.txt): three ranges are the best or within
+        // 1 % of it everywhere (few units: 0.55 ms against 0.63 in 2, 4 or 8) -- except when the unsplit launch is exactly whole
+        // rounds of the chip's 512 slots (16 chains: 1.97 unsplit, 2.00 in three)
+        const int n = nb * gram_wg_per_unit(Mp, 1, with_row);
+        if (n <= 0 || n >= 1024 || n % 512 == 0) return 1;
+        int ks = 3;
+        while (ks > 1 && nchunk / ks < 8) --ks;
+        return ks;
+    }
+    const int n = nb * gram_ntiles(Mp);
     if (n <= 0 || n >= 1024) return 1;
     // one full round; three row ranges up to 640 tiles (re-measured with the 1024-thread combine pass: 160 tiles 1.05 ms per
     // iteration in 3 ranges / 1.08-1.09 in 2, 4; 320 tiles 1.49 in 3 / 1.53 in 2 / 1.58 in 4; 640 tiles 2.46 in 3 / 2.53 in 2)
     int ks = (n <= 256) ? 512 / n : ((n <= 704) ? 3 : (1280 + n / 2) / n);
     if (ks > 8) ks = 8;
-    const int nchunk = rows / GT;
     while (ks > 1 && nchunk / ks < 8) --ks;          // keep at least 128 rows per range
     return ks;
 }
@@ -2728,11 +2758,13 @@ size_t gram_part_doubles(int Mp, int nb, int ksplit) {
 // workgroups per unit of an unsplit launch: with Mp a multiple of 512 the diagonal tiles of every four panels become three combos
 // (and only when the kernel has no delta^T A row to form: the combos have no idle wavefront for it)
 static bool gram_uses_combos(int Mp, int ksplit, int with_row) {
-    return GRAM_COMBO && ksplit <= 1 && Mp % (GRAM_COMBO == 2 ? 256 : 512) == 0 && !with_row;
+    if (GRAM_COMBO == 2) return Mp % 256 == 0 && !with_row;          // pair combos: also the diagonal workgroups of a split-K launch
+    return GRAM_COMBO && ksplit <= 1 && Mp % 512 == 0 && !with_row;
 }
 static int gram_wg_per_unit(int Mp, int ksplit, int with_row) {
     const int n128 = (Mp / NB + 1) / 2;
-    if (gram_uses_combos(Mp, ksplit, with_row)) return n128 * (n128 - 1) / 2 + (GRAM_COMBO == 2 ? n128 / 2 : 3 * (n128 / 4));
+    if (gram_uses_combos(Mp, ksplit, with_row))
+        return (n128 * (n128 - 1) / 2 + (GRAM_COMBO == 2 ? n128 / 2 : 3 * (n128 / 4))) * (ksplit > 1 ? ksplit : 1);
     return gram_ntiles(Mp) * (ksplit > 1 ? ksplit : 1);
 }
 // Which workgroups of an unsplit launch are cut in two row halves: those of the last, partial round, when their halves still fit

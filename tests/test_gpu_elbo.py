@@ -1259,8 +1259,8 @@ def _schedule_case(case):
     if case == "c2_rank4":
         params, Y, c, meta = synthetic.make_named("c2", S=4)
         return params, Y, c, meta, dict(route="gram"), "split-K one pass"
-    if case == "c2_16":           # (24 chains = 96 units = 960 tiles: unsplit, below the 128 units of the full-batch schedule)
-        params, Y, c, meta = synthetic.make_named("c2", S=24)
+    if case == "c2_16":           # (16 chains = 64 units = 512 workgroups, one whole round: unsplit, below the 128 units of the full-batch schedule)
+        params, Y, c, meta = synthetic.make_named("c2", S=16)
         return params, Y, c, meta, dict(route="gram"), "unsplit with raw tiles"
     if case == "c2_reference":
         params, Y, c, meta = synthetic.make_named("c2", S=8)
