@@ -166,10 +166,12 @@ struct GramArgs {
     // combine pass only: 0 = epilogue + trace partials, 1 = epilogue without the trace (K^-1 not read), 2 = trace partials
     // only (H not written) -- lets the combine run before K^-1 exists and the trace follow on another stream
     int trace_mode;
-    // Round 3, unsplit launches with Mp a multiple of 512: (1) the four diagonal tiles of every group of four column panels are
-    // dealt to THREE workgroups of eight full 64 x 32 sub-blocks each ("combos", gram_combo_body) instead of four workgroups
-    // that each leave two wavefronts without matrix work -- wg_per_unit = workgroups per unit (filled by launch_gram);
-    // (2) the workgroups of the LAST, partial round of the launch are cut into two row halves that run side by side on the
+    // Launches without a delta^T A row, Mp a multiple of 256: (1) the diagonal tiles of every two neighbouring column panels are
+    // ONE workgroup ("pair combo", gram_pair_role, round 4: row blocks i and 7 - i of a diagonal tile on one wavefront, nine MFMA
+    // tiles, nothing above the diagonal executed; also the diagonal workgroups of split-K launches).  Round 3's form -- three
+    // workgroups of eight 64 x 32 sub-blocks per four diagonal tiles, gram_combo_body -- is kept behind GRAM_COMBO=1 for A/B
+    // builds.  wg_per_unit = workgroups per unit (filled by launch_gram);
+    // (2) unsplit launches: the workgroups of the LAST, partial round of the launch are cut into two row halves that run side by side on the
     // CUs that free up first; the half that finishes second adds the other's accumulators (two addends: the sum does not
     // depend on which one that is) and runs the epilogue.  tail_wg = workgroups cut (multiple of 8, 0 = off), tail_part =
     // [tail_wg][2] blocks of GRAM_TAIL_DOUBLES followed by [tail_wg] arrival counters (zero between launches: the second
