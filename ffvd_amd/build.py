@@ -135,6 +135,8 @@ VARIANTS = {
     "r2gram": ["-DGRAM_COMBO=0", "-DGRAM_TAIL_SPLIT=0"],
     # ... and round 3's Gram schedule (three 64 x 32-sub-block combos per four diagonal tiles) against round 4's pair combos
     "r3gram": ["-DGRAM_COMBO=1"],
+    # the 64-pivot diagonal factor of the dataflow Cholesky by wavefront 0 alone (round 3) against all four wavefronts (round 4)
+    "factor1w": ["-DDF_FACTOR_4W=0"],
     "dftrace_notail": ["-DFFVD_DF_TRACE", "-DGRAM_TAIL_SPLIT=0"],
     # tiny.hip (the one-launch iteration): wall-clock stamps of every workgroup's phases (tools/tiny_trace.py); a build whose
     # unit-0 head never publishes W, so that every bounded wait of that launch must give up (tests/test_gpu_tiny.py)

@@ -338,6 +338,9 @@ __device__ long long gram_trace_buf[128 * 10 * 4];      // start, end, HW_ID, bl
 // PIPE = false drops the software pipeline (plain left-looking sums, the newest term by v_readlane): about 100
 // VGPRs fewer, for launches whose many workgroups care about occupancy more than about one tile's latency.
 constexpr int LR_LD = NB + 2;
+#ifndef DF_FACTOR_4W
+#define DF_FACTOR_4W 1            // the 64-pivot diagonal factor by all four wavefronts (chol64_mfma_4w); 0: wavefront 0 alone (A/B builds)
+#endif
 constexpr int DV_LD = 17;       // row stride of the 16 x 16 inverse / scratch tiles (doubles)
 template <bool PIPE>
 __device__ __forceinline__ int chol64_1w(double (&a)[NB], double (*Lr)[LR_LD], double *invd, const int lane) {
@@ -484,6 +487,101 @@ __device__ __forceinline__ int chol64_mfma_1w(double (*Ts)[NB + 1], double (*Lr)
     return bad;
 }
 
+// The same factor by the FOUR wavefronts of the workgroup (round 4): wavefront 0 keeps the critical path -- tile (s+1, s), the sums
+// of diagonal tile s + 1 and its 16-pivot chain -- and the tiles (s+2, s), (s+3, s) of column step s, which chol64_mfma_1w solved
+// behind every chain, go to wavefronts 1 and 2 beside it (tiny_chol_inv's schedule on the 4 x 4 tiles of a 64-block): 15.5 -> about
+// 11.5 us per diagonal block, i.e. per block column of every factorisation's latency chain.  Sc: three 16 x DV_LD scratch tiles
+// (S; L_ss^-T of the even and of the odd steps: the helpers of step s read it while wavefront 0 writes the next one).
+// All 256 threads call; returns wavefront 0's verdict on every thread of wavefront 0 (others: 0).
+__device__ __forceinline__ void chol64_tile_solve(double (*Ts)[NB + 1], double (*Lr)[LR_LD], const double (*X)[DV_LD], const int s,
+                                                  const int i, const int lr, const int lk) {
+    const int s0 = 16 * s, i0 = 16 * i;
+    d4 ac2 = (d4){0.0, 0.0, 0.0, 0.0};
+    for (int k = 0; k < s; ++k)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            ac2 = mfma_f64(Lr[s0 + lr][16 * k + 4 * t + lk], Lr[i0 + lr][16 * k + 4 * t + lk], ac2);
+    d4 Rt;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Rt[r] = Ts[i0 + lr][s0 + lk + 4 * r] - ac2[r];      // (T')^T[m][n] = T'[n][m]
+    d4 x = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) x = mfma_f64(X[lk + 4 * t][lr], Rt[t], x);           // A = L_ss^-1[m][kk] = X[kk][m]
+    d4 res = Rt;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) res = mfma_f64(-Lr[s0 + lr][s0 + 4 * t + lk], x[t], res);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) x = mfma_f64(X[lk + 4 * t][lr], res[t], x);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Lr[i0 + lr][s0 + lk + 4 * r] = x[r];                // L_is[n][m]
+}
+// sums + 16-pivot chain of diagonal tile s (one wavefront): L_ss into Lr, L_ss^-T into Xo and (transposed) into dinv_b
+__device__ __forceinline__ int chol64_diag_tile(double (*Ts)[NB + 1], double (*Lr)[LR_LD], double (*Sw)[DV_LD], double (*Xo)[DV_LD],
+                                                double *dinv_b, const int s, const int lane) {
+    const int lr = lane & 15, lk = lane >> 4, s0 = 16 * s;
+    d4 acc = (d4){0.0, 0.0, 0.0, 0.0}, acc1 = acc;
+    for (int k = 0; k < s; ++k)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const double v = Lr[s0 + lr][16 * k + 4 * t + lk];
+            if (t & 1) acc1 = mfma_f64(v, v, acc1);
+            else acc = mfma_f64(v, v, acc);
+        }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Sw[lk + 4 * r][lr] = Ts[s0 + lk + 4 * r][s0 + lr] - (acc[r] + acc1[r]);
+    wave_lds_order();
+    int bad = 0;
+    double a[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) a[c] = (lane < 16) ? Sw[lr][c] : ((lane < 32 && lr == c) ? 1.0 : 0.0);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const double ajj = readlane_f64(a[j], j);
+        if (!(ajj > 0.0) && bad == 0) bad = s0 + j + 1;
+        double piv, y;
+        pivot_sqrt(ajj, piv, y);
+        a[j] *= y;
+#pragma unroll
+        for (int c = j + 1; c < 16; ++c) a[c] = fma(-a[j], readlane_f64(a[j], c), a[c]);
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) Lr[s0 + lr][s0 + c] = (c <= lr) ? a[c] : 0.0;
+    } else if (lane < 32) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            Xo[lr][c] = a[c];                                       // X = L_ss^-T
+            dinv_b[(s0 + c) * 16 + lr] = a[c];                      // (L_ss^-1)[c][lr] = X[lr][c]
+        }
+    }
+    return bad;
+}
+__device__ __forceinline__ int chol64_mfma_4w(double (*Ts)[NB + 1], double (*Lr)[LR_LD], double (*Sc)[16][DV_LD], double *dinv_b) {
+    const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    int bad = 0;
+    if (wave == 0) {
+        __builtin_amdgcn_s_setprio(3);
+        bad = chol64_diag_tile(Ts, Lr, Sc[0], Sc[1], dinv_b, 0, lane);
+        __builtin_amdgcn_s_setprio(0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const double (*X)[DV_LD] = Sc[1 + (s & 1)];
+        if (wave == 0) {
+            __builtin_amdgcn_s_setprio(3);
+            chol64_tile_solve(Ts, Lr, X, s, s + 1, lr, lk);
+            wave_lds_order();
+            const int b2 = chol64_diag_tile(Ts, Lr, Sc[0], Sc[1 + ((s + 1) & 1)], dinv_b, s + 1, lane);
+            if (b2 && !bad) bad = b2;
+            __builtin_amdgcn_s_setprio(0);
+        } else if (s + 1 + wave < 4) chol64_tile_solve(Ts, Lr, X, s, s + 1 + wave, lr, lk);
+        __syncthreads();
+    }
+    return bad;
+}
+
 // Factorise the diagonal block held in LDS tile `Ts` (row-major, stride NB+1): wavefront 0 runs chol64_1w, which
 // leaves L in the LDS tile `Lr`; then all 256 threads publish L in place (lower triangle of the global block) and
 // the four wavefronts invert the four 16x16 diagonal sub-blocks of L (lane = column, 16-step forward substitution)
@@ -496,6 +594,12 @@ __device__ __forceinline__ void diag_block_finish(double (*Ts)[NB + 1], double (
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (Sc) {
+#if DF_FACTOR_4W
+        {
+            const int bad = chol64_mfma_4w(Ts, Lr, Sc, dinv_b);      // (ends with the workgroup synchronised)
+            if (w == 0 && bad && lane == 0 && *info_b == 0) *info_b = k0 + bad;
+        }
+#else
         if (w == 0) {
             __builtin_amdgcn_s_setprio(3);
             const int bad = chol64_mfma_1w(Ts, Lr, Sc, dinv_b, lane);
@@ -503,6 +607,7 @@ __device__ __forceinline__ void diag_block_finish(double (*Ts)[NB + 1], double (
             if (bad && lane == 0 && *info_b == 0) *info_b = k0 + bad;
         }
         __syncthreads();
+#endif
         for (int r = tid >> 6; r < NB; r += 4)
             if (lane <= r) S[(size_t)(k0 + r) * n + k0 + lane] = Lr[r][lane];         // coalesced rows of L
         return;
