@@ -219,9 +219,9 @@ void launch_transpose(hipStream_t stream, const double *in, size_t in_stride, do
 // LDS round trip and one scalar branch per component: 0.55 instead of 0.40 ms for the 2 GiB of config 2).
 // NQ > 0: the SMALLP form with 2 NQ components (P = 5: six FMAs and three reads per element instead of eight and four -- the
 // build is bound by its fp64 VALU work as much as by the write); NQ = 0: the general form.
-template <int KIND, int NQ>
+template <int KIND, int NQ, bool NT>
 __global__ __launch_bounds__(256) void kfu_build_kernel(ProjectArgs a) {
-    kfu_build_body<KIND, NQ>(a, blockIdx.x, blockIdx.y, blockIdx.z);
+    kfu_build_body<KIND, NQ, NT>(a, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 
@@ -246,19 +246,26 @@ void launch_brow_finish(hipStream_t stream, const double *gpart, int nblk, int M
     hipLaunchKernelGGL(brow_finish_kernel, dim3((Mp + 255) / 256, nb), dim3(256), 0, stream, gpart, nblk, Mp, Dl, d_begin, b0, log_Q,
                        yn_over_batch, H, h_stride, brow);
 }
-void launch_kfu_build(hipStream_t stream, const ProjectArgs &a) {
+template <bool NT>
+static void launch_kfu_build_nt(hipStream_t stream, const ProjectArgs &a) {
     dim3 grid(a.Tp / 64, a.Mp / 64, a.nb);
     if (a.P <= 8) {
         const int nq = (a.P + 1) / 2;
         if (a.kind == 0) {
-            if (nq <= 2) hipLaunchKernelGGL((kfu_build_kernel<0, 2>), grid, dim3(256), 0, stream, a);
-            else if (nq == 3) hipLaunchKernelGGL((kfu_build_kernel<0, 3>), grid, dim3(256), 0, stream, a);
-            else hipLaunchKernelGGL((kfu_build_kernel<0, 4>), grid, dim3(256), 0, stream, a);
-        } else hipLaunchKernelGGL((kfu_build_kernel<1, 4>), grid, dim3(256), 0, stream, a);
+            if (nq <= 2) hipLaunchKernelGGL((kfu_build_kernel<0, 2, NT>), grid, dim3(256), 0, stream, a);
+            else if (nq == 3) hipLaunchKernelGGL((kfu_build_kernel<0, 3, NT>), grid, dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL((kfu_build_kernel<0, 4, NT>), grid, dim3(256), 0, stream, a);
+        } else hipLaunchKernelGGL((kfu_build_kernel<1, 4, NT>), grid, dim3(256), 0, stream, a);
     } else {
-        if (a.kind == 0) hipLaunchKernelGGL((kfu_build_kernel<0, 0>), grid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((kfu_build_kernel<1, 0>), grid, dim3(256), 0, stream, a);
+        if (a.kind == 0) hipLaunchKernelGGL((kfu_build_kernel<0, 0, NT>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((kfu_build_kernel<1, 0, NT>), grid, dim3(256), 0, stream, a);
     }
+}
+void launch_kfu_build(hipStream_t stream, const ProjectArgs &a) {
+    static const bool no_nt = getenv("FFVD_KFU_NO_NT") != nullptr;          // A/B switch (read once)
+    // streaming stores for outputs of 1 GB and more (nothing of them survives in a cache until the Gram kernel reads it)
+    if ((size_t)a.nb * a.Tp * a.Mp * sizeof(double) >= ((size_t)1 << 30) && !no_nt) launch_kfu_build_nt<true>(stream, a);
+    else launch_kfu_build_nt<false>(stream, a);
 }
 
 // Operator-API kernel matrix (one kernel, arbitrary N, N2; no padding).

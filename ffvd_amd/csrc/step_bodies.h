@@ -10,7 +10,7 @@
 
 namespace ffvd {
 
-template <int KIND, int NQ>
+template <int KIND, int NQ, bool NT = false>
 __device__ __forceinline__ void kfu_build_body(const ProjectArgs &a, const int bx, const int by, const int bzz) {
     constexpr bool SMALLP = NQ > 0;
     __shared__ double xs[SMALLP ? 1 : MAXP][SMALLP ? 1 : 64];
@@ -57,6 +57,9 @@ __device__ __forceinline__ void kfu_build_body(const ProjectArgs &a, const int b
     for (int p = 0; p < 8; ++p) zr[p] = (SMALLP || p < P) ? zs[lane][p] : 0.0;
     const int rbase = __builtin_amdgcn_readfirstlane(tid >> 6) * 16;
     const bool want_g = a.gpart != nullptr;
+    // NT: K_fu of the big batch (2.1 GB at config 2) is a pure write stream nobody reads before it has left every cache: streaming
+    // stores take the build from 0.515 to 0.446 ms (4.2 -> 4.8 TB/s), the Gram kernel behind it loses 0.03 (profiles/r04_ab_kfu_nt.txt);
+    // a compile-time switch -- as a run-time flag inside the row loop the same stores gained 0.016 ms
     double gacc = 0.0, dlane = 0.0;             // lane i < 16 of every wavefront: delta of row rbase + i
     if (want_g) {
         const int t = t0 + rbase + (lane & 15);
@@ -83,7 +86,8 @@ __device__ __forceinline__ void kfu_build_body(const ProjectArgs &a, const int b
             }
             double v = kernel_value<KIND>(dot, xx[r], zzv, var);
             if (EDGE && (!mok || t0 + r >= a.T)) v = 0.0;
-            out[(size_t)r * Mp] = v;
+            if (NT) __builtin_nontemporal_store(v, &out[(size_t)r * Mp]);
+            else out[(size_t)r * Mp] = v;
             if (want_g) {                       // delta of this row out of lane i: two v_readlane, then ONE vector FMA
                 const double dr = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(dlane), i),
                                                    __builtin_amdgcn_readlane(__double2loint(dlane), i));
