@@ -678,10 +678,12 @@ def test_time_shards_sum_to_the_single_engine_nll(name, ov, nshard, monkeypatch)
         for e in engines:
             sums = e.tshard_finish(total)
             assert sums[7] == S
-            assert sums[6] / S == pytest.approx(whole["nll"], rel=1e-10)
+            # (not the same arithmetic: the plain handle's K_uu chain is one dataflow launch that forms K^-1 itself, the T-shard handle
+            #  multiplies L^-T L^-1 in a launch of its own -- eps * cond(K_uu) on the trace term, 1.5e-10 measured)
+            assert sums[6] / S == pytest.approx(whole["nll"], rel=1e-9)
             assert sums[6] / S == pytest.approx(ref["nll"], rel=1e-7)
             for i, n in enumerate(TERMS_B[:-1]):
-                assert sums[i] / S == pytest.approx(whole[n], rel=1e-9, abs=1e-10), n
+                assert sums[i] / S == pytest.approx(whole[n], rel=1e-9, abs=1e-9), n      # (the trace term is the remainder of a cancellation)
     finally:
         for e in engines:
             e.close()
@@ -745,7 +747,7 @@ def test_time_shards_sum_to_the_single_engine_gradient(name, ov, nshard, monkeyp
         for r, e in enumerate(engines):
             t0, tc = shard_range(T, nshard, r)
             sums, g = e.tshard_grad_fetch(block)
-            assert sums[7] == S and sums[6] / S == pytest.approx(whole["nll"], rel=1e-10)
+            assert sums[7] == S and sums[6] / S == pytest.approx(whole["nll"], rel=1e-9)
             for n in GRAD_NAMES:
                 scale = max(np.abs(gw[n]).max(), 1e-12)
                 assert np.abs(g[n] - gw[n]).max() <= 1e-7 * scale, (n, r)
