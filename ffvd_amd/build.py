@@ -137,6 +137,7 @@ VARIANTS = {
     "r3gram": ["-DGRAM_COMBO=1"],
     # the 64-pivot diagonal factor of the dataflow Cholesky by wavefront 0 alone (round 3) against all four wavefronts (round 4)
     "factor1w": ["-DDF_FACTOR_4W=0"],
+    "offdiagglds": ["-DGRAM_GLDS_OFFDIAG=1"],       # off-diagonal Gram tiles staged by LDS-DMA like the pair combos (measured neutral)
     "dftrace_notail": ["-DFFVD_DF_TRACE", "-DGRAM_TAIL_SPLIT=0"],
     # tiny.hip (the one-launch iteration): wall-clock stamps of every workgroup's phases (tools/tiny_trace.py); a build whose
     # unit-0 head never publishes W, so that every bounded wait of that launch must give up (tests/test_gpu_tiny.py)

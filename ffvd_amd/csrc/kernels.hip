@@ -2090,6 +2090,9 @@ void launch_linear_lowrank(hipStream_t stream, const ProjectArgs &a, double *par
 // (Measured alternatives at M = 512, T = 4096, 128 units: 4 wavefronts of 64x64 3.45 ms; 16 wavefronts of 32x32,
 //  one workgroup per CU 3.36 ms; 128x64 tiles, 8 wavefronts of 32x32 3.27 ms; this layout 2.98 ms.)
 // ---------------------------------------------------------------------------------------------
+#ifndef GRAM_GLDS_OFFDIAG
+#define GRAM_GLDS_OFFDIAG 0         // 1: off-diagonal tiles staged by LDS-DMA too -- measured neutral (2.24 vs 2.25 ms, profiles/r04_ab_gram_offdiag_glds.txt)
+#endif
 #ifndef GRAM_COMBO
 #define GRAM_COMBO 2                // 0: none, 1: three 64 x 32-sub-block workgroups per four diagonal tiles (round 3), 2: pair combos (round 4)
 #endif
@@ -2105,7 +2108,7 @@ template <int N>
 __device__ __forceinline__ bool gram_tail_exchange(const GramArgs &a, const int tail_id, const int half, const bool active,
                                                    d4 (&acc)[N], double &bs0, double &bs1, int *tail_slot);
 
-template <int MODE, bool DIAG>
+template <int MODE, bool DIAG, bool GLDS = false>
 __device__ __forceinline__ void gram_body(const GramArgs a, const int bz, const int ti, const int tj, const int tile,
                                           const int kpart, const int ksplit, double (*As)[GT][G_LD],
                                           double (*Bs)[GT][G_LD], double (*dls)[GT], double *red, const int tail_id = -1,
@@ -2184,12 +2187,35 @@ __device__ __forceinline__ void gram_body(const GramArgs a, const int bz, const 
     const int per = (nchunk_all + nrange - 1) / nrange;
     const int cbeg = kpart * per;
     const int nchunk = (cbeg + per <= nchunk_all) ? cbeg + per : nchunk_all;      // this range: chunks [cbeg, nchunk)
-    gload(cbeg);
-    lstore(cbeg & 1);
+    // GLDS (off-diagonal tiles of launches whose panels are whole: Mp a multiple of 128): the panels go global -> LDS by DMA, as in the
+    // pair combos (gram_pair_role has the notes), no staging registers and no ds_write pass
+    const unsigned voffA = (unsigned)((rowl * Mp + ti * 128 + 2 * lane) * (int)sizeof(double));
+    const unsigned voffB = (unsigned)((rowl * Mp + tj * 128 + 2 * lane) * (int)sizeof(double));
+    auto glds = [&](const double *base, const unsigned voff, const void *lds_row) {
+        typedef __attribute__((address_space(3))) void lvoid;
+        const unsigned dst = (unsigned)(uintptr_t)(lvoid *)lds_row;
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(dst), "s"(base) : "memory");
+    };
+    auto dma = [&](int c, int buf) {
+        const double *base0 = Ab + (size_t)c * GT * Mp, *base1 = base0 + (size_t)8 * Mp;
+        glds(base0, voffA, &As[buf][wave][0]);
+        glds(base0, voffB, &Bs[buf][wave][0]);
+        glds(base1, voffA, &As[buf][wave + 8][0]);
+        glds(base1, voffB, &Bs[buf][wave + 8][0]);
+    };
+    if (GLDS) {
+        dma(cbeg, cbeg & 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        gload(cbeg);
+        lstore(cbeg & 1);
+    }
     __syncthreads();
     for (int c = cbeg; c < nchunk; ++c) {
         const int buf = c & 1;
-        if (c + 1 < nchunk) gload(c + 1);
+        if (c + 1 < nchunk) { if (GLDS) dma(c + 1, buf ^ 1); else gload(c + 1); }
         if (active) {
             const double(*Bp)[G_LD] = DIAG ? As[buf] : Bs[buf];
             double af[4], bf[2], afn[4], bfn[2];
@@ -2219,7 +2245,8 @@ __device__ __forceinline__ void gram_body(const GramArgs a, const int bz, const 
 #pragma unroll
             for (int r = 0; r < GT; ++r) bsum += As[buf][r][tid - 384] * dls[buf][r];
         }
-        if (c + 1 < nchunk) lstore(buf ^ 1);
+        if (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the next chunk has landed (the DMAs are invisible to hipcc's counting)
+        else if (c + 1 < nchunk) lstore(buf ^ 1);
         __syncthreads();
     }
 
@@ -2737,6 +2764,9 @@ __global__ __launch_bounds__(512, 4) void gram_kernel(GramArgs a) {
     const long long tw0 = wall_clock64();     // debug build (tools/gram_trace.py): start and end of the tiles of the first 16 units
 #endif
     if (ti == tj) gram_body<MODE, true>(a, bz, ti, tj, tile, kpart, ksplit, As, Bs, dls, red, tail_id, &tail_slot);
+#if GRAM_GLDS_OFFDIAG
+    else if (a.Mp % 128 == 0) gram_body<MODE, false, true>(a, bz, ti, tj, tile, kpart, ksplit, As, Bs, dls, red, tail_id, &tail_slot);
+#endif
     else gram_body<MODE, false>(a, bz, ti, tj, tile, kpart, ksplit, As, Bs, dls, red, tail_id, &tail_slot);
 #ifdef FFVD_DF_TRACE
     if (threadIdx.x == 0 && bz < 16 && ksplit == 1 && a.ntiles <= 10 && MODE == GRAM_KFU) {
