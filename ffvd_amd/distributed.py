@@ -173,6 +173,24 @@ def exchange_unique_id(make_id, rank, world, rendezvous_dir=None, timeout_s=120.
     return blob
 
 
+def tshard_nll_and_grad(engine, meta, t_begin, reduce_host, native=False):
+    """nll terms + gradient of a T-sharded job from one shard's engine (include/ffvd_abi.h "Gradient of a T-sharded job").
+    `engine` offers tshard_local / tshard_finish_grad / tshard_grad_fetch (or, native=True, elbo_tshard_grad with both exchange
+    steps inside the library); `reduce_host(array) -> summed flat array` is the all-reduce over the shards.  Three exchange steps:
+    raw tiles + chain sums; the gradient block (8 term sums of the first shard + every shared-parameter gradient); and dX, whose rows
+    are placed at their global position first, so that the sum also adds the two parts of the rows neighbouring shards share."""
+    S = meta["S"]
+    if native:
+        sums, g = engine.elbo_tshard_grad(S_total=S)
+    else:
+        t = np.asarray(reduce_host(engine.tshard_local()))
+        sums, g = engine.tshard_grad_fetch(np.asarray(reduce_host(engine.tshard_finish_grad(t, S_total=S))))
+    full = np.zeros((S, meta["T"] + 1, meta["D"]))
+    full[:, t_begin: t_begin + g["X"].shape[1]] = g["X"]
+    g = dict(g, X=np.asarray(reduce_host(full)).reshape(full.shape))
+    return finish(sums), g
+
+
 class ShardedElbo:
     """One rank's share of the ELBO on its own GPU + the scalar all-reduce.
 
@@ -274,18 +292,10 @@ class ShardedElbo:
         back for the WHOLE trajectory -- every shard's rows placed at their global position and summed, which also adds the two
         parts of the rows neighbouring shards share."""
         if self.time_shard:
-            S, t0 = self.meta["S"], self.plan["t_begin"]
             if self.collective == "rccl":
-                sums, g = self.engine.elbo_tshard_grad(S_total=S)
-                reduce_host = self.engine.allreduce_host
-            else:
-                t = self._host_reduce(self.engine.tshard_local())
-                sums, g = self.engine.tshard_grad_fetch(self._host_reduce(self.engine.tshard_finish_grad(t, S_total=S)))
-                reduce_host = lambda a: self._host_reduce(np.ascontiguousarray(a).ravel().copy())
-            full = np.zeros((S, self.meta["T"] + 1, self.meta["D"]))
-            full[:, t0: t0 + g["X"].shape[1]] = g["X"]
-            g["X"] = np.asarray(reduce_host(full)).reshape(full.shape)
-            return finish(sums), g
+                return tshard_nll_and_grad(self.engine, self.meta, self.plan["t_begin"], self.engine.allreduce_host, native=True)
+            return tshard_nll_and_grad(self.engine, self.meta, self.plan["t_begin"],
+                                       lambda a: self._host_reduce(np.ascontiguousarray(a, dtype=np.float64).ravel().copy()))
         terms, g = self.engine.nll_and_grad(S_total=self.meta["S"])
         if not self.reduces:
             return finish(terms["sums8"]), g

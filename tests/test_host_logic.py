@@ -159,6 +159,124 @@ def test_gloo_world2_time_sharding(tmp_path):
     assert "OK" in outs[0] and "OK" in outs[1]
 
 
+TIME_GRAD_WORKER = r'''
+import os, sys, math
+sys.path.insert(0, os.environ["FFVD_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+from ffvd_amd import synthetic, distributed as dm
+from oracle import ffvd_oracle_torch as ot
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+params, Y, c, meta = synthetic.make_named("tiny", S=1, D=2)
+pl = dm.plan(meta, world, rank, "time")
+t0, tc = pl["t_begin"], pl["t_count"]
+KEYS = dm.GRAD_KEYS
+JIT = 1e-5
+
+
+class TorchShard:
+    # A T-shard "engine" in torch fp64 with the decomposition of the HIP one (include/ffvd_abi.h "Gradient of a T-sharded job"):
+    # the shard's rows enter through the raw tiles (K_uf K_fu, K_uf delta, sum_t Kdiag_t, likelihood / transition sums), whose
+    # gradient is the shard's ADDITIVE share; everything the finish reads directly (K_uu, hyper-parameters, priors, x_0) is the
+    # same on every shard and differentiated on the first only.
+    def __init__(self):
+        self.first = t0 == 0
+        self.th = {k: torch.tensor(np.asarray(params[k]), dtype=torch.float64, requires_grad=True) for k in KEYS}
+        self.X = torch.tensor(params["X"][0, t0: t0 + tc + 1], dtype=torch.float64, requires_grad=True)
+        self.Y = torch.tensor(Y[t0: t0 + tc]); self.c = torch.tensor(c[t0: t0 + tc])
+        self.D, self.M = meta["D"], meta["M"]
+
+    def _local(self):
+        th, X = self.th, self.X
+        xc = torch.cat((X[:-1], self.c), dim=1)
+        Kuf = ot._se_K(th["Z"], xc, th["logvariance"], th["loglengthscales"])          # D, M, tc
+        delta = (X[1:] - X[:-1]).T
+        G = Kuf @ Kuf.transpose(1, 2)
+        g = (Kuf @ delta[:, :, None])[:, :, 0]
+        kd = tc * torch.exp(th["logvariance"])
+        Rrow = torch.exp(th["log_Rchols"])[0]
+        lik_q = (-0.5 * (((self.Y - (X[1:] @ th["CC"] + th["DD"])) / Rrow[None, :]) ** 2)).sum()
+        xq = (-0.5 * delta ** 2 / torch.exp(th["log_Q"])[:, None]).sum()
+        return torch.cat([G.reshape(-1), g.reshape(-1), kd, torch.stack([lik_q, xq, torch.tensor(float(tc), dtype=torch.float64)])])
+
+    def tshard_local(self):
+        self.loc = self._local()
+        return self.loc.detach().numpy().copy()
+
+    def tshard_finish_grad(self, total, S_total=1):
+        D, M = self.D, self.M
+        tin = self.loc + (torch.tensor(total) - self.loc).detach()
+        th = self.th if self.first else {k: v.detach() for k, v in self.th.items()}
+        G = tin[: D * M * M].reshape(D, M, M); g = tin[D * M * M: D * M * M + D * M].reshape(D, M)
+        kd = tin[D * M * M + D * M: D * M * M + D * M + D]; lik_q, xq, T = tin[-3], tin[-2], tin[-1]
+        Q = torch.exp(th["log_Q"]); Rrow = torch.exp(th["log_Rchols"])[0]
+        K = ot._se_K(th["Z"], th["Z"], th["logvariance"], th["loglengthscales"]) + JIT * torch.eye(M, dtype=torch.float64)
+        A = K + G / Q[:, None, None]
+        LK, LA = torch.linalg.cholesky(K), torch.linalg.cholesky(A)
+        logdet = 2.0 * (torch.log(torch.diagonal(LA, dim1=1, dim2=2)).sum(-1) - torch.log(torch.diagonal(LK, dim1=1, dim2=2)).sum(-1))
+        y = torch.linalg.solve_triangular(LA, (g / Q[:, None])[:, :, None], upper=False)[:, :, 0]
+        trKG = torch.stack([torch.trace(torch.cholesky_solve(G[d], LK[d])) for d in range(D)])
+        c_se = float(torch.log(torch.tensor(0.05, dtype=torch.float32)).double())
+        hyp = -0.5 * ((th["log_Q"] ** 2).sum() + (th["CC"] ** 2).sum() + (th["DD"] ** 2).sum() + (th["log_Rchols"] ** 2).sum())
+        p_hyper = -0.5 * (th["loglengthscales"] ** 2).sum() - 0.5 * ((th["logvariance"] - c_se) ** 2).sum()
+        p_Z = -0.5 * (th["Z"] ** 2).sum()
+        p_x0 = -0.5 * (self.X[0] ** 2).sum() if self.first else torch.zeros((), dtype=torch.float64)
+        terms = [-(p_hyper + p_Z + p_x0 + hyp) / T, -(lik_q - T * torch.log(Rrow).sum()) / T,
+                 -(xq - 0.5 * T * torch.log(Q).sum()) / T, (0.5 * ((kd - trKG) / Q).sum()) / T,
+                 (0.5 * logdet).sum() / T, (-0.5 * (y * y).sum(-1)).sum() / T]
+        nll = sum(terms)
+        leaves = [self.X] + [self.th[k] for k in KEYS]
+        grads = torch.autograd.grad(nll, leaves, allow_unused=True)
+        self.dX = (grads[0] if grads[0] is not None else torch.zeros_like(self.X)).numpy() / S_total
+        shared = [(gk if gk is not None else torch.zeros_like(self.th[k])).numpy().ravel() / S_total for k, gk in zip(KEYS, grads[1:])]
+        sums8 = np.array([float(v) for v in terms] + [float(nll), 1.0]) if self.first else np.zeros(8)
+        return np.concatenate([sums8] + shared)
+
+    def tshard_grad_fetch(self, block):
+        out, off = {"X": self.dX[None]}, 8
+        for k in KEYS:
+            n = int(np.asarray(params[k]).size)
+            out[k] = block[off: off + n].reshape(np.asarray(params[k]).shape)
+            off += n
+        return block[:8], out
+
+
+def reduce_host(a):
+    t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64).ravel().copy())
+    dm.all_reduce_sums(t)
+    return t.numpy()
+
+
+terms, g = dm.tshard_nll_and_grad(TorchShard(), meta, t0, reduce_host)
+p1 = dict(params, X=params["X"][0])
+ref_t, ref_g = ot.nll_and_grad(p1, Y, c, ["X"] + list(KEYS), U_collapse=True)
+assert abs(terms["nll"] - ref_t["nll"]) <= 1e-9 * abs(ref_t["nll"]), (terms["nll"], ref_t["nll"])
+for k in ["X"] + list(KEYS):
+    got = g[k][0] if k == "X" else g[k]
+    err = np.abs(got - ref_g[k]).max() / max(np.abs(ref_g[k]).max(), 1e-12)
+    assert err <= 1e-6, (k, err)
+print("OK", terms["nll"])
+dist.destroy_process_group()
+'''
+
+
+def test_gloo_world2_time_shard_gradient(tmp_path):
+    """world_size-2 rehearsal of the T-shard BACKWARD pass: a torch stand-in engine with the HIP engine's decomposition (the shard's
+    rows through the raw tiles = its additive share; what the finish reads directly, differentiated on the first shard only) runs
+    through the product's own assembly (`distributed.tshard_nll_and_grad`: tiles -> all-reduce -> gradient block -> all-reduce ->
+    dX rows at their global position -> all-reduce); every rank must hold the single-process nll and gradient."""
+    import subprocess
+    script = tmp_path / "tgworker.py"
+    script.write_text(TIME_GRAD_WORKER)
+    env = dict(os.environ, FFVD_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29538", WORLD_SIZE="2",
+               OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "OK" in outs[0] and "OK" in outs[1]
+
+
 def test_plan_auto_picks_the_shard_axis():
     from ffvd_amd.distributed import plan
     assert "t_begin" not in plan(dict(S=32, D=4, T=4096), 8, 3, "auto")
