@@ -1065,7 +1065,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
                     const int nbp = ns * Dl;
                     const int small = h->sw.atb128 ? 0 : 1;
                     if (sk != s) HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));       // W and L^-1 come from the K_uu chain
-                    if (!acopy_done) launch_symmetrize(s, g.Acopy, Mp, nbp);           // the Gram kernel's own copy is symmetric already
+                    launch_symmetrize(s, g.Acopy, Mp, nbp);                            // (the saved copy holds the lower triangle)
                     AtbArgs t1{};
                     t1.mode = ATB_PLAIN; t1.A = g.Acopy; t1.a_stride = msq; t1.lda = Mp; t1.nA = Mp;
                     t1.B = h->Kuu + msq; t1.b_stride = kstride; t1.ldb = Mp; t1.nB = Mp; t1.b_per_dim = 1; t1.rows = Mp;

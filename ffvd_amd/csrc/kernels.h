@@ -161,7 +161,7 @@ struct GramArgs {
     // gram_combine adds them in fixed order and applies the epilogue.  ksplit <= 1 or part == nullptr: off.
     int ksplit;
     double *part;
-    double *Hcopy;          // GRAM_KFU / GRAM_KFU_RAW (unsplit launch), optional: second, fully symmetric copy of the result (slab stride hcopy_stride, ld Mp) --
+    double *Hcopy;          // GRAM_KFU / GRAM_KFU_RAW (unsplit launch), optional: second copy of the result's lower triangle (slab stride hcopy_stride, ld Mp) --
     size_t hcopy_stride;    // the backward pass keeps A = K_uu + K_uf K_fu / Q, which the factorisation overwrites
     // combine pass only: 0 = epilogue + trace partials, 1 = epilogue without the trace (K^-1 not read), 2 = trace partials
     // only (H not written) -- lets the combine run before K^-1 exists and the trace follow on another stream

@@ -2292,15 +2292,13 @@ __device__ __forceinline__ void gram_body(const GramArgs a, const int bz, const 
                     else if (MODE == GRAM_KFU_RAW) {
                         v = g * scale + Kadd[(size_t)i * Mp + j];
                         Rb[(size_t)i * Mp + j] = g;
-                        if (Cb2 && j <= i) {                    // the copy is made fully symmetric here (lower triangle + mirror)
+                        if (Cb2 && j <= i) {                    // the copy holds the lower triangle (its readers sum over the chains first and mirror the sum: a mirror here was 64 cache lines per store)
                             Cb2[(size_t)i * Mp + j] = v;
-                            if (j < i) Cb2[(size_t)j * Mp + i] = v;
                         }
                     } else if (MODE == GRAM_KFU) {
                         v = g * scale + Kadd[(size_t)i * Mp + j];
-                        if (Cb2 && j <= i) {                    // second, fully symmetric copy (the backward pass keeps A)
+                        if (Cb2 && j <= i) {                    // second copy, lower triangle (the backward pass keeps A)
                             Cb2[(size_t)i * Mp + j] = v;
-                            if (j < i) Cb2[(size_t)j * Mp + i] = v;
                         }
                         const double w = (i > j) ? 2.0 : ((i == j) ? 1.0 : 0.0);
                         trp += w * (Kinv[(size_t)i * Mp + j] * g);
@@ -2496,15 +2494,13 @@ __device__ __forceinline__ void gram_combo_body(const GramArgs a, const int bz, 
                 else if (MODE == GRAM_KFU_RAW) {
                     v = g * scale + Kadd[(size_t)i * Mp + j];
                     Rb[(size_t)i * Mp + j] = g;
-                    if (Cb2 && j <= i) {                    // the copy is made fully symmetric here (lower triangle + mirror)
+                    if (Cb2 && j <= i) {                    // the copy holds the lower triangle (its readers sum over the chains first and mirror the sum: a mirror here was 64 cache lines per store)
                         Cb2[(size_t)i * Mp + j] = v;
-                        if (j < i) Cb2[(size_t)j * Mp + i] = v;
                     }
                 } else if (MODE == GRAM_KFU) {
                     v = g * scale + Kadd[(size_t)i * Mp + j];
                     if (Cb2 && j <= i) {
                         Cb2[(size_t)i * Mp + j] = v;
-                        if (j < i) Cb2[(size_t)j * Mp + i] = v;
                     }
                     const double w = (i > j) ? 2.0 : ((i == j) ? 1.0 : 0.0);
                     trp += w * (Kinv[(size_t)i * Mp + j] * g);
@@ -2658,9 +2654,8 @@ __device__ __forceinline__ void gram_pair_role(const GramArgs a, const int bz, c
             else if (MODE == GRAM_KFU_RAW || MODE == GRAM_KFU) {
                 v = g * scale + Kadd[(size_t)i * Mp + j];
                 if (MODE == GRAM_KFU_RAW) Rb[(size_t)i * Mp + j] = g;
-                if (Cb2 && j <= i) {                    // the copy is made fully symmetric here (lower triangle + mirror)
+                if (Cb2 && j <= i) {                    // the copy holds the lower triangle (its readers sum over the chains first and mirror the sum: a mirror here was 64 cache lines per store)
                     Cb2[(size_t)i * Mp + j] = v;
-                    if (j < i) Cb2[(size_t)j * Mp + i] = v;
                 }
                 if (MODE == GRAM_KFU) {
                     const double w = (i > j) ? 2.0 : ((i == j) ? 1.0 : 0.0);
