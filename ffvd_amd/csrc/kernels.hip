@@ -522,9 +522,12 @@ __device__ __forceinline__ void chol64_tile_solve(double (*Ts)[NB + 1], double (
 #pragma unroll
     for (int r = 0; r < 4; ++r) Lr[i0 + lr][s0 + lk + 4 * r] = x[r];                // L_is[n][m]
 }
-// sums + 16-pivot chain of diagonal tile s (one wavefront): L_ss into Lr, L_ss^-T into Xo and (transposed) into dinv_b
+// sums + 16-pivot chain of diagonal tile s (one wavefront): L_ss into Lr, L_ss^-T into Xo and (transposed) into dinv_b.
+// Id: an identity tile in LDS (the rows lanes 16-31 start from).  The chain as in tiny.hip's tiny_chain16 (tools/probes/lat_probe.hip:
+// 1.92 -> 1.54 us): per-lane base pointers instead of an exec-masked load per element, no scalar test per pivot -- a non-positive or
+// NaN pivot leaves NaN on L's diagonal from there on, looked for once behind the chain.
 __device__ __forceinline__ int chol64_diag_tile(double (*Ts)[NB + 1], double (*Lr)[LR_LD], double (*Sw)[DV_LD], double (*Xo)[DV_LD],
-                                                double *dinv_b, const int s, const int lane) {
+                                                const double (*Id)[DV_LD], double *dinv_b, const int s, const int lane) {
     const int lr = lane & 15, lk = lane >> 4, s0 = 16 * s;
     d4 acc = (d4){0.0, 0.0, 0.0, 0.0}, acc1 = acc;
     for (int k = 0; k < s; ++k)
@@ -537,39 +540,44 @@ __device__ __forceinline__ int chol64_diag_tile(double (*Ts)[NB + 1], double (*L
 #pragma unroll
     for (int r = 0; r < 4; ++r) Sw[lk + 4 * r][lr] = Ts[s0 + lk + 4 * r][s0 + lr] - (acc[r] + acc1[r]);
     wave_lds_order();
-    int bad = 0;
     double a[16];
+    const double *src = (lane < 16) ? &Sw[lr][0] : &Id[lr][0];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) a[c] = (lane < 16) ? Sw[lr][c] : ((lane < 32 && lr == c) ? 1.0 : 0.0);
+    for (int c = 0; c < 16; ++c) a[c] = src[c];
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const double ajj = readlane_f64(a[j], j);
-        if (!(ajj > 0.0) && bad == 0) bad = s0 + j + 1;
         double piv, y;
         pivot_sqrt(ajj, piv, y);
         a[j] *= y;
 #pragma unroll
         for (int c = j + 1; c < 16; ++c) a[c] = fma(-a[j], readlane_f64(a[j], c), a[c]);
     }
-    if (lane < 16) {
+    double diag = a[0];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) Lr[s0 + lr][s0 + c] = (c <= lr) ? a[c] : 0.0;
-    } else if (lane < 32) {
+    for (int c = 1; c < 16; ++c) diag = (lr == c) ? a[c] : diag;
+    if (lane < 32) {
+        double *base = (lane < 16) ? &Lr[s0 + lr][s0] : &Xo[lr][0];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            Xo[lr][c] = a[c];                                       // X = L_ss^-T
-            dinv_b[(s0 + c) * 16 + lr] = a[c];                      // (L_ss^-1)[c][lr] = X[lr][c]
+        for (int c = 0; c < 16; ++c) base[c] = (lane >= 16 || c <= lr) ? a[c] : 0.0;
+        if (lane >= 16) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) dinv_b[(s0 + c) * 16 + lr] = a[c];              // (L_ss^-1)[c][lr] = X[lr][c]
         }
     }
-    return bad;
+    const unsigned long long m = __ballot((lane < 16) & !(diag > 0.0));
+    return m ? s0 + (int)__builtin_ctzll(m) + 1 : 0;
 }
 __device__ __forceinline__ int chol64_mfma_4w(double (*Ts)[NB + 1], double (*Lr)[LR_LD], double (*Sc)[16][DV_LD], double *dinv_b) {
     const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // Sc[3]: the identity tile of the pivot chains (the four scratch tiles are the panel code's inverse blocks at other times)
+    if (threadIdx.x < 256) Sc[3][threadIdx.x >> 4][threadIdx.x & 15] = ((threadIdx.x >> 4) == (threadIdx.x & 15)) ? 1.0 : 0.0;
+    __syncthreads();
     int bad = 0;
     if (wave == 0) {
         __builtin_amdgcn_s_setprio(3);
-        bad = chol64_diag_tile(Ts, Lr, Sc[0], Sc[1], dinv_b, 0, lane);
+        bad = chol64_diag_tile(Ts, Lr, Sc[0], Sc[1], Sc[3], dinv_b, 0, lane);
         __builtin_amdgcn_s_setprio(0);
     }
     __syncthreads();
@@ -580,7 +588,7 @@ __device__ __forceinline__ int chol64_mfma_4w(double (*Ts)[NB + 1], double (*Lr)
             __builtin_amdgcn_s_setprio(3);
             chol64_tile_solve(Ts, Lr, X, s, s + 1, lr, lk);
             wave_lds_order();
-            const int b2 = chol64_diag_tile(Ts, Lr, Sc[0], Sc[1 + ((s + 1) & 1)], dinv_b, s + 1, lane);
+            const int b2 = chol64_diag_tile(Ts, Lr, Sc[0], Sc[1 + ((s + 1) & 1)], Sc[3], dinv_b, s + 1, lane);
             if (b2 && !bad) bad = b2;
             __builtin_amdgcn_s_setprio(0);
         } else if (s + 1 + wave < 4) chol64_tile_solve(Ts, Lr, X, s, s + 1 + wave, lr, lk);

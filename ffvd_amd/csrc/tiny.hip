@@ -64,7 +64,7 @@ __host__ __device__ inline TinyLds tiny_lds(int Mp, int SR) {
     l.mat = o;                                  // head: the matrix being factorised [Mp][LD];  strip: K_fu / F / R / E rows [SR][LD]
     int oh = o + Mp * LD;
     l.dinv = oh; oh += (NT * 16 * 17 > Mp * 9) ? NT * 16 * 17 : Mp * 9;     // head: inverted diagonal tiles W(s,s); (K_uu build: Z / l and |.|^2)
-    l.sc = oh;   oh += 16 * 17;                 // head: the diagonal tile handed to the pivot chain
+    l.sc = oh;   oh += 2 * 16 * 17;             // head: the diagonal tile handed to the pivot chain, and behind it an identity tile (its lanes 16-31)
     int os = o + SR * LD;
     l.xo = os;   os += SR * 16;                 // strip: x / l rows + |.|^2 (K build), later [1 | x_comb] rows
     l.zo = os;   os += Mp * 16;                 // strip: Z / l rows + |.|^2 (K build), later [1 | Z] rows
@@ -144,30 +144,35 @@ __device__ __forceinline__ void tiny_sum(double (&v)[N], double *red) {
 // 16-pivot chain on the tile in Sc (lower triangle valid): lanes 0-15 carry its rows, lanes 16-31 the rows of the identity through
 // the same column operations -- they come out as L_ss^-T (kernels.hip, chol64_mfma_1w).  Writes L_ss (zeros above the diagonal)
 // into the diagonal tile of Am and L_ss^-T into Dv.  Returns 0 or 1 + the first non-positive pivot of the tile.
+// (tools/probes/lat_probe.hip: the bare right-looking chain is 1.06 us; as first written -- the identity rows chosen by a select
+//  per element, i.e. an exec-masked load each; the first bad pivot tracked by a scalar compare per pivot; two exec-masked store
+//  streams -- 1.92 us.  This form: 1.54 us.  Lanes 16-31 read an identity tile that sits in LDS behind Sc; a non-positive or NaN
+//  pivot leaves NaN on the diagonal of L from there on, which is looked for once, behind the chain; one store stream.)
 __device__ __forceinline__ int tiny_chain16(const double (*Sc)[17], double *Am, const int LD, const int s0, double (*Dv)[17], const int lane) {
     const int lr = lane & 15;
-    int bad = 0;
     double a[16];
+    const double *src = &Sc[(lane < 16) ? lr : 16 + lr][0];             // rows 16-31 of Sc's block: the identity tile
 #pragma unroll
-    for (int c = 0; c < 16; ++c) a[c] = (lane < 16) ? Sc[lr][c] : ((lane < 32 && lr == c) ? 1.0 : 0.0);
+    for (int c = 0; c < 16; ++c) a[c] = src[c];
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const double ajj = readlane_f64(a[j], j);
-        if (!(ajj > 0.0) && bad == 0) bad = j + 1;
         double piv, y;
         pivot_sqrt(ajj, piv, y);
         a[j] *= y;
 #pragma unroll
         for (int c = j + 1; c < 16; ++c) a[c] = fma(-a[j], readlane_f64(a[j], c), a[c]);
     }
-    if (lane < 16) {
+    double diag = a[0];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) Am[(size_t)(s0 + lr) * LD + s0 + c] = (c <= lr) ? a[c] : 0.0;
-    } else if (lane < 32) {
+    for (int c = 1; c < 16; ++c) diag = (lr == c) ? a[c] : diag;
+    if (lane < 32) {
+        double *base = (lane < 16) ? Am + (size_t)(s0 + lr) * LD + s0 : &Dv[lr][0];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) Dv[lr][c] = a[c];
+        for (int c = 0; c < 16; ++c) base[c] = (lane >= 16 || c <= lr) ? a[c] : 0.0;
     }
-    return bad;
+    const unsigned long long m = __ballot((lane < 16) & !(diag > 0.0));
+    return m ? (int)__builtin_ctzll(m) + 1 : 0;
 }
 
 // S = A(s,s) - sum_{kbeg<=k<s} L(s,k) L(s,k)^T into Sc (one wavefront)
@@ -265,9 +270,12 @@ __device__ __forceinline__ void tiny_chol_inv(double *Am, const int LD, const in
                 __builtin_amdgcn_s_setprio(3);
                 tiny_tile_solve(Am, LD, Dinv, s, s + 1, false, lane, kb);
                 wave_lds_order();
+                TSTAMP(27);
                 tiny_diag_gather(Am, LD, s + 1, kb, Sc, lane);
                 wave_lds_order();
+                TSTAMP(28);
                 const int b2 = tiny_chain16(Sc, Am, LD, 16 * (s + 1), Dinv[s + 1], lane);
+                TSTAMP(29);
                 if (b2 && !bad) bad = 16 * (s + 1) + b2;
                 __builtin_amdgcn_s_setprio(0);
             }
@@ -763,6 +771,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void tiny_kernel(const Ti
         tab[tau] = ti | (tj << 8);
     }
     if (tid < 8) ilen[tid] = (tid < P) ? exp(a.loglen[(size_t)dg * P + tid]) : 1.0;      // :161
+    if (head)                                                                          // the identity rows of the pivot chains (tiny_chain16)
+        for (int e = tid; e < 16 * 17; e += NTHR) lds[L.sc + 16 * 17 + e] = ((e / 17) == (e % 17)) ? 1.0 : 0.0;
 
     if (head) {
         // This iteration's factorisation flags start at zero (a head is the only writer of its words), and the result starts as NaN:

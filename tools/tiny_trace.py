@@ -4,7 +4,7 @@ import ctypes as ct, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from ffvd_amd import build as fb
-os.environ["FFVD_LIB"] = fb.build_variant("tinytrace")
+os.environ["FFVD_LIB"] = fb.build_variant(os.environ.get("TINY_TRACE_VARIANT", "tinytrace"))
 import numpy as np
 from ffvd_amd.engine import ElboEngine
 z = np.load(os.path.join(ROOT, "tests", "golden", "actuator_slim.npz"), allow_pickle=False)
@@ -37,6 +37,7 @@ print("heads (us):")
 for u in range(min(nunits, 8)):
     print("  u%-3d" % u, " ".join("%s=%.1f" % (n, us[u, i]) for i, n in enumerate(names_h) if not np.isnan(us[u, i])))
 print("head 0 detail (us): prologue %s | chol(H) columns %s | W stored %.1f" % (" ".join("%.1f" % us[0, i] for i in (16, 17)), " ".join("%.1f" % us[0, i] for i in range(18, 26) if not np.isnan(us[0, i])), us[0, 26]))
+print("head 0, last column step of chol(H) (us): tile solve done %.2f, sums done %.2f, 16-pivot chain done %.2f" % (us[0, 27], us[0, 28], us[0, 29]))
 print("strip 0 detail (us): F^T F tiles out %.1f, F^T delta out %.1f" % (us[nunits, 16], us[nunits, 17]))
 print("strips of unit 0 (us):")
 for i in range(nst):
