@@ -810,20 +810,42 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void tiny_kernel(const Ti
             }
             __syncthreads();
             TSTAMP(17);
-#pragma unroll 4
-            for (int idx = tid; idx < ntl * 256; idx += NTHR) {              // lower-triangular tiles only (one wavefront per SIMD: independent elements interleaved)
-                const int tt = tab[idx >> 8], e = idx & 255;
-                const int i = 16 * (tt & 255) + (e >> 4), j = 16 * (tt >> 8) + (e & 15);
-                double v;
-                if (i >= M || j >= M) v = (i == j) ? 1.0 : 0.0;
-                else {
-                    double dot = 0.0;
+            // lower-triangular tiles only.  A thread keeps its element position (r, cj) inside the tile; the inducing inputs of ITS column
+            // in every tile column (z_j, |z_j|^2: NT x 9 doubles) go to registers once, the row's (z_i) once per tile row -- the loop
+            // that read both from LDS per element was bound by the LDS pipe, not by the exp (tools/probes/lat_probe.hip: 5.7 us per
+            // pass of which the exp is 0.8); 256 threads = one tile at a time, 512 = two neighbours
+            {
+                const int e = tid & 255, r = e >> 4, cj = e & 15, half = tid >> 8, step = NTHR >> 8;
+                double zj[TNT][8], zzj[TNT];
 #pragma unroll
-                    for (int p = 0; p < 8; ++p) dot += zs[i * 9 + p] * zs[j * 9 + p];
-                    v = kernel_value<0>(dot, zz[i], zz[j], var);
-                    if (i == j) v += a.jitter;                               // :159
+                for (int tj = 0; tj < TNT; ++tj) {
+                    const int j = (tj < NT) ? 16 * tj + cj : cj;
+#pragma unroll
+                    for (int p = 0; p < 8; ++p) zj[tj][p] = zs[j * 9 + p];
+                    zzj[tj] = zz[j];
                 }
-                Am[(size_t)i * LD + j] = v;
+#pragma unroll
+                for (int ti = 0; ti < TNT; ++ti) {
+                    if (ti < NT) {
+                        const int i = 16 * ti + r;
+                        double zi[8];
+#pragma unroll
+                        for (int p = 0; p < 8; ++p) zi[p] = zs[i * 9 + p];
+                        const double zzi = zz[i];
+#pragma unroll
+                        for (int tj = 0; tj <= ti; ++tj) {
+                            if ((tj & (step - 1)) != half) continue;         // (uniform per wavefront)
+                            const int j = 16 * tj + cj;
+                            double dot = 0.0;
+#pragma unroll
+                            for (int p = 0; p < 8; ++p) dot += zi[p] * zj[tj][p];
+                            double v = kernel_value<0>(dot, zzi, zzj[tj], var);
+                            if (i == j) v += a.jitter;                       // :159
+                            if (i >= M || j >= M) v = (i == j) ? 1.0 : 0.0;
+                            Am[(size_t)i * LD + j] = v;
+                        }
+                    }
+                }
             }
             __syncthreads();
         }
@@ -838,10 +860,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void tiny_kernel(const Ti
 #pragma unroll 4
             for (int i = 16 * tj + wave; i < 16 * tj + 16; i += NW) {
                 Wu[(size_t)i * Mp + j] = Dinv[tj][i & 15][j & 15];
-                Wtu[(size_t)i * Mp + j] = Dinv[tj][j & 15][i & 15];
+                if (a.grad) Wtu[(size_t)i * Mp + j] = Dinv[tj][j & 15][i & 15];
             }
+            if (a.grad) {                                                    // (only the backward pass reads W^T)
 #pragma unroll 4
-            for (int i = 16 * (tj + 1) + wave; i < Mp; i += NW) Wtu[(size_t)i * Mp + j] = Am[(size_t)j * LD + i];     // W^T(i, j) = W(j, i)
+                for (int i = 16 * (tj + 1) + wave; i < Mp; i += NW) Wtu[(size_t)i * Mp + j] = Am[(size_t)j * LD + i];     // W^T(i, j) = W(j, i)
+            }
         }
         TSTAMP(26);
 #ifdef FFVD_TINY_TEST_STALL

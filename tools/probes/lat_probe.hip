@@ -190,6 +190,41 @@ __global__ void probe4(double *out, long long *t, int n) {
     out[lane] = Am[lane] + Dv[lane & 15][0] + bad;
     if (lane == 0) t[0] = t1 - t0;
 }
+// the SE-kernel element of tiny.hip's K_uu build: 8-component dot against an LDS row, expanded-form distance, exp, store to LDS
+template <int MODE>
+__global__ void probe_kbuild(double *out, long long *t, int n) {
+    __shared__ double zs[128 * 9], zz[128], Am[128 * 113];
+    const int tid = threadIdx.x, r = (tid & 255) >> 4, cj = tid & 15;
+    for (int e = tid; e < 128 * 9; e += blockDim.x) zs[e] = 0.01 * (e % 97);
+    for (int e = tid; e < 128; e += blockDim.x) zz[e] = 0.3 + 0.001 * e;
+    __syncthreads();
+    const double var = 1.3;
+    long long t0 = wall_clock64();
+    for (int rep = 0; rep < n; ++rep)
+        for (int ti = 0; ti < 7; ++ti) {
+            const int i = 16 * ti + r;
+            double zi[8];
+#pragma unroll
+            for (int p = 0; p < 8; ++p) zi[p] = zs[i * 9 + p];
+            const double zzi = zz[i];
+#pragma unroll 2
+            for (int tj = 0; tj <= ti; ++tj) {
+                const int j = 16 * tj + cj;
+                double dot = 0.0;
+#pragma unroll
+                for (int p = 0; p < 8; ++p) dot += zi[p] * zs[j * 9 + p];
+                double v;
+                if (MODE == 0) v = kernel_value<0>(dot, zzi, zz[j], var);
+                else if (MODE == 1) v = var * exp(-(-2.0 * dot + (zzi + zz[j])) * 0.5);
+                else v = dot + zzi + zz[j];                                  // no exp: the cost of everything else
+                Am[i * 113 + j] = v + rep;
+            }
+        }
+    long long t1 = wall_clock64();
+    __syncthreads();
+    out[tid & 63] = Am[tid];
+    if (tid == 0) t[0] = t1 - t0;
+}
 int main() {
     double *out; long long *t;
     hipMalloc(&out, 64 * 8); hipMalloc(&t, 4 * 8);
@@ -216,5 +251,8 @@ int main() {
     hipMemcpy(h, t, sizeof(h), hipMemcpyDeviceToHost); printf("candidate v2 (per-lane bad flag, one store stream): %.2f ns per chain\n", h[0] * tick / 1024.0);
     hipLaunchKernelGGL(probe4, dim3(1), dim3(64), 0, 0, out, t, 1024); hipDeviceSynchronize();
     hipMemcpy(h, t, sizeof(h), hipMemcpyDeviceToHost); printf("candidate v4 (identity tile, NaN check afterwards, one store stream): %.2f ns per chain\n", h[0] * tick / 1024.0);
+#define RUNK(M, label) hipLaunchKernelGGL((probe_kbuild<M>), dim3(1), dim3(256), 0, 0, out, t, 64); hipDeviceSynchronize(); \
+    hipMemcpy(h, t, sizeof(h), hipMemcpyDeviceToHost); printf("K build element loop (28 elements per thread, 256 threads), %s: %.2f us per pass = %.1f ns per element per wavefront\n", label, h[0] * tick / 64.0 / 1000.0, h[0] * tick / 64.0 / 28.0);
+    RUNK(0, "exp_kernel") RUNK(1, "library exp") RUNK(2, "no exp")
     return 0;
 }
