@@ -63,6 +63,7 @@ struct ffvd_handle {
         bool debug_sync = false;    // FFVD_DEBUG_SYNC: name every launch group on stderr and wait for it (locates a faulting kernel)
         int side_delay_us = 0;      // FFVD_DEBUG_SIDE_DELAY_US=n: a spin kernel of n us at the head of every side-stream fork (schedule tests: results
         int main_delay_us = 0;      //   must not depend on which stream is late); FFVD_DEBUG_MAIN_DELAY_US=n: the same on the main stream behind a fork
+        bool tiny_xcd = true;       // FFVD_TINY_NO_XCD=1: the one-launch iteration with role-major workgroup ids instead of a unit's workgroups on ONE XCD
         bool no_tiny = false;       // FFVD_NO_TINY=1: the multi-kernel schedule also at the reference's own experiment size (rounds 1-3)
     } sw;
     // resident parameters / data (handle-owned copies)
@@ -72,6 +73,7 @@ struct ffvd_handle {
     bool have_params = false, have_data = false;
     void *comm = nullptr;       // RCCL communicator created by ffvd_comm_init (owned by the handle), else null
     int comm_world = 1, comm_rank = 0;
+    int tiny_cus = 0;           // compute units of the device (one-launch plan)
     double *tsbuf = nullptr;    // T-shard exchange buffer: [nbatch][(Mp+1) x Mp] raw Gram tiles + delta^T K_fu rows, then [S][8] chain sums
     int64_t ts_count = 0;
     double *stage = nullptr;    // staging buffer of ffvd_allreduce_sum
@@ -213,7 +215,7 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
         w.kuu_flow = !on("FFVD_NO_KUU_FLOW");   w.kinv_gram = on("FFVD_KINV_GRAM");   w.chain_rl = on("FFVD_CHAIN_RL");
         w.atb128 = on("FFVD_ATB128");                 w.grad_serial = on("FFVD_GRAD_SERIAL");
         w.debug_sync = on("FFVD_DEBUG_SYNC");
-        w.no_tiny = on("FFVD_NO_TINY");
+        w.no_tiny = on("FFVD_NO_TINY");               w.tiny_xcd = !on("FFVD_TINY_NO_XCD");
         if (const char *e = getenv("FFVD_DEBUG_SIDE_DELAY_US")) w.side_delay_us = atoi(e);
         if (const char *e = getenv("FFVD_DEBUG_MAIN_DELAY_US")) w.main_delay_us = atoi(e);
     }
@@ -421,6 +423,7 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, c.device_id) == hipSuccess) cus = prop.multiProcessorCount;
         h->tiny = tiny_plan(c.kernel_kind, c.T, c.D, c.C, c.M, c.S_local, (int)Dl, c.grad, cus);
+        h->tiny_cus = cus;
         if (h->tiny.ok) {
             HIP_TRY(dev_alloc(h, &h->tiny_scratch, tiny_scratch_doubles(h->tiny, c.T, (int)P, c.M, c.S_local, (int)Dl, c.D, c.Ydim, c.grad)));
             HIP_TRY(dev_alloc(h, &h->tiny_flags, tiny_flag_ints(h->tiny, c.S_local)));
@@ -698,6 +701,10 @@ static int enqueue_tiny(ffvd_handle *h, double *out_dev, StageTimer *st, bool wi
     a.X = p.X; a.Z = p.Z; a.logvar = p.logvariance; a.loglen = p.loglengthscales; a.log_Q = p.log_Q; a.CC = p.CC; a.DD = p.DD;
     a.logR = p.log_Rchols; a.Y = h->Y; a.ctrl = h->ctrl;
     tiny_bind_scratch(a, h->tiny, h->tiny_scratch, h->tiny_flags);
+    {   // all workgroups of a unit on one XCD when the padded grid (8 x ceil(units / 8) unit slots) still fits the chip
+        const int wpu = 1 + h->tiny.nstrips + (a.side ? h->tiny.NT : 0);
+        a.xcd_map = (h->sw.tiny_xcd && 8 * wpu * ((h->tiny.nunits + 7) / 8) <= h->tiny_cus) ? 1 : 0;
+    }
     a.info = h->info; a.chain_nll = h->chain_nll; a.out_terms = out_dev ? out_dev : h->out_terms;
     if (with_grad) {
         const ffvd_handle::GradWs &g = h->gw;

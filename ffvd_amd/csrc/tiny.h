@@ -14,6 +14,7 @@ struct TinyArgs {
     int kind, T, D, C, P, M, Mp, NT, Dl, d_begin, S, Ydim;
     int SR, nstrips, nunits;        // rows per strip workgroup (16 per wavefront), strips per unit, units = S * Dl
     int side;                       // backward: NT more workgroups per unit take the row blocks of the K_uu side (else the strips do)
+    int xcd_map;                    // workgroup id -> (unit, role): all workgroups of a unit on ONE XCD (blockIdx % 8 = unit % 8)
     int prior_type, shared_terms, grad, S_total;
     double jitter;
     const double *X, *Z, *logvar, *loglen, *log_Q, *CC, *DD, *logR, *Y, *ctrl;

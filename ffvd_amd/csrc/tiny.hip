@@ -39,7 +39,7 @@ constexpr long long TINY_SPIN_TICKS = 100000000LL;   // 1 s of the 100 MHz wall 
 // Debug build only (-DFFVD_TINY_TRACE, tools/tiny_trace.py): wall-clock stamps of every workgroup's phases.
 #ifdef FFVD_TINY_TRACE
 __device__ long long tiny_trace_buf[1024 * 32];
-#define TSTAMP(slot) do { if (threadIdx.x == 0 && blockIdx.x < 1024) tiny_trace_buf[blockIdx.x * 32 + (slot)] = wall_clock64(); } while (0)
+#define TSTAMP(slot) do { if (threadIdx.x == 0 && blockIdx.x < 1024) tiny_trace_buf[blockIdx.x * 32 + (slot)] = wall_clock64(); } while (0)   // (by PHYSICAL id: tools/tiny_trace.py undoes xcd_map)
 extern "C" int ffvd_debug_tiny_trace(long long *out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tiny_trace_buf), sizeof(long long) * 1024 * 32);
 }
@@ -754,10 +754,20 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void tiny_kernel(const Ti
     double *ilen = lds + L.tab + 18;                                         // [8] lengthscales (1 where p >= P)
     double *red = lds + L.red;
     double *Am = lds + L.mat;
-    const bool head = (int)blockIdx.x < a.nunits;
-    const bool side = (int)blockIdx.x >= a.nunits * (1 + nst);              // (only launched with a.side)
-    const int u = head ? (int)blockIdx.x : (side ? ((int)blockIdx.x - a.nunits * (1 + nst)) / NT : ((int)blockIdx.x - a.nunits) / nst);
-    const int strip = head ? 0 : (side ? ((int)blockIdx.x - a.nunits * (1 + nst)) % NT : ((int)blockIdx.x - a.nunits) % nst);
+    // role-major virtual id: heads [0, nunits), strips behind them, K_uu-side workgroups last.  xcd_map: the hardware deals
+    // consecutive workgroup ids to the 8 XCDs in turn, each with an L2 of its own -- unit u's workgroups take the ids = u (mod 8), so
+    // that everything they hand each other stays in one L2; ids whose unit does not exist leave at once
+    int vb = (int)blockIdx.x;
+    if (a.xcd_map) {
+        const int wpu = 1 + nst + (a.side ? NT : 0), xcd = vb & 7, slot = vb >> 3;
+        const int uu = (slot / wpu) * 8 + xcd, role = slot % wpu;
+        if (uu >= a.nunits) return;
+        vb = (role == 0) ? uu : ((role <= nst) ? a.nunits + uu * nst + (role - 1) : a.nunits * (1 + nst) + uu * NT + (role - 1 - nst));
+    }
+    const bool head = vb < a.nunits;
+    const bool side = vb >= a.nunits * (1 + nst);                           // (only launched with a.side)
+    const int u = head ? vb : (side ? (vb - a.nunits * (1 + nst)) / NT : (vb - a.nunits) / nst);
+    const int strip = head ? 0 : (side ? (vb - a.nunits * (1 + nst)) % NT : (vb - a.nunits) % nst);
     const int s = u / Dl, dl = u % Dl, dg = a.d_begin + dl;
     const TinyCtx cx = tiny_ctx(a, u, s);
     const double var = exp(a.logvar[dg]);                                   // kernels_multi_output.py:157
@@ -1425,7 +1435,8 @@ void tiny_bind_scratch(TinyArgs &a, const TinyPlan &pl, double *scratch, int *fl
 
 hipError_t launch_tiny(hipStream_t stream, const TinyArgs &a, const TinyPlan &pl, TinyArgs *dev_args, TinyArgs *host_shadow) {
     static size_t attr_bytes[2] = {0, 0};              // dynamic LDS each instantiation has been allowed so far
-    const int grid = pl.nunits * (1 + pl.nstrips + (a.side ? pl.NT : 0));
+    const int wpu = 1 + pl.nstrips + (a.side ? pl.NT : 0);
+    const int grid = a.xcd_map ? 8 * wpu * ((pl.nunits + 7) / 8) : pl.nunits * wpu;
     const int which = pl.nw == 4 ? 0 : 1;
     const void *fn = which == 0 ? reinterpret_cast<const void *>(&tiny_kernel<4>) : reinterpret_cast<const void *>(&tiny_kernel<8>);
     if (pl.lds_bytes > attr_bytes[which] && pl.lds_bytes > 48 * 1024) {

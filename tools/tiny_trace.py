@@ -27,6 +27,15 @@ nunits = S * D
 nst = (T + 63) // 64 if int(e.lib.ffvd_single_launch(e._h)) == 4 else (T + 127) // 128
 NT = (M + 15) // 16
 nwg = nunits * (1 + nst + (NT if grad else 0))
+if not os.environ.get("FFVD_TINY_NO_XCD") and 8 * (1 + nst + (NT if grad else 0)) * ((nunits + 7) // 8) <= 256:        # undo the kernel's xcd_map: physical workgroup id -> role-major id
+    wpu = 1 + nst + (NT if grad else 0)
+    phys = a.copy(); a = np.zeros_like(phys)
+    for b in range(8 * wpu * ((nunits + 7) // 8)):
+        xcd, slot = b & 7, b >> 3
+        uu, role = (slot // wpu) * 8 + xcd, slot % wpu
+        if uu >= nunits or b >= 1024: continue
+        vb = uu if role == 0 else (nunits + uu * nst + role - 1 if role <= nst else nunits * (1 + nst) + uu * NT + role - 1 - nst)
+        a[vb] = phys[b]
 a = a[:nwg].astype(np.float64)
 t0 = a[a > 0].min()
 us = np.where(a > 0, (a - t0) / 100.0, np.nan)
