@@ -340,7 +340,9 @@ __device__ __forceinline__ FinalizeArgs tiny_finalize_args(const TinyArgs &a) {
 // The likelihood gradients of chain s and the transition-prior part of dlog_Q (shared_partials_kernel): functions of the inputs only,
 // formed by the chain's first head while it waits for its strips.
 template <int NW>
-__device__ __noinline__ void tiny_chain_part(const TinyArgs &a, const int s, double *red) {
+__device__ __noinline__ void tiny_chain_part(const TinyArgs &a_mem, const int s, double *red) {
+    const TinyArgs a = a_mem;       // private copy: `a_mem` lives in device memory, and behind a reference the compiler must re-read every
+                                    // pointer of it after every store (two dependent trips to L2 per operand instead of one)
     constexpr int NTHR = 64 * NW;
     const int tid = threadIdx.x;
     const int T = a.T, D = a.D, Dl = a.Dl, J = a.Ydim;
@@ -379,7 +381,8 @@ __device__ __noinline__ void tiny_chain_part(const TinyArgs &a, const int s, dou
 // Everything of unit u is in memory.  The workgroup that completes a chain forms that chain's sums; the one that completes the
 // launch assembles the result.
 template <int NW>
-__device__ __noinline__ void tiny_unit_done(const TinyArgs &a, const int u, double *lds, const TinyLds &L) {
+__device__ __noinline__ void tiny_unit_done(const TinyArgs &a_mem, const int u, double *lds, const TinyLds &L) {
+    const TinyArgs a = a_mem;       // (private copy: see tiny_chain_part)
     constexpr int NTHR = 64 * NW;
     const int tid = threadIdx.x;
     const int s = u / a.Dl;
@@ -391,6 +394,8 @@ __device__ __noinline__ void tiny_unit_done(const TinyArgs &a, const int u, doub
     const int pstride = tiny_pstride(Mp), qstride = tiny_qstride(Mp), ntl = tiny_ntl(a.NT);
     if (a.grad) {
         // ---- unit totals of the backward pass: dl/dZ (K_fu side + K_uu side), dl/dloglengthscales, dl/dlogvariance part --------
+        // (every sum over strips / units / chains below is unrolled by eight: not unrolled, each iteration waited for its own load --
+        //  one L2 latency per addend, 20 us for the 40 units of ten chains)
         const int dl = u % Dl, dg = a.d_begin + dl;
         const double *Qu = a.Qp + (size_t)u * nst * qstride;
         double *uo = a.unit_out + (size_t)u * (M * P + P + 2);
@@ -398,6 +403,7 @@ __device__ __noinline__ void tiny_unit_done(const TinyArgs &a, const int u, doub
         double *etx = lds + L.mat;                   // [P][Mp]
         for (int idx = tid; idx < (P + 1) * Mp; idx += NTHR) {
             double v = 0.0;
+#pragma unroll 8
             for (int st = 0; st < nst; ++st) v += Qu[(size_t)st * qstride + idx];
             if (idx < Mp) cs[idx] = v;
             else etx[idx - Mp] = v;
@@ -419,8 +425,10 @@ __device__ __noinline__ void tiny_unit_done(const TinyArgs &a, const int u, doub
         if (tid < P) {
             const double len = exp(a.loglen[(size_t)dg * P + tid]), inv2 = 1.0 / (len * len);
             double v = 0.0;
+#pragma unroll 8
             for (int st = 0; st < nst; ++st) v += Qu[(size_t)st * qstride + 16 * Mp + tid];      // sum_t r_t x_tp^2
             double k2 = 0.0;
+#pragma unroll 8
             for (int rb = 0; rb < a.NT; ++rb) k2 += a.kuu_part[((size_t)u * a.NT + rb) * (TPP + 1) + tid];
 #pragma unroll
             for (int p = 0; p < TPP; ++p)
@@ -428,7 +436,9 @@ __device__ __noinline__ void tiny_unit_done(const TinyArgs &a, const int u, doub
         }
         if (tid == 0) {
             double v = 0.0;
+#pragma unroll 8
             for (int st = 0; st < nst; ++st) v += Qu[(size_t)st * qstride + 16 * Mp + 8];         // sum E
+#pragma unroll 8
             for (int rb = 0; rb < a.NT; ++rb) v += a.kuu_part[((size_t)u * a.NT + rb) * (TPP + 1) + TPP];
             acc[TPP] = v;
         }
@@ -438,7 +448,9 @@ __device__ __noinline__ void tiny_unit_done(const TinyArgs &a, const int u, doub
             if (tid == p && p < P) uo[M * P + p] = acc[p];
         if (tid == 0) uo[M * P + P] = acc[TPP];
     }
+    TSTAMP(12);
     if (tiny_arrive(cx.cchain, slot) != Dl - 1) return;
+    TSTAMP(13);
     // ---- chain s is complete: its likelihood / transition / trace sums (chain_reduce_kernel), prior_x_0 ------------------------
     {
         double v[3] = {0.0, 0.0, 0.0};
@@ -457,43 +469,48 @@ __device__ __noinline__ void tiny_unit_done(const TinyArgs &a, const int u, doub
     }
     if (a.grad) {
         // ---- dl/dX of the chain (dx_kernel) and the likelihood gradients (shared_partials_kernel) ------------------------------
-        const double *Xs = a.X + (size_t)s * (T + 1) * D;
-        double *gX = a.dX + (size_t)s * (T + 1) * D;
-        const double Tn = (double)T, Sn = (double)a.S_total;
-        const int row = P + 1;
-        for (int idx = tid; idx < (T + 1) * D; idx += NTHR) {
+        TSTAMP(30);
+        // (dX holds the input-only part already: the strips formed it while they waited for W.  What the backward pass adds, per
+        //  element: -1/T of the sum over the local kernels of dl/dx_comb (rows t < T) and, for the unit's own latent dim, +-1/T
+        //  dl/ddelta of the two transitions the state takes part in.  Clamped unconditional loads, four elements per thread in flight:
+        //  as first written -- everything in this one loop, loads behind branches -- it was 44 us of dependent trips to L2.)
+        double *__restrict__ gX = a.dX + (size_t)s * (T + 1) * D;
+        const double *__restrict__ dxc = a.dxc + (size_t)s * Dl * Tp * (P + 1);
+        const double iT = 1.0 / (double)T, iS = 1.0 / (double)a.S_total;
+        const int row = P + 1, nel = (T + 1) * D, d_begin = a.d_begin;
+        auto elem = [&](const int idx) -> double {
             const int t = idx / D, d = idx % D;
-            double g = 0.0;
-            for (int dl = 0; dl < Dl; ++dl) {
-                const double *du = a.dxc + (size_t)(s * Dl + dl) * Tp * row;
-                if (t < T) g += -du[(size_t)t * row + d] / Tn;                          // -dl/dx_comb through every local kernel
-                if (a.d_begin + dl == d) {
-                    const double Q = exp(a.log_Q[d]);
-                    if (t < T) {
-                        const double dlt = Xs[(size_t)(t + 1) * D + d] - Xs[(size_t)t * D + d];
-                        g += du[(size_t)t * row + P] / Tn - dlt / Q / Tn;               // delta_t = x_{t+1} - x_t
-                    }
-                    if (t > 0) {
-                        const double dlt = Xs[(size_t)t * D + d] - Xs[(size_t)(t - 1) * D + d];
-                        g += -du[(size_t)(t - 1) * row + P] / Tn + dlt / Q / Tn;
-                    }
-                }
+            const int tc = (t < T) ? t : T - 1, tm = (t > 0) ? t - 1 : 0;
+            const int dl_own = d - d_begin;
+            const bool own = dl_own >= 0 && dl_own < Dl;
+            const double *__restrict__ du = dxc + (size_t)(own ? dl_own : 0) * Tp * row;
+            const double g0 = gX[idx], dn = du[(size_t)tc * row + P], dp = du[(size_t)tm * row + P];
+            double dcomb = 0.0;
+#pragma unroll 4
+            for (int dl = 0; dl < Dl; ++dl) dcomb += dxc[((size_t)dl * Tp + tc) * row + d];
+            double g = g0;
+            g -= (t < T) ? dcomb * iT : 0.0;
+            g += (own && t < T) ? dn * iT : 0.0;
+            g -= (own && t > 0) ? dp * iT : 0.0;
+            return g * iS;
+        };
+        for (int base = tid; base < nel; base += 4 * NTHR) {
+            double g4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = base + q * NTHR;
+                g4[q] = elem(idx < nel ? idx : nel - 1);
             }
-            if (a.shared_terms) {
-                if (t > 0)
-                    for (int j = 0; j < J; ++j) {
-                        double ym = a.DD[j];
-                        for (int dd = 0; dd < D; ++dd) ym += Xs[(size_t)t * D + dd] * a.CC[(size_t)dd * J + j];
-                        const double R = exp(a.logR[j]);
-                        const double r = (a.Y[(size_t)(t - 1) * J + j] - ym) / R;
-                        g += -(r / R) * a.CC[(size_t)d * J + j] / Tn;
-                    }
-                if (t == 0) g += Xs[d] / Tn;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = base + q * NTHR;
+                if (idx < nel) gX[idx] = g4[q];
             }
-            gX[idx] = g / Sn;
         }
     }
+    TSTAMP(14);
     if (tiny_arrive(cx.call, slot) != a.S - 1) return;
+    TSTAMP(15);
     // ---- the launch is complete: nll assembly, shared-parameter gradients, flags re-armed ----------------------------------------
     {
         const FinalizeArgs fa = tiny_finalize_args(a);
@@ -508,6 +525,7 @@ __device__ __noinline__ void tiny_unit_done(const TinyArgs &a, const int u, doub
         const int S = a.S, ustride = M * P + P + 2;
         for (int idx = tid; idx < M * P; idx += NTHR) {                       // grad_dz_kernel
             double acc = 0.0;
+#pragma unroll 8
             for (int uu = 0; uu < a.nunits; ++uu) acc += a.unit_out[(size_t)uu * ustride + idx];
             double g = -acc / Tn / Sn;
             if (a.shared_terms && a.prior_type == 1) g += wgt * a.Z[idx] / Tn;
@@ -518,6 +536,7 @@ __device__ __noinline__ void tiny_unit_done(const TinyArgs &a, const int u, doub
             double g = 0.0;
             if (dl >= 0 && dl < Dl) {
                 double acc = 0.0;
+#pragma unroll 8
                 for (int ss = 0; ss < S; ++ss) acc += a.unit_out[(size_t)(ss * Dl + dl) * ustride + M * P + p];
                 g = (a.kind != 0) ? 0.0 : -acc / Tn / Sn + wgt * a.loglen[idx] / Tn;
             }
@@ -529,6 +548,7 @@ __device__ __noinline__ void tiny_unit_done(const TinyArgs &a, const int u, doub
             if (dl >= 0 && dl < Dl) {
                 const double alpha = 1.0 / exp(a.log_Q[d]), s2 = exp(a.logvar[d]);
                 double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+#pragma unroll 8
                 for (int ss = 0; ss < S; ++ss) {
                     const size_t bb = (size_t)ss * Dl + dl;
                     v0 += a.unit_out[bb * ustride + M * P + P] - 0.5 * alpha * s2 * Tn;
@@ -546,6 +566,7 @@ __device__ __noinline__ void tiny_unit_done(const TinyArgs &a, const int u, doub
             if (a.shared_terms) {
                 if (idx < D * J + 2 * J) {
                     double acc = 0.0;
+#pragma unroll 8
                     for (int ss = 0; ss < S; ++ss) acc += a.chain_part[(size_t)ss * a.sp_stride + idx];
                     acc /= Sn;
                     if (idx < D * J) g = acc + wgt * a.CC[idx] / Tn;
@@ -565,8 +586,9 @@ __device__ __noinline__ void tiny_unit_done(const TinyArgs &a, const int u, doub
 //   Psi = 1/2 W N2 W^T (dl/dK_uu),  N2 = N - (H - I),  E_u = Psi o K(Z,Z),  its row sums and E_u Z  ->  rows of dl/dZ, partials of
 //   dl/dloglengthscales, dl/dlogvariance.  ZO = [1 | Z] rows in LDS; three 16-row patches of the strip matrix area.
 template <int NW>
-__device__ __noinline__ void tiny_kuu_rows(const TinyArgs &a, const int u, const int rb, double *Ks, const double *ZO, const double *ilen,
+__device__ __noinline__ void tiny_kuu_rows(const TinyArgs &a_mem, const int u, const int rb, double *Ks, const double *ZO, const double *ilen,
                                            const double var) {
+    const TinyArgs a = a_mem;       // (private copy: see tiny_chain_part)
     constexpr int NTHR = 64 * NW;
     const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1157,6 +1179,38 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void tiny_kernel(const Ti
     }
     wave_lds_order();
     TSTAMP(1);
+    if (a.grad) {
+        // The part of dl/dX that is a function of the inputs alone -- likelihood (:248-250,264), transition prior (:283-284), prior_x_0
+        // (:252) -- for this strip's rows, while it would otherwise wait for W: column dg (the unit's own latent dim; the chain's first
+        // unit also takes the columns no unit of this handle owns), unscaled, straight into dX.  The chain's closer adds what comes
+        // out of the backward pass (tiny_unit_done); as one loop there it was 22 us of dependent trips to L2 behind the last strip.
+        const double iT = 1.0 / (double)T, iQT = iT / Qd;
+        const int J = a.Ydim, ncols = 1 + ((dl == 0) ? D - Dl : 0);
+        const int rows = SR + ((strip == nst - 1) ? 1 : 0);                   // (row T when T is a whole number of strips)
+        double *gXs = a.dX + (size_t)s * (T + 1) * D;
+        for (int item = tid; item < rows * ncols; item += NTHR) {
+            const int r = item / ncols, ci = item % ncols, t = t0 + r;
+            if (t > T) continue;
+            const int d = (ci == 0) ? dg : ((ci - 1 < a.d_begin) ? ci - 1 : ci - 1 + Dl);
+            double g = 0.0;
+            if (ci == 0) {
+                const double x1 = Xs[(size_t)t * D + d];
+                if (t < T) g -= (Xs[(size_t)(t + 1) * D + d] - x1) * iQT;     // delta_t = x_{t+1} - x_t
+                if (t > 0) g += (x1 - Xs[(size_t)(t - 1) * D + d]) * iQT;
+            }
+            if (a.shared_terms) {
+                if (t > 0)
+                    for (int j = 0; j < J; ++j) {
+                        double ym = a.DD[j];
+                        for (int dd = 0; dd < D; ++dd) ym += Xs[(size_t)t * D + dd] * a.CC[(size_t)dd * J + j];
+                        const double R = exp(a.logR[j]);
+                        g -= (a.Y[(size_t)(t - 1) * J + j] - ym) * (iT / (R * R)) * a.CC[(size_t)d * J + j];
+                    }
+                else g += Xs[d] * iT;
+            }
+            gXs[(size_t)t * D + d] = g;
+        }
+    }
     // ==========================================================================================================================
     // strip, phase 1:  F = K_fu W (:242), F^T F, F^T delta, sum F^2 (:255), chain-term partials
     // ==========================================================================================================================
