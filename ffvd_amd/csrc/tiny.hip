@@ -412,35 +412,43 @@ __device__ __noinline__ void tiny_unit_done(const TinyArgs &a_mem, const int u, 
         double acc[TPP + 1];
 #pragma unroll
         for (int p = 0; p <= TPP; ++p) acc[p] = 0.0;
+        // (the per-component sums over strips / row blocks go to threads at the TOP of the workgroup -- another wavefront than the
+        //  rows of Z whenever M leaves one free -- so that their two rounds of loads run beside the m loop's instead of behind it)
+        const int tp = NTHR - 1 - tid;
+        if (tp < P) {
+            const double len = exp(a.loglen[(size_t)dg * P + tp]), inv2 = 1.0 / (len * len);
+            double v = 0.0, k2 = 0.0;
+#pragma unroll 8
+            for (int st = 0; st < nst; ++st) v += Qu[(size_t)st * qstride + 16 * Mp + tp];       // sum_t r_t x_tp^2
+#pragma unroll 8
+            for (int rb = 0; rb < a.NT; ++rb) k2 += a.kuu_part[((size_t)u * a.NT + rb) * (TPP + 1) + tp];
+#pragma unroll
+            for (int p = 0; p < TPP; ++p)
+                if (tp == p) acc[p] += v * inv2 + k2;                        // (compile-time indices: the array stays in registers)
+        }
+        if (tp == 8) {
+            double v = 0.0, k2 = 0.0;
+#pragma unroll 8
+            for (int st = 0; st < nst; ++st) v += Qu[(size_t)st * qstride + 16 * Mp + 8];         // sum E
+#pragma unroll 8
+            for (int rb = 0; rb < a.NT; ++rb) k2 += a.kuu_part[((size_t)u * a.NT + rb) * (TPP + 1) + TPP];
+            acc[TPP] = v + k2;
+        }
+        double inv2p[TPP];
+#pragma unroll
+        for (int p = 0; p < TPP; ++p) {
+            const double len = (p < P) ? exp(a.loglen[(size_t)dg * P + p]) : 1.0;
+            inv2p[p] = 1.0 / (len * len);
+        }
         for (int m = tid; m < M; m += NTHR) {
 #pragma unroll
             for (int p = 0; p < TPP; ++p)
                 if (p < P) {
-                    const double len = exp(a.loglen[(size_t)dg * P + p]), inv2 = 1.0 / (len * len);
+                    const double inv2 = inv2p[p];
                     const double z = a.Z[(size_t)m * P + p], e = etx[p * Mp + m];
                     uo[m * P + p] = (e - z * cs[m]) * inv2 + a.dz2[((size_t)u * Mp + m) * TPP + p];
                     acc[p] += (-2.0 * e * z + cs[m] * z * z) * inv2;
                 }
-        }
-        if (tid < P) {
-            const double len = exp(a.loglen[(size_t)dg * P + tid]), inv2 = 1.0 / (len * len);
-            double v = 0.0;
-#pragma unroll 8
-            for (int st = 0; st < nst; ++st) v += Qu[(size_t)st * qstride + 16 * Mp + tid];      // sum_t r_t x_tp^2
-            double k2 = 0.0;
-#pragma unroll 8
-            for (int rb = 0; rb < a.NT; ++rb) k2 += a.kuu_part[((size_t)u * a.NT + rb) * (TPP + 1) + tid];
-#pragma unroll
-            for (int p = 0; p < TPP; ++p)
-                if (tid == p) acc[p] += v * inv2 + k2;                       // (compile-time indices: the array stays in registers)
-        }
-        if (tid == 0) {
-            double v = 0.0;
-#pragma unroll 8
-            for (int st = 0; st < nst; ++st) v += Qu[(size_t)st * qstride + 16 * Mp + 8];         // sum E
-#pragma unroll 8
-            for (int rb = 0; rb < a.NT; ++rb) v += a.kuu_part[((size_t)u * a.NT + rb) * (TPP + 1) + TPP];
-            acc[TPP] = v;
         }
         tiny_sum<TPP + 1, NW>(acc, red);
 #pragma unroll
