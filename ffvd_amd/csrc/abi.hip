@@ -53,6 +53,7 @@ struct ffvd_handle {
     struct Switches {
         bool fused_project = false, grad_explicit = false, no_defer_trace = false, no_late_join = false;
         bool no_main_first = false, no_kfu_first = false, atb128 = false, grad_serial = false, kuu_flow = true, kinv_gram = false, chain_rl = false;
+        int small_side_rows = 32;         // FFVD_SMALL_SIDE_ROWS: block rows of the K_uu chain (Dl * 2 * Mp / 64) up to which the side chain is ONE dataflow launch
         int small_side_wgs = 512;         // FFVD_SMALL_SIDE_WGS: tile-pass workgroups (one round of the chip) up to which an iteration counts as tiny (see small_side)
         bool no_small_side = false;       // FFVD_NO_SMALL_SIDE=1: tiny iterations keep the launch-per-step K_uu chain (round 2)
         bool ref_row_in_gram = false;     // FFVD_REF_ROW_IN_GRAM=1: reference route, delta^T F formed by the Gram kernel's diagonal tiles (rounds 1-2)
@@ -211,7 +212,7 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
         w.fused_project = on("FFVD_FUSED_PROJECT");   w.grad_explicit = on("FFVD_GRAD_EXPLICIT");
         w.no_defer_trace = on("FFVD_NO_DEFER_TRACE"); w.no_late_join = on("FFVD_NO_LATE_JOIN");
         w.no_main_first = on("FFVD_NO_MAIN_FIRST");   w.no_kfu_first = on("FFVD_NO_KFU_FIRST");
-        w.whiten_products = on("FFVD_GRAD_WHITEN_PRODUCTS");   w.lt_armed = on("FFVD_GRAD_LT_ARMED");   w.no_small_side = on("FFVD_NO_SMALL_SIDE");   if (const char *e = getenv("FFVD_SMALL_SIDE_WGS")) w.small_side_wgs = atoi(e);   w.ref_row_in_gram = on("FFVD_REF_ROW_IN_GRAM");   w.no_ref_side = on("FFVD_NO_REF_SIDE");   w.no_linear_lowrank = on("FFVD_NO_LINEAR_LOWRANK");
+        w.whiten_products = on("FFVD_GRAD_WHITEN_PRODUCTS");   w.lt_armed = on("FFVD_GRAD_LT_ARMED");   w.no_small_side = on("FFVD_NO_SMALL_SIDE");   if (const char *e = getenv("FFVD_SMALL_SIDE_WGS")) w.small_side_wgs = atoi(e);   if (const char *e = getenv("FFVD_SMALL_SIDE_ROWS")) w.small_side_rows = atoi(e);   w.ref_row_in_gram = on("FFVD_REF_ROW_IN_GRAM");   w.no_ref_side = on("FFVD_NO_REF_SIDE");   w.no_linear_lowrank = on("FFVD_NO_LINEAR_LOWRANK");
         w.kuu_flow = !on("FFVD_NO_KUU_FLOW");   w.kinv_gram = on("FFVD_KINV_GRAM");   w.chain_rl = on("FFVD_CHAIN_RL");
         w.atb128 = on("FFVD_ATB128");                 w.grad_serial = on("FFVD_GRAD_SERIAL");
         w.debug_sync = on("FFVD_DEBUG_SYNC");
@@ -648,7 +649,7 @@ static ElboSchedule plan_schedule(const ffvd_handle *h) {
     sc.reduce_early = sc.gram_route && on_side;
     sc.small_side = sc.defer_trace && sc.main_first && !c.grad && !kuu_on_main && on_side && !h->sw.chain_rl && !h->sw.no_small_side &&
                     (size_t)sc.first_units * h->ntiles * (h->gsplit > 1 ? h->gsplit : 1) <= (size_t)h->sw.small_side_wgs &&
-                    (size_t)Dl * 2 * (Mp / NB) <= 32;
+                    (size_t)Dl * 2 * (Mp / NB) <= (size_t)h->sw.small_side_rows;
     sc.chain_flow_here = !kuu_on_main && (!on_side || sc.small_side) && potrf_flow_selected(Mp, Dl, CHOL_FLOW) && !h->sw.chain_rl;
     // invariants the launch code relies on (a violated one would be a silent wrong answer, not a crash)
     if ((sc.defer_full && sc.late_join) || (sc.defer_trace && !sc.late_join) || (sc.kuu_flow && sc.defer_full) || (sc.small_side && sc.kuu_flow) ||
