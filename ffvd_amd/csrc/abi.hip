@@ -650,6 +650,10 @@ static ElboSchedule plan_schedule(const ffvd_handle *h) {
     sc.small_side = sc.defer_trace && sc.main_first && !c.grad && !kuu_on_main && on_side && !h->sw.chain_rl && !h->sw.no_small_side &&
                     (size_t)sc.first_units * h->ntiles * (h->gsplit > 1 ? h->gsplit : 1) <= (size_t)h->sw.small_side_wgs &&
                     (size_t)Dl * 2 * (Mp / NB) <= (size_t)h->sw.small_side_rows;
+    // (Round 4, measured and not kept: at 8-16 chains the side chain -- a dozen dependent right-looking launches -- is starved of slots by
+    //  the tile pass and its tail ends 0.14 ms behind Cholesky(A).  As ONE dataflow launch beside the K_fu build it holds its slots
+    //  against the tile pass instead: that pass 1.43 instead of 1.18 ms at 16 chains, the iteration 1.91 either way; a main stream whose
+    //  CU mask leaves 8-32 compute units to the side stream runs 1.2 x slower; `small_side` widened to these sizes: 1.19 vs 1.14 ms at 8.)
     sc.chain_flow_here = !kuu_on_main && (!on_side || sc.small_side) && potrf_flow_selected(Mp, Dl, CHOL_FLOW) && !h->sw.chain_rl;
     // invariants the launch code relies on (a violated one would be a silent wrong answer, not a crash)
     if ((sc.defer_full && sc.late_join) || (sc.defer_trace && !sc.late_join) || (sc.kuu_flow && sc.defer_full) || (sc.small_side && sc.kuu_flow) ||
