@@ -2638,17 +2638,18 @@ extern "C" int ffvd_op_rollout(int kind, const double *Lm_inverse_seq, const dou
                                          steps, xbuf[t & 1], xbuf[(t + 1) & 1], dpx, dpv);
         }
     };
-    // Round 4: the whole loop as ONE persistent launch whose workgroups walk the same three phases per step and meet
-    // at a grid-wide barrier in between (loops.hip; the same kernel bodies: bit-identical).  MEASURED SLOWER -- 64.7 against 32.7 us per
-    // step at 32 rollouts, 148 against 48 at 100: a grid-wide barrier of 256 workgroups costs ~15 us on this chip (every workgroup's
-    // agent-scope release writes back its XCD's L2), three times what the kernel boundary it replaces costs -- so it is opt-in:
+    // Round 4: the whole loop as ONE persistent launch (loops.hip; the same kernel bodies: bit-identical) -- first
+    // with a grid-wide barrier between the phases (64.7 against 32.7 us per step at 32 rollouts: 160-512 workgroups on one counter),
+    // then with one role per workgroup and per-unit counters (40.3 against 36.0; 93 against 57 at 100 rollouts).  MEASURED SLOWER both
+    // times: ~170 agent-scope releases / acquires per step cost more than the three kernel boundaries they replace -- so it is opt-in:
     // FFVD_STEP_LOOP=1.
     const char *nsl = getenv("FFVD_STEP_LOOP");
     const bool use_loop = skinny && nsl && *nsl && strcmp(nsl, "0") != 0;
     if (use_loop) {
-        int32_t *words = sc.alloc<int32_t>(4);
+        const int nwords = loop_words(D);
+        int32_t *words = sc.alloc<int32_t>(nwords);
         OP_CHECK(words, "ffvd_op_rollout");
-        HIP_TRY(hipMemsetAsync(words, 0, 4 * sizeof(int32_t), sc.stream));
+        HIP_TRY(hipMemsetAsync(words, 0, (size_t)nwords * sizeof(int32_t), sc.stream));
         RolloutLoopArgs la{};
         la.pa = pa;
         la.sk = SkinnyArgs{Kf, (size_t)Tp * Mp, Mp, dW, (size_t)Mp * Mp, Mp, 1, R, Mp, Mp, D, Tp, nullptr, 0, 0, ucol, (size_t)Mp, rowsq, fmean,
@@ -2742,13 +2743,14 @@ extern "C" int ffvd_op_pg_sweep(int kind, const double *Lm_inverse_seq, const do
         }
     };
     // Round 4: ONE persistent launch for the sweep (loops.hip), three grid-wide barriers per step instead of four dependent launches:
-    // measured slower (151 against 37 us per step, see ffvd_op_rollout), opt-in with FFVD_STEP_LOOP=1
+    // measured slower (86 against 43 us per step with roles and per-unit counters, 151 with a grid-wide barrier; see ffvd_op_rollout), opt-in with FFVD_STEP_LOOP=1
     const char *nsl = getenv("FFVD_STEP_LOOP");
     const bool use_loop = skinny && nsl && *nsl && strcmp(nsl, "0") != 0;
     if (use_loop) {
-        int32_t *words = sc.alloc<int32_t>(4);
+        const int nwords = loop_words(D);
+        int32_t *words = sc.alloc<int32_t>(nwords);
         OP_CHECK(words, "ffvd_op_pg_sweep");
-        HIP_TRY(hipMemsetAsync(words, 0, 4 * sizeof(int32_t), sc.stream));
+        HIP_TRY(hipMemsetAsync(words, 0, (size_t)nwords * sizeof(int32_t), sc.stream));
         PgLoopArgs la{};
         la.pa = pa;
         la.sk = SkinnyArgs{Kf, (size_t)Tp * Mp, Mp, dW, (size_t)Mp * Mp, Mp, 1, R, Mp, Mp, D, Tp, nullptr, 0, 0, ucol, (size_t)Mp, rowsq, fmean,

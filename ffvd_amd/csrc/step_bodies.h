@@ -340,7 +340,7 @@ struct RolloutLoopArgs {
     int R, C, steps;
     double *xbuf0, *xbuf1;          // the R x (D + C) input rows of step t live in xbuf[t & 1]
     double *predict_x, *predict_var;
-    unsigned *bar;                  // barrier counter, zero before the launch
+    unsigned *bar;                  // counter block (loop_words ints), zero before the launch
     int *abort_w;                   // zero before the launch; non-zero afterwards: a wait gave up, the results are incomplete
 };
 struct PgLoopArgs {
@@ -354,6 +354,7 @@ struct PgLoopArgs {
     unsigned *bar;
     int *abort_w;
 };
+int loop_words(int nb);          // ints of the counter block (`bar`; abort word = bar[1]) for nb units, zero before the launch
 void launch_rollout_loop(hipStream_t stream, const RolloutLoopArgs &a);
 void launch_pg_loop(hipStream_t stream, const PgLoopArgs &a);
 
