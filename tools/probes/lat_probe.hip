@@ -225,6 +225,44 @@ __global__ void probe_kbuild(double *out, long long *t, int n) {
     out[tid & 63] = Am[tid];
     if (tid == 0) t[0] = t1 - t0;
 }
+// cost of the hand-off primitives for ONE workgroup on an otherwise idle chip: n rounds of (256 plain 8-byte stores; release; relaxed
+// atomic add) -- and the same with sc1 write-through stores and no fence -- and n rounds of (acquire; 256 loads)
+template <int MODE>
+__global__ void probe_fence(double *buf, int *word, long long *t, int n) {
+    const int tid = threadIdx.x;
+    typedef __attribute__((address_space(1))) double gdouble;
+    long long t0 = wall_clock64();
+    double acc = 0.0;
+    for (int i = 0; i < n; ++i) {
+        if (MODE == 0) {            // plain stores + release + add
+            buf[tid] = i;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_fetch_add(word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else if (MODE == 1) {     // write-through stores, no fence
+            __hip_atomic_store((gdouble *)buf + tid, (double)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {                    // acquire + loads
+            if (tid == 0) {
+                (void)__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+            acc += buf[tid + 256 * (i & 3)];
+        }
+        __syncthreads();
+    }
+    long long t1 = wall_clock64();
+    if (acc == 1.2345e300) buf[0] = acc;
+    if (tid == 0) t[0] = t1 - t0;
+}
 int main() {
     double *out; long long *t;
     hipMalloc(&out, 64 * 8); hipMalloc(&t, 4 * 8);
@@ -254,5 +292,11 @@ int main() {
 #define RUNK(M, label) hipLaunchKernelGGL((probe_kbuild<M>), dim3(1), dim3(256), 0, 0, out, t, 64); hipDeviceSynchronize(); \
     hipMemcpy(h, t, sizeof(h), hipMemcpyDeviceToHost); printf("K build element loop (28 elements per thread, 256 threads), %s: %.2f us per pass = %.1f ns per element per wavefront\n", label, h[0] * tick / 64.0 / 1000.0, h[0] * tick / 64.0 / 28.0);
     RUNK(0, "exp_kernel") RUNK(1, "library exp") RUNK(2, "no exp")
+    {
+        double *fb; int *fw; hipMalloc(&fb, 2048 * 8); hipMalloc(&fw, 64); hipMemset(fb, 0, 2048 * 8); hipMemset(fw, 0, 64);
+#define RUNF(M, label) hipLaunchKernelGGL((probe_fence<M>), dim3(1), dim3(256), 0, 0, fb, fw, t, 2000); hipDeviceSynchronize(); \
+        hipMemcpy(h, t, sizeof(h), hipMemcpyDeviceToHost); printf("hand-off primitive, %s: %.2f us per round\n", label, h[0] * tick / 2000.0 / 1000.0);
+        RUNF(0, "2 KB of plain stores + agent-scope release + atomic add") RUNF(1, "2 KB of sc1 write-through stores + atomic add, no fence") RUNF(2, "atomic load + agent-scope acquire + 2 KB of loads")
+    }
     return 0;
 }
