@@ -1141,6 +1141,8 @@ struct DfArgs {
     double *kinv;      // optional (identity rows = all of L^-T): (A)^-1 = L^-T L^-1, full symmetric n x n per slab (ld n), formed by
     size_t kinv_stride;//   the identity-row workgroups once their rows are complete (df_inverse_tiles)
     int defer_ext;     // block order: identity-structured rows of all groups behind the main rows of all groups (potrf_df_kernel)
+    int fine;          // small batches (every block row on a CU of its own): a main row also announces every COLUMN it has solved
+                       // (word 2 nb + row), and a gather waits term by term -- see df_column
     const double *lt;  // optional: the identity-structured extra rows of slab b start as L_d^T (d = b % lt_dl) instead of what
     size_t lt_stride;  //   memory holds: block (e, j) = L_d(j, e)^T, read from the lower-triangular n x n factor L_d (ld n)
     int lt_dl;
@@ -1229,8 +1231,18 @@ __device__ __forceinline__ bool df_column(const DfArgs &a, double *S, int *pg, c
         }
     int seen = -2;
     if (j > k0) {
-        seen = df_wait(pg + j, j, a.abort_w, &wslot[wc++ & 1]);          // the panels of block row j are in memory
-        if (seen < 0) return false;
+        // fine: term k of the gather needs tile (j, k) of block row j only -- in memory as soon as that row has solved its column k,
+        // long before it has announced all of them (the last column of a late row otherwise starts its r - 1 terms, 5 us each, only
+        // when the row above has finished its own: 30 us in front of row 7's factor where rows 1-4 need 7, tools/df_trace.py)
+        int *pc = pg + 2 * a.nb + j;
+        int have = 0;                                                        // columns of row j known to be in memory
+        if (a.fine) {
+            have = df_wait(pc, k0 + 1, a.abort_w, &wslot[wc++ & 1]);
+            if (have < 0) return false;
+        } else {
+            seen = df_wait(pg + j, j, a.abort_w, &wslot[wc++ & 1]);          // the panels of block row j are in memory
+            if (seen < 0) return false;
+        }
         DF_STAMP(trow, 5 * (j & 7) + 1);
         d2 vx[8], vl[8];
         auto gload = [&](int k) {
@@ -1249,7 +1261,13 @@ __device__ __forceinline__ bool df_column(const DfArgs &a, double *S, int *pg, c
                 Xs[sr + 8 * i][sc] = vx[i].x; Xs[sr + 8 * i][sc + 1] = vx[i].y;
             }
             __syncthreads();
-            if (k + 1 < j) gload(k + 1);                    // in flight behind this step's MFMAs
+            if (k + 1 < j) {
+                if (a.fine && have < k + 2) {
+                    have = df_wait(pc, k + 2, a.abort_w, &wslot[wc++ & 1]);
+                    if (have < 0) return false;
+                }
+                gload(k + 1);                               // in flight behind this step's MFMAs
+            }
 #pragma unroll 4
             for (int ks = 0; ks < NB / 4; ++ks) {
                 double bl[2], ax[2], bx[2];
@@ -1349,7 +1367,13 @@ __device__ __forceinline__ bool df_column(const DfArgs &a, double *S, int *pg, c
         // X(r,j) is in sm0 for everyone; the global stores stay in flight (the caller waits for them in front of the barrier
         // that publishes them): a barrier that orders the LDS traffic only
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    } else __syncthreads();                                // sm0 / sm1 are free for the next column
+    } else {
+        if (a.fine && row0 < n) {                          // main row: column j of it is in memory -- say so
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 64) df_publish(pg + 2 * a.nb + row0 / NB, j + 1);
+        } else __syncthreads();                            // sm0 / sm1 are free for the next column
+    }
     DF_STAMP(trow, 5 * (j & 7) + 4);
     return true;
 }
@@ -1610,7 +1634,10 @@ __global__ __launch_bounds__(256, 2) void potrf_df_kernel(DfArgs a) {
     double (*Lr)[LR_LD] = reinterpret_cast<double(*)[LR_LD]>(sm0);
     DF_STAMP(trow, 48);
     // the panels of this row are published by wavefront 1 while wavefront 0 runs the pivot chain
-    if (ncols > 0 && tid == 64) df_publish(pg + ri, ri);
+    if (ncols > 0 && tid == 64) {
+        df_publish(pg + ri, ri);
+        if (a.fine) __hip_atomic_store(pg + 2 * nb + ri, ri, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (behind the release above)
+    }
     diag_block_finish<PIPE>(Ts, Lr, invd, S, n, row0, a.info + b, dvb + (size_t)ri * DF_DINV, DF_MFMA_FACTOR ? Dv : nullptr);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -1668,6 +1695,8 @@ static void launch_potrf_flow(hipStream_t stream, double *A, int n, int extra_ro
     // a pivot chain that shares its SIMD with another row's MFMA loop takes up to twice as long (tools/df_trace.py)
     static const int pad_mode = [] { const char *e = getenv("FFVD_DF_PAD"); return e ? atoi(e) : -1; }();
     const bool alone = (pad_mode >= 0) ? (pad_mode != 0) : ((size_t)batch * R <= 256);
+    static const int fine_mode = [] { const char *e = getenv("FFVD_DF_FINE"); return e ? atoi(e) : -1; }();
+    a.fine = ((fine_mode >= 0 ? fine_mode != 0 : alone) && 3 * a.nb <= DF_PS) ? 1 : 0;
     hipLaunchKernelGGL(potrf_df_kernel<true>, dim3((unsigned)((size_t)groups * R * a.G)), dim3(256), alone ? 16384 : 0, stream, a);
 }
 
