@@ -1198,7 +1198,11 @@ __device__ __forceinline__ void df_publish(int *flag, int value) {
 // One block column of one block row: X(r,j) = (A(r,j) - sum_{k0<=k<j} X(r,k) L(j,k)^T) L_jj^-T.  LAST (the column left of
 // the diagonal of a main row) also loads A(r,r), sums X(r,k) X(r,k)^T over k < j into acc_d beside the gather, and leaves the
 // solved tile in sm0 for the newest term.  Returns false when a wait gave up.
-template <bool LAST>
+// EARLY (main rows in the fine mode, columns left of the LAST one): the tile just solved adds its X X^T to acc_d right away, in the
+// time this row would otherwise wait for the next diagonal block, and the LAST column's gather carries L(j,k) terms only -- a late
+// row's last gather is 3.6 us of matrix-pipe time per term with both sums in it, 30 us in front of row 7's factor.  Same terms
+// in the same order: the result does not change by a bit.
+template <bool LAST, bool EARLY = false>
 __device__ __forceinline__ bool df_column(const DfArgs &a, double *S, int *pg, const double *dvb, const int row0, const int j,
                                           const int k0, double (*Xs)[LL_LD], double (*Ls)[LL_LD], double (*Dv)[16][DV_LD],
                                           int *wslot, int &wc, d4 (&cold_d)[2][2], d4 (&acc_d)[2][2], const int trow,
@@ -1210,7 +1214,8 @@ __device__ __forceinline__ bool df_column(const DfArgs &a, double *S, int *pg, c
     const int qr = wave >> 1, qc = wave & 1;
     const int sr = tid >> 5, sc = 2 * (tid & 31);
     const int j0 = j * NB;
-    const bool do_d = LAST && !(qr == 0 && qc == 1);       // the quadrant above the diagonal of S_rr is never read
+    const bool tri = !(qr == 0 && qc == 1);                // the quadrant above the diagonal of S_rr is never read
+    const bool do_d = LAST && tri && a.fine != 1;          // (fine = 1: the earlier columns have added their terms already)
     // this row's own tiles (nobody else writes them): requested first, their latency hides behind the waits and the k loop
     d4 cold_t[2][2], acc_t[2][2];
 #pragma unroll
@@ -1367,8 +1372,32 @@ __device__ __forceinline__ bool df_column(const DfArgs &a, double *S, int *pg, c
         // X(r,j) is in sm0 for everyone; the global stores stay in flight (the caller waits for them in front of the barrier
         // that publishes them): a barrier that orders the LDS traffic only
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    } else if (EARLY) {
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Xs[16 * wave + lr][16 * s4 + 4 * r + lk] = Rt[s4][r];
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 64) df_publish(pg + 2 * a.nb + row0 / NB, j + 1);           // column j of this row is in memory -- say so
+        if (tri) {
+#pragma unroll 4
+            for (int ks = 0; ks < NB / 4; ++ks) {
+                double ax[2], bx[2];
+#pragma unroll
+                for (int x = 0; x < 2; ++x) {
+                    ax[x] = Xs[qr * 32 + 16 * x + lr][4 * ks + lk];
+                    bx[x] = Xs[qc * 32 + 16 * x + lr][4 * ks + lk];
+                }
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                    for (int y = 0; y < 2; ++y) acc_d[x][y] = mfma_f64(ax[x], bx[y], acc_d[x][y]);
+            }
+        }
+        __syncthreads();                                   // sm0 / sm1 are free for the next column
     } else {
-        if (a.fine && row0 < n) {                          // main row: column j of it is in memory -- say so
+        if (a.fine && row0 < n) {                          // (a main row without the early sums: not used by the kernel below)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 64) df_publish(pg + 2 * a.nb + row0 / NB, j + 1);
@@ -1567,16 +1596,31 @@ __global__ __launch_bounds__(256, 2) void potrf_df_kernel(DfArgs a) {
     int wc = 0;
     const int trow = (b == 0) ? ri : -1;
     DF_STAMP(trow, 51);
+    // S_rr = A(r,r) - sum_{k<r} X(r,k) X(r,k)^T (main rows)
+    d4 cold_d[2][2], acc_d[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc_d[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
     {
         const int nplain = main_row ? ncols - 1 : ncols;
         double *xt_row = (a.xt && !main_row && ri - nb < a.nid) ? a.xt + (size_t)b * a.xt_stride + (size_t)(ri - nb) * NB : nullptr;
         const double *lt_src = (a.lt && !main_row && ri - nb < a.nid) ? a.lt + (size_t)(b % a.lt_dl) * a.lt_stride : nullptr;
-        for (int j = k0; j < nplain; ++j) {
-            d4 unused_c[2][2], unused_a[2][2];
-            if (!df_column<false>(a, S, pg, dvb, row0, j, k0, Xs, Ls, Dv, wslot, wc, unused_c, unused_a, trow, xt_row, lt_src,
-                                  ri - nb)) {
-                if (tid == 0 && a.info) a.info[b] = -1;
-                return;
+        if (main_row && a.fine == 1) {
+            for (int j = 0; j < nplain; ++j) {
+                if (!df_column<false, true>(a, S, pg, dvb, row0, j, 0, Xs, Ls, Dv, wslot, wc, cold_d, acc_d, trow)) {
+                    if (tid == 0 && a.info) a.info[b] = -1;
+                    return;
+                }
+            }
+        } else {
+            for (int j = k0; j < nplain; ++j) {
+                d4 unused_c[2][2], unused_a[2][2];
+                if (!df_column<false>(a, S, pg, dvb, row0, j, k0, Xs, Ls, Dv, wslot, wc, unused_c, unused_a, trow, xt_row, lt_src,
+                                      ri - nb)) {
+                    if (tid == 0 && a.info) a.info[b] = -1;
+                    return;
+                }
             }
         }
     }
@@ -1586,12 +1630,6 @@ __global__ __launch_bounds__(256, 2) void potrf_df_kernel(DfArgs a) {
         }
         return;
     }
-    // S_rr = A(r,r) - sum_{k<r} X(r,k) X(r,k)^T
-    d4 cold_d[2][2], acc_d[2][2];
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y) acc_d[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
     if (ncols > 0) {
         if (!df_column<true>(a, S, pg, dvb, row0, ncols - 1, k0, Xs, Ls, Dv, wslot, wc, cold_d, acc_d, trow)) {
             if (tid == 0 && a.info) a.info[b] = -1;
@@ -1696,7 +1734,7 @@ static void launch_potrf_flow(hipStream_t stream, double *A, int n, int extra_ro
     static const int pad_mode = [] { const char *e = getenv("FFVD_DF_PAD"); return e ? atoi(e) : -1; }();
     const bool alone = (pad_mode >= 0) ? (pad_mode != 0) : ((size_t)batch * R <= 256);
     static const int fine_mode = [] { const char *e = getenv("FFVD_DF_FINE"); return e ? atoi(e) : -1; }();
-    a.fine = ((fine_mode >= 0 ? fine_mode != 0 : alone) && 3 * a.nb <= DF_PS) ? 1 : 0;
+    a.fine = ((fine_mode >= 0 ? fine_mode != 0 : alone) && 3 * a.nb <= DF_PS) ? (fine_mode == 2 ? 2 : 1) : 0;    // (2: A/B, no early sums)
     hipLaunchKernelGGL(potrf_df_kernel<true>, dim3((unsigned)((size_t)groups * R * a.G)), dim3(256), alone ? 16384 : 0, stream, a);
 }
 
