@@ -137,6 +137,8 @@ VARIANTS = {
     "r3gram": ["-DGRAM_COMBO=1"],
     # the 64-pivot diagonal factor of the dataflow Cholesky by wavefront 0 alone (round 3) against all four wavefronts (round 4)
     "factor1w": ["-DDF_FACTOR_4W=0"],
+    "factortiles": ["-DDF_FACTOR_ROWS=0"],
+    "dftrace_factortiles": ["-DFFVD_DF_TRACE", "-DDF_FACTOR_ROWS=0"],
     "offdiagglds": ["-DGRAM_GLDS_OFFDIAG=1"],       # off-diagonal Gram tiles staged by LDS-DMA like the pair combos (measured neutral)
     "dftrace_notail": ["-DFFVD_DF_TRACE", "-DGRAM_TAIL_SPLIT=0"],
     # tiny.hip (the one-launch iteration): wall-clock stamps of every workgroup's phases (tools/tiny_trace.py); a build whose
@@ -145,6 +147,8 @@ VARIANTS = {
     "tinystall": ("tiny.hip", ["-DFFVD_TINY_TEST_STALL"]),
     # A/B build: the head does not take row blocks of the K_uu side (tools/dbg_cmp.py diffs the scratch block of two builds)
     "tinynohelp": ("tiny.hip", ["-DFFVD_TINY_NO_HEAD_HELP"]),
+    # A/B build: the blocked Cholesky of the one-launch iteration with tile solves behind every pivot chain (round 4, first form)
+    "tinytiles": ("tiny.hip", ["-DTINY_CHOL_ROWS=0"]),
 }
 
 

@@ -9,6 +9,7 @@
 #include "step_bodies.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -147,6 +148,7 @@ struct ffvd_handle {
     int train_S_total = 0;
     bool stalled = false;       // check_info saw info = -1: the dataflow Cholesky gave up on a bounded wait
     int stall_recoveries = 0;   // iterations re-run with the launch-per-column Cholesky after such a stall
+    long long enq_ns = 0, enq_calls = 0;      // host time spent enqueueing iterations (ffvd_debug_enqueue_us: tools)
     std::string warning;        // one-time note about the first recovery (ffvd_last_error returns it while no error is pending)      // > 0: ffvd_train_local has left a backward pass (scaled 1 / S_total) in gw.pack
     // optional live stage timing (HIP events on the handle's stream)
     bool timing_on = false;
@@ -1186,7 +1188,10 @@ static int fetch_with_stall_recovery(ffvd_handle *h, Enqueue enqueue) {
         {
             CholOverrideGuard guard;
             if (attempt == 1) guard.force_left();
+            const auto t0 = std::chrono::steady_clock::now();
             rc = enqueue();
+            h->enq_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+            ++h->enq_calls;
         }
         if (rc) return rc;
         hipError_t e1 = hipMemcpyAsync(h->h_res, h->resblk, h->res_bytes, hipMemcpyDeviceToHost, h->stream);      // terms, chain nll, info flags
@@ -1204,6 +1209,11 @@ static int fetch_with_stall_recovery(ffvd_handle *h, Enqueue enqueue) {
 }
 
 extern "C" int ffvd_stall_recoveries(const ffvd_handle *h) { return h ? h->stall_recoveries : 0; }
+
+// Debug (tools/sync_step.py): average host time of one iteration's enqueue in microseconds, -1 before the first call.
+extern "C" double ffvd_debug_enqueue_us(const ffvd_handle *h) {
+    return (h && h->enq_calls > 0) ? (double)h->enq_ns / (double)h->enq_calls * 1e-3 : -1.0;
+}
 
 extern "C" int ffvd_single_launch(const ffvd_handle *h) { return (h && h->tiny.ok) ? h->tiny.nw : 0; }
 

@@ -348,6 +348,9 @@ constexpr int LR_LD = NB + 2;
 #ifndef DF_FACTOR_4W
 #define DF_FACTOR_4W 1            // the 64-pivot diagonal factor by all four wavefronts (chol64_mfma_4w); 0: wavefront 0 alone (A/B builds)
 #endif
+#ifndef DF_FACTOR_ROWS
+#define DF_FACTOR_ROWS 1          // chol64_mfma_4w: the tiles below a diagonal tile go through its pivot chain (0: tile solves on the matrix cores, A/B builds)
+#endif
 constexpr int DV_LD = 17;       // row stride of the 16 x 16 inverse / scratch tiles (doubles)
 template <bool PIPE>
 __device__ __forceinline__ int chol64_1w(double (&a)[NB], double (*Lr)[LR_LD], double *invd, const int lane) {
@@ -568,6 +571,86 @@ __device__ __forceinline__ int chol64_diag_tile(double (*Ts)[NB + 1], double (*L
     const unsigned long long m = __ballot((lane < 16) & !(diag > 0.0));
     return m ? s0 + (int)__builtin_ctzll(m) + 1 : 0;
 }
+#if DF_FACTOR_ROWS
+// Round 4, second form: the tiles BELOW diagonal tile s ride through its 16-pivot chain.  The chain is right-looking -- pivot j scales
+// column j of every row and subtracts its multiple of row j's multipliers from the columns right of it -- so a lane that starts from a
+// row of T'_is = T_is - sum_{k<s} L_ik L_sk^T comes out holding that row of L_is, exactly as the unblocked factorisation would produce
+// it.  Lanes 0-15: the diagonal tile, 16-31: the identity (-> L_ss^-T for the panel solves), 32-47 / 48-63: tiles (s+1, s), (s+2, s);
+// step 0 has a third tile below, which a second wavefront takes through the same chain (it repeats the pivots for itself).  What was
+// a tile solve on the matrix cores behind every chain (three dependent groups of four MFMAs with an LDS round trip, then the sums of
+// the next diagonal tile) is gone from the latency chain: the wavefronts form the left-looking sums of the step's tiles side by
+// side, one barrier, chain.  tools/df_trace.py: the factor of a 64-block 14.5 -> about 10.5 us.
+__device__ __forceinline__ int chol64_mfma_4w(double (*Ts)[NB + 1], double (*Lr)[LR_LD], double (*Sc)[16][DV_LD], double *dinv_b) {
+    const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (threadIdx.x < 256) Sc[3][threadIdx.x >> 4][threadIdx.x & 15] = ((threadIdx.x >> 4) == (threadIdx.x & 15)) ? 1.0 : 0.0;
+    __syncthreads();
+    int bad = 0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int s0 = 16 * s;
+        if (s > 0) {
+            const int i = s + wave;
+            if (i < 4) {                                     // T'_is in row-per-lane reach: Sc[wave]
+                const int i0 = 16 * i;
+                d4 acc = (d4){0.0, 0.0, 0.0, 0.0}, acc1 = acc;
+                for (int k = 0; k < s; ++k)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const double av = Lr[i0 + lr][16 * k + 4 * t + lk], bv = Lr[s0 + lr][16 * k + 4 * t + lk];
+                        if (t & 1) acc1 = mfma_f64(av, bv, acc1);
+                        else acc = mfma_f64(av, bv, acc);
+                    }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Sc[wave][lk + 4 * r][lr] = Ts[i0 + lk + 4 * r][s0 + lr] - (acc[r] + acc1[r]);
+            }
+            __syncthreads();
+        }
+        if (wave == 0 || (s == 0 && wave == 1)) {
+            __builtin_amdgcn_s_setprio(3);
+            // which tile this lane's row belongs to: 0 the diagonal one, -1 the identity, t > 0: tile (s + t, s); -2: nothing (a copy of the
+            // diagonal rows, not stored)
+            int tl;
+            if (wave == 0) tl = (lk == 0) ? 0 : (lk == 1) ? -1 : ((s + lk - 1 < 4) ? lk - 1 : -2);
+            else tl = (lk == 1) ? 3 : -2;
+            const double *src;
+            if (tl == -1) src = &Sc[3][lr][0];
+            else if (s == 0) src = &Ts[16 * (tl > 0 ? tl : 0) + lr][0];
+            else src = &Sc[tl > 0 ? tl : 0][lr][0];
+            double a[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) a[c] = src[c];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const double ajj = readlane_f64(a[j], j);
+                double piv, y;
+                pivot_sqrt(ajj, piv, y);
+                a[j] *= y;
+#pragma unroll
+                for (int c = j + 1; c < 16; ++c) a[c] = fma(-a[j], readlane_f64(a[j], c), a[c]);
+            }
+            double diag = a[0];
+#pragma unroll
+            for (int c = 1; c < 16; ++c) diag = (lr == c) ? a[c] : diag;
+            if (tl >= 0) {
+                double *base = &Lr[s0 + 16 * tl + lr][s0];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) base[c] = (tl > 0 || c <= lr) ? a[c] : 0.0;
+            } else if (tl == -1) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) dinv_b[(s0 + c) * 16 + lr] = a[c];              // (L_ss^-1)[c][lr] = (L_ss^-T)[lr][c]
+            }
+            if (wave == 0) {
+                const unsigned long long m = __ballot((lane < 16) & !(diag > 0.0));
+                if (m && !bad) bad = s0 + (int)__builtin_ctzll(m) + 1;
+            }
+            __builtin_amdgcn_s_setprio(0);
+        }
+        __syncthreads();
+    }
+    return bad;
+}
+#else
 __device__ __forceinline__ int chol64_mfma_4w(double (*Ts)[NB + 1], double (*Lr)[LR_LD], double (*Sc)[16][DV_LD], double *dinv_b) {
     const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -596,6 +679,7 @@ __device__ __forceinline__ int chol64_mfma_4w(double (*Ts)[NB + 1], double (*Lr)
     }
     return bad;
 }
+#endif
 
 // Factorise the diagonal block held in LDS tile `Ts` (row-major, stride NB+1): wavefront 0 runs chol64_1w, which
 // leaves L in the LDS tile `Lr`; then all 256 threads publish L in place (lower triangle of the global block) and

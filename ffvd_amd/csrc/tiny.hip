@@ -248,6 +248,114 @@ __device__ __forceinline__ void tiny_pregather(double *Am, const int LD, const i
     }
 }
 
+#ifndef TINY_CHOL_ROWS
+#define TINY_CHOL_ROWS 1      // 0: the round-4 first form below (tile solves on the matrix cores behind every chain; A/B build `tinytiles`)
+#endif
+#if TINY_CHOL_ROWS
+// One older term range of a tile of a LATER column, in place (one wavefront):  A(i, c) -= sum_{k<kend} L(i,k) L(c,k)^T
+__device__ __forceinline__ void tiny_tile_sub(double *Am, const int LD, const int i, const int c, const int kbeg, const int kend, const int lane) {
+    const int lr = lane & 15, lk = lane >> 4, i0 = 16 * i, c0 = 16 * c;
+    d4 a0 = (d4){0.0, 0.0, 0.0, 0.0}, a1 = a0;
+    for (int k = kbeg; k < kend; ++k) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const double av = Am[(size_t)(i0 + lr) * LD + 16 * k + 4 * t + lk], bv = Am[(size_t)(c0 + lr) * LD + 16 * k + 4 * t + lk];
+            if (t & 1) a1 = mfma_f64(av, bv, a1);
+            else a0 = mfma_f64(av, bv, a0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Am[(size_t)(i0 + lk + 4 * r) * LD + c0 + lr] -= a0[r] + a1[r];
+}
+// In: lower triangle of Am.  Out: lower triangle = L (diagonal tiles with zeros above the diagonal), tiles above the diagonal =
+// W = L^-T, Dinv[s] = W(s,s).
+// Every tile BELOW diagonal tile s rides through that tile's 16-pivot chain (kernels.hip, chol64_mfma_4w has the argument: the chain is
+// the unblocked right-looking elimination, a lane that starts from a row of T'(i,s) = A(i,s) - sum_{k<s} L(i,k) L(s,k)^T leaves it as
+// that row of L(i,s)).  A chain wavefront carries the diagonal tile's rows in lanes 0-15 and three riders in lanes 16-63: wavefront
+// 0 the identity (-> L_ss^-T = W(s,s)) and tiles (s+1,s), (s+2,s), wavefronts 1, 2 the tiles further down -- they repeat the pivots for
+// themselves.  Column step s:
+//   (a) every wavefront: the newest term, A(i,s) -= L(i,s-1) L(s,s-1)^T, for the tiles i >= s it is dealt (4 MFMAs each); barrier
+//   (b) chain wavefronts: the chain;   the others, beside it: the older terms (k < s) of column s+1's tiles, in place, and the tiles
+//       W(e, s-1), e < s-1, of the inverse (they need W(s-1,s-1), which chain s-1 left) as before on the matrix cores; barrier
+// so that the latency chain of a column is one 4-MFMA product, two barriers and the pivot chain -- the first form had a tile solve
+// (three dependent groups of four MFMAs), the sums of the next diagonal tile and two LDS round trips there: 3.15 -> 2.2 us per column.
+template <int NW>
+__device__ __forceinline__ void tiny_chol_inv(double *Am, const int LD, const int NT, double (*Dinv)[16][17], double (*Sc)[17],
+                                              int32_t *info_word) {
+    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const double (*Id)[17] = Sc + 16;                                        // the identity tile behind Sc
+    // cnt[s]: chain wavefronts other than 0 that have read their rows in step s -- they read the diagonal tile that wavefront 0
+    // overwrites with L_ss behind its chain (1.5 us later: the wait never spins, but the order is not left to timing)
+    int *cnt = reinterpret_cast<int *>(&Sc[0][0]);
+    if (tid < 16) cnt[tid] = 0;
+    __syncthreads();
+    int bad = 0;
+    for (int s = 0; s < NT; ++s) {
+        const int s0 = 16 * s;
+        if (s > 0) {
+            for (int i = s + wave; i < NT; i += NW) tiny_tile_sub(Am, LD, i, s, s - 1, s, lane);
+            __syncthreads();
+        }
+        TSTAMP(27);
+        const int nr = NT - s;                                               // riders: the identity, then tiles s+1 .. NT-1
+        const int ncw = (nr + 2) / 3;                                        // chain wavefronts (<= 3: NT <= 8)
+        if (wave < ncw) {
+            __builtin_amdgcn_s_setprio(3);
+            const int q = 3 * wave + lk - 1;                                 // this lane group's rider (lk = 0: the diagonal tile)
+            const bool live = lk > 0 && q < nr;
+            const double *src = (lk > 0 && q == 0) ? &Id[lr][0] : Am + (size_t)(s0 + (live ? 16 * q : 0) + lr) * LD + s0;
+            double a[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) a[c] = src[c];
+            if (wave > 0) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_fetch_add(cnt + s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const double ajj = readlane_f64(a[j], j);
+                double piv, y;
+                pivot_sqrt(ajj, piv, y);
+                a[j] *= y;
+#pragma unroll
+                for (int c = j + 1; c < 16; ++c) a[c] = fma(-a[j], readlane_f64(a[j], c), a[c]);
+            }
+            double diag = a[0];
+#pragma unroll
+            for (int c = 1; c < 16; ++c) diag = (lr == c) ? a[c] : diag;
+            if (wave == 0 && ncw > 1)
+                while (__hip_atomic_load(cnt + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < ncw - 1) { }
+            if (lk == 0 ? wave == 0 : live) {
+                double *base = (lk > 0 && q == 0) ? &Dinv[s][lr][0] : Am + (size_t)(s0 + (lk > 0 ? 16 * q : 0) + lr) * LD + s0;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) base[c] = (lk > 0 || c <= lr) ? a[c] : 0.0;
+            }
+            if (wave == 0) {
+                const unsigned long long m = __ballot((lane < 16) & !(diag > 0.0));
+                if (m && !bad) bad = s0 + (int)__builtin_ctzll(m) + 1;
+            }
+            __builtin_amdgcn_s_setprio(0);
+            TSTAMP(29);
+        } else {
+            const int nid = NW - ncw, me = wave - ncw;
+            int idx = 0;
+            if (s >= 1)
+                for (int i = s + 1; i < NT; ++i, ++idx)
+                    if (idx % nid == me) tiny_tile_sub(Am, LD, i, s + 1, 0, s, lane);
+            for (int e = 0; e + 1 < s; ++e, ++idx)
+                if (idx % nid == me) tiny_tile_solve(Am, LD, Dinv, s - 1, e, true, lane);
+        }
+        __syncthreads();
+        TSTAMP(18 + (s < 8 ? s : 7));
+    }
+    {   // the inverse's tiles of the last column
+        for (int e = wave; e + 1 < NT; e += NW) tiny_tile_solve(Am, LD, Dinv, NT - 1, e, true, lane);
+        __syncthreads();
+    }
+    if (wave == 0 && lane == 0 && bad && *info_word == 0) *info_word = bad;
+}
+#else
 // In: lower triangle of Am.  Out: lower triangle = L (diagonal tiles with zeros above the diagonal), tiles above the diagonal =
 // W = L^-T, Dinv[s] = W(s,s).  Left-looking by tile column; wavefront 0 owns the critical path (tile (s+1,s), then the gather and
 // the 16-pivot chain of diagonal tile s+1), the others solve the remaining tiles of column s beside it; one barrier per column.
@@ -297,6 +405,7 @@ __device__ __forceinline__ void tiny_chol_inv(double *Am, const int LD, const in
     }
     if (wave == 0 && lane == 0 && bad && *info_word == 0) *info_word = bad;
 }
+#endif
 
 // element (i, j) of W = L^-T as tiny_chol_inv leaves it (i <= j by tiles; zero below the block diagonal)
 __device__ __forceinline__ double tiny_w_elem(const double *Am, const int LD, double (*Dinv)[16][17], const int i, const int j) {

@@ -13,3 +13,9 @@ for S in [int(x) for x in kw.get("S", "4,8,32").split(",")]:
     t0 = time.perf_counter()
     for _ in range(n): e.nll_terms()
     print("SYNC S=%d ms/call=%.3f" % (S, (time.perf_counter() - t0) / n * 1e3), os.environ.get("FFVD_NO_MAIN_FIRST", ""))
+    if "enq" in kw:      # host time of the enqueue alone (all launches of the iteration submitted, nothing waited for)
+        import ctypes
+        from ffvd_amd import _lib
+        f = ctypes.CDLL(_lib.LIB_PATH).ffvd_debug_enqueue_us
+        f.restype = ctypes.c_double; f.argtypes = [ctypes.c_void_p]
+        print("   host enqueue %.1f us per iteration" % f(e._h))

@@ -46,7 +46,7 @@ print("heads (us):")
 for u in range(min(nunits, 8)):
     print("  u%-3d" % u, " ".join("%s=%.1f" % (n, us[u, i]) for i, n in enumerate(names_h) if not np.isnan(us[u, i])))
 print("head 0 detail (us): prologue %s | chol(H) columns %s | W stored %.1f" % (" ".join("%.1f" % us[0, i] for i in (16, 17)), " ".join("%.1f" % us[0, i] for i in range(18, 26) if not np.isnan(us[0, i])), us[0, 26]))
-print("head 0, last column step of chol(H) (us): tile solve done %.2f, sums done %.2f, 16-pivot chain done %.2f" % (us[0, 27], us[0, 28], us[0, 29]))
+print("head 0, last column step of chol(H) (us): newest terms subtracted %.2f, 16-pivot chain done %.2f" % (us[0, 27], us[0, 29]))
 cl = [int(np.nanargmax(us[:, 11]))] if np.any(~np.isnan(us[:, 11])) else []
 for w in cl[:1]:
     print("closing workgroup %d (us): unit totals done %.1f, chain arrival %.1f, chain sums done %.1f, dX done %.1f, launch arrival %.1f, end %.1f" % (w, us[w, 12], us[w, 13], us[w, 30], us[w, 14], us[w, 15], np.nanmax(us[w, :12])))
