@@ -1817,7 +1817,7 @@ static void launch_potrf_flow(hipStream_t stream, double *A, int n, int extra_ro
     // a pivot chain that shares its SIMD with another row's MFMA loop takes up to twice as long (tools/df_trace.py)
     static const int pad_mode = [] { const char *e = getenv("FFVD_DF_PAD"); return e ? atoi(e) : -1; }();
     const bool alone = (pad_mode >= 0) ? (pad_mode != 0) : ((size_t)batch * R <= 256);
-    static const int fine_mode = [] { const char *e = getenv("FFVD_DF_FINE"); return e ? atoi(e) : -1; }();
+    const int fine_mode = [] { const char *e = getenv("FFVD_DF_FINE"); return e ? atoi(e) : -1; }();      // (read per launch: tests switch it)
     a.fine = ((fine_mode >= 0 ? fine_mode != 0 : alone) && 3 * a.nb <= DF_PS) ? (fine_mode == 2 ? 2 : 1) : 0;    // (2: A/B, no early sums)
     hipLaunchKernelGGL(potrf_df_kernel<true>, dim3((unsigned)((size_t)groups * R * a.G)), dim3(256), alone ? 16384 : 0, stream, a);
 }

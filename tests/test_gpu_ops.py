@@ -79,6 +79,28 @@ def test_cholesky_more_workgroups_than_the_chip_holds():
     np.testing.assert_allclose(L, np.linalg.cholesky(A), rtol=1e-9, atol=1e-10)
 
 
+@pytest.mark.parametrize("n", [512, 320])
+def test_dataflow_cholesky_progress_modes_agree_bitwise(n, monkeypatch):
+    """Few matrices (every block row on a compute unit of its own): a block row announces every column it has solved, a gather waits
+    term by term, and the diagonal sums are formed column by column (FFVD_DF_FINE = 1, the default there); 2 = the progress words
+    without the early sums; 0 = row-level progress as for large batches.  Same terms in the same order: identical bits."""
+    lib = _lib.load()
+    batch = 32                               # >= 32 matrices: the dataflow launch; 32 x 8 block rows = one per compute unit
+    rng = np.random.default_rng(n)
+    B = rng.standard_normal((batch, n, n + 2))
+    A = B @ np.swapaxes(B, 1, 2) + 0.5 * np.eye(n)
+    out = {}
+    for mode in ("1", "2", "0"):
+        monkeypatch.setenv("FFVD_DF_FINE", mode)
+        L = np.empty_like(A)
+        info = np.zeros(batch, dtype=np.int32)
+        rc = lib.ffvd_op_cholesky(_lib.dptr(A), n, batch, _lib.dptr(L), info.ctypes.data_as(_lib.C.POINTER(_lib.C.c_int32)))
+        assert rc == 0 and not info.any()
+        out[mode] = L
+    assert np.array_equal(out["1"], out["0"]) and np.array_equal(out["2"], out["0"])
+    np.testing.assert_allclose(out["1"], np.linalg.cholesky(A), rtol=1e-9, atol=1e-10)
+
+
 _STALL_SCRIPT = r"""
 import sys, time
 import numpy as np
