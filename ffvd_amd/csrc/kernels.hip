@@ -1816,9 +1816,12 @@ static void launch_potrf_flow(hipStream_t stream, double *A, int n, int extra_ro
     // Few matrices (every block row finds a CU of its own): 16 KB of unused dynamic LDS keep a second workgroup off the CU --
     // a pivot chain that shares its SIMD with another row's MFMA loop takes up to twice as long (tools/df_trace.py)
     static const int pad_mode = [] { const char *e = getenv("FFVD_DF_PAD"); return e ? atoi(e) : -1; }();
-    const bool alone = (pad_mode >= 0) ? (pad_mode != 0) : ((size_t)batch * R <= 256);
+    // (... and up to 640 block rows without identity-structured rows -- 64 matrices of a 16-chain rank: 1.87 vs 1.945 ms per iteration with
+    //  one row per compute unit; 288 and 432 rows no difference, 864 none, 1152 rows 2 % slower: profiles/r04_ab_df_pad.txt)
+    const bool one_per_cu = (size_t)batch * R <= 256 || (a.nid == 0 && (size_t)batch * R <= 640);
+    const bool alone = (pad_mode >= 0) ? (pad_mode != 0) : one_per_cu;
     const int fine_mode = [] { const char *e = getenv("FFVD_DF_FINE"); return e ? atoi(e) : -1; }();      // (read per launch: tests switch it)
-    a.fine = ((fine_mode >= 0 ? fine_mode != 0 : alone) && 3 * a.nb <= DF_PS) ? (fine_mode == 2 ? 2 : 1) : 0;    // (2: A/B, no early sums)
+    a.fine = ((fine_mode >= 0 ? fine_mode != 0 : (alone && (size_t)batch * R <= 256)) && 3 * a.nb <= DF_PS) ? (fine_mode == 2 ? 2 : 1) : 0;    // (2: A/B, no early sums)
     hipLaunchKernelGGL(potrf_df_kernel<true>, dim3((unsigned)((size_t)groups * R * a.G)), dim3(256), alone ? 16384 : 0, stream, a);
 }
 
