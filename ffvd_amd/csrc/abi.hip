@@ -2654,8 +2654,50 @@ extern "C" int ffvd_op_rollout(int kind, const double *Lm_inverse_seq, const dou
     // times: ~170 agent-scope releases / acquires per step cost more than the three kernel boundaries they replace -- so it is opt-in:
     // FFVD_STEP_LOOP=1.
     const char *nsl = getenv("FFVD_STEP_LOOP");
-    const bool use_loop = skinny && nsl && *nsl && strcmp(nsl, "0") != 0;
-    if (use_loop) {
+    const int loop_mode = (nsl && *nsl) ? atoi(nsl) : -1;
+    // Third form (loops.hip, rollout_resident_kernel; FFVD_STEP_LOOP=2): L^-T and W q_sqrt stay in LDS for the whole loop, three hand-offs
+    // per step.  Measured as the slope between 200 and 800 steps at M = 512, D = 4 (tools/rollout_modes.py): 16.6-19.2 us per step at 16
+    // rollouts, 19.3-23.9 at 32, 27-50 at 64 against 19.6-20.8 / 20.1-20.6 / 20.5-25.7 for the launches -- a hand-off among 32 workgroups
+    // costs 4-5 us here (release 2, wait + acquire 2.5-3: FFVD_RR_STAMPS=1), three of them are what three kernel boundaries cost.  Opt-in.
+    const bool resident = skinny && rollout_resident_ok(R, D, P, Mp) && loop_mode == 2;
+    const bool use_loop = skinny && loop_mode == 1;
+    bool resident_done = false;
+    if (resident) {
+        const int RT = (R + 15) / 16, RP = 16 * RT, NS = Mp / 16;
+        int32_t *words = sc.alloc<int32_t>(rollout_resident_words());
+        double *Kt = sc.alloc<double>((size_t)D * Mp * RP), *part = sc.alloc<double>((size_t)D * NS * RP * 4);
+        double *xb = sc.alloc<double>((size_t)2 * RP * D), *dxl = sc.upload(x_last, D);
+        OP_CHECK(words && Kt && part && xb && dxl, "ffvd_op_rollout");
+        HIP_TRY(hipMemsetAsync(words, 0, (size_t)rollout_resident_words() * sizeof(int32_t), sc.stream));
+        RolloutResidentArgs ra{};
+        ra.kind = kind; ra.R = R; ra.RT = RT; ra.D = D; ra.C = C; ra.P = P; ra.M = M; ra.Mp = Mp; ra.steps = steps; ra.NS = NS;
+        ra.hv = hv; ra.W = dW; ra.w_stride = (size_t)Mp * Mp; ra.WQ = q_sqrt ? dWQ : nullptr; ra.ucol = ucol;
+        ra.log_Q = dlq; ra.eps = deps; ra.ctrl = dctrl; ra.x_last = dxl; ra.Kt = Kt; ra.part = part; ra.xbuf = xb;
+        ra.predict_x = dpx; ra.predict_var = dpv; ra.words = words; ra.abort_w = words + 1;
+        long long *dst = nullptr;
+        if (getenv("FFVD_RR_STAMPS")) { dst = sc.alloc<long long>(32); if (dst) HIP_TRY(hipMemsetAsync(dst, 0, 32 * sizeof(long long), sc.stream)); }
+        ra.stamps = dst;
+        const int lrc = launch_rollout_resident(sc.stream, ra);
+        if (lrc == 0) {
+            int32_t hw[4] = {0, 0, 0, 0};
+            HIP_TRY(hipMemcpyAsync(hw, words, sizeof hw, hipMemcpyDeviceToHost, sc.stream));
+            HIP_TRY(hipStreamSynchronize(sc.stream));
+            resident_done = hw[1] == 0;          // (a wait gave up: the per-step launches below, from the initial rows)
+            if (dst && steps > 10) {             // tools: where step 10 spent its time (us since its start), slab 0 (the updater) and the last slab of dim 0
+                long long hs[32];
+                HIP_TRY(hipMemcpy(hs, dst, sizeof hs, hipMemcpyDeviceToHost));
+                static const char *nm[12] = {"start", "x_t seen", "inputs staged", "K stored", "K counted", "all K seen", "products", "partials stored",
+                                             "partials counted", "all partials seen", "updated", "x counted"};
+                for (int w = 0; w < 2; ++w) {
+                    fprintf(stderr, "rollout_resident R=%d q=%d slab %s:", R, q_sqrt ? 1 : 0, w ? "last" : "0");
+                    for (int i = 1; i < 12; ++i) if (hs[16 * w + i]) fprintf(stderr, "  %s %.2f", nm[i], (double)(hs[16 * w + i] - hs[16 * w]) / 100.0);
+                    fprintf(stderr, "\n");
+                }
+            }
+        } else (void)hipGetLastError();
+    }
+    if (resident_done) {
+    } else if (use_loop) {
         const int nwords = loop_words(D);
         int32_t *words = sc.alloc<int32_t>(nwords);
         OP_CHECK(words, "ffvd_op_rollout");

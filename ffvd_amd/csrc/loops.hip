@@ -150,6 +150,233 @@ __global__ __launch_bounds__(256) void pg_loop_kernel(PgLoopArgs a, const int GA
     }
 }
 
+// ---- third form (round 4, end): the loop with RESIDENT operands ----------------------------------------------------------------------
+// The two forms above replace kernel boundaries by hand-offs and keep everything else: every step still streams L^-T (2 MB per dim,
+// 4 with W q_sqrt) through 170 workgroups that each announce and await something.  This one is built around what a hand-off costs
+// (tools/probes/handoff_probe.hip: 1.6 us per 128 KB inside an XCD, 2.8 us across) and has THREE of them per step:
+//   workgroup (d, s) owns 16 columns of dim d's W = L^-T (and of W q_sqrt) -- loaded into LDS ONCE, before the loop -- and the 16
+//   inducing points of the same index range; all workgroups of a dim sit on one XCD (id = 8 s + d).  Per step:
+//   1. K(x_t, z_m) for its 16 inducing points and all rollouts -> Kt[d][m][r] (rollouts contiguous: the products' A fragments are
+//      then coalesced loads straight from L2, no staging)                                                  -> count on cK[d]
+//   2. (all slabs of the dim arrived)  F = K W and K (W q_sqrt) for its 16 columns on the matrix cores (W is upper triangular: slab s
+//      contracts over 16 (s + 1) rows), the wavefronts split the contraction or the row tiles, partial sums meet in LDS;
+//      per rollout sum_j F^2, sum_j F u_j, sum_j (F q)^2 of the slab -> part[d][s][r]                      -> count on cP[d]
+//   3. workgroup (d, 0): (all slabs arrived) adds the slabs in fixed order, x_{t+1,d} = x_td + f_mu + eps sqrt(f_var + Q_d)  (:300-314),
+//      predict_x / predict_var                                                                              -> count on cX
+//   and everyone starts step t + 1 when all D dims have counted on cX (the only hand-off that crosses XCDs).
+// Every wait is bounded (loop_wait); an abort makes the caller run the per-step launches.  Not bit-identical to them (the sums over a
+// row of F are formed per slab in another order): tests hold it to the oracle and to the launches at 1e-9.
+constexpr int RR_RED = 4 * 2 * 4 * 64;            // doubles: accumulators of four wavefronts, two right-hand sides
+constexpr int RR_PF = 16;                         // A fragments in flight per lane
+template <int KIND>
+__global__ __launch_bounds__(256) void rollout_resident_kernel(RolloutResidentArgs a) {
+    extern __shared__ double rr_lds[];
+    __shared__ int slot;
+    const int d = blockIdx.x & 7, s = blockIdx.x >> 3;
+    if (d >= a.D) return;
+    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Mp = a.Mp, P = a.P, D = a.D, R = a.R, RT = a.RT, RP = 16 * RT, NS = a.NS, C = a.C;
+    const bool hasq = a.WQ != nullptr;
+    double *Wp = rr_lds;                                   // [mlim][16]
+    double *WQp = Wp + (size_t)Mp * 16;                    // [Mp][16] (only with q_sqrt)
+    double *red = hasq ? WQp + (size_t)Mp * 16 : WQp;      // [4][2][4][64]
+    double *zsl = red + RR_RED;                            // [16][8]  this slab's inducing inputs (scaled)
+    double *xrow = zsl + 128;                              // [64][8]  the step's inputs (scaled)
+    double *usl = xrow + 512;                              // [16]
+    double *sums = usl + 16;                               // [4][64][3] (the updater's quarter sums)
+    const int mlim = 16 * (s + 1), j0 = 16 * s;
+    {
+        const double *Wd = a.W + (size_t)d * a.w_stride;
+        for (int e = tid; e < mlim * 16; e += 256) Wp[e] = Wd[(size_t)(e >> 4) * Mp + j0 + (e & 15)];
+        if (hasq) {
+            const double *Qd = a.WQ + (size_t)d * a.w_stride;
+            for (int e = tid; e < Mp * 16; e += 256) WQp[e] = Qd[(size_t)(e >> 4) * Mp + j0 + (e & 15)];
+        }
+        if (tid < 128) zsl[tid] = ((tid & 7) < P) ? a.hv.Zs[((size_t)d * Mp + j0 + (tid >> 3)) * P + (tid & 7)] : 0.0;
+        if (tid < 16) usl[tid] = a.ucol[(size_t)d * Mp + j0 + tid];
+    }
+    const double var = a.hv.variance[d];
+    const double zzm = a.hv.zz[(size_t)d * Mp + j0 + (tid >> 4)];
+    const bool mok = j0 + (tid >> 4) < a.M;
+    double lenp = 1.0;                                     // thread (r, p) of the input staging keeps its lengthscale
+    if (KIND == 0 && (tid & 7) < P) lenp = a.hv.len[(size_t)d * P + (tid & 7)];
+    const double Qd = exp(a.log_Q[d]);
+    int *base = a.words, *abort_w = a.abort_w;
+    int *cX = loop_word(base, 0), *cK = loop_word(base, 1 + d), *cP = loop_word(base, 9 + d);
+    // which part of the products this wavefront forms: row tile rt, part kp of nkp of the contraction
+    int nkp, rt, kp;
+    if (RT == 1) { nkp = 4; rt = 0; kp = wave; }
+    else if (RT == 2) { nkp = 2; rt = wave & 1; kp = wave >> 1; }
+    else { nkp = 1; rt = wave; kp = 0; }
+    const bool active = rt < RT;
+    const int nksW = mlim / 4, perW = (nksW + nkp - 1) / nkp, kw0 = kp * perW, kw1 = (kw0 + perW < nksW) ? kw0 + perW : nksW;
+    const int nksQ = Mp / 4, perQ = (nksQ + nkp - 1) / nkp, kq0 = kp * perQ, kq1 = (kq0 + perQ < nksQ) ? kq0 + perQ : nksQ;
+    double *Ktd = a.Kt + (size_t)d * Mp * RP;
+    __syncthreads();
+    long long *stp = (a.stamps && d == 0 && (s == 0 || s == NS - 1)) ? a.stamps + (s == 0 ? 0 : 16) : nullptr;
+#define RR_STAMP(i) do { if (stp && t == 10 && tid == 0) stp[i] = wall_clock64(); } while (0)
+    for (int t = 0; t < a.steps; ++t) {
+        RR_STAMP(0);
+        if (t > 0 && !loop_wait(cX, D * t, abort_w, &slot)) return;                     // every dim of x_t is written
+        RR_STAMP(1);
+        const double *xin = a.xbuf + (size_t)(t & 1) * RP * D;
+        double *xout = a.xbuf + (size_t)((t + 1) & 1) * RP * D;
+        for (int e = tid; e < RP * 8; e += 256) {                                         // (256 = 32 rows x 8: a thread keeps its p)
+            const int r = e >> 3, p = e & 7;
+            double v = 0.0;
+            if (r < R && p < P) {
+                v = (p < D) ? (t == 0 ? a.x_last[p] : xin[(size_t)r * D + p]) : a.ctrl[(size_t)t * C + (p - D)];
+                v = (KIND == 0) ? v / lenp : v * var;
+            }
+            xrow[e] = v;
+        }
+        __syncthreads();
+        RR_STAMP(2);
+        {   // 1. K(x_t, z_m): thread = (inducing point m = tid >> 4, rollout r = tid & 15 of every row tile)
+            const int m = tid >> 4;
+            double zr[8];
+#pragma unroll
+            for (int p = 0; p < 8; ++p) zr[p] = zsl[m * 8 + p];
+            for (int pass = 0; pass < RT; ++pass) {
+                const int r = 16 * pass + (tid & 15);
+                double dot = 0.0, xx = 0.0;
+#pragma unroll
+                for (int p = 0; p < 8; ++p) { const double xv = xrow[r * 8 + p]; dot += xv * zr[p]; if (KIND == 0) xx += xv * xv; }
+                double v = kernel_value<KIND>(dot, xx, zzm, var);
+                if (r >= R || !mok) v = 0.0;
+                Ktd[(size_t)(j0 + m) * RP + r] = v;
+            }
+        }
+        RR_STAMP(3);
+        loop_arrive(cK);
+        RR_STAMP(4);
+        if (!loop_wait(cK, NS * (t + 1), abort_w, &slot)) return;
+        RR_STAMP(5);
+        // 2. the products for this slab's 16 columns
+        d4 accW = (d4){0.0, 0.0, 0.0, 0.0}, accQ = accW;
+        if (active) {
+            // A fragments straight from L2 (one 8-byte load per MFMA and lane, 4 lines per wavefront instruction): RR_PF of them in
+            // flight ahead of the MFMAs that use them, or the loop is one L2 latency per 8 MFMAs
+            const double *Ka = Ktd + 16 * rt + lr + (size_t)lk * RP;                      // element (4 ks + lk, r): Ka[4 ks * RP]
+            const int k0 = hasq ? kq0 : kw0, k1 = hasq ? kq1 : kw1;                       // (with q_sqrt both products walk the same range)
+            double cur[RR_PF], nxt[RR_PF];
+#pragma unroll
+            for (int i = 0; i < RR_PF; ++i) cur[i] = Ka[(size_t)4 * ((k0 + i < k1) ? k0 + i : k1 - 1) * RP];
+            for (int kb = k0; kb < k1; kb += RR_PF) {
+                if (kb + RR_PF < k1) {
+#pragma unroll
+                    for (int i = 0; i < RR_PF; ++i) nxt[i] = Ka[(size_t)4 * ((kb + RR_PF + i < k1) ? kb + RR_PF + i : k1 - 1) * RP];
+                }
+#pragma unroll
+                for (int i = 0; i < RR_PF; ++i) {
+                    const int ks = kb + i;
+                    if (ks < k1) {
+                        if (hasq) accQ = mfma_f64(cur[i], WQp[(4 * ks + lk) * 16 + lr], accQ);
+                        if (ks < nksW) accW = mfma_f64(cur[i], Wp[(4 * ks + lk) * 16 + lr], accW);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < RR_PF; ++i) cur[i] = nxt[i];
+            }
+        }
+        RR_STAMP(6);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            red[((wave * 2 + 0) * 4 + q) * 64 + lane] = accW[q];
+            red[((wave * 2 + 1) * 4 + q) * 64 + lane] = accQ[q];
+        }
+        __syncthreads();
+        if (active && kp == 0) {
+            const double uj = usl[lr];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                double f = 0.0, fq = 0.0;
+                for (int pp = 0; pp < nkp; ++pp) {                                        // fixed order over the parts of the contraction
+                    const int w2 = (RT == 1) ? pp : ((RT == 2) ? rt + 2 * pp : rt);
+                    f += red[((w2 * 2 + 0) * 4 + q) * 64 + lane];
+                    fq += red[((w2 * 2 + 1) * 4 + q) * 64 + lane];
+                }
+                double rs = f * f, fm = f * uj, ex = fq * fq;
+#pragma unroll
+                for (int mm = 1; mm < 16; mm <<= 1) { rs += __shfl_xor(rs, mm); fm += __shfl_xor(fm, mm); ex += __shfl_xor(ex, mm); }
+                if (lr == 0) {
+                    double *pp = a.part + (((size_t)d * NS + s) * RP + 16 * rt + lk + 4 * q) * 4;
+                    pp[0] = rs; pp[1] = fm; pp[2] = ex;
+                }
+            }
+        }
+        RR_STAMP(7);
+        loop_arrive(cP);
+        RR_STAMP(8);
+        if (s == 0) {
+            // 3. conditional epilogue + update of dim d (conditionals_multi_output.py:355-387, base_model.py:300-314)
+            if (!loop_wait(cP, NS * (t + 1), abort_w, &slot)) return;
+            RR_STAMP(9);
+            {
+                const int r = tid & 63, qtr = tid >> 6, nq = NS / 4;                      // nq <= 8
+                double rs = 0.0, fm = 0.0, ex = 0.0;
+                if (r < RP) {
+                    double2 v01[8];
+                    double v2[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {                                          // all loads first, then the adds in slab order
+                        const double *pp = a.part + (((size_t)d * NS + qtr * nq + ((i < nq) ? i : 0)) * RP + r) * 4;
+                        v01[i] = *reinterpret_cast<const double2 *>(pp);
+                        v2[i] = pp[2];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (i < nq) { rs += v01[i].x; fm += v01[i].y; ex += v2[i]; }
+                }
+                sums[(qtr * 64 + r) * 3 + 0] = rs; sums[(qtr * 64 + r) * 3 + 1] = fm; sums[(qtr * 64 + r) * 3 + 2] = ex;
+            }
+            __syncthreads();
+            if (tid < R) {
+                const int r = tid;
+                double rs = 0.0, fm = 0.0, ex = 0.0;
+#pragma unroll
+                for (int qtr = 0; qtr < 4; ++qtr) { rs += sums[(qtr * 64 + r) * 3]; fm += sums[(qtr * 64 + r) * 3 + 1]; ex += sums[(qtr * 64 + r) * 3 + 2]; }
+                const double xd = (t == 0) ? a.x_last[d] : xin[(size_t)r * D + d];
+                double kd = var;
+                if (KIND == 1) {
+                    kd = 0.0;
+                    for (int p = 0; p < P; ++p) {
+                        const double xv = (p < D) ? (t == 0 ? a.x_last[p] : xin[(size_t)r * D + p]) : a.ctrl[(size_t)t * C + (p - D)];
+                        kd += (xv * xv) * var;
+                    }
+                }
+                double vv = kd - rs;
+                if (hasq) vv = vv + ex;
+                const double v = vv + Qd;
+                const double xn = (fm + xd) + a.eps[((size_t)t * R + r) * D + d] * sqrt(v);
+                const size_t o = ((size_t)r * a.steps + t) * D + d;
+                a.predict_x[o] = xn;
+                a.predict_var[o] = v;
+                xout[(size_t)r * D + d] = xn;
+            }
+            RR_STAMP(10);
+            loop_arrive(cX);
+            RR_STAMP(11);
+        }
+    }
+#undef RR_STAMP
+}
+
+bool rollout_resident_ok(int R, int D, int P, int Mp) { return R >= 1 && R <= 64 && D >= 1 && D <= 8 && P <= 8 && Mp >= 64 && Mp <= 512 && Mp % 64 == 0; }
+int rollout_resident_words() { return (2 + 17) * LOOP_WORD_STRIDE; }
+int launch_rollout_resident(hipStream_t stream, const RolloutResidentArgs &a) {
+    const size_t lds = ((size_t)a.Mp * 16 * (a.WQ ? 2 : 1) + RR_RED + 128 + 512 + 16 + 768) * sizeof(double);
+    auto go = [&](auto kind) -> int {
+        auto fn = rollout_resident_kernel<decltype(kind)::value>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(fn, dim3(8 * a.NS), dim3(256), lds, stream, a);
+        return (int)hipGetLastError();
+    };
+    return a.kind == 0 ? go(std::integral_constant<int, 0>{}) : go(std::integral_constant<int, 1>{});
+}
+
 // every workgroup must be resident at once: 256 threads and ~25 KB of LDS each, two per CU at most
 static int loop_capacity() {
     static const int cus = [] {

@@ -354,6 +354,25 @@ struct PgLoopArgs {
     unsigned *bar;
     int *abort_w;
 };
+// ---- the rollout loop with RESIDENT operands (loops.hip, rollout_resident_kernel) ------------------------------------------------
+struct RolloutResidentArgs {
+    int kind, R, RT, D, C, P, M, Mp, steps, NS;     // RT = row tiles of 16 rollouts, NS = Mp / 16 column slabs per dim
+    HyperView hv;
+    const double *W;  size_t w_stride;              // [D][Mp][Mp]  W = L^-T (upper triangular), row-major
+    const double *WQ;                                // optional [D][Mp][Mp]  W q_sqrt
+    const double *ucol;                              // [D][Mp]
+    const double *log_Q, *eps, *ctrl, *x_last;      // eps [steps][R][D]; ctrl [steps][C] or null; x_last [D]
+    double *Kt;                                      // [D][Mp][16 RT]   K(x_t, Z) of the step, rollouts contiguous
+    double *part;                                    // [D][NS][16 RT][4] per-slab sums of a row: sum F^2, F.u, sum (F q)^2
+    double *xbuf;                                    // [2][16 RT][D]     the states of step t in xbuf[t & 1]
+    double *predict_x, *predict_var;                 // [R][steps][D]
+    int *words, *abort_w;                            // counter block (rollout_resident_words ints, zero before the launch), abort = words + 1
+    long long *stamps;                               // optional (FFVD_RR_STAMPS=1, tools): [2][16] wall-clock stamps of step 10, slabs 0 and NS - 1 of dim 0
+};
+bool rollout_resident_ok(int R, int D, int P, int Mp);
+int rollout_resident_words();
+int launch_rollout_resident(hipStream_t stream, const RolloutResidentArgs &a);      // 0, or a hipError_t value
+
 int loop_words(int nb);          // ints of the counter block (`bar`; abort word = bar[1]) for nb units, zero before the launch
 void launch_rollout_loop(hipStream_t stream, const RolloutLoopArgs &a);
 void launch_pg_loop(hipStream_t stream, const PgLoopArgs &a);

@@ -475,11 +475,8 @@ def test_step_loops_equal_the_per_step_launches(monkeypatch):
         x0, epg, u = rng.standard_normal((R, D)), rng.standard_normal((T, R, D)), rng.random((T, R))
         Rch = np.exp(params["log_Rchols"])
         out = {}
-        for mode in ("loop", "launches"):
-            if mode == "loop":
-                monkeypatch.setenv("FFVD_STEP_LOOP", "1")
-            else:
-                monkeypatch.delenv("FFVD_STEP_LOOP", raising=False)
+        for mode, env in (("loop", "1"), ("launches", "0"), ("resident", "2")):
+            monkeypatch.setenv("FFVD_STEP_LOOP", env)
             out[mode] = (rollout(L, params["Z"], kern, U, H, X[-1], ctrl, T, steps, Q, eps),
                          rollout(L, params["Z"], kern, U, None, X[-1], ctrl, T, steps, Q, eps),
                          pg_sweep(L, params["Z"], kern, params["U"], X, Y, c, params["CC"], params["DD"], Rch, Q, x0, epg, u))
@@ -487,3 +484,8 @@ def test_step_loops_equal_the_per_step_launches(monkeypatch):
         for a, b in zip(out["loop"], out["launches"]):
             np.testing.assert_array_equal(a[0], b[0])
             np.testing.assert_array_equal(a[1], b[1])
+        # the rollout loop with resident operands (FFVD_STEP_LOOP=2, opt-in like the other loop: up to 64 rollouts, M <= 512, 8 latent
+        # dims; 100 rollouts fall back to the launches): other summation order inside a row of F, same values to rounding
+        for a, b in zip(out["resident"][:2], out["launches"][:2]):
+            np.testing.assert_allclose(a[0], b[0], rtol=1e-9, atol=1e-10)
+            np.testing.assert_allclose(a[1], b[1], rtol=1e-9, atol=1e-10)
