@@ -2658,8 +2658,10 @@ extern "C" int ffvd_op_rollout(int kind, const double *Lm_inverse_seq, const dou
     // Third form (loops.hip, rollout_resident_kernel; FFVD_STEP_LOOP=2): L^-T and W q_sqrt stay in LDS for the whole loop, three hand-offs
     // per step.  Measured as the slope between 200 and 800 steps at M = 512, D = 4 (tools/rollout_modes.py): 16.6-19.2 us per step at 16
     // rollouts, 19.3-23.9 at 32, 27-50 at 64 against 19.6-20.8 / 20.1-20.6 / 20.5-25.7 for the launches -- a hand-off among 32 workgroups
-    // costs 4-5 us here (release 2, wait + acquire 2.5-3: FFVD_RR_STAMPS=1), three of them are what three kernel boundaries cost.  Opt-in.
-    const bool resident = skinny && rollout_resident_ok(R, D, P, Mp) && loop_mode == 2;
+    // costs 4-5 us here (release 2, wait + acquire 2.5-3: FFVD_RR_STAMPS=1), three of them are what three kernel boundaries cost.
+    // (Second measurement, with the hand-offs rebuilt without cache maintenance -- write-through stores and sc1 loads instead of fences, as in
+    //  the Gram kernel's tail exchange: 10.1-11.8 us per step at 16 rollouts, 13.6-17.9 at 32, 20.5-27 at 64.  The default up to 32 rollouts.)
+    const bool resident = skinny && rollout_resident_ok(R, D, P, Mp) && (loop_mode == 2 || (loop_mode < 0 && R <= 32));
     const bool use_loop = skinny && loop_mode == 1;
     bool resident_done = false;
     if (resident) {

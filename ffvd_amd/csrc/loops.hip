@@ -164,8 +164,46 @@ __global__ __launch_bounds__(256) void pg_loop_kernel(PgLoopArgs a, const int GA
 //   3. workgroup (d, 0): (all slabs arrived) adds the slabs in fixed order, x_{t+1,d} = x_td + f_mu + eps sqrt(f_var + Q_d)  (:300-314),
 //      predict_x / predict_var                                                                              -> count on cX
 //   and everyone starts step t + 1 when all D dims have counted on cX (the only hand-off that crosses XCDs).
-// Every wait is bounded (loop_wait); an abort makes the caller run the per-step launches.  Not bit-identical to them (the sums over a
+// Every wait is bounded; an abort makes the caller run the per-step launches.  Not bit-identical to them (the sums over a
 // row of F are formed per slab in another order): tests hold it to the oracle and to the launches at 1e-9.
+#if !defined(__gfx942__) && !defined(__gfx950__) && defined(__HIP_DEVICE_COMPILE__)
+#error "rollout_resident_kernel's hand-offs rely on gfx942 / gfx950 semantics (agent-scope accesses = sc1: write-through stores counted in vmcnt, loads past the non-coherent caches)"
+#endif
+// Hand-offs without cache maintenance (what the stamps of the fenced version asked for: release 2 us, wait + acquire 2.5-3 us among the
+// 32 workgroups of a dim).  Every word another workgroup reads is written with an agent-scope (sc1, write-through) store and read with an
+// agent-scope load, i.e. past the caches that are not coherent across compute units / XCDs; the producer waits for its stores
+// (s_waitcnt vmcnt(0)) in front of the workgroup barrier behind which one lane counts, the consumer's loads are issued behind the
+// barrier that follows its poll.  No fence on either side -- the Gram kernel's tail exchange (kernels.hip) is the same construction.
+__device__ __forceinline__ void rr_store(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double rr_load(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ bool rr_wait(int *word, const int need, int *abort_w, int *slot) {
+    if (threadIdx.x == 0) {
+        int ok = 1;
+        if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+            const long long t0 = wall_clock64();
+            for (;;) {
+                __builtin_amdgcn_s_sleep(1);
+                if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) break;
+                if (__hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = 0; break; }
+                if (wall_clock64() - t0 > LOOP_SPIN_TICKS) {
+                    __hip_atomic_store(abort_w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = 0;
+                    break;
+                }
+            }
+        }
+        *slot = ok;
+    }
+    __syncthreads();
+    const int ok = *slot;
+    __syncthreads();
+    return ok != 0;
+}
+__device__ __forceinline__ void rr_arrive(int *word) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 constexpr int RR_RED = 4 * 2 * 4 * 64;            // doubles: accumulators of four wavefronts, two right-hand sides
 constexpr int RR_PF = 16;                         // A fragments in flight per lane
 template <int KIND>
@@ -210,15 +248,16 @@ __global__ __launch_bounds__(256) void rollout_resident_kernel(RolloutResidentAr
     else if (RT == 2) { nkp = 2; rt = wave & 1; kp = wave >> 1; }
     else { nkp = 1; rt = wave; kp = 0; }
     const bool active = rt < RT;
-    const int nksW = mlim / 4, perW = (nksW + nkp - 1) / nkp, kw0 = kp * perW, kw1 = (kw0 + perW < nksW) ? kw0 + perW : nksW;
-    const int nksQ = Mp / 4, perQ = (nksQ + nkp - 1) / nkp, kq0 = kp * perQ, kq1 = (kq0 + perQ < nksQ) ? kq0 + perQ : nksQ;
+    // the contraction in PAIRS of k-steps (8 inducing points): Kt keeps the two values a lane needs for a pair side by side
+    const int npW = mlim / 8, ppW = (npW + nkp - 1) / nkp, pw0 = kp * ppW, pw1 = (pw0 + ppW < npW) ? pw0 + ppW : npW;
+    const int npQ = Mp / 8, ppQ = (npQ + nkp - 1) / nkp, pq0 = kp * ppQ, pq1 = (pq0 + ppQ < npQ) ? pq0 + ppQ : npQ;
     double *Ktd = a.Kt + (size_t)d * Mp * RP;
     __syncthreads();
     long long *stp = (a.stamps && d == 0 && (s == 0 || s == NS - 1)) ? a.stamps + (s == 0 ? 0 : 16) : nullptr;
 #define RR_STAMP(i) do { if (stp && t == 10 && tid == 0) stp[i] = wall_clock64(); } while (0)
     for (int t = 0; t < a.steps; ++t) {
         RR_STAMP(0);
-        if (t > 0 && !loop_wait(cX, D * t, abort_w, &slot)) return;                     // every dim of x_t is written
+        if (t > 0 && !rr_wait(cX, D * t, abort_w, &slot)) return;                     // every dim of x_t is written
         RR_STAMP(1);
         const double *xin = a.xbuf + (size_t)(t & 1) * RP * D;
         double *xout = a.xbuf + (size_t)((t + 1) & 1) * RP * D;
@@ -226,7 +265,7 @@ __global__ __launch_bounds__(256) void rollout_resident_kernel(RolloutResidentAr
             const int r = e >> 3, p = e & 7;
             double v = 0.0;
             if (r < R && p < P) {
-                v = (p < D) ? (t == 0 ? a.x_last[p] : xin[(size_t)r * D + p]) : a.ctrl[(size_t)t * C + (p - D)];
+                v = (p < D) ? (t == 0 ? a.x_last[p] : rr_load(xin + (size_t)r * D + p)) : a.ctrl[(size_t)t * C + (p - D)];
                 v = (KIND == 0) ? v / lenp : v * var;
             }
             xrow[e] = v;
@@ -245,35 +284,49 @@ __global__ __launch_bounds__(256) void rollout_resident_kernel(RolloutResidentAr
                 for (int p = 0; p < 8; ++p) { const double xv = xrow[r * 8 + p]; dot += xv * zr[p]; if (KIND == 0) xx += xv * xv; }
                 double v = kernel_value<KIND>(dot, xx, zzm, var);
                 if (r >= R || !mok) v = 0.0;
-                Ktd[(size_t)(j0 + m) * RP + r] = v;
+                // K(x_r, z_m), m = 8 a + 4 b + c, at ((4 a + c) RP + r) 2 + b: lane (r, c) of a product wavefront reads k-steps 2 a and
+                // 2 a + 1 with one 16-byte load
+                const int mg = j0 + m;
+                rr_store(Ktd + ((size_t)((mg >> 3) * 4 + (mg & 3)) * RP + r) * 2 + ((mg >> 2) & 1), v);
             }
         }
         RR_STAMP(3);
-        loop_arrive(cK);
+        rr_arrive(cK);
         RR_STAMP(4);
-        if (!loop_wait(cK, NS * (t + 1), abort_w, &slot)) return;
+        if (!rr_wait(cK, NS * (t + 1), abort_w, &slot)) return;
         RR_STAMP(5);
         // 2. the products for this slab's 16 columns
         d4 accW = (d4){0.0, 0.0, 0.0, 0.0}, accQ = accW;
         if (active) {
-            // A fragments straight from L2 (one 8-byte load per MFMA and lane, 4 lines per wavefront instruction): RR_PF of them in
-            // flight ahead of the MFMAs that use them, or the loop is one L2 latency per 8 MFMAs
-            const double *Ka = Ktd + 16 * rt + lr + (size_t)lk * RP;                      // element (4 ks + lk, r): Ka[4 ks * RP]
-            const int k0 = hasq ? kq0 : kw0, k1 = hasq ? kq1 : kw1;                       // (with q_sqrt both products walk the same range)
-            double cur[RR_PF], nxt[RR_PF];
+            // A fragments straight from L2: one 16-byte load per lane and pair of k-steps, RR_PF pairs in flight ahead of the MFMAs that
+            // use them and as many behind them (an L2 round trip is 1 us, a pair of MFMAs 0.05)
+            const double *Ka = Ktd + ((size_t)lk * RP + 16 * rt + lr) * 2;                // pair a: Ka[a * 8 RP]
+            const int p0 = hasq ? pq0 : pw0, p1 = hasq ? pq1 : pw1;                       // (with q_sqrt both products walk the same range)
+            auto lda = [&](int pr) {
+                const double *q = Ka + (size_t)((pr < p1) ? pr : p1 - 1) * 8 * RP;
+                return make_double2(rr_load(q), rr_load(q + 1));
+            };
+            double2 cur[RR_PF], nxt[RR_PF];
 #pragma unroll
-            for (int i = 0; i < RR_PF; ++i) cur[i] = Ka[(size_t)4 * ((k0 + i < k1) ? k0 + i : k1 - 1) * RP];
-            for (int kb = k0; kb < k1; kb += RR_PF) {
-                if (kb + RR_PF < k1) {
+            for (int i = 0; i < RR_PF; ++i) cur[i] = lda(p0 + i);
+            for (int pb = p0; pb < p1; pb += RR_PF) {
+                if (pb + RR_PF < p1) {
 #pragma unroll
-                    for (int i = 0; i < RR_PF; ++i) nxt[i] = Ka[(size_t)4 * ((kb + RR_PF + i < k1) ? kb + RR_PF + i : k1 - 1) * RP];
+                    for (int i = 0; i < RR_PF; ++i) nxt[i] = lda(pb + RR_PF + i);
                 }
 #pragma unroll
                 for (int i = 0; i < RR_PF; ++i) {
-                    const int ks = kb + i;
-                    if (ks < k1) {
-                        if (hasq) accQ = mfma_f64(cur[i], WQp[(4 * ks + lk) * 16 + lr], accQ);
-                        if (ks < nksW) accW = mfma_f64(cur[i], Wp[(4 * ks + lk) * 16 + lr], accW);
+                    const int pr = pb + i;
+                    if (pr < p1) {
+                        const int m0 = 8 * pr + lk;
+                        if (hasq) {
+                            accQ = mfma_f64(cur[i].x, WQp[m0 * 16 + lr], accQ);
+                            accQ = mfma_f64(cur[i].y, WQp[(m0 + 4) * 16 + lr], accQ);
+                        }
+                        if (pr < npW) {
+                            accW = mfma_f64(cur[i].x, Wp[m0 * 16 + lr], accW);
+                            accW = mfma_f64(cur[i].y, Wp[(m0 + 4) * 16 + lr], accW);
+                        }
                     }
                 }
 #pragma unroll
@@ -302,32 +355,30 @@ __global__ __launch_bounds__(256) void rollout_resident_kernel(RolloutResidentAr
                 for (int mm = 1; mm < 16; mm <<= 1) { rs += __shfl_xor(rs, mm); fm += __shfl_xor(fm, mm); ex += __shfl_xor(ex, mm); }
                 if (lr == 0) {
                     double *pp = a.part + (((size_t)d * NS + s) * RP + 16 * rt + lk + 4 * q) * 4;
-                    pp[0] = rs; pp[1] = fm; pp[2] = ex;
+                    rr_store(pp, rs); rr_store(pp + 1, fm); rr_store(pp + 2, ex);
                 }
             }
         }
         RR_STAMP(7);
-        loop_arrive(cP);
+        rr_arrive(cP);
         RR_STAMP(8);
         if (s == 0) {
             // 3. conditional epilogue + update of dim d (conditionals_multi_output.py:355-387, base_model.py:300-314)
-            if (!loop_wait(cP, NS * (t + 1), abort_w, &slot)) return;
+            if (!rr_wait(cP, NS * (t + 1), abort_w, &slot)) return;
             RR_STAMP(9);
             {
                 const int r = tid & 63, qtr = tid >> 6, nq = NS / 4;                      // nq <= 8
                 double rs = 0.0, fm = 0.0, ex = 0.0;
                 if (r < RP) {
-                    double2 v01[8];
-                    double v2[8];
+                    double v0[8], v1[8], v2[8];
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {                                          // all loads first, then the adds in slab order
                         const double *pp = a.part + (((size_t)d * NS + qtr * nq + ((i < nq) ? i : 0)) * RP + r) * 4;
-                        v01[i] = *reinterpret_cast<const double2 *>(pp);
-                        v2[i] = pp[2];
+                        v0[i] = rr_load(pp); v1[i] = rr_load(pp + 1); v2[i] = rr_load(pp + 2);
                     }
 #pragma unroll
                     for (int i = 0; i < 8; ++i)
-                        if (i < nq) { rs += v01[i].x; fm += v01[i].y; ex += v2[i]; }
+                        if (i < nq) { rs += v0[i]; fm += v1[i]; ex += v2[i]; }
                 }
                 sums[(qtr * 64 + r) * 3 + 0] = rs; sums[(qtr * 64 + r) * 3 + 1] = fm; sums[(qtr * 64 + r) * 3 + 2] = ex;
             }
@@ -337,12 +388,12 @@ __global__ __launch_bounds__(256) void rollout_resident_kernel(RolloutResidentAr
                 double rs = 0.0, fm = 0.0, ex = 0.0;
 #pragma unroll
                 for (int qtr = 0; qtr < 4; ++qtr) { rs += sums[(qtr * 64 + r) * 3]; fm += sums[(qtr * 64 + r) * 3 + 1]; ex += sums[(qtr * 64 + r) * 3 + 2]; }
-                const double xd = (t == 0) ? a.x_last[d] : xin[(size_t)r * D + d];
+                const double xd = (t == 0) ? a.x_last[d] : rr_load(xin + (size_t)r * D + d);
                 double kd = var;
                 if (KIND == 1) {
                     kd = 0.0;
                     for (int p = 0; p < P; ++p) {
-                        const double xv = (p < D) ? (t == 0 ? a.x_last[p] : xin[(size_t)r * D + p]) : a.ctrl[(size_t)t * C + (p - D)];
+                        const double xv = (p < D) ? (t == 0 ? a.x_last[p] : rr_load(xin + (size_t)r * D + p)) : a.ctrl[(size_t)t * C + (p - D)];
                         kd += (xv * xv) * var;
                     }
                 }
@@ -353,10 +404,10 @@ __global__ __launch_bounds__(256) void rollout_resident_kernel(RolloutResidentAr
                 const size_t o = ((size_t)r * a.steps + t) * D + d;
                 a.predict_x[o] = xn;
                 a.predict_var[o] = v;
-                xout[(size_t)r * D + d] = xn;
+                rr_store(xout + (size_t)r * D + d, xn);
             }
             RR_STAMP(10);
-            loop_arrive(cX);
+            rr_arrive(cX);
             RR_STAMP(11);
         }
     }
