@@ -61,13 +61,16 @@ U, H = cmo.collapse_u_mean_after_kernel_precalculation(L, np.concatenate((X[:-1]
                                                        np.exp(params["log_Q"]))
 rng = np.random.default_rng(0)
 for R, steps in ((32, 200), (100, 200)):
-    ctrl = np.concatenate((c, rng.standard_normal((steps, C))))
-    eps = rng.standard_normal((steps, R, D))
+    ctrl = np.concatenate((c, rng.standard_normal((4 * steps, C))))
+    eps = rng.standard_normal((4 * steps, R, D))
     rollout(L, params["Z"], kern, U, H, X[-1], ctrl, T, 2, np.exp(params["log_Q"]), eps[:2])
     t0 = time.perf_counter()
-    rollout(L, params["Z"], kern, U, H, X[-1], ctrl, T, steps, np.exp(params["log_Q"]), eps)
+    rollout(L, params["Z"], kern, U, H, X[-1], ctrl, T, steps, np.exp(params["log_Q"]), eps[:steps])
     dt = time.perf_counter() - t0
-    out[f"rollout_R{R}_us_per_step"] = dt / steps * 1e6
+    out[f"rollout_R{R}_us_per_step"] = dt / steps * 1e6          # whole call (uploads L^-T, forms W q_sqrt: ~2.5 ms) over 200 steps
+    t0 = time.perf_counter()
+    rollout(L, params["Z"], kern, U, H, X[-1], ctrl, T, 4 * steps, np.exp(params["log_Q"]), eps)
+    out[f"rollout_R{R}_us_per_step_marginal"] = (time.perf_counter() - t0 - dt) / (3 * steps) * 1e6      # slope between 200 and 800 steps
 # particle-Gibbs sweep (intent of PG_for_X_speedup): 100 particles over the whole trajectory, explicit U
 from ffvd_amd.prediction import pg_sweep
 N = 100
