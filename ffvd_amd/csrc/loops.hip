@@ -181,9 +181,12 @@ __device__ __forceinline__ bool rr_wait(int *word, const int need, int *abort_w,
         int ok = 1;
         if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
             const long long t0 = wall_clock64();
-            for (;;) {
-                __builtin_amdgcn_s_sleep(1);
+            for (int spin = 0;; ++spin) {
+#ifdef RR_POLL_SLEEP
+                __builtin_amdgcn_s_sleep(RR_POLL_SLEEP);
+#endif
                 if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) break;
+                if ((spin & 63) != 63) continue;                   // (the abort word and the clock once in 64 polls)
                 if (__hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = 0; break; }
                 if (wall_clock64() - t0 > LOOP_SPIN_TICKS) {
                     __hip_atomic_store(abort_w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(256) void rollout_resident_kernel(RolloutResidentAr
         if (!rr_wait(cK, NS * (t + 1), abort_w, &slot)) return;
         RR_STAMP(5);
         // 2. the products for this slab's 16 columns
-        d4 accW = (d4){0.0, 0.0, 0.0, 0.0}, accQ = accW;
+        d4 accW = (d4){0.0, 0.0, 0.0, 0.0}, accQ = accW, accW1 = accW, accQ1 = accW;
         if (active) {
             // A fragments straight from L2: one 16-byte load per lane and pair of k-steps, RR_PF pairs in flight ahead of the MFMAs that
             // use them and as many behind them (an L2 round trip is 1 us, a pair of MFMAs 0.05)
@@ -319,14 +322,12 @@ __global__ __launch_bounds__(256) void rollout_resident_kernel(RolloutResidentAr
                     const int pr = pb + i;
                     if (pr < p1) {
                         const int m0 = 8 * pr + lk;
-                        if (hasq) {
-                            accQ = mfma_f64(cur[i].x, WQp[m0 * 16 + lr], accQ);
-                            accQ = mfma_f64(cur[i].y, WQp[(m0 + 4) * 16 + lr], accQ);
-                        }
-                        if (pr < npW) {
-                            accW = mfma_f64(cur[i].x, Wp[m0 * 16 + lr], accW);
-                            accW = mfma_f64(cur[i].y, Wp[(m0 + 4) * 16 + lr], accW);
-                        }
+                        // (four accumulators in turn: an MFMA that adds to the previous one's result waits for it -- with two chains the
+                        //  loop ran at half the pipe's rate)
+                        if (hasq) accQ = mfma_f64(cur[i].x, WQp[m0 * 16 + lr], accQ);
+                        if (pr < npW) accW = mfma_f64(cur[i].x, Wp[m0 * 16 + lr], accW);
+                        if (hasq) accQ1 = mfma_f64(cur[i].y, WQp[(m0 + 4) * 16 + lr], accQ1);
+                        if (pr < npW) accW1 = mfma_f64(cur[i].y, Wp[(m0 + 4) * 16 + lr], accW1);
                     }
                 }
 #pragma unroll
@@ -336,8 +337,8 @@ __global__ __launch_bounds__(256) void rollout_resident_kernel(RolloutResidentAr
         RR_STAMP(6);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            red[((wave * 2 + 0) * 4 + q) * 64 + lane] = accW[q];
-            red[((wave * 2 + 1) * 4 + q) * 64 + lane] = accQ[q];
+            red[((wave * 2 + 0) * 4 + q) * 64 + lane] = accW[q] + accW1[q];
+            red[((wave * 2 + 1) * 4 + q) * 64 + lane] = accQ[q] + accQ1[q];
         }
         __syncthreads();
         if (active && kp == 0) {
