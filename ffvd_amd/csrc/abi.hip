@@ -39,6 +39,7 @@ struct ffvd_handle {
     double *dinvK = nullptr, *dinvH = nullptr;   // Cholesky scratch (kernels.h DINV_STRIDE per matrix)
     double *gpart = nullptr;                     // split-K partial tiles of the Gram kernel (few units per pass)
     int gsplit = 1;
+    bool side_late = false;     // few chains, forward: the K_uu side chain as ONE dataflow launch BEHIND the tile pass (plan_schedule); decided with gsplit at create
     double *graw = nullptr;                      // unsplit first pass: raw Gram tiles for the deferred trace pass
     double *gtail = nullptr;                     // unsplit passes: blocks + counters of the tail split (kernels.h GramArgs)
     int gtail_wg = 0;
@@ -57,6 +58,7 @@ struct ffvd_handle {
         int small_side_rows = 32;         // FFVD_SMALL_SIDE_ROWS: block rows of the K_uu chain (Dl * 2 * Mp / 64) up to which the side chain is ONE dataflow launch
         int small_side_wgs = 512;         // FFVD_SMALL_SIDE_WGS: tile-pass workgroups (one round of the chip) up to which an iteration counts as tiny (see small_side)
         bool no_small_side = false;       // FFVD_NO_SMALL_SIDE=1: tiny iterations keep the launch-per-step K_uu chain (round 2)
+        bool no_side_late = false;        // FFVD_NO_SIDE_LATE=1: few-chain forward iterations keep the K_uu chain beside the tile pass (round 4, first half)
         bool ref_row_in_gram = false;     // FFVD_REF_ROW_IN_GRAM=1: reference route, delta^T F formed by the Gram kernel's diagonal tiles (rounds 1-2)
         bool no_ref_side = false;         // FFVD_NO_REF_SIDE=1: reference route / explicit-U branch with the K_uu chain on the main stream in front of the K_fu build
         bool no_linear_lowrank = false;   // FFVD_NO_LINEAR_LOWRANK=1: LinearK explicit-U forward through the M-wide projection (rounds 1-2)
@@ -214,7 +216,7 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
         w.fused_project = on("FFVD_FUSED_PROJECT");   w.grad_explicit = on("FFVD_GRAD_EXPLICIT");
         w.no_defer_trace = on("FFVD_NO_DEFER_TRACE"); w.no_late_join = on("FFVD_NO_LATE_JOIN");
         w.no_main_first = on("FFVD_NO_MAIN_FIRST");   w.no_kfu_first = on("FFVD_NO_KFU_FIRST");
-        w.whiten_products = on("FFVD_GRAD_WHITEN_PRODUCTS");   w.lt_armed = on("FFVD_GRAD_LT_ARMED");   w.no_small_side = on("FFVD_NO_SMALL_SIDE");   if (const char *e = getenv("FFVD_SMALL_SIDE_WGS")) w.small_side_wgs = atoi(e);   if (const char *e = getenv("FFVD_SMALL_SIDE_ROWS")) w.small_side_rows = atoi(e);   w.ref_row_in_gram = on("FFVD_REF_ROW_IN_GRAM");   w.no_ref_side = on("FFVD_NO_REF_SIDE");   w.no_linear_lowrank = on("FFVD_NO_LINEAR_LOWRANK");
+        w.whiten_products = on("FFVD_GRAD_WHITEN_PRODUCTS");   w.lt_armed = on("FFVD_GRAD_LT_ARMED");   w.no_small_side = on("FFVD_NO_SMALL_SIDE");   w.no_side_late = on("FFVD_NO_SIDE_LATE");   if (const char *e = getenv("FFVD_SMALL_SIDE_WGS")) w.small_side_wgs = atoi(e);   if (const char *e = getenv("FFVD_SMALL_SIDE_ROWS")) w.small_side_rows = atoi(e);   w.ref_row_in_gram = on("FFVD_REF_ROW_IN_GRAM");   w.no_ref_side = on("FFVD_NO_REF_SIDE");   w.no_linear_lowrank = on("FFVD_NO_LINEAR_LOWRANK");
         w.kuu_flow = !on("FFVD_NO_KUU_FLOW");   w.kinv_gram = on("FFVD_KINV_GRAM");   w.chain_rl = on("FFVD_CHAIN_RL");
         w.atb128 = on("FFVD_ATB128");                 w.grad_serial = on("FFVD_GRAD_SERIAL");
         w.debug_sync = on("FFVD_DEBUG_SYNC");
@@ -402,7 +404,18 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
         const int upass = h->cpp * (int)Dl;
         // the K_fu build forms delta^T K_fu (Gram route) / the projection GEMM forms delta^T F (reference route): the Gram kernel has no row
         const bool ext_row = (c.route == FFVD_ROUTE_GRAM && c.T_total == 0) || (c.route == FFVD_ROUTE_REFERENCE && h->ngr > 0 && !h->sw.ref_row_in_gram);
-        h->gsplit = gram_ksplit((int)Mp, upass, (int)Tp, ext_row ? 0 : 1);
+        // Few chains (one pass, no backward pass): the K_uu side chain goes BEHIND the tile pass as one dataflow launch (beside Cholesky(A)),
+        // and the tile pass takes the row ranges that fill the chip's 512 slots exactly -- beside the pass, the chain's two dozen launches
+        // only ran where the pass left slots free, which is what held the pass at three ranges (plan_schedule, side_late)
+        h->side_late = c.route == FFVD_ROUTE_GRAM && !c.grad && c.T_total == 0 && c.S_local <= h->cpp && upass <= 32 && !h->sw.no_side_late &&
+                       !h->sw.no_defer_trace && !h->sw.no_late_join && !h->sw.no_main_first && !h->sw.chain_rl &&
+                       (size_t)Dl * 2 * (Mp / NB) <= 64 && (size_t)Dl * 2 * (Mp / NB) > (size_t)h->sw.small_side_rows &&
+                       potrf_flow_forms_inverse((int)Mp, (int)Dl, CHOL_FLOW);
+        if (h->side_late) {
+            h->gsplit = gram_ksplit((int)Mp, upass, (int)Tp, ext_row ? 0 : 1, true);
+            if (h->gsplit <= 1) h->side_late = false;
+        }
+        if (!h->side_late) h->gsplit = gram_ksplit((int)Mp, upass, (int)Tp, ext_row ? 0 : 1);
         if (ext_row) HIP_TRY(dev_alloc(h, &h->growpart, (size_t)upass * (Tp / 64) * Mp));
         h->gtail_wg = gram_tail_wg((int)Mp, upass, h->gsplit, ext_row ? 0 : 1);
         if (h->gtail_wg > 0) {
@@ -619,6 +632,7 @@ struct ElboSchedule {
     bool kuu_flow;                  //   ... as ONE dataflow launch resident before the K_fu build, joined before the Gram kernel
     bool kfu_first, ident_on_side;
     bool zt_rows, ref_side;         // explicit-U / reference route: the chain's dataflow launch beside the K_fu build
+    bool side_late;                 // few chains: the side chain as one dataflow launch BEHIND the tile pass, trace partials and reductions behind it on the side stream
     bool small_side;                // tiny iteration on the multi-kernel path: the side chain as one dataflow launch, reductions on the main stream
     bool chain_flow_here;           // the chain is the dataflow launch on the stream that builds K_uu (the build zeroes its words)
     bool reduce_early;
@@ -656,15 +670,19 @@ static ElboSchedule plan_schedule(const ffvd_handle *h) {
     //  the tile pass and its tail ends 0.14 ms behind Cholesky(A).  As ONE dataflow launch beside the K_fu build it holds its slots
     //  against the tile pass instead: that pass 1.43 instead of 1.18 ms at 16 chains, the iteration 1.91 either way; a main stream whose
     //  CU mask leaves 8-32 compute units to the side stream runs 1.2 x slower; `small_side` widened to these sizes: 1.19 vs 1.14 ms at 8.)
-    sc.chain_flow_here = !kuu_on_main && (!on_side || sc.small_side) && potrf_flow_selected(Mp, Dl, CHOL_FLOW) && !h->sw.chain_rl;
+    sc.side_late = h->side_late && sc.defer_trace && sc.main_first && !kuu_on_main && on_side && !sc.small_side &&
+                   potrf_flow_forms_inverse(Mp, Dl, CHOL_FLOW);            // (a forced launch-per-column Cholesky: the first-half schedule)
+    sc.chain_flow_here = !kuu_on_main && (!on_side || sc.small_side || sc.side_late) && potrf_flow_selected(Mp, Dl, CHOL_FLOW) && !h->sw.chain_rl;
     // invariants the launch code relies on (a violated one would be a silent wrong answer, not a crash)
     if ((sc.defer_full && sc.late_join) || (sc.defer_trace && !sc.late_join) || (sc.kuu_flow && sc.defer_full) || (sc.small_side && sc.kuu_flow) ||
+        (sc.side_late && (sc.small_side || !sc.main_first || !sc.chain_flow_here)) ||
         (sc.ref_side && sc.side_chain) || (sc.main_first && !sc.defer_trace) || (sc.kuu_flow && h->graw))
         sc.name = nullptr;
     else if (!sc.gram_route) sc.name = sc.ref_side ? "projection route, K_uu chain as one dataflow launch on the side stream beside the K_fu build"
                                                    : "projection route, serial (K_uu chain on the main stream)";
     else if (sc.kuu_flow) sc.name = "full unsplit: K_uu chain as one dataflow launch beside the K_fu build, joined before the Gram kernel";
     else if (sc.defer_full && sc.side_chain) sc.name = "unsplit with raw tiles: K_uu chain beside K_fu build and Gram kernel, trace pass on the side stream, joined at finalize";
+    else if (sc.side_late) sc.name = "side late: split-K one pass filling the chip, the K_uu chain as one dataflow launch behind it beside Cholesky(A), trace partials behind the chain";
     else if (sc.small_side) sc.name = "small side: split-K one pass, side chain as one dataflow launch, reductions and trace partials on the main stream";
     else if (sc.defer_trace) sc.name = "split-K one pass, late join: combine waits for the K_uu copy, trace partials on the side stream";
     else if (sc.late_join) sc.name = "split-K several passes: the first combine pass waits for the whole chain";
@@ -907,6 +925,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
     // nothing competes for slots and the side chain IS the critical path -- ONE dataflow launch that also leaves L^-1 and K^-1
     // instead of six dependent launches, and the per-chain reductions move to the main stream, which has the slack there
     const bool small_side = sc.small_side;
+    const bool side_late = sc.side_late;
     // (chain as the dataflow launch on the stream that builds K_uu: the build zeroes its progress words, one launch less)
     const bool chain_flow_here = sc.chain_flow_here;
     int chain_rc = FFVD_OK;
@@ -918,7 +937,12 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
             // (beside the K_fu build / tile pass of a small batch) the right-looking launches, whose workgroups come and go
             const bool chain_flow = chain_flow_here;
             if (chain_flow && (gram_route || grad_a || grad_ref)) linv_done = true;
-            if (chain_flow && small_side && gram_route && potrf_flow_forms_inverse((int)Mp, (int)Dl, CHOL_FLOW)) kinv_done = true;
+            if (chain_flow && (small_side || side_late) && gram_route && potrf_flow_forms_inverse((int)Mp, (int)Dl, CHOL_FLOW)) kinv_done = true;
+            if (side_late) {
+                // the reductions of the inputs first (they need nothing), then the chain once the tile pass has left the chip
+                if (reduce_early && !reduce_done) { launch_chain_reduce(sk, ra, h->chain_partial); reduce_launched = true; }
+                HIP_TRY(hipStreamWaitEvent(sk, h->ev_tiles, 0));
+            }
             launch_potrf_ext(sk, h->Kuu, Mp, zt_rows ? NB : Mp, zt_rows ? 0 : Mp, Dl, kstride, h->info, h->dinvK,
                              chain_flow ? CHOL_FLOW : CHOL_AUTO, linv_done ? h->Linv : nullptr, msq, chain_flow /* words zeroed by the build */,
                              false, kinv_done ? h->Kinv : nullptr, msq);
@@ -948,7 +972,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
         // the per-chain likelihood / transition reductions depend on the inputs only (Gram route: no row sums of F), so
         // they ride on the side stream behind the K_uu chain and are back long before finalize needs them (kuu_on_main: they
         // already ran on the main stream while it waited for the chain's kernel to be dispatched)
-        if (reduce_early && !reduce_done && !reduce_on_main) {
+        if (reduce_early && !reduce_done && !reduce_on_main && !reduce_launched) {
             launch_chain_reduce(sk, ra, h->chain_partial);
             HIP_TRY(hipEventRecord(h->ev_join2, sk));
         }

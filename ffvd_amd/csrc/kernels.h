@@ -183,7 +183,7 @@ struct GramArgs {
 };
 int gram_ntiles(int Mp);
 // how many row ranges launch_gram should use for `nb` units (1 = no split), and the doubles `part` then needs
-int gram_ksplit(int Mp, int nb, int rows, int with_row);
+int gram_ksplit(int Mp, int nb, int rows, int with_row, bool fill_slots = false);      // fill_slots: nothing runs beside the launch -- the row ranges that make it whole rounds of the chip's 512 slots
 size_t gram_part_doubles(int Mp, int nb, int ksplit);
 // phase 0: everything; 1: tile pass only; 2: combine pass only; 3: trace-only combine pass (split-K launches);
 // 4: combine pass (epilogue + trace) over `part` whatever ksplit is (T-shards: the all-reduced raw tiles, ksplit = 1)

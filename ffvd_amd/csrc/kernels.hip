@@ -3024,9 +3024,20 @@ static int gram_wg_per_unit(int Mp, int ksplit, int with_row);
 // Few tiles cannot fill the 512 workgroup slots (256 CUs x 2), and 1-2 tiles per slot balance badly (640 tiles take
 // 1.56 x the time of 512).  Measured at M = 512, T = 4096: 160 tiles 0.60 ms unsplit / 0.48 ms in 3 row ranges (one
 // full round) / 0.55-0.62 ms in 2, 4, 6, 8; 320 tiles 1.10 -> 0.86 ms in 3-4 ranges; 640 tiles 1.67 -> 1.52 ms in 2.
-int gram_ksplit(int Mp, int nb, int rows, int with_row) {
+int gram_ksplit(int Mp, int nb, int rows, int with_row, bool fill_slots) {
     if (const char *e = getenv("FFVD_GSPLIT")) return atoi(e) > 0 ? atoi(e) : 1;       // tuning override
     const int nchunk = rows / GT;
+    if (fill_slots && gram_uses_combos(Mp, 1, with_row) && GRAM_COMBO == 2) {
+        // Nothing beside the launch (the K_uu chain runs behind it): the ranges that give every slot of the chip one workgroup --
+        // tools/gsplit_s1.sh: 4 chains 320 us in four ranges against 382 in three, 2 chains 157 against 202, 1 chain 150 in eight
+        // Measured per-rank iterations, side chain behind the pass vs beside it in three ranges (tools/sync_step.py, same box):
+        // 8 chains 1.10 vs 1.20 ms (two ranges), 1-2 chains 0.525 / 0.550 vs 0.538 / 0.560 (eight ranges), but 4 chains 0.750 vs 0.734 --
+        // the chain's one launch with its inverse (250 us) outlasts Cholesky(A) by more than four ranges save there: not at 128 workgroups
+        const int n = nb * gram_wg_per_unit(Mp, 1, with_row);
+        if (n == 256 && nchunk / 2 >= 8) return 2;
+        if (n > 0 && n <= 64 && nchunk / 8 >= 8) return 8;
+        return 0;                                                                   // (the caller keeps the first-half schedule)
+    }
     if (gram_uses_combos(Mp, 1, with_row) && GRAM_COMBO == 2) {
         // pair combos: 8 workgroups per unit at M = 512.  Measured per-rank iteration times at config 2's shape, 1 .. 24 chains and
         // 1, 2, 3, 4, 6, 8 row ranges (tools/gram_split_sweep.sh, profiles/r04_gram_split.txt): three ranges are the best or within

@@ -1283,6 +1283,12 @@ def _schedule_case(case):
     if case == "c2_rank4":
         params, Y, c, meta = synthetic.make_named("c2", S=4)
         return params, Y, c, meta, dict(route="gram"), "split-K one pass"
+    if case == "c2_rank8":        # (forward at 8 and at 1-2 chains: the side chain behind the tile pass; with grad and at 4 chains: beside it)
+        params, Y, c, meta = synthetic.make_named("c2", S=8)
+        return params, Y, c, meta, dict(route="gram"), "side late"
+    if case == "c2_rank2":
+        params, Y, c, meta = synthetic.make_named("c2", S=2)
+        return params, Y, c, meta, dict(route="gram"), "side late"
     if case == "c2_16":           # (16 chains = 64 units = 512 workgroups, one whole round: unsplit, below the 128 units of the full-batch schedule)
         params, Y, c, meta = synthetic.make_named("c2", S=16)
         return params, Y, c, meta, dict(route="gram"), "unsplit with raw tiles"
@@ -1295,7 +1301,7 @@ def _schedule_case(case):
     raise KeyError(case)
 
 
-@pytest.mark.parametrize("case,grad", [("c2_full", False), ("c2_full", True), ("c2_rank4", False), ("c2_rank4", True), ("c2_16", False),
+@pytest.mark.parametrize("case,grad", [("c2_full", False), ("c2_full", True), ("c2_rank4", False), ("c2_rank4", True), ("c2_rank8", False), ("c2_rank2", False), ("c2_16", False),
                                        ("c2_reference", False), ("actuator_multi_kernel", False), ("actuator_multi_kernel", True)])
 def test_results_do_not_depend_on_which_stream_is_late(case, grad, monkeypatch):
     """the iteration runs on two streams tied by events, and a missing wait would not crash -- stale progress words or
