@@ -2882,8 +2882,19 @@ __global__ __launch_bounds__(512, 4) void gram_kernel(GramArgs a) {
     }
     // (pair combos last 9 / 8 of an off-diagonal tile; dealing them FIRST in the launch, one per CU while the chip fills, changed
     //  nothing against this unit-major order: 3.12 vs 3.12 ms, profiles/r04_ab_gram_pair.txt)
-    const int unit_l = loc / per_unit, wsel = loc % per_unit;
-    const int bz = unit_l * 8 + xcd;
+    int unit_l = loc / per_unit, wsel = loc % per_unit;
+    int bz = unit_l * 8 + xcd;
+    // Fewer units than XCDs (1-4 units of a one- or two-chain rank, split-K): a unit's row ranges are dealt to 8 / nb XCDs instead of all to
+    // one -- the ranges read disjoint rows of K_fu, so nothing is shared that an L2 could keep; half of the chip idled otherwise
+    // (one chain: 220 us of tile pass on four XCDs)
+    const int spread = (ksplit > 1 && a.combo && a.nb <= 4 && 8 % a.nb == 0 && ksplit % (8 / a.nb) == 0) ? 8 / a.nb : 1;
+    if (spread > 1) {
+        const int sub = per_unit / spread;                   // workgroups of a unit on this XCD
+        if (loc >= sub) return;
+        bz = xcd % a.nb;
+        const int rsub = xcd / a.nb, kper = ksplit / spread;
+        wsel = (loc / kper) * ksplit + (loc % kper) * spread + rsub;     // (tile w = loc / kper, row range (loc % kper) * spread + rsub)
+    }
     if (bz >= a.nb) return;
     int tile, kpart;
     if (a.combo) {

@@ -906,7 +906,9 @@ def test_two_processes_time_shard(tmp_path, monkeypatch):
 
 @pytest.mark.parametrize("ov,env", [(dict(M=256, T=320, S=3, D=2), {"FFVD_GSPLIT": "1"}),       # one off-diagonal tile + one pair combo per unit
                                     (dict(M=768, T=832, S=1, D=2), {"FFVD_GSPLIT": "1"}),       # 15 + 3
-                                    (dict(M=512, T=576, S=34, D=4), {})])                       # 1088 workgroups: 64 of them cut in row halves
+                                    (dict(M=512, T=576, S=34, D=4), {}),                        # 1088 workgroups: 64 of them cut in row halves
+                                    (dict(M=512, T=4096, S=1, D=4), {}),                        # 4 units in 8 row ranges: a unit's ranges on two XCDs
+                                    (dict(M=512, T=4096, S=1, D=2), {})])                       # 2 units: on four XCDs each
 def test_gram_pair_combos_other_shapes(ov, env, monkeypatch):
     """The 16-granular diagonal workgroups of the Gram kernel (two diagonal 128-tiles per workgroup, nine MFMA tiles per wavefront,
     LDS-DMA staging) away from config 2: other panel counts, and a launch whose last workgroups -- pair combos among them -- run as
