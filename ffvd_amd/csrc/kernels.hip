@@ -1225,6 +1225,7 @@ struct DfArgs {
     double *kinv;      // optional (identity rows = all of L^-T): (A)^-1 = L^-T L^-1, full symmetric n x n per slab (ld n), formed by
     size_t kinv_stride;//   the identity-row workgroups once their rows are complete (df_inverse_tiles)
     int defer_ext;     // block order: identity-structured rows of all groups behind the main rows of all groups (potrf_df_kernel)
+    int kinv_help;     // (with kinv, every workgroup resident at once) the main-row workgroups form half of the inverse's tiles: df_inverse_tiles
     int fine;          // small batches (every block row on a CU of its own): a main row also announces every COLUMN it has solved
                        // (word 2 nb + row), and a gather waits term by term -- see df_column
     const double *lt;  // optional: the identity-structured extra rows of slab b start as L_d^T (d = b % lt_dl) instead of what
@@ -1557,20 +1558,29 @@ __device__ __forceinline__ void df_vector_row(const DfArgs &a, double *S, int *p
 // A^-1 = L^-T L^-1 = W W^T:  (e,f) = sum_{j >= e} W(e,j) W(f,j)^T  (rows f < e belong to workgroups dispatched earlier).  The
 // same staging loop as the panel gather; both triangles are written.  A separate product launch after the factorisation
 // costs the K_uu chain 0.13-0.17 ms beside the K_fu build (its workgroups queue behind that kernel's), these tiles 0.04.
+// DfArgs::kinv_help (every workgroup of the launch resident at once): main-row workgroup e, done with its own block row, takes
+// the tiles (e, f) with e + f odd off identity-row workgroup e -- the most loaded one had 20 tile products behind the chain (60 us;
+// half of them now), and the main rows had left the chip by then.
 __device__ __forceinline__ bool df_inverse_tiles(const DfArgs &a, double *S, int *pg, const int b, const int e,
-                                                 double (*Xs)[LL_LD], double (*Ls)[LL_LD], int *wslot) {
+                                                 double (*Xs)[LL_LD], double (*Ls)[LL_LD], int *wslot, const bool helper = false) {
     const int n = a.n, nb = a.nb;
     const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qr = wave >> 1, qc = wave & 1;
     const int sr = tid >> 5, sc = 2 * (tid & 31);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wavefront's stores of the row have left it
-    __syncthreads();
-    if (tid == 0) df_publish(pg + nb + e, 1);
+    int wc = 0;
+    if (!helper) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wavefront's stores of the row have left it
+        __syncthreads();
+        if (tid == 0) df_publish(pg + nb + e, 1);
+    } else if (e > 0) {                                         // (tile (0, 0) is even: row 0's helper has nothing to do)
+        const int seen = df_wait(pg + nb + e, 1, a.abort_w, &wslot[wc++ & 1]);
+        if (seen < 0) return false;
+    }
     double *Kb = a.kinv + (size_t)b * a.kinv_stride;
     const double *We = S + (size_t)(n + e * NB) * n;
-    int wc = 0;
     for (int f = 0; f <= e; ++f) {
+        if (a.kinv_help && (((e + f) & 1) != 0) != helper) continue;
         if (f < e) {
             const int seen = df_wait(pg + nb + f, 1, a.abort_w, &wslot[wc++ & 1]);
             if (seen < 0) return false;
@@ -1769,6 +1779,12 @@ __global__ __launch_bounds__(256, 2) void potrf_df_kernel(DfArgs a) {
 #endif
     if (tid == 0) df_publish(pg + ri, ri + 1);
     DF_STAMP(trow, 50);
+    if (a.kinv_help) {
+        __syncthreads();                                      // (LDS of the diagonal factor is free again)
+        if (!df_inverse_tiles(a, S, pg, b, ri, Xs, Ls, wslot, true)) {
+            if (tid == 0 && a.info) a.info[b] = -1;
+        }
+    }
 }
 
 size_t potrf_scratch_doubles(int n, int batch) {
@@ -1819,6 +1835,8 @@ static void launch_potrf_flow(hipStream_t stream, double *A, int n, int extra_ro
     // (... and up to 640 block rows without identity-structured rows -- 64 matrices of a 16-chain rank: 1.87 vs 1.945 ms per iteration with
     //  one row per compute unit; 288 and 432 rows no difference, 864 none, 1152 rows 2 % slower: profiles/r04_ab_df_pad.txt)
     const bool one_per_cu = (size_t)batch * R <= 256 || (a.nid == 0 && (size_t)batch * R <= 640);
+    static const int kh_mode = [] { const char *e = getenv("FFVD_DF_KINV_HELP"); return e ? atoi(e) : -1; }();
+    a.kinv_help = (a.kinv && a.nid == a.nb && (size_t)batch * R <= 256 && kh_mode != 0) ? 1 : 0;
     const bool alone = (pad_mode >= 0) ? (pad_mode != 0) : one_per_cu;
     const int fine_mode = [] { const char *e = getenv("FFVD_DF_FINE"); return e ? atoi(e) : -1; }();      // (read per launch: tests switch it)
     a.fine = ((fine_mode >= 0 ? fine_mode != 0 : (alone && (size_t)batch * R <= 256)) && 3 * a.nb <= DF_PS) ? (fine_mode == 2 ? 2 : 1) : 0;    // (2: A/B, no early sums)
@@ -3041,11 +3059,12 @@ int gram_ksplit(int Mp, int nb, int rows, int with_row, bool fill_slots) {
     if (fill_slots && gram_uses_combos(Mp, 1, with_row) && GRAM_COMBO == 2) {
         // Nothing beside the launch (the K_uu chain runs behind it): the ranges that give every slot of the chip one workgroup --
         // tools/gsplit_s1.sh: 4 chains 320 us in four ranges against 382 in three, 2 chains 157 against 202, 1 chain 150 in eight
-        // Measured per-rank iterations, side chain behind the pass vs beside it in three ranges (tools/sync_step.py, same box):
-        // 8 chains 1.10 vs 1.20 ms (two ranges), 1-2 chains 0.525 / 0.550 vs 0.538 / 0.560 (eight ranges), but 4 chains 0.750 vs 0.734 --
-        // the chain's one launch with its inverse (250 us) outlasts Cholesky(A) by more than four ranges save there: not at 128 workgroups
+        // Measured per-rank iterations, side chain behind the pass vs beside it in three ranges (tools/sync_step.py, same box,
+        // profiles/r04_ab_side_late.txt): 8 chains 1.07 vs 1.20 ms (two ranges), 4 chains 0.688 vs 0.705 (four; 0.750 vs 0.734 before the
+        // main-row workgroups of the chain's launch helped with its inverse), 1-2 chains 0.44 / 0.53 vs 0.54 / 0.56 (eight ranges)
         const int n = nb * gram_wg_per_unit(Mp, 1, with_row);
-        if (n == 256 && nchunk / 2 >= 8) return 2;
+        for (int ks = 2; ks <= 8; ks *= 2)
+            if (n * ks == 512 && nchunk / ks >= 8) return ks;
         if (n > 0 && n <= 64 && nchunk / 8 >= 8) return 8;
         return 0;                                                                   // (the caller keeps the first-half schedule)
     }

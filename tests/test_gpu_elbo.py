@@ -1282,10 +1282,13 @@ def _schedule_case(case):
     if case == "c2_full":
         params, Y, c, meta = synthetic.make_named("c2")
         return params, Y, c, meta, dict(route="gram"), "full unsplit"
-    if case == "c2_rank4":
+    if case == "c2_rank4":        # (forward at 1, 2, 4, 8 chains: the side chain behind the tile pass; with grad and at other counts: beside it)
         params, Y, c, meta = synthetic.make_named("c2", S=4)
+        return params, Y, c, meta, dict(route="gram"), "side late"
+    if case == "c2_rank3":
+        params, Y, c, meta = synthetic.make_named("c2", S=3)
         return params, Y, c, meta, dict(route="gram"), "split-K one pass"
-    if case == "c2_rank8":        # (forward at 8 and at 1-2 chains: the side chain behind the tile pass; with grad and at 4 chains: beside it)
+    if case == "c2_rank8":
         params, Y, c, meta = synthetic.make_named("c2", S=8)
         return params, Y, c, meta, dict(route="gram"), "side late"
     if case == "c2_rank2":
@@ -1303,7 +1306,7 @@ def _schedule_case(case):
     raise KeyError(case)
 
 
-@pytest.mark.parametrize("case,grad", [("c2_full", False), ("c2_full", True), ("c2_rank4", False), ("c2_rank4", True), ("c2_rank8", False), ("c2_rank2", False), ("c2_16", False),
+@pytest.mark.parametrize("case,grad", [("c2_full", False), ("c2_full", True), ("c2_rank4", False), ("c2_rank4", True), ("c2_rank3", False), ("c2_rank8", False), ("c2_rank2", False), ("c2_16", False),
                                        ("c2_reference", False), ("actuator_multi_kernel", False), ("actuator_multi_kernel", True)])
 def test_results_do_not_depend_on_which_stream_is_late(case, grad, monkeypatch):
     """the iteration runs on two streams tied by events, and a missing wait would not crash -- stale progress words or
