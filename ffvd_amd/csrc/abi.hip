@@ -1049,7 +1049,11 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
                     if (!main_first) HIP_TRY(hipEventRecord(h->ev_tiles, s));
                     HIP_TRY(hipStreamWaitEvent(s, h->ev_kuu, 0));
                     ga.trace_mode = 1;
+                    // side late: the trace pass runs long after this one (behind the K_uu chain) -- it reads the summed raw tiles this
+                    // pass leaves in partial 0 instead of all the row ranges again (134 MB at 4 chains: 20-27 us of the iteration's tail)
+                    ga.raw_summed = (side_late || small_side) ? 1 : 0;      // (small side: the trace pass follows on this stream)
                     launch_gram(s, ga, 2);
+                    if (side_late) HIP_TRY(hipEventRecord(h->ev_tiles, s));      // (the trace pass below waits for THIS record)
                     trace_pending = true;      // enqueued behind the factorisation: the main stream is the critical one
                 } else {
                     HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));

@@ -166,6 +166,7 @@ struct GramArgs {
     // combine pass only: 0 = epilogue + trace partials, 1 = epilogue without the trace (K^-1 not read), 2 = trace partials
     // only (H not written) -- lets the combine run before K^-1 exists and the trace follow on another stream
     int trace_mode;
+    int raw_summed;     // split-K combine: the pass without the trace (trace_mode 1) leaves the summed raw tile in partial 0, the trace pass (2) reads only that -- the caller orders the two passes
     // Launches without a delta^T A row, Mp a multiple of 256: (1) the diagonal tiles of every two neighbouring column panels are
     // ONE workgroup ("pair combo", gram_pair_role, round 4: row blocks i and 7 - i of a diagonal tile on one wavefront, nine MFMA
     // tiles, nothing above the diagonal executed; also the diagonal workgroups of split-K launches).  Round 3's form -- three

@@ -2998,10 +2998,12 @@ __global__ __launch_bounds__(1024) void gram_combine_kernel(GramArgs a) {
         const int i = I0 + ri, j = J0 + cj;
         const size_t off = (size_t)i * Mp + j;
         double2 g = {0.0, 0.0};
-        for (int ks = 0; ks < a.ksplit; ++ks) {
+        const int nks = (a.raw_summed && a.trace_mode == 2) ? 1 : a.ksplit;
+        for (int ks = 0; ks < nks; ++ks) {
             const double2 q = *reinterpret_cast<const double2 *>(P0 + (size_t)ks * ks_stride + off);
             g.x += q.x; g.y += q.y;
         }
+        if (a.raw_summed && a.trace_mode == 1) *reinterpret_cast<double2 *>(const_cast<double *>(P0) + off) = g;      // (this thread alone reads and writes the element)
         double2 v = {0.0, 0.0};
         if (MODE == GRAM_F) {
             v.x = g.x * scale + ((i == j) ? 1.0 : 0.0);
