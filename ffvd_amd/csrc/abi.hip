@@ -407,10 +407,11 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
         // Few chains (one pass, no backward pass): the K_uu side chain goes BEHIND the tile pass as one dataflow launch (beside Cholesky(A)),
         // and the tile pass takes the row ranges that fill the chip's 512 slots exactly -- beside the pass, the chain's two dozen launches
         // only ran where the pass left slots free, which is what held the pass at three ranges (plan_schedule, side_late)
-        h->side_late = c.route == FFVD_ROUTE_GRAM && !c.grad && c.T_total == 0 && c.S_local <= h->cpp && upass <= 32 && !h->sw.no_side_late &&
-                       !h->sw.no_defer_trace && !h->sw.no_late_join && !h->sw.no_main_first && !h->sw.chain_rl &&
-                       (size_t)Dl * 2 * (Mp / NB) <= 64 && (size_t)Dl * 2 * (Mp / NB) > (size_t)h->sw.small_side_rows &&
-                       potrf_flow_forms_inverse((int)Mp, (int)Dl, CHOL_FLOW);
+        const bool late_ok = c.route == FFVD_ROUTE_GRAM && !c.grad && c.T_total == 0 && c.S_local <= h->cpp && !h->sw.no_side_late &&
+                             !h->sw.no_defer_trace && !h->sw.no_late_join && !h->sw.no_main_first && !h->sw.chain_rl &&
+                             (size_t)Dl * 2 * (Mp / NB) <= 64 && (size_t)Dl * 2 * (Mp / NB) > (size_t)h->sw.small_side_rows &&
+                             potrf_flow_forms_inverse((int)Mp, (int)Dl, CHOL_FLOW);
+        h->side_late = late_ok && upass <= 32;
         if (h->side_late) {
             h->gsplit = gram_ksplit((int)Mp, upass, (int)Tp, ext_row ? 0 : 1, true);
             if (h->gsplit <= 1) h->side_late = false;
@@ -427,8 +428,12 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
             // a K_fu build of 0.4 ms or more: the K_uu chain as ONE dataflow launch finishes beside it, the main stream
             // joins before the Gram kernel, which then forms the trace partials in its own epilogue
             h->kuu_flow_sched = true;
-        else if (c.route == FFVD_ROUTE_GRAM && (size_t)upass * Tp * Mp >= (size_t)64 * 4096 * 512 && !h->sw.no_defer_trace)
+        else if (c.route == FFVD_ROUTE_GRAM && (size_t)upass * Tp * Mp >= (size_t)64 * 4096 * 512 && !h->sw.no_defer_trace) {
             HIP_TRY(dev_alloc(h, &h->graw, (size_t)upass * (Mp + 1) * Mp));   // raw tiles + trace pass beside Cholesky(A)
+            // (unsplit pass of up to 16 chains: the chain's launches were starved by the pass and ended 0.1 ms behind Cholesky(A) -- behind
+            //  the pass as one dataflow launch as well)
+            h->side_late = late_ok && upass <= 64;
+        }
     }
     if (c.branch == FFVD_BRANCH_A && !c.grad && !h->sw.no_linear_lowrank && linear_lowrank_supported(c.kernel_kind, P))
         HIP_TRY(dev_alloc(h, &h->lrpart, linear_lowrank_doubles((int)Mp, (int)Dl, P)));
@@ -670,17 +675,18 @@ static ElboSchedule plan_schedule(const ffvd_handle *h) {
     //  the tile pass and its tail ends 0.14 ms behind Cholesky(A).  As ONE dataflow launch beside the K_fu build it holds its slots
     //  against the tile pass instead: that pass 1.43 instead of 1.18 ms at 16 chains, the iteration 1.91 either way; a main stream whose
     //  CU mask leaves 8-32 compute units to the side stream runs 1.2 x slower; `small_side` widened to these sizes: 1.19 vs 1.14 ms at 8.)
-    sc.side_late = h->side_late && sc.defer_trace && sc.main_first && !kuu_on_main && on_side && !sc.small_side &&
+    sc.side_late = h->side_late && ((sc.defer_trace && sc.main_first) || (sc.defer_full && sc.kfu_first)) && !kuu_on_main && on_side && !sc.small_side &&
                    potrf_flow_forms_inverse(Mp, Dl, CHOL_FLOW);            // (a forced launch-per-column Cholesky: the first-half schedule)
     sc.chain_flow_here = !kuu_on_main && (!on_side || sc.small_side || sc.side_late) && potrf_flow_selected(Mp, Dl, CHOL_FLOW) && !h->sw.chain_rl;
     // invariants the launch code relies on (a violated one would be a silent wrong answer, not a crash)
     if ((sc.defer_full && sc.late_join) || (sc.defer_trace && !sc.late_join) || (sc.kuu_flow && sc.defer_full) || (sc.small_side && sc.kuu_flow) ||
-        (sc.side_late && (sc.small_side || !sc.main_first || !sc.chain_flow_here)) ||
+        (sc.side_late && (sc.small_side || !(sc.main_first || sc.defer_full) || !sc.chain_flow_here)) ||
         (sc.ref_side && sc.side_chain) || (sc.main_first && !sc.defer_trace) || (sc.kuu_flow && h->graw))
         sc.name = nullptr;
     else if (!sc.gram_route) sc.name = sc.ref_side ? "projection route, K_uu chain as one dataflow launch on the side stream beside the K_fu build"
                                                    : "projection route, serial (K_uu chain on the main stream)";
     else if (sc.kuu_flow) sc.name = "full unsplit: K_uu chain as one dataflow launch beside the K_fu build, joined before the Gram kernel";
+    else if (sc.side_late && sc.defer_full) sc.name = "side late: unsplit pass with raw tiles, the K_uu chain as one dataflow launch behind it beside Cholesky(A), trace pass behind the chain";
     else if (sc.defer_full && sc.side_chain) sc.name = "unsplit with raw tiles: K_uu chain beside K_fu build and Gram kernel, trace pass on the side stream, joined at finalize";
     else if (sc.side_late) sc.name = "side late: split-K one pass filling the chip, the K_uu chain as one dataflow launch behind it beside Cholesky(A), trace partials behind the chain";
     else if (sc.small_side) sc.name = "small side: split-K one pass, side chain as one dataflow launch, reductions and trace partials on the main stream";
@@ -983,7 +989,8 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
                          chain_flow_here ? h->dinvK : nullptr);
         if (defer_trace || (defer_full && sk != s)) HIP_TRY(hipEventRecord(h->ev_kuu, sk));
     }
-    if ((chain_rc = chain_rest()) != FFVD_OK) return chain_rc;
+    const bool chain_deferred = side_late && defer_full;       // the chain is enqueued behind the first pass's Gram launch (below)
+    if (!chain_deferred && (chain_rc = chain_rest()) != FFVD_OK) return chain_rc;
     DBG_SYNC(h, "forward: K_uu chain");
     if (st && !kfu_first) st->mark(0);
     for (int s0 = 0; s0 < c.S_local; s0 += h->cpp) {
@@ -1084,6 +1091,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
                 // hop (chain -> here) instead of two (tile pass -> side stream, side stream -> finalize)
                 trace_on_main = true;
             } else if (trace_pending) {
+                if (chain_deferred && s0 == 0 && (chain_rc = chain_rest()) != FFVD_OK) return chain_rc;      // (waits for ev_tiles itself)
                 // trace partials from the raw tiles, on the side stream (K^-1 precedes in its order).  Enqueued AHEAD of the
                 // factorisation: that is one launch whose row workgroups hold every slot of the chip for most of its length,
                 // and a kernel that arrives behind it only starts when they leave (finalize then waited 0.26 ms for this pass)

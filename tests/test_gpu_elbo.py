@@ -1296,7 +1296,7 @@ def _schedule_case(case):
         return params, Y, c, meta, dict(route="gram"), "side late"
     if case == "c2_16":           # (16 chains = 64 units = 512 workgroups, one whole round: unsplit, below the 128 units of the full-batch schedule)
         params, Y, c, meta = synthetic.make_named("c2", S=16)
-        return params, Y, c, meta, dict(route="gram"), "unsplit with raw tiles"
+        return params, Y, c, meta, dict(route="gram"), "side late: unsplit pass with raw tiles"
     if case == "c2_reference":
         params, Y, c, meta = synthetic.make_named("c2", S=8)
         return params, Y, c, meta, dict(route="reference"), "projection route, K_uu chain as one dataflow launch on the side stream"
