@@ -411,7 +411,7 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
                              !h->sw.no_defer_trace && !h->sw.no_late_join && !h->sw.no_main_first && !h->sw.chain_rl &&
                              (size_t)Dl * 2 * (Mp / NB) <= 64 && (size_t)Dl * 2 * (Mp / NB) > (size_t)h->sw.small_side_rows &&
                              potrf_flow_forms_inverse((int)Mp, (int)Dl, CHOL_FLOW);
-        h->side_late = late_ok && upass <= 32;
+        h->side_late = late_ok && upass <= 96;
         if (h->side_late) {
             h->gsplit = gram_ksplit((int)Mp, upass, (int)Tp, ext_row ? 0 : 1, true);
             if (h->gsplit <= 1) h->side_late = false;

@@ -3065,8 +3065,11 @@ int gram_ksplit(int Mp, int nb, int rows, int with_row, bool fill_slots) {
         // profiles/r04_ab_side_late.txt): 8 chains 1.07 vs 1.20 ms (two ranges), 4 chains 0.688 vs 0.705 (four; 0.750 vs 0.734 before the
         // main-row workgroups of the chain's launch helped with its inverse), 1-2 chains 0.44 / 0.53 vs 0.54 / 0.56 (eight ranges)
         const int n = nb * gram_wg_per_unit(Mp, 1, with_row);
-        for (int ks = 2; ks <= 8; ks *= 2)
-            if (n * ks == 512 && nchunk / ks >= 8) return ks;
+        // (other chain counts, whole rounds of the 512 slots: 6 / 12 / 24 chains = three rounds in 8 / 4 / 2 ranges 0.887 / 1.43 / 2.47 vs
+        //  0.911 / 1.47 / 2.60 ms; 20 chains = five rounds in four ranges 2.275 vs 2.176: not beyond three rounds)
+        if (n > 0 && n % 512 == 0) return 0;                                         // (whole rounds unsplit: the caller's unsplit schedule)
+        for (int ks = 2; ks <= 8; ++ks)
+            if (n > 0 && (n * ks) % 512 == 0 && n * ks <= 1536 && nchunk / ks >= 8) return ks;
         if (n > 0 && n <= 64 && nchunk / 8 >= 8) return 8;
         return 0;                                                                   // (the caller keeps the first-half schedule)
     }
