@@ -951,7 +951,7 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
             }
             launch_potrf_ext(sk, h->Kuu, Mp, zt_rows ? NB : Mp, zt_rows ? 0 : Mp, Dl, kstride, h->info, h->dinvK,
                              chain_flow ? CHOL_FLOW : CHOL_AUTO, linv_done ? h->Linv : nullptr, msq, chain_flow /* words zeroed by the build */,
-                             false, kinv_done ? h->Kinv : nullptr, msq);
+                             false, kinv_done ? h->Kinv : nullptr, msq, nullptr, 0, 1, small_side || side_late);
         }
         if (gram_route || grad_a || grad_ref) {
             // K^-1 = L^-T L^-1 (shared by all chains) and log|K|

@@ -72,7 +72,9 @@ bool potrf_flow_selected(int n, int batch, int hint);
 void launch_potrf_ext(hipStream_t stream, double *A, int n, int extra_rows, int identity_rows, int batch,
                       size_t slab_stride, int32_t *info, double *dinv, int hint = CHOL_AUTO, double *linv_t = nullptr,
                       size_t linv_t_stride = 0, bool words_zeroed = false, bool tail_is_vector = false, double *kinv = nullptr,
-                      size_t kinv_stride = 0, const double *lt_rows = nullptr, size_t lt_stride = 0, int lt_dl = 1);
+                      size_t kinv_stride = 0, const double *lt_rows = nullptr, size_t lt_stride = 0, int lt_dl = 1,
+                      bool kinv_help = false);      // (with kinv, dataflow variant, whole launch resident: the main-row workgroups stay and form half of the inverse's tiles --
+                                                    //  for a chain that runs beside little else; beside the full batch's K_fu build they were in its way: 0.062 vs 0.053 ms)
 // lt_rows (dataflow variant only -- ask potrf_flow_selected; the others read the rows from memory, arm them with
 // launch_set_lt_rows): the identity-structured extra rows of slab b START as L_d^T, d = b % lt_dl, read straight from the
 // lower-triangular factor L_d (n x n, ld n, slabs of lt_stride doubles) -- the rows in memory are not read, only written (and

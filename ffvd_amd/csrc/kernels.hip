@@ -1807,7 +1807,7 @@ void potrf_flow_clear(hipStream_t stream, double *scratch, int batch) {
 static void launch_potrf_flow(hipStream_t stream, double *A, int n, int extra_rows, int identity_rows, int batch,
                               size_t slab_stride, int32_t *info, double *scratch, double *linv_t, size_t linv_t_stride,
                               bool words_zeroed, bool tail_is_vector, double *kinv, size_t kinv_stride, const double *lt_rows,
-                              size_t lt_stride, int lt_dl) {
+                              size_t lt_stride, int lt_dl, bool kinv_help) {
     DfArgs a{};
     a.lt = lt_rows; a.lt_stride = lt_stride; a.lt_dl = lt_dl > 0 ? lt_dl : 1;
     a.xt = linv_t; a.xt_stride = linv_t_stride;
@@ -1836,7 +1836,7 @@ static void launch_potrf_flow(hipStream_t stream, double *A, int n, int extra_ro
     //  one row per compute unit; 288 and 432 rows no difference, 864 none, 1152 rows 2 % slower: profiles/r04_ab_df_pad.txt)
     const bool one_per_cu = (size_t)batch * R <= 256 || (a.nid == 0 && (size_t)batch * R <= 640);
     static const int kh_mode = [] { const char *e = getenv("FFVD_DF_KINV_HELP"); return e ? atoi(e) : -1; }();
-    a.kinv_help = (a.kinv && a.nid == a.nb && (size_t)batch * R <= 256 && kh_mode != 0) ? 1 : 0;
+    a.kinv_help = (kinv_help && a.kinv && a.nid == a.nb && (size_t)batch * R <= 256 && kh_mode != 0) ? 1 : 0;
     const bool alone = (pad_mode >= 0) ? (pad_mode != 0) : one_per_cu;
     const int fine_mode = [] { const char *e = getenv("FFVD_DF_FINE"); return e ? atoi(e) : -1; }();      // (read per launch: tests switch it)
     a.fine = ((fine_mode >= 0 ? fine_mode != 0 : (alone && (size_t)batch * R <= 256)) && 3 * a.nb <= DF_PS) ? (fine_mode == 2 ? 2 : 1) : 0;    // (2: A/B, no early sums)
@@ -1874,13 +1874,13 @@ static int chol_variant(int batch, int nb, int hint) {
 void launch_potrf_ext(hipStream_t stream, double *A, int n, int extra_rows, int identity_rows, int batch,
                       size_t slab_stride, int32_t *info, double *dinv, int hint, double *linv_t, size_t linv_t_stride,
                       bool words_zeroed, bool tail_is_vector, double *kinv, size_t kinv_stride, const double *lt_rows,
-                      size_t lt_stride, int lt_dl) {
+                      size_t lt_stride, int lt_dl, bool kinv_help) {
     const int nb = n / NB;
     const int nid = identity_rows / NB, ntail = extra_rows / NB - nid;
     const int variant = chol_variant(batch, nb, hint);
     if (variant == 3) {
         launch_potrf_flow(stream, A, n, extra_rows, identity_rows, batch, slab_stride, info, dinv, linv_t, linv_t_stride, words_zeroed,
-                          tail_is_vector, kinv, kinv_stride, lt_rows, lt_stride, lt_dl);
+                          tail_is_vector, kinv, kinv_stride, lt_rows, lt_stride, lt_dl, kinv_help);
         return;
     }
     if (variant == 1) {
