@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void rollout_resident_kernel(RolloutResidentAr
     else if (RT == 2) { nkp = 2; rt = wave & 1; kp = wave >> 1; }
     else { nkp = 1; rt = wave; kp = 0; }
     const bool active = rt < RT;
-    // the contraction in PAIRS of k-steps (8 inducing points): Kt keeps the two values a lane needs for a pair side by side
+    // the contraction in PAIRS of k-steps (8 inducing points)
     const int npW = mlim / 8, ppW = (npW + nkp - 1) / nkp, pw0 = kp * ppW, pw1 = (pw0 + ppW < npW) ? pw0 + ppW : npW;
     const int npQ = Mp / 8, ppQ = (npQ + nkp - 1) / nkp, pq0 = kp * ppQ, pq1 = (pq0 + ppQ < npQ) ? pq0 + ppQ : npQ;
     double *Ktd = a.Kt + (size_t)d * Mp * RP;
@@ -287,10 +287,7 @@ __global__ __launch_bounds__(256) void rollout_resident_kernel(RolloutResidentAr
                 for (int p = 0; p < 8; ++p) { const double xv = xrow[r * 8 + p]; dot += xv * zr[p]; if (KIND == 0) xx += xv * xv; }
                 double v = kernel_value<KIND>(dot, xx, zzm, var);
                 if (r >= R || !mok) v = 0.0;
-                // K(x_r, z_m), m = 8 a + 4 b + c, at ((4 a + c) RP + r) 2 + b: lane (r, c) of a product wavefront reads k-steps 2 a and
-                // 2 a + 1 with one 16-byte load
-                const int mg = j0 + m;
-                rr_store(Ktd + ((size_t)((mg >> 3) * 4 + (mg & 3)) * RP + r) * 2 + ((mg >> 2) & 1), v);
+                rr_store(Ktd + (size_t)(j0 + m) * RP + r, v);
             }
         }
         RR_STAMP(3);
@@ -301,13 +298,12 @@ __global__ __launch_bounds__(256) void rollout_resident_kernel(RolloutResidentAr
         // 2. the products for this slab's 16 columns
         d4 accW = (d4){0.0, 0.0, 0.0, 0.0}, accQ = accW, accW1 = accW, accQ1 = accW;
         if (active) {
-            // A fragments straight from L2: one 16-byte load per lane and pair of k-steps, RR_PF pairs in flight ahead of the MFMAs that
-            // use them and as many behind them (an L2 round trip is 1 us, a pair of MFMAs 0.05)
-            const double *Ka = Ktd + ((size_t)lk * RP + 16 * rt + lr) * 2;                // pair a: Ka[a * 8 RP]
+            // A fragments straight from L2 (8 bytes per lane and k-step), RR_PF pairs of k-steps in flight ahead of the MFMAs that use them
+            const double *Ka = Ktd + (size_t)lk * RP + 16 * rt + lr;                      // element (m, r) at m RP + r: a wavefront's load is four full lines
             const int p0 = hasq ? pq0 : pw0, p1 = hasq ? pq1 : pw1;                       // (with q_sqrt both products walk the same range)
-            auto lda = [&](int pr) {
+            auto lda = [&](int pr) {                                                       // k-steps 2 pr and 2 pr + 1
                 const double *q = Ka + (size_t)((pr < p1) ? pr : p1 - 1) * 8 * RP;
-                return make_double2(rr_load(q), rr_load(q + 1));
+                return make_double2(rr_load(q), rr_load(q + (size_t)4 * RP));
             };
             double2 cur[RR_PF], nxt[RR_PF];
 #pragma unroll
