@@ -2697,7 +2697,9 @@ extern "C" int ffvd_op_rollout(int kind, const double *Lm_inverse_seq, const dou
     // costs 4-5 us here (release 2, wait + acquire 2.5-3: FFVD_RR_STAMPS=1), three of them are what three kernel boundaries cost.
     // (Second measurement, with the hand-offs rebuilt without cache maintenance -- write-through stores and sc1 loads instead of fences, as in
     //  the Gram kernel's tail exchange: 10.1-11.8 us per step at 16 rollouts, 13.6-17.9 at 32, 20.5-27 at 64.  The default up to 32 rollouts.)
-    const bool resident = skinny && rollout_resident_ok(R, D, P, Mp) && (loop_mode == 2 || (loop_mode < 0 && R <= 32));
+    // (Third measurement, the products' MFMA section branch-free per chunk: 10.4-12.5 / 12.5-15.4 / 17.9-22.5 us per step.  The default
+    //  wherever it applies: up to 64 rollouts, M <= 512, 8 latent dims.)
+    const bool resident = skinny && rollout_resident_ok(R, D, P, Mp) && (loop_mode == 2 || loop_mode < 0);
     const bool use_loop = skinny && loop_mode == 1;
     bool resident_done = false;
     if (resident) {

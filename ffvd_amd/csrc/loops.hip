@@ -305,30 +305,54 @@ __global__ __launch_bounds__(256) void rollout_resident_kernel(RolloutResidentAr
                 const double *q = Ka + (size_t)((pr < p1) ? pr : p1 - 1) * 8 * RP;
                 return make_double2(rr_load(q), rr_load(q + (size_t)4 * RP));
             };
-            double2 cur[RR_PF], nxt[RR_PF];
+            // (the MFMA section of a chunk of RR_PF pairs is branch-free when the whole chunk has the same right-hand sides -- with a
+            //  test per MFMA every one of them waited for its own LDS read: 8.7 us for 128 MFMAs)
+            auto run = [&](auto hq) {
+                constexpr bool HQ = decltype(hq)::value;
+                double2 cur[RR_PF], nxt[RR_PF];
 #pragma unroll
-            for (int i = 0; i < RR_PF; ++i) cur[i] = lda(p0 + i);
-            for (int pb = p0; pb < p1; pb += RR_PF) {
-                if (pb + RR_PF < p1) {
+                for (int i = 0; i < RR_PF; ++i) cur[i] = lda(p0 + i);
+                for (int pb = p0; pb < p1; pb += RR_PF) {
+                    if (pb + RR_PF < p1) {
 #pragma unroll
-                    for (int i = 0; i < RR_PF; ++i) nxt[i] = lda(pb + RR_PF + i);
-                }
-#pragma unroll
-                for (int i = 0; i < RR_PF; ++i) {
-                    const int pr = pb + i;
-                    if (pr < p1) {
-                        const int m0 = 8 * pr + lk;
-                        // (four accumulators in turn: an MFMA that adds to the previous one's result waits for it -- with two chains the
-                        //  loop ran at half the pipe's rate)
-                        if (hasq) accQ = mfma_f64(cur[i].x, WQp[m0 * 16 + lr], accQ);
-                        if (pr < npW) accW = mfma_f64(cur[i].x, Wp[m0 * 16 + lr], accW);
-                        if (hasq) accQ1 = mfma_f64(cur[i].y, WQp[(m0 + 4) * 16 + lr], accQ1);
-                        if (pr < npW) accW1 = mfma_f64(cur[i].y, Wp[(m0 + 4) * 16 + lr], accW1);
+                        for (int i = 0; i < RR_PF; ++i) nxt[i] = lda(pb + RR_PF + i);
                     }
-                }
+                    const bool full = pb + RR_PF <= p1;
+                    if (full && pb + RR_PF <= npW) {                  // every pair: W (and W q_sqrt)
 #pragma unroll
-                for (int i = 0; i < RR_PF; ++i) cur[i] = nxt[i];
-            }
+                        for (int i = 0; i < RR_PF; ++i) {
+                            const int m0 = 8 * (pb + i) + lk;
+                            if (HQ) accQ = mfma_f64(cur[i].x, WQp[m0 * 16 + lr], accQ);
+                            accW = mfma_f64(cur[i].x, Wp[m0 * 16 + lr], accW);
+                            if (HQ) accQ1 = mfma_f64(cur[i].y, WQp[(m0 + 4) * 16 + lr], accQ1);
+                            accW1 = mfma_f64(cur[i].y, Wp[(m0 + 4) * 16 + lr], accW1);
+                        }
+                    } else if (HQ && full && pb >= npW) {             // every pair: W q_sqrt only
+#pragma unroll
+                        for (int i = 0; i < RR_PF; ++i) {
+                            const int m0 = 8 * (pb + i) + lk;
+                            accQ = mfma_f64(cur[i].x, WQp[m0 * 16 + lr], accQ);
+                            accQ1 = mfma_f64(cur[i].y, WQp[(m0 + 4) * 16 + lr], accQ1);
+                        }
+                    } else {                                          // a partial chunk or one that straddles the end of W's rows
+#pragma unroll
+                        for (int i = 0; i < RR_PF; ++i) {
+                            const int pr = pb + i;
+                            if (pr < p1) {
+                                const int m0 = 8 * pr + lk;
+                                if (HQ) accQ = mfma_f64(cur[i].x, WQp[m0 * 16 + lr], accQ);
+                                if (pr < npW) accW = mfma_f64(cur[i].x, Wp[m0 * 16 + lr], accW);
+                                if (HQ) accQ1 = mfma_f64(cur[i].y, WQp[(m0 + 4) * 16 + lr], accQ1);
+                                if (pr < npW) accW1 = mfma_f64(cur[i].y, Wp[(m0 + 4) * 16 + lr], accW1);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < RR_PF; ++i) cur[i] = nxt[i];
+                }
+            };
+            if (hasq) run(std::true_type{});
+            else run(std::false_type{});
         }
         RR_STAMP(6);
 #pragma unroll
