@@ -16,7 +16,7 @@ L = cmo.kernel_pre_cal(params["Z"], kern)
 U, H = cmo.collapse_u_mean_after_kernel_precalculation(L, np.concatenate((X[:-1], c), axis=1), X, params["Z"], kern, np.exp(params["log_Q"]))
 rng = np.random.default_rng(0)
 steps = int(os.environ.get("STEPS", "400"))
-for R in (16, 32, 64):
+for R in tuple(int(x) for x in os.environ.get("RS", "16,32,64,100,128").split(",")):
     ctrl = np.concatenate((c, rng.standard_normal((steps, C))))
     eps = rng.standard_normal((steps, R, D))
     ref = None
