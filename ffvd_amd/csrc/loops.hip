@@ -176,6 +176,8 @@ __global__ __launch_bounds__(256) void pg_loop_kernel(PgLoopArgs a, const int GA
 // barrier that follows its poll.  No fence on either side -- the Gram kernel's tail exchange (kernels.hip) is the same construction.
 __device__ __forceinline__ void rr_store(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double rr_load(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+constexpr long long RR_SPIN_TICKS = 10000000LL;         // 0.1 s of the 100 MHz wall clock: a step is 10-25 us; a wait this long means that the
+                                                         // launch's workgroups are not all on the chip (another tenant): give up, the caller runs the launches
 __device__ __forceinline__ bool rr_wait(int *word, const int need, int *abort_w, int *slot) {
     if (threadIdx.x == 0) {
         int ok = 1;
@@ -188,7 +190,7 @@ __device__ __forceinline__ bool rr_wait(int *word, const int need, int *abort_w,
                 if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) break;
                 if ((spin & 63) != 63) continue;                   // (the abort word and the clock once in 64 polls)
                 if (__hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = 0; break; }
-                if (wall_clock64() - t0 > LOOP_SPIN_TICKS) {
+                if (wall_clock64() - t0 > RR_SPIN_TICKS) {
                     __hip_atomic_store(abort_w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     ok = 0;
                     break;
