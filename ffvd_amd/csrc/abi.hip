@@ -2717,6 +2717,7 @@ extern "C" int ffvd_op_rollout(int kind, const double *Lm_inverse_seq, const dou
         long long *dst = nullptr;
         if (getenv("FFVD_RR_STAMPS")) { dst = sc.alloc<long long>(32); if (dst) HIP_TRY(hipMemsetAsync(dst, 0, 32 * sizeof(long long), sc.stream)); }
         ra.stamps = dst;
+        ra.test_stall = getenv("FFVD_RR_TEST_STALL") ? 1 : 0;
         const int lrc = launch_rollout_resident(sc.stream, ra);
         if (lrc == 0) {
             int32_t hw[4] = {0, 0, 0, 0};

@@ -261,6 +261,7 @@ __global__ __launch_bounds__(256) void rollout_resident_kernel(RolloutResidentAr
     long long *stp = (a.stamps && d == 0 && (s == 0 || s == NS - 1)) ? a.stamps + (s == 0 ? 0 : 16) : nullptr;
 #define RR_STAMP(i) do { if (stp && t == 10 && tid == 0) stp[i] = wall_clock64(); } while (0)
     for (int t = 0; t < a.steps; ++t) {
+        if (a.test_stall && d == 0 && s == 0 && t == 3) return;
         RR_STAMP(0);
         if (t > 0 && !rr_wait(cX, D * t, abort_w, &slot)) return;                     // every dim of x_t is written
         RR_STAMP(1);

@@ -367,6 +367,7 @@ struct RolloutResidentArgs {
     double *xbuf;                                    // [2][16 RT][D]     the states of step t in xbuf[t & 1]
     double *predict_x, *predict_var;                 // [R][steps][D]
     int *words, *abort_w;                            // counter block (rollout_resident_words ints, zero before the launch), abort = words + 1
+    int test_stall;                                  // tests (FFVD_RR_TEST_STALL=1): slab 0 of dim 0 leaves at step 3 -- every wait of the launch must give up
     long long *stamps;                               // optional (FFVD_RR_STAMPS=1, tools): [2][16] wall-clock stamps of step 10, slabs 0 and NS - 1 of dim 0
 };
 bool rollout_resident_ok(int R, int D, int P, int Mp);

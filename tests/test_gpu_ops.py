@@ -447,6 +447,36 @@ def test_pg_sweep_linear_kernel():
     np.testing.assert_allclose(pg, po, rtol=1e-8, atol=1e-9)
 
 
+def test_resident_rollout_loop_gives_up_and_the_launches_take_over(monkeypatch):
+    """The rollout loop with resident operands is one launch whose 128 workgroups wait for each other: every wait is bounded, and a
+    launch that cannot finish (here: one workgroup leaves at step 3) must end with its abort word set, after which the per-step launches
+    run the loop from the initial rows -- same bits as FFVD_STEP_LOOP=0."""
+    import time
+    from ffvd_amd import conditionals_multi_output as cmo
+    from ffvd_amd.prediction import rollout
+    params, Y, c, meta = synthetic.make_named("small")
+    D, C, T = meta["D"], meta["C"], meta["T"]
+    X, Q = params["X"][0], np.exp(params["log_Q"])
+    kern = [SquaredExponential(D + C, variance=np.exp(params["logvariance"][d]), lengthscales=np.exp(params["loglengthscales"][d]))
+            for d in range(D)]
+    rng = np.random.default_rng(11)
+    R, steps = 20, 12
+    ctrl = np.concatenate((c, rng.standard_normal((steps, C))))
+    eps = rng.standard_normal((steps, R, D))
+    L = cmo.kernel_pre_cal(params["Z"], kern)
+    U, H = cmo.collapse_u_mean_after_kernel_precalculation(L, np.concatenate((X[:-1], c), axis=1), X, params["Z"], kern, Q)
+    monkeypatch.setenv("FFVD_STEP_LOOP", "0")
+    want = rollout(L, params["Z"], kern, U, H, X[-1], ctrl, T, steps, Q, eps)
+    monkeypatch.setenv("FFVD_STEP_LOOP", "2")
+    monkeypatch.setenv("FFVD_RR_TEST_STALL", "1")
+    t0 = time.perf_counter()
+    got = rollout(L, params["Z"], kern, U, H, X[-1], ctrl, T, steps, Q, eps)
+    el = time.perf_counter() - t0
+    assert 0.09 < el < 5.0, el                     # the bounded wait (0.1 s) fired, nothing hung
+    np.testing.assert_array_equal(got[0], want[0])
+    np.testing.assert_array_equal(got[1], want[1])
+
+
 def test_step_loops_equal_the_per_step_launches(monkeypatch):
     """Round 4: the step loops of the rollouts and of the particle-Gibbs sweep can run as ONE persistent launch whose
     workgroups walk the phases of every step and meet at a grid-wide barrier (loops.hip, FFVD_STEP_LOOP=1 -- opt-in: measured 2-4 x
