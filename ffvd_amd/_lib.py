@@ -86,6 +86,7 @@ _SIGNATURES = {
     "ffvd_sghmc_apply": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_uint32, C.c_int, C.c_void_p, _dp,
                                    C.POINTER(C.c_double)]),
     "ffvd_stall_recoveries": (C.c_int, [C.c_void_p]),
+    "ffvd_stall_hold": (C.c_int, [C.c_void_p]),
     "ffvd_single_launch": (C.c_int, [C.c_void_p]),
     "ffvd_schedule_name": (C.c_char_p, [C.c_void_p]),
     "ffvd_get_stream": (C.c_void_p, [C.c_void_p]),
@@ -170,8 +171,21 @@ def load():
         fn = getattr(lib, name)          # AttributeError here = ABI/header mismatch: fail loudly
         fn.restype = res
         fn.argtypes = args
+    for name, (res, args) in _DEBUG_SIGNATURES.items():      # not part of the ABI (absent from ffvd_abi.h): bound when present
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype = res
+            fn.argtypes = args
     _lib = lib
     return lib
+
+
+# diagnostic exports of the library used by tools/ and tests/ (not declared in include/ffvd_abi.h)
+_DEBUG_SIGNATURES = {
+    "ffvd_debug_tiny_private_bytes": (C.c_int64, [C.c_void_p]),
+    "ffvd_debug_tiny_uploads": (C.c_int, [C.c_void_p, C.c_int]),
+    "ffvd_debug_enqueue_us": (C.c_double, [C.c_void_p]),
+}
 
 
 def exported_symbols():

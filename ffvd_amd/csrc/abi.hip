@@ -88,7 +88,9 @@ struct ffvd_handle {
     double *tiny_scratch = nullptr;
     int *tiny_flags = nullptr;
     TinyArgs *tiny_dargs = nullptr;     // [2] device copies of the argument block (forward / forward + backward)
-    TinyArgs *tiny_hargs = nullptr;     // [2] pinned host shadows of what those copies hold
+    TinyArgRing tiny_ring[2];           // per copy: pinned upload slots guarded by events + what the device copy holds (tiny.h)
+    bool tiny_ring_made = false;
+    size_t tiny_private_bytes = 0;      // scratch per lane of the one-launch kernel as the loaded code object reports it
     bool tiny_dirty = false;       // a launch was abandoned on a bounded wait: its hand-off words are re-zeroed before the next one
     bool info_pending = false;  // an ffvd_elbo_async was enqueued whose Cholesky info flags nobody has looked at yet
     // workspace
@@ -150,6 +152,8 @@ struct ffvd_handle {
     int train_S_total = 0;
     bool stalled = false;       // check_info saw info = -1: the dataflow Cholesky gave up on a bounded wait
     int stall_recoveries = 0;   // iterations re-run with the launch-per-column Cholesky after such a stall
+    int stall_hold = 0;         // > 0: this many further calls stay on the schedule without inter-workgroup waits (fetch_with_stall_recovery)
+    int stall_hold_next = 16;   // length of the next hold: doubles with every stalled probe (cap 1024), back to 16 after a clean one
     long long enq_ns = 0, enq_calls = 0;      // host time spent enqueueing iterations (ffvd_debug_enqueue_us: tools)
     std::string warning;        // one-time note about the first recovery (ffvd_last_error returns it while no error is pending)      // > 0: ffvd_train_local has left a backward pass (scaled 1 / S_total) in gw.pack
     // optional live stage timing (HIP events on the handle's stream)
@@ -194,7 +198,7 @@ extern "C" int ffvd_destroy(ffvd_handle *h) {
     for (void *p : h->allocs) hipFree(p);
     for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
     if (h->h_res) hipHostFree(h->h_res);
-    if (h->tiny_hargs) hipHostFree(h->tiny_hargs);
+    if (h->tiny_ring_made) { tiny_ring_destroy(h->tiny_ring[0]); tiny_ring_destroy(h->tiny_ring[1]); }
     if (h->aux) { hipStreamSynchronize(h->aux); hipStreamDestroy(h->aux); }
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_join) hipEventDestroy(h->ev_join);
@@ -446,12 +450,30 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
         h->tiny = tiny_plan(c.kernel_kind, c.T, c.D, c.C, c.M, c.S_local, (int)Dl, c.grad, cus);
         h->tiny_cus = cus;
         if (h->tiny.ok) {
+            // The plan needs every workgroup resident at once, and a wave is resident only with its scratch: the figure the loaded
+            // code object reports must be the one this file was validated with, and the launch's total must stay within a budget
+            // the runtime grants without throttling wave slots (checked where the handle is made, not assumed).
+            size_t pb = 0;
+            const int wpu_max = 1 + h->tiny.nstrips + (h->tiny.side ? h->tiny.NT : 0);
+            if (tiny_kernel_private_bytes(h->tiny.nw, &pb) != hipSuccess || pb > TINY_PRIVATE_BYTES_MAX ||
+                pb * 64 * h->tiny.nw * (size_t)h->tiny.nunits * wpu_max > TINY_PRIVATE_LAUNCH_BUDGET) {
+                char wmsg[256];
+                snprintf(wmsg, sizeof wmsg, "warning: one-launch iteration not used: its kernel reports %zu bytes of private memory per lane "
+                         "(validated up to %zu; launch budget %zu MB)", pb, TINY_PRIVATE_BYTES_MAX, TINY_PRIVATE_LAUNCH_BUDGET >> 20);
+                h->warning = wmsg;
+                h->err = h->warning;
+                h->tiny.ok = false;
+            }
+            h->tiny_private_bytes = pb;
+        }
+        if (h->tiny.ok) {
             HIP_TRY(dev_alloc(h, &h->tiny_scratch, tiny_scratch_doubles(h->tiny, c.T, (int)P, c.M, c.S_local, (int)Dl, c.D, c.Ydim, c.grad)));
             HIP_TRY(dev_alloc(h, &h->tiny_flags, tiny_flag_ints(h->tiny, c.S_local)));
             HIP_TRY(hipMemsetAsync(h->tiny_flags, 0, tiny_flag_ints(h->tiny, c.S_local) * sizeof(int), h->stream));
             HIP_TRY(dev_alloc(h, &h->tiny_dargs, 2));
-            HIP_TRY(hipHostMalloc((void **)&h->tiny_hargs, 2 * sizeof(TinyArgs)));
-            memset(h->tiny_hargs, 0xff, 2 * sizeof(TinyArgs));          // (differs from any real block: the first launch uploads)
+            HIP_TRY(tiny_ring_create(h->tiny_ring[0]));
+            HIP_TRY(tiny_ring_create(h->tiny_ring[1]));
+            h->tiny_ring_made = true;
         }
     }
     HIP_TRY(dev_alloc(h, &h->dinvK, potrf_scratch_doubles((int)Mp, (int)Dl)));
@@ -697,6 +719,7 @@ static ElboSchedule plan_schedule(const ffvd_handle *h) {
 }
 extern "C" const char *ffvd_schedule_name(const ffvd_handle *h) {
     if (!h) return "";
+    if (h->stall_hold > 0) return "stall back-off: multi-kernel schedule with the launch-per-column Cholesky (no inter-workgroup waits) until the next probe";
     if (h->tiny.ok && potrf_override_current() == CHOL_FORCE_NONE) return "one launch (tiny.hip)";
     const ElboSchedule sc = plan_schedule(h);
     return sc.name ? sc.name : "INVALID";
@@ -725,7 +748,8 @@ static int enqueue_tiny(ffvd_handle *h, double *out_dev, StageTimer *st, bool wi
         HIP_TRY(hipMemsetAsync(h->tiny_flags, 0, tiny_flag_ints(h->tiny, c.S_local) * sizeof(int), s));
         h->tiny_dirty = false;
     }
-    TinyArgs a{};
+    TinyArgs a;
+    memset(&a, 0, sizeof a);        // padding included: the block is compared bytewise with what the device copy holds (launch_tiny)
     a.kind = c.kernel_kind; a.T = c.T; a.D = c.D; a.C = c.C; a.P = h->P; a.M = c.M; a.Dl = h->Dl; a.d_begin = c.d_begin;
     a.S = c.S_local; a.Ydim = c.Ydim; a.prior_type = c.prior_type; a.shared_terms = c.shared_terms;
     a.grad = with_grad ? 1 : 0; a.S_total = S_total; a.jitter = c.jitter;
@@ -742,7 +766,7 @@ static int enqueue_tiny(ffvd_handle *h, double *out_dev, StageTimer *st, bool wi
         a.dX = g.dX; a.dZ = g.dZ; a.dlogvar = g.dlogvar; a.dloglen = g.dloglen; a.dlogQ = g.dlogQ; a.dCC = g.dCC; a.dDD = g.dDD;
         a.dlogR = g.dlogR;
     }
-    HIP_TRY(launch_tiny(s, a, h->tiny, h->tiny_dargs + (with_grad ? 1 : 0), h->tiny_hargs + (with_grad ? 1 : 0)));
+    HIP_TRY(launch_tiny(s, a, h->tiny, h->tiny_dargs + (with_grad ? 1 : 0), h->tiny_ring[with_grad ? 1 : 0]));
     if (st) { st->mark(2); st->mark(4); }
     DBG_SYNC(h, with_grad ? "one-launch iteration + backward pass" : "one-launch iteration");
     return FFVD_OK;
@@ -1217,10 +1241,19 @@ struct CholOverrideGuard {
     ~CholOverrideGuard() { if (armed) potrf_override_variant(CHOL_FORCE_NONE); }
 };
 
+// A stall is remembered.  The one-launch iteration and the dataflow Cholesky need every workgroup resident at once; a
+// co-tenant that keeps compute units busy makes EVERY call wait out its bounded spin (1 s) before the recovery runs -- FFVD_OK each
+// time, an hour of waiting over the 4000 outer iterations of FFVD_Main.py.  So after a recovery the handle stays on the schedule without
+// inter-workgroup waits (launch-per-column Cholesky, multi-kernel iteration) for `stall_hold` calls, then probes the fast path again;
+// a probe that stalls doubles the hold (16, 32, ... 1024 calls), one that succeeds resets it.  ffvd_schedule_name reports the state.
+static constexpr int STALL_HOLD_FIRST = 16, STALL_HOLD_MAX = 1024;
+
 template <class Enqueue>
 static int fetch_with_stall_recovery(ffvd_handle *h, Enqueue enqueue) {
     int rc;
-    for (int attempt = 0;; ++attempt) {
+    const bool held = h->stall_hold > 0;        // back-off: this call does not try the paths that stalled
+    if (held) --h->stall_hold;
+    for (int attempt = held ? 1 : 0;; ++attempt) {
         {
             CholOverrideGuard guard;
             if (attempt == 1) guard.force_left();
@@ -1234,17 +1267,22 @@ static int fetch_with_stall_recovery(ffvd_handle *h, Enqueue enqueue) {
         hipError_t e2 = (e1 == hipSuccess) ? hipStreamSynchronize(h->stream) : e1;
         if (e2 != hipSuccess) return set_error(h, FFVD_EDEVICE, std::string("result copy failed: ") + hipGetErrorString(e2));
         rc = check_info(h);
-        if (rc == FFVD_OK && attempt == 1) {
+        if (rc == FFVD_OK && attempt == 1 && !held) {
             if (h->stall_recoveries++ == 0)
                 h->warning = "warning: the one-launch (dataflow) Cholesky gave up on a bounded wait; the iteration was re-run with "
                              "the launch-per-column Cholesky and completed";
             h->err = h->warning;
+            h->stall_hold = h->stall_hold_next;
+            h->stall_hold_next = std::min(2 * h->stall_hold_next, STALL_HOLD_MAX);
+        } else if (rc == FFVD_OK && attempt == 0 && h->stall_hold_next != STALL_HOLD_FIRST) {
+            h->stall_hold_next = STALL_HOLD_FIRST;      // the fast path ran through again: forget the history
         }
         if (!(rc == FFVD_EDEVICE && h->stalled && attempt == 0)) return rc;
     }
 }
 
 extern "C" int ffvd_stall_recoveries(const ffvd_handle *h) { return h ? h->stall_recoveries : 0; }
+extern "C" int ffvd_stall_hold(const ffvd_handle *h) { return h ? h->stall_hold : 0; }
 
 // Debug (tools/sync_step.py): average host time of one iteration's enqueue in microseconds, -1 before the first call.
 extern "C" double ffvd_debug_enqueue_us(const ffvd_handle *h) {
@@ -1252,6 +1290,12 @@ extern "C" double ffvd_debug_enqueue_us(const ffvd_handle *h) {
 }
 
 extern "C" int ffvd_single_launch(const ffvd_handle *h) { return (h && h->tiny.ok) ? h->tiny.nw : 0; }
+// Debug / tests: scratch bytes per lane of the one-launch kernel (0 when the shape has no one-launch plan); how often the argument
+// block of the forward (which = 0) / forward + backward (1) launch travelled to the device.
+extern "C" int64_t ffvd_debug_tiny_private_bytes(const ffvd_handle *h) { return h ? (int64_t)h->tiny_private_bytes : 0; }
+extern "C" int ffvd_debug_tiny_uploads(const ffvd_handle *h, int which) {
+    return (h && h->tiny_ring_made && (which == 0 || which == 1)) ? h->tiny_ring[which].uploads : 0;
+}
 
 // Debug: copy `count` doubles of the one-launch path's scratch block, starting at `offset`, to the host (tools only).
 extern "C" int64_t ffvd_debug_tiny_scratch(ffvd_handle *h, int64_t offset, int64_t count, double *out) {

@@ -55,8 +55,27 @@ size_t tiny_scratch_doubles(const TinyPlan &pl, int T, int P, int M, int S, int 
 size_t tiny_flag_ints(const TinyPlan &pl, int S);
 // carve `scratch` / `flags` into the pointers of `a` (shapes already filled in)
 void tiny_bind_scratch(TinyArgs &a, const TinyPlan &pl, double *scratch, int *flags);
-// dev_args: a TinyArgs in device memory the kernel reads its arguments from; host_shadow: what that copy currently holds (pinned or
-// plain host memory that stays valid until the stream has passed the copy: the handle owns both, one pair per launch flavour)
-hipError_t launch_tiny(hipStream_t stream, const TinyArgs &a, const TinyPlan &pl, TinyArgs *dev_args, TinyArgs *host_shadow);
+// The argument block travels to the device only when it differs from what the device copy holds.  Uploads are asynchronous copies
+// out of pinned memory, so a slot must not be rewritten before the copy that reads it has run (two back-to-back enqueues with
+// different blocks -- alternating output buffers of ffvd_elbo_async -- would otherwise hand launch 1 the block of launch 2).  A ring of
+// pinned slots, each guarded by an event recorded right behind its upload; what the device holds is remembered in PLAIN memory and
+// compared bytewise (callers zero the whole block, padding included, before filling it).
+struct TinyArgRing {
+    static constexpr int N = 4;
+    TinyArgs *pinned = nullptr;     // [N] pinned staging slots (hipHostMalloc, owned by the handle)
+    hipEvent_t ev[N] = {};          // recorded behind the upload that reads slot i
+    bool used[N] = {};
+    int next = 0;
+    int uploads = 0;                // how many times the block travelled (tests)
+    TinyArgs held;                  // what the device copy holds
+    bool held_valid = false;
+};
+constexpr size_t TINY_PRIVATE_BYTES_MAX = 1024;                 // scratch per lane the kernels were validated with (576 at the time of writing)
+constexpr size_t TINY_PRIVATE_LAUNCH_BUDGET = (size_t)128 << 20;    // scratch of all resident waves of one launch
+hipError_t tiny_kernel_private_bytes(int nw, size_t *bytes);
+hipError_t tiny_ring_create(TinyArgRing &r);
+void tiny_ring_destroy(TinyArgRing &r);
+// dev_args: a TinyArgs in device memory the kernel reads its arguments from (one per launch flavour, with its ring).
+hipError_t launch_tiny(hipStream_t stream, const TinyArgs &a, const TinyPlan &pl, TinyArgs *dev_args, TinyArgRing &ring);
 
 }  // namespace ffvd

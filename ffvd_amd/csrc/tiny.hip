@@ -490,8 +490,13 @@ __device__ __noinline__ void tiny_chain_part(const TinyArgs &a_mem, const int s,
 // Everything of unit u is in memory.  The workgroup that completes a chain forms that chain's sums; the one that completes the
 // launch assembles the result.
 template <int NW>
-__device__ __noinline__ void tiny_unit_done(const TinyArgs &a_mem, const int u, double *lds, const TinyLds &L) {
+__device__ __noinline__ void tiny_unit_done(const TinyArgs &a_mem, const int u, double *lds, const int l_ctl, const int l_red, const int l_vec, const int l_mat) {
     const TinyArgs a = a_mem;       // (private copy: see tiny_chain_part)
+    // The LDS offsets arrive BY VALUE rather than as a reference to the kernel's TinyLds: NO pointer to the kernel's private memory crosses
+    // a call in this file (round 4's silent corruption was a by-value argument block read by a callee through such a pointer; its
+    // writer was never identified on the hardware -- DESIGN.md section 13 has what is known -- so the pattern itself is gone).
+    TinyLds L{};
+    L.ctl = l_ctl; L.red = l_red; L.vec = l_vec; L.mat = l_mat;
     constexpr int NTHR = 64 * NW;
     const int tid = threadIdx.x;
     const int s = u / a.Dl;
@@ -1109,7 +1114,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void tiny_kernel(const Ti
         }
         TSTAMP(7);
         if (!a.grad) {
-            tiny_unit_done<NW>(a, u, lds, L);
+            tiny_unit_done<NW>(a, u, lds, L.ctl, L.red, L.vec, L.mat);
             TSTAMP(8);
             return;
         }
@@ -1179,7 +1184,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void tiny_kernel(const Ti
                 for (int rb = h0; rb < h0 + hn; ++rb) tiny_kuu_rows<NW>(a, u, rb, Am, ZO, ilen, var);
             }
             if (tiny_arrive(cx.c2, slot) != nst) return;                      // nst strips + this head
-            tiny_unit_done<NW>(a, u, lds, L);
+            tiny_unit_done<NW>(a, u, lds, L.ctl, L.red, L.vec, L.mat);
         }
         return;
     }
@@ -1200,7 +1205,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void tiny_kernel(const Ti
         TSTAMP(9);
         if (tiny_arrive(cx.c2, slot) != narrive2 - 1) return;
         TSTAMP(10);
-        tiny_unit_done<NW>(a, u, lds, L);
+        tiny_unit_done<NW>(a, u, lds, L.ctl, L.red, L.vec, L.mat);
         TSTAMP(11);
         return;
     }
@@ -1520,7 +1525,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void tiny_kernel(const Ti
     TSTAMP(9);
     if (tiny_arrive(cx.c2, slot) != narrive2 - 1) return;
     TSTAMP(10);
-    tiny_unit_done<NW>(a, u, lds, L);
+    tiny_unit_done<NW>(a, u, lds, L.ctl, L.red, L.vec, L.mat);
     TSTAMP(11);
 }
 
@@ -1604,22 +1609,65 @@ void tiny_bind_scratch(TinyArgs &a, const TinyPlan &pl, double *scratch, int *fl
     a.flags = flags;
 }
 
-hipError_t launch_tiny(hipStream_t stream, const TinyArgs &a, const TinyPlan &pl, TinyArgs *dev_args, TinyArgs *host_shadow) {
-    static size_t attr_bytes[2] = {0, 0};              // dynamic LDS each instantiation has been allowed so far
+// Private (scratch) memory per lane of the kernel a plan launches, as the loaded code object reports it.  The plan needs EVERY
+// workgroup resident at once, and a wave is only resident with its scratch: ffvd_create checks this figure against what the file was
+// validated with (TINY_PRIVATE_BYTES_MAX) and against a budget for the whole launch before it lets a handle take the one-launch path.
+hipError_t tiny_kernel_private_bytes(int nw, size_t *bytes) {
+    hipFuncAttributes fa;
+    const void *fn = nw == 4 ? reinterpret_cast<const void *>(&tiny_kernel<4>) : reinterpret_cast<const void *>(&tiny_kernel<8>);
+    hipError_t e = hipFuncGetAttributes(&fa, fn);
+    if (e != hipSuccess) return e;
+    *bytes = (size_t)fa.localSizeBytes;
+    return hipSuccess;
+}
+
+hipError_t tiny_ring_create(TinyArgRing &r) {
+    hipError_t e = hipHostMalloc((void **)&r.pinned, TinyArgRing::N * sizeof(TinyArgs));
+    if (e != hipSuccess) return e;
+    for (int i = 0; i < TinyArgRing::N; ++i) {
+        e = hipEventCreateWithFlags(&r.ev[i], hipEventDisableTiming);
+        if (e != hipSuccess) return e;
+        r.used[i] = false;
+    }
+    r.next = 0; r.uploads = 0; r.held_valid = false;
+    return hipSuccess;
+}
+void tiny_ring_destroy(TinyArgRing &r) {
+    for (int i = 0; i < TinyArgRing::N; ++i)
+        if (r.ev[i]) { hipEventDestroy(r.ev[i]); r.ev[i] = nullptr; }
+    if (r.pinned) { hipHostFree(r.pinned); r.pinned = nullptr; }
+}
+
+hipError_t launch_tiny(hipStream_t stream, const TinyArgs &a, const TinyPlan &pl, TinyArgs *dev_args, TinyArgRing &ring) {
+    static size_t attr_bytes_dev[16][2] = {};          // dynamic LDS each instantiation has been allowed so far, per device
+    int dev = 0;
+    size_t *attr_bytes = (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16) ? attr_bytes_dev[dev] : nullptr;      // (unknown device: always set)
     const int wpu = 1 + pl.nstrips + (a.side ? pl.NT : 0);
     const int grid = a.xcd_map ? 8 * wpu * ((pl.nunits + 7) / 8) : pl.nunits * wpu;
     const int which = pl.nw == 4 ? 0 : 1;
     const void *fn = which == 0 ? reinterpret_cast<const void *>(&tiny_kernel<4>) : reinterpret_cast<const void *>(&tiny_kernel<8>);
-    if (pl.lds_bytes > attr_bytes[which] && pl.lds_bytes > 48 * 1024) {
+    if ((!attr_bytes || pl.lds_bytes > attr_bytes[which]) && pl.lds_bytes > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes);
         if (e != hipSuccess) return e;
-        attr_bytes[which] = pl.lds_bytes;
+        if (attr_bytes) attr_bytes[which] = pl.lds_bytes;
     }
     // the argument block travels only when it differs from what the device copy holds (steady state: never)
-    if (memcmp(host_shadow, &a, sizeof(TinyArgs)) != 0) {
-        *host_shadow = a;
-        hipError_t e = hipMemcpyAsync(dev_args, host_shadow, sizeof(TinyArgs), hipMemcpyHostToDevice, stream);
+    if (!ring.held_valid || memcmp(&ring.held, &a, sizeof(TinyArgs)) != 0) {
+        const int i = ring.next;
+        ring.next = (i + 1) % TinyArgRing::N;
+        if (ring.used[i]) {                             // the copy that read this slot N uploads ago: long done, but make sure
+            hipError_t e = hipEventSynchronize(ring.ev[i]);
+            if (e != hipSuccess) return e;
+        }
+        memcpy(&ring.pinned[i], &a, sizeof(TinyArgs));
+        hipError_t e = hipMemcpyAsync(dev_args, &ring.pinned[i], sizeof(TinyArgs), hipMemcpyHostToDevice, stream);
         if (e != hipSuccess) return e;
+        e = hipEventRecord(ring.ev[i], stream);
+        if (e != hipSuccess) return e;
+        ring.used[i] = true;
+        memcpy(&ring.held, &a, sizeof(TinyArgs));
+        ring.held_valid = true;
+        ++ring.uploads;
     }
     if (which == 0) hipLaunchKernelGGL(tiny_kernel<4>, dim3(grid), dim3(256), pl.lds_bytes, stream, (const TinyArgs *)dev_args);
     else hipLaunchKernelGGL(tiny_kernel<8>, dim3(grid), dim3(512), pl.lds_bytes, stream, (const TinyArgs *)dev_args);

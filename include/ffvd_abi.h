@@ -130,6 +130,13 @@ int  ffvd_sync(ffvd_handle *h);
  * abandoned launch), so after the all-reduce EVERY rank sees non-finite sums, returns an error (FFVD_EDEVICE on the rank that
  * stalled, FFVD_ENOTPD elsewhere) and leaves its parameters untouched.  ffvd_tshard_finish (no collective after it) retries. */
 int  ffvd_stall_recoveries(const ffvd_handle *h);
+/* A stall is remembered: after a recovery the handle's synchronous calls stay on the schedule that has no inter-workgroup waits
+ * (multi-kernel iteration, launch-per-column Cholesky) for this many further calls -- 16 after the first recovery -- and then try
+ * the fast path again; a probe that stalls again doubles the hold (up to 1024 calls), a clean one resets it.  A co-tenant that keeps
+ * compute units busy therefore costs one bounded wait per hold instead of one per call (the reference's only failure mode is an
+ * error surfaced at session.run, dgp_model.py:320-324; here the call returns FFVD_OK either way).  ffvd_schedule_name names the
+ * state while it lasts.  Collective calls neither retry nor consult the hold. */
+int  ffvd_stall_hold(const ffvd_handle *h);
 /* Non-zero when the handle evaluates its iteration (and, with grad = 1, the backward pass) as ONE kernel launch: the collapsed-U
  * branch with SquaredExponential kernels in fp64 at the reference's own experiment size (FFVD_Main.py:356-369: M <= 128,
  * P = D + C <= 8, every role's workgroup resident at once; ffvd_amd/csrc/tiny.hip).  The value is the wavefronts per workgroup
