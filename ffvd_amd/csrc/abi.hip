@@ -83,6 +83,14 @@ struct ffvd_handle {
     double *stage = nullptr;    // staging buffer of ffvd_allreduce_sum
     int64_t stage_count = 0;
     bool kuu_flow_sched = false;   // schedule of the big unsplit Gram pass, decided in ffvd_create (see there)
+    // pass-pipelined forward iteration (enqueue_elbo_pipe; FFVD_PIPE=<passes>, FFVD_PIPE_MODE=<bits>): streams for the K_fu builds
+    // of later passes and for every other pass's Gram launch, one event per pass and stage, one Cholesky scratch region per pass
+    int pipe_passes = 0, pipe_mode = 0;
+    hipStream_t pipe_build = nullptr, pipe_gram = nullptr, pipe_chol = nullptr;
+    std::vector<hipEvent_t> pipe_evB, pipe_evG;
+    hipEvent_t pipe_evC = nullptr;
+    double *pipe_dinv = nullptr;
+    size_t pipe_dinv_stride = 0;
     // one-launch iteration of the reference's own experiment size (tiny.hip): decided once in ffvd_create
     TinyPlan tiny{};
     double *tiny_scratch = nullptr;
@@ -207,6 +215,11 @@ extern "C" int ffvd_destroy(ffvd_handle *h) {
     if (h->ev_tiles) hipEventDestroy(h->ev_tiles);
     if (h->ev_go) hipEventDestroy(h->ev_go);
     if (h->ev_hwords) hipEventDestroy(h->ev_hwords);
+    for (hipEvent_t e : h->pipe_evB) hipEventDestroy(e);
+    for (hipEvent_t e : h->pipe_evG) hipEventDestroy(e);
+    if (h->pipe_evC) hipEventDestroy(h->pipe_evC);
+    for (hipStream_t ps : {h->pipe_build, h->pipe_gram, h->pipe_chol})
+        if (ps) { hipStreamSynchronize(ps); hipStreamDestroy(ps); }
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
     return FFVD_OK;
@@ -437,6 +450,31 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
             // (unsplit pass of up to 16 chains: the chain's launches were starved by the pass and ended 0.1 ms behind Cholesky(A) -- behind
             //  the pass as one dataflow launch as well)
             h->side_late = late_ok && upass <= 64;
+        }
+    }
+    // Pass-pipelined forward iteration (enqueue_elbo_pipe): only where the full-batch schedule runs today
+    // (one buffer pass over all chains, unsplit Gram launches, K_uu chain as one dataflow launch with L^-1 and K^-1 out of it)
+    if (h->kuu_flow_sched && !c.grad && c.T_total == 0 && h->cpp >= c.S_local && !h->gpart && !h->graw && h->growpart) {
+        int passes = 0;
+        if (const char *e = getenv("FFVD_PIPE")) passes = atoi(e);
+        if (const char *e = getenv("FFVD_PIPE_MODE")) h->pipe_mode = atoi(e);
+        if (passes > c.S_local) passes = c.S_local;
+        if (passes >= 2 && potrf_flow_forms_inverse((int)Mp, (int)Dl, CHOL_FLOW) && !h->sw.kinv_gram) {
+            h->pipe_passes = passes;
+            int lo = 0, hi = 0;
+            HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            HIP_TRY(hipStreamCreateWithFlags(&h->pipe_build, hipStreamNonBlocking));
+            HIP_TRY(hipStreamCreateWithFlags(&h->pipe_gram, hipStreamNonBlocking));
+            HIP_TRY(hipStreamCreateWithPriority(&h->pipe_chol, hipStreamNonBlocking, (h->pipe_mode & 4) ? lo : hi));
+            h->pipe_evB.resize(passes); h->pipe_evG.resize(passes);
+            for (int i = 0; i < passes; ++i) {
+                HIP_TRY(hipEventCreateWithFlags(&h->pipe_evB[i], hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&h->pipe_evG[i], hipEventDisableTiming));
+            }
+            HIP_TRY(hipEventCreateWithFlags(&h->pipe_evC, hipEventDisableTiming));
+            const int max_units = ((c.S_local + passes - 1) / passes) * (int)Dl;
+            h->pipe_dinv_stride = (potrf_scratch_doubles((int)Mp, max_units) + 31) / 32 * 32;
+            HIP_TRY(dev_alloc(h, &h->pipe_dinv, h->pipe_dinv_stride * passes));
         }
     }
     if (c.branch == FFVD_BRANCH_A && !c.grad && !h->sw.no_linear_lowrank && linear_lowrank_supported(c.kernel_kind, P))
@@ -717,10 +755,13 @@ static ElboSchedule plan_schedule(const ffvd_handle *h) {
     else sc.name = "serial: K_uu chain on the main stream in front of the K_fu build";
     return sc;
 }
+// (the pipelined passes need the dataflow Cholesky: a forced launch-per-column variant -- stall recovery, FFVD_CHOL -- takes the plain schedule)
+static bool pipe_selected(const ffvd_handle *h) { return h->pipe_passes >= 2 && potrf_override_current() == CHOL_FORCE_NONE; }
 extern "C" const char *ffvd_schedule_name(const ffvd_handle *h) {
     if (!h) return "";
     if (h->stall_hold > 0) return "stall back-off: multi-kernel schedule with the launch-per-column Cholesky (no inter-workgroup waits) until the next probe";
     if (h->tiny.ok && potrf_override_current() == CHOL_FORCE_NONE) return "one launch (tiny.hip)";
+    if (pipe_selected(h)) return "pipelined passes: K_fu build of pass p+1 | Gram kernel of pass p | Cholesky(A) of pass p-1 on separate streams";
     const ElboSchedule sc = plan_schedule(h);
     return sc.name ? sc.name : "INVALID";
 }
@@ -772,10 +813,167 @@ static int enqueue_tiny(ffvd_handle *h, double *out_dev, StageTimer *st, bool wi
     return FFVD_OK;
 }
 
+
+// ---- argument blocks of the forward iteration's launches: one builder each, shared by every schedule --------------------------------
+static ProjectArgs elbo_project_args(const ffvd_handle *h, const HyperView &hv, int s0, int ns, bool gram_route) {
+    const ffvd_config &c = h->cfg;
+    const ffvd_params &p = h->cur;
+    const size_t msq = (size_t)h->Mp * h->Mp, kstride = 2 * msq;
+    ProjectArgs pa{};
+    pa.kind = c.kernel_kind;
+    pa.x = p.X; pa.x_chain_stride = (size_t)(c.T + 1) * c.D; pa.x_ld = c.D; pa.x_cols = c.D;
+    pa.ctrl = h->ctrl; pa.T = c.T; pa.Tp = h->Tp; pa.C = c.C; pa.P = h->P; pa.M = c.M; pa.Mp = h->Mp; pa.Dl = h->Dl;
+    pa.d_begin = c.d_begin; pa.hv = hv; pa.W = h->Kuu + msq; pa.w_stride = kstride;
+    pa.U = p.U; pa.u_ld = c.D; pa.b0 = s0 * h->Dl; pa.nb = ns * h->Dl;
+    pa.F = (c.branch == FFVD_BRANCH_B) ? h->F : nullptr;
+    pa.rowsq = h->rowsq;
+    pa.fmean = (c.branch == FFVD_BRANCH_A) ? h->fmean : nullptr;
+    pa.ng = h->ng;
+    pa.gpart = gram_route ? h->growpart : nullptr;      // Gram route: delta^T K_fu is summed where K_fu is made
+    return pa;
+}
+static size_t elbo_h_stride(const ffvd_handle *h) { return (size_t)(h->cfg.grad ? 2 * h->Mp + NB : h->Mp + NB) * h->Mp; }
+static GramArgs elbo_gram_args(const ffvd_handle *h, int s0, int ns, bool gram_route) {
+    const ffvd_config &c = h->cfg;
+    const ffvd_params &p = h->cur;
+    const int Mp = h->Mp;
+    const size_t msq = (size_t)Mp * Mp;
+    GramArgs ga{};
+    ga.mode = gram_route ? GRAM_KFU : GRAM_F;
+    ga.A = h->F; ga.a_stride = (size_t)h->Tp * Mp; ga.rows = h->Tp; ga.with_row = h->growpart ? 0 : 1;
+    ga.X = p.X; ga.log_Q = p.log_Q; ga.T = c.T; ga.D = c.D; ga.Mp = Mp; ga.Dl = h->Dl;
+    ga.d_begin = c.d_begin; ga.b0 = s0 * h->Dl; ga.nb = ns * h->Dl; ga.yn_over_batch = 1.0;
+    ga.H = h->H; ga.h_stride = elbo_h_stride(h);
+    if (c.grad) ga.brow = 2 * Mp;   // rows [Mp, 2Mp) hold I (they become L_A^-T), the b row moves to 2 Mp
+    ga.Kadd = h->Kcopy; ga.kadd_stride = msq; ga.Kinv = h->Kinv; ga.kinv_stride = msq; ga.trpart = h->trpart;
+    if (h->gpart) { ga.ksplit = h->gsplit; ga.part = h->gpart; }     // same row ranges in every pass of this handle
+    // tail split of the last partial round (full passes only: launch_gram drops it when the unit count differs)
+    if (h->gtail) { ga.tail_wg = h->gtail_wg; ga.tail_part = h->gtail; }
+    return ga;
+}
+static ReduceArgs elbo_reduce_args(const ffvd_handle *h, bool gram_route) {
+    const ffvd_config &c = h->cfg;
+    const ffvd_params &p = h->cur;
+    ReduceArgs ra{};
+    ra.kind = c.kernel_kind; ra.branch = c.branch; ra.X = p.X; ra.ctrl = h->ctrl; ra.Y = h->Y;
+    ra.log_Q = p.log_Q; ra.CC = p.CC; ra.DD = p.DD; ra.log_Rchols = p.log_Rchols; ra.variance = h->variance;
+    ra.T = c.T; ra.Tp = h->Tp; ra.D = c.D; ra.C = c.C; ra.Ydim = c.Ydim; ra.Dl = h->Dl; ra.d_begin = c.d_begin;
+    ra.S = c.S_local; ra.ng = h->ng; ra.shared_terms = c.shared_terms;
+    ra.xk = p.X; ra.xk_chain_stride = (size_t)(c.T + 1) * c.D; ra.xk_ld = c.D; ra.xk_cols = c.D;
+    ra.rowsq = (gram_route || c.dtype == FFVD_F32C) ? nullptr : h->rowsq; ra.fmean = h->fmean; ra.chain_terms = h->chain_terms;
+    if (h->ngr) ra.ng = h->ngr;
+    if (h->lrpart) ra.ng = 1;            // LinearK through its rank: one value per (unit, row)
+    return ra;
+}
+// (trpart / ntiles / fsq_from_trpart of the fp32-contraction path and `whitened` of the training forward are set by the caller)
+static FinalizeArgs elbo_finalize_args(const ffvd_handle *h, double *out_dev, bool gram_route) {
+    const ffvd_config &c = h->cfg;
+    const ffvd_params &p = h->cur;
+    FinalizeArgs fa{};
+    fa.kind = c.kernel_kind; fa.branch = c.branch; fa.prior_type = c.prior_type; fa.shared_terms = c.shared_terms;
+    fa.T = c.T; fa.D = c.D; fa.P = h->P; fa.M = c.M; fa.Ydim = c.Ydim; fa.Dl = h->Dl; fa.d_begin = c.d_begin;
+    fa.S = c.S_local; fa.Z = p.Z; fa.U = p.U; fa.logvar = p.logvariance; fa.loglen = p.loglengthscales;
+    fa.log_Q = p.log_Q; fa.CC = p.CC; fa.DD = p.DD; fa.log_Rchols = p.log_Rchols;
+    fa.chain_terms = h->chain_terms; fa.hterms = h->hterms; fa.chain_nll = h->chain_nll;
+    fa.route = gram_route ? 1 : 0; fa.kterms = h->kterms; fa.trpart = h->trpart; fa.ntiles = h->ntiles;
+    fa.out_terms = out_dev ? out_dev : h->out_terms;
+    fa.info = h->info; fa.ninfo = h->Dl + h->nbatch;       // any failed / abandoned factorisation of this rank -> NaN sums on every rank
+    return fa;
+}
+
+
+// ---- pass-pipelined forward iteration ----------------------------------------------------------------------------
+// The per-(s, d) units of conditionals_multi_output.py:238-255 are independent, and the full-batch iteration is three phases bound by
+// three different things: the K_fu build by HBM writes, the Gram kernel by the matrix pipe, Cholesky(A) by latency.  This schedule cuts
+// the chains into `pipe_passes` passes (each with its own slice of F, H and growpart -- the buffers already hold all chains) and lets
+// the phases of neighbouring passes run side by side:
+//
+//   main   : prep, K_uu build | reductions | build(0) | Gram(0) ........... Gram(2) ...                      | wait C | finalize
+//   aux    :   K_uu chain (one dataflow launch, L^-1, K^-1, log|K|) --ev_join--> (every Gram launch waits for it once per stream)
+//   build  :                     wait B0 | build(1) build(2) ...            (mode bit 0: build(p) waits for Gram(p-2) -- "lazy")
+//   gram   :                                  wait B1 | Gram(1) ........... Gram(3) ...     (mode bit 1: every Gram launch on main)
+//   chol   : clears of all passes' progress words | wait G0 | Chol(0) finish(0) | wait G1 | Chol(1) ...     --evC-->
+//
+// Odd passes' Gram launches go to a second stream so that Gram(p+1) can take the slots Gram(p)'s early finishers free (stream order
+// would hold it until the last workgroup of Gram(p) has left: the ends of a round are spread over 0.3 ms).
+// FFVD_PIPE=<passes> turns it on for handles that would run the "full unsplit" schedule; results are bit-identical to that schedule
+// (same kernels on the same units; only the launch partition differs).
+static int enqueue_elbo_pipe(ffvd_handle *h, double *out_dev, StageTimer *st) {
+    const ffvd_config &c = h->cfg;
+    const int Mp = h->Mp, Tp = h->Tp, Dl = h->Dl, P = h->P, NP = h->pipe_passes;
+    const ffvd_params &p = h->cur;
+    hipStream_t s = h->stream, sk = h->aux, sb = h->pipe_build, sg = (h->pipe_mode & 2) ? h->stream : h->pipe_gram, sc = h->pipe_chol;
+    const size_t msq = (size_t)Mp * Mp, kstride = 2 * msq, fstride = (size_t)Tp * Mp, hstride = elbo_h_stride(h);
+    const bool lazy = (h->pipe_mode & 1) != 0;
+    const int nt = (h->pipe_mode & 8) ? 0 : 1;          // streaming stores for every pass's K_fu unless bit 3 says cacheable
+    if (st) st->mark(-1);
+    launch_prep_hypers(s, c.kernel_kind, p.Z, c.M, Mp, P, Dl, c.d_begin, p.logvariance, p.loglengthscales,
+                       h->variance, h->len, h->Zs, h->zz, h->info, Dl + h->nbatch);
+    HyperView hv{h->variance, h->len, h->Zs, h->zz};
+    launch_kuu_build(s, c.kernel_kind, hv, c.M, Mp, P, Dl, c.jitter, h->Kuu, h->Kcopy);
+    { int rcf = fork_side(h, h->ev_fork, s, sk); if (rcf) return rcf; }
+    // the chain's row workgroups must be on the chip before the first K_fu build floods it (as in the full-batch schedule)
+    potrf_flow_clear(sk, h->dinvK, Dl);
+    HIP_TRY(hipEventRecord(h->ev_go, sk));
+    launch_potrf_ext(sk, h->Kuu, Mp, Mp, Mp, Dl, kstride, h->info, h->dinvK, CHOL_FLOW, h->Linv, msq, true, false, h->Kinv, msq);
+    launch_h_finish(sk, h->Kuu, Mp, kstride, Dl, h->kterms);
+    HIP_TRY(hipEventRecord(h->ev_join, sk));
+    launch_chain_reduce(s, elbo_reduce_args(h, true), h->chain_partial);      // inputs only; fills the wait below
+    HIP_TRY(hipStreamWaitEvent(s, h->ev_go, 0));
+    // progress words of every pass's factorisation: cleared up front on the stream that runs them
+    HIP_TRY(hipStreamWaitEvent(sc, h->ev_fork, 0));
+    for (int q = 0; q < NP; ++q) {
+        const int c0 = (int)((long long)c.S_local * q / NP), c1 = (int)((long long)c.S_local * (q + 1) / NP);
+        potrf_flow_clear(sc, h->pipe_dinv + h->pipe_dinv_stride * q, (c1 - c0) * Dl);
+    }
+    if (st) st->mark(0);
+    for (int q = 0; q < NP; ++q) {
+        const int c0 = (int)((long long)c.S_local * q / NP), c1 = (int)((long long)c.S_local * (q + 1) / NP);
+        const int ns = c1 - c0, u0 = c0 * Dl, nu = ns * Dl;
+        // K_fu of the pass (+ the row b from the partial sums it leaves)
+        hipStream_t bs = q == 0 ? s : sb;
+        if (q == 1) HIP_TRY(hipStreamWaitEvent(sb, h->pipe_evB[0], 0));            // builds one after the other
+        if (lazy && q >= 2) HIP_TRY(hipStreamWaitEvent(sb, h->pipe_evG[q - 2], 0));  // ... and not before Gram(q-2) has left
+        ProjectArgs pa = elbo_project_args(h, hv, c0, ns, true);
+        pa.F = h->F + (size_t)u0 * fstride;
+        pa.gpart = h->growpart + (size_t)u0 * (Tp / 64) * Mp;
+        launch_kfu_build(bs, pa, nt);
+        launch_brow_finish(bs, pa.gpart, Tp / 64, Mp, Dl, c.d_begin, u0, nu, p.log_Q, 1.0, h->H + (size_t)u0 * hstride, hstride, Mp);
+        HIP_TRY(hipEventRecord(h->pipe_evB[q], bs));
+        if (st && q == 0) st->mark(1);
+        // Gram kernel of the pass (trace partials in its epilogue: needs K_uu's copy and K^-1 from the chain)
+        hipStream_t gs = (q % 2 == 0) ? s : sg;
+        if (gs != bs) HIP_TRY(hipStreamWaitEvent(gs, h->pipe_evB[q], 0));
+        if (q < 2) HIP_TRY(hipStreamWaitEvent(gs, h->ev_join, 0));
+        GramArgs ga = elbo_gram_args(h, c0, ns, true);
+        ga.A = h->F + (size_t)u0 * fstride;
+        ga.H = h->H + (size_t)u0 * hstride;
+        ga.tail_wg = 0; ga.tail_part = nullptr;              // (the tail split's blocks are sized for the full batch's launch)
+        launch_gram(gs, ga);
+        HIP_TRY(hipEventRecord(h->pipe_evG[q], gs));
+        // Cholesky(A) of the pass, log|A| and b^T A^-1 b
+        HIP_TRY(hipStreamWaitEvent(sc, h->pipe_evG[q], 0));
+        launch_potrf_ext(sc, ga.H, Mp, NB, 0, nu, hstride, h->info + Dl + u0, h->pipe_dinv + h->pipe_dinv_stride * q, CHOL_FLOW, nullptr, 0,
+                         true, true);
+        launch_h_finish(sc, ga.H, Mp, hstride, nu, h->hterms + (size_t)2 * u0);
+    }
+    if (st) { st->mark(2); }
+    HIP_TRY(hipEventRecord(h->pipe_evC, sc));
+    HIP_TRY(hipStreamWaitEvent(s, h->pipe_evC, 0));
+    if (NP >= 2 && sg != s) HIP_TRY(hipStreamWaitEvent(s, h->pipe_evG[NP % 2 == 0 ? NP - 1 : NP - 2], 0));   // (implied by evC; keeps the graph explicit)
+    if (st) st->mark(3);
+    launch_finalize(s, elbo_finalize_args(h, out_dev, true));
+    if (st) st->mark(4);
+    DBG_SYNC(h, "forward (pipelined passes)");
+    HIP_TRY(hipGetLastError());
+    return FFVD_OK;
+}
+
 static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
     if (tiny_selected(h)) return enqueue_tiny(h, out_dev, st, false, h->cfg.S_local);
     StageTimer live{h};
     if (!st && h->timing_on) st = &live;
+    if (pipe_selected(h)) return enqueue_elbo_pipe(h, out_dev, st);
     const ffvd_config &c = h->cfg;
     const int Mp = h->Mp, Tp = h->Tp, Dl = h->Dl, P = h->P;
     hipStream_t s = h->stream;
@@ -813,52 +1011,15 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
     // 2 x 268 MB less traffic at config 2.  The launch-per-column variants (forced by FFVD_CHOL or by the stall recovery) read the
     // rows from memory: launch_set_lt_rows in front of them.
     const bool lt_virtual = sc.lt_virtual;
-    auto project_args = [&](int s0, int ns) {
-        ProjectArgs pa{};
-        pa.kind = c.kernel_kind;
-        pa.x = p.X; pa.x_chain_stride = (size_t)(c.T + 1) * c.D; pa.x_ld = c.D; pa.x_cols = c.D;
-        pa.ctrl = h->ctrl; pa.T = c.T; pa.Tp = Tp; pa.C = c.C; pa.P = P; pa.M = c.M; pa.Mp = Mp; pa.Dl = Dl;
-        pa.d_begin = c.d_begin; pa.hv = hv; pa.W = h->Kuu + msq; pa.w_stride = kstride;
-        pa.U = p.U; pa.u_ld = c.D; pa.b0 = s0 * Dl; pa.nb = ns * Dl;
-        pa.F = (c.branch == FFVD_BRANCH_B) ? h->F : nullptr;
-        pa.rowsq = h->rowsq;
-        pa.fmean = (c.branch == FFVD_BRANCH_A) ? h->fmean : nullptr;
-        pa.ng = h->ng;
-        pa.gpart = gram_route ? h->growpart : nullptr;      // Gram route: delta^T K_fu is summed where K_fu is made
-        return pa;
-    };
-    auto gram_args = [&](int s0, int ns) {
-        GramArgs ga{};
-        ga.mode = gram_route ? GRAM_KFU : GRAM_F;
-        ga.A = h->F; ga.a_stride = (size_t)Tp * Mp; ga.rows = Tp; ga.with_row = h->growpart ? 0 : 1;
-        ga.X = p.X; ga.log_Q = p.log_Q; ga.T = c.T; ga.D = c.D; ga.Mp = Mp; ga.Dl = Dl;
-        ga.d_begin = c.d_begin; ga.b0 = s0 * Dl; ga.nb = ns * Dl; ga.yn_over_batch = 1.0;
-        ga.H = h->H; ga.h_stride = (size_t)(c.grad ? 2 * Mp + NB : Mp + NB) * Mp;
-        if (c.grad) ga.brow = 2 * Mp;   // rows [Mp, 2Mp) hold I (they become L_A^-T), the b row moves to 2 Mp
-        ga.Kadd = h->Kcopy; ga.kadd_stride = msq; ga.Kinv = h->Kinv; ga.kinv_stride = msq; ga.trpart = h->trpart;
-        if (h->gpart) { ga.ksplit = h->gsplit; ga.part = h->gpart; }     // same row ranges in every pass of this handle
-        // tail split of the last partial round (full passes only: launch_gram drops it when the unit count differs)
-        if (h->gtail) { ga.tail_wg = h->gtail_wg; ga.tail_part = h->gtail; }
-        return ga;
-    };
+    auto project_args = [&](int s0, int ns) { return elbo_project_args(h, hv, s0, ns, gram_route); };
+    auto gram_args = [&](int s0, int ns) { return elbo_gram_args(h, s0, ns, gram_route); };
     // Gram route: the row b = delta^T K_fu / Q of a pass, from the partial sums its K_fu build left behind (kernels.h ProjectArgs::gpart)
     auto brow_finish = [&](int s0, int ns) {
         if (!h->growpart) return;
         launch_brow_finish(s, h->growpart, Tp / 64, Mp, Dl, c.d_begin, s0 * Dl, ns * Dl, p.log_Q, 1.0, h->H,
                            (size_t)(c.grad ? 2 * Mp + NB : Mp + NB) * Mp, c.grad ? 2 * Mp : Mp);
     };
-    auto reduce_args = [&]() {
-        ReduceArgs ra{};
-        ra.kind = c.kernel_kind; ra.branch = c.branch; ra.X = p.X; ra.ctrl = h->ctrl; ra.Y = h->Y;
-        ra.log_Q = p.log_Q; ra.CC = p.CC; ra.DD = p.DD; ra.log_Rchols = p.log_Rchols; ra.variance = h->variance;
-        ra.T = c.T; ra.Tp = Tp; ra.D = c.D; ra.C = c.C; ra.Ydim = c.Ydim; ra.Dl = Dl; ra.d_begin = c.d_begin;
-        ra.S = c.S_local; ra.ng = h->ng; ra.shared_terms = c.shared_terms;
-        ra.xk = p.X; ra.xk_chain_stride = (size_t)(c.T + 1) * c.D; ra.xk_ld = c.D; ra.xk_cols = c.D;
-        ra.rowsq = (gram_route || c.dtype == FFVD_F32C) ? nullptr : h->rowsq; ra.fmean = h->fmean; ra.chain_terms = h->chain_terms;
-        if (h->ngr) ra.ng = h->ngr;
-        if (h->lrpart) ra.ng = 1;            // LinearK through its rank: one value per (unit, row)
-        return ra;
-    };
+    auto reduce_args = [&]() { return elbo_reduce_args(h, gram_route); };
     bool reduce_done = false;
     // One split-K pass, K_uu chain beside it: at few chains that chain is the critical path (0.54 ms against 0.47 ms of
     // K_fu build + tile pass at 4 chains), and the only thing the main stream needs from its tail is K^-1 for the trace
@@ -1176,21 +1337,13 @@ static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
     }
     if (!reduce_early) launch_chain_reduce(s, ra, h->chain_partial);
     else if (!reduce_done && !trace_on_main) HIP_TRY(hipStreamWaitEvent(s, h->ev_join2, 0));
-    FinalizeArgs fa{};
-    fa.kind = c.kernel_kind; fa.branch = c.branch; fa.prior_type = c.prior_type; fa.shared_terms = c.shared_terms;
-    fa.T = c.T; fa.D = c.D; fa.P = P; fa.M = c.M; fa.Ydim = c.Ydim; fa.Dl = Dl; fa.d_begin = c.d_begin;
-    fa.S = c.S_local; fa.Z = p.Z; fa.U = p.U; fa.logvar = p.logvariance; fa.loglen = p.loglengthscales;
-    fa.log_Q = p.log_Q; fa.CC = p.CC; fa.DD = p.DD; fa.log_Rchols = p.log_Rchols;
-    fa.chain_terms = h->chain_terms; fa.hterms = h->hterms; fa.chain_nll = h->chain_nll;
-    fa.route = gram_route ? 1 : 0; fa.kterms = h->kterms; fa.trpart = h->trpart; fa.ntiles = h->ntiles;
+    FinalizeArgs fa = elbo_finalize_args(h, out_dev, gram_route);
     fa.whitened = (c.grad && h->gw.whitened && gram_route && !lt_rows) ? 1 : 0;      // L^T rows: the slab holds the factor of A itself
     if (c.dtype == FFVD_F32C) {           // sum_t |F_t|^2 per unit from the projection's fp64 tile sums
         launch_sum_partials(s, h->sqpart, h->nsq, h->nbatch, h->sqsum);
         fa.trpart = h->sqsum; fa.ntiles = 1; fa.fsq_from_trpart = 1;
     } else if (grad_ref)                  // the backward pass wants the same per-unit sum (dl/dalpha): all row sums of F^2 of a unit
         launch_sum_partials(s, h->rowsq, h->ngr * Tp, h->nbatch, h->gw.fsq);
-    fa.out_terms = out_dev ? out_dev : h->out_terms;
-    fa.info = h->info; fa.ninfo = Dl + h->nbatch;       // any failed / abandoned factorisation of this rank -> NaN sums on every rank
     launch_finalize(s, fa);
     if (st) st->mark(4);
     DBG_SYNC(h, "forward: reductions + finalize");

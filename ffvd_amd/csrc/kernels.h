@@ -132,7 +132,7 @@ bool linear_lowrank_supported(int kind, int P);
 size_t linear_lowrank_doubles(int Mp, int Dl, int P);
 void launch_linear_lowrank(hipStream_t stream, const ProjectArgs &a, double *part);
 // a.F[bz][t][m] = K_fu itself (route K_uu + K_uf K_fu / Q); uses x, ctrl, hv, T, Tp, M, Mp, b0, nb of `a`.
-void launch_kfu_build(hipStream_t stream, const ProjectArgs &a);
+void launch_kfu_build(hipStream_t stream, const ProjectArgs &a, int streaming = -1 /* -1: by output size, 0 / 1: cacheable / streaming stores */);
 
 // GRAM_KFU_RAW: as GRAM_KFU, but the trace partials are left to a later trace-only pass (phase 3) over the raw tiles
 // this launch also writes into `part` (ksplit = 1 layout) -- K^-1 is not read

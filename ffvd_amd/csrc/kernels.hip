@@ -261,10 +261,12 @@ static void launch_kfu_build_nt(hipStream_t stream, const ProjectArgs &a) {
         else hipLaunchKernelGGL((kfu_build_kernel<1, 0, NT>), grid, dim3(256), 0, stream, a);
     }
 }
-void launch_kfu_build(hipStream_t stream, const ProjectArgs &a) {
+void launch_kfu_build(hipStream_t stream, const ProjectArgs &a, int streaming) {
     static const bool no_nt = getenv("FFVD_KFU_NO_NT") != nullptr;          // A/B switch (read once)
-    // streaming stores for outputs of 1 GB and more (nothing of them survives in a cache until the Gram kernel reads it)
-    if ((size_t)a.nb * a.Tp * a.Mp * sizeof(double) >= ((size_t)1 << 30) && !no_nt) launch_kfu_build_nt<true>(stream, a);
+    // streaming stores for outputs of 1 GB and more (nothing of them survives in a cache until the Gram kernel reads it);
+    // `streaming` 0 / 1 decides for the caller (a pass of a pipelined iteration is part of a larger output)
+    const bool nt = streaming >= 0 ? streaming != 0 : ((size_t)a.nb * a.Tp * a.Mp * sizeof(double) >= ((size_t)1 << 30) && !no_nt);
+    if (nt) launch_kfu_build_nt<true>(stream, a);
     else launch_kfu_build_nt<false>(stream, a);
 }
 
