@@ -3286,6 +3286,33 @@ extern "C" int ffvd_tshard_grad_fetch(ffvd_handle *h, double out_terms[8], const
     return FFVD_OK;
 }
 
+// Optimiser step of a T-sharded job (dgp_model.py:303-305 trains every variable).  After ffvd_tshard_grad_fetch /
+// ffvd_elbo_tshard_grad the exchanged block in gw.pack holds the WHOLE job's shared-parameter gradients, identical on every shard;
+// dX holds this shard's own T + 1 rows, whose first and last row each lack the part of the neighbouring shard.  The caller adds
+// those parts (one small exchange of boundary rows, ffvd_amd/distributed.py) and hands the rows back here: they replace gw.dX and the
+// fused Adam update runs over every parameter array.  Shared parameters receive the same gradient and carry the same optimiser
+// state on every shard, the two copies of a boundary row likewise: the shards' parameters stay identical without a broadcast.
+extern "C" int ffvd_tshard_adam_apply(ffvd_handle *h, const double *dX_rows, double lr, double beta1, double beta2, double eps,
+                                      uint32_t train_mask, double out_terms[8], double *out_nll) {
+    int rc;
+    if ((rc = tshard_grad_ready(h, "ffvd_tshard_adam_apply", h ? h->cfg.S_local : 0))) return rc;
+    if (!dX_rows) return set_error(h, FFVD_EINVAL, "ffvd_tshard_adam_apply: null dX rows");
+    if (!(lr > 0.0) || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0) || !(eps >= 0.0))
+        return set_error(h, FFVD_EINVAL, "ffvd_tshard_adam_apply: bad hyper-parameter");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    if (!h->adam_ready && (rc = ffvd_optimizer_reset(h))) return rc;
+    const ffvd_config &c = h->cfg;
+    HIP_TRY(hipMemcpyAsync(h->h_sums, h->gw.pack, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->gw.dX, dX_rows, (size_t)c.S_local * (c.T + 1) * c.D * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));          // the host rows are the caller's
+    for (int i = 0; i < 8; ++i)
+        if (!std::isfinite(h->h_sums[i]))
+            return set_error(h, FFVD_ENOTPD, "ffvd_tshard_adam_apply: non-finite sums in the exchanged block (a factorisation failed on a shard); parameters untouched");
+    if ((rc = adam_update(h, lr, beta1, beta2, eps, train_mask))) return rc;
+    train_report(h, out_terms, out_nll);
+    return FFVD_OK;
+}
+
 extern "C" int ffvd_allreduce_sum_async(ffvd_handle *h, void *rccl_comm, double *buf_dev, int64_t count);
 extern "C" int ffvd_elbo_tshard(ffvd_handle *h, void *rccl_comm, double out_terms[8], double *out_nll) {
     int rc;

@@ -191,6 +191,41 @@ def tshard_nll_and_grad(engine, meta, t_begin, reduce_host, native=False):
     return finish(sums), g
 
 
+def tshard_boundary_rows(gX, rank, world, reduce_host):
+    """Complete the rows of dX that neighbouring T-shards share.  `gX` = this shard's S x (tc + 1) x D rows (first / last row: this
+    shard's part only).  One all-reduce of a (world - 1) x S x D buffer -- boundary b sits between shards b and b + 1; each shard adds
+    its part of the (at most two) boundaries it touches -- instead of the whole trajectory's dX: 2 rows per shard travel, not T."""
+    gX = np.array(gX, dtype=np.float64, copy=True)
+    if world <= 1:
+        return gX
+    S, _, D = gX.shape
+    B = np.zeros((world - 1, S, D))
+    if rank > 0:
+        B[rank - 1] = gX[:, 0, :]
+    if rank < world - 1:
+        B[rank] = gX[:, -1, :]
+    B = np.asarray(reduce_host(B)).reshape(world - 1, S, D)
+    if rank > 0:
+        gX[:, 0, :] = B[rank - 1]
+    if rank < world - 1:
+        gX[:, -1, :] = B[rank]
+    return gX
+
+
+def tshard_adam_step(engine, meta, rank, world, reduce_host, lr, beta1=0.9, beta2=0.999, eps=1e-8, train=None, native=False):
+    """One Adam step of a T-sharded job (dgp_model.py:303-305 across T-shards): the two exchange steps of the gradient (raw tiles +
+    chain sums; the gradient block), the boundary rows of dX, then every shard updates its own rows of X and its copy of the shared
+    parameters.  Returns the job's terms before the update."""
+    S = meta["S"]
+    if native:
+        sums, g = engine.elbo_tshard_grad(S_total=S)
+    else:
+        t = np.asarray(reduce_host(engine.tshard_local()))
+        sums, g = engine.tshard_grad_fetch(np.asarray(reduce_host(engine.tshard_finish_grad(t, S_total=S))))
+    rows = tshard_boundary_rows(g["X"], rank, world, reduce_host)
+    return finish(engine.tshard_adam_apply(rows, lr, beta1, beta2, eps, train))
+
+
 class ShardedElbo:
     """One rank's share of the ELBO on its own GPU + the scalar all-reduce.
 
@@ -327,7 +362,13 @@ class ShardedElbo:
         collective nothing but the 8 sums reaches the host; groups RCCL cannot form (collective="torch": two test ranks on
         one GPU) carry the block through torch.distributed.  Returns the whole-job terms before the update."""
         if self.time_shard:
-            raise ValueError("T-shard handles have no device-resident optimiser step (nll_and_grad returns the job's gradient)")
+            # (T-shards: two exchange steps of the gradient + the boundary rows of dX, tshard_adam_step)
+            if self.collective == "rccl":
+                return tshard_adam_step(self.engine, self.meta, self.rank, self.world, self.engine.allreduce_host, lr, beta1, beta2,
+                                        eps, train, native=True)
+            return tshard_adam_step(self.engine, self.meta, self.rank, self.world,
+                                    lambda a: self._host_reduce(np.ascontiguousarray(a, dtype=np.float64).ravel().copy()),
+                                    lr, beta1, beta2, eps, train)
         S = self.meta["S"]
         if not self.reduces:
             self.engine.shard_of = 1

@@ -408,6 +408,18 @@ class ElboEngine:
         _lib.check(self.lib.ffvd_tshard_grad_fetch(self._h, _lib.dptr(out), ct.byref(gs)), self._h, "ffvd_tshard_grad_fetch")
         return out, g
 
+    def tshard_adam_apply(self, dX_rows, lr, beta1=0.9, beta2=0.999, eps=1e-8, train=None):
+        """Optimiser step of a T-sharded job, last part: `dX_rows` = this shard's S x (T + 1) x D rows of dX with the neighbours'
+        parts of the first and last row added (distributed.tshard_adam_step); the shared-parameter gradients are the ones the
+        preceding tshard_grad_fetch / elbo_tshard_grad left on the device.  Returns the job's 8 sums (before the update)."""
+        rows = _lib.as_f64(dX_rows, (self.S, self.T + 1, self.D), "dX_rows")
+        mask = _lib.TRAIN_ALL if train is None else sum(_lib.TRAIN_BITS[k] for k in train)
+        out = np.zeros(8)
+        nll = ct.c_double()
+        _lib.check(self.lib.ffvd_tshard_adam_apply(self._h, _lib.dptr(rows), float(lr), float(beta1), float(beta2), float(eps),
+                                                   int(mask), _lib.dptr(out), ct.byref(nll)), self._h, "ffvd_tshard_adam_apply")
+        return out
+
     def allreduce_host(self, array, comm=None):
         """all-reduce(sum) of a small host fp64 array through the handle's device staging buffer on the engine's stream
         (8 sums + shared-parameter gradients of a sharded training step: a few KB).  Returns a new flat array."""

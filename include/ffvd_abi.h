@@ -316,6 +316,14 @@ int  ffvd_tshard_finish_grad(ffvd_handle *h, int S_total, double out_terms[8], d
 int  ffvd_tshard_grad_fetch(ffvd_handle *h, double out_terms[8], const ffvd_grads *gout);
 int  ffvd_elbo_tshard_grad(ffvd_handle *h, void *rccl_comm, int S_total, double out_terms[8], double *out_nll,
                            const ffvd_grads *gout);
+/* Optimiser step of a T-sharded job (the reference trains every variable with one AdamOptimizer, dgp_model.py:303-305).  Call after
+ * ffvd_tshard_grad_fetch / ffvd_elbo_tshard_grad: the exchanged block already holds the job's shared-parameter gradients, identical
+ * on every shard.  `dX_rows` = the shard's own S_local x (T + 1) x D rows of dX AFTER the caller has added the neighbouring shards'
+ * parts of the first and the last row (host memory; ffvd_amd/distributed.py exchanges them with one small all-reduce).  The fused
+ * Adam update then runs over every array of `train_mask`; shared parameters and both copies of a boundary row receive identical
+ * gradients and carry identical state, so the shards stay in step without a broadcast.  out_terms = the job's 8 sums. */
+int  ffvd_tshard_adam_apply(ffvd_handle *h, const double *dX_rows, double lr, double beta1, double beta2, double eps,
+                            uint32_t train_mask, double out_terms[8], double *out_nll);
 
 /* the handle's HIP stream (a hipStream_t), so that a collective library or another framework can order its work after
  * ffvd_elbo_async without a host synchronisation (e.g. torch.cuda.ExternalStream around the RCCL all-reduce). */

@@ -773,6 +773,86 @@ def test_time_shards_sum_to_the_single_engine_gradient(name, ov, nshard, monkeyp
             e.close()
 
 
+@pytest.mark.parametrize("name,ov,nshard", [("small", dict(S=2, D=2), 3), ("ragged", dict(S=1, D=2), 2)])
+def test_time_shards_adam_trajectory(name, ov, nshard, monkeypatch):
+    """T-shard handles train (dgp_model.py:303-305 trains every variable).  `nshard` handles on the one GPU, the
+    exchanges carried by a fake collective (sums in Python), the product's own assembly per shard (`distributed.tshard_adam_step`:
+    tiles, gradient block, boundary rows of dX, ffvd_tshard_adam_apply).  After every step: (i) each shard's parameters equal a
+    host-side Adam (TensorFlow semantics, oracle/ffvd_optim_oracle.py) applied to the job's gradient to 1e-13; (ii) the shards' copies
+    of the shared parameters are bit-identical, and so are the two copies of every row neighbouring shards share; (iii) the first
+    step's nll is the unsharded engine's (1e-9) and four steps lower it."""
+    from ffvd_amd import distributed as dm
+    from oracle import ffvd_optim_oracle as oo
+    params, Y, c, meta = synthetic.make_named(name, **ov)
+    T, S, D = meta["T"], meta["S"], meta["D"]
+    lr = 0.003
+    monkeypatch.setenv("FFVD_NO_TINY", "1")
+    with ElboEngine(T, D, meta["C"], meta["M"], S, route="gram", grad=True) as e:
+        e.set_data(Y, c)
+        whole = e.nll_terms(params)["nll"]
+    monkeypatch.delenv("FFVD_NO_TINY")
+    engines, ranges = [], []
+    try:
+        for r in range(nshard):
+            t0, tc = dm.shard_range(T, nshard, r)
+            e = ElboEngine(tc, D, meta["C"], meta["M"], S, route="gram", t_shard=(t0, T), grad=True)
+            e.set_data(Y[t0: t0 + tc], c[t0: t0 + tc])
+            e.set_params(dict(params, X=np.ascontiguousarray(params["X"][:, t0: t0 + tc + 1])))
+            engines.append(e)
+            ranges.append((t0, tc))
+        host = {k: np.array(params[k], dtype=np.float64) for k in list(GRAD_NAMES) + ["X"]}
+        hm = {k: np.zeros_like(v) for k, v in host.items()}
+        hv = {k: np.zeros_like(v) for k, v in host.items()}
+        nlls = []
+        for step in range(1, 5):
+            # a collective all shards take part in, faked: phase 1 collects every shard's contribution, phase 2 hands out the sum
+            class Fake:
+                def __init__(self):
+                    self.parts, self.total = [], None
+                def collect(self, a):
+                    self.parts.append(np.array(a, dtype=np.float64).ravel())
+                    return np.zeros_like(self.parts[-1])
+                def give(self, a):
+                    return self.total
+            f3 = Fake()
+            locs = [e.tshard_local() for e in engines]
+            total = np.sum(locs, axis=0)
+            blocks = [e.tshard_finish_grad(total, S_total=S) for e in engines]
+            block = np.sum(blocks, axis=0)
+            fetched = [e.tshard_grad_fetch(block) for e in engines]
+            for r, (sums, g) in enumerate(fetched):
+                dm.tshard_boundary_rows(g["X"], r, nshard, f3.collect)
+            f3.total = np.sum(f3.parts, axis=0) if nshard > 1 else None
+            # the job's gradient as the shards hold it: shared arrays from the block, dX assembled from the completed rows
+            gX = np.zeros_like(host["X"])
+            outs = []
+            for r, (e, (sums, g)) in enumerate(zip(engines, fetched)):
+                rows = dm.tshard_boundary_rows(g["X"], r, nshard, f3.give)
+                t0, tc = ranges[r]
+                gX[:, t0: t0 + tc + 1] = rows
+                outs.append(e.tshard_adam_apply(rows, lr))
+            nlls.append(dm.finish(outs[0])["nll"])
+            assert all(np.array_equal(o, outs[0]) for o in outs)
+            shared = fetched[0][1]
+            for k in GRAD_NAMES:
+                host[k], hm[k], hv[k] = oo.adam_step(host[k], shared[k], hm[k], hv[k], step, lr)
+            host["X"], hm["X"], hv["X"] = oo.adam_step(host["X"], gX, hm["X"], hv["X"], step, lr)
+            got = [e.get_params() for e in engines]
+            for r, gp in enumerate(got):
+                t0, tc = ranges[r]
+                for k in GRAD_NAMES:
+                    np.testing.assert_array_equal(gp[k], got[0][k], err_msg=f"step {step} shard {r} {k}: copies diverged")
+                    np.testing.assert_allclose(gp[k], host[k], rtol=0, atol=1e-13 * max(1.0, float(np.max(np.abs(host[k])))), err_msg=k)
+                np.testing.assert_allclose(gp["X"], host["X"][:, t0: t0 + tc + 1], rtol=0, atol=1e-13)
+                if r > 0:
+                    np.testing.assert_array_equal(gp["X"][:, 0], got[r - 1]["X"][:, -1], err_msg=f"step {step}: boundary row {r}")
+        assert nlls[0] == pytest.approx(whole, rel=1e-9)
+        assert nlls[-1] < nlls[0]
+    finally:
+        for e in engines:
+            e.close()
+
+
 def test_time_shard_gradient_through_native_rccl_one_rank(monkeypatch):
     """ffvd_elbo_tshard_grad end to end on one rank (both collectives are the identity, everything else is the real path), and
     what a T-shard handle refuses."""
@@ -788,8 +868,14 @@ def test_time_shard_gradient_through_native_rccl_one_rank(monkeypatch):
         t, g = sh.nll_and_grad()
         t2, g2 = sh.nll_and_grad()
         assert t == t2 and all(np.array_equal(g[k], g2[k]) for k in g)
-        with pytest.raises(ValueError, match="optimiser step"):
-            sh.adam_step(1e-3)
+        # (round 5: T-shard handles train -- ffvd_tshard_adam_apply; on one rank the boundary exchange is empty)
+        before = sh.engine.get_params()
+        t3 = sh.adam_step(1e-3)
+        after = sh.engine.get_params()
+        assert t3["nll"] == t["nll"]
+        for k in ("X", "Z", "log_Q", "loglengthscales"):
+            assert np.max(np.abs(after[k] - before[k])) > 0 and np.max(np.abs(after[k] - before[k])) <= 1e-3 * (1 + 1e-6), k
+        assert sh.nll_terms()["nll"] < t["nll"]
     finally:
         sh.close()
     assert t["nll"] == pytest.approx(whole["nll"], rel=1e-9)
