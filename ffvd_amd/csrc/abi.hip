@@ -69,6 +69,7 @@ struct ffvd_handle {
         int main_delay_us = 0;      //   must not depend on which stream is late); FFVD_DEBUG_MAIN_DELAY_US=n: the same on the main stream behind a fork
         bool tiny_xcd = true;       // FFVD_TINY_NO_XCD=1: the one-launch iteration with role-major workgroup ids instead of a unit's workgroups on ONE XCD
         bool no_tiny = false;       // FFVD_NO_TINY=1: the multi-kernel schedule also at the reference's own experiment size (rounds 1-3)
+        bool no_tiny_a = false;     // FFVD_NO_TINY_A=1: ... for the explicit-U branch only (rounds 1-4)
     } sw;
     // resident parameters / data (handle-owned copies)
     double *X = nullptr, *Z = nullptr, *U = nullptr, *logvar = nullptr, *loglen = nullptr, *logQ = nullptr;
@@ -237,7 +238,7 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
         w.kuu_flow = !on("FFVD_NO_KUU_FLOW");   w.kinv_gram = on("FFVD_KINV_GRAM");   w.chain_rl = on("FFVD_CHAIN_RL");
         w.atb128 = on("FFVD_ATB128");                 w.grad_serial = on("FFVD_GRAD_SERIAL");
         w.debug_sync = on("FFVD_DEBUG_SYNC");
-        w.no_tiny = on("FFVD_NO_TINY");               w.tiny_xcd = !on("FFVD_TINY_NO_XCD");
+        w.no_tiny = on("FFVD_NO_TINY");               w.no_tiny_a = on("FFVD_NO_TINY_A");               w.tiny_xcd = !on("FFVD_TINY_NO_XCD");
         if (const char *e = getenv("FFVD_DEBUG_SIDE_DELAY_US")) w.side_delay_us = atoi(e);
         if (const char *e = getenv("FFVD_DEBUG_MAIN_DELAY_US")) w.main_delay_us = atoi(e);
     }
@@ -479,7 +480,7 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
     }
     if (c.branch == FFVD_BRANCH_A && !c.grad && !h->sw.no_linear_lowrank && linear_lowrank_supported(c.kernel_kind, P))
         HIP_TRY(dev_alloc(h, &h->lrpart, linear_lowrank_doubles((int)Mp, (int)Dl, P)));
-    if (c.branch == FFVD_BRANCH_B && c.dtype == FFVD_F64 && c.T_total == 0 && !h->sw.no_tiny) {
+    if (c.dtype == FFVD_F64 && c.T_total == 0 && !h->sw.no_tiny && !(c.branch == FFVD_BRANCH_A && h->sw.no_tiny_a)) {      // (both branches since round 5)
         // The whole iteration as ONE launch when every role's workgroup fits on the chip at once (tiny.hip).  The multi-kernel
         // workspaces above stay: a launch abandoned on a bounded wait is re-run on them (fetch_with_stall_recovery).
         int cus = 0;
@@ -794,6 +795,7 @@ static int enqueue_tiny(ffvd_handle *h, double *out_dev, StageTimer *st, bool wi
     a.kind = c.kernel_kind; a.T = c.T; a.D = c.D; a.C = c.C; a.P = h->P; a.M = c.M; a.Dl = h->Dl; a.d_begin = c.d_begin;
     a.S = c.S_local; a.Ydim = c.Ydim; a.prior_type = c.prior_type; a.shared_terms = c.shared_terms;
     a.grad = with_grad ? 1 : 0; a.S_total = S_total; a.jitter = c.jitter;
+    a.branch = (c.branch == FFVD_BRANCH_B) ? 1 : 0; a.U = p.U;
     a.X = p.X; a.Z = p.Z; a.logvar = p.logvariance; a.loglen = p.loglengthscales; a.log_Q = p.log_Q; a.CC = p.CC; a.DD = p.DD;
     a.logR = p.log_Rchols; a.Y = h->Y; a.ctrl = h->ctrl;
     tiny_bind_scratch(a, h->tiny, h->tiny_scratch, h->tiny_flags);
@@ -805,7 +807,7 @@ static int enqueue_tiny(ffvd_handle *h, double *out_dev, StageTimer *st, bool wi
     if (with_grad) {
         const ffvd_handle::GradWs &g = h->gw;
         a.dX = g.dX; a.dZ = g.dZ; a.dlogvar = g.dlogvar; a.dloglen = g.dloglen; a.dlogQ = g.dlogQ; a.dCC = g.dCC; a.dDD = g.dDD;
-        a.dlogR = g.dlogR;
+        a.dlogR = g.dlogR; a.dU = g.dU;
     }
     HIP_TRY(launch_tiny(s, a, h->tiny, h->tiny_dargs + (with_grad ? 1 : 0), h->tiny_ring[with_grad ? 1 : 0]));
     if (st) { st->mark(2); st->mark(4); }

@@ -16,12 +16,14 @@ struct TinyArgs {
     int side;                       // backward: NT more workgroups per unit take the row blocks of the K_uu side (else the strips do)
     int xcd_map;                    // workgroup id -> (unit, role): all workgroups of a unit on ONE XCD (blockIdx % 8 = unit % 8)
     int prior_type, shared_terms, grad, S_total;
+    int branch;                     // 1: collapsed U (dgp_model.py:267-288);  0: explicit U (:289-297, regularizer :337-359; cases 1/2/3/6)
     double jitter;
     const double *X, *Z, *logvar, *loglen, *log_Q, *CC, *DD, *logR, *Y, *ctrl;
+    const double *U;                // [M][D] whitened inducing outputs (explicit-U branch)
     // scratch (tiny_scratch_doubles; all of it is rewritten by every launch)
     double *Wg, *Wt;                // [nunits][Mp*Mp]  W = L^-T (upper block triangle) and its transpose L^-1
     double *Pp;                     // [nunits][nstrips][pstride]  per-strip F^T F tiles, F^T delta, chain-term partials
-    double *Hs, *Nw, *Nm2;          // [nunits][Mp*Mp]  backward: H - I, N = I - H^-1 - w w^T, N - (H - I)
+    double *Hs, *Nw, *Nm2;          // [nunits][Mp*Mp]  backward: H - I, N = I - H^-1 - w w^T, (scratch);  explicit U: alpha F^T F, 2 Phi, Lbar (tiny.hip, head)
     double *wv;                     // [nunits][Mp]     backward: w = H^-1 b
     double *hterms;                 // [nunits][2]      log|H|, b^T H^-1 b   (FinalizeArgs::hterms)
     double *uterms;                 // [nunits][8]      backward scalars of a unit: 0 dl/dalpha
@@ -38,7 +40,9 @@ struct TinyArgs {
     int *flags;                     // [nunits*4 + S + 8] hand-off words, all zero between launches (the last workgroup re-arms them)
     int32_t *info;                  // [Dl + nunits]
     double *chain_nll, *out_terms;
+    double *du_unit;                // [nunits][Mp]  explicit-U backward: alpha F^T r per unit (= dl/du in whitened variables)
     double *dX, *dZ, *dlogvar, *dloglen, *dlogQ, *dCC, *dDD, *dlogR;   // backward outputs (layout of ffvd_grads)
+    double *dU;                     // [M][D] explicit-U branch
 };
 
 struct TinyPlan {

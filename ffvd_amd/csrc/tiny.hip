@@ -437,9 +437,9 @@ __device__ __forceinline__ TinyCtx tiny_ctx(const TinyArgs &a, int u, int s) {
 
 __device__ __forceinline__ FinalizeArgs tiny_finalize_args(const TinyArgs &a) {
     FinalizeArgs fa{};
-    fa.kind = a.kind; fa.branch = 1; fa.prior_type = a.prior_type; fa.shared_terms = a.shared_terms;
+    fa.kind = a.kind; fa.branch = a.branch; fa.prior_type = a.prior_type; fa.shared_terms = a.shared_terms;
     fa.T = a.T; fa.D = a.D; fa.P = a.P; fa.M = a.M; fa.Ydim = a.Ydim; fa.Dl = a.Dl; fa.d_begin = a.d_begin; fa.S = a.S;
-    fa.Z = a.Z; fa.U = nullptr; fa.logvar = a.logvar; fa.loglen = a.loglen; fa.log_Q = a.log_Q; fa.CC = a.CC; fa.DD = a.DD;
+    fa.Z = a.Z; fa.U = a.U; fa.logvar = a.logvar; fa.loglen = a.loglen; fa.log_Q = a.log_Q; fa.CC = a.CC; fa.DD = a.DD;
     fa.log_Rchols = a.logR; fa.chain_terms = a.chain_terms; fa.hterms = a.hterms; fa.route = 0; fa.kterms = nullptr;
     fa.whitened = 0; fa.trpart = nullptr; fa.ntiles = 0; fa.fsq_from_trpart = 0; fa.chain_nll = a.chain_nll;
     fa.out_terms = a.out_terms; fa.info = a.info; fa.ninfo = a.Dl + a.nunits;
@@ -475,9 +475,11 @@ __device__ __noinline__ void tiny_chain_part(const TinyArgs &a_mem, const int s,
                     }
                 }
             } else {
+                // (explicit-U branch: the transition term is -1/2 alpha r^2 + T/2 log alpha with r = delta - mean, all of it in the
+                //  unit's dl/dalpha -- tiny_kernel, head -- nothing here)
                 const int d = a.d_begin + (item - D * J - 2 * J);
                 const double Q = exp(a.log_Q[d]);
-                for (int t = tid; t < T; t += NTHR) {
+                if (a.branch == 1) for (int t = tid; t < T; t += NTHR) {
                     const double dlt = Xs[(size_t)(t + 1) * D + d] - Xs[(size_t)t * D + d];
                     v[0] += 0.5 - 0.5 * dlt * dlt / Q;
                 }
@@ -683,6 +685,18 @@ __device__ __noinline__ void tiny_unit_done(const TinyArgs &a_mem, const int u, 
             a.dlogvar[d] = gv;
             a.dlogQ[d] = gq;
         }
+        if (a.branch == 0)                                                    // dU (explicit-U branch): -du / T per chain + prior_U (dgp_model.py:134-135)
+            for (int idx = tid; idx < M * D; idx += NTHR) {
+                const int m = idx / D, d = idx % D, dl = d - a.d_begin;
+                double g = 0.0;
+                if (dl >= 0 && dl < Dl) {
+                    double acc = 0.0;
+#pragma unroll 8
+                    for (int ss = 0; ss < S; ++ss) acc += a.du_unit[(size_t)(ss * Dl + dl) * Mp + m];
+                    g = -acc / Tn / Sn + wgt * a.U[idx] / Tn;
+                }
+                a.dU[idx] = g;
+            }
         for (int idx = tid; idx < D * J + J + J * J; idx += NTHR) {
             double g = 0.0;
             if (a.shared_terms) {
@@ -736,7 +750,7 @@ __device__ __noinline__ void tiny_kuu_rows(const TinyArgs &a_mem, const int u, c
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const size_t idx = (size_t)(16 * (rb + kk) + 4 * t + lk) * Mp + 16 * j + lr;
-                        nn[kk][t] = Nu[idx]; nh[kk][t] = Hu[idx];
+                        nn[kk][t] = Nu[idx]; nh[kk][t] = (a.branch == 1) ? Hu[idx] : 0.0;      // (explicit U: Nw holds 2 Phi, the Cholesky adjoint's middle factor)
                     }
                 }
 #pragma unroll
@@ -1045,6 +1059,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void tiny_kernel(const Ti
             return;
         }
         TSTAMP(4);
+        const bool BA = a.branch == 0;
+        if (BA && !a.grad) {                                                  // explicit U, forward: no H -- the strips' sums are the unit's terms
+            if (tid == 0) { a.hterms[2 * u] = 0.0; a.hterms[2 * u + 1] = 0.0; }
+            tiny_unit_done<NW>(a, u, lds, L.ctl, L.red, L.vec, L.mat);
+            TSTAMP(8);
+            return;
+        }
         double *bv = lds + L.vec, *yv = bv + Mp, *wl = yv + Mp;
         const double *Pu = a.Pp + (size_t)u * nst * pstride;
         double *Hu = a.Hs + (size_t)u * msq;
@@ -1084,7 +1105,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void tiny_kernel(const Ti
                         if (idx >= ntl * 256) { bv[idx - ntl * 256] = v; continue; }          // :248
                         const int tt = tab[idx >> 8], e = idx & 255;
                         const int gi = 16 * (tt & 255) + (e >> 4), gj = 16 * (tt >> 8) + (e & 15);
-                        Am[(size_t)gi * LD + gj] = v + ((gi == gj) ? 1.0 : 0.0);
+                        if (!BA) Am[(size_t)gi * LD + gj] = v + ((gi == gj) ? 1.0 : 0.0);      // (explicit U: Am keeps L and W)
                         if (gi == gj) trHm += v;
                         if (a.grad) { Hu[(size_t)gi * Mp + gj] = v; Hu[(size_t)gj * Mp + gi] = v; }
                     }
@@ -1093,6 +1114,90 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void tiny_kernel(const Ti
         }
         __syncthreads();
         TSTAMP(5);
+        if (BA) {
+            // ==================================================================================================================
+            // head, explicit-U backward (conditionals_multi_output.py:6-70 differentiated; oracle/ffvd_grad_oracle.py, nll_grad_explicit_u):
+            //   bv = alpha F^T r = dl/du,   Hs = alpha F^T F,   beta = W u,   X = W (dl/dW)^T W = W Hs + beta bv^T,
+            //   Lbar = -tril(X),   S = L^T Lbar,   2 Phi = strict lower of S + its transpose + diag(S)   (the Cholesky adjoint's middle
+            //   factor: dl/dK_uu = W Phi W^T, formed row block by row block in tiny_kuu_rows),   dl/dalpha = Q (v0 + v1 + T / 2).
+            // Am still holds L (lower triangle) and W (tiles above the diagonal, Dinv on it): no second factorisation in this branch.
+            // ==================================================================================================================
+            double *uv = yv;                                                  // u, zero padded
+            for (int m = tid; m < Mp; m += NTHR) {
+                uv[m] = (m < M) ? a.U[(size_t)m * D + dg] : 0.0;
+                a.du_unit[(size_t)u * Mp + m] = bv[m];
+            }
+            __syncthreads();
+            for (int i = tid; i < Mp; i += NTHR) {                            // beta = W u (W upper triangular by tiles)
+                const int ti = i >> 4;
+                double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc0 += Dinv[ti][i & 15][k] * uv[16 * ti + k];
+                for (int k = 16 * (ti + 1); k + 1 < Mp; k += 2) { acc0 += Am[(size_t)i * LD + k] * uv[k]; acc1 += Am[(size_t)i * LD + k + 1] * uv[k + 1]; }
+                wl[i] = acc0 + acc1;
+            }
+            __syncthreads();                                                  // (also: every thread's stores of Hs are issued; read back below by this workgroup)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            double *Lb = a.Nm2 + (size_t)u * msq;
+            for (int tau = wave; tau < ntl; tau += NW) {                      // Lbar(ti, tj), tj <= ti
+                const int ti = tab[tau] & 255, tj = tab[tau] >> 8;
+                d4 a0 = (d4){0.0, 0.0, 0.0, 0.0}, a1 = a0;
+                for (int k = ti; k < NT; ++k) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const double av = (k == ti) ? Dinv[ti][lr][4 * t + lk] : Am[(size_t)(16 * ti + lr) * LD + 16 * k + 4 * t + lk];
+                        const double bw = Hu[(size_t)(16 * k + 4 * t + lk) * Mp + 16 * tj + lr];
+                        if (t & 1) a1 = mfma_f64(av, bw, a1);
+                        else a0 = mfma_f64(av, bw, a0);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int gi = 16 * ti + lk + 4 * r, gj = 16 * tj + lr;
+                    const double x = (a0[r] + a1[r]) + wl[gi] * bv[gj];
+                    Lb[(size_t)gi * Mp + gj] = (gi >= gj) ? -x : 0.0;
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            double *Nu = a.Nw + (size_t)u * msq;
+            for (int tau = wave; tau < ntl; tau += NW) {                      // S(ti, tj) = sum_{k >= ti} L(k, ti)^T Lbar(k, tj), tj <= ti
+                const int ti = tab[tau] & 255, tj = tab[tau] >> 8;
+                d4 a0 = (d4){0.0, 0.0, 0.0, 0.0}, a1 = a0;
+                for (int k = ti; k < NT; ++k) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const double av = Am[(size_t)(16 * k + 4 * t + lk) * LD + 16 * ti + lr];      // L^T(ti, k)[lr][4 t + lk]; L's diagonal tiles are zero above the diagonal
+                        const double bw = Lb[(size_t)(16 * k + 4 * t + lk) * Mp + 16 * tj + lr];
+                        if (t & 1) a1 = mfma_f64(av, bw, a1);
+                        else a0 = mfma_f64(av, bw, a0);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int gi = 16 * ti + lk + 4 * r, gj = 16 * tj + lr;
+                    if (gi >= gj) {
+                        const double v = a0[r] + a1[r];
+                        Nu[(size_t)gi * Mp + gj] = v;
+                        Nu[(size_t)gj * Mp + gi] = v;
+                    }
+                }
+            }
+            {
+                double v[2] = {0.0, 0.0};                                    // the strips' transition and trace sums of this unit
+                for (int st = tid; st < nst; st += NTHR) {
+                    const double *sc = Pu + (size_t)st * pstride + ntl * 256 + Mp;
+                    v[0] += sc[0]; v[1] += sc[1];
+                }
+                tiny_sum<2, NW>(v, red);
+                if (tid == 0) {
+                    a.hterms[2 * u] = 0.0; a.hterms[2 * u + 1] = 0.0;
+                    a.uterms[(size_t)u * 8] = Qd * (v[0] + v[1] + 0.5 * (double)T);      // dl/dalpha = -1/2 sum r^2 - 1/2 sum var + T / (2 alpha)
+                }
+            }
+            (void)trHm;
+        } else {
         tiny_chol_inv<NW>(Am, LD, NT, Dinv, Sc, a.info + Dl + u);
         TSTAMP(6);
         for (int j = tid; j < Mp; j += NTHR) {                                // y = L_H^-1 b = W_H^T b
@@ -1165,6 +1270,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void tiny_kernel(const Ti
             }
             (void)quad;
         }
+        }       // (collapsed branch)
         tiny_publish(cx.fN, 1);
         TSTAMP(8);
         if (a.side) return;
@@ -1218,7 +1324,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void tiny_kernel(const Ti
     double *zs = lds + L.zo, *zz = zs + (size_t)Mp * 9;
     double *dlt = lds + L.misc, *rowv = dlt + SR, *chn = rowv + SR;          // chn: [2][SR] per-row transition / likelihood terms
     const double *Xs = a.X + (size_t)s * (T + 1) * D;
+    const bool BA = a.branch == 0;                                            // explicit-U branch (regularizer, dgp_model.py:337-359)
+    double *uvs = lds + L.vec;                                                // explicit U: the unit's column of U, zero padded (phase 2 reads it as `wl`)
     __syncthreads();
+    if (BA)
+        for (int m = tid; m < Mp; m += NTHR) uvs[m] = (m < M) ? a.U[(size_t)m * D + dg] : 0.0;
     {
         const int p = tid & 7;
         const double len = ilen[p];
@@ -1239,7 +1349,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void tiny_kernel(const Ti
         if (t < T) {
             dv = Xs[(size_t)(t + 1) * D + dg] - Xs[(size_t)t * D + dg];     // :247
             const double q = dv / sqrt(Qd);                                  // dgp_model.py:283-284
-            tq = -0.5 * (q * q);
+            tq = BA ? 0.0 : -0.5 * (q * q);                                  // (explicit U: the residual r = delta - mean, once F is there)
             if (dl == 0 && a.shared_terms)
                 for (int j = 0; j < a.Ydim; ++j) {
                     double ym = 0.0;
@@ -1315,7 +1425,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void tiny_kernel(const Ti
             if (t > T) continue;
             const int d = (ci == 0) ? dg : ((ci - 1 < a.d_begin) ? ci - 1 : ci - 1 + Dl);
             double g = 0.0;
-            if (ci == 0) {
+            if (ci == 0 && !BA) {                                             // (explicit U: the whole dl/ddelta comes out of phase 2)
                 const double x1 = Xs[(size_t)t * D + d];
                 if (t < T) g -= (Xs[(size_t)(t + 1) * D + d] - x1) * iQT;     // delta_t = x_{t+1} - x_t
                 if (t > 0) g += (x1 - Xs[(size_t)(t - 1) * D + d]) * iQT;
@@ -1345,26 +1455,41 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void tiny_kernel(const Ti
     tiny_row_gemm<1>(facc, Arow, Wu, Mp, NT, lr, lk);
     wave_lds_order();
     {
-        double rs[4] = {0.0, 0.0, 0.0, 0.0};
+        double rs[4] = {0.0, 0.0, 0.0, 0.0}, fm[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int j = 0; j < TNT; ++j)
             if (j < NT) {
+                const double uj = BA ? uvs[16 * j + lr] : 0.0;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     rs[r] += facc[j][r] * facc[j][r];
+                    fm[r] += facc[j][r] * uj;                                  // fmean = A^T u (conditionals_multi_output.py:48)
                     Ks[(size_t)(16 * wave + lk + 4 * r) * LD + 16 * j + lr] = facc[j][r];      // F replaces K_fu in LDS (K_fu stays in registers)
                 }
             }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
 #pragma unroll
-            for (int m = 8; m > 0; m >>= 1) rs[r] += __shfl_xor(rs[r], m);
-            if (lr == 0) rowv[16 * wave + lk + 4 * r] = rs[r];
+            for (int m = 8; m > 0; m >>= 1) { rs[r] += __shfl_xor(rs[r], m); fm[r] += __shfl_xor(fm[r], m); }
+            if (lr == 0) {
+                const int row = 16 * wave + lk + 4 * r;
+                rowv[row] = rs[r];
+                if (BA) {
+                    // the transition term of the explicit-U branch: logdensity_norm_diag(X[1:], mean + X[:-1], sqrt(Q)) (dgp_model.py:346-351);
+                    // from here on `dlt` holds the residual r_t = delta_t - mean_t (F^T r, r u^T and dl/ddelta below)
+                    const double res = (t0 + row < T) ? dlt[row] - fm[r] : 0.0;
+                    const double q = res / sqrt(Qd);
+                    dlt[row] = res;
+                    chn[row] = -0.5 * (q * q);
+                }
+            }
         }
     }
     __syncthreads();
     TSTAMP(3);
     double *Pu = a.Pp + ((size_t)u * nst + strip) * pstride;
+    const bool need_mm = !BA || a.grad;                                       // (explicit U, forward only: the head reads the three sums alone)
+    if (need_mm)
     for (int tau = wave; tau < ntl; tau += NW) {
         const int ti = tab[tau] & 255, tj = tab[tau] >> 8;
         d4 a0 = (d4){0.0, 0.0, 0.0, 0.0}, a1 = a0;
@@ -1378,6 +1503,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void tiny_kernel(const Ti
         for (int r = 0; r < 4; ++r) Pu[tau * 256 + (lk + 4 * r) * 16 + lr] = a0[r] + a1[r];
     }
     TSTAMP(16);
+    if (need_mm)
     for (int m = tid; m < Mp; m += NTHR) {
         double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll 4
@@ -1416,12 +1542,26 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void tiny_kernel(const Ti
         else if (t < T && n <= P) v = (n - 1 < D) ? Xs[(size_t)t * D + n - 1] : a.ctrl[(size_t)t * a.C + (n - 1 - D)];
         XO[e] = v;
     }
-    if (tiny_wait(cx.fN, 1, cx.abort_w, slot) < 0) return;
+    // (explicit U: dl/dK_fu = alpha (F + r u^T) W^T -- the collapsed branch's form with N = I, w = u, delta -> r -- needs nothing of the
+    //  head: the strip runs straight on; only the K_uu-side row blocks below wait for its flag)
+    if (!BA && tiny_wait(cx.fN, 1, cx.abort_w, slot) < 0) return;
     TSTAMP(6);
-    for (int m = tid; m < Mp; m += NTHR) wl[m] = a.wv[(size_t)u * Mp + m];
+    if (!BA)
+        for (int m = tid; m < Mp; m += NTHR) wl[m] = a.wv[(size_t)u * Mp + m];
     __syncthreads();
     const int Tp = nst * SR, drow = P + 1;
     double *dxu = a.dxc + (size_t)u * Tp * drow;
+    if (BA) {
+        for (int r = tid; r < SR; r += NTHR)                                  // dl/ddelta_t = -alpha r_t
+            if (t0 + r < T) dxu[(size_t)(t0 + r) * drow + P] = -alpha * dlt[r];
+#pragma unroll
+        for (int j = 0; j < TNT; ++j)
+            if (j < NT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    Ks[(size_t)(16 * wave + lk + 4 * r) * LD + 16 * j + lr] += dlt[16 * wave + lk + 4 * r] * wl[16 * j + lr];          // R = F + r u^T (own rows)
+            }
+    } else {
     for (int r = tid; r < SR; r += NTHR) {                                   // dl/ddelta_t = alpha (F w)_t
         double acc0 = 0.0, acc1 = 0.0;
         for (int j = 0; j + 1 < Mp; j += 2) { acc0 += Ks[(size_t)r * LD + j] * wl[j]; acc1 += Ks[(size_t)r * LD + j + 1] * wl[j + 1]; }
@@ -1439,6 +1579,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void tiny_kernel(const Ti
             for (int r = 0; r < 4; ++r)
                 Ks[(size_t)(16 * wave + lk + 4 * r) * LD + 16 * j + lr] = facc[j][r] + dlt[16 * wave + lk + 4 * r] * wl[16 * j + lr];   // R
         }
+    }
     wave_lds_order();
 #pragma unroll
     for (int j = 0; j < TNT; ++j) facc[j] = (d4){0.0, 0.0, 0.0, 0.0};
@@ -1517,6 +1658,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void tiny_kernel(const Ti
     if (!a.side) {
         int hn, h0;
         tiny_kuu_split(NT, nst, hn, h0);
+        if (BA && tiny_wait(cx.fN, 1, cx.abort_w, slot) < 0) return;         // (2 Phi from the head; the collapsed branch waited for N above)
         for (int rb = strip; rb < NT; rb += nst) {
             if (rb >= h0 && rb < h0 + hn) continue;                           // the head's blocks
             tiny_kuu_rows<NW>(a, u, rb, Ks, ZO, ilen, var);
@@ -1556,7 +1698,7 @@ TinyPlan tiny_plan(int kind, int T, int D, int C, int M, int S, int Dl, int grad
 
 namespace {
 struct TinyCarve {
-    size_t Wg, Wt, Pp, Hs, Nw, Nm2, wv, hterms, uterms, Qp, dxc, dz2, kuu, uout, cterms, cpart, psums, kst, total;
+    size_t Wg, Wt, Pp, Hs, Nw, Nm2, wv, hterms, uterms, Qp, dxc, dz2, kuu, uout, cterms, cpart, psums, kst, duu, total;
 };
 TinyCarve tiny_carve(const TinyPlan &pl, int T, int P, int M, int S, int Dl, int D, int Ydim, int grad) {
     (void)T;
@@ -1583,6 +1725,7 @@ TinyCarve tiny_carve(const TinyPlan &pl, int T, int P, int M, int S, int Dl, int
         c.kuu = o; o += al(nu * pl.NT * (TINY_PMAX + 1));
         c.uout = o; o += al(nu * ((size_t)M * P + P + 2));
         c.cpart = o; o += al((size_t)S * (D * Ydim + 2 * Ydim + Dl));
+        c.duu = o; o += al(nu * pl.Mp);
     }
     c.total = o;
     return c;
@@ -1604,7 +1747,7 @@ void tiny_bind_scratch(TinyArgs &a, const TinyPlan &pl, double *scratch, int *fl
     if (a.grad) {
         a.Nw = scratch + c.Nw; a.Nm2 = scratch + c.Nm2; a.wv = scratch + c.wv; a.uterms = scratch + c.uterms;
         a.Qp = scratch + c.Qp; a.dxc = scratch + c.dxc; a.Kst = scratch + c.kst; a.dz2 = scratch + c.dz2; a.kuu_part = scratch + c.kuu;
-        a.unit_out = scratch + c.uout; a.chain_part = scratch + c.cpart;
+        a.unit_out = scratch + c.uout; a.chain_part = scratch + c.cpart; a.du_unit = scratch + c.duu;
     }
     a.flags = flags;
 }

@@ -371,3 +371,132 @@ def test_one_launch_private_memory_and_bit_repeatability():
                 vals.append((t["nll"], float(np.abs(g["Z"]).sum()), float(np.abs(g["X"]).sum()), g["Z"].tobytes(), g["X"].tobytes()))
                 assert e.nll_terms()["nll"] == f
             assert len(set(vals)) == 1 and vals[0][0] == f, (S, [v[:3] for v in vals])
+
+
+# ---- explicit-U branch (cases 1 / 2 / 3 / 6 of FFVD_Main.py:273-324; dgp_model.py:289-297, regularizer :337-359) in ONE launch (round 5) -----
+GRAD_KEYS_A = GRAD_KEYS + ("U",)
+
+
+def oracle_grad_a(params, Y, c, **kw):
+    S = params["X"].shape[0]
+    want = None
+    for s in range(S):
+        g = gorc.nll_grad_explicit_u(dict(params, X=params["X"][s]), Y, c, **kw)
+        if want is None:
+            want = {k: np.zeros_like(v) for k, v in g.items() if k != "X"}
+            want["X"] = np.zeros_like(params["X"])
+        for k in g:
+            if k == "X":
+                want["X"][s] = g["X"] / S
+            else:
+                want[k] += g[k] / S
+    return want
+
+
+@pytest.mark.parametrize("name", ["tiny", "small", "ragged"])
+def test_explicit_u_forward_matches_golden_and_oracle(name):
+    """Branch A through ONE launch: F = K_fu L^-T on the strips, mean = F u, var = sigma^2 - |F_t|^2 (conditionals_multi_output.py:33-48),
+    the transition term on the residual x_{t+1} - x_t - mean (dgp_model.py:346-351), no H and no second factorisation; every named
+    term against the golden vector and the oracle to 1e-10, bit-reproducible."""
+    params, Y, c, meta = synthetic.make_named(name)
+    g = load_golden(name)
+    with engine(meta, U_collapse=False) as e:
+        assert single_launch(e) in (4, 8)
+        e.set_data(Y, c)
+        got = e.nll_terms(params)
+        again = e.nll_terms(params)
+    ref = orc.nll_terms_chains(params, Y, c, U_collapse=False)
+    for n in TERMS:
+        assert got[n] == pytest.approx(float(g["A_" + n]), rel=1e-10, abs=1e-11), n
+        assert got[n] == pytest.approx(ref[n], rel=1e-10, abs=1e-11), n
+        assert got[n] == again[n], n
+    np.testing.assert_allclose(got["nll_per_chain"], ref["nll_per_chain"], rtol=1e-10)
+
+
+@pytest.mark.parametrize("S", [1, 10])
+def test_explicit_u_actuator_config1(S):
+    """BASELINE configs[0] with U_collapse = False (FFVD_Main.py cases 1 / 2 / 3 / 6 at the reference's own size): chain 0 carries the
+    fixture's X, its nll is the golden value (SURVEY 8a anchor -2.2645993638...)."""
+    params, Y, c, meta, z = actuator(S)
+    with engine(meta, U_collapse=False) as e:
+        assert single_launch(e) in (4, 8)
+        e.set_data(Y, c)
+        got = e.nll_terms(params)
+    assert got["nll_per_chain"][0] == pytest.approx(float(load_golden("actuator")["A_nll"]), rel=1e-10)
+    ref = orc.nll_terms_chains(params, Y, c, U_collapse=False)
+    for n in TERMS:
+        assert got[n] == pytest.approx(ref[n], rel=1e-10, abs=1e-11), n
+
+
+@pytest.mark.parametrize("shape", [dict(T=64, D=1, C=1, M=16, S=1), dict(T=17, D=2, C=0, M=5, S=3), dict(T=512, D=4, C=1, M=128, S=2),
+                                   dict(T=1000, D=3, C=2, M=113, S=2), dict(T=200, D=6, C=2, M=40, S=5), dict(T=130, D=2, C=1, M=97, S=7),
+                                   dict(T=512, D=4, C=1, M=100, S=10), dict(T=512, D=4, C=1, M=100, S=6), dict(T=512, D=4, C=1, M=100, S=1)])
+def test_explicit_u_shapes_forward_and_gradient(shape):
+    """The edge shapes of the collapsed branch's test through the explicit-U launch: forward against the oracle, gradient -- dU and the
+    Cholesky adjoint of K_uu included (dl/dK_uu = W Phi W^T, Phi from L^T tril(-W (dl/dW)^T W)) -- against the closed form of
+    oracle/ffvd_grad_oracle.py (itself checked against torch autograd in tests/test_oracle.py)."""
+    params, Y, c, meta = synthetic.make_workload(**shape)
+    with engine(meta, grad=True, U_collapse=False) as e:
+        assert single_launch(e) in (4, 8), shape
+        e.set_data(Y, c)
+        t, g = e.nll_and_grad(params)
+        f = e.nll_terms(params)
+        t2, g2 = e.nll_and_grad(params)
+    ref = orc.nll_terms_chains(params, Y, c, U_collapse=False)
+    for n in TERMS:
+        assert t[n] == pytest.approx(ref[n], rel=1e-9, abs=1e-10), n
+        assert f[n] == t[n], n
+    want = oracle_grad_a(params, Y, c)
+    for k in GRAD_KEYS_A:
+        scale = float(np.max(np.abs(want[k]))) or 1.0
+        tol = 2e-6 if k == "Z" else 1e-7
+        assert np.max(np.abs(g[k] - want[k])) < tol * scale, (k, np.max(np.abs(g[k] - want[k])) / scale)
+        assert np.array_equal(g[k], g2[k]), k                                  # launches repeat bit for bit
+
+
+def test_explicit_u_equals_the_multi_kernel_schedule(monkeypatch):
+    """FFVD_NO_TINY_A=1 (rounds 1-4: the explicit-U branch on 17 / 53 dependent launches) against the one launch: same nll, same
+    gradient, and four device-resident Adam steps (all nine arrays, U included) end at the same parameters."""
+    params, Y, c, meta = synthetic.make_named("small")
+    out = {}
+    for mode in ("one", "multi"):
+        if mode == "multi":
+            monkeypatch.setenv("FFVD_NO_TINY_A", "1")
+        with engine(meta, grad=True, U_collapse=False) as e:
+            assert (single_launch(e) != 0) == (mode == "one")
+            e.set_data(Y, c)
+            t, g = e.nll_and_grad(params)
+            e.set_params(params)
+            nlls = [e.adam_step(0.003)["nll"] for _ in range(4)]
+            out[mode] = (t, g, e.get_params(), nlls)
+    monkeypatch.delenv("FFVD_NO_TINY_A")
+    assert out["one"][0]["nll"] == pytest.approx(out["multi"][0]["nll"], rel=1e-10)
+    for k in GRAD_KEYS_A:
+        a, b = out["one"][1][k], out["multi"][1][k]
+        assert np.max(np.abs(a - b)) < (5e-6 if k == "Z" else 1e-7) * np.max(np.abs(b)), k
+    for k in GRAD_KEYS_A:
+        a, b = out["one"][2][k], out["multi"][2][k]
+        assert np.max(np.abs(a - b)) < 1e-6 * max(1.0, np.max(np.abs(b))), k
+    assert out["one"][3][-1] < out["one"][3][0]
+
+
+def test_explicit_u_dim_shards():
+    """Latent-dim shards of the explicit-U launch: sums and gradient shares (dU: each shard its own columns) add up to the single
+    handle's."""
+    params, Y, c, meta = synthetic.make_workload(T=150, D=4, C=1, M=50, S=3)
+    with engine(meta, grad=True, U_collapse=False) as e:
+        e.set_data(Y, c)
+        whole_t, whole_g = e.nll_and_grad(params)
+    sums = np.zeros(8)
+    gsum = {k: 0.0 for k in GRAD_KEYS_A}
+    for d0, dc, shared in ((0, 1, True), (1, 3, False)):
+        with engine(meta, grad=True, U_collapse=False, d_begin=d0, d_count=dc, shared_terms=shared) as e:
+            assert single_launch(e)
+            e.set_data(Y, c)
+            t, g = e.nll_and_grad(params)
+            sums += t["sums8"]
+            for k in GRAD_KEYS_A:
+                gsum[k] = gsum[k] + g[k]
+    assert sums[6] / sums[7] == pytest.approx(whole_t["nll"], rel=1e-11)
+    for k in GRAD_KEYS_A:
+        assert np.max(np.abs(gsum[k] - whole_g[k])) < 1e-9 * max(1e-30, np.max(np.abs(whole_g[k]))), k
