@@ -13,11 +13,13 @@ M, C = params["Z"].shape[0], c.shape[1]
 S = int(os.environ.get("ACT_S", "1"))
 params["X"] = np.repeat(params["X"][None], S, axis=0) + 1e-3 * np.random.default_rng(0).standard_normal((S,) + params["X"].shape)
 modes = {'forward': (False,), 'train': (True,)}.get(sys.argv[1] if len(sys.argv) > 1 else '', (False, True))
+collapse = os.environ.get("ACT_BRANCH", "B").upper() != "A"          # ACT_BRANCH=A: the explicit-U branch (FFVD_Main.py cases 1 / 2 / 3 / 6)
 for grad in modes:
-    e = ElboEngine(T, D, C, M, S, route="gram", grad=grad)
+    e = ElboEngine(T, D, C, M, S, grad=grad, **(dict(route="gram") if collapse else dict(U_collapse=False)))
     e.set_data(Y, c); e.set_params(params)
     f = (lambda: e.adam_step(1e-9)) if grad else (lambda: e.nll_terms())
     for _ in range(10): f()
     n = 300; t0 = time.perf_counter()
     for _ in range(n): f()
-    print("actuator T=%d M=%d D=%d S=%d %s: %.3f ms per call" % (T, M, D, S, "adam_step" if grad else "forward", (time.perf_counter()-t0)/n*1e3))
+    print("actuator T=%d M=%d D=%d S=%d branch %s (%s) %s: %.3f ms per call" % (T, M, D, S, "B" if collapse else "A", "one launch" if int(e.lib.ffvd_single_launch(e._h)) else "multi-kernel",
+                                                                          "adam_step" if grad else "forward", (time.perf_counter()-t0)/n*1e3))
