@@ -494,7 +494,7 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
             // the runtime grants without throttling wave slots (checked where the handle is made, not assumed).
             size_t pb = 0;
             const int wpu_max = 1 + h->tiny.nstrips + (h->tiny.side ? h->tiny.NT : 0);
-            if (tiny_kernel_private_bytes(h->tiny.nw, &pb) != hipSuccess || pb > TINY_PRIVATE_BYTES_MAX ||
+            if (tiny_kernel_private_bytes(h->tiny.nw, c.branch == FFVD_BRANCH_B ? 1 : 0, &pb) != hipSuccess || pb > TINY_PRIVATE_BYTES_MAX ||
                 pb * 64 * h->tiny.nw * (size_t)h->tiny.nunits * wpu_max > TINY_PRIVATE_LAUNCH_BUDGET) {
                 char wmsg[256];
                 snprintf(wmsg, sizeof wmsg, "warning: one-launch iteration not used: its kernel reports %zu bytes of private memory per lane "

@@ -76,7 +76,7 @@ struct TinyArgRing {
 };
 constexpr size_t TINY_PRIVATE_BYTES_MAX = 1024;                 // scratch per lane the kernels were validated with (576 at the time of writing)
 constexpr size_t TINY_PRIVATE_LAUNCH_BUDGET = (size_t)128 << 20;    // scratch of all resident waves of one launch
-hipError_t tiny_kernel_private_bytes(int nw, size_t *bytes);
+hipError_t tiny_kernel_private_bytes(int nw, int branch /* 1 collapsed, 0 explicit U */, size_t *bytes);
 hipError_t tiny_ring_create(TinyArgRing &r);
 void tiny_ring_destroy(TinyArgRing &r);
 // dev_args: a TinyArgs in device memory the kernel reads its arguments from (one per launch flavour, with its ring).

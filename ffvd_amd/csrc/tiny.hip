@@ -897,7 +897,9 @@ __device__ __forceinline__ void tiny_row_gemm(d4 (&acc)[TNT], const double *Arow
 // 50-field block either sat in SGPRs for the whole kernel (400+ SGPR spills) or -- for a callee that is not inlined -- in a
 // private-memory copy that did not survive the spill traffic of the K_uu-side code (wrong chain sums, then memory faults, once a
 // head ran that code before closing its unit; found by diffing the scratch block of two builds, tools/dbg_cmp.py).
-template <int NW>
+// BR: the branch as a compile-time constant (1 collapsed U, 0 explicit U) -- the collapsed branch's code is what it was before the
+// explicit-U roles were written into the same body (as a run-time switch they cost it ten spilled registers).
+template <int NW, int BR>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void tiny_kernel(const TinyArgs *__restrict__ ap) {      // (<= 256 registers: the MFMAs take VGPR accumulators, no AGPR copies)
     const TinyArgs &a = *ap;
     constexpr int NTHR = 64 * NW, SR = 16 * NW;
@@ -1059,7 +1061,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void tiny_kernel(const Ti
             return;
         }
         TSTAMP(4);
-        const bool BA = a.branch == 0;
+        constexpr bool BA = BR == 0;
         if (BA && !a.grad) {                                                  // explicit U, forward: no H -- the strips' sums are the unit's terms
             if (tid == 0) { a.hterms[2 * u] = 0.0; a.hterms[2 * u + 1] = 0.0; }
             tiny_unit_done<NW>(a, u, lds, L.ctl, L.red, L.vec, L.mat);
@@ -1324,7 +1326,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void tiny_kernel(const Ti
     double *zs = lds + L.zo, *zz = zs + (size_t)Mp * 9;
     double *dlt = lds + L.misc, *rowv = dlt + SR, *chn = rowv + SR;          // chn: [2][SR] per-row transition / likelihood terms
     const double *Xs = a.X + (size_t)s * (T + 1) * D;
-    const bool BA = a.branch == 0;                                            // explicit-U branch (regularizer, dgp_model.py:337-359)
+    constexpr bool BA = BR == 0;                                              // explicit-U branch (regularizer, dgp_model.py:337-359)
     double *uvs = lds + L.vec;                                                // explicit U: the unit's column of U, zero padded (phase 2 reads it as `wl`)
     __syncthreads();
     if (BA)
@@ -1755,9 +1757,13 @@ void tiny_bind_scratch(TinyArgs &a, const TinyPlan &pl, double *scratch, int *fl
 // Private (scratch) memory per lane of the kernel a plan launches, as the loaded code object reports it.  The plan needs EVERY
 // workgroup resident at once, and a wave is only resident with its scratch: ffvd_create checks this figure against what the file was
 // validated with (TINY_PRIVATE_BYTES_MAX) and against a budget for the whole launch before it lets a handle take the one-launch path.
-hipError_t tiny_kernel_private_bytes(int nw, size_t *bytes) {
+static const void *tiny_kernel_fn(int nw, int branch) {
+    if (nw == 4) return branch ? reinterpret_cast<const void *>(&tiny_kernel<4, 1>) : reinterpret_cast<const void *>(&tiny_kernel<4, 0>);
+    return branch ? reinterpret_cast<const void *>(&tiny_kernel<8, 1>) : reinterpret_cast<const void *>(&tiny_kernel<8, 0>);
+}
+hipError_t tiny_kernel_private_bytes(int nw, int branch, size_t *bytes) {
     hipFuncAttributes fa;
-    const void *fn = nw == 4 ? reinterpret_cast<const void *>(&tiny_kernel<4>) : reinterpret_cast<const void *>(&tiny_kernel<8>);
+    const void *fn = tiny_kernel_fn(nw, branch);
     hipError_t e = hipFuncGetAttributes(&fa, fn);
     if (e != hipSuccess) return e;
     *bytes = (size_t)fa.localSizeBytes;
@@ -1782,13 +1788,13 @@ void tiny_ring_destroy(TinyArgRing &r) {
 }
 
 hipError_t launch_tiny(hipStream_t stream, const TinyArgs &a, const TinyPlan &pl, TinyArgs *dev_args, TinyArgRing &ring) {
-    static size_t attr_bytes_dev[16][2] = {};          // dynamic LDS each instantiation has been allowed so far, per device
+    static size_t attr_bytes_dev[16][4] = {};          // dynamic LDS each instantiation has been allowed so far, per device
     int dev = 0;
     size_t *attr_bytes = (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16) ? attr_bytes_dev[dev] : nullptr;      // (unknown device: always set)
     const int wpu = 1 + pl.nstrips + (a.side ? pl.NT : 0);
     const int grid = a.xcd_map ? 8 * wpu * ((pl.nunits + 7) / 8) : pl.nunits * wpu;
-    const int which = pl.nw == 4 ? 0 : 1;
-    const void *fn = which == 0 ? reinterpret_cast<const void *>(&tiny_kernel<4>) : reinterpret_cast<const void *>(&tiny_kernel<8>);
+    const int which = (pl.nw == 4 ? 0 : 1) + (a.branch ? 0 : 2);
+    const void *fn = tiny_kernel_fn(pl.nw, a.branch);
     if ((!attr_bytes || pl.lds_bytes > attr_bytes[which]) && pl.lds_bytes > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes);
         if (e != hipSuccess) return e;
@@ -1812,8 +1818,11 @@ hipError_t launch_tiny(hipStream_t stream, const TinyArgs &a, const TinyPlan &pl
         ring.held_valid = true;
         ++ring.uploads;
     }
-    if (which == 0) hipLaunchKernelGGL(tiny_kernel<4>, dim3(grid), dim3(256), pl.lds_bytes, stream, (const TinyArgs *)dev_args);
-    else hipLaunchKernelGGL(tiny_kernel<8>, dim3(grid), dim3(512), pl.lds_bytes, stream, (const TinyArgs *)dev_args);
+    const TinyArgs *da = dev_args;
+    if (pl.nw == 4 && a.branch) hipLaunchKernelGGL((tiny_kernel<4, 1>), dim3(grid), dim3(256), pl.lds_bytes, stream, da);
+    else if (pl.nw == 4) hipLaunchKernelGGL((tiny_kernel<4, 0>), dim3(grid), dim3(256), pl.lds_bytes, stream, da);
+    else if (a.branch) hipLaunchKernelGGL((tiny_kernel<8, 1>), dim3(grid), dim3(512), pl.lds_bytes, stream, da);
+    else hipLaunchKernelGGL((tiny_kernel<8, 0>), dim3(grid), dim3(512), pl.lds_bytes, stream, da);
     return hipGetLastError();
 }
 
