@@ -1392,6 +1392,35 @@ def _schedule_case(case):
     raise KeyError(case)
 
 
+@pytest.mark.parametrize("passes,mode", [(2, 0), (3, 0), (4, 1), (5, 2)])
+def test_pipelined_passes_are_bit_identical(passes, mode, monkeypatch):
+    """the pass-pipelined forward iteration (enqueue_elbo_pipe, FFVD_PIPE / FFVD_PIPE_MODE: K_fu build of pass p+1 |
+    Gram kernel of pass p | Cholesky(A) of pass p-1 on separate streams; measured slower, kept opt-in -- DESIGN.md section 5 "Round 5")
+    runs the same kernels on the same units with another launch partition: at BASELINE configs[1]'s full shape its terms and per-chain
+    nll equal the full-batch schedule's bit for bit -- uneven partitions (32 chains in 3 or 5 passes) and delayed streams included."""
+    params, Y, c, meta = synthetic.make_named("c2")
+    with ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], meta["S"], route="gram") as e:
+        assert "full unsplit" in e.lib.ffvd_schedule_name(e._h).decode()
+        e.set_data(Y, c)
+        base = e.nll_terms(params)
+    monkeypatch.setenv("FFVD_PIPE", str(passes))
+    monkeypatch.setenv("FFVD_PIPE_MODE", str(mode))
+    for env in ({}, {"FFVD_DEBUG_SIDE_DELAY_US": "300"}, {"FFVD_DEBUG_MAIN_DELAY_US": "300"}):
+        for k in ("FFVD_DEBUG_SIDE_DELAY_US", "FFVD_DEBUG_MAIN_DELAY_US"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], meta["S"], route="gram") as e:
+            assert "pipelined passes" in e.lib.ffvd_schedule_name(e._h).decode()
+            e.set_data(Y, c)
+            got = e.nll_terms(params)
+            again = e.nll_terms(params)
+            assert int(e.lib.ffvd_stall_recoveries(e._h)) == 0
+        for n in TERMS_B:
+            assert got[n] == base[n] and again[n] == base[n], (passes, mode, env, n)
+        np.testing.assert_array_equal(got["nll_per_chain"], base["nll_per_chain"])
+
+
 @pytest.mark.parametrize("case,grad", [("c2_full", False), ("c2_full", True), ("c2_rank4", False), ("c2_rank4", True), ("c2_rank3", False), ("c2_rank8", False), ("c2_rank2", False), ("c2_16", False),
                                        ("c2_reference", False), ("actuator_multi_kernel", False), ("actuator_multi_kernel", True)])
 def test_results_do_not_depend_on_which_stream_is_late(case, grad, monkeypatch):
