@@ -269,8 +269,11 @@ __device__ __forceinline__ void pg_step_body(const double *mean, const double *v
                                                           const double *eps_t, const double *unif_t, const double *y_t,
                                                           const double *x_ref_next, const double *CC, const double *DD,
                                                           const double *Rch, const double *ctrl_next, int R, int D, int C,
-                                                          int Ydim, double *xc, double *cand, double *parts_next,
-                                                          int32_t *idx_out) {
+                                                          int Ydim, const double *xc_in, double *xc, double *cand, double *parts_next,
+                                                          int32_t *idx_out, const bool write_out = true) {
+    // xc_in: the R x (D + C) input rows of this step; xc: where the resampled rows go (the per-step launch passes the same array twice;
+    // the fused front kernel alternates two buffers: other workgroups still read xc_in).  write_out = false: parts_next / idx_out
+    // are left to another workgroup that computes the same values.
     __shared__ double w[PG_MAXN], cdf[PG_MAXN];
     __shared__ double wmax_s;
     const int N = R + 1, P = D + C, i0 = threadIdx.x, istep = STRIDED ? (int)blockDim.x : PG_MAXN;
@@ -279,7 +282,7 @@ __device__ __forceinline__ void pg_step_body(const double *mean, const double *v
             double xn;
             if (i < R) {
                 const double v = var[i * D + p] + exp(log_Q[p]);
-                xn = (mean[i * D + p] + xc[i * P + p]) + eps_t[i * D + p] * sqrt(v);          // :99-101
+                xn = (mean[i * D + p] + xc_in[i * P + p]) + eps_t[i * D + p] * sqrt(v);       // :99-101
             } else xn = x_ref_next[p];                                                         // :111
             cand[(size_t)i * D + p] = xn;
         }
@@ -319,10 +322,10 @@ __device__ __forceinline__ void pg_step_body(const double *mean, const double *v
             if (cdf[mid] > target) hi = mid; else lo = mid + 1;
         }
         const int k = (lo < N) ? lo : N - 1;
-        idx_out[i] = k;
+        if (write_out) idx_out[i] = k;
         for (int p = 0; p < D; ++p) {
             const double x = cand[(size_t)k * D + p];
-            parts_next[(size_t)i * D + p] = x;
+            if (write_out) parts_next[(size_t)i * D + p] = x;
             xc[i * P + p] = x;
         }
         if (ctrl_next)
@@ -330,6 +333,22 @@ __device__ __forceinline__ void pg_step_body(const double *mean, const double *v
     }
     __syncthreads();      // (a persistent caller reuses w / cdf)
 }
+
+// ---- particle-Gibbs step in two launches (kernels.hip, pg_front_kernel) -------------------------------------------------------------------
+constexpr int PG_FRONT_MAX = 1024;      // (particles + 1) x latent dims the fused front keeps in LDS
+struct PgFrontArgs {
+    ProjectArgs pa;                 // K_fu rows of the particles of THIS step (pa.x = x_out of the resampling, or the initial rows)
+    int do_step, build;             // do_step: epilogue + propagate + weight + resample of the PREVIOUS step first; build: the K_fu tile behind it
+    int kind, R, D, C, Ydim, ngs;
+    const double *variance, *rowsq, *fmean;      // the previous step's skinny product
+    const double *log_Q, *eps_t, *unif_t, *y_t, *x_ref_next, *CC, *DD, *Rch, *ctrl_next;
+    const double *x_in;             // R x (D + C) rows the previous step's product was formed from
+    double *x_out;                  // resampled rows (never x_in: other workgroups still read it)
+    double *parts_next;
+    int32_t *idx_out;
+};
+bool pg_front_ok(int R, int D);
+void launch_pg_front(hipStream_t stream, const PgFrontArgs &a);
 
 // ---- one persistent launch per step loop (loops.hip) ------------------------------------------------------------------------------
 struct RolloutLoopArgs {
