@@ -208,7 +208,41 @@ __device__ __forceinline__ void conditional_finish_body(const int vb, int kind, 
     if (extra) var[idx] = var[idx] + ex;                            // fvar + reduce_sum(square(LTA), 1)  (:380)
 }
 
-struct FinishIn {
+// The same epilogue by ONE thread per output (n, d), bit for bit: conditional_finish_body gives lane l of a 16-lane group the partials
+// g = l, l + 16, ... (added in that order) and then adds the 16 lane sums in a butterfly -- a balanced binary tree over l in natural
+// order.  Here a thread keeps the 16 residue sums itself (every load independent of the others: one trip to L2 for all of them, where
+// the 16-lane form makes ng / 16 dependent trips per virtual block) and adds them in the same tree.  For callers that need ALL
+// outputs in one workgroup (the fused particle-Gibbs front).
+__device__ __forceinline__ void conditional_finish_thread(const int idx, int kind, const double *x, int N, int P, const double *variance,
+                                                          const double *rowsq, const double *fmean, int ng, int Tp, int D,
+                                                          double *mean, double *var) {
+    if (idx >= N * D) return;
+    const int n = idx / D, d = idx % D;
+    double rs[16], fm[16];
+#pragma unroll
+    for (int l = 0; l < 16; ++l) { rs[l] = 0.0; fm[l] = 0.0; }
+    const double *pr = rowsq + (size_t)d * ng * Tp + n, *pf = fmean + (size_t)d * ng * Tp + n;
+    for (int g0 = 0; g0 < ng; g0 += 16) {
+#pragma unroll
+        for (int l = 0; l < 16; ++l)
+            if (g0 + l < ng) { rs[l] += pr[(size_t)(g0 + l) * Tp]; fm[l] += pf[(size_t)(g0 + l) * Tp]; }
+    }
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) {
+#pragma unroll
+        for (int l = 0; l < 16; l += 2 * m) { rs[l] += rs[l + m]; fm[l] += fm[l + m]; }
+    }
+    double kd = variance[d];
+    if (kind == 1) {
+        double s = 0.0;
+        for (int p = 0; p < P; ++p) { const double v = x[(size_t)n * P + p]; s += (v * v) * variance[d]; }
+        kd = s;
+    }
+    mean[idx] = fm[0];
+    var[idx] = kd - rs[0];
+}
+
+struct FinishIn {struct FinishIn {
     int kind, P, ng, Tp, D, extra_ng;
     const double *variance, *rowsq, *fmean, *extra;     // extra: optional [D][extra_ng][Tp]
 };
