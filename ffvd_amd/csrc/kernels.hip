@@ -3483,8 +3483,10 @@ template <int KIND, int NQ>
 __global__ __launch_bounds__(256) void pg_front_kernel(PgFrontArgs a) {
     __shared__ double mean_s[PG_FRONT_MAX], var_s[PG_FRONT_MAX], cand_s[PG_FRONT_MAX + 8];
     if (a.do_step) {
-        for (int idx = threadIdx.x; idx < a.R * a.D; idx += 256)
-            conditional_finish_thread(idx, a.kind, a.x_in, a.R, a.pa.P, a.variance, a.rowsq, a.fmean, a.ngs, a.pa.Tp, a.D, mean_s, var_s);
+        for (int o = threadIdx.x; o < a.R * a.D; o += 256) {      // (n fastest across the threads: coalesced reads of the partials)
+            const int d = o / a.R, n = o - d * a.R;
+            conditional_finish_thread(n * a.D + d, a.kind, a.x_in, a.R, a.pa.P, a.variance, a.rowsq, a.fmean, a.ngs, a.pa.Tp, a.D, mean_s, var_s);
+        }
         __syncthreads();
         const bool writer = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
         pg_step_body<1>(mean_s, var_s, a.log_Q, a.eps_t, a.unif_t, a.y_t, a.x_ref_next, a.CC, a.DD, a.Rch, a.ctrl_next, a.R, a.D, a.C, a.Ydim,
