@@ -138,16 +138,32 @@ __device__ __forceinline__ void skinny_body(const SkinnyArgs &a, const int bx, c
     // four CONSECUTIVE doubles of its A row (two 16-byte loads feed four MFMAs, 128-byte runs per row) instead of four 8-byte ones
     const double *ap0 = Ab + (size_t)(r0 + lr) * a.lda + 4 * lk, *ap1 = ap0 + (size_t)16 * a.lda;
     const double *bp = Bb + (size_t)(4 * lk) * ldb + n0 + lr;
-    for (int kb = kb0; kb < kb1; ++kb) {       // (the compiler does not unroll this loop; two blocks in flight by hand were no faster)
-        const int k0 = 16 * kb;
-        const d2 a0l = *reinterpret_cast<const d2 *>(ap0 + k0), a0h = *reinterpret_cast<const d2 *>(ap0 + k0 + 2);
-        const d2 a1l = *reinterpret_cast<const d2 *>(ap1 + k0), a1h = *reinterpret_cast<const d2 *>(ap1 + k0 + 2);
-        const double *bq = bp + (size_t)k0 * ldb;
-        const double b0 = bq[0], b1 = bq[ldb], b2 = bq[2 * (size_t)ldb], b3 = bq[3 * (size_t)ldb];
-        acc[0] = mfma_f64(a0l.x, b0, acc[0]); acc[1] = mfma_f64(a1l.x, b0, acc[1]);
-        acc[0] = mfma_f64(a0l.y, b1, acc[0]); acc[1] = mfma_f64(a1l.y, b1, acc[1]);
-        acc[0] = mfma_f64(a0h.x, b2, acc[0]); acc[1] = mfma_f64(a1h.x, b2, acc[1]);
-        acc[0] = mfma_f64(a0h.y, b3, acc[0]); acc[1] = mfma_f64(a1h.y, b3, acc[1]);
+    // Round 5: the operands of FOUR k blocks are requested before the first of their 32 MFMAs (one trip to L2 per four blocks).  As
+    // first written -- one block per loop trip, which the compiler does not unroll -- every trip waited for its own loads: 1.2 us per
+    // block against 0.23 us of matrix work, 12-13 us for the kernel at 100 rows (tools/pg_trace.sh).  Same MFMAs on the same
+    // accumulators in the same order: same bits.
+    constexpr int SKB = 4;
+    for (int kbb = kb0; kbb < kb1; kbb += SKB) {
+        d2 a0l[SKB], a0h[SKB], a1l[SKB], a1h[SKB];
+        double bv[SKB][4];
+#pragma unroll
+        for (int i = 0; i < SKB; ++i) {
+            const int kb = (kbb + i < kb1) ? kbb + i : kb1 - 1;       // (clamped: a trailing partial chunk re-reads its last block, unused)
+            const int k0 = 16 * kb;
+            a0l[i] = *reinterpret_cast<const d2 *>(ap0 + k0); a0h[i] = *reinterpret_cast<const d2 *>(ap0 + k0 + 2);
+            a1l[i] = *reinterpret_cast<const d2 *>(ap1 + k0); a1h[i] = *reinterpret_cast<const d2 *>(ap1 + k0 + 2);
+            const double *bq = bp + (size_t)k0 * ldb;
+            bv[i][0] = bq[0]; bv[i][1] = bq[ldb]; bv[i][2] = bq[2 * (size_t)ldb]; bv[i][3] = bq[3 * (size_t)ldb];
+        }
+#pragma unroll
+        for (int i = 0; i < SKB; ++i) {
+            if (kbb + i < kb1) {
+                acc[0] = mfma_f64(a0l[i].x, bv[i][0], acc[0]); acc[1] = mfma_f64(a1l[i].x, bv[i][0], acc[1]);
+                acc[0] = mfma_f64(a0l[i].y, bv[i][1], acc[0]); acc[1] = mfma_f64(a1l[i].y, bv[i][1], acc[1]);
+                acc[0] = mfma_f64(a0h[i].x, bv[i][2], acc[0]); acc[1] = mfma_f64(a1h[i].x, bv[i][2], acc[1]);
+                acc[0] = mfma_f64(a0h[i].y, bv[i][3], acc[0]); acc[1] = mfma_f64(a1h[i].y, bv[i][3], acc[1]);
+            }
+        }
     }
     if (w > 0) {
 #pragma unroll
