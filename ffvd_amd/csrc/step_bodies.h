@@ -258,7 +258,7 @@ __device__ __forceinline__ void conditional_finish_thread(const int idx, int kin
     var[idx] = kd - rs[0];
 }
 
-struct FinishIn {struct FinishIn {
+struct FinishIn {
     int kind, P, ng, Tp, D, extra_ng;
     const double *variance, *rowsq, *fmean, *extra;     // extra: optional [D][extra_ng][Tp]
 };
