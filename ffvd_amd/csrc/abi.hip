@@ -3034,36 +3034,6 @@ extern "C" int ffvd_op_pg_sweep(int kind, const double *Lm_inverse_seq, const do
                            R, D, C, Ydim, dxc, cand, dparts + (size_t)t * R * D, didx + (size_t)t * R);
         }
     };
-    // Round 5: two launches per step (kernels.hip, pg_front_kernel): the conditional epilogue and the propagate / weight / resample of
-    // step t - 1 are repeated by every workgroup of step t's K_fu build (same bodies, same order: same bits as the four launches);
-    // the rows alternate between two buffers.  FFVD_PG_FUSED=0 keeps the four launches.
-    double *dxc2 = sc.alloc<double>(xc0.size());
-    OP_CHECK(dxc2, "ffvd_op_pg_sweep");
-    auto step_launches_fused = [&]() {
-        double *xb[2] = {dxc, dxc2};
-        PgFrontArgs fa{};
-        fa.kind = kind; fa.R = R; fa.D = D; fa.C = C; fa.Ydim = Ydim; fa.ngs = ngs; fa.variance = variance; fa.rowsq = rowsq; fa.fmean = fmean;
-        fa.log_Q = dlq; fa.CC = dCC; fa.DD = dDD; fa.Rch = dR;
-        for (int t = 0; t <= steps; ++t) {
-            fa.pa = pa;
-            fa.pa.x = xb[t & 1];
-            fa.do_step = t > 0; fa.build = t < steps;
-            if (t > 0) {                                                          // the step whose product the last skinny launch formed
-                const int q = t - 1;
-                fa.eps_t = deps + (size_t)q * R * D; fa.unif_t = dun + (size_t)q * R; fa.y_t = dY + (size_t)q * Ydim;
-                fa.x_ref_next = dXr + (size_t)(q + 1) * D;
-                fa.ctrl_next = (C && q + 1 < steps) ? dctrl + (size_t)(q + 1) * C : nullptr;
-                fa.x_in = xb[q & 1]; fa.x_out = xb[t & 1];
-                fa.parts_next = dparts + (size_t)q * R * D; fa.idx_out = didx + (size_t)q * R;
-            }
-            launch_pg_front(sc.stream, fa);
-            if (t < steps)
-                launch_skinny_gemm(sc.stream, Kf, (size_t)Tp * Mp, Mp, dW, (size_t)Mp * Mp, Mp, 1, R, Mp, Mp, D, Tp,
-                                   nullptr, 0, 0, ucol, Mp, rowsq, fmean);
-        }
-    };
-    const char *pgf = getenv("FFVD_PG_FUSED");
-    const bool fused = skinny && pg_front_ok(R, D) && !(pgf && *pgf && strcmp(pgf, "0") == 0);
     // Round 4: ONE persistent launch for the sweep (loops.hip), three grid-wide barriers per step instead of four dependent launches:
     // measured slower (86 against 43 us per step with roles and per-unit counters, 151 with a grid-wide barrier; see ffvd_op_rollout), opt-in with FFVD_STEP_LOOP=1
     const char *nsl = getenv("FFVD_STEP_LOOP");
@@ -3089,8 +3059,7 @@ extern "C" int ffvd_op_pg_sweep(int kind, const double *Lm_inverse_seq, const do
             HIP_TRY(hipMemcpyAsync(dxc, xc0.data(), xc0.size() * sizeof(double), hipMemcpyHostToDevice, sc.stream));
             step_launches();
         }
-    } else if (fused) step_launches_fused();
-    else step_launches();
+    } else step_launches();
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(particles + (size_t)R * D, dparts, (size_t)steps * R * D * sizeof(double), hipMemcpyDeviceToHost, sc.stream));
     HIP_TRY(hipMemcpyAsync(idx, didx, (size_t)steps * R * sizeof(int32_t), hipMemcpyDeviceToHost, sc.stream));

@@ -3469,48 +3469,7 @@ __global__ __launch_bounds__(PG_MAXN) void pg_step_kernel(const double *mean, co
                                                           const double *Rch, const double *ctrl_next, int R, int D, int C,
                                                           int Ydim, double *xc, double *cand, double *parts_next,
                                                           int32_t *idx_out) {
-    pg_step_body<0>(mean, var, log_Q, eps_t, unif_t, y_t, x_ref_next, CC, DD, Rch, ctrl_next, R, D, C, Ydim, xc, xc, cand, parts_next, idx_out);
-}
-
-// ---- particle-Gibbs sweep, two launches per step (round 5) ---------------------------------------------------------------------------
-// A step was four dependent launches (K_fu rows of the particles, skinny product, conditional epilogue, propagate + weight + resample:
-// 40 us, of which the kernels are about half -- the rest is what four launch boundaries cost).  The last two are ONE workgroup's
-// work on R (D + C) numbers: every workgroup of the NEXT step's K_fu build can afford to repeat them for itself (100 particles: a few
-// microseconds, in LDS) instead of waiting for a launch that does them once.  pg_front = [epilogue + propagate + weight + resample of
-// step t - 1, by every workgroup, same bodies, same order: same bits] + [K(x_t, Z) tile of this workgroup].  Input rows of step t - 1
-// in x_in, resampled rows to x_out (every workgroup writes the same values; it reads back only what it wrote itself).
-template <int KIND, int NQ>
-__global__ __launch_bounds__(256) void pg_front_kernel(PgFrontArgs a) {
-    __shared__ double mean_s[PG_FRONT_MAX], var_s[PG_FRONT_MAX], cand_s[PG_FRONT_MAX + 8];
-    if (a.do_step) {
-        for (int o = threadIdx.x; o < a.R * a.D; o += 256) {      // (n fastest across the threads: coalesced reads of the partials)
-            const int d = o / a.R, n = o - d * a.R;
-            conditional_finish_thread(n * a.D + d, a.kind, a.x_in, a.R, a.pa.P, a.variance, a.rowsq, a.fmean, a.ngs, a.pa.Tp, a.D, mean_s, var_s);
-        }
-        __syncthreads();
-        const bool writer = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
-        pg_step_body<1>(mean_s, var_s, a.log_Q, a.eps_t, a.unif_t, a.y_t, a.x_ref_next, a.CC, a.DD, a.Rch, a.ctrl_next, a.R, a.D, a.C, a.Ydim,
-                        a.x_in, a.x_out, cand_s, a.parts_next, a.idx_out, writer);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this workgroup's rows of x_out are in memory before its K_fu tile reads them
-        __syncthreads();
-    }
-    if (a.build) kfu_build_body<KIND, NQ>(a.pa, blockIdx.x, blockIdx.y, blockIdx.z);
-}
-bool pg_front_ok(int R, int D) { return (R + 1) * D <= PG_FRONT_MAX && R + 1 <= PG_MAXN; }
-void launch_pg_front(hipStream_t stream, const PgFrontArgs &a) {
-    const ProjectArgs &pa = a.pa;
-    const dim3 grid = a.build ? dim3(pa.Tp / 64, pa.Mp / 64, pa.nb) : dim3(1, 1, 1);
-    if (pa.P <= 8) {
-        const int nq = (pa.P + 1) / 2;
-        if (pa.kind == 0) {
-            if (nq <= 2) hipLaunchKernelGGL((pg_front_kernel<0, 2>), grid, dim3(256), 0, stream, a);
-            else if (nq == 3) hipLaunchKernelGGL((pg_front_kernel<0, 3>), grid, dim3(256), 0, stream, a);
-            else hipLaunchKernelGGL((pg_front_kernel<0, 4>), grid, dim3(256), 0, stream, a);
-        } else hipLaunchKernelGGL((pg_front_kernel<1, 4>), grid, dim3(256), 0, stream, a);
-    } else {
-        if (pa.kind == 0) hipLaunchKernelGGL((pg_front_kernel<0, 0>), grid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((pg_front_kernel<1, 0>), grid, dim3(256), 0, stream, a);
-    }
+    pg_step_body<0>(mean, var, log_Q, eps_t, unif_t, y_t, x_ref_next, CC, DD, Rch, ctrl_next, R, D, C, Ydim, xc, cand, parts_next, idx_out);
 }
 void launch_pg_step(hipStream_t stream, const double *mean, const double *var, const double *log_Q, const double *eps_t,
                     const double *unif_t, const double *y_t, const double *x_ref_next, const double *CC, const double *DD,

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void pg_loop_kernel(PgLoopArgs a, const int GA
             __syncthreads();
             pg_step_body<1>(a.mean, a.var, a.log_Q, a.eps + (size_t)t * R * D, a.unif + (size_t)t * R, a.Y + (size_t)t * a.Ydim,
                             a.X_ref + (size_t)(t + 1) * D, a.CC, a.DD, a.Rch, (a.C && a.ctrl && t + 1 < a.steps) ? a.ctrl + (size_t)(t + 1) * a.C : nullptr,
-                            R, D, a.C, a.Ydim, pa.x, const_cast<double *>(pa.x), a.cand, a.parts + (size_t)t * R * D, a.idx + (size_t)t * R);
+                            R, D, a.C, a.Ydim, const_cast<double *>(pa.x), a.cand, a.parts + (size_t)t * R * D, a.idx + (size_t)t * R);
             loop_arrive(loop_word(base, 0));
         }
     }

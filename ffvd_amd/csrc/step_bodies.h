@@ -138,32 +138,16 @@ __device__ __forceinline__ void skinny_body(const SkinnyArgs &a, const int bx, c
     // four CONSECUTIVE doubles of its A row (two 16-byte loads feed four MFMAs, 128-byte runs per row) instead of four 8-byte ones
     const double *ap0 = Ab + (size_t)(r0 + lr) * a.lda + 4 * lk, *ap1 = ap0 + (size_t)16 * a.lda;
     const double *bp = Bb + (size_t)(4 * lk) * ldb + n0 + lr;
-    // Round 5: the operands of FOUR k blocks are requested before the first of their 32 MFMAs (one trip to L2 per four blocks).  As
-    // first written -- one block per loop trip, which the compiler does not unroll -- every trip waited for its own loads: 1.2 us per
-    // block against 0.23 us of matrix work, 12-13 us for the kernel at 100 rows (tools/pg_trace.sh).  Same MFMAs on the same
-    // accumulators in the same order: same bits.
-    constexpr int SKB = 4;
-    for (int kbb = kb0; kbb < kb1; kbb += SKB) {
-        d2 a0l[SKB], a0h[SKB], a1l[SKB], a1h[SKB];
-        double bv[SKB][4];
-#pragma unroll
-        for (int i = 0; i < SKB; ++i) {
-            const int kb = (kbb + i < kb1) ? kbb + i : kb1 - 1;       // (clamped: a trailing partial chunk re-reads its last block, unused)
-            const int k0 = 16 * kb;
-            a0l[i] = *reinterpret_cast<const d2 *>(ap0 + k0); a0h[i] = *reinterpret_cast<const d2 *>(ap0 + k0 + 2);
-            a1l[i] = *reinterpret_cast<const d2 *>(ap1 + k0); a1h[i] = *reinterpret_cast<const d2 *>(ap1 + k0 + 2);
-            const double *bq = bp + (size_t)k0 * ldb;
-            bv[i][0] = bq[0]; bv[i][1] = bq[ldb]; bv[i][2] = bq[2 * (size_t)ldb]; bv[i][3] = bq[3 * (size_t)ldb];
-        }
-#pragma unroll
-        for (int i = 0; i < SKB; ++i) {
-            if (kbb + i < kb1) {
-                acc[0] = mfma_f64(a0l[i].x, bv[i][0], acc[0]); acc[1] = mfma_f64(a1l[i].x, bv[i][0], acc[1]);
-                acc[0] = mfma_f64(a0l[i].y, bv[i][1], acc[0]); acc[1] = mfma_f64(a1l[i].y, bv[i][1], acc[1]);
-                acc[0] = mfma_f64(a0h[i].x, bv[i][2], acc[0]); acc[1] = mfma_f64(a1h[i].x, bv[i][2], acc[1]);
-                acc[0] = mfma_f64(a0h[i].y, bv[i][3], acc[0]); acc[1] = mfma_f64(a1h[i].y, bv[i][3], acc[1]);
-            }
-        }
+    for (int kb = kb0; kb < kb1; ++kb) {       // (the compiler does not unroll this loop; two blocks in flight by hand were no faster)
+        const int k0 = 16 * kb;
+        const d2 a0l = *reinterpret_cast<const d2 *>(ap0 + k0), a0h = *reinterpret_cast<const d2 *>(ap0 + k0 + 2);
+        const d2 a1l = *reinterpret_cast<const d2 *>(ap1 + k0), a1h = *reinterpret_cast<const d2 *>(ap1 + k0 + 2);
+        const double *bq = bp + (size_t)k0 * ldb;
+        const double b0 = bq[0], b1 = bq[ldb], b2 = bq[2 * (size_t)ldb], b3 = bq[3 * (size_t)ldb];
+        acc[0] = mfma_f64(a0l.x, b0, acc[0]); acc[1] = mfma_f64(a1l.x, b0, acc[1]);
+        acc[0] = mfma_f64(a0l.y, b1, acc[0]); acc[1] = mfma_f64(a1l.y, b1, acc[1]);
+        acc[0] = mfma_f64(a0h.x, b2, acc[0]); acc[1] = mfma_f64(a1h.x, b2, acc[1]);
+        acc[0] = mfma_f64(a0h.y, b3, acc[0]); acc[1] = mfma_f64(a1h.y, b3, acc[1]);
     }
     if (w > 0) {
 #pragma unroll
@@ -222,40 +206,6 @@ __device__ __forceinline__ void conditional_finish_body(const int vb, int kind, 
     mean[idx] = fm;
     var[idx] = kd - rs;
     if (extra) var[idx] = var[idx] + ex;                            // fvar + reduce_sum(square(LTA), 1)  (:380)
-}
-
-// The same epilogue by ONE thread per output (n, d), bit for bit: conditional_finish_body gives lane l of a 16-lane group the partials
-// g = l, l + 16, ... (added in that order) and then adds the 16 lane sums in a butterfly -- a balanced binary tree over l in natural
-// order.  Here a thread keeps the 16 residue sums itself (every load independent of the others: one trip to L2 for all of them, where
-// the 16-lane form makes ng / 16 dependent trips per virtual block) and adds them in the same tree.  For callers that need ALL
-// outputs in one workgroup (the fused particle-Gibbs front).
-__device__ __forceinline__ void conditional_finish_thread(const int idx, int kind, const double *x, int N, int P, const double *variance,
-                                                          const double *rowsq, const double *fmean, int ng, int Tp, int D,
-                                                          double *mean, double *var) {
-    if (idx >= N * D) return;
-    const int n = idx / D, d = idx % D;
-    double rs[16], fm[16];
-#pragma unroll
-    for (int l = 0; l < 16; ++l) { rs[l] = 0.0; fm[l] = 0.0; }
-    const double *pr = rowsq + (size_t)d * ng * Tp + n, *pf = fmean + (size_t)d * ng * Tp + n;
-    for (int g0 = 0; g0 < ng; g0 += 16) {
-#pragma unroll
-        for (int l = 0; l < 16; ++l)
-            if (g0 + l < ng) { rs[l] += pr[(size_t)(g0 + l) * Tp]; fm[l] += pf[(size_t)(g0 + l) * Tp]; }
-    }
-#pragma unroll
-    for (int m = 1; m < 16; m <<= 1) {
-#pragma unroll
-        for (int l = 0; l < 16; l += 2 * m) { rs[l] += rs[l + m]; fm[l] += fm[l + m]; }
-    }
-    double kd = variance[d];
-    if (kind == 1) {
-        double s = 0.0;
-        for (int p = 0; p < P; ++p) { const double v = x[(size_t)n * P + p]; s += (v * v) * variance[d]; }
-        kd = s;
-    }
-    mean[idx] = fm[0];
-    var[idx] = kd - rs[0];
 }
 
 struct FinishIn {
@@ -319,11 +269,8 @@ __device__ __forceinline__ void pg_step_body(const double *mean, const double *v
                                                           const double *eps_t, const double *unif_t, const double *y_t,
                                                           const double *x_ref_next, const double *CC, const double *DD,
                                                           const double *Rch, const double *ctrl_next, int R, int D, int C,
-                                                          int Ydim, const double *xc_in, double *xc, double *cand, double *parts_next,
-                                                          int32_t *idx_out, const bool write_out = true) {
-    // xc_in: the R x (D + C) input rows of this step; xc: where the resampled rows go (the per-step launch passes the same array twice;
-    // the fused front kernel alternates two buffers: other workgroups still read xc_in).  write_out = false: parts_next / idx_out
-    // are left to another workgroup that computes the same values.
+                                                          int Ydim, double *xc, double *cand, double *parts_next,
+                                                          int32_t *idx_out) {
     __shared__ double w[PG_MAXN], cdf[PG_MAXN];
     __shared__ double wmax_s;
     const int N = R + 1, P = D + C, i0 = threadIdx.x, istep = STRIDED ? (int)blockDim.x : PG_MAXN;
@@ -332,7 +279,7 @@ __device__ __forceinline__ void pg_step_body(const double *mean, const double *v
             double xn;
             if (i < R) {
                 const double v = var[i * D + p] + exp(log_Q[p]);
-                xn = (mean[i * D + p] + xc_in[i * P + p]) + eps_t[i * D + p] * sqrt(v);       // :99-101
+                xn = (mean[i * D + p] + xc[i * P + p]) + eps_t[i * D + p] * sqrt(v);          // :99-101
             } else xn = x_ref_next[p];                                                         // :111
             cand[(size_t)i * D + p] = xn;
         }
@@ -351,39 +298,17 @@ __device__ __forceinline__ void pg_step_body(const double *mean, const double *v
         w[i] = -0.5 * q + (-ld);
     }
     __syncthreads();
-    // max of the log weights: every thread over its particles, wavefront shuffles, the wavefronts' values through LDS (exact whatever the
-    // order); then exp(w - max) and the CDF.  The oracle's cumsum adds the weights one after the other in index order; so does wavefront 0,
-    // 64 at a time out of registers (v_readlane of lane k, one add) -- 0.5 us for 100 particles where one thread walking LDS took 5 (and 5
-    // more for the max): the step kernel 9.8 -> 3 us (tools/pg_trace.sh).
-    {
-        double m = -1.0e300;
-        for (int i = i0; i < N; i += istep) m = (w[i] > m) ? w[i] : m;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { const double t = __shfl_xor(m, o); m = (t > m) ? t : m; }
-        if ((threadIdx.x & 63) == 0) cdf[threadIdx.x >> 6] = m;          // (cdf is free until the scan below)
-        __syncthreads();
-        if (i0 == 0) {
-            double mm = cdf[0];
-            for (int k = 1; k < (int)((blockDim.x + 63) >> 6); ++k) mm = (cdf[k] > mm) ? cdf[k] : mm;
-            wmax_s = mm;
-        }
+    if (i0 == 0) {
+        double m = w[0];
+        for (int k = 1; k < N; ++k) m = (w[k] > m) ? w[k] : m;
+        wmax_s = m;
     }
     __syncthreads();
     for (int i = i0; i < N; i += istep) w[i] = exp(w[i] - wmax_s);
     __syncthreads();
-    if (threadIdx.x < 64) {
-        const int lane = threadIdx.x;
+    if (i0 == 0) {
         double c = 0.0;
-        for (int b0 = 0; b0 < N; b0 += 64) {
-            const double wv = (b0 + lane < N) ? w[b0 + lane] : 0.0;
-            double mine = 0.0;
-#pragma unroll
-            for (int k = 0; k < 64; ++k) {
-                c += __shfl(wv, k);                      // (constant lane: v_readlane; lanes past N add exact zeros behind the last real one)
-                mine = (lane == k) ? c : mine;
-            }
-            if (b0 + lane < N) cdf[b0 + lane] = mine;
-        }
+        for (int k = 0; k < N; ++k) { c += w[k]; cdf[k] = c; }
     }
     __syncthreads();
     for (int i = i0; i < R; i += istep) {
@@ -394,10 +319,10 @@ __device__ __forceinline__ void pg_step_body(const double *mean, const double *v
             if (cdf[mid] > target) hi = mid; else lo = mid + 1;
         }
         const int k = (lo < N) ? lo : N - 1;
-        if (write_out) idx_out[i] = k;
+        idx_out[i] = k;
         for (int p = 0; p < D; ++p) {
             const double x = cand[(size_t)k * D + p];
-            if (write_out) parts_next[(size_t)i * D + p] = x;
+            parts_next[(size_t)i * D + p] = x;
             xc[i * P + p] = x;
         }
         if (ctrl_next)
@@ -405,22 +330,6 @@ __device__ __forceinline__ void pg_step_body(const double *mean, const double *v
     }
     __syncthreads();      // (a persistent caller reuses w / cdf)
 }
-
-// ---- particle-Gibbs step in two launches (kernels.hip, pg_front_kernel) -------------------------------------------------------------------
-constexpr int PG_FRONT_MAX = 1024;      // (particles + 1) x latent dims the fused front keeps in LDS
-struct PgFrontArgs {
-    ProjectArgs pa;                 // K_fu rows of the particles of THIS step (pa.x = x_out of the resampling, or the initial rows)
-    int do_step, build;             // do_step: epilogue + propagate + weight + resample of the PREVIOUS step first; build: the K_fu tile behind it
-    int kind, R, D, C, Ydim, ngs;
-    const double *variance, *rowsq, *fmean;      // the previous step's skinny product
-    const double *log_Q, *eps_t, *unif_t, *y_t, *x_ref_next, *CC, *DD, *Rch, *ctrl_next;
-    const double *x_in;             // R x (D + C) rows the previous step's product was formed from
-    double *x_out;                  // resampled rows (never x_in: other workgroups still read it)
-    double *parts_next;
-    int32_t *idx_out;
-};
-bool pg_front_ok(int R, int D);
-void launch_pg_front(hipStream_t stream, const PgFrontArgs &a);
 
 // ---- one persistent launch per step loop (loops.hip) ------------------------------------------------------------------------------
 struct RolloutLoopArgs {

@@ -409,32 +409,6 @@ def test_pg_sweep_matches_oracle(name, ov, N, Ydim):
     np.testing.assert_array_equal(p1[1:], np.repeat(X[1:, None, :], N - 1, axis=1))
 
 
-def test_pg_sweep_two_launches_per_step_equal_four(monkeypatch):
-    """Round 5: the sweep's step as two launches (the conditional epilogue and the propagate / weight / resample of step t - 1 repeated
-    by every workgroup of step t's K_fu build, kernels.hip pg_front_kernel) against the four dependent launches of rounds 1-4
-    (FFVD_PG_FUSED=0): the same bodies in the same order -- particles and ancestor indices bit for bit, 100 particles at M = 77."""
-    from ffvd_amd import conditionals_multi_output as cmo
-    from ffvd_amd.prediction import pg_sweep
-    from ffvd_amd.kernels import SquaredExponential
-    params, Y, c, meta = synthetic.make_named("ragged")
-    D, C, T = meta["D"], meta["C"], meta["T"]
-    X = params["X"][0]
-    Q = np.exp(params["log_Q"])
-    rng = np.random.default_rng(12)
-    N = 100
-    kern = [SquaredExponential(D + C, variance=np.exp(params["logvariance"][d]),
-                               lengthscales=np.exp(params["loglengthscales"][d])) for d in range(D)]
-    x0, eps, u = rng.standard_normal((N - 1, D)), rng.standard_normal((T, N - 1, D)), rng.random((T, N - 1))
-    Lg = cmo.kernel_pre_cal(params["Z"], kern)
-    args = (Lg, params["Z"], kern, params["U"], X, Y, c, params["CC"], params["DD"], np.exp(params["log_Rchols"]), Q, x0, eps, u)
-    monkeypatch.delenv("FFVD_PG_FUSED", raising=False)
-    p2, i2 = pg_sweep(*args)
-    monkeypatch.setenv("FFVD_PG_FUSED", "0")
-    p4, i4 = pg_sweep(*args)
-    np.testing.assert_array_equal(i2, i4)
-    np.testing.assert_array_equal(p2, p4)
-
-
 def test_pg_sweep_argument_errors():
     from ffvd_amd.prediction import pg_sweep
     from ffvd_amd.kernels import SquaredExponential

@@ -1,5 +1,7 @@
-"""Wall time of one particle-Gibbs sweep at config 2's shape (T = 4096 steps, 100 particles, M = 512, D = 4), the step as two launches
-(default) and as the four launches of rounds 1-4 (FFVD_PG_FUSED=0); the two results must be bit-identical.  GPU box helper."""
+"""Wall time of one particle-Gibbs sweep at config 2's shape (T = 4096 steps, 100 particles, M = 512, D = 4), twice per setting of
+FFVD_PG_FUSED (an experiment switch of round 5 -- the fused two-launch step, measured slower and removed again; the switch is ignored by
+the shipped library: both settings time the four-launch step).  Results must be bit-identical.  GPU box helper; tools/pg_trace.sh
+runs it under rocprofv3 for the per-kernel table."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
