@@ -2235,21 +2235,81 @@ extern "C" int ffvd_sghmc_apply(ffvd_handle *h, double epsilon, double mdecay, u
     return FFVD_OK;
 }
 
-// ---- operator-level entry points (temporaries allocated per call; not the hot path) --------------
+// ---- operator-level entry points (temporaries per call; not the hot path) -------------------------------------------------------------
+// Round 5: the temporaries come from a per-thread cache instead of hipMalloc / hipFree / hipStreamCreate per call.  A rollout call made
+// ~27 allocations and as many frees around 200 steps of 15 us: 2.7 ms of host work per call (profiles/r04_next_rows.json: 27.6 us per
+// step of a 200-step call against 15.3 marginal).  A block is handed out again when its size fits (smallest block that is large enough
+// and at most 4 x the request); the cache is bounded (256 blocks / 8 GiB: beyond that everything idle is freed) and can be released
+// with ffvd_op_release_cache().  Nothing relies on fresh memory being zero (hipMalloc never promised that).
 namespace {
-struct Scratch {
-    std::vector<void *> ptrs;
+struct OpCache {
+    struct Block { void *p; size_t bytes; bool busy; };
+    std::vector<Block> blocks;
+    size_t total = 0;
     hipStream_t stream = nullptr;
+    int device = -1;
+    void release_idle() {
+        std::vector<Block> keep;
+        for (Block &b : blocks) {
+            if (b.busy) keep.push_back(b);
+            else { hipFree(b.p); total -= b.bytes; }
+        }
+        blocks.swap(keep);
+    }
+    void release_all() {
+        release_idle();
+        if (stream && blocks.empty()) { hipStreamDestroy(stream); stream = nullptr; }
+    }
+    ~OpCache() { /* process exit: the runtime may already be gone; leave the memory to it */ }
+};
+thread_local OpCache g_op_cache;
+
+struct Scratch {
+    std::vector<size_t> mine;           // indices into the cache of the blocks this call holds
+    hipStream_t stream = nullptr;
+    bool begin() {
+        OpCache &c = g_op_cache;
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+        if (c.device != dev) {           // (another device was made current on this thread: start over)
+            c.release_all();
+            c.device = dev;
+        }
+        if (!c.stream && hipStreamCreate(&c.stream) != hipSuccess) return false;
+        stream = c.stream;
+        return true;
+    }
     ~Scratch() {
-        if (stream) { hipStreamSynchronize(stream); hipStreamDestroy(stream); }
-        for (void *p : ptrs) hipFree(p);
+        if (stream) hipStreamSynchronize(stream);
+        OpCache &c = g_op_cache;
+        for (size_t i : mine) c.blocks[i].busy = false;
+        if (c.blocks.size() > 256 || c.total > ((size_t)8 << 30)) c.release_idle();
     }
     template <class T>
     T *alloc(size_t n) {
-        void *p = nullptr;
-        if (hipMalloc(&p, (n ? n : 1) * sizeof(T)) != hipSuccess) return nullptr;
-        ptrs.push_back(p);
-        return (T *)p;
+        OpCache &c = g_op_cache;
+        const size_t bytes = ((n ? n : 1) * sizeof(T) + 255) / 256 * 256;
+        size_t best = (size_t)-1;
+        for (size_t i = 0; i < c.blocks.size(); ++i) {
+            const OpCache::Block &b = c.blocks[i];
+            if (!b.busy && b.bytes >= bytes && b.bytes <= 4 * bytes && (best == (size_t)-1 || b.bytes < c.blocks[best].bytes)) best = i;
+        }
+        if (best == (size_t)-1) {
+            void *p = nullptr;
+            if (hipMalloc(&p, bytes) != hipSuccess) {
+                (void)hipGetLastError();
+                c.release_idle();                                   // make room and try once more
+                mine.clear();
+                for (size_t i = 0; i < c.blocks.size(); ++i) if (c.blocks[i].busy) mine.push_back(i);      // (indices moved; every busy block is this call's: one call per thread at a time)
+                if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+            }
+            c.blocks.push_back({p, bytes, false});
+            c.total += bytes;
+            best = c.blocks.size() - 1;
+        }
+        c.blocks[best].busy = true;
+        mine.push_back(best);
+        return (T *)c.blocks[best].p;
     }
     double *upload(const double *src, size_t n) {
         double *d = alloc<double>(n);
@@ -2259,11 +2319,17 @@ struct Scratch {
 };
 }  // namespace
 
+// Free what the calling thread's operator cache holds (device buffers of finished ffvd_op_* calls, their stream).
+extern "C" int ffvd_op_release_cache(void) {
+    g_op_cache.release_all();
+    return FFVD_OK;
+}
+
 #define OP_BEGIN(name)                                                                       \
     ffvd_handle *h = nullptr;                                                                \
     (void)h;                                                                                 \
     Scratch sc;                                                                              \
-    if (hipStreamCreate(&sc.stream) != hipSuccess)                                           \
+    if (!sc.begin())                                                                         \
         return set_error(nullptr, FFVD_EDEVICE, name ": no usable HIP device / stream creation failed");
 #define OP_CHECK(ptr, name) \
     if (!(ptr)) return set_error(nullptr, FFVD_ENOMEM, name ": device allocation or upload failed");
@@ -2631,6 +2697,8 @@ extern "C" int ffvd_op_get_rand(const double *mean, const double *var, const dou
 }
 
 // shared by ffvd_op_collapse_u_mean / ffvd_op_conditional_precalc: pad a caller-supplied stack of D M x M matrices
+// (M a multiple of the block size: nothing to pad -- the callers upload the caller's array itself, pad_needed)
+static bool pad_needed(int M, int Mp) { return M != Mp; }
 static std::vector<double> pad_stack(const double *src, int D, int M, int Mp) {
     std::vector<double> out((size_t)D * Mp * Mp, 0.0);
     for (int d = 0; d < D; ++d)
@@ -2642,6 +2710,13 @@ static std::vector<double> pad_stack(const double *src, int D, int M, int Mp) {
     return out;
 }
 
+// upload a stack of D M x M matrices padded to Mp (`keep` owns the padded host copy until the call returns; none when M == Mp)
+static double *upload_stack(Scratch &sc, const double *src, int D, int M, int Mp, std::vector<double> &keep) {
+    if (!pad_needed(M, Mp)) return sc.upload(src, (size_t)D * M * M);
+    keep = pad_stack(src, D, M, Mp);
+    return sc.upload(keep.data(), keep.size());
+}
+
 extern "C" int ffvd_op_collapse_u_mean(int kind, const double *Lm_inverse_seq, const double *X_combine, const double *X,
                                        const double *Z, int T, int M, int P, int D, const double *logvariance,
                                        const double *loglengthscales, const double *Q, double *U_mean,
@@ -2651,7 +2726,7 @@ extern "C" int ffvd_op_collapse_u_mean(int kind, const double *Lm_inverse_seq, c
         return set_error(nullptr, FFVD_EINVAL, "ffvd_op_collapse_u_mean: bad argument");
     OP_BEGIN("ffvd_op_collapse_u_mean");
     const int Mp = round_up(M, NB), Tp = round_up(T, STRIP), ng = (Mp + 511) / 512;
-    std::vector<double> Wp = pad_stack(Lm_inverse_seq, D, M, Mp);
+    std::vector<double> Wp;
     std::vector<double> logQ(D);
     for (int d = 0; d < D; ++d) logQ[d] = log(Q[d]);
     // slab per dim: rows [0,Mp) H, rows [Mp,2Mp) identity -> L_H^-T, row 2Mp carries b -> L_H^-1 b
@@ -2659,7 +2734,7 @@ extern "C" int ffvd_op_collapse_u_mean(int kind, const double *Lm_inverse_seq, c
     std::vector<double> Hinit((size_t)D * hstride, 0.0);
     for (int d = 0; d < D; ++d)
         for (int i = 0; i < Mp; ++i) Hinit[(size_t)d * hstride + (size_t)(Mp + i) * Mp + i] = 1.0;
-    double *dW = sc.upload(Wp.data(), Wp.size());
+    double *dW = upload_stack(sc, Lm_inverse_seq, D, M, Mp, Wp);
     double *dXc = sc.upload(X_combine, (size_t)T * P), *dX = sc.upload(X, (size_t)(T + 1) * D);
     double *dZ = sc.upload(Z, (size_t)M * P), *dlv = sc.upload(logvariance, D), *dlq = sc.upload(logQ.data(), D);
     double *dll = sc.alloc<double>((size_t)D * P);
@@ -2720,8 +2795,8 @@ extern "C" int ffvd_op_conditional_precalc(int kind, const double *Lm_inverse_se
     OP_BEGIN("ffvd_op_conditional_precalc");
     if (N == 0) return FFVD_OK;
     const int Mp = round_up(M, NB), Tp = round_up(N, STRIP), ng = (Mp + 511) / 512;
-    std::vector<double> Wp = pad_stack(Lm_inverse_seq, D, M, Mp);
-    double *dW = sc.upload(Wp.data(), Wp.size());
+    std::vector<double> Wp;
+    double *dW = upload_stack(sc, Lm_inverse_seq, D, M, Mp, Wp);
     double *dX = sc.upload(Xnew, (size_t)N * P), *dZ = sc.upload(Z, (size_t)M * P), *dU = sc.upload(f, (size_t)M * D);
     double *dlv = sc.upload(logvariance, D), *dll = sc.alloc<double>((size_t)D * P);
     double *variance = sc.alloc<double>(D), *len = sc.alloc<double>((size_t)D * P);
@@ -2814,13 +2889,13 @@ extern "C" int ffvd_op_rollout(int kind, const double *Lm_inverse_seq, const dou
     // per 128-column tile and dim): 16 workgroups instead of the 4 of the fused projection kernel, whose single
     // workgroup per dim made a step compute-bound on one CU
     const int Mp = round_up(M, NB), Tp = round_up(R, STRIP), ng = (Mp + 127) / 128;
-    std::vector<double> Wp = pad_stack(Lm_inverse_seq, D, M, Mp);
+    std::vector<double> Wp;
     std::vector<double> xc0((size_t)R * P);
     for (int r = 0; r < R; ++r) {
         for (int d = 0; d < D; ++d) xc0[(size_t)r * P + d] = x_last[d];              // x_t = X[-1] (:226), every rollout
         for (int c = 0; c < C; ++c) xc0[(size_t)r * P + D + c] = ctrl[c];            // control row of step 0 (:293)
     }
-    double *dW = sc.upload(Wp.data(), Wp.size());
+    double *dW = upload_stack(sc, Lm_inverse_seq, D, M, Mp, Wp);
     double *dxc = sc.upload(xc0.data(), xc0.size()), *dZ = sc.upload(Z, (size_t)M * P), *dU = sc.upload(f, (size_t)M * D);
     double *dxc2 = sc.alloc<double>(xc0.size());          // the rows of step t + 1 (the step kernel reads one buffer and writes the other)
     double *dlv = sc.upload(logvariance, D), *dll = sc.alloc<double>((size_t)D * P), *dlq = sc.upload(log_Q, D);
@@ -2838,8 +2913,7 @@ extern "C" int ffvd_op_rollout(int kind, const double *Lm_inverse_seq, const dou
     double *dmean = sc.alloc<double>((size_t)R * D), *dvar = sc.alloc<double>((size_t)R * D);
     double *dpx = sc.alloc<double>((size_t)R * steps * D), *dpv = sc.alloc<double>((size_t)R * steps * D);
     std::vector<double> Qp;
-    if (q_sqrt && skinny) Qp = pad_stack(q_sqrt, 1, M, Mp);                // (F is zero in the padded columns)
-    double *dQs = q_sqrt ? (skinny ? sc.upload(Qp.data(), Qp.size()) : sc.upload(q_sqrt, (size_t)M * M)) : nullptr;   // slice d = 0 only
+    double *dQs = q_sqrt ? (skinny ? upload_stack(sc, q_sqrt, 1, M, Mp, Qp) /* (F is zero in the padded columns) */ : sc.upload(q_sqrt, (size_t)M * M)) : nullptr;   // slice d = 0 only
     double *extra = q_sqrt ? sc.alloc<double>((size_t)D * (skinny ? ngs : 1) * Tp) : nullptr;
     // skinny path: W q_sqrt once per call (D products of M^3), so that the inflation term is a second right-hand side of the
     // step's one product instead of a dependent product on F
@@ -2982,13 +3056,13 @@ extern "C" int ffvd_op_pg_sweep(int kind, const double *Lm_inverse_seq, const do
     memcpy(particles, x0, (size_t)R * D * sizeof(double));                                   // particles[0] (:87)
     if (steps == 0) return FFVD_OK;
     const int Mp = round_up(M, NB), Tp = round_up(R, STRIP), ng = (Mp + 127) / 128;
-    std::vector<double> Wp = pad_stack(Lm_inverse_seq, D, M, Mp);
+    std::vector<double> Wp;
     std::vector<double> xc0((size_t)R * P);
     for (int r = 0; r < R; ++r) {
         for (int d = 0; d < D; ++d) xc0[(size_t)r * P + d] = x0[(size_t)r * D + d];
         for (int c = 0; c < C; ++c) xc0[(size_t)r * P + D + c] = ctrl[c];                     // control row of step 0 (:93)
     }
-    double *dW = sc.upload(Wp.data(), Wp.size());
+    double *dW = upload_stack(sc, Lm_inverse_seq, D, M, Mp, Wp);
     double *dxc = sc.upload(xc0.data(), xc0.size()), *dZ = sc.upload(Z, (size_t)M * P), *dU = sc.upload(U, (size_t)M * D);
     double *dlv = sc.upload(logvariance, D), *dll = sc.alloc<double>((size_t)D * P), *dlq = sc.upload(log_Q, D);
     double *deps = sc.upload(eps, (size_t)steps * R * D), *dun = sc.upload(unif, (size_t)steps * R);

@@ -403,6 +403,11 @@ int  ffvd_op_adam_step(double *theta, const double *grad, double *m, double *v, 
 int  ffvd_op_sghmc_step(double *theta, const double *grad, double *xi, double *g, double *g2, double *p,
                         const double *noise, int64_t n, double epsilon, double mdecay, double X_N, int burn_in);
 
+/* The ffvd_op_* entry points keep their device temporaries and their stream in a per-thread cache between calls (a rollout call
+ * made ~27 allocations around its step loop: 2.7 ms of host work per call).  ffvd_op_release_cache frees what the calling thread's
+ * cache holds; the cache also trims itself beyond 256 blocks / 8 GiB. */
+int  ffvd_op_release_cache(void);
+
 /* The prediction loop of collect_samples_formal (base_model.py:288-314) for R posterior rollouts advanced side by
  * side on the device: per step, conditional_after_kernel_precalculation at the R current states (:300, q_sqrt = the
  * d = 0 slice or NULL as in ffvd_op_conditional_precalc), then x_next = x + f_mu + eps * sqrt(f_var + Q) (:304-306).
