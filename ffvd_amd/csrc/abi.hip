@@ -971,386 +971,463 @@ static int enqueue_elbo_pipe(ffvd_handle *h, double *out_dev, StageTimer *st) {
     return FFVD_OK;
 }
 
+// ---- the multi-kernel forward iteration, phase by phase -------------------------------------------------------
+// enqueue_elbo used to be one 425-line function; it is now the sequence below, each phase a function of its own over one context.
+// The SCHEDULE is sc (plan_schedule: every flag decided in one place, named, checked); the context only adds launch PROGRESS -- which
+// buffers a launch has produced so far -- and the two streams.  Launch order is exactly what it was: results are bit-identical.
+//
+// Event graphs of the named schedules (M = main stream, S = side stream; "->e" records, "e->" waits):
+//   full unsplit (kuu_flow)   M: prep, K_uu build ->fork | reductions | go-> build(K_fu), brow | join-> Gram | hwords-> Chol(A), finish | finalize
+//                             S: fork-> clear ->go | chain (one dataflow launch: L, L^-1, K^-1) | clear H words ->hwords | log|K| ->join
+//   unsplit + raw tiles       M: prep ->fork | build, brow | kuu-> Gram(raw) ->tiles | Chol(A) | join2-> finalize
+//   (defer_full)              S: fork-> K_uu build ->kuu | chain (launches) | K^-1, log|K| ->join | reductions | tiles-> trace pass ->join2
+//   split-K one pass          M: prep ->fork | build, brow, tile pass ->tiles | kuu-> combine (no trace) | Chol(A) | join2-> finalize
+//   (defer_trace, main_first) S: fork-> K_uu build ->kuu | chain | K^-1, log|K| ->join | reductions | tiles-> trace partials ->join2
+//   side late                 as the two above, but the chain is ONE dataflow launch enqueued behind the tile pass (tiles-> chain), the
+//                             reductions in front of it, the trace pass behind it
+//   small side                split-K one pass with the chain as one dataflow launch; reductions and trace partials on M (join-> trace)
+//   split-K several passes    M: ... tile pass | join-> combine with trace | Chol(A) ... per pass
+//   projection route, side    M: prep, K_uu build ->fork | go-> build | join-> projection GEMM, brow | Gram | Chol(H) | reductions, finalize
+//   (ref_side)                S: fork-> clear ->go | chain (dataflow) | [K^-1, log|K| for a backward pass] ->join
+//   serial                    everything on M in dependence order.
+struct FwdCtx {
+    ffvd_handle *h;
+    double *out_dev;
+    StageTimer *st;
+    ElboSchedule sc;
+    HyperView hv;
+    hipStream_t s, sk;              // main stream; the stream that carries the K_uu chain (= s while nothing runs beside the main stream)
+    size_t msq, kstride;
+    ReduceArgs ra;
+    // launch progress, not schedule
+    bool kuu_on_main = false;       // K_uu is built (and its chain launched) before the common chain code
+    bool linv_done = false;         // L^-1 comes / came out of the factorisation itself
+    bool kinv_done = false;         // K^-1 came out of the chain's dataflow launch (no product launch)
+    bool hwords_zeroed = false;     // Cholesky(A)'s progress words were cleared on the side stream (ev_hwords)
+    bool ident_early = false;       // training: the identity rows of the first pass were re-armed early on the main stream
+    bool reduce_done = false, reduce_launched = false, trace_on_main = false;
+    bool chain_deferred = false;    // the chain is enqueued behind the first pass's Gram launch
+
+    ProjectArgs project_args(int s0, int ns) const { return elbo_project_args(h, hv, s0, ns, sc.gram_route); }
+    GramArgs gram_args(int s0, int ns) const { return elbo_gram_args(h, s0, ns, sc.gram_route); }
+    // Gram route: the row b = delta^T K_fu / Q of a pass, from the partial sums its K_fu build left behind (kernels.h ProjectArgs::gpart)
+    void brow_finish(int s0, int ns) const {
+        if (!h->growpart) return;
+        const ffvd_config &c = h->cfg;
+        launch_brow_finish(s, h->growpart, h->Tp / 64, h->Mp, h->Dl, c.d_begin, s0 * h->Dl, ns * h->Dl, h->cur.log_Q, 1.0, h->H,
+                           elbo_h_stride(h), c.grad ? 2 * h->Mp : h->Mp);
+    }
+};
+
+// Projection route / explicit-U branch on the projection GEMM (fp64): only the GEMM needs the chain's W = L^-T, the K_fu build does
+// not -- the chain's dataflow launch goes to the side stream (resident before the build floods the chip) and the main stream waits
+// for it in front of the first projection GEMM: config 2 in the reference's op order 6.31 -> 6.05 ms.  LinearK through its rank
+// (zt_rows): the chain carries Z^T instead of the identity rows.
+static int fwd_chain_ref_side(FwdCtx &x) {
+    ffvd_handle *h = x.h;
+    const ffvd_config &c = h->cfg;
+    const int Mp = h->Mp, Dl = h->Dl;
+    const bool zt_rows = x.sc.zt_rows, wants_linv = x.sc.grad_a || x.sc.grad_ref;
+    x.sk = h->aux;
+    launch_kuu_build(x.s, c.kernel_kind, x.hv, c.M, Mp, h->P, Dl, c.jitter, h->Kuu, wants_linv ? h->Kcopy : nullptr, zt_rows);
+    { int rcf = fork_side(h, h->ev_fork, x.s, x.sk); if (rcf) return rcf; }
+    potrf_flow_clear(x.sk, h->dinvK, Dl);
+    HIP_TRY(hipEventRecord(h->ev_go, x.sk));
+    x.linv_done = wants_linv;
+    launch_potrf_ext(x.sk, h->Kuu, Mp, zt_rows ? NB : Mp, zt_rows ? 0 : Mp, Dl, x.kstride, h->info, h->dinvK, CHOL_FLOW,
+                     x.linv_done ? h->Linv : nullptr, x.msq, true);
+    HIP_TRY(hipStreamWaitEvent(x.s, h->ev_go, 0));
+    x.kuu_on_main = true;          // (built and factorised: fwd_chain_rest adds K^-1 / log|K| where a backward pass wants them)
+    return FFVD_OK;
+}
+
+// Gram route: nothing of the K_fu build depends on K_uu, so the latency-bound K_uu chain runs on the side stream.  This is the fork
+// and whatever the schedule wants on either stream BEFORE the chain's own launches (fwd_chain_rest): the full-batch schedule's
+// dataflow chain and the work that fills the main stream's wait for it; the first pass's K_fu build / tile pass when the main
+// stream is the critical one (kfu_first, main_first); the identity rows of a training pass on the side stream.
+static int fwd_chain_fork(FwdCtx &x) {
+    ffvd_handle *h = x.h;
+    const ffvd_config &c = h->cfg;
+    const ElboSchedule &sc = x.sc;
+    const int Mp = h->Mp, Dl = h->Dl;
+    hipStream_t s = x.s;
+    x.sk = h->aux;
+    hipStream_t sk = x.sk;
+    x.kuu_on_main = sc.kuu_flow;
+    if (x.kuu_on_main)
+        launch_kuu_build(s, c.kernel_kind, x.hv, c.M, Mp, h->P, Dl, c.jitter, h->Kuu, h->Kcopy);
+    { int rcf = fork_side(h, h->ev_fork, s, sk); if (rcf) return rcf; }
+    if (x.kuu_on_main) {
+        HIP_TRY(hipEventRecord(h->ev_kuu, s));
+        x.linv_done = potrf_flow_selected(Mp, Dl, CHOL_FLOW);      // L^-1 comes out of the factorisation itself
+        if (x.linv_done) {
+            // The chain's 64-odd row workgroups (76.8 KB of LDS, 256 VGPRs) must be on the chip BEFORE the K_fu build
+            // floods it with small ones, or they wait for that kernel to drain: the main stream resumes one
+            // cross-queue hop after the clear that sits directly in front of the chain's kernel
+            potrf_flow_clear(sk, h->dinvK, Dl);
+            HIP_TRY(hipEventRecord(h->ev_go, sk));
+        }
+        x.kinv_done = x.linv_done && !h->sw.kinv_gram && potrf_flow_forms_inverse(Mp, Dl, CHOL_FLOW);
+        launch_potrf_ext(sk, h->Kuu, Mp, Mp, Mp, Dl, x.kstride, h->info, h->dinvK, CHOL_FLOW, h->Linv, x.msq, x.linv_done, false,
+                         x.kinv_done ? h->Kinv : nullptr, x.msq);
+        if (x.linv_done) {
+            launch_chain_reduce(s, x.ra, h->chain_partial);      // inputs only; fills the wait below
+            x.reduce_done = true;
+            if (c.grad && c.branch == FFVD_BRANCH_B && !sc.lt_rows) {
+                // training: the identity rows that become L_A^-T are re-armed here too (rows the K_fu build and the Gram
+                // kernel do not touch) instead of between the K_fu build and the Gram kernel
+                const GramArgs gi = x.gram_args(0, sc.ns_first);
+                launch_set_identity(s, h->H, gi.h_stride, Mp, Mp, sc.ns_first * Dl);
+                x.ident_early = true;
+            }
+            HIP_TRY(hipStreamWaitEvent(s, h->ev_go, 0));
+            if (c.S_local <= h->cpp) {          // single pass: the words of Cholesky(A) are cleared here, off the main stream
+                potrf_flow_clear(sk, h->dinvH, h->nbatch);
+                HIP_TRY(hipEventRecord(h->ev_hwords, sk));      // the factorisation that trusts this clear waits for THIS event
+                x.hwords_zeroed = true;
+            }
+        }
+    }
+    if (sc.kfu_first) {         // the first pass's K_fu build goes to the main stream before the chain is enqueued
+        if (x.st) x.st->mark(0);
+        launch_kfu_build(s, x.project_args(0, sc.ns_first));
+        x.brow_finish(0, sc.ns_first);
+        if (x.st) x.st->mark(1);
+    }
+    if (sc.main_first) {        // ... and so does the split-K tile pass (it needs neither K_uu nor K^-1)
+        const GramArgs ga = x.gram_args(0, c.S_local);
+        launch_gram(s, ga, 1);
+        HIP_TRY(hipEventRecord(h->ev_tiles, s));
+    }
+    // training: the identity rows that become L_A^-T are re-armed on the side stream, ahead of the K_uu build whose
+    // event the main stream waits for anyway (0.05 ms off the critical path at the full batch)
+    if (sc.ident_on_side) {
+        const GramArgs ga = x.gram_args(0, sc.ns_first);
+        launch_set_identity(sk, h->H, ga.h_stride, Mp, Mp, sc.ns_first * Dl);
+    }
+    return FFVD_OK;
+}
+
+// The K_uu chain's own launches on x.sk (unless the prelude already enqueued its factorisation): Cholesky with the L^-T rows, then --
+// Gram route and backward passes -- K^-1 = L^-T L^-1 and log|K|, the join event, and the per-chain reductions where they ride behind
+// the chain.
+static int fwd_chain_rest(FwdCtx &x) {
+    ffvd_handle *h = x.h;
+    const ffvd_config &c = h->cfg;
+    const ElboSchedule &sc = x.sc;
+    const int Mp = h->Mp, Dl = h->Dl;
+    hipStream_t s = x.s, sk = x.sk;
+    const size_t msq = x.msq, kstride = x.kstride;
+    const bool zt_rows = sc.zt_rows, needs_inverse = sc.gram_route || sc.grad_a || sc.grad_ref;
+    if (!x.kuu_on_main) {
+        // chain on the main stream = on the critical path with nothing beside it: the dataflow launch; on the side stream
+        // (beside the K_fu build / tile pass of a small batch) the right-looking launches, whose workgroups come and go
+        const bool chain_flow = sc.chain_flow_here;
+        if (chain_flow && needs_inverse) x.linv_done = true;
+        if (chain_flow && (sc.small_side || sc.side_late) && sc.gram_route && potrf_flow_forms_inverse(Mp, Dl, CHOL_FLOW)) x.kinv_done = true;
+        if (sc.side_late) {
+            // the reductions of the inputs first (they need nothing), then the chain once the tile pass has left the chip
+            if (sc.reduce_early && !x.reduce_done) { launch_chain_reduce(sk, x.ra, h->chain_partial); x.reduce_launched = true; }
+            HIP_TRY(hipStreamWaitEvent(sk, h->ev_tiles, 0));
+        }
+        launch_potrf_ext(sk, h->Kuu, Mp, zt_rows ? NB : Mp, zt_rows ? 0 : Mp, Dl, kstride, h->info, h->dinvK,
+                         chain_flow ? CHOL_FLOW : CHOL_AUTO, x.linv_done ? h->Linv : nullptr, msq, chain_flow /* words zeroed by the build */,
+                         false, x.kinv_done ? h->Kinv : nullptr, msq, nullptr, 0, 1, sc.small_side || sc.side_late);
+    }
+    if (needs_inverse) {
+        // K^-1 = L^-T L^-1 (shared by all chains) and log|K|
+        if (!x.linv_done) launch_transpose(sk, h->Kuu + msq, kstride, h->Linv, msq, Mp, Dl);
+        GramArgs gk{};
+        gk.mode = GRAM_PLAIN; gk.A = h->Linv; gk.a_stride = msq; gk.rows = Mp; gk.with_row = 0; gk.Mp = Mp; gk.Dl = Dl;
+        gk.d_begin = c.d_begin; gk.b0 = 0; gk.nb = Dl; gk.yn_over_batch = 1.0; gk.H = h->Kinv; gk.h_stride = msq;
+        if (x.kinv_done) {
+            // (the identity-row workgroups of the chain's launch have formed it: kernels.hip, df_inverse_tiles)
+        } else if (c.grad || (x.kuu_on_main && !h->sw.kinv_gram)) {
+            // the backward pass reads K^-1 everywhere, the Gram kernel only writes lower tiles; and beside the K_fu build
+            // (kuu_on_main: the main stream waits for this product) 256-thread workgroups find a slot where the Gram
+            // kernel's 1024-thread ones wait for the build to drain (0.19 against 0.05 ms)
+            AtbArgs ak{};
+            ak.mode = ATB_PLAIN; ak.A = h->Linv; ak.a_stride = msq; ak.lda = Mp; ak.nA = Mp; ak.B = h->Linv; ak.b_stride = msq;
+            ak.ldb = Mp; ak.nB = Mp; ak.rows = Mp; ak.C = h->Kinv; ak.c_stride = msq; ak.ldc = Mp; ak.nb = Dl; ak.Dl = Dl;
+            ak.k_lower = 1;                                  // L^-1 is lower triangular
+            ak.small_tiles = x.kuu_on_main ? 1 : 0;
+            launch_atb(sk, ak);
+        } else launch_gram(sk, gk);     // (split-K here was measured slower: 0.42 vs 0.37 ms for the K_uu stage)
+        launch_h_finish(sk, h->Kuu, Mp, kstride, Dl, h->kterms);
+        if (sk != s) HIP_TRY(hipEventRecord(h->ev_join, sk));
+    } else if (sc.ref_side) HIP_TRY(hipEventRecord(h->ev_join, sk));
+    // the per-chain likelihood / transition reductions depend on the inputs only (Gram route: no row sums of F), so
+    // they ride on the side stream behind the K_uu chain and are back long before finalize needs them (kuu_on_main: they
+    // already ran on the main stream while it waited for the chain's kernel to be dispatched)
+    if (sc.reduce_early && !x.reduce_done && !sc.small_side /* reductions on the main stream */ && !x.reduce_launched) {
+        launch_chain_reduce(sk, x.ra, h->chain_partial);
+        HIP_TRY(hipEventRecord(h->ev_join2, sk));
+    }
+    return FFVD_OK;
+}
+
+// K(X_combine, Z) of one pass and what turns it into the pass's F / fmean / row sums: five forms, by route, branch and arithmetic.
+static int fwd_pass_project(FwdCtx &x, int s0, int ns) {
+    ffvd_handle *h = x.h;
+    const ffvd_config &c = h->cfg;
+    const ElboSchedule &sc = x.sc;
+    const ffvd_params &p = h->cur;
+    const int Mp = h->Mp, Tp = h->Tp, Dl = h->Dl;
+    hipStream_t s = x.s, sk = x.sk;
+    const size_t msq = x.msq, kstride = x.kstride;
+    ProjectArgs pa = x.project_args(s0, ns);
+    if (sc.gram_route) {
+        if (!(sc.kfu_first && s0 == 0)) { launch_kfu_build(s, pa); x.brow_finish(s0, ns); }
+        if (s0 == 0 && sk != s && !sc.late_join) HIP_TRY(hipStreamWaitEvent(s, sc.defer_full ? h->ev_kuu : h->ev_join, 0));
+    } else if (c.dtype == FFVD_F32C) {
+        if (s0 == 0) launch_linv_f32(s, h->Kuu + msq, kstride, h->Linv32, Mp, Dl);     // L^-1 as the fp32 B operand
+        launch_kfu_build_f32(s, pa, h->Kf32);                     // K(X_combine, Z)           (:240)
+        ProjF32Args pg{};
+        pg.Kf = h->Kf32; pg.kf_stride = (size_t)Tp * Mp; pg.LinvT = h->Linv32; pg.F = h->F32; pg.f_stride = (size_t)Tp * Mp;
+        pg.sqpart = h->sqpart; pg.Tp = Tp; pg.Mp = Mp; pg.Dl = Dl; pg.b0 = s0 * Dl; pg.nb = ns * Dl;
+        launch_proj_gemm_f32(s, pg);                              // tilde_F = Knm Lm^-T, sum F^2  (:242,:255)
+    } else if (h->ngr && c.branch == FFVD_BRANCH_B) {
+        pa.F = h->Kf2;
+        launch_kfu_build(s, pa);                                  // K(X_combine, Z)           (:240)
+        ProjGemmArgs pg{};
+        pg.Kf = h->Kf2; pg.kf_stride = (size_t)Tp * Mp; pg.W = h->Kuu + msq; pg.w_stride = kstride;
+        pg.F = h->F; pg.f_stride = (size_t)Tp * Mp; pg.rowsq = h->rowsq; pg.Tp = Tp; pg.Mp = Mp; pg.Dl = Dl;
+        pg.b0 = s0 * Dl; pg.nb = ns * Dl;
+        pg.gpart = h->growpart; pg.X = p.X; pg.T = c.T; pg.D = c.D; pg.d_begin = c.d_begin;      // delta^T F by 128-row tiles (:247-248)
+        if (sc.ref_side && s0 == 0) HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));               // W = L^-T from the side stream's chain
+        launch_proj_gemm(s, pg);                                  // tilde_F = Knm Lm^-T, sum F^2  (:242,:255)
+        if (h->growpart)
+            launch_brow_finish(s, h->growpart, (int)((Tp + 127) / 128), Mp, Dl, c.d_begin, s0 * Dl, ns * Dl, p.log_Q, 1.0, h->H,
+                               elbo_h_stride(h), c.grad ? 2 * Mp : Mp);
+    } else if (h->lrpart) {
+        // explicit-U branch, LinearK, forward only: fmean and sum_j F^2 through the kernel's rank P (no K_fu, no F)
+        if (sk != s && s0 == 0) HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));
+        launch_linear_lowrank(s, pa, h->lrpart);
+    } else if (c.branch == FFVD_BRANCH_A && h->ngr) {
+        // explicit-U branch: K_fu once, then the triangular GEMM with fvar / fmean folded into its epilogue (F unstored)
+        pa.F = h->F + (sc.grad_a ? (size_t)s0 * Dl * Tp * Mp : 0);
+        launch_kfu_build(s, pa);
+        if (sc.ref_side && s0 == 0) HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));               // W = L^-T from the side stream's chain
+        if (s0 == 0) launch_ucols(s, p.U, c.M, Mp, c.D, c.d_begin, Dl, h->ucolA);
+        ProjGemmArgs pg{};
+        pg.Kf = pa.F; pg.kf_stride = (size_t)Tp * Mp; pg.W = h->Kuu + msq; pg.w_stride = kstride;
+        pg.F = nullptr; pg.f_stride = 0; pg.rowsq = h->rowsq; pg.fmean = h->fmean; pg.u = h->ucolA; pg.u_stride = Mp;
+        pg.Tp = Tp; pg.Mp = Mp; pg.Dl = Dl; pg.b0 = s0 * Dl; pg.nb = ns * Dl;
+        launch_proj_gemm(s, pg);
+    } else {
+        if (sc.grad_a) {                    // (FFVD_FUSED_PROJECT) the backward pass still needs K_fu itself
+            pa.F = h->F;
+            launch_kfu_build(s, pa);
+            pa.F = nullptr;
+        }
+        launch_project(s, pa);
+    }
+    if (x.st && !(sc.kfu_first && s0 == 0)) x.st->mark(1);
+    DBG_SYNC(h, "forward: K_fu / projection");
+    return FFVD_OK;
+}
+
+// H = F^T F / Q + I (projection route) or A = K_uu + K_uf K_fu / Q (Gram route) of one pass: the tile pass + combine of a split-K
+// launch, the unsplit launch with raw tiles beside the chain, the fp32 product, or the plain unsplit launch.
+static int fwd_pass_gram(FwdCtx &x, int s0, int ns, GramArgs &ga, bool &trace_pending, bool &acopy_done) {
+    ffvd_handle *h = x.h;
+    const ffvd_config &c = h->cfg;
+    const ElboSchedule &sc = x.sc;
+    const ffvd_params &p = h->cur;
+    const int Mp = h->Mp, Tp = h->Tp, Dl = h->Dl;
+    hipStream_t s = x.s, sk = x.sk;
+    if (sc.lt_rows) {
+        // (armed right in front of the factorisation, when at all: L comes from the K_uu chain)
+    } else if (c.grad && !((sc.ident_on_side || x.ident_early) && s0 == 0)) launch_set_identity(s, h->H, ga.h_stride, Mp, Mp, ns * Dl);
+    if (s0 == 0 && sc.late_join) {
+        if (!sc.main_first) launch_gram(s, ga, 1);
+        if (sc.defer_trace) {
+            if (!sc.main_first) HIP_TRY(hipEventRecord(h->ev_tiles, s));
+            HIP_TRY(hipStreamWaitEvent(s, h->ev_kuu, 0));
+            ga.trace_mode = 1;
+            // side late: the trace pass runs long after this one (behind the K_uu chain) -- it reads the summed raw tiles this
+            // pass leaves in partial 0 instead of all the row ranges again (134 MB at 4 chains: 20-27 us of the iteration's tail)
+            ga.raw_summed = (sc.side_late || sc.small_side) ? 1 : 0;      // (small side: the trace pass follows on this stream)
+            launch_gram(s, ga, 2);
+            if (sc.side_late) HIP_TRY(hipEventRecord(h->ev_tiles, s));      // (the trace pass waits for THIS record)
+            trace_pending = true;      // enqueued behind the factorisation: the main stream is the critical one
+        } else {
+            HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));
+            launch_gram(s, ga, 2);
+        }
+    } else if (s0 == 0 && sc.defer_full && sk != s) {
+        ga.mode = GRAM_KFU_RAW; ga.part = h->graw; ga.ksplit = 1;
+        if (c.grad) { ga.Hcopy = h->gw.Acopy; ga.hcopy_stride = x.msq; acopy_done = true; }
+        launch_gram(s, ga);
+        HIP_TRY(hipEventRecord(h->ev_tiles, s));
+        trace_pending = true;
+    } else if (c.dtype == FFVD_F32C) {
+        GramF32Args gf{};
+        gf.F = h->F32; gf.f_stride = (size_t)Tp * Mp; gf.rows = Tp; gf.with_row = 1; gf.brow = c.grad ? 2 * Mp : Mp;
+        gf.X = p.X; gf.log_Q = p.log_Q; gf.T = c.T; gf.D = c.D; gf.Mp = Mp; gf.Dl = Dl; gf.d_begin = c.d_begin;
+        gf.b0 = s0 * Dl; gf.nb = ns * Dl; gf.yn_over_batch = 1.0; gf.H = h->H; gf.h_stride = ga.h_stride;
+        gf.flush = h->gram_flush;
+        launch_gram_f32(s, gf);                               // H = F^T F / Q + I, b = delta^T F / Q  (:246-248)
+    } else {
+        // training: the unsplit Gram kernel stores the symmetric copy of A itself (no copy + symmetrize launches: 0.25 ms)
+        if (c.grad && sc.gram_route && !ga.part) { ga.Hcopy = h->gw.Acopy; ga.hcopy_stride = x.msq; acopy_done = true; }
+        launch_gram(s, ga);
+    }
+    if (x.st) x.st->mark(2);
+    DBG_SYNC(h, "forward: Gram");
+    return FFVD_OK;
+}
+
+// Gram-route training without L^T rows (FFVD_GRAD_WHITEN_PRODUCTS): H = W^T A W (W = L^-T of K_uu) replaces A in the slab, b = W^T c
+// replaces c: the factorisation, the explicit inverse and everything the backward pass derives from them then live in the whitened
+// variables, where cond(H) is about 1e4 instead of the 1e7 of A
+static int fwd_whiten_products(FwdCtx &x, int ns, const GramArgs &ga) {
+    ffvd_handle *h = x.h;
+    ffvd_handle::GradWs &g = h->gw;
+    const int Mp = h->Mp, Dl = h->Dl, nbp = ns * Dl;
+    const size_t msq = x.msq, kstride = x.kstride;
+    hipStream_t s = x.s;
+    const int small = h->sw.atb128 ? 0 : 1;
+    if (x.sk != s) HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));       // W and L^-1 come from the K_uu chain
+    launch_symmetrize(s, g.Acopy, Mp, nbp);                            // (the saved copy holds the lower triangle)
+    AtbArgs t1{};
+    t1.mode = ATB_PLAIN; t1.A = g.Acopy; t1.a_stride = msq; t1.lda = Mp; t1.nA = Mp;
+    t1.B = h->Kuu + msq; t1.b_stride = kstride; t1.ldb = Mp; t1.nB = Mp; t1.b_per_dim = 1; t1.rows = Mp;
+    t1.C = g.T1; t1.c_stride = msq; t1.ldc = Mp; t1.nb = nbp; t1.Dl = Dl; t1.krange = 8; t1.small_tiles = small;      // W upper triangular
+    launch_atb(s, t1);                                                  // T1 = A W
+    AtbArgs t2{};
+    t2.mode = ATB_PLAIN; t2.A = h->Kuu + msq; t2.a_stride = kstride; t2.lda = Mp; t2.nA = Mp; t2.a_per_dim = 1;
+    t2.B = g.T1; t2.b_stride = msq; t2.ldb = Mp; t2.nB = Mp; t2.rows = Mp;
+    t2.C = h->H; t2.c_stride = ga.h_stride; t2.ldc = Mp; t2.nb = nbp; t2.Dl = Dl; t2.krange = 4; t2.sym = 1; t2.small_tiles = small;
+    launch_atb(s, t2);                                                  // H = W^T T1 into rows [0, Mp)
+    launch_matvec(s, h->Linv, msq, h->H + 2 * msq, ga.h_stride, Mp, g.bw, 1, Mp, Mp, nbp, Dl);   // b = W^T c
+    HIP_TRY(hipMemcpy2DAsync(h->H + 2 * msq, ga.h_stride * sizeof(double), g.bw, (size_t)Mp * sizeof(double),
+                             (size_t)Mp * sizeof(double), (size_t)nbp, hipMemcpyDeviceToDevice, s));
+    return FFVD_OK;
+}
+
+// Cholesky of the pass's H / A slabs (one dataflow launch, the row b as a vector; training: with the L^T / identity rows), log|.| and
+// the quadratic term; in front of it the trace pass on the side stream where the schedule defers it, behind it the trace pass /
+// reductions of the small-side schedule.
+static int fwd_pass_factor(FwdCtx &x, int s0, int ns, GramArgs &ga, bool &trace_pending, const bool acopy_done) {
+    ffvd_handle *h = x.h;
+    const ffvd_config &c = h->cfg;
+    const ElboSchedule &sc = x.sc;
+    const int Mp = h->Mp, Dl = h->Dl;
+    hipStream_t s = x.s, sk = x.sk;
+    const size_t msq = x.msq, kstride = x.kstride;
+    int rc;
+    if (trace_pending && sc.small_side) {
+        // tiny iteration: the trace partials wait for the chain on the MAIN stream, behind Cholesky(A) -- one cross-stream
+        // hop (chain -> here) instead of two (tile pass -> side stream, side stream -> finalize)
+        x.trace_on_main = true;
+    } else if (trace_pending) {
+        if (x.chain_deferred && s0 == 0 && (rc = fwd_chain_rest(x)) != FFVD_OK) return rc;      // (waits for ev_tiles itself)
+        // trace partials from the raw tiles, on the side stream (K^-1 precedes in its order).  Enqueued AHEAD of the
+        // factorisation: that is one launch whose row workgroups hold every slot of the chip for most of its length,
+        // and a kernel that arrives behind it only starts when they leave (finalize then waited 0.26 ms for this pass)
+        HIP_TRY(hipStreamWaitEvent(sk, h->ev_tiles, 0));
+        launch_gram(sk, ga, 3);
+        HIP_TRY(hipEventRecord(h->ev_join2, sk));                 // supersedes the record after the reductions
+        trace_pending = false;
+    }
+    const bool words = x.hwords_zeroed && s0 == 0;
+    if (c.grad) {       // keep A = K_uu + K_uf K_fu / Q: the factorisation overwrites it in place
+        if (!acopy_done)
+            HIP_TRY(hipMemcpy2DAsync(h->gw.Acopy, msq * sizeof(double), h->H, ga.h_stride * sizeof(double),
+                                     msq * sizeof(double), (size_t)ns * Dl, hipMemcpyDeviceToDevice, s));
+        if (sc.lt_rows) {
+            if (sk != s && s0 == 0) HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));       // L (and W, L^-1 for the backward pass) come from the K_uu chain
+            if (!sc.lt_virtual) launch_set_lt_rows(s, h->Kuu, kstride, Dl, h->H, ga.h_stride, Mp, Mp, ns * Dl);
+        } else if (h->gw.whitened && sc.gram_route) {
+            if ((rc = fwd_whiten_products(x, ns, ga)) != FFVD_OK) return rc;
+        }
+        if (words) HIP_TRY(hipStreamWaitEvent(s, h->ev_hwords, 0));      // the side-stream clear of these words
+        launch_potrf_ext(s, h->H, Mp, Mp + NB, Mp, ns * Dl, ga.h_stride, h->info + Dl + s0 * Dl, h->dinvH, CHOL_FLOW, nullptr, 0,
+                         words, true, nullptr, 0, sc.lt_virtual ? h->Kuu : nullptr, kstride, Dl);
+        launch_h_finish(s, h->H, Mp, ga.h_stride, ns * Dl, h->hterms + (size_t)2 * s0 * Dl, 2 * Mp);
+    } else {
+        if (words) HIP_TRY(hipStreamWaitEvent(s, h->ev_hwords, 0));      // the side-stream clear of these words
+        launch_potrf_ext(s, h->H, Mp, NB, 0, ns * Dl, ga.h_stride, h->info + Dl + s0 * Dl, h->dinvH, CHOL_FLOW, nullptr, 0, words, true);
+        launch_h_finish(s, h->H, Mp, ga.h_stride, ns * Dl, h->hterms + (size_t)2 * s0 * Dl);
+    }
+    if (sc.small_side && !x.reduce_launched) { launch_chain_reduce(s, x.ra, h->chain_partial); x.reduce_launched = true; }
+    if (trace_pending && x.trace_on_main) {
+        HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));
+        launch_gram(s, ga, 3);
+        trace_pending = false;
+    }
+    if (x.st) x.st->mark(3);
+    DBG_SYNC(h, "forward: Cholesky(H) + solves");
+    return FFVD_OK;
+}
+
+// the per-chain reductions where nothing ran them early, the join with the side stream, the nll assembly
+static int fwd_finalize(FwdCtx &x) {
+    ffvd_handle *h = x.h;
+    const ffvd_config &c = h->cfg;
+    const ElboSchedule &sc = x.sc;
+    hipStream_t s = x.s;
+    if (!sc.reduce_early) launch_chain_reduce(s, x.ra, h->chain_partial);
+    else if (!x.reduce_done && !x.trace_on_main) HIP_TRY(hipStreamWaitEvent(s, h->ev_join2, 0));
+    FinalizeArgs fa = elbo_finalize_args(h, x.out_dev, sc.gram_route);
+    fa.whitened = (c.grad && h->gw.whitened && sc.gram_route && !sc.lt_rows) ? 1 : 0;      // L^T rows: the slab holds the factor of A itself
+    if (c.dtype == FFVD_F32C) {           // sum_t |F_t|^2 per unit from the projection's fp64 tile sums
+        launch_sum_partials(s, h->sqpart, h->nsq, h->nbatch, h->sqsum);
+        fa.trpart = h->sqsum; fa.ntiles = 1; fa.fsq_from_trpart = 1;
+    } else if (sc.grad_ref)               // the backward pass wants the same per-unit sum (dl/dalpha): all row sums of F^2 of a unit
+        launch_sum_partials(s, h->rowsq, h->ngr * h->Tp, h->nbatch, h->gw.fsq);
+    launch_finalize(s, fa);
+    if (x.st) x.st->mark(4);
+    DBG_SYNC(h, "forward: reductions + finalize");
+    HIP_TRY(hipGetLastError());
+    return FFVD_OK;
+}
+
 static int enqueue_elbo(ffvd_handle *h, double *out_dev, StageTimer *st) {
     if (tiny_selected(h)) return enqueue_tiny(h, out_dev, st, false, h->cfg.S_local);
     StageTimer live{h};
     if (!st && h->timing_on) st = &live;
     if (pipe_selected(h)) return enqueue_elbo_pipe(h, out_dev, st);
     const ffvd_config &c = h->cfg;
-    const int Mp = h->Mp, Tp = h->Tp, Dl = h->Dl, P = h->P;
-    hipStream_t s = h->stream;
     const ffvd_params &p = h->cur;
+    const int Mp = h->Mp, Dl = h->Dl;
     if (st) st->mark(-1);
-    launch_prep_hypers(s, c.kernel_kind, p.Z, c.M, Mp, P, Dl, c.d_begin, p.logvariance, p.loglengthscales,
+    launch_prep_hypers(h->stream, c.kernel_kind, p.Z, c.M, Mp, h->P, Dl, c.d_begin, p.logvariance, p.loglengthscales,
                        h->variance, h->len, h->Zs, h->zz, h->info, Dl + h->nbatch);
-    HyperView hv{h->variance, h->len, h->Zs, h->zz};
-    const ElboSchedule sc = plan_schedule(h);
-    if (!sc.name) return set_error(h, FFVD_EINVAL, "internal: inconsistent schedule flags (plan_schedule)");
-    const bool gram_route = sc.gram_route;
-    // Gram route: nothing of the K_fu build depends on K_uu, so the latency-bound K_uu chain (build, Cholesky with
-    // the L^-T rows, K^-1, log|K|: a handful of workgroups per launch) runs on the side stream.  Schedules, by what
-    // the first pass looks like (DESIGN.md section 5 has the measurements):
-    //   unsplit Gram, large pass (defer_full): main = K_fu build, wait for the K_uu COPY, Gram kernel that also keeps
-    //     its raw tiles, Cholesky(A); side = chain, then the trace partials from the raw tiles; join at finalize.
-    //   split-K Gram, one pass (defer_trace): main = K_fu build, tile pass, wait for the K_uu copy, combine without
-    //     the trace, Cholesky(A); side = chain, trace partials from the split-K partial tiles; join at finalize.
-    //   split-K Gram, several passes (late_join only): the combine pass of the first pass waits for the whole chain.
-    //   small unsplit pass without raw-tile buffer: the chain runs first on the main stream (sk == s).
-    hipStream_t sk = s;
-    // split-K first pass: its tile kernel writes raw partials and needs neither K_uu nor K^-1, so the chain may run
-    // beside the K_fu build AND the tile pass and only has to be back for the combine pass
-    const bool late_join = sc.late_join;
-    const size_t kstride = (size_t)2 * Mp * Mp;
-    const size_t msq = (size_t)Mp * Mp;
-    const bool grad_a = sc.grad_a;
-    const bool grad_ref = sc.grad_ref;     // training in the reference's op order (fp64 or fp32 contractions)
-    // Gram-route training, whitened backward pass (the default): the extension rows of every A-slab are armed with L^T instead of
-    // I, so that the factorisation of A leaves L^T L_A^-T = L_H^-T there (L_H = L^-1 L_A is the factor of H = L^-1 A L^-T) and
-    // y = L_A^-1 c = L_H^-1 W^T c in the b row: everything the whitened backward pass reads, without the two M^3 products per
-    // unit that formed H (0.8 ms at config 2).  DESIGN.md section 7.
-    const bool lt_rows = sc.lt_rows;
-    // ... and the dataflow factorisation reads L^T straight from the factor L (kernels.h, launch_potrf_ext lt_rows): nothing to arm,
-    // 2 x 268 MB less traffic at config 2.  The launch-per-column variants (forced by FFVD_CHOL or by the stall recovery) read the
-    // rows from memory: launch_set_lt_rows in front of them.
-    const bool lt_virtual = sc.lt_virtual;
-    auto project_args = [&](int s0, int ns) { return elbo_project_args(h, hv, s0, ns, gram_route); };
-    auto gram_args = [&](int s0, int ns) { return elbo_gram_args(h, s0, ns, gram_route); };
-    // Gram route: the row b = delta^T K_fu / Q of a pass, from the partial sums its K_fu build left behind (kernels.h ProjectArgs::gpart)
-    auto brow_finish = [&](int s0, int ns) {
-        if (!h->growpart) return;
-        launch_brow_finish(s, h->growpart, Tp / 64, Mp, Dl, c.d_begin, s0 * Dl, ns * Dl, p.log_Q, 1.0, h->H,
-                           (size_t)(c.grad ? 2 * Mp + NB : Mp + NB) * Mp, c.grad ? 2 * Mp : Mp);
-    };
-    auto reduce_args = [&]() { return elbo_reduce_args(h, gram_route); };
-    bool reduce_done = false;
-    // One split-K pass, K_uu chain beside it: at few chains that chain is the critical path (0.54 ms against 0.47 ms of
-    // K_fu build + tile pass at 4 chains), and the only thing the main stream needs from its tail is K^-1 for the trace
-    // partials.  So the combine pass waits for the K_uu copy alone, Cholesky(A) starts at once, and the trace partials
-    // are computed from the same raw partial tiles on the side stream once K^-1 is there.
-    const bool defer_trace = sc.defer_trace;
-    // ... and with the main stream now the critical one, its K_fu build and tile pass are enqueued BEFORE the ~25
-    // launches of the chain (the caller reads the result back every iteration, so each iteration starts on idle streams)
-    const bool main_first = sc.main_first;
-    // Unsplit first pass beside the chain: same idea with the raw tiles written by the Gram kernel itself
-    const bool defer_full = sc.defer_full;
-    const int ns_first = sc.ns_first;
-    const bool kfu_first = sc.kfu_first;     // the first pass's K_fu build goes to the main stream before the chain is enqueued
-    const bool ident_on_side = sc.ident_on_side;
-    bool kuu_on_main = false, linv_done = false, hwords_zeroed = false, ident_early = false;      // launch progress, not schedule
-    bool kinv_done = false;     // K^-1 came out of the chain's dataflow launch (no product launch)
-    // Reference route / explicit-U branch on the projection GEMM (fp64): only the GEMM needs the chain's W = L^-T, the K_fu build
-    // does not -- the chain's dataflow launch goes to the side stream (resident before the build floods the chip, as in the Gram
-    // route's schedule below) and the main stream waits for it in front of the first projection GEMM: config 2 in the reference's
-    // op order 6.31 -> 6.05 ms.  (Config 5 generates K_fu inside its projection kernel: nothing to overlap there.)
-    // LinearK through its rank (h->lrpart, forward of the explicit-U branch): the chain carries Z^T instead of the identity rows
-    const bool zt_rows = sc.zt_rows;
-    const bool ref_side = sc.ref_side;
-    if (ref_side) {
-        sk = h->aux;
-        launch_kuu_build(s, c.kernel_kind, hv, c.M, Mp, P, Dl, c.jitter, h->Kuu, (grad_a || grad_ref) ? h->Kcopy : nullptr, zt_rows);
-        { int rcf = fork_side(h, h->ev_fork, s, sk); if (rcf) return rcf; }
-        potrf_flow_clear(sk, h->dinvK, (int)Dl);
-        HIP_TRY(hipEventRecord(h->ev_go, sk));
-        linv_done = grad_a || grad_ref;
-        launch_potrf_ext(sk, h->Kuu, Mp, zt_rows ? NB : Mp, zt_rows ? 0 : Mp, Dl, kstride, h->info, h->dinvK, CHOL_FLOW,
-                         linv_done ? h->Linv : nullptr, msq, true);
-        HIP_TRY(hipStreamWaitEvent(s, h->ev_go, 0));
-        kuu_on_main = true;          // (built and factorised: chain_rest below adds K^-1 / log|K| where a backward pass wants them)
+    FwdCtx x{};
+    x.h = h; x.out_dev = out_dev; x.st = st;
+    x.sc = plan_schedule(h);
+    if (!x.sc.name) return set_error(h, FFVD_EINVAL, "internal: inconsistent schedule flags (plan_schedule)");
+    x.hv = HyperView{h->variance, h->len, h->Zs, h->zz};
+    x.s = h->stream; x.sk = h->stream;
+    x.msq = (size_t)Mp * Mp; x.kstride = 2 * x.msq;
+    x.ra = elbo_reduce_args(h, x.sc.gram_route);
+    const ElboSchedule &sc = x.sc;
+    int rc;
+    // ---- the K_uu chain: where it runs, what is enqueued around it ----
+    if (sc.ref_side && (rc = fwd_chain_ref_side(x)) != FFVD_OK) return rc;
+    if (sc.side_chain && (rc = fwd_chain_fork(x)) != FFVD_OK) return rc;
+    if (!x.kuu_on_main) {
+        launch_kuu_build(x.sk, c.kernel_kind, x.hv, c.M, Mp, h->P, Dl, c.jitter, h->Kuu,
+                         (sc.gram_route || sc.grad_a || sc.grad_ref) ? h->Kcopy : nullptr, sc.zt_rows, sc.chain_flow_here ? h->dinvK : nullptr);
+        if (sc.defer_trace || (sc.defer_full && x.sk != x.s)) HIP_TRY(hipEventRecord(h->ev_kuu, x.sk));
     }
-    if (sc.side_chain) {
-        sk = h->aux;
-        kuu_on_main = sc.kuu_flow;
-        if (kuu_on_main)
-            launch_kuu_build(s, c.kernel_kind, hv, c.M, Mp, P, Dl, c.jitter, h->Kuu, h->Kcopy);
-        { int rcf = fork_side(h, h->ev_fork, s, sk); if (rcf) return rcf; }
-        if (kuu_on_main) {
-            HIP_TRY(hipEventRecord(h->ev_kuu, s));
-            linv_done = potrf_flow_selected((int)Mp, (int)Dl, CHOL_FLOW);      // L^-1 comes out of the factorisation itself
-            if (linv_done) {
-                // The chain's 64-odd row workgroups (76.8 KB of LDS, 256 VGPRs) must be on the chip BEFORE the K_fu build
-                // floods it with small ones, or they wait for that kernel to drain: the main stream resumes one
-                // cross-queue hop after the clear that sits directly in front of the chain's kernel
-                potrf_flow_clear(sk, h->dinvK, (int)Dl);
-                HIP_TRY(hipEventRecord(h->ev_go, sk));
-            }
-            kinv_done = linv_done && !h->sw.kinv_gram && potrf_flow_forms_inverse((int)Mp, (int)Dl, CHOL_FLOW);
-            launch_potrf_ext(sk, h->Kuu, Mp, Mp, Mp, Dl, kstride, h->info, h->dinvK, CHOL_FLOW, h->Linv, msq, linv_done, false,
-                             kinv_done ? h->Kinv : nullptr, msq);
-            if (linv_done) {
-                launch_chain_reduce(s, reduce_args(), h->chain_partial);      // inputs only; fills the wait below
-                reduce_done = true;
-                if (c.grad && c.branch == FFVD_BRANCH_B && !lt_rows) {
-                    // training: the identity rows that become L_A^-T are re-armed here too (rows the K_fu build and the Gram
-                    // kernel do not touch) instead of between the K_fu build and the Gram kernel
-                    const GramArgs gi = gram_args(0, ns_first);
-                    launch_set_identity(s, h->H, gi.h_stride, Mp, Mp, ns_first * Dl);
-                    ident_early = true;
-                }
-                HIP_TRY(hipStreamWaitEvent(s, h->ev_go, 0));
-                if (c.S_local <= h->cpp) {          // single pass: the words of Cholesky(A) are cleared here, off the main stream
-                    potrf_flow_clear(sk, h->dinvH, h->nbatch);
-                    HIP_TRY(hipEventRecord(h->ev_hwords, sk));      // the factorisation that trusts this clear waits for THIS event
-                    hwords_zeroed = true;
-                }
-            }
-        }
-        if (kfu_first) {
-            if (st) st->mark(0);
-            launch_kfu_build(s, project_args(0, ns_first));
-            brow_finish(0, ns_first);
-            if (st) st->mark(1);
-        }
-        if (main_first) {
-            const GramArgs ga = gram_args(0, c.S_local);
-            launch_gram(s, ga, 1);
-            HIP_TRY(hipEventRecord(h->ev_tiles, s));
-        }
-        // training: the identity rows that become L_A^-T are re-armed on the side stream, ahead of the K_uu build whose
-        // event the main stream waits for anyway (0.05 ms off the critical path at the full batch)
-        if (ident_on_side) {
-            const GramArgs ga = gram_args(0, ns_first);
-            launch_set_identity(sk, h->H, ga.h_stride, Mp, Mp, ns_first * Dl);
-        }
-    }
-    const ReduceArgs ra = reduce_args();
-    const bool reduce_early = sc.reduce_early;
-    // The whole iteration is a handful of workgroups (the reference's own experiment size, FFVD_Main.py:356-369: M = 100, T <= 512):
-    // nothing competes for slots and the side chain IS the critical path -- ONE dataflow launch that also leaves L^-1 and K^-1
-    // instead of six dependent launches, and the per-chain reductions move to the main stream, which has the slack there
-    const bool small_side = sc.small_side;
-    const bool side_late = sc.side_late;
-    // (chain as the dataflow launch on the stream that builds K_uu: the build zeroes its progress words, one launch less)
-    const bool chain_flow_here = sc.chain_flow_here;
-    int chain_rc = FFVD_OK;
-    const bool reduce_on_main = small_side;
-    bool reduce_launched = false, trace_on_main = false;
-    auto chain_rest = [&]() -> int {
-        if (!kuu_on_main) {
-            // chain on the main stream = on the critical path with nothing beside it: the dataflow launch; on the side stream
-            // (beside the K_fu build / tile pass of a small batch) the right-looking launches, whose workgroups come and go
-            const bool chain_flow = chain_flow_here;
-            if (chain_flow && (gram_route || grad_a || grad_ref)) linv_done = true;
-            if (chain_flow && (small_side || side_late) && gram_route && potrf_flow_forms_inverse((int)Mp, (int)Dl, CHOL_FLOW)) kinv_done = true;
-            if (side_late) {
-                // the reductions of the inputs first (they need nothing), then the chain once the tile pass has left the chip
-                if (reduce_early && !reduce_done) { launch_chain_reduce(sk, ra, h->chain_partial); reduce_launched = true; }
-                HIP_TRY(hipStreamWaitEvent(sk, h->ev_tiles, 0));
-            }
-            launch_potrf_ext(sk, h->Kuu, Mp, zt_rows ? NB : Mp, zt_rows ? 0 : Mp, Dl, kstride, h->info, h->dinvK,
-                             chain_flow ? CHOL_FLOW : CHOL_AUTO, linv_done ? h->Linv : nullptr, msq, chain_flow /* words zeroed by the build */,
-                             false, kinv_done ? h->Kinv : nullptr, msq, nullptr, 0, 1, small_side || side_late);
-        }
-        if (gram_route || grad_a || grad_ref) {
-            // K^-1 = L^-T L^-1 (shared by all chains) and log|K|
-            if (!linv_done) launch_transpose(sk, h->Kuu + msq, kstride, h->Linv, msq, Mp, Dl);
-            GramArgs gk{};
-            gk.mode = GRAM_PLAIN; gk.A = h->Linv; gk.a_stride = msq; gk.rows = Mp; gk.with_row = 0; gk.Mp = Mp; gk.Dl = Dl;
-            gk.d_begin = c.d_begin; gk.b0 = 0; gk.nb = Dl; gk.yn_over_batch = 1.0; gk.H = h->Kinv; gk.h_stride = msq;
-            if (kinv_done) {
-                // (the identity-row workgroups of the chain's launch have formed it: kernels.hip, df_inverse_tiles)
-            } else if (c.grad || (kuu_on_main && !h->sw.kinv_gram)) {
-                // the backward pass reads K^-1 everywhere, the Gram kernel only writes lower tiles; and beside the K_fu build
-                // (kuu_on_main: the main stream waits for this product) 256-thread workgroups find a slot where the Gram
-                // kernel's 1024-thread ones wait for the build to drain (0.19 against 0.05 ms)
-                AtbArgs ak{};
-                ak.mode = ATB_PLAIN; ak.A = h->Linv; ak.a_stride = msq; ak.lda = Mp; ak.nA = Mp; ak.B = h->Linv; ak.b_stride = msq;
-                ak.ldb = Mp; ak.nB = Mp; ak.rows = Mp; ak.C = h->Kinv; ak.c_stride = msq; ak.ldc = Mp; ak.nb = Dl; ak.Dl = Dl;
-                ak.k_lower = 1;                                  // L^-1 is lower triangular
-                ak.small_tiles = kuu_on_main ? 1 : 0;
-                launch_atb(sk, ak);
-            } else launch_gram(sk, gk);     // (split-K here was measured slower: 0.42 vs 0.37 ms for the K_uu stage)
-            launch_h_finish(sk, h->Kuu, Mp, kstride, Dl, h->kterms);
-            if (sk != s) HIP_TRY(hipEventRecord(h->ev_join, sk));
-        } else if (ref_side) HIP_TRY(hipEventRecord(h->ev_join, sk));
-        // the per-chain likelihood / transition reductions depend on the inputs only (Gram route: no row sums of F), so
-        // they ride on the side stream behind the K_uu chain and are back long before finalize needs them (kuu_on_main: they
-        // already ran on the main stream while it waited for the chain's kernel to be dispatched)
-        if (reduce_early && !reduce_done && !reduce_on_main && !reduce_launched) {
-            launch_chain_reduce(sk, ra, h->chain_partial);
-            HIP_TRY(hipEventRecord(h->ev_join2, sk));
-        }
-        return FFVD_OK;
-    };
-    if (!kuu_on_main) {
-        launch_kuu_build(sk, c.kernel_kind, hv, c.M, Mp, P, Dl, c.jitter, h->Kuu, (gram_route || grad_a || grad_ref) ? h->Kcopy : nullptr, zt_rows,
-                         chain_flow_here ? h->dinvK : nullptr);
-        if (defer_trace || (defer_full && sk != s)) HIP_TRY(hipEventRecord(h->ev_kuu, sk));
-    }
-    const bool chain_deferred = side_late && defer_full;       // the chain is enqueued behind the first pass's Gram launch (below)
-    if (!chain_deferred && (chain_rc = chain_rest()) != FFVD_OK) return chain_rc;
+    x.chain_deferred = sc.side_late && sc.defer_full;       // the chain is enqueued behind the first pass's Gram launch (fwd_pass_factor)
+    if (!x.chain_deferred && (rc = fwd_chain_rest(x)) != FFVD_OK) return rc;
     DBG_SYNC(h, "forward: K_uu chain");
-    if (st && !kfu_first) st->mark(0);
+    if (st && !sc.kfu_first) st->mark(0);
+    // ---- the passes over the chains: projection / K_fu, Gram, factorisation ----
     for (int s0 = 0; s0 < c.S_local; s0 += h->cpp) {
         const int ns = (s0 + h->cpp <= c.S_local) ? h->cpp : c.S_local - s0;
-        ProjectArgs pa = project_args(s0, ns);
-        if (gram_route) {
-            if (!(kfu_first && s0 == 0)) { launch_kfu_build(s, pa); brow_finish(s0, ns); }
-            if (s0 == 0 && sk != s && !late_join) HIP_TRY(hipStreamWaitEvent(s, defer_full ? h->ev_kuu : h->ev_join, 0));
-        } else if (c.dtype == FFVD_F32C) {
-            if (s0 == 0) launch_linv_f32(s, h->Kuu + msq, kstride, h->Linv32, Mp, Dl);     // L^-1 as the fp32 B operand
-            launch_kfu_build_f32(s, pa, h->Kf32);                     // K(X_combine, Z)           (:240)
-            ProjF32Args pg{};
-            pg.Kf = h->Kf32; pg.kf_stride = (size_t)Tp * Mp; pg.LinvT = h->Linv32; pg.F = h->F32; pg.f_stride = (size_t)Tp * Mp;
-            pg.sqpart = h->sqpart; pg.Tp = Tp; pg.Mp = Mp; pg.Dl = Dl; pg.b0 = s0 * Dl; pg.nb = ns * Dl;
-            launch_proj_gemm_f32(s, pg);                              // tilde_F = Knm Lm^-T, sum F^2  (:242,:255)
-        } else if (h->ngr && c.branch == FFVD_BRANCH_B) {
-            pa.F = h->Kf2;
-            launch_kfu_build(s, pa);                                  // K(X_combine, Z)           (:240)
-            ProjGemmArgs pg{};
-            pg.Kf = h->Kf2; pg.kf_stride = (size_t)Tp * Mp; pg.W = h->Kuu + msq; pg.w_stride = kstride;
-            pg.F = h->F; pg.f_stride = (size_t)Tp * Mp; pg.rowsq = h->rowsq; pg.Tp = Tp; pg.Mp = Mp; pg.Dl = Dl;
-            pg.b0 = s0 * Dl; pg.nb = ns * Dl;
-            pg.gpart = h->growpart; pg.X = p.X; pg.T = c.T; pg.D = c.D; pg.d_begin = c.d_begin;      // delta^T F by 128-row tiles (:247-248)
-            if (ref_side && s0 == 0) HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));                  // W = L^-T from the side stream's chain
-            launch_proj_gemm(s, pg);                                  // tilde_F = Knm Lm^-T, sum F^2  (:242,:255)
-            if (h->growpart)
-                launch_brow_finish(s, h->growpart, (int)((Tp + 127) / 128), Mp, Dl, c.d_begin, s0 * Dl, ns * Dl, p.log_Q, 1.0, h->H,
-                                   (size_t)(c.grad ? 2 * Mp + NB : Mp + NB) * Mp, c.grad ? 2 * Mp : Mp);
-        } else if (h->lrpart) {
-            // explicit-U branch, LinearK, forward only: fmean and sum_j F^2 through the kernel's rank P (no K_fu, no F)
-            if (sk != s && s0 == 0) HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));
-            launch_linear_lowrank(s, pa, h->lrpart);
-        } else if (c.branch == FFVD_BRANCH_A && h->ngr) {
-            // explicit-U branch: K_fu once, then the triangular GEMM with fvar / fmean folded into its epilogue (F unstored)
-            pa.F = h->F + (grad_a ? (size_t)s0 * Dl * Tp * Mp : 0);
-            launch_kfu_build(s, pa);
-            if (ref_side && s0 == 0) HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));                  // W = L^-T from the side stream's chain
-            if (s0 == 0) launch_ucols(s, p.U, c.M, Mp, c.D, c.d_begin, Dl, h->ucolA);
-            ProjGemmArgs pg{};
-            pg.Kf = pa.F; pg.kf_stride = (size_t)Tp * Mp; pg.W = h->Kuu + msq; pg.w_stride = kstride;
-            pg.F = nullptr; pg.f_stride = 0; pg.rowsq = h->rowsq; pg.fmean = h->fmean; pg.u = h->ucolA; pg.u_stride = Mp;
-            pg.Tp = Tp; pg.Mp = Mp; pg.Dl = Dl; pg.b0 = s0 * Dl; pg.nb = ns * Dl;
-            launch_proj_gemm(s, pg);
-        } else {
-            if (grad_a) {                       // (FFVD_FUSED_PROJECT) the backward pass still needs K_fu itself
-                pa.F = h->F;
-                launch_kfu_build(s, pa);
-                pa.F = nullptr;
-            }
-            launch_project(s, pa);
-        }
-        if (st && !(kfu_first && s0 == 0)) st->mark(1);
-        DBG_SYNC(h, "forward: K_fu / projection");
-        if (c.branch == FFVD_BRANCH_B) {
-            GramArgs ga = gram_args(s0, ns);
-            bool trace_pending = false, acopy_done = false;      // acopy_done: the Gram kernel stored the copy of A itself
-            if (lt_rows) {
-                // (armed right in front of the factorisation, when at all: L comes from the K_uu chain)
-            } else if (c.grad && !((ident_on_side || ident_early) && s0 == 0)) launch_set_identity(s, h->H, ga.h_stride, Mp, Mp, ns * Dl);
-            if (s0 == 0 && late_join) {
-                if (!main_first) launch_gram(s, ga, 1);
-                if (defer_trace) {
-                    if (!main_first) HIP_TRY(hipEventRecord(h->ev_tiles, s));
-                    HIP_TRY(hipStreamWaitEvent(s, h->ev_kuu, 0));
-                    ga.trace_mode = 1;
-                    // side late: the trace pass runs long after this one (behind the K_uu chain) -- it reads the summed raw tiles this
-                    // pass leaves in partial 0 instead of all the row ranges again (134 MB at 4 chains: 20-27 us of the iteration's tail)
-                    ga.raw_summed = (side_late || small_side) ? 1 : 0;      // (small side: the trace pass follows on this stream)
-                    launch_gram(s, ga, 2);
-                    if (side_late) HIP_TRY(hipEventRecord(h->ev_tiles, s));      // (the trace pass below waits for THIS record)
-                    trace_pending = true;      // enqueued behind the factorisation: the main stream is the critical one
-                } else {
-                    HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));
-                    launch_gram(s, ga, 2);
-                }
-            } else if (s0 == 0 && defer_full && sk != s) {
-                ga.mode = GRAM_KFU_RAW; ga.part = h->graw; ga.ksplit = 1;
-                if (c.grad) { ga.Hcopy = h->gw.Acopy; ga.hcopy_stride = msq; acopy_done = true; }
-                launch_gram(s, ga);
-                HIP_TRY(hipEventRecord(h->ev_tiles, s));
-                trace_pending = true;
-            } else if (c.dtype == FFVD_F32C) {
-                GramF32Args gf{};
-                gf.F = h->F32; gf.f_stride = (size_t)Tp * Mp; gf.rows = Tp; gf.with_row = 1; gf.brow = c.grad ? 2 * Mp : Mp;
-                gf.X = p.X; gf.log_Q = p.log_Q; gf.T = c.T; gf.D = c.D; gf.Mp = Mp; gf.Dl = Dl; gf.d_begin = c.d_begin;
-                gf.b0 = s0 * Dl; gf.nb = ns * Dl; gf.yn_over_batch = 1.0; gf.H = h->H; gf.h_stride = ga.h_stride;
-                gf.flush = h->gram_flush;
-                launch_gram_f32(s, gf);                               // H = F^T F / Q + I, b = delta^T F / Q  (:246-248)
-            } else {
-                // training: the unsplit Gram kernel stores the symmetric copy of A itself (no copy + symmetrize launches: 0.25 ms)
-                if (c.grad && gram_route && !ga.part) { ga.Hcopy = h->gw.Acopy; ga.hcopy_stride = msq; acopy_done = true; }
-                launch_gram(s, ga);
-            }
-            if (st) st->mark(2);
-            DBG_SYNC(h, "forward: Gram");
-            if (trace_pending && small_side) {
-                // tiny iteration: the trace partials wait for the chain on the MAIN stream, behind Cholesky(A) -- one cross-stream
-                // hop (chain -> here) instead of two (tile pass -> side stream, side stream -> finalize)
-                trace_on_main = true;
-            } else if (trace_pending) {
-                if (chain_deferred && s0 == 0 && (chain_rc = chain_rest()) != FFVD_OK) return chain_rc;      // (waits for ev_tiles itself)
-                // trace partials from the raw tiles, on the side stream (K^-1 precedes in its order).  Enqueued AHEAD of the
-                // factorisation: that is one launch whose row workgroups hold every slot of the chip for most of its length,
-                // and a kernel that arrives behind it only starts when they leave (finalize then waited 0.26 ms for this pass)
-                HIP_TRY(hipStreamWaitEvent(sk, h->ev_tiles, 0));
-                launch_gram(sk, ga, 3);
-                HIP_TRY(hipEventRecord(h->ev_join2, sk));                 // supersedes the record after the reductions
-                trace_pending = false;
-            }
-            if (c.grad) {       // keep A = K_uu + K_uf K_fu / Q: the factorisation overwrites it in place
-                if (!acopy_done)
-                    HIP_TRY(hipMemcpy2DAsync(h->gw.Acopy, msq * sizeof(double), h->H, ga.h_stride * sizeof(double),
-                                             msq * sizeof(double), (size_t)ns * Dl, hipMemcpyDeviceToDevice, s));
-                if (lt_rows) {
-                    if (sk != s && s0 == 0) HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));       // L (and W, L^-1 for the backward pass) come from the K_uu chain
-                    if (!lt_virtual) launch_set_lt_rows(s, h->Kuu, kstride, Dl, h->H, ga.h_stride, Mp, Mp, ns * Dl);
-                } else if (h->gw.whitened && gram_route) {
-                    // H = W^T A W (W = L^-T of K_uu) replaces A in the slab, b = W^T c replaces c: the factorisation, the
-                    // explicit inverse and everything the backward pass derives from them then live in the whitened
-                    // variables, where cond(H) is about 1e4 instead of the 1e7 of A
-                    ffvd_handle::GradWs &g = h->gw;
-                    const int nbp = ns * Dl;
-                    const int small = h->sw.atb128 ? 0 : 1;
-                    if (sk != s) HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));       // W and L^-1 come from the K_uu chain
-                    launch_symmetrize(s, g.Acopy, Mp, nbp);                            // (the saved copy holds the lower triangle)
-                    AtbArgs t1{};
-                    t1.mode = ATB_PLAIN; t1.A = g.Acopy; t1.a_stride = msq; t1.lda = Mp; t1.nA = Mp;
-                    t1.B = h->Kuu + msq; t1.b_stride = kstride; t1.ldb = Mp; t1.nB = Mp; t1.b_per_dim = 1; t1.rows = Mp;
-                    t1.C = g.T1; t1.c_stride = msq; t1.ldc = Mp; t1.nb = nbp; t1.Dl = Dl; t1.krange = 8; t1.small_tiles = small;      // W upper triangular
-                    launch_atb(s, t1);                                                  // T1 = A W
-                    AtbArgs t2{};
-                    t2.mode = ATB_PLAIN; t2.A = h->Kuu + msq; t2.a_stride = kstride; t2.lda = Mp; t2.nA = Mp; t2.a_per_dim = 1;
-                    t2.B = g.T1; t2.b_stride = msq; t2.ldb = Mp; t2.nB = Mp; t2.rows = Mp;
-                    t2.C = h->H; t2.c_stride = ga.h_stride; t2.ldc = Mp; t2.nb = nbp; t2.Dl = Dl; t2.krange = 4; t2.sym = 1; t2.small_tiles = small;
-                    launch_atb(s, t2);                                                  // H = W^T T1 into rows [0, Mp)
-                    launch_matvec(s, h->Linv, msq, h->H + 2 * msq, ga.h_stride, Mp, g.bw, 1, Mp, Mp, nbp, Dl);   // b = W^T c
-                    HIP_TRY(hipMemcpy2DAsync(h->H + 2 * msq, ga.h_stride * sizeof(double), g.bw, (size_t)Mp * sizeof(double),
-                                             (size_t)Mp * sizeof(double), (size_t)nbp, hipMemcpyDeviceToDevice, s));
-                }
-                if (hwords_zeroed && s0 == 0) HIP_TRY(hipStreamWaitEvent(s, h->ev_hwords, 0));      // the side-stream clear of these words
-                launch_potrf_ext(s, h->H, Mp, Mp + NB, Mp, ns * Dl, ga.h_stride, h->info + Dl + s0 * Dl, h->dinvH, CHOL_FLOW, nullptr, 0,
-                                 hwords_zeroed && s0 == 0, true, nullptr, 0, lt_virtual ? h->Kuu : nullptr, kstride, Dl);
-                launch_h_finish(s, h->H, Mp, ga.h_stride, ns * Dl, h->hterms + (size_t)2 * s0 * Dl, 2 * Mp);
-            } else {
-                if (hwords_zeroed && s0 == 0) HIP_TRY(hipStreamWaitEvent(s, h->ev_hwords, 0));      // the side-stream clear of these words
-                launch_potrf_ext(s, h->H, Mp, NB, 0, ns * Dl, ga.h_stride, h->info + Dl + s0 * Dl, h->dinvH, CHOL_FLOW, nullptr, 0,
-                                 hwords_zeroed && s0 == 0, true);
-                launch_h_finish(s, h->H, Mp, ga.h_stride, ns * Dl, h->hterms + (size_t)2 * s0 * Dl);
-            }
-            if (reduce_on_main && !reduce_launched) { launch_chain_reduce(s, ra, h->chain_partial); reduce_launched = true; }
-            if (trace_pending && trace_on_main) {
-                HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));
-                launch_gram(s, ga, 3);
-                trace_pending = false;
-            }
-            if (st) st->mark(3);
-            DBG_SYNC(h, "forward: Cholesky(H) + solves");
-        }
+        if ((rc = fwd_pass_project(x, s0, ns)) != FFVD_OK) return rc;
+        if (c.branch != FFVD_BRANCH_B) continue;
+        GramArgs ga = x.gram_args(s0, ns);
+        bool trace_pending = false, acopy_done = false;      // acopy_done: the Gram kernel stored the copy of A itself
+        if ((rc = fwd_pass_gram(x, s0, ns, ga, trace_pending, acopy_done)) != FFVD_OK) return rc;
+        if ((rc = fwd_pass_factor(x, s0, ns, ga, trace_pending, acopy_done)) != FFVD_OK) return rc;
     }
-    if (!reduce_early) launch_chain_reduce(s, ra, h->chain_partial);
-    else if (!reduce_done && !trace_on_main) HIP_TRY(hipStreamWaitEvent(s, h->ev_join2, 0));
-    FinalizeArgs fa = elbo_finalize_args(h, out_dev, gram_route);
-    fa.whitened = (c.grad && h->gw.whitened && gram_route && !lt_rows) ? 1 : 0;      // L^T rows: the slab holds the factor of A itself
-    if (c.dtype == FFVD_F32C) {           // sum_t |F_t|^2 per unit from the projection's fp64 tile sums
-        launch_sum_partials(s, h->sqpart, h->nsq, h->nbatch, h->sqsum);
-        fa.trpart = h->sqsum; fa.ntiles = 1; fa.fsq_from_trpart = 1;
-    } else if (grad_ref)                  // the backward pass wants the same per-unit sum (dl/dalpha): all row sums of F^2 of a unit
-        launch_sum_partials(s, h->rowsq, h->ngr * Tp, h->nbatch, h->gw.fsq);
-    launch_finalize(s, fa);
-    if (st) st->mark(4);
-    DBG_SYNC(h, "forward: reductions + finalize");
-    HIP_TRY(hipGetLastError());
-    return FFVD_OK;
+    return fwd_finalize(x);
 }
 
 static int ready(ffvd_handle *h, const char *who) {
