@@ -90,6 +90,7 @@ _SIGNATURES = {
     "ffvd_stall_recoveries": (C.c_int, [C.c_void_p]),
     "ffvd_stall_hold": (C.c_int, [C.c_void_p]),
     "ffvd_op_release_cache": (C.c_int, []),
+    "ffvd_op_rollout_fallbacks": (C.c_int, []),
     "ffvd_single_launch": (C.c_int, [C.c_void_p]),
     "ffvd_schedule_name": (C.c_char_p, [C.c_void_p]),
     "ffvd_get_stream": (C.c_void_p, [C.c_void_p]),

@@ -20,6 +20,7 @@
 using namespace ffvd;
 
 static thread_local std::string g_last_error;
+static int g_rollout_fallbacks = 0;     // ffvd_op_rollout calls of this process that fell back from the resident loop to the per-step launches
 
 #define HIP_TRY(expr)                                                                         \
     do {                                                                                      \
@@ -2952,6 +2953,8 @@ extern "C" int ffvd_op_sghmc_step(double *theta, const double *grad, double *xi,
     return FFVD_OK;
 }
 
+extern "C" int ffvd_op_rollout_fallbacks(void) { return g_rollout_fallbacks; }
+
 extern "C" int ffvd_op_rollout(int kind, const double *Lm_inverse_seq, const double *Z, int M, int P, int D,
                                const double *logvariance, const double *loglengthscales, const double *f,
                                const double *q_sqrt, const double *x_last, int R, const double *ctrl, int C, int steps,
@@ -3074,6 +3077,14 @@ extern "C" int ffvd_op_rollout(int kind, const double *Lm_inverse_seq, const dou
             HIP_TRY(hipMemcpyAsync(hw, words, sizeof hw, hipMemcpyDeviceToHost, sc.stream));
             HIP_TRY(hipStreamSynchronize(sc.stream));
             resident_done = hw[1] == 0;          // (a wait gave up: the per-step launches below, from the initial rows)
+            if (!resident_done) {
+                // the two forms agree to 1e-9, not bit for bit, so a fallback decided by run-time contention must not be
+                // silent -- counted (ffvd_op_rollout_fallbacks) and left as a warning for ffvd_last_error(NULL)
+                ++g_rollout_fallbacks;
+                g_last_error = "warning: ffvd_op_rollout: the resident-operand loop gave up on a bounded wait (its workgroups were not all "
+                               "resident: another tenant on the GPU?); the call was completed by the per-step launches, whose results "
+                               "agree to 1e-9 but are not bit-identical (FFVD_STEP_LOOP=0 selects them always)";
+            }
             if (dst && steps > 10) {             // tools: where step 10 spent its time (us since its start), slab 0 (the updater) and the last slab of dim 0
                 long long hs[32];
                 HIP_TRY(hipMemcpy(hs, dst, sizeof hs, hipMemcpyDeviceToHost));

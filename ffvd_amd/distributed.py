@@ -99,6 +99,8 @@ def all_reduce_grads(grads, mode="chains", device=None, group=None):
 
 
 _RENDEZVOUS_GENERATION = [0]      # communicators this process has formed through a rendezvous directory
+import time as _time
+_PROCESS_SEEN = _time.time()      # (file rendezvous: ids written before this process started belong to an earlier run)
 
 
 def exchange_unique_id(make_id, rank, world, rendezvous_dir=None, timeout_s=120.0, tag=None, cleanup_s=None):
@@ -153,9 +155,19 @@ def exchange_unique_id(make_id, rank, world, rendezvous_dir=None, timeout_s=120.
                 raise RuntimeError(f"RCCL unique id could not be created on rank 0: {err}")
             return blob
         t0 = time.monotonic()
-        while not os.path.exists(path):
+        born = _PROCESS_SEEN - float(os.environ.get("FFVD_RENDEZVOUS_SLACK_S", "2"))
+        while True:
+            # (consecutive runs with the same nonce -- MASTER_PORT 29500, run id 'none' -- share the file name; a file left by
+            #  an EARLIER run was written before this process existed: a reader ignores anything older than the moment this module
+            #  was imported (minus FFVD_RENDEZVOUS_SLACK_S, default 2 s, for ranks that start a little apart) and keeps polling for
+            #  the file rank 0 of ITS job writes)
+            try:
+                if os.path.getmtime(path) >= born:
+                    break
+            except OSError:
+                pass
             if time.monotonic() - t0 > timeout_s:
-                raise TimeoutError(f"rank {rank}: no RCCL id at {path} after {timeout_s:.0f} s")
+                raise TimeoutError(f"rank {rank}: no fresh RCCL id at {path} after {timeout_s:.0f} s")
             time.sleep(0.01)
         with open(path, "rb") as f:
             data = f.read()
@@ -184,7 +196,20 @@ def tshard_nll_and_grad(engine, meta, t_begin, reduce_host, native=False):
         sums, g = engine.elbo_tshard_grad(S_total=S)
     else:
         t = np.asarray(reduce_host(engine.tshard_local()))
-        sums, g = engine.tshard_grad_fetch(np.asarray(reduce_host(engine.tshard_finish_grad(t, S_total=S))))
+        # (a finish that fails on THIS rank -- a second stall, a HIP error -- must still take part in the reduce the other
+        #  ranks are entering, with a NaN-headed block like the native path's, and raise afterwards: they then fail too instead of waiting)
+        failure = None
+        try:
+            block = engine.tshard_finish_grad(t, S_total=S)
+        except Exception as exc:        # noqa: BLE001 -- re-raised below, after the collective
+            failure = exc
+            block = np.full(int(engine.lib.ffvd_train_exchange_count(engine._h)), np.nan) if hasattr(engine, "lib") else None
+            if block is None:
+                raise
+        block = np.asarray(reduce_host(block))
+        if failure is not None:
+            raise failure               # (the other ranks raise in tshard_grad_fetch on the NaN-headed block: nobody enters the dX exchange)
+        sums, g = engine.tshard_grad_fetch(block)
     full = np.zeros((S, meta["T"] + 1, meta["D"]))
     full[:, t_begin: t_begin + g["X"].shape[1]] = g["X"]
     g = dict(g, X=np.asarray(reduce_host(full)).reshape(full.shape))

@@ -418,6 +418,11 @@ int  ffvd_op_rollout(int kind, const double *Lm_inverse_seq, const double *Z, in
                      const double *logvariance, const double *loglengthscales, const double *f, const double *q_sqrt,
                      const double *x_last, int R, const double *ctrl, int C, int steps, const double *log_Q,
                      const double *eps, double *predict_x, double *predict_var);
+/* How many ffvd_op_rollout calls of this process completed on the per-step launches because the resident-operand loop (the default
+ * up to 64 rollouts, M <= 512) gave up on a bounded wait -- its workgroups must all be resident, a co-tenant can prevent that.  The
+ * two forms agree to 1e-9 but not bit for bit: a seeded rollout is bit-reproducible only while this counter stands still (or with
+ * FFVD_STEP_LOOP=0, which always takes the launches).  The call that fell back also leaves a warning in ffvd_last_error(NULL). */
+int  ffvd_op_rollout_fallbacks(void);
 
 /* One particle-Gibbs sweep over the latent trajectory: the INTENT of BaseModel.PG_for_X_speedup (base_model.py:78-138;
  * as written that op never updates X -- discarded TensorArray.write results (:115), an assign that is never run (:137) --

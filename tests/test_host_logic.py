@@ -441,6 +441,17 @@ def test_file_rendezvous_ignores_stale_ids_and_forwards_failures(tmp_path, monke
     assert os.path.exists(os.path.join(d, "rccl_unique_id.29777.run7"))
     time.sleep(0.6)
     assert not os.path.exists(os.path.join(d, "rccl_unique_id.29777.run7"))                          # removed by rank 0's timer
+    # two consecutive runs with the SAME nonce (MASTER_PORT 29500 twice) share the file name; an id written before this
+    # process existed belongs to the earlier run: a reader ignores it and keeps polling for its own job's file
+    stale = os.path.join(d, "rccl_unique_id.29777.again")
+    with open(stale, "wb") as f:
+        f.write(b"OK" + other)
+    old_time = dist_mod._PROCESS_SEEN - 60.0
+    os.utime(stale, (old_time, old_time))
+    with pytest.raises(TimeoutError, match="fresh"):
+        dist_mod.exchange_unique_id(None, 1, 2, rendezvous_dir=d, tag="again", timeout_s=0.05)
+    assert dist_mod.exchange_unique_id(lambda: good, 0, 2, rendezvous_dir=d, tag="again") == good      # rank 0 of THIS job replaces it
+    assert dist_mod.exchange_unique_id(None, 1, 2, rendezvous_dir=d, tag="again") == good
 
 
 ADAM_WORKER = r'''
