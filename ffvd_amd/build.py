@@ -149,6 +149,8 @@ VARIANTS = {
     "tinynohelp": ("tiny.hip", ["-DFFVD_TINY_NO_HEAD_HELP"]),
     # A/B build: the blocked Cholesky of the one-launch iteration with tile solves behind every pivot chain (round 4, first form)
     "tinytiles": ("tiny.hip", ["-DTINY_CHOL_ROWS=0"]),
+    # the resident rollout loop with release / acquire fences at its hand-offs (inside the HIP memory model; tests compare both forms)
+    "rrfenced": ("loops.hip", ["-DFFVD_RR_FENCED"]),
 }
 
 

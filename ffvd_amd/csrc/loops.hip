@@ -178,6 +178,10 @@ __device__ __forceinline__ void rr_store(double *p, double v) { __hip_atomic_sto
 __device__ __forceinline__ double rr_load(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 constexpr long long RR_SPIN_TICKS = 10000000LL;         // 0.1 s of the 100 MHz wall clock: a step is 10-25 us; a wait this long means that the
                                                          // launch's workgroups are not all on the chip (another tenant): give up, the caller runs the launches
+// -DFFVD_RR_FENCED (build variant `rrfenced`): the same hand-offs INSIDE the HIP memory model -- an agent-scope release in
+// front of every count, an agent-scope acquire behind every satisfied wait (what the first measurement of this form used: 4-5 us per
+// hand-off instead of 2-3).  tests/test_gpu_ops.py runs the oracle-parity rollout test on both builds; the product build's
+// fence-free form is verified by that comparison and by the soak only -- it rests on gfx942 / gfx950 semantics (the #error above).
 __device__ __forceinline__ bool rr_wait(int *word, const int need, int *abort_w, int *slot) {
     if (threadIdx.x == 0) {
         int ok = 1;
@@ -197,6 +201,10 @@ __device__ __forceinline__ bool rr_wait(int *word, const int need, int *abort_w,
                 }
             }
         }
+#ifdef FFVD_RR_FENCED
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
         *slot = ok;
     }
     __syncthreads();
@@ -207,7 +215,13 @@ __device__ __forceinline__ bool rr_wait(int *word, const int need, int *abort_w,
 __device__ __forceinline__ void rr_arrive(int *word) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) {
+#ifdef FFVD_RR_FENCED
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        __hip_atomic_fetch_add(word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 constexpr int RR_RED = 4 * 2 * 4 * 64;            // doubles: accumulators of four wavefronts, two right-hand sides
 constexpr int RR_PF = 16;                         // A fragments in flight per lane

@@ -354,6 +354,54 @@ def test_rollout_matches_oracle(name, R, steps, with_q):
     np.testing.assert_array_equal(px2[0], px2[-1])
 
 
+_RR_SCRIPT = r"""
+import sys
+import numpy as np
+from ffvd_amd import synthetic, _lib, conditionals_multi_output as cmo
+from ffvd_amd.prediction import rollout
+from ffvd_amd.kernels import SquaredExponential
+params, Y, c, meta = synthetic.make_named("small")
+D, C, T = meta["D"], meta["C"], meta["T"]
+X = params["X"][0]
+Q = np.exp(params["log_Q"])
+kern = [SquaredExponential(D + C, variance=np.exp(params["logvariance"][d]), lengthscales=np.exp(params["loglengthscales"][d])) for d in range(D)]
+rng = np.random.default_rng(5)
+R, steps = 24, 40
+ctrl = np.concatenate((c, rng.standard_normal((steps, C))))
+eps = rng.standard_normal((steps, R, D))
+xc = np.concatenate((X[:-1], c), axis=1)
+Lg = cmo.kernel_pre_cal(params["Z"], kern)
+Ug, Hg = cmo.collapse_u_mean_after_kernel_precalculation(Lg, xc, X, params["Z"], kern, Q)
+px, pv = rollout(Lg, params["Z"], kern, Ug, Hg, X[-1], ctrl, T, steps, Q, eps)
+px2, pv2 = rollout(Lg, params["Z"], kern, Ug, Hg, X[-1], ctrl, T, steps, Q, eps)
+assert np.array_equal(px, px2) and np.array_equal(pv, pv2)
+print("FALLBACKS", int(_lib.load().ffvd_op_rollout_fallbacks()))
+np.savez(sys.argv[1], px=px, pv=pv)
+"""
+
+
+def test_rollout_resident_loop_fenced_build_agrees(tmp_path):
+    """the resident rollout loop's hand-offs carry no fences (agent-scope write-through stores and loads, gfx942 / gfx950
+    semantics).  The build variant `rrfenced` puts an agent-scope release in front of every count and an acquire behind every wait --
+    the construction the HIP memory model prescribes; the same seeded rollout through both builds must give the same bits (the
+    fences change when data becomes visible, never what is computed), and neither may fall back to the per-step launches."""
+    import subprocess
+    import sys
+    from ffvd_amd import build as fb
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for name, lib in (("product", fb.build()), ("rrfenced", fb.build_variant("rrfenced"))):
+        env = dict(os.environ, FFVD_LIB=lib, PYTHONPATH=root)
+        env.pop("FFVD_STEP_LOOP", None)
+        path = str(tmp_path / f"{name}.npz")
+        out = subprocess.run([sys.executable, "-c", _RR_SCRIPT, path], env=env, capture_output=True, text=True, timeout=200)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert "FALLBACKS 0" in out.stdout, out.stdout
+        outs[name] = np.load(path)
+    np.testing.assert_array_equal(outs["product"]["px"], outs["rrfenced"]["px"])
+    np.testing.assert_array_equal(outs["product"]["pv"], outs["rrfenced"]["pv"])
+
+
 def test_rollout_argument_errors():
     from ffvd_amd.prediction import rollout
     from ffvd_amd.kernels import SquaredExponential
