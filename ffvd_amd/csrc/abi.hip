@@ -49,6 +49,8 @@ struct ffvd_handle {
     hipStream_t aux = nullptr;          // side stream: the K_uu chain runs beside the K_fu build (Gram route)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_kuu = nullptr, ev_tiles = nullptr, ev_go = nullptr;
     hipEvent_t ev_hwords = nullptr;     // recorded right behind a side-stream clear of Cholesky(A)'s progress words: the launch that trusts the clear waits for IT
+    hipEvent_t ev_prior = nullptr;      // recorded behind an early prior-sums launch on the side stream (fwd_prior_sums)
+    double *prior_sums = nullptr;       // [16] the ten parameter-only sums of the nll assembly, formed early in the iteration
     std::string err;
     std::vector<void *> allocs;
     int64_t ws_bytes = 0;
@@ -71,6 +73,7 @@ struct ffvd_handle {
         bool tiny_xcd = true;       // FFVD_TINY_NO_XCD=1: the one-launch iteration with role-major workgroup ids instead of a unit's workgroups on ONE XCD
         bool no_tiny = false;       // FFVD_NO_TINY=1: the multi-kernel schedule also at the reference's own experiment size (rounds 1-3)
         bool no_tiny_a = false;     // FFVD_NO_TINY_A=1: ... for the explicit-U branch only (rounds 1-4)
+        bool no_early_priors = false;   // FFVD_NO_EARLY_PRIORS=1: the parameter-only sums inside the finalize launch at the iteration's tail (rounds 1-4)
     } sw;
     // resident parameters / data (handle-owned copies)
     double *X = nullptr, *Z = nullptr, *U = nullptr, *logvar = nullptr, *loglen = nullptr, *logQ = nullptr;
@@ -217,6 +220,7 @@ extern "C" int ffvd_destroy(ffvd_handle *h) {
     if (h->ev_tiles) hipEventDestroy(h->ev_tiles);
     if (h->ev_go) hipEventDestroy(h->ev_go);
     if (h->ev_hwords) hipEventDestroy(h->ev_hwords);
+    if (h->ev_prior) hipEventDestroy(h->ev_prior);
     for (hipEvent_t e : h->pipe_evB) hipEventDestroy(e);
     for (hipEvent_t e : h->pipe_evG) hipEventDestroy(e);
     if (h->pipe_evC) hipEventDestroy(h->pipe_evC);
@@ -239,7 +243,8 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
         w.kuu_flow = !on("FFVD_NO_KUU_FLOW");   w.kinv_gram = on("FFVD_KINV_GRAM");   w.chain_rl = on("FFVD_CHAIN_RL");
         w.atb128 = on("FFVD_ATB128");                 w.grad_serial = on("FFVD_GRAD_SERIAL");
         w.debug_sync = on("FFVD_DEBUG_SYNC");
-        w.no_tiny = on("FFVD_NO_TINY");               w.no_tiny_a = on("FFVD_NO_TINY_A");               w.tiny_xcd = !on("FFVD_TINY_NO_XCD");
+        w.no_tiny = on("FFVD_NO_TINY");               w.no_tiny_a = on("FFVD_NO_TINY_A");
+        w.no_early_priors = on("FFVD_NO_EARLY_PRIORS");               w.tiny_xcd = !on("FFVD_TINY_NO_XCD");
         if (const char *e = getenv("FFVD_DEBUG_SIDE_DELAY_US")) w.side_delay_us = atoi(e);
         if (const char *e = getenv("FFVD_DEBUG_MAIN_DELAY_US")) w.main_delay_us = atoi(e);
     }
@@ -275,6 +280,8 @@ static int create_impl(const ffvd_config *cfg, ffvd_handle *h) {
     HIP_TRY(hipEventCreateWithFlags(&h->ev_tiles, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_go, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_hwords, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_prior, hipEventDisableTiming));
+    HIP_TRY(dev_alloc(h, &h->prior_sums, 16));
     HIP_TRY(dev_alloc(h, &h->X, (size_t)c.S_local * (c.T + 1) * c.D));
     HIP_TRY(dev_alloc(h, &h->Z, (size_t)c.M * P));
     HIP_TRY(dev_alloc(h, &h->U, (size_t)c.M * c.D));
@@ -1008,6 +1015,7 @@ struct FwdCtx {
     bool ident_early = false;       // training: the identity rows of the first pass were re-armed early on the main stream
     bool reduce_done = false, reduce_launched = false, trace_on_main = false;
     bool chain_deferred = false;    // the chain is enqueued behind the first pass's Gram launch
+    int prior_early = 0;            // the parameter-only sums of the assembly were formed early: 1 on the main stream, 2 on the side stream (ev_prior)
 
     ProjectArgs project_args(int s0, int ns) const { return elbo_project_args(h, hv, s0, ns, sc.gram_route); }
     GramArgs gram_args(int s0, int ns) const { return elbo_gram_args(h, s0, ns, sc.gram_route); }
@@ -1019,6 +1027,22 @@ struct FwdCtx {
                            elbo_h_stride(h), c.grad ? 2 * h->Mp : h->Mp);
     }
 };
+
+// The ten parameter-only sums of the nll assembly (priors, log R, log sqrt Q: finalize_priors) are a function of the parameters alone:
+// formed EARLY they leave the finalize launch at the iteration's tail -- one workgroup, a chain of dependent loads -- with the
+// per-chain assembly only (19 -> 9 us of every forward iteration's tail; the same code, the same bits).  Where: on the main stream
+// inside its wait for the chain's kernel (full-batch and projection-route schedules), or as the side stream's first launch where
+// that stream idles at the start (few-chain schedules); schedules without a slack window keep them in the finalize launch.
+static int fwd_prior_sums(FwdCtx &x, hipStream_t stream) {
+    ffvd_handle *h = x.h;
+    if (h->sw.no_early_priors || x.prior_early) return FFVD_OK;
+    launch_prior_sums(stream, elbo_finalize_args(h, x.out_dev, x.sc.gram_route), h->prior_sums);
+    if (stream != x.s) {
+        HIP_TRY(hipEventRecord(h->ev_prior, stream));
+        x.prior_early = 2;
+    } else x.prior_early = 1;
+    return FFVD_OK;
+}
 
 // Projection route / explicit-U branch on the projection GEMM (fp64): only the GEMM needs the chain's W = L^-T, the K_fu build does
 // not -- the chain's dataflow launch goes to the side stream (resident before the build floods the chip) and the main stream waits
@@ -1037,6 +1061,7 @@ static int fwd_chain_ref_side(FwdCtx &x) {
     x.linv_done = wants_linv;
     launch_potrf_ext(x.sk, h->Kuu, Mp, zt_rows ? NB : Mp, zt_rows ? 0 : Mp, Dl, x.kstride, h->info, h->dinvK, CHOL_FLOW,
                      x.linv_done ? h->Linv : nullptr, x.msq, true);
+    { int rcp = fwd_prior_sums(x, x.s); if (rcp) return rcp; }      // (fills the main stream's wait below)
     HIP_TRY(hipStreamWaitEvent(x.s, h->ev_go, 0));
     x.kuu_on_main = true;          // (built and factorised: fwd_chain_rest adds K^-1 / log|K| where a backward pass wants them)
     return FFVD_OK;
@@ -1058,6 +1083,7 @@ static int fwd_chain_fork(FwdCtx &x) {
     if (x.kuu_on_main)
         launch_kuu_build(s, c.kernel_kind, x.hv, c.M, Mp, h->P, Dl, c.jitter, h->Kuu, h->Kcopy);
     { int rcf = fork_side(h, h->ev_fork, s, sk); if (rcf) return rcf; }
+    if (!x.kuu_on_main && !sc.small_side) { int rcp = fwd_prior_sums(x, sk); if (rcp) return rcp; }      // (the side stream idles here; small side: its chain is the critical path)
     if (x.kuu_on_main) {
         HIP_TRY(hipEventRecord(h->ev_kuu, s));
         x.linv_done = potrf_flow_selected(Mp, Dl, CHOL_FLOW);      // L^-1 comes out of the factorisation itself
@@ -1074,6 +1100,7 @@ static int fwd_chain_fork(FwdCtx &x) {
         if (x.linv_done) {
             launch_chain_reduce(s, x.ra, h->chain_partial);      // inputs only; fills the wait below
             x.reduce_done = true;
+            { int rcp = fwd_prior_sums(x, s); if (rcp) return rcp; }      // (likewise)
             if (c.grad && c.branch == FFVD_BRANCH_B && !sc.lt_rows) {
                 // training: the identity rows that become L_A^-T are re-armed here too (rows the K_fu build and the Gram
                 // kernel do not touch) instead of between the K_fu build and the Gram kernel
@@ -1372,6 +1399,10 @@ static int fwd_finalize(FwdCtx &x) {
     if (!sc.reduce_early) launch_chain_reduce(s, x.ra, h->chain_partial);
     else if (!x.reduce_done && !x.trace_on_main) HIP_TRY(hipStreamWaitEvent(s, h->ev_join2, 0));
     FinalizeArgs fa = elbo_finalize_args(h, x.out_dev, sc.gram_route);
+    if (x.prior_early) {
+        if (x.prior_early == 2) HIP_TRY(hipStreamWaitEvent(s, h->ev_prior, 0));
+        fa.prior_sums = h->prior_sums;
+    }
     fa.whitened = (c.grad && h->gw.whitened && sc.gram_route && !sc.lt_rows) ? 1 : 0;      // L^T rows: the slab holds the factor of A itself
     if (c.dtype == FFVD_F32C) {           // sum_t |F_t|^2 per unit from the projection's fp64 tile sums
         launch_sum_partials(s, h->sqpart, h->nsq, h->nbatch, h->sqsum);

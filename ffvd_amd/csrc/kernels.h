@@ -234,11 +234,15 @@ struct FinalizeArgs {
     int fsq_from_trpart;           // route 0, fp32-contraction path: trpart[S*Dl][ntiles] = sum_t |F_t|^2 (no row sums)
     double *chain_nll;             // [S]
     double *out_terms;             // [8]
+    const double *prior_sums;      // optional [10]: the parameter-only sums of the assembly (finalize_priors), formed earlier in the iteration by
+                                   //   launch_prior_sums -- the finalize launch at the iteration's tail then only assembles
     const int32_t *info;           // optional: the iteration's factorisation flags ([ninfo]: K_uu per local dim, then one per unit).  Any
     int ninfo;                     //   non-zero flag (bad pivot, or -1: a dataflow launch gave up on a bounded wait and left finite garbage)
                                    //   turns the seven sums into NaN, so that an all-reduce carries the failure to EVERY rank
 };
 void launch_finalize(hipStream_t stream, const FinalizeArgs &a);
+// the ten parameter-only sums of the nll assembly (priors, log R, log sqrt Q) into out[10]: a function of the parameters alone
+void launch_prior_sums(hipStream_t stream, const FinalizeArgs &a, double *out);
 
 // conditional() epilogue: mean[n][d] = sum_g fmean, var[n][d] = Kdiag(x_n) - sum_g rowsq  (N x D outputs)
 void launch_conditional_finish(hipStream_t stream, int kind, const double *x, int N, int P, const double *variance,

@@ -3406,7 +3406,23 @@ void launch_get_rand(hipStream_t stream, const double *mean, const double *var, 
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
     __shared__ double scratch[4][10];
-    finalize_body<256>(a, scratch);
+    if (a.prior_sums) {               // formed earlier in the iteration by the same code (prior_sums_kernel): the same bits
+        double sm[10];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) sm[i] = a.prior_sums[i];
+        finalize_assemble<256>(a, scratch, sm);
+    } else finalize_body<256>(a, scratch);
+}
+__global__ __launch_bounds__(256) void prior_sums_kernel(FinalizeArgs a, double *out) {
+    __shared__ double scratch[4][10];
+    double sm[10];
+    finalize_priors<256>(a, scratch, sm);
+#pragma unroll
+    for (int i = 0; i < 10; ++i)
+        if ((int)threadIdx.x == i) out[i] = sm[i];
+}
+void launch_prior_sums(hipStream_t stream, const FinalizeArgs &a, double *out) {
+    hipLaunchKernelGGL(prior_sums_kernel, dim3(1), dim3(256), 0, stream, a, out);
 }
 void launch_finalize(hipStream_t stream, const FinalizeArgs &a) {
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, stream, a);
