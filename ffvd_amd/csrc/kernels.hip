@@ -1228,6 +1228,7 @@ struct DfArgs {
     size_t kinv_stride;//   the identity-row workgroups once their rows are complete (df_inverse_tiles)
     int defer_ext;     // block order: identity-structured rows of all groups behind the main rows of all groups (potrf_df_kernel)
     int kinv_help;     // (with kinv, every workgroup resident at once) the main-row workgroups form half of the inverse's tiles: df_inverse_tiles
+    int kacc;          // (with kinv) the inverse's tiles are accumulated column by column as the rows of L^-T arrive: df_inverse_column
     int fine;          // small batches (every block row on a CU of its own): a main row also announces every COLUMN it has solved
                        // (word 2 nb + row), and a gather waits term by term -- see df_column
     const double *lt;  // optional: the identity-structured extra rows of slab b start as L_d^T (d = b % lt_dl) instead of what
@@ -1556,6 +1557,84 @@ __device__ __forceinline__ void df_vector_row(const DfArgs &a, double *S, int *p
     }
 }
 
+// Round 5 (lead 2): the inverse's tiles accumulated AS THE COLUMNS ARRIVE.  Tile (e, f) of A^-1 = W W^T, W = L^-T, is
+// sum_{j >= e} W(e,j) W(f,j)^T, and term j exists as soon as block column j of rows e and f is solved -- df_inverse_tiles forms all
+// of it behind the last column (up to 20 tile products: 60-70 us behind the chain of a K_uu matrix).  Here identity-row workgroup e,
+// right behind its column j: announces it (word 3 nb + e = columns done), and for every f <= e waits for row f's column j, carries the
+// tile's accumulator over from the previous column THROUGH MEMORY (the same lanes wrote it), runs the same 16 MFMA steps on it and
+// puts it back; the last column also writes the mirror image.  The same products on the same accumulators in the same order as
+// df_inverse_tiles: the same bits.  What is left behind the last column is one product per tile of the workgroup's row.
+__device__ __forceinline__ bool df_inverse_column(const DfArgs &a, double *S, int *pg, const int b, const int e, const int j,
+                                                  double (*Xs)[LL_LD], double (*Ls)[LL_LD], int *wslot, int &wc) {
+    const int n = a.n, nb = a.nb;
+    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qr = wave >> 1, qc = wave & 1;
+    const int sr = tid >> 5, sc = 2 * (tid & 31);
+    int *pc = pg + 3 * nb;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wavefront's stores of W(e,j) (and of the previous column's tiles) have left it
+    __syncthreads();
+    if (tid == 0) df_publish(pc + e, j + 1);
+    double *Kb = a.kinv + (size_t)b * a.kinv_stride;
+    const double *We = S + (size_t)(n + e * NB) * n + (size_t)j * NB;
+    const bool last = j + 1 == nb;
+    for (int f = 0; f <= e; ++f) {
+        if (f < e) {
+            const int seen = df_wait(pc + f, j + 1, a.abort_w, &wslot[wc++ & 1]);
+            if (seen < 0) return false;
+        }
+        const double *Wf = S + (size_t)(n + f * NB) * n + (size_t)j * NB;
+        d2 vx[8], vl[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            vx[i] = *reinterpret_cast<const d2 *>(We + (size_t)(sr + 8 * i) * n + sc);
+            vl[i] = *reinterpret_cast<const d2 *>(Wf + (size_t)(sr + 8 * i) * n + sc);
+        }
+        d4 acc[2][2];
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const size_t i = (size_t)(e * NB + qr * 32 + 16 * x + lk + 4 * q), jj = (size_t)(f * NB + qc * 32 + 16 * y + lr);
+                    acc[x][y][q] = (j > e) ? Kb[i * n + jj] : 0.0;
+                }
+        __syncthreads();                                // everyone is done reading the previous tiles
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            Xs[sr + 8 * i][sc] = vx[i].x; Xs[sr + 8 * i][sc + 1] = vx[i].y;
+            Ls[sr + 8 * i][sc] = vl[i].x; Ls[sr + 8 * i][sc + 1] = vl[i].y;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int ks = 0; ks < NB / 4; ++ks) {
+            double ax[2], bl[2];
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                ax[x] = Xs[qr * 32 + 16 * x + lr][4 * ks + lk];
+                bl[x] = Ls[qc * 32 + 16 * x + lr][4 * ks + lk];
+            }
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y) acc[x][y] = mfma_f64(ax[x], bl[y], acc[x][y]);
+        }
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const size_t i = (size_t)(e * NB + qr * 32 + 16 * x + lk + 4 * q), jj = (size_t)(f * NB + qc * 32 + 16 * y + lr);
+                    Kb[i * n + jj] = acc[x][y][q];
+                    if (last && f < e) Kb[jj * n + i] = acc[x][y][q];
+                }
+    }
+    __syncthreads();                                    // (the next column's staging reuses the tiles)
+    return true;
+}
+
 // Identity-row workgroup e, its row W(e, e..) = (L^-T)(e, .) complete: announce it, then form the tiles (e, f), f <= e, of
 // A^-1 = L^-T L^-1 = W W^T:  (e,f) = sum_{j >= e} W(e,j) W(f,j)^T  (rows f < e belong to workgroups dispatched earlier).  The
 // same staging loop as the panel gather; both triangles are written.  A separate product launch after the factorisation
@@ -1710,6 +1789,7 @@ __global__ __launch_bounds__(256, 2) void potrf_df_kernel(DfArgs a) {
                 }
             }
         } else {
+            const bool kacc = a.kacc && !main_row && ri - nb < a.nid;
             for (int j = k0; j < nplain; ++j) {
                 d4 unused_c[2][2], unused_a[2][2];
                 if (!df_column<false>(a, S, pg, dvb, row0, j, k0, Xs, Ls, Dv, wslot, wc, unused_c, unused_a, trow, xt_row, lt_src,
@@ -1717,11 +1797,15 @@ __global__ __launch_bounds__(256, 2) void potrf_df_kernel(DfArgs a) {
                     if (tid == 0 && a.info) a.info[b] = -1;
                     return;
                 }
+                if (kacc && !df_inverse_column(a, S, pg, b, ri - nb, j, Xs, Ls, wslot, wc)) {
+                    if (tid == 0 && a.info) a.info[b] = -1;
+                    return;
+                }
             }
         }
     }
     if (!main_row) {
-        if (a.kinv && ri - nb < a.nid && !df_inverse_tiles(a, S, pg, b, ri - nb, Xs, Ls, wslot)) {
+        if (a.kinv && !a.kacc && ri - nb < a.nid && !df_inverse_tiles(a, S, pg, b, ri - nb, Xs, Ls, wslot)) {
             if (tid == 0 && a.info) a.info[b] = -1;
         }
         return;
@@ -1838,7 +1922,11 @@ static void launch_potrf_flow(hipStream_t stream, double *A, int n, int extra_ro
     //  one row per compute unit; 288 and 432 rows no difference, 864 none, 1152 rows 2 % slower: profiles/r04_ab_df_pad.txt)
     const bool one_per_cu = (size_t)batch * R <= 256 || (a.nid == 0 && (size_t)batch * R <= 640);
     static const int kh_mode = [] { const char *e = getenv("FFVD_DF_KINV_HELP"); return e ? atoi(e) : -1; }();
-    a.kinv_help = (kinv_help && a.kinv && a.nid == a.nb && (size_t)batch * R <= 256 && kh_mode != 0) ? 1 : 0;
+    // column-wise accumulation of the inverse's tiles (df_inverse_column): FFVD_DF_KACC=0 / 1, default on where the chain runs by itself
+    // (the few-chain schedules: that is where the chain's tail is on the iteration's critical path); needs a fourth set of progress words
+    const int kacc_mode = [] { const char *e = getenv("FFVD_DF_KACC"); return e ? atoi(e) : -1; }();      // (read per launch: tests switch it)
+    a.kacc = (a.kinv && a.nid == a.nb && 4 * a.nb <= DF_PS && (kacc_mode >= 0 ? kacc_mode != 0 : kinv_help)) ? 1 : 0;
+    a.kinv_help = (kinv_help && a.kinv && !a.kacc && a.nid == a.nb && (size_t)batch * R <= 256 && kh_mode != 0) ? 1 : 0;
     const bool alone = (pad_mode >= 0) ? (pad_mode != 0) : one_per_cu;
     const int fine_mode = [] { const char *e = getenv("FFVD_DF_FINE"); return e ? atoi(e) : -1; }();      // (read per launch: tests switch it)
     a.fine = ((fine_mode >= 0 ? fine_mode != 0 : (alone && (size_t)batch * R <= 256)) && 3 * a.nb <= DF_PS) ? (fine_mode == 2 ? 2 : 1) : 0;    // (2: A/B, no early sums)

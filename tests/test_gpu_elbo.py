@@ -1392,6 +1392,29 @@ def _schedule_case(case):
     raise KeyError(case)
 
 
+@pytest.mark.parametrize("S", [1, 4])
+def test_inverse_tiles_by_column_equal_the_tail_form(S, monkeypatch):
+    """Round 5 (lead 2): in the few-chain schedules the K_uu chain's dataflow launch also leaves K^-1 = L^-T L^-1; its
+    tiles are now accumulated column by column as the rows of L^-T arrive (df_inverse_column: the accumulators travel through memory
+    between columns) instead of all at once behind the last column (df_inverse_tiles, FFVD_DF_KACC=0).  The same products on the same
+    accumulators in the same order: every term and the per-chain nll bit for bit, at the shape of a 1- and a 4-chain rank of config 2."""
+    params, Y, c, meta = synthetic.make_named("c2", S=S)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FFVD_DF_KACC", mode)
+        with ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], meta["S"], route="gram") as e:
+            assert "side late" in e.lib.ffvd_schedule_name(e._h).decode()
+            e.set_data(Y, c)
+            outs[mode] = (e.nll_terms(params), e.nll_terms(params))
+            assert int(e.lib.ffvd_stall_recoveries(e._h)) == 0
+    monkeypatch.delenv("FFVD_DF_KACC")
+    for n in TERMS_B:
+        assert outs["1"][0][n] == outs["0"][0][n] == outs["1"][1][n], n
+    np.testing.assert_array_equal(outs["1"][0]["nll_per_chain"], outs["0"][0]["nll_per_chain"])
+    ref = orc.nll_terms_chains(params, Y, c, U_collapse=True)
+    assert outs["1"][0]["nll"] == pytest.approx(ref["nll"], rel=1e-8)
+
+
 @pytest.mark.parametrize("passes,mode", [(2, 0), (3, 0), (4, 1), (5, 2)])
 def test_pipelined_passes_are_bit_identical(passes, mode, monkeypatch):
     """the pass-pipelined forward iteration (enqueue_elbo_pipe, FFVD_PIPE / FFVD_PIPE_MODE: K_fu build of pass p+1 |
