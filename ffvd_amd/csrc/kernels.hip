@@ -1922,10 +1922,14 @@ static void launch_potrf_flow(hipStream_t stream, double *A, int n, int extra_ro
     //  one row per compute unit; 288 and 432 rows no difference, 864 none, 1152 rows 2 % slower: profiles/r04_ab_df_pad.txt)
     const bool one_per_cu = (size_t)batch * R <= 256 || (a.nid == 0 && (size_t)batch * R <= 640);
     static const int kh_mode = [] { const char *e = getenv("FFVD_DF_KINV_HELP"); return e ? atoi(e) : -1; }();
-    // column-wise accumulation of the inverse's tiles (df_inverse_column): FFVD_DF_KACC=0 / 1, default on where the chain runs by itself
-    // (the few-chain schedules: that is where the chain's tail is on the iteration's critical path); needs a fourth set of progress words
+    // column-wise accumulation of the inverse's tiles (df_inverse_column): opt-in, FFVD_DF_KACC=1 -- built for the few-chain schedules,
+    // where the chain's tail is on the iteration's critical path, bit-identical, and measured SLOWER there (per-rank iteration at
+    // 1 / 2 / 4 / 8 chains 0.458 / 0.540 / 0.718 / 1.026 ms against 0.428 / 0.508 / 0.685 / 1.003, profiles/r05_ab_kacc.txt): a tile
+    // update through memory is a wait, two tile loads, the accumulator's round trip, 64 MFMAs and a store in sequence (4-8 us), row 7
+    // has eight of them behind the last column, nobody helps it (the main rows' help needs finished rows), and the identity rows now
+    // wait for each other at every column.  Needs a fourth set of progress words.
     const int kacc_mode = [] { const char *e = getenv("FFVD_DF_KACC"); return e ? atoi(e) : -1; }();      // (read per launch: tests switch it)
-    a.kacc = (a.kinv && a.nid == a.nb && 4 * a.nb <= DF_PS && (kacc_mode >= 0 ? kacc_mode != 0 : kinv_help)) ? 1 : 0;
+    a.kacc = (a.kinv && a.nid == a.nb && 4 * a.nb <= DF_PS && kacc_mode > 0) ? 1 : 0;
     a.kinv_help = (kinv_help && a.kinv && !a.kacc && a.nid == a.nb && (size_t)batch * R <= 256 && kh_mode != 0) ? 1 : 0;
     const bool alone = (pad_mode >= 0) ? (pad_mode != 0) : one_per_cu;
     const int fine_mode = [] { const char *e = getenv("FFVD_DF_FINE"); return e ? atoi(e) : -1; }();      // (read per launch: tests switch it)

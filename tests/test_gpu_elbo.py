@@ -1395,8 +1395,8 @@ def _schedule_case(case):
 @pytest.mark.parametrize("S", [1, 4])
 def test_inverse_tiles_by_column_equal_the_tail_form(S, monkeypatch):
     """Round 5 (lead 2): in the few-chain schedules the K_uu chain's dataflow launch also leaves K^-1 = L^-T L^-1; its
-    tiles are now accumulated column by column as the rows of L^-T arrive (df_inverse_column: the accumulators travel through memory
-    between columns) instead of all at once behind the last column (df_inverse_tiles, FFVD_DF_KACC=0).  The same products on the same
+    tiles can be accumulated column by column as the rows of L^-T arrive (df_inverse_column, FFVD_DF_KACC=1: the accumulators travel
+    through memory between columns; measured slower, opt-in) instead of all at once behind the last column (df_inverse_tiles).  The same products on the same
     accumulators in the same order: every term and the per-chain nll bit for bit, at the shape of a 1- and a 4-chain rank of config 2."""
     params, Y, c, meta = synthetic.make_named("c2", S=S)
     outs = {}
