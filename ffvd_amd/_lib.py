@@ -85,6 +85,8 @@ _SIGNATURES = {
                                   C.POINTER(C.c_double)]),
     "ffvd_tshard_adam_apply": (C.c_int, [C.c_void_p, _dp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_uint32, _dp,
                                          C.POINTER(C.c_double)]),
+    "ffvd_tshard_sghmc_apply": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_uint32, C.c_int, C.c_void_p, _dp,
+                                          C.POINTER(C.c_double)]),
     "ffvd_sghmc_apply": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_uint32, C.c_int, C.c_void_p, _dp,
                                    C.POINTER(C.c_double)]),
     "ffvd_stall_recoveries": (C.c_int, [C.c_void_p]),

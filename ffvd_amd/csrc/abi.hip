@@ -2301,7 +2301,9 @@ static int sghmc_update(ffvd_handle *h, double epsilon, double mdecay, uint32_t 
         t.theta = theta[i]; t.grad = grad[i]; t.s0 = h->hmc[i][0]; t.s1 = h->hmc[i][1]; t.s2 = h->hmc[i][2];
         t.s3 = h->hmc[i][3]; t.noise = h->hmc[i][4]; t.n = (int64_t)n[i];
     }
-    launch_sghmc(h->stream, tab, epsilon, mdecay, (double)(h->cfg.T + 1), burn_in);      // X_N = rows of X (dgp_model.py:203)
+    // X_N = rows of X (dgp_model.py:203) -- of the JOB's trajectory: a T-shard handle holds T_r + 1 of its T_total + 1 rows
+    const double x_n = (double)((h->cfg.T_total > 0 ? h->cfg.T_total : h->cfg.T) + 1);
+    launch_sghmc(h->stream, tab, epsilon, mdecay, x_n, burn_in);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));           // the noise arrays are the caller's: done with them on return
     return FFVD_OK;
@@ -3504,6 +3506,26 @@ extern "C" int ffvd_tshard_adam_apply(ffvd_handle *h, const double *dX_rows, dou
         if (!std::isfinite(h->h_sums[i]))
             return set_error(h, FFVD_ENOTPD, "ffvd_tshard_adam_apply: non-finite sums in the exchanged block (a factorisation failed on a shard); parameters untouched");
     if ((rc = adam_update(h, lr, beta1, beta2, eps, train_mask))) return rc;
+    train_report(h, out_terms, out_nll);
+    return FFVD_OK;
+}
+
+// ... and the SG-HMC update (burn_in_op / sample_op, base_model.py:143-179) of a T-sharded job: X is never an SG-HMC variable
+// (dgp_model.py:213-244), so the exchanged block is all it needs -- every shard applies the same update with the same noise.
+extern "C" int ffvd_tshard_sghmc_apply(ffvd_handle *h, double epsilon, double mdecay, uint32_t sample_mask, int burn_in,
+                                       const ffvd_params *noise, double out_terms[8], double *out_nll) {
+    int rc;
+    if ((rc = tshard_grad_ready(h, "ffvd_tshard_sghmc_apply", h ? h->cfg.S_local : 0))) return rc;
+    if (!noise || !(epsilon > 0.0) || !(mdecay >= 0.0)) return set_error(h, FFVD_EINVAL, "ffvd_tshard_sghmc_apply: bad argument");
+    if (sample_mask & FFVD_TRAIN_X) return set_error(h, FFVD_EINVAL, "ffvd_tshard_sghmc_apply: X is never an SG-HMC variable (dgp_model.py:213-244)");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    if ((rc = sghmc_prepare(h, sample_mask, noise, "ffvd_tshard_sghmc_apply"))) return rc;
+    HIP_TRY(hipMemcpyAsync(h->h_sums, h->gw.pack, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < 8; ++i)
+        if (!std::isfinite(h->h_sums[i]))
+            return set_error(h, FFVD_ENOTPD, "ffvd_tshard_sghmc_apply: non-finite sums in the exchanged block (a factorisation failed on a shard); parameters untouched");
+    if ((rc = sghmc_update(h, epsilon, mdecay, sample_mask, burn_in))) return rc;
     train_report(h, out_terms, out_nll);
     return FFVD_OK;
 }

@@ -251,6 +251,18 @@ def tshard_adam_step(engine, meta, rank, world, reduce_host, lr, beta1=0.9, beta
     return finish(engine.tshard_adam_apply(rows, lr, beta1, beta2, eps, train))
 
 
+def tshard_sghmc_step(engine, meta, reduce_host, noise, epsilon=0.01, mdecay=0.05, burn_in=True, native=False):
+    """One burn_in_op / sample_op of a T-sharded job: the two exchange steps of the gradient, then every shard applies the update of
+    the shared parameters with the same noise (X is never an SG-HMC variable: no rows travel)."""
+    S = meta["S"]
+    if native:
+        engine.elbo_tshard_grad(S_total=S)
+    else:
+        t = np.asarray(reduce_host(engine.tshard_local()))
+        engine.tshard_grad_fetch(np.asarray(reduce_host(engine.tshard_finish_grad(t, S_total=S))))
+    return finish(engine.tshard_sghmc_apply(noise, epsilon, mdecay, burn_in))
+
+
 class ShardedElbo:
     """One rank's share of the ELBO on its own GPU + the scalar all-reduce.
 
@@ -410,7 +422,11 @@ class ShardedElbo:
     def sghmc_step(self, noise, epsilon=0.01, mdecay=0.05, burn_in=True):
         """One burn_in_op / sample_op of the whole job; `noise` must be identical on every rank."""
         if self.time_shard:
-            raise ValueError("T-shard handles have no device-resident sampler step (nll_and_grad returns the job's gradient)")
+            if self.collective == "rccl":
+                return tshard_sghmc_step(self.engine, self.meta, self.engine.allreduce_host, noise, epsilon, mdecay, burn_in, native=True)
+            return tshard_sghmc_step(self.engine, self.meta,
+                                     lambda a: self._host_reduce(np.ascontiguousarray(a, dtype=np.float64).ravel().copy()),
+                                     noise, epsilon, mdecay, burn_in)
         S = self.meta["S"]
         if not self.reduces:
             self.engine.shard_of = 1

@@ -420,6 +420,16 @@ class ElboEngine:
                                                    int(mask), _lib.dptr(out), ct.byref(nll)), self._h, "ffvd_tshard_adam_apply")
         return out
 
+    def tshard_sghmc_apply(self, noise, epsilon=0.01, mdecay=0.05, burn_in=True):
+        """SG-HMC update of a T-sharded job from the block the preceding tshard_grad_fetch / elbo_tshard_grad left on the device."""
+        ps, mask, keep = self._noise_struct(noise, "tshard_sghmc_apply")
+        out = np.zeros(8)
+        nll = ct.c_double()
+        _lib.check(self.lib.ffvd_tshard_sghmc_apply(self._h, float(epsilon), float(mdecay), int(mask), int(bool(burn_in)), ct.byref(ps),
+                                                    _lib.dptr(out), ct.byref(nll)), self._h, "ffvd_tshard_sghmc_apply")
+        del keep
+        return out
+
     def allreduce_host(self, array, comm=None):
         """all-reduce(sum) of a small host fp64 array through the handle's device staging buffer on the engine's stream
         (8 sums + shared-parameter gradients of a sharded training step: a few KB).  Returns a new flat array."""

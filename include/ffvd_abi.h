@@ -324,6 +324,11 @@ int  ffvd_elbo_tshard_grad(ffvd_handle *h, void *rccl_comm, int S_total, double 
  * gradients and carry identical state, so the shards stay in step without a broadcast.  out_terms = the job's 8 sums. */
 int  ffvd_tshard_adam_apply(ffvd_handle *h, const double *dX_rows, double lr, double beta1, double beta2, double eps,
                             uint32_t train_mask, double out_terms[8], double *out_nll);
+/* ... and the SG-HMC update (burn_in_op / sample_op, base_model.py:143-179) of a T-sharded job from the same exchanged block: X is
+ * never an SG-HMC variable, so no rows travel; `noise` must be identical on every shard; X_N of the step size is the JOB's row
+ * count (T_total + 1). */
+int  ffvd_tshard_sghmc_apply(ffvd_handle *h, double epsilon, double mdecay, uint32_t sample_mask, int burn_in,
+                             const ffvd_params *noise, double out_terms[8], double *out_nll);
 
 /* the handle's HIP stream (a hipStream_t), so that a collective library or another framework can order its work after
  * ffvd_elbo_async without a host synchronisation (e.g. torch.cuda.ExternalStream around the RCCL all-reduce). */

@@ -848,6 +848,27 @@ def test_time_shards_adam_trajectory(name, ov, nshard, monkeypatch):
                     np.testing.assert_array_equal(gp["X"][:, 0], got[r - 1]["X"][:, -1], err_msg=f"step {step}: boundary row {r}")
         assert nlls[0] == pytest.approx(whole, rel=1e-9)
         assert nlls[-1] < nlls[0]
+        # ---- then two SG-HMC steps (burn_in_op, sample_op: base_model.py:143-179) on the kernel hyper-parameters: the same noise on
+        # every shard, X_N of the step size = the JOB's rows (T + 1), the shards' copies bit-identical, equal to the host-side oracle
+        rng = np.random.default_rng(9)
+        keys = ("logvariance", "loglengthscales")
+        st = {k: [np.ones_like(host[k]), np.ones_like(host[k]), np.ones_like(host[k]), np.zeros_like(host[k])] for k in keys}
+        for burn in (True, False):
+            noise = {k: rng.standard_normal(host[k].shape) for k in keys}
+            locs = [e.tshard_local() for e in engines]
+            total = np.sum(locs, axis=0)
+            block = np.sum([e.tshard_finish_grad(total, S_total=S) for e in engines], axis=0)
+            fetched = [e.tshard_grad_fetch(block) for e in engines]
+            outs = [e.tshard_sghmc_apply(noise, 0.01, 0.05, burn) for e in engines]
+            assert all(np.array_equal(o, outs[0]) for o in outs)
+            for k in keys:
+                th, xi, g1, g2, pm = oo.sghmc_step(host[k], fetched[0][1][k], st[k][0], st[k][1], st[k][2], st[k][3], noise[k], 0.01, 0.05, T + 1, burn)
+                host[k], st[k] = th, [xi, g1, g2, pm]
+            got = [e.get_params() for e in engines]
+            for gp in got:
+                for k in keys:
+                    np.testing.assert_array_equal(gp[k], got[0][k], err_msg=f"sghmc {k}: copies diverged")
+                    np.testing.assert_allclose(gp[k], host[k], rtol=0, atol=1e-13 * max(1.0, float(np.max(np.abs(host[k])))), err_msg=k)
     finally:
         for e in engines:
             e.close()
