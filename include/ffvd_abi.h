@@ -410,7 +410,8 @@ int  ffvd_op_sghmc_step(double *theta, const double *grad, double *xi, double *g
 
 /* The ffvd_op_* entry points keep their device temporaries and their stream in a per-thread cache between calls (a rollout call
  * made ~27 allocations around its step loop: 2.7 ms of host work per call).  ffvd_op_release_cache frees what the calling thread's
- * cache holds; the cache also trims itself beyond 256 blocks / 8 GiB. */
+ * cache holds; the cache also trims itself beyond 256 blocks / 8 GiB.  A host that runs ffvd_op_* calls on short-lived threads
+ * calls it before a thread exits (nothing is freed at thread exit: the HIP runtime may already be shutting down then). */
 int  ffvd_op_release_cache(void);
 
 /* The prediction loop of collect_samples_formal (base_model.py:288-314) for R posterior rollouts advanced side by
