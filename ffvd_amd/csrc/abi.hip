@@ -2420,6 +2420,9 @@ struct Scratch {
         }
         c.blocks[best].busy = true;
         mine.push_back(best);
+        // FFVD_OP_CACHE_POISON=1 (tests): every block handed out starts as NaN bytes -- nothing may rely on what a block held before
+        static const bool poison = [] { const char *e = getenv("FFVD_OP_CACHE_POISON"); return e && *e && strcmp(e, "0") != 0; }();
+        if (poison && stream) (void)hipMemsetAsync(c.blocks[best].p, 0xFF, c.blocks[best].bytes, stream);
         return (T *)c.blocks[best].p;
     }
     double *upload(const double *src, size_t n) {

@@ -402,6 +402,58 @@ def test_rollout_resident_loop_fenced_build_agrees(tmp_path):
     np.testing.assert_array_equal(outs["product"]["pv"], outs["rrfenced"]["pv"])
 
 
+_CACHE_SCRIPT = r"""
+import sys
+import numpy as np
+from ffvd_amd import synthetic, _lib, conditionals_multi_output as cmo
+from ffvd_amd.prediction import rollout, pg_sweep
+from ffvd_amd.kernels import SquaredExponential
+out = {}
+for name, R in (("small", 24), ("ragged", 70), ("tiny", 5), ("small", 24)):        # different shapes in turn: cached blocks change hands
+    params, Y, c, meta = synthetic.make_named(name)
+    D, C, T = meta["D"], meta["C"], meta["T"]
+    X = params["X"][0]
+    Q = np.exp(params["log_Q"])
+    kern = [SquaredExponential(D + C, variance=np.exp(params["logvariance"][d]), lengthscales=np.exp(params["loglengthscales"][d])) for d in range(D)]
+    rng = np.random.default_rng(5)
+    steps = 9
+    ctrl = np.concatenate((c, rng.standard_normal((steps, C))))
+    eps = rng.standard_normal((steps, R, D))
+    xc = np.concatenate((X[:-1], c), axis=1)
+    Lg = cmo.kernel_pre_cal(params["Z"], kern)
+    Ug, Hg = cmo.collapse_u_mean_after_kernel_precalculation(Lg, xc, X, params["Z"], kern, Q)
+    px, pv = rollout(Lg, params["Z"], kern, Ug, Hg, X[-1], ctrl, T, steps, Q, eps)
+    x0, e2, u = rng.standard_normal((R, D)), rng.standard_normal((T, R, D)), rng.random((T, R))
+    parts, idx = pg_sweep(Lg, params["Z"], kern, params["U"], X, Y, c, params["CC"], params["DD"], np.exp(params["log_Rchols"]), Q, x0, e2, u)
+    mean, var = cmo.conditional(xc, params["Z"], kern, params["U"], white=True)
+    k = f"{name}{len(out)}"
+    out.update({k + "px": px, k + "pv": pv, k + "parts": parts, k + "idx": idx, k + "mean": np.asarray(mean), k + "var": np.asarray(var), k + "U": Ug})
+assert _lib.load().ffvd_op_release_cache() == 0
+np.savez(sys.argv[1], **out)
+"""
+
+
+def test_operator_cache_hands_out_blocks_nobody_relies_on(tmp_path):
+    """Round 5: the ffvd_op_* entry points keep their device temporaries in a per-thread cache instead of hipMalloc / hipFree per call.
+    A cached block comes back with whatever its last user left in it; FFVD_OP_CACHE_POISON=1 makes every block start as NaN bytes.
+    A sequence of operator calls over changing shapes (rollouts, a particle-Gibbs sweep, conditionals, the posterior U) must give
+    the same bits with and without the poison -- nothing reads what it has not written."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for mode in ("0", "1"):
+        env = dict(os.environ, FFVD_OP_CACHE_POISON=mode, PYTHONPATH=root)
+        path = str(tmp_path / f"cache{mode}.npz")
+        out = subprocess.run([sys.executable, "-c", _CACHE_SCRIPT, path], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        outs[mode] = np.load(path)
+    assert sorted(outs["0"].files) == sorted(outs["1"].files) and len(outs["0"].files) == 28
+    for k in outs["0"].files:
+        assert np.all(np.isfinite(outs["0"][k])), k
+        np.testing.assert_array_equal(outs["0"][k], outs["1"][k], err_msg=k)
+
+
 def test_rollout_argument_errors():
     from ffvd_amd.prediction import rollout
     from ffvd_amd.kernels import SquaredExponential
