@@ -3058,12 +3058,13 @@ extern "C" int ffvd_op_rollout(int kind, const double *Lm_inverse_seq, const dou
     auto step_launches = [&]() {                                              // three dependent launches per step
         for (int t = 0; t < steps; ++t) {
             pa.x = xbuf[t & 1];
-            launch_kfu_build(sc.stream, pa);                                     // K(x_t, Z) per dim
             if (skinny) {
+                launch_kfu_build_t(sc.stream, pa, Tp);                               // K(x_t, Z) per dim, m-major (coalesced operand loads)
                 // conditional_after_kernel_precalculation (:300) and, in the same launch, sum_j (F q_sqrt)_j^2 = |K (W q_sqrt)|^2 (:371-380)
-                launch_skinny_gemm(sc.stream, Kf, (size_t)Tp * Mp, Mp, dW, (size_t)Mp * Mp, Mp, 1, R, Mp, Mp, D, Tp,
-                                   nullptr, 0, 0, ucol, Mp, rowsq, fmean, q_sqrt ? dWQ : nullptr, (size_t)Mp * Mp, Mp, Mp, extra);
+                launch_skinny_gemm(sc.stream, Kf, (size_t)Tp * Mp, Tp, dW, (size_t)Mp * Mp, Mp, 1, R, Mp, Mp, D, Tp,
+                                   nullptr, 0, 0, ucol, Mp, rowsq, fmean, q_sqrt ? dWQ : nullptr, (size_t)Mp * Mp, Mp, Mp, extra, 1);
             } else {
+                launch_kfu_build(sc.stream, pa);                                     // K(x_t, Z) per dim
                 launch_proj_gemm(sc.stream, pg);
                 if (q_sqrt) launch_qsqrt_inflation(sc.stream, F, (size_t)Tp * Mp, Tp, Mp, M, dQs, extra, R, D);
             }
@@ -3222,10 +3223,11 @@ extern "C" int ffvd_op_pg_sweep(int kind, const double *Lm_inverse_seq, const do
     // the whole sweep is enqueued at once: steps x (K_fu rows, projection, conditional, propagate + weight + resample)
     auto step_launches = [&]() {
         for (int t = 0; t < steps; ++t) {
-            launch_kfu_build(sc.stream, pa);
-            if (skinny) launch_skinny_gemm(sc.stream, Kf, (size_t)Tp * Mp, Mp, dW, (size_t)Mp * Mp, Mp, 1, R, Mp, Mp, D, Tp,
-                                           nullptr, 0, 0, ucol, Mp, rowsq, fmean);
-            else launch_proj_gemm(sc.stream, pg);                                // conditional_after_kernel_precalculation (:95-97)
+            if (skinny) {                               // K(x_t, Z) m-major: the skinny product's operand loads coalesce
+                launch_kfu_build_t(sc.stream, pa, Tp);
+                launch_skinny_gemm(sc.stream, Kf, (size_t)Tp * Mp, Tp, dW, (size_t)Mp * Mp, Mp, 1, R, Mp, Mp, D, Tp,
+                                   nullptr, 0, 0, ucol, Mp, rowsq, fmean, nullptr, 0, 0, 0, nullptr, 1);
+            } else { launch_kfu_build(sc.stream, pa); launch_proj_gemm(sc.stream, pg); }                                // conditional_after_kernel_precalculation (:95-97)
             launch_conditional_finish(sc.stream, kind, dxc, R, P, variance, rowsq, fmean, ngs, Tp, D, dmean, dvar, nullptr);
             launch_pg_step(sc.stream, dmean, dvar, dlq, deps + (size_t)t * R * D, dun + (size_t)t * R, dY + (size_t)t * Ydim,
                            dXr + (size_t)(t + 1) * D, dCC, dDD, dR, (C && t + 1 < steps) ? dctrl + (size_t)(t + 1) * C : nullptr,

@@ -132,6 +132,7 @@ bool linear_lowrank_supported(int kind, int P);
 size_t linear_lowrank_doubles(int Mp, int Dl, int P);
 void launch_linear_lowrank(hipStream_t stream, const ProjectArgs &a, double *part);
 // a.F[bz][t][m] = K_fu itself (route K_uu + K_uf K_fu / Q); uses x, ctrl, hv, T, Tp, M, Mp, b0, nb of `a`.
+void launch_kfu_build_t(hipStream_t stream, const ProjectArgs &a, int ldt);      // a.F <- KT[nb][Mp][ldt]: a step's K(x, Z), m-major
 void launch_kfu_build(hipStream_t stream, const ProjectArgs &a, int streaming = -1 /* -1: by output size, 0 / 1: cacheable / streaming stores */);
 
 // GRAM_KFU_RAW: as GRAM_KFU, but the trace partials are left to a later trace-only pass (phase 3) over the raw tiles
@@ -255,7 +256,8 @@ void launch_skinny_gemm(hipStream_t stream, const double *A, size_t a_stride, in
                         int upper, int rows, int K, int N, int nb, int Tp, double *C, size_t c_stride, int ldc,
                         const double *u, size_t u_stride, double *sq, double *dot,
                         // optional second right-hand side B2 (K x N2, dense) in the same launch: only sq2[nb][N2 / 16][Tp] is formed
-                        const double *B2 = nullptr, size_t b2_stride = 0, int ldb2 = 0, int N2 = 0, double *sq2 = nullptr);
+                        const double *B2 = nullptr, size_t b2_stride = 0, int ldb2 = 0, int N2 = 0, double *sq2 = nullptr,
+                        int a_trans = 0 /* A is k-major AT[nb][K][lda], as launch_kfu_build_t writes it */);
 // out[i * out_ld + b * out_bs] = sum_j W[b][i][j] y[b][j]
 void launch_matvec(hipStream_t stream, const double *W, size_t w_stride, const double *y, size_t y_stride, int Mp,
                    double *out, int out_ld, int out_bs, int M, int batch, int w_mod = 0);   // w_mod > 0: W slab index = batch index % w_mod

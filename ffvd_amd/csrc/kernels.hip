@@ -19,7 +19,13 @@
 //     same panel/trailing kernels: identity rows become L^{-T}, the row delta^T F / Q becomes L_H^{-1} b.
 #include "kernels.h"
 #include "dev_common.h"
+#define FFVD_STEP_TRACE_OWNER
 #include "step_bodies.h"
+#if defined(FFVD_STEP_TRACE)
+extern "C" int ffvd_debug_step_trace(long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ffvd::step_trace_buf), sizeof(long long) * 4096 * 8);
+}
+#endif
 #include <type_traits>
 #include <cstdlib>
 
@@ -259,6 +265,27 @@ static void launch_kfu_build_nt(hipStream_t stream, const ProjectArgs &a) {
     } else {
         if (a.kind == 0) hipLaunchKernelGGL((kfu_build_kernel<0, 0, NT>), grid, dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((kfu_build_kernel<1, 0, NT>), grid, dim3(256), 0, stream, a);
+    }
+}
+template <int KIND, int NQ, int MW>
+__global__ __launch_bounds__(256) void kfu_build_t_kernel(ProjectArgs a, int ldt) {
+    kfu_build_t_body<KIND, NQ, MW>(a, ldt, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+// K(x, Z) of a step, transposed: a.F receives KT[nb][Mp][ldt] (ldt >= a.Tp) -- the skinny product's coalesced A operand.  A step has
+// few rows: tiles of 64 rows x 16 inducing points (4 per wavefront) put its 128 x 512 x 4 values on 256 workgroups instead of 64.
+void launch_kfu_build_t(hipStream_t stream, const ProjectArgs &a, int ldt) {
+    constexpr int MW = 4;
+    dim3 grid(a.Tp / 64, a.Mp / (4 * MW), a.nb);
+    if (a.P <= 8) {
+        const int nq = (a.P + 1) / 2;
+        if (a.kind == 0) {
+            if (nq <= 2) hipLaunchKernelGGL((kfu_build_t_kernel<0, 2, MW>), grid, dim3(256), 0, stream, a, ldt);
+            else if (nq == 3) hipLaunchKernelGGL((kfu_build_t_kernel<0, 3, MW>), grid, dim3(256), 0, stream, a, ldt);
+            else hipLaunchKernelGGL((kfu_build_t_kernel<0, 4, MW>), grid, dim3(256), 0, stream, a, ldt);
+        } else hipLaunchKernelGGL((kfu_build_t_kernel<1, 4, MW>), grid, dim3(256), 0, stream, a, ldt);
+    } else {
+        if (a.kind == 0) hipLaunchKernelGGL((kfu_build_t_kernel<0, 0, MW>), grid, dim3(256), 0, stream, a, ldt);
+        else hipLaunchKernelGGL((kfu_build_t_kernel<1, 0, MW>), grid, dim3(256), 0, stream, a, ldt);
     }
 }
 void launch_kfu_build(hipStream_t stream, const ProjectArgs &a, int streaming) {
@@ -3384,15 +3411,36 @@ void launch_conditional_finish(hipStream_t stream, int kind, const double *x, in
 __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
     skinny_body(a, blockIdx.x, blockIdx.y, blockIdx.z);
 }
+// Same product from a 1-D grid for nb <= 8 units: workgroup id i runs on XCD i % 8 (round-robin dispatch), unit u owns the XCDs
+// x with x % nb == u and deals its (slab, row group) pairs over them, so a unit's A rows and B slabs are fetched into one or two L2s
+// instead of all eight.  The arithmetic of a workgroup does not depend on where it runs.
+__global__ __launch_bounds__(256) void skinny_gemm_xcd_kernel(SkinnyArgs a, int nbx, int nby) {
+    const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    const int u = xcd % a.nb, j = xcd / a.nb, cnt = (8 - u + a.nb - 1) / a.nb;
+    const int widx = k * cnt + j;
+    if (widx >= nbx * nby) return;
+    // a CU takes slots k and k + 32 of its XCD (two workgroups per CU, 32 CUs; HW_ID stamps, profiles/r05_step_trace.txt): every other
+    // block of 32 slots walks the slabs backwards, so that a long triangular slab (up to K / 16 k blocks) shares its CU's MFMA pipes
+    // with a short one.  The choice depends on the row group only: (slab, row group) pairs are still covered once each.
+    const int by = widx / nbx, rev = ((by * nbx) / (32 * cnt)) & 1;
+    const int bx = widx % nbx;
+    skinny_body(a, rev ? nbx - 1 - bx : bx, by, u);
+}
 // rows <= Tp (a multiple of 32) rows of A exist; N, K multiples of 16.
 void launch_skinny_gemm(hipStream_t stream, const double *A, size_t a_stride, int lda, const double *B, size_t b_stride, int ldb,
                         int upper, int rows, int K, int N, int nb, int Tp, double *C, size_t c_stride, int ldc,
                         const double *u, size_t u_stride, double *sq, double *dot, const double *B2, size_t b2_stride, int ldb2,
-                        int N2, double *sq2) {
+                        int N2, double *sq2, int a_trans) {
     if (rows <= 0 || nb <= 0) return;
     SkinnyArgs a{A, a_stride, lda, B, b_stride, ldb, upper, rows, K, N, nb, Tp, C, c_stride, ldc, u, u_stride, sq, dot,
-                 B2, b2_stride, ldb2, B2 ? N2 : 0, sq2};
-    hipLaunchKernelGGL(skinny_gemm_kernel, dim3(N / 16 + (B2 ? N2 / 16 : 0), (rows + 31) / 32, nb), dim3(256), 0, stream, a);
+                 B2, b2_stride, ldb2, B2 ? N2 : 0, sq2, a_trans};
+    const int nbx = N / 16 + (B2 ? N2 / 16 : 0), nby = (rows + 31) / 32;
+    static const bool flat = !(getenv("FFVD_SKINNY_GRID3D") && atoi(getenv("FFVD_SKINNY_GRID3D")));
+    if (flat && nb <= 8) {
+        const int slots = (nbx * nby + 8 / nb - 1) / (8 / nb);       // per XCD: the unit with the fewest XCDs has 8 / nb of them
+        hipLaunchKernelGGL(skinny_gemm_xcd_kernel, dim3(8 * slots), dim3(256), 0, stream, a, nbx, nby);
+    } else
+        hipLaunchKernelGGL(skinny_gemm_kernel, dim3(nbx, nby, nb), dim3(256), 0, stream, a);
 }
 
 // out[b][i] = sum_j W[b][i][j] * y[b][j]   (posterior mean of the whitened inducing outputs: L_H^-T (L_H^-1 b))

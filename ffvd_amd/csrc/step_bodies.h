@@ -106,6 +106,71 @@ __device__ __forceinline__ void kfu_build_body(const ProjectArgs &a, const int b
     __syncthreads();      // (a persistent caller reuses the LDS tiles for its next block)
 }
 
+// K(x, Z) of a step stored TRANSPOSED, KT[b][m][ldt] (m-major, the step's rows contiguous): what the skinny product below wants as
+// its A operand -- an MFMA lane holds one ROW's value, so with row-major K a 16-lane group reads 16 rows 4 KB apart (16 cache lines
+// per load, the texture addresser's limit: 1.1 us per k block measured by stamps, profiles/r05_step_trace.txt); m-major the same lanes
+// read 128 contiguous bytes.  A lane owns a row here and walks 16 of the tile's inducing points; every value is computed by the
+// expression kfu_build_body uses (same operands, same order), so the two layouts hold the same bits.
+template <int KIND, int NQ, int MW>       // MW inducing points per wavefront: a workgroup's tile is 64 rows x 4 MW points
+__device__ __forceinline__ void kfu_build_t_body(const ProjectArgs &a, const int ldt, const int bx, const int by, const int bzz) {
+    constexpr bool SMALLP = NQ > 0;
+    __shared__ double xs[SMALLP ? 1 : MAXP][SMALLP ? 1 : 64];
+    __shared__ __attribute__((aligned(16))) double xr8[SMALLP ? 64 : 1][8];
+    __shared__ double zs[4 * MW][(SMALLP ? 8 : MAXP) + 1];
+    __shared__ double zzs[4 * MW];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int t0 = bx * 64, m0 = by * (4 * MW), bz = bzz;
+    const int b = a.b0 + bz, dl = b % a.Dl, s = b / a.Dl;
+    const int P = a.P, Mp = a.Mp;
+    const double var = a.hv.variance[dl];
+    for (int p = tid >> 6; p < (SMALLP ? 8 : P); p += 4) {
+        const int t = t0 + lane;
+        double v = 0.0;
+        if (t < a.T && p < P) {
+            v = (p < a.x_cols) ? a.x[(size_t)s * a.x_chain_stride + (size_t)t * a.x_ld + p]
+                               : a.ctrl[(size_t)t * a.C + (p - a.x_cols)];
+            if (KIND == 0) v = v / a.hv.len[(size_t)dl * P + p];
+            else v = v * var;
+        }
+        if (SMALLP) xr8[lane][p] = v;
+        else xs[p][lane] = v;
+        if (lane < 4 * MW) zs[lane][p] = (p < P) ? a.hv.Zs[((size_t)dl * Mp + m0 + lane) * P + p] : 0.0;
+    }
+    if (tid < 4 * MW) zzs[tid] = a.hv.zz[(size_t)dl * Mp + m0 + tid];
+    __syncthreads();
+    double xr[8];                               // this lane's row (first 8 components) in registers
+#pragma unroll
+    for (int p = 0; p < 8; ++p) xr[p] = SMALLP ? xr8[lane][p] : (p < P ? xs[p][lane] : 0.0);
+    double xxv = 0.0;
+    if (KIND == 0) {
+        if (SMALLP) for (int p = 0; p < 8; ++p) xxv += xr[p] * xr[p];                   // padding adds exact zeros
+        else for (int p = 0; p < P; ++p) xxv += xs[p][lane] * xs[p][lane];
+    }
+    const int mbase = __builtin_amdgcn_readfirstlane(tid >> 6) * MW;
+    const bool tok = t0 + lane < a.T;
+    double *out = a.F + ((size_t)bz * Mp + m0) * ldt + t0 + lane;
+#pragma unroll 4
+    for (int i = 0; i < MW; ++i) {
+        const int m = mbase + i;
+        double dot = 0.0;
+        if (SMALLP) {
+#pragma unroll
+            for (int q = 0; q < (NQ > 0 ? NQ : 1); ++q) {
+                dot += xr[2 * q] * zs[m][2 * q];
+                dot += xr[2 * q + 1] * zs[m][2 * q + 1];
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < 8; ++p)
+                if (p < P) dot += xr[p] * zs[m][p];
+            for (int p = 8; p < P; ++p) dot += xs[p][lane] * zs[m][p];
+        }
+        double v = kernel_value<KIND>(dot, xxv, zzs[m], var);
+        if (!tok || m0 + m >= a.M) v = 0.0;
+        out[(size_t)m * ldt] = v;
+    }
+}
+
 struct SkinnyArgs {
     const double *A; size_t a_stride; int lda;
     const double *B; size_t b_stride; int ldb;      // b_stride = 0: one B for every unit
@@ -118,10 +183,26 @@ struct SkinnyArgs {
     // F = K W this way: both products read the same K rows and the step loses a dependent launch.
     const double *B2; size_t b2_stride; int ldb2, N2;
     double *sq2;
+    int a_trans;                                    // A is stored k-major, AT[b][K][lda] (kfu_build_t_body): coalesced operand loads
 };
 
+// Debug build only (-DFFVD_STEP_TRACE, variant `steptrace`, tools/step_trace.py): wall-clock stamps of every workgroup of the last
+// skinny launch (start, operands of the first k block there, k loop done, end) -- kernels.hip owns the buffer.
+#if defined(FFVD_STEP_TRACE) && defined(FFVD_STEP_TRACE_OWNER)
+__device__ long long step_trace_buf[4096 * 8];
+#define STEP_STAMP(wg, slot) do { if (threadIdx.x == 0 && (wg) < 4096) step_trace_buf[(wg) * 8 + (slot)] = wall_clock64(); } while (0)
+#define STEP_NOTE(wg, slot, v) do { if (threadIdx.x == 0 && (wg) < 4096) step_trace_buf[(wg) * 8 + (slot)] = (v); } while (0)
+#else
+#define STEP_STAMP(wg, slot) do { } while (0)
+#define STEP_NOTE(wg, slot, v) do { } while (0)
+#endif
+#ifndef FFVD_SKINNY_CHUNK
+#define FFVD_SKINNY_CHUNK 1       // k blocks whose operands are in flight together: 2 and 4 measured no faster (profiles/r05_step_trace.txt)
+#endif
 __device__ __forceinline__ void skinny_body(const SkinnyArgs &a, const int bx, const int by, const int bzz) {
-    __shared__ double red[3][2][4][64];
+    __shared__ double red[4][2][4][64];
+    const int wg_lin = blockIdx.x + (int)gridDim.x * (blockIdx.y + (int)gridDim.y * blockIdx.z);
+    STEP_STAMP(wg_lin, 0);
     const int nslab1 = a.N / 16;
     const bool second = bx >= nslab1;
     const int n0 = (second ? bx - nslab1 : bx) * 16, r0 = by * 32, b = bzz;
@@ -136,8 +217,32 @@ __device__ __forceinline__ void skinny_body(const SkinnyArgs &a, const int bx, c
     d4 acc[2] = {(d4){0.0, 0.0, 0.0, 0.0}, (d4){0.0, 0.0, 0.0, 0.0}};
     // Inside a k block the four lane groups take k = 4 lk + s in MFMA s (a sum does not care about its order), so a lane reads
     // four CONSECUTIVE doubles of its A row (two 16-byte loads feed four MFMAs, 128-byte runs per row) instead of four 8-byte ones
-    const double *ap0 = Ab + (size_t)(r0 + lr) * a.lda + 4 * lk, *ap1 = ap0 + (size_t)16 * a.lda;
     const double *bp = Bb + (size_t)(4 * lk) * ldb + n0 + lr;
+    if (a.a_trans) {
+        const double *atp = Ab + (size_t)(4 * lk) * a.lda + r0 + lr;        // AT[k][row]: 16 lanes = 128 contiguous bytes
+        const size_t la = (size_t)a.lda;
+        constexpr int CH = FFVD_SKINNY_CHUNK;
+        // operands of up to CH k blocks in flight (the loads are one line per 16 lanes now: the loop is bound by their latency)
+        for (int kb = kb0; kb < kb1; kb += CH) {
+            double av[CH][8], bv[CH][4];
+#pragma unroll
+            for (int j = 0; j < CH; ++j)
+                if (kb + j < kb1) {
+                    const double *aq = atp + (size_t)(16 * (kb + j)) * la, *bq = bp + (size_t)(16 * (kb + j)) * ldb;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { av[j][e] = aq[e * la]; av[j][4 + e] = aq[e * la + 16]; bv[j][e] = bq[e * (size_t)ldb]; }
+                }
+#pragma unroll
+            for (int j = 0; j < CH; ++j)
+                if (kb + j < kb1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[0] = mfma_f64(av[j][e], bv[j][e], acc[0]); acc[1] = mfma_f64(av[j][4 + e], bv[j][e], acc[1]);
+                    }
+                }
+        }
+    } else {
+    const double *ap0 = Ab + (size_t)(r0 + lr) * a.lda + 4 * lk, *ap1 = ap0 + (size_t)16 * a.lda;
     for (int kb = kb0; kb < kb1; ++kb) {       // (the compiler does not unroll this loop; two blocks in flight by hand were no faster)
         const int k0 = 16 * kb;
         const d2 a0l = *reinterpret_cast<const d2 *>(ap0 + k0), a0h = *reinterpret_cast<const d2 *>(ap0 + k0 + 2);
@@ -149,35 +254,46 @@ __device__ __forceinline__ void skinny_body(const SkinnyArgs &a, const int bx, c
         acc[0] = mfma_f64(a0h.x, b2, acc[0]); acc[1] = mfma_f64(a1h.x, b2, acc[1]);
         acc[0] = mfma_f64(a0h.y, b3, acc[0]); acc[1] = mfma_f64(a1h.y, b3, acc[1]);
     }
-    if (w > 0) {
-#pragma unroll
-        for (int x = 0; x < 2; ++x)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) red[w - 1][x][q][lane] = acc[x][q];
     }
-    __syncthreads();
-    if (w == 0) {
-    const int slab = n0 / 16, nslab = second ? a.N2 / 16 : nslab1;
-    const double un = (a.u && !second) ? a.u[(size_t)b * a.u_stride + n0 + lr] : 0.0;
-    double *sqp = second ? a.sq2 : a.sq, *dotp = second ? nullptr : a.dot, *Cp = second ? nullptr : a.C;
+    STEP_STAMP(wg_lin, 1);
+    STEP_NOTE(wg_lin, 4, bx); STEP_NOTE(wg_lin, 5, kb1 > kb0 ? kb1 - kb0 : 0);
+    STEP_NOTE(wg_lin, 6, __builtin_amdgcn_s_getreg((31 << 11) | 4)); STEP_NOTE(wg_lin, 7, __builtin_amdgcn_s_getreg((31 << 11) | 20));   // HW_ID, XCC_ID
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const double c = ((acc[x][q] + red[0][x][q][lane]) + red[1][x][q][lane]) + red[2][x][q][lane];
-            const int row = r0 + 16 * x + lk + 4 * q;
-            if (Cp) Cp[(size_t)b * a.c_stride + (size_t)row * a.ldc + n0 + lr] = c;
-            double s2 = c * c, du = c * un;
-            s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2); s2 += __shfl_xor(s2, 4); s2 += __shfl_xor(s2, 8);
-            du += __shfl_xor(du, 1); du += __shfl_xor(du, 2); du += __shfl_xor(du, 4); du += __shfl_xor(du, 8);
-            if (lr == 0) {
-                const size_t o = ((size_t)b * nslab + slab) * a.Tp + row;
-                if (sqp) sqp[o] = s2;
-                if (dotp) dotp[o] = du;
-            }
+        for (int q = 0; q < 4; ++q) red[w][x][q][lane] = acc[x][q];
+    __syncthreads();
+    STEP_STAMP(wg_lin, 2);
+    {   // every wavefront finishes two of the eight 4-row groups; the four partial sums of an element are added in wavefront order
+    const int slab = n0 / 16, nslab = second ? a.N2 / 16 : nslab1;
+    const double un = (a.u && !second) ? a.u[(size_t)b * a.u_stride + n0 + lr] : 0.0;
+    double *sqp = second ? a.sq2 : a.sq, *dotp = second ? nullptr : a.dot, *Cp = second ? nullptr : a.C;
+    const int x = w >> 1;
+    double cv[2], s2[2], du[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int q = 2 * (w & 1) + h;
+        cv[h] = ((red[0][x][q][lane] + red[1][x][q][lane]) + red[2][x][q][lane]) + red[3][x][q][lane];
+        s2[h] = cv[h] * cv[h]; du[h] = cv[h] * un;
+    }
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { s2[h] += __shfl_xor(s2[h], m); du[h] += __shfl_xor(du[h], m); }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int q = 2 * (w & 1) + h, row = r0 + 16 * x + lk + 4 * q;
+        if (Cp) Cp[(size_t)b * a.c_stride + (size_t)row * a.ldc + n0 + lr] = cv[h];
+        if (lr == 0) {
+            const size_t o = ((size_t)b * nslab + slab) * a.Tp + row;
+            if (sqp) sqp[o] = s2[h];
+            if (dotp) dotp[o] = du[h];
         }
     }
+    }
     __syncthreads();      // (a persistent caller reuses `red`)
+    STEP_STAMP(wg_lin, 3);
 }
 
 __device__ __forceinline__ void conditional_finish_body(const int vb, int kind, const double *x, int N, int P, const double *variance,
