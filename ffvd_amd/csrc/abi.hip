@@ -3228,9 +3228,10 @@ extern "C" int ffvd_op_pg_sweep(int kind, const double *Lm_inverse_seq, const do
                 launch_skinny_gemm(sc.stream, Kf, (size_t)Tp * Mp, Tp, dW, (size_t)Mp * Mp, Mp, 1, R, Mp, Mp, D, Tp,
                                    nullptr, 0, 0, ucol, Mp, rowsq, fmean, nullptr, 0, 0, 0, nullptr, 1);
             } else { launch_kfu_build(sc.stream, pa); launch_proj_gemm(sc.stream, pg); }                                // conditional_after_kernel_precalculation (:95-97)
+            const double *ctrl_next = (C && t + 1 < steps) ? dctrl + (size_t)(t + 1) * C : nullptr;
             launch_conditional_finish(sc.stream, kind, dxc, R, P, variance, rowsq, fmean, ngs, Tp, D, dmean, dvar, nullptr);
             launch_pg_step(sc.stream, dmean, dvar, dlq, deps + (size_t)t * R * D, dun + (size_t)t * R, dY + (size_t)t * Ydim,
-                           dXr + (size_t)(t + 1) * D, dCC, dDD, dR, (C && t + 1 < steps) ? dctrl + (size_t)(t + 1) * C : nullptr,
+                           dXr + (size_t)(t + 1) * D, dCC, dDD, dR, ctrl_next,
                            R, D, C, Ydim, dxc, cand, dparts + (size_t)t * R * D, didx + (size_t)t * R);
         }
     };

@@ -381,14 +381,12 @@ constexpr int PG_MAXN = 1024, PG_MAXY = 8;
 // One particle-Gibbs step by ONE workgroup (pg_step_kernel: a thread per particle, STRIDED = 0; the persistent sweep: 256 threads,
 // a thread walks the particles i, i + 256, ...): the same arithmetic per particle either way.
 template <int STRIDED>
-__device__ __forceinline__ void pg_step_body(const double *mean, const double *var, const double *log_Q,
+__device__ __forceinline__ void pg_step_general_body(double *w, double *cdf, double &wmax_s, const double *mean, const double *var, const double *log_Q,
                                                           const double *eps_t, const double *unif_t, const double *y_t,
                                                           const double *x_ref_next, const double *CC, const double *DD,
                                                           const double *Rch, const double *ctrl_next, int R, int D, int C,
                                                           int Ydim, double *xc, double *cand, double *parts_next,
                                                           int32_t *idx_out) {
-    __shared__ double w[PG_MAXN], cdf[PG_MAXN];
-    __shared__ double wmax_s;
     const int N = R + 1, P = D + C, i0 = threadIdx.x, istep = STRIDED ? (int)blockDim.x : PG_MAXN;
     for (int i = i0; i < N; i += istep) {
         for (int p = 0; p < D; ++p) {
@@ -446,6 +444,143 @@ __device__ __forceinline__ void pg_step_body(const double *mean, const double *v
     }
     __syncthreads();      // (a persistent caller reuses w / cdf)
 }
+
+// The same step when D <= 8 and (R + 1) D <= PG_FAST_ND (the shapes the reference runs): the step's constants (exp(log_Q), CC, DD,
+// R's rows and log diagonal, y_t, the next controls) are read once into LDS, a particle's inputs are all in flight before the first
+// use, its candidate stays in registers and LDS (no store -> load trip through memory), loops over D and Ydim are unrolled with
+// predicates (no private-memory arrays), the max is a wavefront reduction.  Every expression is the general body's with the same
+// operands in the same order (stamps: 8.7 -> us inside the kernel, profiles/r05_step_trace.txt); the CDF stays ONE thread's
+// running sum in index order, as the oracle's cumsum.
+constexpr int PG_FAST_ND = 2048;
+template <int STRIDED>
+__device__ __forceinline__ void pg_step_fast_body(double *w, double *cdf, double &wmax_s, const double *mean, const double *var,
+                                                  const double *log_Q, const double *eps_t, const double *unif_t, const double *y_t,
+                                                  const double *x_ref_next, const double *CC, const double *DD, const double *Rch,
+                                                  const double *ctrl_next, int R, int D, int C, int Ydim, double *xc,
+                                                  double *parts_next, int32_t *idx_out) {
+    __shared__ double cands[PG_FAST_ND];
+    __shared__ double eq[8], CCs[64], DDs[8], ys[8], logd[8], Rs[64], ctl[MAXP], xref[8];
+    const int N = R + 1, P = D + C, tid = threadIdx.x, nt = blockDim.x, istep = STRIDED ? nt : PG_MAXN;
+    STEP_STAMP(4095, 0);
+    double v[8], mu[8], x0[8], e[8], un = 0.0;
+    auto load = [&](const int i) {
+        if (i < R) {
+#pragma unroll
+            for (int p = 0; p < 8; ++p)
+                if (p < D) { v[p] = var[i * D + p]; mu[p] = mean[i * D + p]; x0[p] = xc[i * P + p]; e[p] = eps_t[i * D + p]; }
+            un = unif_t[i];
+        }
+    };
+    int i = tid;
+    if (i < N) load(i);
+    for (int k = tid; k < D; k += nt) { eq[k] = exp(log_Q[k]); xref[k] = x_ref_next[k]; }
+    for (int k = tid; k < D * Ydim; k += nt) CCs[k] = CC[k];
+    for (int k = tid; k < Ydim * Ydim; k += nt) Rs[k] = Rch[k];
+    for (int k = tid; k < Ydim; k += nt) { DDs[k] = DD[k]; ys[k] = y_t[k]; logd[k] = log(Rch[k * Ydim + k]); }
+    if (ctrl_next) for (int k = tid; k < C; k += nt) ctl[k] = ctrl_next[k];
+    __syncthreads();
+    STEP_STAMP(4095, 6);
+    double unl = un;                             // (STRIDED: a thread's particles are resampled in the same order below)
+    for (; i < N;) {
+        double xn[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+            if (p < D) {
+                if (i < R) {
+                    const double vv = v[p] + eq[p];
+                    xn[p] = (mu[p] + x0[p]) + e[p] * sqrt(vv);                                 // :99-101
+                } else xn[p] = xref[p];                                                        // :111
+                cands[i * D + p] = xn[p];
+            }
+        STEP_STAMP(4095, 7);
+        // logdensity_norm(Y[tt], predict_mean(x), Rchols), likelihoods.py:76-79,114-127
+        double a[PG_MAXY], q = 0.0, ld = 0.0;
+#pragma unroll
+        for (int j = 0; j < PG_MAXY; ++j)
+            if (j < Ydim) {
+                double ym = 0.0;
+#pragma unroll
+                for (int d = 0; d < 8; ++d)
+                    if (d < D) ym += xn[d] * CCs[d * Ydim + j];
+                ym += DDs[j];
+                double r = ys[j] - ym;
+#pragma unroll
+                for (int k = 0; k < j; ++k) r -= Rs[j * Ydim + k] * a[k];
+                a[j] = r / Rs[j * Ydim + j];
+                q += a[j] * a[j];
+                ld += logd[j];
+            }
+        w[i] = -0.5 * q + (-ld);
+        i += istep;
+        if (STRIDED && i < N) load(i);
+    }
+    STEP_STAMP(4095, 1);
+    __syncthreads();
+    if (tid < 64) {                              // max over the particles: a wavefront reduction (a max does not care about its order)
+        double m = w[0];
+        for (int k = tid; k < N; k += 64) m = (w[k] > m) ? w[k] : m;
+#pragma unroll
+        for (int sft = 1; sft < 64; sft <<= 1) { const double o = __shfl_xor(m, sft); m = (o > m) ? o : m; }
+        if (tid == 0) wmax_s = m;
+    }
+    __syncthreads();
+    STEP_STAMP(4095, 2);
+    for (int k = tid; k < N; k += istep) w[k] = exp(w[k] - wmax_s);
+    __syncthreads();
+    STEP_STAMP(4095, 3);
+    if (tid == 0) {                              // the running sum in index order, eight reads ahead of the dependent adds
+        double c = 0.0;
+        int k = 0;
+        for (; k + 8 <= N; k += 8) {
+            double t8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t8[u] = w[k + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { c += t8[u]; cdf[k + u] = c; }
+        }
+        for (; k < N; ++k) { c += w[k]; cdf[k] = c; }
+    }
+    __syncthreads();
+    STEP_STAMP(4095, 4);
+    for (int r = tid; r < R; r += istep) {
+        const double target = (STRIDED ? unif_t[r] : unl) * cdf[N - 1];
+        int lo = 0, hi = N;                      // first k with cdf[k] > target
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cdf[mid] > target) hi = mid; else lo = mid + 1;
+        }
+        const int k = (lo < N) ? lo : N - 1;
+        idx_out[r] = k;
+        for (int p = 0; p < D; ++p) {
+            const double x = cands[k * D + p];
+            parts_next[(size_t)r * D + p] = x;
+            xc[r * P + p] = x;
+        }
+        if (ctrl_next)
+            for (int c = 0; c < C; ++c) xc[r * P + D + c] = ctl[c];
+    }
+    __syncthreads();      // (a persistent caller reuses the LDS blocks)
+    STEP_STAMP(4095, 5);
+}
+
+// One particle-Gibbs step by one workgroup; the shapes decide the form (both forms of a caller -- per-step launch, persistent
+// sweep -- come through here, so they agree bit for bit).
+template <int STRIDED>
+__device__ __forceinline__ void pg_step_body(const double *mean, const double *var, const double *log_Q,
+                                             const double *eps_t, const double *unif_t, const double *y_t,
+                                             const double *x_ref_next, const double *CC, const double *DD,
+                                             const double *Rch, const double *ctrl_next, int R, int D, int C,
+                                             int Ydim, double *xc, double *cand, double *parts_next, int32_t *idx_out) {
+    __shared__ double w[PG_MAXN], cdf[PG_MAXN];
+    __shared__ double wmax_s;
+    if (D <= 8 && (R + 1) * D <= PG_FAST_ND)
+        pg_step_fast_body<STRIDED>(w, cdf, wmax_s, mean, var, log_Q, eps_t, unif_t, y_t, x_ref_next, CC, DD, Rch, ctrl_next, R, D, C, Ydim,
+                                   xc, parts_next, idx_out);
+    else
+        pg_step_general_body<STRIDED>(w, cdf, wmax_s, mean, var, log_Q, eps_t, unif_t, y_t, x_ref_next, CC, DD, Rch, ctrl_next, R, D, C,
+                                      Ydim, xc, cand, parts_next, idx_out);
+}
+
 
 // ---- one persistent launch per step loop (loops.hip) ------------------------------------------------------------------------------
 struct RolloutLoopArgs {

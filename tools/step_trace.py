@@ -20,6 +20,8 @@ lib = ctypes.CDLL(_lib.LIB_PATH)
 buf = np.zeros(4096 * 8, dtype=np.int64)
 assert lib.ffvd_debug_step_trace(buf.ctypes.data_as(ctypes.c_void_p)) == 0
 raw = buf.reshape(4096, 8)
+pg = raw[4095].astype(np.float64) / 100.0
+raw = raw[:4095]
 live = raw[:, 0] > 0
 st = raw[live, :4].astype(np.float64) / 100.0      # us (100 MHz wall clock)
 slab, iters = raw[live, 4], raw[live, 5]
@@ -48,3 +50,7 @@ print("compute units used: %d (XCCs %d); workgroups per CU: min %d max %d; k ite
       (len(per_cu), len(set(xcc.tolist())), min(len(v) for v in per_cu.values()), max(len(v) for v in per_cu.values()), loads.min(), np.median(loads), loads.max()))
 print("first CUs' workgroups (iterations each):", [sorted(v) for v in list(per_cu.values())[:12]])
 print("HW_ID samples:", [hex(int(x)) for x in hw[:8]], "XCC_ID:", [int(x) for x in xcc[:16]])
+if pg[0] > 0:
+    print("pg_step: constants + first loads %.2f, candidates %.2f, weights %.2f us" % (pg[6] - pg[0], pg[7] - pg[6], pg[1] - pg[7]))
+    print("pg_step (one workgroup), us: candidates + weights %.2f, max %.2f, exp %.2f, cdf %.2f, resample + gather %.2f; total %.2f" %
+          (pg[1] - pg[0], pg[2] - pg[1], pg[3] - pg[2], pg[4] - pg[3], pg[5] - pg[4], pg[5] - pg[0]))
