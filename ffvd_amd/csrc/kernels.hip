@@ -22,6 +22,9 @@
 #define FFVD_STEP_TRACE_OWNER
 #include "step_bodies.h"
 #if defined(FFVD_STEP_TRACE)
+extern "C" int ffvd_debug_step_spans(unsigned long long *out) {      // [64 steps][4 kernels][first workgroup's start, a late end]
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ffvd::step_span), sizeof(unsigned long long) * 64 * 4 * 2);
+}
 extern "C" int ffvd_debug_step_trace(long long *out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ffvd::step_trace_buf), sizeof(long long) * 4096 * 8);
 }

@@ -106,6 +106,26 @@ __device__ __forceinline__ void kfu_build_body(const ProjectArgs &a, const int b
     __syncthreads();      // (a persistent caller reuses the LDS tiles for its next block)
 }
 
+// Debug build only (-DFFVD_STEP_TRACE, variant `steptrace`, tools/step_trace.py): wall-clock stamps of every workgroup of the last
+// skinny launch (start, operands of the first k block there, k loop done, end) -- kernels.hip owns the buffer.
+#if defined(FFVD_STEP_TRACE) && defined(FFVD_STEP_TRACE_OWNER)
+__device__ long long step_trace_buf[4096 * 8];
+#define STEP_STAMP(wg, slot) do { if (threadIdx.x == 0 && (wg) < 4096) step_trace_buf[(wg) * 8 + (slot)] = wall_clock64(); } while (0)
+#define STEP_NOTE(wg, slot, v) do { if (threadIdx.x == 0 && (wg) < 4096) step_trace_buf[(wg) * 8 + (slot)] = (v); } while (0)
+// first start / last end of each of a step's kernels, for the first 64 steps of the process (0: K build, 1: product, 2: epilogue, 3: step)
+__device__ int step_span_ctr;
+__device__ unsigned long long step_span[64 * 4 * 2];
+// (plain stores: the first workgroup's start, and whichever end stamp lands last -- atomics from 512 workgroups stretch the kernels)
+#define STEP_SPAN_BEGIN(k) do { if (threadIdx.x == 0 && blockIdx.x + blockIdx.y + blockIdx.z == 0 && step_span_ctr < 64) step_span[(step_span_ctr * 4 + (k)) * 2] = (unsigned long long)wall_clock64(); } while (0)
+#define STEP_SPAN_END(k) do { if (threadIdx.x == 0 && step_span_ctr < 64) step_span[(step_span_ctr * 4 + (k)) * 2 + 1] = (unsigned long long)wall_clock64(); } while (0)
+#define STEP_SPAN_NEXT() do { if (threadIdx.x == 0) step_span_ctr = step_span_ctr + 1; } while (0)
+#else
+#define STEP_STAMP(wg, slot) do { } while (0)
+#define STEP_NOTE(wg, slot, v) do { } while (0)
+#define STEP_SPAN_BEGIN(k) do { } while (0)
+#define STEP_SPAN_END(k) do { } while (0)
+#define STEP_SPAN_NEXT() do { } while (0)
+#endif
 // K(x, Z) of a step stored TRANSPOSED, KT[b][m][ldt] (m-major, the step's rows contiguous): what the skinny product below wants as
 // its A operand -- an MFMA lane holds one ROW's value, so with row-major K a 16-lane group reads 16 rows 4 KB apart (16 cache lines
 // per load, the texture addresser's limit: 1.1 us per k block measured by stamps, profiles/r05_step_trace.txt); m-major the same lanes
@@ -119,6 +139,7 @@ __device__ __forceinline__ void kfu_build_t_body(const ProjectArgs &a, const int
     __shared__ double zs[4 * MW][(SMALLP ? 8 : MAXP) + 1];
     __shared__ double zzs[4 * MW];
     const int tid = threadIdx.x, lane = tid & 63;
+    STEP_SPAN_BEGIN(0);
     const int t0 = bx * 64, m0 = by * (4 * MW), bz = bzz;
     const int b = a.b0 + bz, dl = b % a.Dl, s = b / a.Dl;
     const int P = a.P, Mp = a.Mp;
@@ -169,6 +190,7 @@ __device__ __forceinline__ void kfu_build_t_body(const ProjectArgs &a, const int
         if (!tok || m0 + m >= a.M) v = 0.0;
         out[(size_t)m * ldt] = v;
     }
+    STEP_SPAN_END(0);
 }
 
 struct SkinnyArgs {
@@ -186,16 +208,6 @@ struct SkinnyArgs {
     int a_trans;                                    // A is stored k-major, AT[b][K][lda] (kfu_build_t_body): coalesced operand loads
 };
 
-// Debug build only (-DFFVD_STEP_TRACE, variant `steptrace`, tools/step_trace.py): wall-clock stamps of every workgroup of the last
-// skinny launch (start, operands of the first k block there, k loop done, end) -- kernels.hip owns the buffer.
-#if defined(FFVD_STEP_TRACE) && defined(FFVD_STEP_TRACE_OWNER)
-__device__ long long step_trace_buf[4096 * 8];
-#define STEP_STAMP(wg, slot) do { if (threadIdx.x == 0 && (wg) < 4096) step_trace_buf[(wg) * 8 + (slot)] = wall_clock64(); } while (0)
-#define STEP_NOTE(wg, slot, v) do { if (threadIdx.x == 0 && (wg) < 4096) step_trace_buf[(wg) * 8 + (slot)] = (v); } while (0)
-#else
-#define STEP_STAMP(wg, slot) do { } while (0)
-#define STEP_NOTE(wg, slot, v) do { } while (0)
-#endif
 #ifndef FFVD_SKINNY_CHUNK
 #define FFVD_SKINNY_CHUNK 1       // k blocks whose operands are in flight together: 2 and 4 measured no faster (profiles/r05_step_trace.txt)
 #endif
@@ -203,6 +215,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyArgs &a, const int bx, c
     __shared__ double red[4][2][4][64];
     const int wg_lin = blockIdx.x + (int)gridDim.x * (blockIdx.y + (int)gridDim.y * blockIdx.z);
     STEP_STAMP(wg_lin, 0);
+    STEP_SPAN_BEGIN(1);
     const int nslab1 = a.N / 16;
     const bool second = bx >= nslab1;
     const int n0 = (second ? bx - nslab1 : bx) * 16, r0 = by * 32, b = bzz;
@@ -294,12 +307,14 @@ __device__ __forceinline__ void skinny_body(const SkinnyArgs &a, const int bx, c
     }
     __syncthreads();      // (a persistent caller reuses `red`)
     STEP_STAMP(wg_lin, 3);
+    STEP_SPAN_END(1);
 }
 
 __device__ __forceinline__ void conditional_finish_body(const int vb, int kind, const double *x, int N, int P, const double *variance,
                                           const double *rowsq, const double *fmean, int ng, int Tp, int D,
                                           double *mean, double *var, const double *extra /*[D][extra_ng][Tp] or null*/,
                                           int extra_ng) {
+    STEP_SPAN_BEGIN(2);
     const int idx = (vb * 256 + (int)threadIdx.x) >> 4, l = threadIdx.x & 15;
     const bool live = idx < N * D;
     const int n = live ? idx / D : 0, d = live ? idx % D : 0;
@@ -312,6 +327,7 @@ __device__ __forceinline__ void conditional_finish_body(const int vb, int kind, 
         for (int g = l; g < extra_ng; g += 16) ex += extra[((size_t)d * extra_ng + g) * Tp + n];
 #pragma unroll
     for (int m = 1; m < 16; m <<= 1) { rs += __shfl_xor(rs, m); fm += __shfl_xor(fm, m); ex += __shfl_xor(ex, m); }
+    STEP_SPAN_END(2);                            // (before the 8-byte stores of the lane-0s)
     if (!live || l != 0) return;
     double kd = variance[d];
     if (kind == 1) {
@@ -462,6 +478,7 @@ __device__ __forceinline__ void pg_step_fast_body(double *w, double *cdf, double
     __shared__ double eq[8], CCs[64], DDs[8], ys[8], logd[8], Rs[64], ctl[MAXP], xref[8];
     const int N = R + 1, P = D + C, tid = threadIdx.x, nt = blockDim.x, istep = STRIDED ? nt : PG_MAXN;
     STEP_STAMP(4095, 0);
+    STEP_SPAN_BEGIN(3);
     double v[8], mu[8], x0[8], e[8], un = 0.0;
     auto load = [&](const int i) {
         if (i < R) {
@@ -529,7 +546,7 @@ __device__ __forceinline__ void pg_step_fast_body(double *w, double *cdf, double
     __syncthreads();
     STEP_STAMP(4095, 3);
     if (tid == 0) {                              // the running sum in index order, eight reads ahead of the dependent adds
-        double c = 0.0;
+        double c = 0.0;                          // (35 cycles per element; the next block's reads in flight during the adds: no faster)
         int k = 0;
         for (; k + 8 <= N; k += 8) {
             double t8[8];
@@ -561,6 +578,8 @@ __device__ __forceinline__ void pg_step_fast_body(double *w, double *cdf, double
     }
     __syncthreads();      // (a persistent caller reuses the LDS blocks)
     STEP_STAMP(4095, 5);
+    STEP_SPAN_END(3);
+    STEP_SPAN_NEXT();
 }
 
 // One particle-Gibbs step by one workgroup; the shapes decide the form (both forms of a caller -- per-step launch, persistent

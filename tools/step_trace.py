@@ -54,3 +54,13 @@ if pg[0] > 0:
     print("pg_step: constants + first loads %.2f, candidates %.2f, weights %.2f us" % (pg[6] - pg[0], pg[7] - pg[6], pg[1] - pg[7]))
     print("pg_step (one workgroup), us: candidates + weights %.2f, max %.2f, exp %.2f, cdf %.2f, resample + gather %.2f; total %.2f" %
           (pg[1] - pg[0], pg[2] - pg[1], pg[3] - pg[2], pg[4] - pg[3], pg[5] - pg[4], pg[5] - pg[0]))
+sp = np.zeros(64 * 4 * 2, dtype=np.uint64)
+if hasattr(lib, "ffvd_debug_step_spans") and lib.ffvd_debug_step_spans(sp.ctypes.data_as(ctypes.c_void_p)) == 0:
+    sp = sp.reshape(64, 4, 2).astype(np.float64)
+    start, end = sp[:, :, 0] / 100.0, sp[:, :, 1] / 100.0
+    ok = np.arange(8, 63)                          # steady steps
+    names = ("K build", "product", "epilogue", "step")
+    print("timeline of a step, untraced (median over steps 8..62, us): " + ", ".join(
+        "%s %.2f" % (names[k], np.median(end[ok, k] - start[ok, k])) for k in range(4)))
+    print("   gaps: " + ", ".join("%s -> %s %.2f" % (names[k], names[(k + 1) % 4], np.median((start[ok, k + 1] if k < 3 else start[ok + 1, 0]) - end[ok, k])) for k in range(4)))
+    print("   step period %.2f us" % np.median(start[ok + 1, 0] - start[ok, 0]))
