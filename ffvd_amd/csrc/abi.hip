@@ -3089,7 +3089,10 @@ extern "C" int ffvd_op_rollout(int kind, const double *Lm_inverse_seq, const dou
     //  the Gram kernel's tail exchange: 10.1-11.8 us per step at 16 rollouts, 13.6-17.9 at 32, 20.5-27 at 64.  The default up to 32 rollouts.)
     // (Third measurement, the products' MFMA section branch-free per chunk: 10.4-12.5 / 12.5-15.4 / 17.9-22.5 us per step.  The default
     //  wherever it applies: up to 64 rollouts, M <= 512, 8 latent dims.)
-    const bool resident = skinny && rollout_resident_ok(R, D, P, Mp) && (loop_mode == 2 || loop_mode < 0);
+    // (Round 5: with K^T operands, the XCD-mapped grid and long / short slabs paired per CU the per-step launches take 15.4-15.6 us
+    //  (18.4-21.8 with q_sqrt) from 40 to 64 rollouts, the resident loop 16.6-18.6 (20.3-23.4); at 32: 15.0 / 16.6 against 12.7 / 14.9,
+    //  profiles/r05_rollout_modes.txt -- the resident loop is the default up to 32 rollouts, FFVD_STEP_LOOP=2 asks for it up to 64.)
+    const bool resident = skinny && rollout_resident_ok(R, D, P, Mp) && (loop_mode == 2 || (loop_mode < 0 && R <= 32));
     const bool use_loop = skinny && loop_mode == 1;
     bool resident_done = false;
     if (resident) {

@@ -617,7 +617,7 @@ def test_step_loops_equal_the_per_step_launches(monkeypatch):
         for a, b in zip(out["loop"], out["launches"]):
             np.testing.assert_array_equal(a[0], b[0])
             np.testing.assert_array_equal(a[1], b[1])
-        # the rollout loop with resident operands (FFVD_STEP_LOOP=2; the default up to 64 rollouts with M <= 512 and 8 latent dims;
+        # the rollout loop with resident operands (FFVD_STEP_LOOP=2; the default up to 32 rollouts, on request up to 64, with M <= 512 and 8 latent dims;
         # 100 rollouts fall back to the launches): other summation order inside a row of F, same values to rounding
         for a, b in zip(out["resident"][:2], out["launches"][:2]):
             np.testing.assert_allclose(a[0], b[0], rtol=1e-9, atol=1e-10)
