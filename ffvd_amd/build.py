@@ -152,6 +152,8 @@ VARIANTS = {
     # the resident rollout loop with release / acquire fences at its hand-offs (inside the HIP memory model; tests compare both forms)
     "rrfenced": ("loops.hip", ["-DFFVD_RR_FENCED"]),
     # wall-clock stamps of every workgroup of the skinny product of a rollout / particle-Gibbs step (tools/step_trace.py)
+    # wall-clock stamps of every workgroup of the fused backward product (tools/bwd_trace.py)
+    "bwdtrace": ("grad.hip", ["-DFFVD_BWD_TRACE"]),
     "steptrace": ["-DFFVD_STEP_TRACE"], "steptrace4": ["-DFFVD_STEP_TRACE", "-DFFVD_SKINNY_CHUNK=4"],
 }
 

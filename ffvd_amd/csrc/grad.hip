@@ -493,9 +493,25 @@ __device__ __forceinline__ TileAcc gemm_rowmajor_a(double (*As)[AT][A_LDT], doub
 // Row partials go out per column tile (rp), column partials per 64-row block; row_combine_kernel adds the former.
 // ---------------------------------------------------------------------------------------------
 constexpr int XW_LD = 128 + 4;
+// Debug build only (-DFFVD_BWD_TRACE, variant `bwdtrace`, tools/bwd_trace.py): per workgroup of the last bwd_fused launch the wall clock
+// at its start, after the main loop, at the epilogue's phases and at its end, and where it ran (HW_ID, XCC_ID).
+#ifdef FFVD_BWD_TRACE
+__device__ long long bwd_trace_buf[16384 * 8];
+}  // namespace ffvd
+extern "C" int ffvd_debug_bwd_trace(long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ffvd::bwd_trace_buf), sizeof(long long) * 16384 * 8);
+}
+namespace ffvd {
+#define BWD_STAMP(slot) do { if (threadIdx.x == 0 && blockIdx.x < 16384) bwd_trace_buf[blockIdx.x * 8 + (slot)] = wall_clock64(); } while (0)
+#define BWD_WHERE() do { if (threadIdx.x == 0 && blockIdx.x < 16384) bwd_trace_buf[blockIdx.x * 8 + 3] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf) << 32); } while (0)
+#else
+#define BWD_STAMP(slot) do { } while (0)
+#define BWD_WHERE() do { } while (0)
+#endif
 __global__ __launch_bounds__(512, 4) void bwd_fused_kernel(BwdFusedArgs a) {
     __shared__ double As[2][AT][A_LDT];
     __shared__ double Bs[2][AT][A_LD];
+    BWD_STAMP(0); BWD_WHERE();
     // XCD-aware order (speed only): consecutive workgroup ids go to the 8 XCDs round-robin, each with its own L2.  The ntj column
     // tiles of one 128-row panel of K_fu (they read the same 128 x Mp rows) take ids 8 apart, i.e. the same XCD, back to back
     // (5.24-5.33 against 5.29-5.35 ms at config 2, alternating runs on one box).
@@ -516,6 +532,7 @@ __global__ __launch_bounds__(512, 4) void bwd_fused_kernel(BwdFusedArgs a) {
     const RowMajorTile rt{ti, tj, tid, lane, wr, wc, lr, lk};
     TileAcc res = gemm_rowmajor_a(As, Bs, rt, Kfb, Tp, Gb, Mp, Mp, 1 << 30);
     d4 (&acc)[4][2] = res.v;
+    BWD_STAMP(1);
 #if defined(BWD_DIAG) && BWD_DIAG == 1      // diagnostic build (tools/build_grad_variant.sh): main loop only
     {
         double v = 0.0;
@@ -575,6 +592,7 @@ __global__ __launch_bounds__(512, 4) void bwd_fused_kernel(BwdFusedArgs a) {
 #pragma unroll
     for (int y = 0; y < 2; ++y) uj[y] = jok[y] ? ub[jc[y]] : 0.0;
     __syncthreads();
+    BWD_STAMP(4);
     // One 16-row strip (x) of the wavefront's 64 x 32 block at a time, so that its accumulators die as the loop advances:
     //   e in place of g, the kfu partial over the wavefront's 32 columns (16-lane DPP sum);
     //   columns: [cs; etx] += [1; x^T] e -- the accumulator layout of e IS the B-operand layout with k = rows;
@@ -629,6 +647,7 @@ __global__ __launch_bounds__(512, 4) void bwd_fused_kernel(BwdFusedArgs a) {
             for (int q = 0; q < 4; ++q) RPw[(wr * 64 + 16 * x + lk + 4 * q) * 8 + lr] = r4[q];
         }
     }
+    BWD_STAMP(5);
     {       // column partials of the 64-row block (ti, wr)
         const int nblk = Tp / 64, blk = ti * 2 + wr;
 #pragma unroll
@@ -646,6 +665,7 @@ __global__ __launch_bounds__(512, 4) void bwd_fused_kernel(BwdFusedArgs a) {
         }
     }
     __syncthreads();
+    BWD_STAMP(6);
     for (int idx = tid; idx < 128 * 8; idx += 512) {
         const int row = idx >> 3, c = idx & 7;
         const int t = ti * 128 + row;
@@ -653,6 +673,7 @@ __global__ __launch_bounds__(512, 4) void bwd_fused_kernel(BwdFusedArgs a) {
         const double v = (RPlo[row * 8 + c] + RPlo[128 * 8 + row * 8 + c]) + (RPhi[row * 8 + c] + RPhi[128 * 8 + row * 8 + c]);
         a.rp[(((size_t)tj * a.nb + bz) * Tp + t) * 8 + c] = v;
     }
+    BWD_STAMP(2);
 }
 
 // Adds the row partials of the column tiles and forms the per-block sums rx2[p] = sum_t r_t x_tp^2.
