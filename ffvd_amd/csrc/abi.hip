@@ -2359,6 +2359,8 @@ struct OpCache {
     size_t total = 0;
     hipStream_t stream = nullptr;
     int device = -1;
+    void *pinned = nullptr;             // page-locked staging block for large results (a device-to-host copy into fresh pageable memory
+    size_t pinned_bytes = 0;            //  pins its pages on the fly: 13 MB took up to 30 ms; through this block + memcpy: ~3)
     void release_idle() {
         std::vector<Block> keep;
         for (Block &b : blocks) {
@@ -2370,6 +2372,7 @@ struct OpCache {
     void release_all() {
         release_idle();
         if (stream && blocks.empty()) { hipStreamDestroy(stream); stream = nullptr; }
+        if (pinned) { hipHostFree(pinned); pinned = nullptr; pinned_bytes = 0; }
     }
     ~OpCache() { /* process exit: the runtime may already be gone; leave the memory to it */ }
 };
@@ -2424,6 +2427,25 @@ struct Scratch {
         static const bool poison = [] { const char *e = getenv("FFVD_OP_CACHE_POISON"); return e && *e && strcmp(e, "0") != 0; }();
         if (poison && stream) (void)hipMemsetAsync(c.blocks[best].p, 0xFF, c.blocks[best].bytes, stream);
         return (T *)c.blocks[best].p;
+    }
+    // device -> host for a large result: through the thread's page-locked block when it has (or gets) one of that size, else directly.
+    // Synchronises the stream.
+    bool download(void *dst, const void *src, size_t bytes) {
+        OpCache &c = g_op_cache;
+        if (bytes >= ((size_t)1 << 20) && bytes <= ((size_t)256 << 20)) {
+            if (c.pinned_bytes < bytes) {
+                if (c.pinned) { hipHostFree(c.pinned); c.pinned = nullptr; c.pinned_bytes = 0; }
+                if (hipHostMalloc(&c.pinned, bytes, hipHostMallocDefault) == hipSuccess) c.pinned_bytes = bytes;
+                else { (void)hipGetLastError(); c.pinned = nullptr; }
+            }
+            if (c.pinned) {
+                if (hipMemcpyAsync(c.pinned, src, bytes, hipMemcpyDeviceToHost, stream) != hipSuccess) return false;
+                if (hipStreamSynchronize(stream) != hipSuccess) return false;
+                memcpy(dst, c.pinned, bytes);
+                return true;
+            }
+        }
+        return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream) == hipSuccess && hipStreamSynchronize(stream) == hipSuccess;
     }
     double *upload(const double *src, size_t n) {
         double *d = alloc<double>(n);
@@ -3263,11 +3285,22 @@ extern "C" int ffvd_op_pg_sweep(int kind, const double *Lm_inverse_seq, const do
             HIP_TRY(hipMemcpyAsync(dxc, xc0.data(), xc0.size() * sizeof(double), hipMemcpyHostToDevice, sc.stream));
             step_launches();
         }
-    } else step_launches();
+    } else {
+        const bool timing = getenv("FFVD_PG_TIMING") != nullptr;          // debug: how long the host takes to enqueue the sweep
+        const auto t0 = std::chrono::steady_clock::now();
+        step_launches();
+        if (timing) {
+            const auto t1 = std::chrono::steady_clock::now();
+            hipStreamSynchronize(sc.stream);
+            const auto t2 = std::chrono::steady_clock::now();
+            fprintf(stderr, "ffvd_op_pg_sweep: %d steps enqueued in %.2f ms, drained %.2f ms later\n", steps,
+                    std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t1).count());
+        }
+    }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(particles + (size_t)R * D, dparts, (size_t)steps * R * D * sizeof(double), hipMemcpyDeviceToHost, sc.stream));
-    HIP_TRY(hipMemcpyAsync(idx, didx, (size_t)steps * R * sizeof(int32_t), hipMemcpyDeviceToHost, sc.stream));
-    HIP_TRY(hipStreamSynchronize(sc.stream));
+    if (!sc.download(particles + (size_t)R * D, dparts, (size_t)steps * R * D * sizeof(double)) ||
+        !sc.download(idx, didx, (size_t)steps * R * sizeof(int32_t)))
+        return set_error(nullptr, FFVD_EDEVICE, "ffvd_op_pg_sweep: copying the results to the host failed");
     return FFVD_OK;
 }
 
