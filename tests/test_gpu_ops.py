@@ -354,6 +354,42 @@ def test_rollout_matches_oracle(name, R, steps, with_q):
     np.testing.assert_array_equal(px2[0], px2[-1])
 
 
+def test_step_kernels_with_more_than_eight_inputs():
+    """The m-major K build of a step has a general form for P = D + C > 8 inputs (no zero-padded 8-component rows), the one-workgroup
+    particle-Gibbs step one for D > 8 latent dims: rollouts (with q_sqrt) and a sweep at D = 9, C = 2 against the CPU restatement."""
+    from ffvd_amd import conditionals_multi_output as cmo
+    from ffvd_amd.prediction import rollout, pg_sweep
+    from ffvd_amd.kernels import SquaredExponential
+    from oracle import ffvd_pg_oracle as pgo
+    params, Y, c, meta = synthetic.make_named("tiny", D=9, C=2)
+    D, C, T = meta["D"], meta["C"], meta["T"]
+    X = params["X"][0]
+    Q = np.exp(params["log_Q"])
+    okern = orc.make_kernels(params)
+    kern = [SquaredExponential(D + C, variance=np.exp(params["logvariance"][d]),
+                               lengthscales=np.exp(params["loglengthscales"][d])) for d in range(D)]
+    rng = np.random.default_rng(8)
+    R, steps = 5, 6
+    ctrl = np.concatenate((c, rng.standard_normal((steps, C))))
+    eps = rng.standard_normal((steps, R, D))
+    xc = np.concatenate((X[:-1], c), axis=1)
+    Lo = orc.kernel_pre_cal(params["Z"], okern)
+    Uo, Ho = orc.collapse_u_mean_after_kernel_precalculation(Lo, xc, X, params["Z"], okern, Q)
+    px_o, pv_o = orc.rollout(Lo, params["Z"], okern, Uo, Ho, X[-1], ctrl, T, steps, Q, eps)
+    Lg = cmo.kernel_pre_cal(params["Z"], kern)
+    Ug, Hg = cmo.collapse_u_mean_after_kernel_precalculation(Lg, xc, X, params["Z"], kern, Q)
+    px, pv = rollout(Lg, params["Z"], kern, Ug, Hg, X[-1], ctrl, T, steps, Q, eps)
+    np.testing.assert_allclose(px, px_o, rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(pv, pv_o, rtol=1e-8, atol=1e-10)
+    N = 7
+    x0, epg, u = rng.standard_normal((N - 1, D)), rng.standard_normal((T, N - 1, D)), rng.random((T, N - 1))
+    Rch = np.exp(params["log_Rchols"])
+    po, io = pgo.pg_sweep(Lo, params["Z"], okern, params["U"], X, Y, c, params["CC"], params["DD"], Rch, Q, x0, epg, u)
+    pg, ig = pg_sweep(Lg, params["Z"], kern, params["U"], X, Y, c, params["CC"], params["DD"], Rch, Q, x0, epg, u)
+    np.testing.assert_array_equal(ig, io)
+    np.testing.assert_allclose(pg, po, rtol=1e-9, atol=1e-10)
+
+
 _RR_SCRIPT = r"""
 import sys
 import numpy as np
