@@ -438,6 +438,53 @@ def test_rollout_resident_loop_fenced_build_agrees(tmp_path):
     np.testing.assert_array_equal(outs["product"]["pv"], outs["rrfenced"]["pv"])
 
 
+_GRID_SCRIPT = r"""
+import sys
+import numpy as np
+from ffvd_amd import synthetic, conditionals_multi_output as cmo
+from ffvd_amd.prediction import rollout
+from ffvd_amd.kernels import SquaredExponential
+out = {}
+for D, R in ((1, 37), (2, 70), (3, 33), (5, 100), (6, 64), (7, 37), (8, 129)):
+    params, Y, c, meta = synthetic.make_named("small", D=D)
+    C, T = meta["C"], meta["T"]
+    X = params["X"][0]
+    Q = np.exp(params["log_Q"])
+    kern = [SquaredExponential(D + C, variance=np.exp(params["logvariance"][d]), lengthscales=np.exp(params["loglengthscales"][d])) for d in range(D)]
+    rng = np.random.default_rng(D)
+    steps = 6
+    ctrl = np.concatenate((c, rng.standard_normal((steps, C))))
+    eps = rng.standard_normal((steps, R, D))
+    xc = np.concatenate((X[:-1], c), axis=1)
+    Lg = cmo.kernel_pre_cal(params["Z"], kern)
+    Ug, Hg = cmo.collapse_u_mean_after_kernel_precalculation(Lg, xc, X, params["Z"], kern, Q)
+    for q in (0, 1):
+        px, pv = rollout(Lg, params["Z"], kern, Ug, Hg if q else None, X[-1], ctrl, T, steps, Q, eps)
+        out["px%d_%d" % (D, q)], out["pv%d_%d" % (D, q)] = px, pv
+np.savez(sys.argv[1], **out)
+"""
+
+
+def test_skinny_product_grid_is_only_a_placement(tmp_path):
+    """Round 5: the skinny product of a step runs on a 1-D grid that maps each latent dim to its own XCDs and walks every other block
+    of 32 slots backwards (long and short triangular slabs share a CU).  Which workgroup computes which (slab, row group) must not
+    change a bit: rollouts with 1 to 8 latent dims (1, 2, 3 XCDs per dim; with and without the q_sqrt right-hand side; 2 to 5 row
+    groups) through the mapped grid and through the plain 3-D grid (FFVD_SKINNY_GRID3D=1)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for name, extra in (("mapped", {}), ("grid3d", {"FFVD_SKINNY_GRID3D": "1"})):
+        env = dict(os.environ, PYTHONPATH=root, FFVD_STEP_LOOP="0", **extra)
+        path = str(tmp_path / f"{name}.npz")
+        out = subprocess.run([sys.executable, "-c", _GRID_SCRIPT, path], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        outs[name] = np.load(path)
+    assert len(outs["mapped"].files) == 28
+    for k in outs["mapped"].files:
+        np.testing.assert_array_equal(outs["mapped"][k], outs["grid3d"][k], err_msg=k)
+
+
 _CACHE_SCRIPT = r"""
 import sys
 import numpy as np
