@@ -13,6 +13,7 @@
 // Dense contractions run on the fp64 MFMA through one general batched C = A^T B kernel.
 #include "kernels.h"
 #include "grad.h"
+#include <cstdint>
 
 namespace ffvd {
 
@@ -408,6 +409,13 @@ struct RowMajorTile {
     int ti, tj, tid, lane, wr, wc, lr, lk;
 };
 struct TileAcc { d4 v[4][2]; };
+// Refill of the next chunk (round 5; tools/probes/chunk_probe.hip, profiles/r05_chunk_probe.txt: with both operands register-staged one
+// chunk ahead and stored in front of the barrier this loop shape runs at 0.76 of the fp64 MFMA peak, the barrier alone costs 0.05):
+//   B chunk (16 rows of 128 consecutive doubles): LDS-DMA, one wavefront-instruction per 1 KiB row, no registers, issued behind the first
+//   k-step and waited for by hand in front of the barrier (a full column tile only: a ragged last tile keeps the register path, its
+//   out-of-range columns must become zeros);
+//   A chunk (transposed on its way into LDS, so through registers): loaded TWO chunks ahead into the same registers, stored behind the
+//   first k-step into the buffer the last barrier freed -- nothing waits for a load that was issued a chunk ago.       0.88 in the probe.
 __device__ __forceinline__ TileAcc gemm_rowmajor_a(double (*As)[AT][A_LDT], double (*Bs)[AT][A_LD], const RowMajorTile t,
                                                 const double *A, int nrowsA, const double *B, int ld,
                                                 int kend, int last_chunk) {
@@ -418,25 +426,31 @@ __device__ __forceinline__ TileAcc gemm_rowmajor_a(double (*As)[AT][A_LDT], doub
     const bool okB = colB < ncolsB;
     const int colBc = okB ? colB : 0;
     const int rowl = tid >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool bdma = (t.tj + 1) * 128 <= ncolsB;       // (uniform)
     const int arow = t.ti * 128 + (tid >> 2), aseg = 4 * (tid & 3);
     const bool okAr = arow < nrowsA;
     const double *Arow = A + (size_t)(okAr ? arow : 0) * lda + aseg;
     double2 ra[2], rb[2];
-    auto gload = [&](int c) {
+    auto aload = [&](int c) {
         ra[0] = *reinterpret_cast<const double2 *>(Arow + (size_t)c * AT);
         ra[1] = *reinterpret_cast<const double2 *>(Arow + (size_t)c * AT + 2);
+    };
+    auto astore = [&](int buf) {
+        const int il = tid >> 2;
+        As[buf][aseg + 0][il] = okAr ? ra[0].x : 0.0;
+        As[buf][aseg + 1][il] = okAr ? ra[0].y : 0.0;
+        As[buf][aseg + 2][il] = okAr ? ra[1].x : 0.0;
+        As[buf][aseg + 3][il] = okAr ? ra[1].y : 0.0;
+    };
+    auto bload = [&](int c) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const size_t k = (size_t)c * AT + rowl + 8 * i;
             rb[i] = *reinterpret_cast<const double2 *>(B + k * ldb + colBc);
         }
     };
-    auto lstore = [&](int buf) {
-        const int il = tid >> 2;
-        As[buf][aseg + 0][il] = okAr ? ra[0].x : 0.0;
-        As[buf][aseg + 1][il] = okAr ? ra[0].y : 0.0;
-        As[buf][aseg + 2][il] = okAr ? ra[1].x : 0.0;
-        As[buf][aseg + 3][il] = okAr ? ra[1].y : 0.0;
+    auto bstore = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             double2 vb = rb[i];
@@ -444,33 +458,62 @@ __device__ __forceinline__ TileAcc gemm_rowmajor_a(double (*As)[AT][A_LDT], doub
             *reinterpret_cast<double2 *>(&Bs[buf][rowl + 8 * i][2 * lane]) = vb;
         }
     };
+    // LDS-DMA of one 1 KiB row (lane l -> bytes 16 l): uniform 64-bit base + ONE per-lane byte offset, LDS address through M0; written as
+    // asm, so hipcc does not count it (see the Gram kernel's staging, kernels.hip): waited for by hand below.
+    typedef __attribute__((address_space(3))) void lvoid;
+    const unsigned voff = (unsigned)(2 * lane * (int)sizeof(double));
+    auto glds = [&](const double *base, const void *lds_row) {
+        const unsigned dst = (unsigned)(uintptr_t)(lvoid *)lds_row;
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(dst), "s"(base) : "memory");
+    };
+    auto bdma_issue = [&](int c, int buf) {
+        const double *base = B + ((size_t)c * AT + wv) * ldb + (size_t)t.tj * 128;
+        glds(base, &Bs[buf][wv][0]);
+        glds(base + (size_t)8 * ldb, &Bs[buf][wv + 8][0]);
+    };
 #pragma unroll
     for (int x = 0; x < 4; ++x)
 #pragma unroll
         for (int y = 0; y < 2; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
     const int nchunk = kend / AT;
     const bool rows_live = t.ti * 128 + t.wr * 64 < nrowsA;     // a wavefront whose 64 rows are all padding (few-row launches)
-    gload(0);
-    lstore(0);
+    auto ksteps = [&](const int buf, const int ks0, const int ks1) {
+#pragma unroll
+        for (int ks = ks0; ks < ks1; ++ks) {
+            double af[4], bf[2];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) af[x] = As[buf][4 * ks + t.lk][t.wr * 64 + 16 * x + t.lr];
+#pragma unroll
+            for (int y = 0; y < 2; ++y) bf[y] = Bs[buf][4 * ks + t.lk][t.wc * 32 + 16 * y + t.lr];
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y) acc[x][y] = mfma_f64(af[x], bf[y], acc[x][y]);
+        }
+    };
+    aload(0);
+    if (bdma) bdma_issue(0, 0); else bload(0);
+    astore(0);
+    if (!bdma) bstore(0);
+    if (nchunk > 1) { aload(1); asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }      // (the DMAs are older than these two loads)
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int c = 0; c < nchunk; ++c) {
         const int buf = c & 1;
-        if (c + 1 < nchunk) gload(c + 1);
-        if (c <= last_chunk && rows_live) {
-#pragma unroll
-            for (int ks = 0; ks < AT / 4; ++ks) {
-                double af[4], bf[2];
-#pragma unroll
-                for (int x = 0; x < 4; ++x) af[x] = As[buf][4 * ks + t.lk][t.wr * 64 + 16 * x + t.lr];
-#pragma unroll
-                for (int y = 0; y < 2; ++y) bf[y] = Bs[buf][4 * ks + t.lk][t.wc * 32 + 16 * y + t.lr];
-#pragma unroll
-                for (int x = 0; x < 4; ++x)
-#pragma unroll
-                    for (int y = 0; y < 2; ++y) acc[x][y] = mfma_f64(af[x], bf[y], acc[x][y]);
-            }
+        const bool live = c <= last_chunk && rows_live;
+        if (live) ksteps(buf, 0, 1);
+        if (c + 1 < nchunk) {
+            astore(buf ^ 1);                                    // chunk c + 1, in registers since the last iteration
+            if (bdma) bdma_issue(c + 1, buf ^ 1); else bload(c + 1);
         }
-        if (c + 1 < nchunk) lstore(buf ^ 1);
+        if (c + 2 < nchunk) aload(c + 2);
+        if (live) ksteps(buf, 1, AT / 4);
+        if (bdma) {
+            if (c + 2 < nchunk) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");     // the two DMAs have landed; the A loads of chunk c + 2 may still fly
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (c + 1 < nchunk) bstore(buf ^ 1);
         __syncthreads();
     }
     TileAcc r;

@@ -7,6 +7,7 @@
 // Build + run: hipcc -O3 --offload-arch=gfx950 tools/probes/chunk_probe.hip -o tools/probes/chunk_probe && tools/probes/chunk_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdint>
 #include <cstdlib>
 typedef double d4 __attribute__((ext_vector_type(4)));
 #define MF(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0)
@@ -16,11 +17,11 @@ __global__ __launch_bounds__(512, 4) void k(double *out, const double *A, const 
     __shared__ double As[2][AT][LDT], Bs[2][AT][LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 2, wc = wave & 3, lr = lane & 15, lk = lane >> 4;
     for (int i = tid; i < 2 * AT * LD; i += 512) { (&As[0][0][0])[i] = A[i % 4096] + 1.0; (&Bs[0][0][0])[i] = B[i % 4096] - 1.0; }
-    constexpr bool GL = MODE == 3 || MODE == 4 || MODE == 5 || MODE >= 7, ST = MODE == 3 || MODE == 4 || MODE == 6 || MODE == 7;
+    constexpr bool GL = (MODE == 3 || MODE == 4 || MODE == 5 || MODE >= 7) && MODE < 11, ST = MODE == 3 || MODE == 4 || MODE == 6 || MODE == 7;
     __syncthreads();
     d4 acc[4][2];
     for (int x = 0; x < 4; ++x) for (int y = 0; y < 2; ++y) acc[x][y] = (d4){0, 0, 0, 0};
-    const double *Ag = A + (size_t)(MODE == 7 ? blockIdx.x / 4 : blockIdx.x) * 128 * ld + (size_t)(tid >> 2) * ld + 4 * (tid & 3);      // this workgroup's own 128 x ld panel
+    const double *Ag = A + (size_t)((MODE == 7 || MODE == 12) ? blockIdx.x / 4 : blockIdx.x) * 128 * ld + (size_t)(tid >> 2) * ld + 4 * (tid & 3);      // this workgroup's own 128 x ld panel
     const double *Bg = B + (size_t)(tid >> 6) * 128 + 2 * lane;                                           // B: ld x 128, shared
     double2 ra[2] = {{1.0, 2.0}, {3.0, 4.0}}, rb[2] = {{5.0, 6.0}, {7.0, 8.0}};
     double af[4], bf[2];
@@ -58,6 +59,40 @@ __global__ __launch_bounds__(512, 4) void k(double *out, const double *A, const 
             __syncthreads();
             mm();                                   // last k-step of this chunk: operands in registers
             frag(buf ^ 1, 0);                       // first k-step of the next chunk, behind those MFMAs
+        } else if (MODE == 11 || MODE == 12) {
+            // B chunk: LDS-DMA, no registers (rows of 128 doubles = 1 KiB = one wavefront-instruction; LDS row stride 144 doubles);
+            // A chunk: registers, loaded TWO chunks ahead, stored behind k-step 0 into the buffer the last barrier freed.
+            typedef __attribute__((address_space(3))) void lvoid;
+            auto glds = [&](const double *base, const void *lds_row) {
+                const unsigned dst = (unsigned)(uintptr_t)(lvoid *)lds_row, voff = (unsigned)(2 * lane * sizeof(double));
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(voff), "s"(dst), "s"(base) : "memory");
+            };
+            if (c == 0) {
+                ra[0] = *reinterpret_cast<const double2 *>(Ag + (size_t)(1 % (ld / AT)) * AT); ra[1] = *reinterpret_cast<const double2 *>(Ag + (size_t)(1 % (ld / AT)) * AT + 2);
+            }
+            if (c + 1 < nchunk) {
+                const int cc = (c + 1) % (ld / AT);
+                const int wv = __builtin_amdgcn_readfirstlane(wave);
+                const double *brow = B + ((size_t)cc * AT + wv) * 128;
+                glds(brow, &Bs[buf ^ 1][wv][0]);
+                glds(brow + (size_t)8 * 128, &Bs[buf ^ 1][wv + 8][0]);
+            }
+            frag(buf, 0); mm();
+            if (c + 1 < nchunk) {
+                const int il = tid >> 2, as = 4 * (tid & 3);
+                As[buf ^ 1][as][il] = ra[0].x; As[buf ^ 1][as + 1][il] = ra[0].y; As[buf ^ 1][as + 2][il] = ra[1].x; As[buf ^ 1][as + 3][il] = ra[1].y;
+            }
+            if (c + 2 < nchunk) {
+                const int cc = (c + 2) % (ld / AT);
+                ra[0] = *reinterpret_cast<const double2 *>(Ag + (size_t)cc * AT); ra[1] = *reinterpret_cast<const double2 *>(Ag + (size_t)cc * AT + 2);
+            }
+            frag(buf, 1); mm();
+            frag(buf, 2); mm();
+            frag(buf, 3); mm();
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");        // the two DMAs have landed (the A loads of chunk c + 2, issued behind them, may still fly)
+            __syncthreads();
         } else if (MODE == 8 || MODE == 9 || MODE == 10) {
             // 8: the next chunk's LDS stores in front of the last k-step's MFMAs (its fragments are loaded first), barrier behind them
             // 9: the stores in two halves, behind k-steps 1 and 2;  10: stores behind k-step 0 (the loads were issued a whole chunk earlier: distance 2)
@@ -173,6 +208,8 @@ int main() {
     run<8>(out, A, B, "8: as 3, the stores in front of the last k-step's MFMAs, barrier behind them");
     run<9>(out, A, B, "9: as 3, the stores in two halves behind k-steps 1 and 2");
     run<10>(out, A, B, "10: as 3, the stores behind k-step 0, their loads issued a chunk earlier (same registers)");
+    run<11>(out, A, B, "11: B chunk by LDS-DMA, A chunk in registers two chunks ahead, stored behind k-step 0");
+    run<12>(out, A, B, "12: as 11, four workgroups share an A panel");
     run3<0>(out, A, B, "one workgroup per CU, 8 wavefronts of 64 x 64 (16 accumulators): no barrier");
     run3<1>(out, A, B, "   + a workgroup barrier per chunk");
     run3<3>(out, A, B, "   + register-staged global loads / LDS stores of the next chunk");
