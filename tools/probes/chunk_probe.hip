@@ -93,6 +93,28 @@ __global__ __launch_bounds__(512, 4) void k(double *out, const double *A, const 
             frag(buf, 3); mm();
             asm volatile("s_waitcnt vmcnt(2)" ::: "memory");        // the two DMAs have landed (the A loads of chunk c + 2, issued behind them, may still fly)
             __syncthreads();
+        } else if (MODE == 13) {
+            // both operands K-major in memory (the Gram kernel's case): both chunks by LDS-DMA one chunk ahead, no staging registers at all
+            typedef __attribute__((address_space(3))) void lvoid;
+            auto glds = [&](const double *base, const void *lds_row) {
+                const unsigned dst = (unsigned)(uintptr_t)(lvoid *)lds_row, voff = (unsigned)(2 * lane * sizeof(double));
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(voff), "s"(dst), "s"(base) : "memory");
+            };
+            if (c + 1 < nchunk) {
+                const int cc = (c + 1) % (ld / AT), wv = __builtin_amdgcn_readfirstlane(wave);
+                const double *brow = B + ((size_t)cc * AT + wv) * 128;
+                const double *arow = A + (size_t)(blockIdx.x % 64) * ld * 128 + ((size_t)cc * AT + wv) * 128;       // A^T: ld rows of 128, a 1 MB panel per 8 workgroups
+                glds(brow, &Bs[buf ^ 1][wv][0]);
+                glds(brow + (size_t)8 * 128, &Bs[buf ^ 1][wv + 8][0]);
+                glds(arow, &As[buf ^ 1][wv][0]);
+                glds(arow + (size_t)8 * 128, &As[buf ^ 1][wv + 8][0]);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) { frag(buf, ks); mm(); }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
         } else if (MODE == 8 || MODE == 9 || MODE == 10) {
             // 8: the next chunk's LDS stores in front of the last k-step's MFMAs (its fragments are loaded first), barrier behind them
             // 9: the stores in two halves, behind k-steps 1 and 2;  10: stores behind k-step 0 (the loads were issued a whole chunk earlier: distance 2)
@@ -210,6 +232,7 @@ int main() {
     run<10>(out, A, B, "10: as 3, the stores behind k-step 0, their loads issued a chunk earlier (same registers)");
     run<11>(out, A, B, "11: B chunk by LDS-DMA, A chunk in registers two chunks ahead, stored behind k-step 0");
     run<12>(out, A, B, "12: as 11, four workgroups share an A panel");
+    run<13>(out, A, B, "13: both chunks by LDS-DMA one chunk ahead (operands K-major in memory, the Gram kernel's refill)");
     run3<0>(out, A, B, "one workgroup per CU, 8 wavefronts of 64 x 64 (16 accumulators): no barrier");
     run3<1>(out, A, B, "   + a workgroup barrier per chunk");
     run3<3>(out, A, B, "   + register-staged global loads / LDS stores of the next chunk");
