@@ -154,6 +154,8 @@ VARIANTS = {
     # wall-clock stamps of every workgroup of the skinny product of a rollout / particle-Gibbs step (tools/step_trace.py)
     # wall-clock stamps of every workgroup of the fused backward product (tools/bwd_trace.py)
     "bwdtrace": ("grad.hip", ["-DFFVD_BWD_TRACE"]),
+    "bwdtrace_base": ("grad.hip", ["-DFFVD_BWD_TRACE", "-DBWD_EPI_XWF=0"]),
+    "bwdtrace_vsf": ("grad.hip", ["-DFFVD_BWD_TRACE", "-DBWD_EPI_VSF=1"]),
     "steptrace": ["-DFFVD_STEP_TRACE"], "steptrace4": ["-DFFVD_STEP_TRACE", "-DFFVD_SKINNY_CHUNK=4"],
 }
 

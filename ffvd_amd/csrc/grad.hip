@@ -539,14 +539,14 @@ constexpr int XW_LD = 128 + 4;
 // Debug build only (-DFFVD_BWD_TRACE, variant `bwdtrace`, tools/bwd_trace.py): per workgroup of the last bwd_fused launch the wall clock
 // at its start, after the main loop, at the epilogue's phases and at its end, and where it ran (HW_ID, XCC_ID).
 #ifdef FFVD_BWD_TRACE
-__device__ long long bwd_trace_buf[16384 * 8];
+__device__ long long bwd_trace_buf[16384 * 12];
 }  // namespace ffvd
 extern "C" int ffvd_debug_bwd_trace(long long *out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ffvd::bwd_trace_buf), sizeof(long long) * 16384 * 8);
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ffvd::bwd_trace_buf), sizeof(long long) * 16384 * 12);
 }
 namespace ffvd {
-#define BWD_STAMP(slot) do { if (threadIdx.x == 0 && blockIdx.x < 16384) bwd_trace_buf[blockIdx.x * 8 + (slot)] = wall_clock64(); } while (0)
-#define BWD_WHERE() do { if (threadIdx.x == 0 && blockIdx.x < 16384) bwd_trace_buf[blockIdx.x * 8 + 3] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf) << 32); } while (0)
+#define BWD_STAMP(slot) do { if (threadIdx.x == 0 && blockIdx.x < 16384) bwd_trace_buf[blockIdx.x * 12 + (slot)] = wall_clock64(); } while (0)
+#define BWD_WHERE() do { if (threadIdx.x == 0 && blockIdx.x < 16384) bwd_trace_buf[blockIdx.x * 12 + 3] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf) << 32); } while (0)
 #else
 #define BWD_STAMP(slot) do { } while (0)
 #define BWD_WHERE() do { } while (0)
@@ -645,8 +645,28 @@ __global__ __launch_bounds__(512, 4) void bwd_fused_kernel(BwdFusedArgs a) {
     // The K_fu values of strip x + 1 are requested before the matrix work of strip x.
     d4 ac[2] = {(d4){0.0, 0.0, 0.0, 0.0}, (d4){0.0, 0.0, 0.0, 0.0}};
     double *Tw = sb + wave * (16 * 17);
+#ifndef BWD_EPI_XWF
+#define BWD_EPI_XWF 1        // A/B switches of the epilogue's fragment prefetches (tools: variants bwdtrace_base / bwdtrace_vsf)
+#endif
+#ifndef BWD_EPI_VSF
+#define BWD_EPI_VSF 0
+#endif
+#if BWD_EPI_VSF
+    double vsf[2][4];                            // the [1, z] fragments of the wavefront's 32 columns: the same for every strip
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) vsf[y][ks] = (lr < 8) ? Vs[lr * XW_LD + wc * 32 + 16 * y + 4 * ks + lk] : 0.0;
+#endif
 #pragma unroll
     for (int x = 0; x < 4; ++x) {
+        // the strip's four [1; x^T] fragments are requested first: an LDS read takes hundreds of cycles beside the other workgroup's main
+        // loop (stamps: 8 MFMAs behind 8 reads took 2.3 us), the e pass below covers them
+        double xwf[4];
+#if BWD_EPI_XWF
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) xwf[ks] = (lr < 8) ? XW[lr * XW_LD + wr * 64 + 16 * x + 4 * ks + lk] : 0.0;
+#endif
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int il = wr * 64 + 16 * x + lk + 4 * q;
@@ -663,14 +683,18 @@ __global__ __launch_bounds__(512, 4) void bwd_fused_kernel(BwdFusedArgs a) {
             v = row16_sum(v);
             if (lr == 0) RPw[il * 8 + 7] = v;
         }
+        if (x == 0) BWD_STAMP(7);
         if (x + 1 < 4) kload(x + 1);
 #pragma unroll
         for (int y = 0; y < 2; ++y)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const double af = (lr < 8) ? XW[lr * XW_LD + wr * 64 + 16 * x + 4 * ks + lk] : 0.0;
-                ac[y] = mfma_f64(af, acc[x][y][ks], ac[y]);
+#if !BWD_EPI_XWF
+                xwf[ks] = (lr < 8) ? XW[lr * XW_LD + wr * 64 + 16 * x + 4 * ks + lk] : 0.0;
+#endif
+                ac[y] = mfma_f64(xwf[ks], acc[x][y][ks], ac[y]);
             }
+        if (x == 0) BWD_STAMP(8);
         d4 r4 = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int y = 0; y < 2; ++y) {
@@ -680,8 +704,12 @@ __global__ __launch_bounds__(512, 4) void bwd_fused_kernel(BwdFusedArgs a) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const double af = Tw[lr * 17 + 4 * ks + lk];
+#if BWD_EPI_VSF
+                r4 = mfma_f64(af, vsf[y][ks], r4);
+#else
                 const double bf = (lr < 8) ? Vs[lr * XW_LD + wc * 32 + 16 * y + 4 * ks + lk] : 0.0;
                 r4 = mfma_f64(af, bf, r4);
+#endif
             }
             wave_lds_order();
         }
@@ -689,6 +717,7 @@ __global__ __launch_bounds__(512, 4) void bwd_fused_kernel(BwdFusedArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) RPw[(wr * 64 + 16 * x + lk + 4 * q) * 8 + lr] = r4[q];
         }
+        if (x == 0) BWD_STAMP(9);
     }
     BWD_STAMP(5);
     {       // column partials of the 64-row block (ti, wr)

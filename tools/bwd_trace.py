@@ -11,9 +11,9 @@ e = ElboEngine(meta["T"], meta["D"], meta["C"], meta["M"], meta["S"], route="gra
 e.set_data(Y, c); e.set_params(params)
 for _ in range(3): e.adam_step(1e-9)
 lib = ctypes.CDLL(_lib.LIB_PATH)
-buf = np.zeros(16384 * 8, dtype=np.int64)
+buf = np.zeros(16384 * 12, dtype=np.int64)
 assert lib.ffvd_debug_bwd_trace(buf.ctypes.data_as(ctypes.c_void_p)) == 0
-raw = buf.reshape(16384, 8)
+raw = buf.reshape(16384, 12)
 live = raw[:, 2] > 0
 st = raw[live, :3].astype(np.float64) / 100.0          # us
 where = raw[live, 3]
@@ -43,3 +43,6 @@ ep = raw[live][:, [1, 4, 5, 6, 2]].astype(np.float64) / 100.0
 d = np.diff(ep, axis=1)
 print("epilogue phases of wavefront 0 (median us): staging + first K_fu loads %.2f, four strips %.2f, wait for the other wavefronts %.2f, combine + store %.2f" %
       tuple(np.median(d, axis=0)))
+s0 = raw[live][:, [4, 7, 8, 9]].astype(np.float64) / 100.0
+d0 = np.diff(s0, axis=1)
+print("first strip of wavefront 0 (median us): e in place + kfu partial %.2f, column products (8 MFMAs) %.2f, patches + row products (8 MFMAs) + partial stores %.2f" % tuple(np.median(d0, axis=0)))
