@@ -2431,22 +2431,28 @@ struct Scratch {
     // device -> host for a large result: through the thread's page-locked block when it has (or gets) one of that size, else directly.
     // Synchronises the stream.
     bool download(void *dst, const void *src, size_t bytes) {
-        OpCache &c = g_op_cache;
-        if (bytes >= ((size_t)1 << 20) && bytes <= ((size_t)256 << 20)) {
-            if (c.pinned_bytes < bytes) {
-                if (c.pinned) { hipHostFree(c.pinned); c.pinned = nullptr; c.pinned_bytes = 0; }
-                if (hipHostMalloc(&c.pinned, bytes, hipHostMallocDefault) == hipSuccess) c.pinned_bytes = bytes;
-                else { (void)hipGetLastError(); c.pinned = nullptr; }
-            }
-            if (c.pinned) {
-                if (hipMemcpyAsync(c.pinned, src, bytes, hipMemcpyDeviceToHost, stream) != hipSuccess) return false;
-                if (hipStreamSynchronize(stream) != hipSuccess) return false;
-                memcpy(dst, c.pinned, bytes);
-                return true;
-            }
+        if (void *pin = pinned_block(bytes)) {
+            if (hipMemcpyAsync(pin, src, bytes, hipMemcpyDeviceToHost, stream) != hipSuccess) return false;
+            if (hipStreamSynchronize(stream) != hipSuccess) return false;
+            memcpy(dst, pin, bytes);
+            return true;
         }
         return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream) == hipSuccess && hipStreamSynchronize(stream) == hipSuccess;
     }
+    // the thread's page-locked block, grown to `bytes` (nullptr when it cannot be had or the size is outside 1 MB .. 256 MB)
+    void *pinned_block(size_t bytes) {
+        OpCache &c = g_op_cache;
+        if (bytes < ((size_t)1 << 20) || bytes > ((size_t)256 << 20)) return nullptr;
+        if (c.pinned_bytes < bytes) {
+            if (c.pinned) { hipHostFree(c.pinned); c.pinned = nullptr; c.pinned_bytes = 0; }
+            if (hipHostMalloc(&c.pinned, bytes, hipHostMallocDefault) == hipSuccess) c.pinned_bytes = bytes;
+            else { (void)hipGetLastError(); c.pinned = nullptr; }
+        }
+        return c.pinned;
+    }
+    // host -> device, asynchronous, straight from the caller's memory.  (Measured: large uploads through the page-locked block + a
+    // synchronisation made a 200-step rollout call 0.4 ms slower and changed nothing for the sweep -- the 28 ms some calls spend here in
+    // tools/bench_next.py's process are a wait of the stream behind the 0.2 ms DMA, whichever memory it reads; FFVD_PG_TIMING=1 shows it.)
     double *upload(const double *src, size_t n) {
         double *d = alloc<double>(n);
         if (d && n && hipMemcpyAsync(d, src, n * sizeof(double), hipMemcpyHostToDevice, stream) != hipSuccess) return nullptr;
@@ -3202,6 +3208,7 @@ extern "C" int ffvd_op_pg_sweep(int kind, const double *Lm_inverse_seq, const do
     for (int j = 0; j < Ydim; ++j)
         if (!(Rchols[(size_t)j * Ydim + j] > 0.0)) return set_error(nullptr, FFVD_EINVAL, "ffvd_op_pg_sweep: Rchols diagonal must be positive");
     OP_BEGIN("ffvd_op_pg_sweep");
+    const auto t_begin = std::chrono::steady_clock::now();
     const int R = n_free, steps = X_N - 1;
     memcpy(particles, x0, (size_t)R * D * sizeof(double));                                   // particles[0] (:87)
     if (steps == 0) return FFVD_OK;
@@ -3212,10 +3219,17 @@ extern "C" int ffvd_op_pg_sweep(int kind, const double *Lm_inverse_seq, const do
         for (int d = 0; d < D; ++d) xc0[(size_t)r * P + d] = x0[(size_t)r * D + d];
         for (int c = 0; c < C; ++c) xc0[(size_t)r * P + D + c] = ctrl[c];                     // control row of step 0 (:93)
     }
+    const bool pg_timing = getenv("FFVD_PG_TIMING") != nullptr;
+    auto lap = [&](const char *what) {
+        if (pg_timing) fprintf(stderr, "ffvd_op_pg_sweep:   %s at %.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+    };
+    lap("begin");
     double *dW = upload_stack(sc, Lm_inverse_seq, D, M, Mp, Wp);
+    lap("L^-T uploaded");
     double *dxc = sc.upload(xc0.data(), xc0.size()), *dZ = sc.upload(Z, (size_t)M * P), *dU = sc.upload(U, (size_t)M * D);
     double *dlv = sc.upload(logvariance, D), *dll = sc.alloc<double>((size_t)D * P), *dlq = sc.upload(log_Q, D);
     double *deps = sc.upload(eps, (size_t)steps * R * D), *dun = sc.upload(unif, (size_t)steps * R);
+    lap("draws uploaded");
     double *dctrl = C ? sc.upload(ctrl, (size_t)steps * C) : nullptr;
     double *dXr = sc.upload(X_ref, (size_t)X_N * D), *dY = sc.upload(Y, (size_t)steps * Ydim);
     double *dCC = sc.upload(CC, (size_t)D * Ydim), *dDD = sc.upload(DD, Ydim), *dR = sc.upload(Rchols, (size_t)Ydim * Ydim);
@@ -3229,6 +3243,7 @@ extern "C" int ffvd_op_pg_sweep(int kind, const double *Lm_inverse_seq, const do
     double *cand = sc.alloc<double>((size_t)(R + 1) * D);
     double *dparts = sc.alloc<double>((size_t)steps * R * D);
     int32_t *didx = sc.alloc<int32_t>((size_t)steps * R);
+    lap("temporaries allocated");
     if (!dW || !dxc || !dZ || !dU || !dlv || !dll || !dlq || !deps || !dun || (C && !dctrl) || !dXr || !dY || !dCC || !dDD ||
         !dR || !variance || !len || !Zs || !zz || !Kf || !ucol || !rowsq || !fmean || !dmean || !dvar || !cand || !dparts || !didx)
         return set_error(nullptr, FFVD_ENOMEM, "ffvd_op_pg_sweep: device allocation or upload failed");
@@ -3287,6 +3302,10 @@ extern "C" int ffvd_op_pg_sweep(int kind, const double *Lm_inverse_seq, const do
         }
     } else {
         const bool timing = getenv("FFVD_PG_TIMING") != nullptr;          // debug: how long the host takes to enqueue the sweep
+        if (timing) {
+            hipStreamSynchronize(sc.stream);
+            fprintf(stderr, "ffvd_op_pg_sweep: uploads and set-up %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+        }
         const auto t0 = std::chrono::steady_clock::now();
         step_launches();
         if (timing) {
@@ -3298,9 +3317,13 @@ extern "C" int ffvd_op_pg_sweep(int kind, const double *Lm_inverse_seq, const do
         }
     }
     HIP_TRY(hipGetLastError());
+    const auto t_dl = std::chrono::steady_clock::now();
     if (!sc.download(particles + (size_t)R * D, dparts, (size_t)steps * R * D * sizeof(double)) ||
         !sc.download(idx, didx, (size_t)steps * R * sizeof(int32_t)))
         return set_error(nullptr, FFVD_EDEVICE, "ffvd_op_pg_sweep: copying the results to the host failed");
+    if (getenv("FFVD_PG_TIMING"))
+        fprintf(stderr, "ffvd_op_pg_sweep: results to the host %.2f ms (after the sweep had drained)\n",
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_dl).count());
     return FFVD_OK;
 }
 
