@@ -3057,6 +3057,17 @@ extern "C" int ffvd_op_rollout(int kind, const double *Lm_inverse_seq, const dou
     double *dmean = sc.alloc<double>((size_t)R * D), *dvar = sc.alloc<double>((size_t)R * D);
     double *dpx = sc.alloc<double>((size_t)R * steps * D), *dpv = sc.alloc<double>((size_t)R * steps * D);
     std::vector<double> Qp;
+    // W = L^-T is upper triangular; when q_sqrt (slice 0) is too -- the reference hands over L_H^-T -- so is W q_sqrt, and the second
+    // right-hand side of a step's product stops at a slab's last row like the first (exact zeros are skipped: half of its k range)
+    int q_upper = 0;
+    if (q_sqrt && skinny) {
+        q_upper = 1;
+        for (int i = 1; i < M && q_upper; ++i)
+            for (int j = 0; j < i; ++j)
+                if (q_sqrt[(size_t)i * M + j] != 0.0) { q_upper = 0; break; }
+    }
+    static const bool no_upper2 = getenv("FFVD_NO_QSQRT_UPPER") != nullptr;       // A/B switch (read once)
+    if (no_upper2) q_upper = 0;
     double *dQs = q_sqrt ? (skinny ? upload_stack(sc, q_sqrt, 1, M, Mp, Qp) /* (F is zero in the padded columns) */ : sc.upload(q_sqrt, (size_t)M * M)) : nullptr;   // slice d = 0 only
     double *extra = q_sqrt ? sc.alloc<double>((size_t)D * (skinny ? ngs : 1) * Tp) : nullptr;
     // skinny path: W q_sqrt once per call (D products of M^3), so that the inflation term is a second right-hand side of the
@@ -3090,7 +3101,7 @@ extern "C" int ffvd_op_rollout(int kind, const double *Lm_inverse_seq, const dou
                 launch_kfu_build_t(sc.stream, pa, Tp);                               // K(x_t, Z) per dim, m-major (coalesced operand loads)
                 // conditional_after_kernel_precalculation (:300) and, in the same launch, sum_j (F q_sqrt)_j^2 = |K (W q_sqrt)|^2 (:371-380)
                 launch_skinny_gemm(sc.stream, Kf, (size_t)Tp * Mp, Tp, dW, (size_t)Mp * Mp, Mp, 1, R, Mp, Mp, D, Tp,
-                                   nullptr, 0, 0, ucol, Mp, rowsq, fmean, q_sqrt ? dWQ : nullptr, (size_t)Mp * Mp, Mp, Mp, extra, 1);
+                                   nullptr, 0, 0, ucol, Mp, rowsq, fmean, q_sqrt ? dWQ : nullptr, (size_t)Mp * Mp, Mp, Mp, extra, 1, q_upper);
             } else {
                 launch_kfu_build(sc.stream, pa);                                     // K(x_t, Z) per dim
                 launch_proj_gemm(sc.stream, pg);
@@ -3132,7 +3143,7 @@ extern "C" int ffvd_op_rollout(int kind, const double *Lm_inverse_seq, const dou
         HIP_TRY(hipMemsetAsync(words, 0, (size_t)rollout_resident_words() * sizeof(int32_t), sc.stream));
         RolloutResidentArgs ra{};
         ra.kind = kind; ra.R = R; ra.RT = RT; ra.D = D; ra.C = C; ra.P = P; ra.M = M; ra.Mp = Mp; ra.steps = steps; ra.NS = NS;
-        ra.hv = hv; ra.W = dW; ra.w_stride = (size_t)Mp * Mp; ra.WQ = q_sqrt ? dWQ : nullptr; ra.ucol = ucol;
+        ra.hv = hv; ra.W = dW; ra.w_stride = (size_t)Mp * Mp; ra.WQ = q_sqrt ? dWQ : nullptr; ra.wq_upper = q_sqrt ? q_upper : 0; ra.ucol = ucol;
         ra.log_Q = dlq; ra.eps = deps; ra.ctrl = dctrl; ra.x_last = dxl; ra.Kt = Kt; ra.part = part; ra.xbuf = xb;
         ra.predict_x = dpx; ra.predict_var = dpv; ra.words = words; ra.abort_w = words + 1;
         long long *dst = nullptr;
@@ -3175,7 +3186,7 @@ extern "C" int ffvd_op_rollout(int kind, const double *Lm_inverse_seq, const dou
         RolloutLoopArgs la{};
         la.pa = pa;
         la.sk = SkinnyArgs{Kf, (size_t)Tp * Mp, Mp, dW, (size_t)Mp * Mp, Mp, 1, R, Mp, Mp, D, Tp, nullptr, 0, 0, ucol, (size_t)Mp, rowsq, fmean,
-                           q_sqrt ? dWQ : nullptr, (size_t)Mp * Mp, Mp, q_sqrt ? Mp : 0, extra};
+                           q_sqrt ? dWQ : nullptr, (size_t)Mp * Mp, Mp, q_sqrt ? Mp : 0, extra, 0, q_sqrt ? q_upper : 0};
         la.f = FinishIn{kind, D + C, ngs, Tp, D, ngs, variance, rowsq, fmean, extra};
         la.log_Q = dlq; la.eps = deps; la.ctrl = dctrl; la.R = R; la.C = C; la.steps = steps;
         la.xbuf0 = xbuf[0]; la.xbuf1 = xbuf[1]; la.predict_x = dpx; la.predict_var = dpv;

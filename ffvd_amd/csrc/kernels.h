@@ -257,7 +257,8 @@ void launch_skinny_gemm(hipStream_t stream, const double *A, size_t a_stride, in
                         const double *u, size_t u_stride, double *sq, double *dot,
                         // optional second right-hand side B2 (K x N2, dense) in the same launch: only sq2[nb][N2 / 16][Tp] is formed
                         const double *B2 = nullptr, size_t b2_stride = 0, int ldb2 = 0, int N2 = 0, double *sq2 = nullptr,
-                        int a_trans = 0 /* A is k-major AT[nb][K][lda], as launch_kfu_build_t writes it */);
+                        int a_trans = 0 /* A is k-major AT[nb][K][lda], as launch_kfu_build_t writes it */,
+                        int upper2 = 0 /* B2 is upper triangular too */);
 // out[i * out_ld + b * out_bs] = sum_j W[b][i][j] y[b][j]
 void launch_matvec(hipStream_t stream, const double *W, size_t w_stride, const double *y, size_t y_stride, int Mp,
                    double *out, int out_ld, int out_bs, int M, int batch, int w_mod = 0);   // w_mod > 0: W slab index = batch index % w_mod

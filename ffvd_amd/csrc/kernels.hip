@@ -3433,10 +3433,10 @@ __global__ __launch_bounds__(256) void skinny_gemm_xcd_kernel(SkinnyArgs a, int 
 void launch_skinny_gemm(hipStream_t stream, const double *A, size_t a_stride, int lda, const double *B, size_t b_stride, int ldb,
                         int upper, int rows, int K, int N, int nb, int Tp, double *C, size_t c_stride, int ldc,
                         const double *u, size_t u_stride, double *sq, double *dot, const double *B2, size_t b2_stride, int ldb2,
-                        int N2, double *sq2, int a_trans) {
+                        int N2, double *sq2, int a_trans, int upper2) {
     if (rows <= 0 || nb <= 0) return;
     SkinnyArgs a{A, a_stride, lda, B, b_stride, ldb, upper, rows, K, N, nb, Tp, C, c_stride, ldc, u, u_stride, sq, dot,
-                 B2, b2_stride, ldb2, B2 ? N2 : 0, sq2, a_trans};
+                 B2, b2_stride, ldb2, B2 ? N2 : 0, sq2, a_trans, B2 ? upper2 : 0};
     const int nbx = N / 16 + (B2 ? N2 / 16 : 0), nby = (rows + 31) / 32;
     static const bool flat = !(getenv("FFVD_SKINNY_GRID3D") && atoi(getenv("FFVD_SKINNY_GRID3D")));
     if (flat && nb <= 8) {

@@ -269,7 +269,8 @@ __global__ __launch_bounds__(256) void rollout_resident_kernel(RolloutResidentAr
     const bool active = rt < RT;
     // the contraction in PAIRS of k-steps (8 inducing points)
     const int npW = mlim / 8, ppW = (npW + nkp - 1) / nkp, pw0 = kp * ppW, pw1 = (pw0 + ppW < npW) ? pw0 + ppW : npW;
-    const int npQ = Mp / 8, ppQ = (npQ + nkp - 1) / nkp, pq0 = kp * ppQ, pq1 = (pq0 + ppQ < npQ) ? pq0 + ppQ : npQ;
+    const int npQ = a.wq_upper ? npW : Mp / 8, ppQ = (npQ + nkp - 1) / nkp,          // (an upper-triangular W q_sqrt ends where W ends)
+          pq0 = kp * ppQ, pq1 = (pq0 + ppQ < npQ) ? pq0 + ppQ : npQ;
     double *Ktd = a.Kt + (size_t)d * Mp * RP;
     __syncthreads();
     long long *stp = (a.stamps && d == 0 && (s == 0 || s == NS - 1)) ? a.stamps + (s == 0 ? 0 : 16) : nullptr;

@@ -206,6 +206,7 @@ struct SkinnyArgs {
     const double *B2; size_t b2_stride; int ldb2, N2;
     double *sq2;
     int a_trans;                                    // A is stored k-major, AT[b][K][lda] (kfu_build_t_body): coalesced operand loads
+    int upper2;                                     // B2[k][n] = 0 for k > n as well (W q_sqrt with an upper-triangular q_sqrt: the reference's L_H^-T)
 };
 
 #ifndef FFVD_SKINNY_CHUNK
@@ -224,7 +225,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyArgs &a, const int bx, c
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const double *Ab = a.A + (size_t)b * a.a_stride, *Bb = second ? a.B2 + (size_t)b * a.b2_stride : a.B + (size_t)b * a.b_stride;
     const int ldb = second ? a.ldb2 : a.ldb;
-    const int kend = (!second && a.upper && n0 + 16 < a.K) ? n0 + 16 : a.K;
+    const int kend = ((second ? a.upper2 : a.upper) && n0 + 16 < a.K) ? n0 + 16 : a.K;
     const int nkb = kend / 16, per = (nkb + 3) / 4;                 // 16-wide k blocks, a quarter of them per wavefront
     const int kb0 = w * per, kb1 = (kb0 + per < nkb) ? kb0 + per : nkb;
     d4 acc[2] = {(d4){0.0, 0.0, 0.0, 0.0}, (d4){0.0, 0.0, 0.0, 0.0}};
@@ -630,6 +631,7 @@ struct RolloutResidentArgs {
     HyperView hv;
     const double *W;  size_t w_stride;              // [D][Mp][Mp]  W = L^-T (upper triangular), row-major
     const double *WQ;                                // optional [D][Mp][Mp]  W q_sqrt
+    int wq_upper;                                    // W q_sqrt is upper triangular like W (q_sqrt = L_H^-T): its rows below a slab's last column are skipped
     const double *ucol;                              // [D][Mp]
     const double *log_Q, *eps, *ctrl, *x_last;      // eps [steps][R][D]; ctrl [steps][C] or null; x_last [D]
     double *Kt;                                      // [D][Mp][16 RT]   K(x_t, Z) of the step, rollouts contiguous

@@ -390,6 +390,42 @@ def test_step_kernels_with_more_than_eight_inputs():
     np.testing.assert_allclose(pg, po, rtol=1e-9, atol=1e-10)
 
 
+@pytest.mark.parametrize("R", [20, 70])
+def test_rollout_with_a_dense_q_sqrt(R):
+    """The reference hands over q_sqrt = L_H^-T, upper triangular like W = L^-T: W q_sqrt is then triangular too and the step's second
+    product skips the zero rows (round 5).  A caller's q_sqrt need not be triangular: with a dense one (slice d = 0, quirk a14) both
+    forms of the loop -- the resident one at 20 rollouts, the per-step launches at 70 -- must take the full k range."""
+    from ffvd_amd import conditionals_multi_output as cmo
+    from ffvd_amd.prediction import rollout
+    from ffvd_amd.kernels import SquaredExponential
+    params, Y, c, meta = synthetic.make_named("small")
+    D, C, T = meta["D"], meta["C"], meta["T"]
+    X = params["X"][0]
+    Q = np.exp(params["log_Q"])
+    okern = orc.make_kernels(params)
+    kern = [SquaredExponential(D + C, variance=np.exp(params["logvariance"][d]),
+                               lengthscales=np.exp(params["loglengthscales"][d])) for d in range(D)]
+    rng = np.random.default_rng(17)
+    steps = 9
+    ctrl = np.concatenate((c, rng.standard_normal((steps, C))))
+    eps = rng.standard_normal((steps, R, D))
+    xc = np.concatenate((X[:-1], c), axis=1)
+    Lo = orc.kernel_pre_cal(params["Z"], okern)
+    Uo, Ho = orc.collapse_u_mean_after_kernel_precalculation(Lo, xc, X, params["Z"], okern, Q)
+    assert np.all(np.tril(Ho[0], -1) == 0.0)                       # what the reference passes IS upper triangular
+    Hd = Ho + 0.05 * rng.standard_normal(Ho.shape) * np.abs(Ho).max()
+    px_o, pv_o = orc.rollout(Lo, params["Z"], okern, Uo, Hd, X[-1], ctrl, T, steps, Q, eps)
+    Lg = cmo.kernel_pre_cal(params["Z"], kern)
+    px, pv = rollout(Lg, params["Z"], kern, Uo, Hd, X[-1], ctrl, T, steps, Q, eps)
+    np.testing.assert_allclose(px, px_o, rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(pv, pv_o, rtol=1e-8, atol=1e-10)
+    # and the triangular one through the same call differs from the dense result (the inflation term is not a no-op)
+    px_t, pv_t = rollout(Lg, params["Z"], kern, Uo, Ho, X[-1], ctrl, T, steps, Q, eps)
+    px_to, pv_to = orc.rollout(Lo, params["Z"], okern, Uo, Ho, X[-1], ctrl, T, steps, Q, eps)
+    np.testing.assert_allclose(pv_t, pv_to, rtol=1e-8, atol=1e-10)
+    assert np.abs(pv_t - pv).max() > 1e-6
+
+
 _RR_SCRIPT = r"""
 import sys
 import numpy as np
