@@ -77,10 +77,16 @@ N = 100
 x0, eps_pg, un = rng.standard_normal((N - 1, D)), rng.standard_normal((T, N - 1, D)), rng.random((T, N - 1))
 Rch = np.exp(params["log_Rchols"])
 pg_sweep(L, params["Z"], kern, params["U"], X[:33], Y, c, params["CC"], params["DD"], Rch, np.exp(params["log_Q"]), x0, eps_pg[:32], un[:32])
-t0 = time.perf_counter()
-parts, idx = pg_sweep(L, params["Z"], kern, params["U"], X, Y, c, params["CC"], params["DD"], Rch, np.exp(params["log_Q"]), x0, eps_pg, un)
-dt = time.perf_counter() - t0
+# (three sweeps: in this process one call in two or three spends 19-28 ms waiting behind its first upload -- FFVD_PG_TIMING=1 shows it inside the call,
+#  profiles/r05_step_trace.txt section 13 -- ; all three are reported, the row is their median)
+runs = []
+for _ in range(3):
+    t0 = time.perf_counter()
+    parts, idx = pg_sweep(L, params["Z"], kern, params["U"], X, Y, c, params["CC"], params["DD"], Rch, np.exp(params["log_Q"]), x0, eps_pg, un)
+    runs.append(time.perf_counter() - t0)
+dt = sorted(runs)[1]
 out["pg_sweep_N100_ms"] = dt * 1e3
+out["pg_sweep_N100_ms_runs"] = [r * 1e3 for r in runs]
 out["pg_sweep_N100_us_per_step"] = dt / T * 1e6
 out["pg_reference_share"] = float((idx == N - 1).mean())
 os.write(_json_fd, (json.dumps(out) + "\n").encode())
